@@ -1,0 +1,125 @@
+/* C ABI of libu2seg_hip.so — the MI355X (gfx950) kernels behind the U2Seg Panoptic-FPN hot path.
+ *
+ * Every entry point takes raw device pointers, sizes and a hipStream_t passed as void*; nothing is
+ * allocated inside (workspaces are caller-provided); the return value is 0 on success, a positive
+ * hipError_t on a launch failure, a negative number on an argument the kernel cannot serve.
+ * The caller is a torch.autograd.Function in u2seg_amd/layers (the reference binds its native ops
+ * the same way: detectron2/layers/roi_align_rotated.py:9-46 + detectron2/layers/csrc/vision.cpp:111-116).
+ *
+ * Activations are NHWC bfloat16 (raw uint16 bits), statistics / losses / box arithmetic are fp32.
+ * Each prototype cites the reference call site(s) it replaces (paths relative to the reference root).
+ */
+#ifndef U2SEG_HIP_H
+#define U2SEG_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- convolution / linear family (conv_igemm.hip) -------------------------------------------
+ * Replaces F.conv2d in detectron2/layers/wrappers.py:127-134 (all Conv2d of backbone/resnet.py:194-210,
+ * 355-358, backbone/fpn.py:141-158, meta_arch/semantic_seg.py:196-205, proposal_generator/rpn.py:127-134,
+ * roi_heads/mask_head.py:242-251), nn.Linear in roi_heads/box_head.py:66-74 and roi_heads/fast_rcnn.py:236-239,
+ * and (through mul/div + a flipped, transposed filter) their data gradients.
+ *   out[m][n] = sum_{kh,kw,c} in[src(m,kh,kw)][c] * wt[n][kh][kw][c]   (+bias)(+=old)(relu)
+ *   src: sy = oy*mul - pad_h + kh; if div > 1 the tap contributes only when sy % div == 0 and then sy /= div.
+ *   stats (optional, [2][N] fp32, pre-zeroed): column sum and sum of squares of the stored bf16 outputs.
+ * variant bit0: 1 = register-staged operands instead of global_load_lds. */
+int u2_conv_igemm(const void* in, const void* wt, void* out, const float* bias, float* stats,
+                  int B, int Hin, int Win, int C, int in_ld, int Hout, int Wout, int N, int out_ld,
+                  int KH, int KW, int pad_h, int pad_w, int mul, int div, int relu, int accumulate,
+                  int variant, void* stream);
+
+/* Weight gradient: dw[n][kh][kw][c] += sum_m dy[m][n] * x[src(m,kh,kw)][c]; fp32 atomics, dw pre-zeroed.
+ * variant bit0: register staging; bit1: scalar LDS gathers instead of ds_read_b64_tr_b16. */
+int u2_conv_wgrad(const void* x, const void* dy, float* dw, int B, int Hin, int Win, int C, int x_ld,
+                  int Hout, int Wout, int N, int dy_ld, int KH, int KW, int pad_h, int pad_w,
+                  int stride, int variant, void* stream);
+
+/* ---- normalisation / activation (norm.hip) ----------------------------------------------------
+ * Replaces nn.SyncBatchNorm / nn.GroupNorm / relu_ chosen by detectron2/layers/batch_norm.py:169-197. */
+int u2_colstats(const void* x, float* out /*[slots][2][C]*/, int slots, int rows_per_slot, int C, int ld, void* stream);
+int u2_bn_finalize_fwd(const float* sums, float count, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                       float* shift, int C, void* stream);
+int u2_affine_act(const void* x, const float* scale, const float* shift, const void* resid, void* out, int slots,
+                  int rows_per_slot, int C, int ld, int relu, void* stream);
+int u2_norm_bwd_reduce(const void* dout, const void* mask, const void* x, const float* mean, const float* invstd,
+                       float* out /*[slots][2][C]*/, int slots, int rows_per_slot, int C, int ld, int relu, void* stream);
+int u2_bn_finalize_bwd(const float* sums, float count, const float* gamma, const float* mean, const float* invstd,
+                       const float* local_sums, float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C,
+                       void* stream);
+int u2_norm_bwd_apply(const void* dout, const void* mask, const void* x, const float* k1, const float* k2,
+                      const float* k3, void* dx, void* dres, int slots, int rows_per_slot, int C, int ld, int relu,
+                      void* stream);
+int u2_relu_bwd(const void* dout, const void* out, void* dz, long long numel, void* stream);
+
+/* ---- pooling / resampling (pool_resize.hip) ----------------------------------------------------
+ * backbone/resnet.py:358 (max_pool2d 3x3 s2 p1), backbone/fpn.py:153-155 (nearest x2 + add),
+ * meta_arch/semantic_seg.py:206-211 (bilinear x2), meta_arch/rcnn.py:223-234 (normalise + pad) feeding the stem. */
+int u2_maxpool3x3s2_fwd(const void* x, void* y, void* idx, int B, int H, int W, int C, void* stream);
+int u2_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, int B, int H, int W, int C, void* stream);
+int u2_fpn_upsample_add_fwd(const void* lateral, const void* top, void* out, int B, int H, int W, int C, void* stream);
+int u2_fpn_upsample_add_bwd(const void* dout, void* dtop, int B, int H, int W, int C, void* stream);
+int u2_bilinear_up2_fwd(const void* x, void* out, int B, int H, int W, int C, int accumulate, void* stream);
+int u2_bilinear_up2_bwd(const void* dout, void* dx, int B, int H, int W, int C, void* stream);
+int u2_stem_im2col(const void* img, int is_uint8, const float* mean, const float* stdv, void* col, int b, int h, int w,
+                   int Hpad, int Wpad, int KP, void* stream);
+
+/* ---- losses (losses.hip) -----------------------------------------------------------------------
+ * meta_arch/semantic_seg.py:255-267, roi_heads/fast_rcnn.py:307-347,424-463, roi_heads/mask_head.py:33-112,
+ * proposal_generator/rpn.py:366-429, modeling/box_regression.py:43-76. */
+int u2_semseg_upsample_ce(const void* logits, const void* target, float* grad_acc, float* loss_sum, float* valid_cnt,
+                          int B, int h, int w, int LP, int NC, int ignore, void* stream);
+int u2_scale_to_bf16(const float* acc, const float* num, const float* den, float mult, void* out, long long n,
+                     void* stream);
+int u2_softmax_ce(const void* logits, const void* labels, void* dlogits, float* loss_sum, int R, int NC, int LP,
+                  float gscale, void* stream);
+int u2_mask_predict_bce(const void* x, const float* Wp, const float* bp, const void* cls, const void* target, void* dx,
+                        float* dWp, float* dbp, float* loss_sum, void* logit_out, int N, int P, int C, float gscale,
+                        void* stream);
+int u2_rpn_loss_level(const void* obj, const void* dlt, const void* labels, const int* match, const float* gt,
+                      const float* anchors, void* dobj, void* ddlt, float* loss, int B, int HW, int A, int LPo, int LPd,
+                      int Atot, int lvl_off, int G, float gscale, void* stream);
+int u2_box_reg_l1(const void* pred, const float* prop, const float* gtb, const void* labels, void* dpred, float* loss,
+                  int R, int LP, int bg_label, float wx, float wy, float ww, float wh, float gscale, void* stream);
+
+/* ---- ROI bookkeeping (roi.hip) -----------------------------------------------------------------
+ * layers/roi_align.py:49-65 via modeling/poolers.py:206-263; structures/masks.py:191-218; modeling/poolers.py:23-59;
+ * structures/boxes.py:312-358 + modeling/matcher.py:62-127; modeling/box_regression.py:78-116; layers/nms.py:9-20. */
+int u2_roi_align_fwd(const void* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels,
+                     const float* rois, const int* level, void* out, int R, int C, int PH, int PW, void* stream);
+int u2_roi_align_bwd(float* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,
+                     const float* rois, const int* level, const void* dout, int R, int C, int PH, int PW, float gscale,
+                     void* stream);
+int u2_mask_crop(const void* masks, const float* rois, void* out, int R, int H, int W, int P, void* stream);
+int u2_assign_levels(const float* boxes, int* level, int n, int min_level, int max_level, float canonical_size,
+                     int canonical_level, void* stream);
+int u2_iou_match(const float* boxes, int per_image_boxes, const float* gt, const int* ngt, int* match, float* mval,
+                 unsigned int* gt_max, signed char* labels, int B, int n, int G, float lo, float hi,
+                 int allow_low_quality, void* stream);
+int u2_apply_deltas(const float* src, const float* deltas, const int* img, const float* sizes, float* out, int n,
+                    float wx, float wy, float ww, float wh, float clamp, int do_clip, void* stream);
+long long u2_nms_workspace_bytes(int B, int n);
+int u2_batched_nms(const float* boxes, const int* group, const int* cnt, void* workspace, int* keep, int* nkeep, int B,
+                   int n, float thr, int max_keep, void* stream);
+
+/* ---- optimizer (optim.hip): solver/build.py:36-37,63-73,119-139 ------------------------------- */
+int u2_sgd_clip_step(float* params, const float* grads, float* momentum_buf, const int* chunk_tensor,
+                     const long long* chunk_begin, const int* chunk_len, int n_chunks, float* norm2, int n_tensors,
+                     const float* wd_per_tensor, float lr, float momentum, float clip, float grad_scale, void* stream);
+
+/* ---- k-means over DINO embeddings (kmeans.hip): u2seg/Instance_Clustering/shared/utils/nn_utils.py:304-379 ---- */
+int u2_kmeans_assign(const float* x, const float* c, float* cnorm_ws /*[K]*/, long long* labels, int N, int D, int K,
+                     void* stream);
+int u2_kmeans_update(const float* x, const long long* labels, float* csum, float* counts, int N, int D, int K,
+                     void* stream);
+int u2_kmeans_finalize(const float* csum, const float* counts, float* c, int D, int K, void* stream);
+
+/* library self-description */
+int u2_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,199 @@
+// Standalone GPU self-test + micro-benchmark of the GEMM-family kernels through the C ABI
+// (no torch dependency, so it starts in a second on a fresh GPU box).  Test infrastructure only.
+//   build: u2seg_amd/csrc/build.sh && hipcc tests/native/selftest.cpp -Iinclude -Lu2seg_amd/csrc -lu2seg_hip ...
+//   run:   selftest [bench]
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "u2seg_hip.h"
+
+#define HIPCHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(2); } } while (0)
+
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+static float bf2f(uint16_t v) { uint32_t u = ((uint32_t)v) << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint32_t rng_state = 12345;
+static float frand() { rng_state = rng_state * 1664525u + 1013904223u; return ((rng_state >> 8) & 0xffff) / 32768.0f - 1.0f; }
+
+template <typename T> struct DBuf {
+  T* d = nullptr; size_t n = 0;
+  explicit DBuf(size_t n_) : n(n_) { HIPCHK(hipMalloc(&d, n * sizeof(T) + 256)); HIPCHK(hipMemset(d, 0, n * sizeof(T) + 256)); }
+  ~DBuf() { (void)hipFree(d); }
+  void up(const std::vector<T>& h) { HIPCHK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
+  std::vector<T> down() { std::vector<T> h(n); HIPCHK(hipMemcpy(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost)); return h; }
+};
+
+struct ConvCase { int B, Hin, Win, C, N, KH, KW, pad, mul, div, relu, accum, bias, stats; const char* name; };
+
+static int out_dim(int in, int k, int pad, int mul, int div) {
+  if (div > 1) return in * div;           // dgrad of a stride-`div` conv whose forward output was `in`
+  return (in + 2 * pad - k) / mul + 1;
+}
+
+static int test_conv(const ConvCase& c, int variant) {
+  const int Hout = out_dim(c.Hin, c.KH, c.pad, c.mul, c.div), Wout = out_dim(c.Win, c.KW, c.pad, c.mul, c.div);
+  const int M = c.B * Hout * Wout, T = c.KH * c.KW;
+  const int out_ld = ((c.N + 31) / 32) * 32;
+  std::vector<uint16_t> hin((size_t)c.B * c.Hin * c.Win * c.C), hw((size_t)c.N * T * c.C), hout((size_t)M * out_ld);
+  std::vector<float> hb(c.N);
+  for (auto& v : hin) v = f2bf(frand());
+  for (auto& v : hw) v = f2bf(frand() * 0.25f);
+  for (auto& v : hout) v = f2bf(frand());
+  for (auto& v : hb) v = frand();
+  DBuf<uint16_t> din(hin.size()), dw(hw.size()), dout(hout.size());
+  DBuf<float> db(c.N), dst(2 * c.N);
+  din.up(hin); dw.up(hw); dout.up(hout); db.up(hb);
+  int rc = u2_conv_igemm(din.d, dw.d, dout.d, c.bias ? db.d : nullptr, c.stats ? dst.d : nullptr, c.B, c.Hin, c.Win, c.C, c.C,
+                         Hout, Wout, c.N, out_ld, c.KH, c.KW, c.pad, c.pad, c.mul, c.div, c.relu, c.accum, variant, nullptr);
+  HIPCHK(hipDeviceSynchronize());
+  if (rc) { printf("FAIL %-28s v%d launch rc=%d\n", c.name, variant, rc); return 1; }
+  auto got = dout.down();
+  auto gst = dst.down();
+  double max_err = 0, max_ref = 0, st_err = 0;
+  std::vector<double> s0(c.N, 0.0), s1(c.N, 0.0);
+  for (int m = 0; m < M; ++m) {
+    const int img = m / (Hout * Wout), rem = m % (Hout * Wout), oy = rem / Wout, ox = rem % Wout;
+    for (int n = 0; n < c.N; ++n) {
+      double acc = 0;
+      for (int kh = 0; kh < c.KH; ++kh)
+        for (int kw = 0; kw < c.KW; ++kw) {
+          int sy = oy * c.mul - c.pad + kh, sx = ox * c.mul - c.pad + kw;
+          if (sy < 0 || sx < 0) continue;
+          if (c.div > 1) { if (sy % c.div || sx % c.div) continue; sy /= c.div; sx /= c.div; }
+          if (sy >= c.Hin || sx >= c.Win) continue;
+          const uint16_t* ip = &hin[((size_t)(img * c.Hin + sy) * c.Win + sx) * c.C];
+          const uint16_t* wp = &hw[((size_t)n * T + kh * c.KW + kw) * c.C];
+          for (int k = 0; k < c.C; ++k) acc += (double)bf2f(ip[k]) * bf2f(wp[k]);
+        }
+      if (c.bias) acc += hb[n];
+      float ref = (float)acc;
+      if (c.accum) { ref = bf2f(f2bf(ref)) + bf2f(hout[(size_t)m * out_ld + n]); }
+      if (c.relu) ref = fmaxf(ref, 0.f);
+      const float g = bf2f(got[(size_t)m * out_ld + n]);
+      max_err = fmax(max_err, fabs((double)g - ref));
+      max_ref = fmax(max_ref, fabs((double)ref));
+      s0[n] += g; s1[n] += (double)g * g;
+    }
+  }
+  if (c.stats)
+    for (int n = 0; n < c.N; ++n) {
+      st_err = fmax(st_err, fabs(s0[n] - gst[n]) / (1.0 + fabs(s0[n])));
+      st_err = fmax(st_err, fabs(s1[n] - gst[c.N + n]) / (1.0 + fabs(s1[n])));
+    }
+  const bool ok = max_err <= 0.01 * max_ref + 1e-3 && st_err < 1e-3;
+  printf("%s %-28s v%d  max_err %.4g (max_ref %.4g) stats_relerr %.3g\n", ok ? "PASS" : "FAIL", c.name, variant, max_err, max_ref, st_err);
+  return ok ? 0 : 1;
+}
+
+struct WgCase { int B, Hin, Win, C, N, KH, KW, pad, stride; const char* name; };
+
+static int test_wgrad(const WgCase& c, int variant) {
+  const int Hout = (c.Hin + 2 * c.pad - c.KH) / c.stride + 1, Wout = (c.Win + 2 * c.pad - c.KW) / c.stride + 1;
+  const int M = c.B * Hout * Wout, T = c.KH * c.KW;
+  std::vector<uint16_t> hx((size_t)c.B * c.Hin * c.Win * c.C), hdy((size_t)M * c.N);
+  for (auto& v : hx) v = f2bf(frand());
+  for (auto& v : hdy) v = f2bf(frand());
+  DBuf<uint16_t> dx(hx.size()), ddy(hdy.size());
+  DBuf<float> ddw((size_t)c.N * T * c.C);
+  dx.up(hx); ddy.up(hdy);
+  int rc = u2_conv_wgrad(dx.d, ddy.d, ddw.d, c.B, c.Hin, c.Win, c.C, c.C, Hout, Wout, c.N, c.N, c.KH, c.KW, c.pad, c.pad,
+                         c.stride, variant, nullptr);
+  HIPCHK(hipDeviceSynchronize());
+  if (rc) { printf("FAIL %-28s v%d launch rc=%d\n", c.name, variant, rc); return 1; }
+  auto got = ddw.down();
+  std::vector<double> ref((size_t)c.N * T * c.C, 0.0);
+  for (int m = 0; m < M; ++m) {
+    const int img = m / (Hout * Wout), rem = m % (Hout * Wout), oy = rem / Wout, ox = rem % Wout;
+    for (int kh = 0; kh < c.KH; ++kh)
+      for (int kw = 0; kw < c.KW; ++kw) {
+        const int sy = oy * c.stride - c.pad + kh, sx = ox * c.stride - c.pad + kw;
+        if (sy < 0 || sx < 0 || sy >= c.Hin || sx >= c.Win) continue;
+        const uint16_t* ip = &hx[((size_t)(img * c.Hin + sy) * c.Win + sx) * c.C];
+        for (int n = 0; n < c.N; ++n) {
+          const double g = bf2f(hdy[(size_t)m * c.N + n]);
+          double* r = &ref[((size_t)n * T + kh * c.KW + kw) * c.C];
+          for (int k = 0; k < c.C; ++k) r[k] += g * bf2f(ip[k]);
+        }
+      }
+  }
+  double max_err = 0, max_ref = 0;
+  for (size_t i = 0; i < ref.size(); ++i) { max_err = fmax(max_err, fabs(ref[i] - got[i])); max_ref = fmax(max_ref, fabs(ref[i])); }
+  const bool ok = max_err <= 2e-3 * max_ref + 1e-3;
+  printf("%s %-28s v%d  max_err %.4g (max_ref %.4g)\n", ok ? "PASS" : "FAIL", c.name, variant, max_err, max_ref);
+  return ok ? 0 : 1;
+}
+
+static void bench_conv(const char* name, int B, int H, int W, int C, int N, int K, int pad, int stride, int variant) {
+  const int Hout = (H + 2 * pad - K) / stride + 1, Wout = (W + 2 * pad - K) / stride + 1;
+  const size_t M = (size_t)B * Hout * Wout;
+  DBuf<uint16_t> din((size_t)B * H * W * C), dw((size_t)N * K * K * C), dout(M * N), ddy(M * N);
+  DBuf<float> dgw((size_t)N * K * K * C), dst(2 * N);
+  std::vector<uint16_t> h(din.n); for (auto& v : h) v = f2bf(frand()); din.up(h);
+  std::vector<uint16_t> hw(dw.n); for (auto& v : hw) v = f2bf(frand() * 0.1f); dw.up(hw);
+  std::vector<uint16_t> hy(ddy.n); for (auto& v : hy) v = f2bf(frand()); ddy.up(hy);
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  const double flop = 2.0 * M * N * K * K * C;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int iters = 10;
+    for (int i = 0; i < 2; ++i) {
+      if (pass == 0) u2_conv_igemm(din.d, dw.d, dout.d, nullptr, dst.d, B, H, W, C, C, Hout, Wout, N, N, K, K, pad, pad, stride, 1, 0, 0, variant, nullptr);
+      else u2_conv_wgrad(din.d, ddy.d, dgw.d, B, H, W, C, C, Hout, Wout, N, N, K, K, pad, pad, stride, variant, nullptr);
+    }
+    HIPCHK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) {
+      if (pass == 0) u2_conv_igemm(din.d, dw.d, dout.d, nullptr, dst.d, B, H, W, C, C, Hout, Wout, N, N, K, K, pad, pad, stride, 1, 0, 0, variant, nullptr);
+      else u2_conv_wgrad(din.d, ddy.d, dgw.d, B, H, W, C, C, Hout, Wout, N, N, K, K, pad, pad, stride, variant, nullptr);
+    }
+    HIPCHK(hipEventRecord(e1)); HIPCHK(hipEventSynchronize(e1));
+    float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+    const double bytes = pass == 0 ? 2.0 * ((double)B * H * W * C + (double)M * N) : 2.0 * ((double)B * H * W * C + (double)M * N);
+    printf("BENCH %-26s %-5s v%d  %8.3f ms  %8.1f TFLOP/s  %7.1f GB/s(min traffic)\n", name, pass == 0 ? "fwd" : "wgrad", variant, ms,
+           flop / ms * 1e-9, bytes / ms * 1e-6);
+  }
+}
+
+int main(int argc, char** argv) {
+  int fails = 0;
+  hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, 0));
+  printf("device: %s  CUs %d  abi %d\n", prop.gcnArchName, prop.multiProcessorCount, u2_abi_version());
+  const ConvCase convs[] = {
+      {2, 9, 11, 64, 64, 1, 1, 0, 1, 1, 0, 0, 0, 1, "1x1 c64 n64 stats"},
+      {1, 13, 17, 128, 200, 3, 3, 1, 1, 1, 1, 0, 1, 0, "3x3 c128 n200 bias relu"},
+      {2, 14, 18, 64, 96, 3, 3, 1, 2, 1, 0, 0, 0, 1, "3x3 s2 c64 n96 stats"},
+      {2, 7, 9, 96, 64, 3, 3, 1, 1, 2, 0, 0, 0, 0, "dgrad(3x3 s2) c96(bk32) n64"},
+      {1, 8, 10, 256, 40, 1, 1, 0, 2, 1, 0, 0, 0, 0, "1x1 s2 c256 n40"},
+      {1, 300, 1, 160, 64, 1, 1, 0, 1, 1, 0, 0, 0, 1, "gemm k160(bk32) n64 stats"},
+      {1, 200, 1, 128, 801, 1, 1, 0, 1, 1, 0, 0, 1, 0, "linear k128 n801 bias"},
+      {1, 9, 9, 64, 64, 3, 3, 1, 1, 1, 1, 1, 0, 0, "3x3 accumulate relu"},
+  };
+  for (int v = 0; v < 2; ++v)
+    for (const auto& c : convs) fails += test_conv(c, v);
+  const WgCase wgs[] = {
+      {2, 9, 11, 64, 64, 1, 1, 0, 1, "wgrad 1x1 c64 n64"},
+      {1, 13, 17, 128, 136, 3, 3, 1, 1, "wgrad 3x3 c128 n136"},
+      {2, 14, 18, 72, 96, 3, 3, 1, 2, "wgrad 3x3 s2 c72 n96"},
+      {1, 700, 1, 160, 64, 1, 1, 0, 1, "wgrad gemm k160 n64"},
+  };
+  for (int v = 0; v < 4; ++v)
+    for (const auto& c : wgs) fails += test_wgrad(c, v);
+  printf("SELFTEST %s (%d failures)\n", fails ? "FAILED" : "OK", fails);
+  if (argc > 1 && !strcmp(argv[1], "bench")) {
+    for (int v = 0; v < 1; ++v) {
+      bench_conv("res2 3x3 64->64 B16", 16, 200, 336, 64, 64, 3, 1, 1, v);
+      bench_conv("res2 1x1 64->256 B16", 16, 200, 336, 64, 256, 1, 0, 1, v);
+      bench_conv("res2 1x1 256->64 B16", 16, 200, 336, 256, 64, 1, 0, 1, v);
+      bench_conv("res3 3x3 128->128 B16", 16, 100, 168, 128, 128, 3, 1, 1, v);
+      bench_conv("res4 3x3 256->256 B16", 16, 50, 84, 256, 256, 3, 1, 1, v);
+      bench_conv("res4 1x1 1024->256 B16", 16, 50, 84, 1024, 256, 1, 0, 1, v);
+      bench_conv("res5 3x3 512->512 B16", 16, 25, 42, 512, 512, 3, 1, 1, v);
+      bench_conv("fpn_out2 3x3 256->256 B16", 16, 200, 336, 256, 256, 3, 1, 1, v);
+      bench_conv("fc1 12544->1024 M8192", 1, 8192, 1, 12544, 1024, 1, 0, 1, v);
+      bench_conv("gemm 8192x8192x8192", 1, 8192, 1, 8192, 8192, 1, 0, 1, v);
+    }
+    bench_conv("res4 3x3 256->256 B16 (regstage)", 16, 50, 84, 256, 256, 3, 1, 1, 1);
+  }
+  return fails ? 1 : 0;
+}

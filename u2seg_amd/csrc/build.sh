@@ -1,0 +1,16 @@
+#!/bin/bash
+# Builds libu2seg_hip.so (gfx950 only) in-tree. Usage: build.sh [extra hipcc flags]
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I. -I../../include -Wno-unused-result"
+OBJS=""
+for f in conv_igemm norm pool_resize losses roi optim kmeans; do
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ ../../include/u2seg_hip.h -nt $f.o ]; then
+    $HIPCC $FLAGS "$@" -c $f.hip -o $f.o &
+  fi
+  OBJS="$OBJS $f.o"
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC $OBJS -o libu2seg_hip.so
+echo "built $(pwd)/libu2seg_hip.so"

@@ -1,0 +1,552 @@
+// Implicit-GEMM convolution family on CDNA4 MFMA (gfx950), bf16 in / fp32 accumulate.
+//
+// Replaces the F.conv2d / F.linear / ConvTranspose2d calls behind
+//   detectron2/layers/wrappers.py:127-134 (Conv2d.forward), roi_heads/box_head.py:94-97,
+//   roi_heads/fast_rcnn.py:288-305, roi_heads/mask_head.py:287-290   (reference file:line)
+// and their autograd backward (dgrad = the same gather with mul/div swapped and a flipped,
+// transposed filter; wgrad = pixel-reduction GEMM with split-K + fp32 atomics).
+//
+// Data layout (HBM): activations NHWC bf16 ("pixel rows" of C channels, pitch in_ld), weights
+// [N][KH*KW][C] bf16 (K contiguous per output channel), outputs [M][out_ld] bf16, M = B*Hout*Wout.
+//
+// Tile: 128 pixels x 128 output channels x BK reduction per workgroup of 4 waves (2x2, 64x64 per
+// wave, 4x4 v_mfma_f32_16x16x32_bf16).  Operands reach LDS by global_load_lds (16 B per lane, the
+// LDS image is lane-linear, the XOR bank swizzle is applied on the *source* chunk index and again
+// on the fragment read).  Zero padding / row tails read a 16-byte zero page instead of branching.
+// The MFMA is issued with the weight tile as the "A" operand and the pixel tile as "B", so every
+// lane ends up with 4 consecutive channels of one pixel; the tile is then transposed through LDS
+// and written with 16-byte coalesced stores (bias / accumulate / ReLU / BN column statistics fused).
+#include "common.h"
+#include "u2seg_hip.h"
+
+namespace {
+
+struct ConvArgs {
+  const bf16_t* in;
+  const bf16_t* wt;
+  bf16_t* out;
+  const float* bias;
+  float* stats;
+  const bf16_t* zero;
+  int B, Hin, Win, C, in_ld;
+  int Hout, Wout, N, out_ld;
+  int KH, KW, pad_h, pad_w, mul, div;
+  int relu, accumulate;
+  int M, tiles_m, tiles_n;
+};
+
+constexpr int TM = 128;  // pixels per tile
+constexpr int TN = 128;  // output channels per tile
+constexpr int OPITCH = TN + 8;  // bf16 elements per row of the staged output tile
+
+template <int BK> __device__ __forceinline__ int swz(int row);
+template <> __device__ __forceinline__ int swz<64>(int row) { return row & 7; }
+template <> __device__ __forceinline__ int swz<32>(int row) { return (-(row >> 2)) & 3; }
+
+__device__ __forceinline__ void glds16(const bf16_t* src, void* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds(U2_GLB_PTR(src), U2_LDS_PTR(lds_dst_wave_base), 16, 0, 0);
+}
+
+template <int BK, bool GLDS>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
+  constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
+  constexpr int NCH = (TM * CPR) / 256;       // chunks per thread per operand
+  constexpr int ROWS_PER_WAVE_INSTR = 64 / CPR;
+  constexpr int TILE_BYTES = TM * BK * 2;     // one operand, one stage
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = a.tiles_m * a.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int tile_m = tile / a.tiles_n;
+  const int tile_n = tile - tile_m * a.tiles_n;
+  const int m0 = tile_m * TM;
+  const int n0 = tile_n * TN;
+
+  // ---- per-thread chunk bookkeeping (rows are fixed across the K loop) ----
+  int p_img[NCH], p_by[NCH], p_bx[NCH];
+  bool p_ok[NCH];
+  const bf16_t* w_row[NCH];
+  int cc;  // data chunk (8 channels) this lane fetches within a row; identical for all NCH rows
+  {
+    const int row_in_instr = lane / CPR;
+    const int slot = lane % CPR;
+    cc = slot ^ swz<BK>(row_in_instr);  // (instr,wave) offsets are multiples of the swizzle period
+    const int hw = a.Hout * a.Wout;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int row = (i * 4 + w) * ROWS_PER_WAVE_INSTR + row_in_instr;
+      const int m = m0 + row;
+      p_ok[i] = m < a.M;
+      const int mm = p_ok[i] ? m : 0;
+      const int img = mm / hw;
+      const int rem = mm - img * hw;
+      const int oy = rem / a.Wout;
+      const int ox = rem - oy * a.Wout;
+      p_img[i] = img;
+      p_by[i] = oy * a.mul - a.pad_h;
+      p_bx[i] = ox * a.mul - a.pad_w;
+      const int n = n0 + row;
+      w_row[i] = (n < a.N) ? a.wt + (size_t)n * ((size_t)a.KH * a.KW * a.C) + cc * 8 : nullptr;
+    }
+  }
+
+  const int kc_per_tap = a.C / BK;
+  const int nk = a.KH * a.KW * kc_per_tap;
+
+  uint4 stage_regs[GLDS ? 1 : 2 * NCH];
+
+  auto issue = [&](int kt, int buf) {
+    const int tap = kt / kc_per_tap;
+    const int c0 = (kt - tap * kc_per_tap) * BK;
+    const int kh = tap / a.KW;
+    const int kw = tap - kh * a.KW;
+    unsigned char* pbase = smem + buf * STAGE_BYTES;
+    unsigned char* wbase = pbase + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int sy = p_by[i] + kh, sx = p_bx[i] + kw;
+      bool ok = p_ok[i] && sy >= 0 && sx >= 0;
+      if (a.div > 1) {
+        ok = ok && (sy % a.div == 0) && (sx % a.div == 0);
+        sy /= a.div;
+        sx /= a.div;
+      }
+      ok = ok && sy < a.Hin && sx < a.Win;
+      const bf16_t* src = ok ? a.in + ((size_t)(p_img[i] * a.Hin + sy) * a.Win + sx) * a.in_ld + c0 + cc * 8
+                             : a.zero;
+      const bf16_t* wsrc = w_row[i] ? w_row[i] + (size_t)tap * a.C + c0 : a.zero;
+      if constexpr (GLDS) {
+        glds16(src, pbase + (i * 4 + w) * 1024);
+        glds16(wsrc, wbase + (i * 4 + w) * 1024);
+      } else {
+        stage_regs[2 * i] = *reinterpret_cast<const uint4*>(src);
+        stage_regs[2 * i + 1] = *reinterpret_cast<const uint4*>(wsrc);
+      }
+    }
+  };
+  auto commit = [&](int buf) {  // register-staged path only
+    if constexpr (!GLDS) {
+      unsigned char* pbase = smem + buf * STAGE_BYTES;
+      unsigned char* wbase = pbase + TILE_BYTES;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        *reinterpret_cast<uint4*>(pbase + (i * 4 + w) * 1024 + lane * 16) = stage_regs[2 * i];
+        *reinterpret_cast<uint4*>(wbase + (i * 4 + w) * 1024 + lane * 16) = stage_regs[2 * i + 1];
+      }
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int wr = w >> 1;  // which 64-channel half of the tile
+  const int wc = w & 1;   // which 64-pixel half of the tile
+  const int fr = lane & 15;
+  const int fg = lane >> 4;
+
+  auto compute = [&](int buf) {
+    const unsigned char* pbase = smem + buf * STAGE_BYTES;
+    const unsigned char* wbase = pbase + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      s16x8 wf[4], pf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int nrow = wr * 64 + t * 16 + fr;
+        const int prow = wc * 64 + t * 16 + fr;
+        const int kc = ks * 4 + fg;
+        wf[t] = *reinterpret_cast<const s16x8*>(wbase + nrow * (BK * 2) + ((kc ^ swz<BK>(nrow)) << 4));
+        pf[t] = *reinterpret_cast<const s16x8*>(pbase + prow * (BK * 2) + ((kc ^ swz<BK>(prow)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], pf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if constexpr (GLDS) {
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+      compute(kt & 1);
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      issue(kt, 0);
+      __syncthreads();
+      commit(0);
+      __syncthreads();
+      compute(0);
+    }
+  }
+
+  // ---- epilogue: accumulators -> LDS (bf16, [pixel][channel]) -> coalesced 16-byte stores ----
+  __syncthreads();
+  bf16_t* otile = reinterpret_cast<bf16_t*>(smem);
+  float* red = reinterpret_cast<float*>(smem + TM * OPITCH * 2);  // [2][4][128] floats
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int nl = wr * 64 + i * 16 + fg * 4;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (a.bias) {
+      const int n = n0 + nl;
+      b0 = (n + 0 < a.N) ? a.bias[n + 0] : 0.f;
+      b1 = (n + 1 < a.N) ? a.bias[n + 1] : 0.f;
+      b2 = (n + 2 < a.N) ? a.bias[n + 2] : 0.f;
+      b3 = (n + 3 < a.N) ? a.bias[n + 3] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ml = wc * 64 + j * 16 + fr;
+      float v0 = acc[i][j][0] + b0, v1 = acc[i][j][1] + b1, v2 = acc[i][j][2] + b2, v3 = acc[i][j][3] + b3;
+      if (a.relu && !a.accumulate) {
+        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+      }
+      uint2 pk;
+      pk.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+      pk.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+      *reinterpret_cast<uint2*>(otile + ml * OPITCH + nl) = pk;
+    }
+  }
+  __syncthreads();
+
+  const int cchunk = tid & 15;
+  const int rbase = tid >> 4;
+  float s[8], ss[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+  const bool vec_ok = ((a.out_ld & 7) == 0) && (n0 + cchunk * 8 + 8 <= a.N);
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 16 + rbase;
+    const int m = m0 + row;
+    if (m >= a.M) continue;
+    uint4 v = *reinterpret_cast<const uint4*>(otile + row * OPITCH + cchunk * 8);
+    bf16_t e8[8];
+    *reinterpret_cast<uint4*>(e8) = v;
+    bf16_t* dst = a.out + (size_t)m * a.out_ld + n0 + cchunk * 8;
+    if (a.accumulate) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (n0 + cchunk * 8 + e < a.N) {
+          float f = bf2f(e8[e]) + bf2f(dst[e]);
+          if (a.relu) f = fmaxf(f, 0.f);
+          e8[e] = f2bf(f);
+        }
+      }
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = bf2f(e8[e]);
+        s[e] += f;
+        ss[e] += f * f;
+      }
+    }
+    if (vec_ok) {
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(e8);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n0 + cchunk * 8 + e < a.N) dst[e] = e8[e];
+    }
+  }
+  if (a.stats) {
+    // lanes sharing (lane & 15) hold partial sums of the same 8 channels
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s[e] += __shfl_xor(s[e], 16, 64);
+      s[e] += __shfl_xor(s[e], 32, 64);
+      ss[e] += __shfl_xor(ss[e], 16, 64);
+      ss[e] += __shfl_xor(ss[e], 32, 64);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(0 * 4 + w) * 128 + lane * 8 + e] = s[e];
+        red[(1 * 4 + w) * 128 + lane * 8 + e] = ss[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 128 && n0 + tid < a.N) {
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) {
+        t0 += red[(0 * 4 + ww) * 128 + tid];
+        t1 += red[(1 * 4 + ww) * 128 + tid];
+      }
+      atomicAdd(a.stats + n0 + tid, t0);
+      atomicAdd(a.stats + a.N + n0 + tid, t1);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: dW[n][tap][c] += sum_m dY[m][n] * X[src(m,tap)][c]    (fp32 atomics, split over pixels)
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const bf16_t* x;    // NHWC input of the forward conv (pixel pitch x_ld)
+  const bf16_t* dy;   // [M][dy_ld] output gradient
+  float* dw;          // [N][T][C] fp32, accumulated atomically
+  const bf16_t* zero;
+  int B, Hin, Win, C, x_ld;
+  int Hout, Wout, N, dy_ld;
+  int KH, KW, pad_h, pad_w, stride;
+  int M, tiles_n, tiles_c, pix_per_wg;
+};
+
+constexpr int WP = 32;  // pixels per reduction step
+
+template <bool GLDS, bool TR>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
+  constexpr int TILE_BYTES = WP * 128 * 2;  // 8 KB per operand per stage
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = blockIdx.x;
+  const int tile_c = t % a.tiles_c; t /= a.tiles_c;
+  const int tile_n = t % a.tiles_n; t /= a.tiles_n;
+  const int tap = t;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int n0 = tile_n * 128, c0 = tile_c * 128;
+  const int mbeg = blockIdx.y * a.pix_per_wg;
+  const int mend = min(a.M, mbeg + a.pix_per_wg);
+  if (mbeg >= mend) return;
+  const int nsteps = (mend - mbeg + WP - 1) / WP;
+  const int hw = a.Hout * a.Wout;
+  const bool direct = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad_h == 0 && a.pad_w == 0);
+
+  // chunk assignment: instr i in {0,1}: linear chunk p = (i*4+w)*64 + lane; pix = p>>4, slot = p&15
+  const int pix_in_instr = lane >> 4;
+  const int slot = lane & 15;
+
+  uint4 stage_regs[GLDS ? 1 : 4];
+  auto issue = [&](int step, int buf) {
+    unsigned char* ybase = smem + buf * STAGE_BYTES;
+    unsigned char* xbase = ybase + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pix = (i * 4 + w) * 4 + pix_in_instr;
+      const int cc = slot ^ (pix & 15);
+      const int m = mbeg + step * WP + pix;
+      const bool mok = m < mend;
+      const bf16_t* ysrc = (mok && n0 + cc * 8 < a.N) ? a.dy + (size_t)m * a.dy_ld + n0 + cc * 8 : a.zero;
+      const bf16_t* xsrc = a.zero;
+      if (mok && c0 + cc * 8 < a.C) {
+        if (direct) {
+          xsrc = a.x + (size_t)m * a.x_ld + c0 + cc * 8;
+        } else {
+          const int img = m / hw;
+          const int rem = m - img * hw;
+          const int oy = rem / a.Wout;
+          const int ox = rem - oy * a.Wout;
+          const int sy = oy * a.stride - a.pad_h + kh;
+          const int sx = ox * a.stride - a.pad_w + kw;
+          if (sy >= 0 && sy < a.Hin && sx >= 0 && sx < a.Win)
+            xsrc = a.x + ((size_t)(img * a.Hin + sy) * a.Win + sx) * a.x_ld + c0 + cc * 8;
+        }
+      }
+      if constexpr (GLDS) {
+        glds16(ysrc, ybase + (i * 4 + w) * 1024);
+        glds16(xsrc, xbase + (i * 4 + w) * 1024);
+      } else {
+        stage_regs[2 * i] = *reinterpret_cast<const uint4*>(ysrc);
+        stage_regs[2 * i + 1] = *reinterpret_cast<const uint4*>(xsrc);
+      }
+    }
+  };
+  auto commit = [&](int buf) {
+    if constexpr (!GLDS) {
+      unsigned char* ybase = smem + buf * STAGE_BYTES;
+      unsigned char* xbase = ybase + TILE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        *reinterpret_cast<uint4*>(ybase + (i * 4 + w) * 1024 + lane * 16) = stage_regs[2 * i];
+        *reinterpret_cast<uint4*>(xbase + (i * 4 + w) * 1024 + lane * 16) = stage_regs[2 * i + 1];
+      }
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int wr = w >> 1, wc = w & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // fragment for channel block `cb` (16 channels starting at ch0): lane gets, for channel ch0+fr,
+  // the 8 pixels 8*fg .. 8*fg+7 of the step.  LDS image: [pix][128 ch] bf16, 16-byte chunks
+  // XOR-swizzled by (pix & 15).
+  auto load_frag = [&](const unsigned char* base, int ch0) -> s16x8 {
+    s16x8 r;
+    if constexpr (TR) {
+      // ds_read_b64_tr_b16: lane q (= fr) of a 16-lane group supplies the address of 4 contiguous
+      // bf16 (pixel p0 + q/4, channels ch0 + (q%4)*4 ..+3); it receives channel ch0+q of pixels p0..p0+3.
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pix = fg * 8 + h * 4 + (fr >> 2);
+        const int ch = ch0 + (fr & 3) * 4;
+        const int chunk = (ch >> 3) ^ (pix & 15);
+        const unsigned char* p = base + pix * 256 + chunk * 16 + (ch & 7) * 2;
+        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+        r[h * 4 + 0] = v[0]; r[h * 4 + 1] = v[1]; r[h * 4 + 2] = v[2]; r[h * 4 + 3] = v[3];
+      }
+    } else {
+      const int ch = ch0 + fr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int pix = fg * 8 + e;
+        const int chunk = (ch >> 3) ^ (pix & 15);
+        r[e] = *reinterpret_cast<const short*>(base + pix * 256 + chunk * 16 + (ch & 7) * 2);
+      }
+    }
+    return r;
+  };
+
+  auto compute = [&](int buf) {
+    const unsigned char* ybase = smem + buf * STAGE_BYTES;
+    const unsigned char* xbase = ybase + TILE_BYTES;
+    s16x8 yf[4], xf[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      yf[q] = load_frag(ybase, wr * 64 + q * 16);
+      xf[q] = load_frag(xbase, wc * 64 + q * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+  };
+
+  if constexpr (GLDS) {
+    issue(0, 0);
+    for (int st = 0; st < nsteps; ++st) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (st + 1 < nsteps) issue(st + 1, (st + 1) & 1);
+      compute(st & 1);
+    }
+  } else {
+    for (int st = 0; st < nsteps; ++st) {
+      issue(st, 0);
+      __syncthreads();
+      commit(0);
+      __syncthreads();
+      compute(0);
+    }
+  }
+
+  // D[i = n][j = c]: lane holds column c = fr, rows n = fg*4 + r
+  const int T = a.KH * a.KW;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + wc * 64 + j * 16 + fr;
+      if (c >= a.C) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wr * 64 + i * 16 + fg * 4 + r;
+        if (n < a.N) atomicAdd(a.dw + ((size_t)n * T + tap) * a.C + c, acc[i][j][r]);
+      }
+    }
+}
+
+__device__ __attribute__((aligned(256))) bf16_t g_zero_page[128];
+
+const bf16_t* zero_page_ptr() {
+  static const bf16_t* p = nullptr;
+  if (!p) {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_page)) != hipSuccess) return nullptr;
+    p = reinterpret_cast<const bf16_t*>(q);
+  }
+  return p;
+}
+
+}  // namespace
+
+extern "C" int u2_conv_igemm(const void* in, const void* wt, void* out, const float* bias, float* stats,
+                             int B, int Hin, int Win, int C, int in_ld, int Hout, int Wout, int N, int out_ld,
+                             int KH, int KW, int pad_h, int pad_w, int mul, int div, int relu, int accumulate,
+                             int variant, void* stream) {
+  if (C % 32 != 0 || (in_ld & 7) != 0) return -1;
+  if (B <= 0 || Hout <= 0 || Wout <= 0 || N <= 0) return 0;
+  ConvArgs a;
+  a.in = (const bf16_t*)in; a.wt = (const bf16_t*)wt; a.out = (bf16_t*)out; a.bias = bias; a.stats = stats;
+  a.zero = zero_page_ptr();
+  if (!a.zero) return -2;
+  a.B = B; a.Hin = Hin; a.Win = Win; a.C = C; a.in_ld = in_ld;
+  a.Hout = Hout; a.Wout = Wout; a.N = N; a.out_ld = out_ld;
+  a.KH = KH; a.KW = KW; a.pad_h = pad_h; a.pad_w = pad_w; a.mul = mul; a.div = div;
+  a.relu = relu; a.accumulate = accumulate;
+  a.M = B * Hout * Wout;
+  a.tiles_m = (a.M + TM - 1) / TM;
+  a.tiles_n = (N + TN - 1) / TN;
+  const dim3 grid(a.tiles_m * a.tiles_n), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const bool glds = (variant & 1) == 0;
+  if (C % 64 == 0) {
+    const size_t lds = 2 * 2 * TM * 64 * 2;  // 64 KiB
+    if (glds) hipLaunchKernelGGL((conv_igemm_kernel<64, true>), grid, block, lds, s, a);
+    else      hipLaunchKernelGGL((conv_igemm_kernel<64, false>), grid, block, lds, s, a);
+  } else {
+    const size_t lds = TM * OPITCH * 2 + 2 * 4 * 128 * 4;  // epilogue footprint dominates (38 KiB)
+    if (glds) hipLaunchKernelGGL((conv_igemm_kernel<32, true>), grid, block, lds, s, a);
+    else      hipLaunchKernelGGL((conv_igemm_kernel<32, false>), grid, block, lds, s, a);
+  }
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_conv_wgrad(const void* x, const void* dy, float* dw, int B, int Hin, int Win, int C, int x_ld,
+                             int Hout, int Wout, int N, int dy_ld, int KH, int KW, int pad_h, int pad_w,
+                             int stride, int variant, void* stream) {
+  if ((C & 7) != 0 || (x_ld & 7) != 0 || (dy_ld & 7) != 0 || (N & 7) != 0) return -1;
+  if (B <= 0 || Hout <= 0 || Wout <= 0) return 0;
+  WgradArgs a;
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw; a.zero = zero_page_ptr();
+  if (!a.zero) return -2;
+  a.B = B; a.Hin = Hin; a.Win = Win; a.C = C; a.x_ld = x_ld;
+  a.Hout = Hout; a.Wout = Wout; a.N = N; a.dy_ld = dy_ld;
+  a.KH = KH; a.KW = KW; a.pad_h = pad_h; a.pad_w = pad_w; a.stride = stride;
+  a.M = B * Hout * Wout;
+  a.tiles_n = (N + 127) / 128;
+  a.tiles_c = (C + 127) / 128;
+  const int tiles = a.tiles_n * a.tiles_c * KH * KW;
+  // aim for ~8 workgroups per CU in total; each split handles a multiple of WP pixels
+  int splits = (2048 + tiles - 1) / tiles;
+  const int max_splits = (a.M + 4 * WP - 1) / (4 * WP);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int ppw = (a.M + splits - 1) / splits;
+  ppw = ((ppw + WP - 1) / WP) * WP;
+  splits = (a.M + ppw - 1) / ppw;
+  a.pix_per_wg = ppw;
+  const dim3 grid(tiles, splits), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const bool glds = (variant & 1) == 0, tr = (variant & 2) == 0;
+  if (glds && tr)       hipLaunchKernelGGL((conv_wgrad_kernel<true, true>), grid, block, 0, s, a);
+  else if (glds && !tr) hipLaunchKernelGGL((conv_wgrad_kernel<true, false>), grid, block, 0, s, a);
+  else if (!glds && tr) hipLaunchKernelGGL((conv_wgrad_kernel<false, true>), grid, block, 0, s, a);
+  else                  hipLaunchKernelGGL((conv_wgrad_kernel<false, false>), grid, block, 0, s, a);
+  U2_CHECK_LAUNCH();
+  return 0;
+}

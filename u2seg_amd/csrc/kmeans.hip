@@ -1,0 +1,235 @@
+// Lloyd k-means over fp32 embeddings: assignment (pairwise distance + argmin) and update (segmented sums).
+//
+// Replaces KMeans in u2seg/Instance_Clustering/shared/utils/nn_utils.py:304-379:
+//   E-step  cl = argmin_j sum_d (x_id - c_jd)^2      (:353-355, a pykeops LazyTensor reduction)
+//   M-step  c.zero_(); c.scatter_add_(0, cl.repeat(1,D), x); Ncl = bincount(cl); c /= Ncl   (:358-364)
+// E-step here: dist_j = |c_j|^2 - 2 x.c_j (the |x|^2 term does not change the argmin) with the dot products on
+// the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, an fma chain in k order), so labels agree with the reference
+// except where two centroids are equidistant to within fp32 rounding of the two formulations.
+// Empty clusters give 0/0 = NaN centroids exactly like the reference (noted at usl-imagenet.py:135).
+#include "common.h"
+#include "u2seg_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int KM_PTS = 128;    // points per workgroup (32 per wave)
+constexpr int KM_BD = 16;      // dims per staged chunk
+constexpr int KM_PITCH = 17;   // padded LDS row pitch (floats)
+constexpr int KM_TILES = 10;   // 32-centroid tiles per pass (320 centroids)
+
+__global__ __launch_bounds__(256) void cnorm_kernel(const float* __restrict__ c, float* __restrict__ cn, int D, int K) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= K) return;
+  float s = 0.f;
+  for (int d = threadIdx.x & 63; d < D; d += 64) { const float v = c[(size_t)j * D + d]; s += v * v; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) cn[j] = s;
+}
+
+__device__ __forceinline__ bool km_less(float v, int j, float bv, int bj) {
+  // torch.argmin order: NaN beats numbers, first index wins ties
+  const bool vn = v != v, bn = bv != bv;
+  if (vn != bn) return vn;
+  if (vn) return j < bj;
+  return v < bv || (v == bv && j < bj);
+}
+
+__global__ __launch_bounds__(256, 1) void kmeans_assign_kernel(const float* __restrict__ x, const float* __restrict__ c,
+                                                               const float* __restrict__ cn, long long* __restrict__ labels,
+                                                               int N, int D, int K) {
+  __shared__ float xs[KM_PTS * KM_PITCH];
+  __shared__ float cs[KM_TILES * 32 * KM_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int p0 = blockIdx.x * KM_PTS;
+  const int li = lane & 31, lk = lane >> 5;
+
+  float best_v[16];
+  int best_j[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { best_v[r] = INFINITY; best_j[r] = 0x7fffffff; }
+
+  for (int k0 = 0; k0 < K; k0 += KM_TILES * 32) {
+    const int ntile = min(KM_TILES, (K - k0 + 31) / 32);
+    f32x16 acc[KM_TILES];
+#pragma unroll
+    for (int t = 0; t < KM_TILES; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float4 xr[2], cr[5];
+    auto gload = [&](int d0) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int f = q * 256 + tid;           // float4 index: row = f/4, col4 = f%4
+        const int row = f >> 2, c4 = f & 3;
+        const int p = p0 + row;
+        xr[q] = (p < N) ? *reinterpret_cast<const float4*>(x + (size_t)p * D + d0 + c4 * 4) : make_float4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int f = q * 256 + tid;
+        const int row = f >> 2, c4 = f & 3;
+        const int j = k0 + row;
+        cr[q] = (row < ntile * 32 && j < K) ? *reinterpret_cast<const float4*>(c + (size_t)j * D + d0 + c4 * 4)
+                                            : make_float4(0, 0, 0, 0);
+      }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int f = q * 256 + tid;
+        float* dst = xs + (f >> 2) * KM_PITCH + (f & 3) * 4;
+        dst[0] = xr[q].x; dst[1] = xr[q].y; dst[2] = xr[q].z; dst[3] = xr[q].w;
+      }
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int f = q * 256 + tid;
+        float* dst = cs + (f >> 2) * KM_PITCH + (f & 3) * 4;
+        dst[0] = cr[q].x; dst[1] = cr[q].y; dst[2] = cr[q].z; dst[3] = cr[q].w;
+      }
+    };
+
+    gload(0);
+    for (int d0 = 0; d0 < D; d0 += KM_BD) {
+      __syncthreads();
+      lstore();
+      __syncthreads();
+      if (d0 + KM_BD < D) gload(d0 + KM_BD);
+#pragma unroll
+      for (int ks = 0; ks < KM_BD / 2; ++ks) {
+        const float a = xs[(w * 32 + li) * KM_PITCH + ks * 2 + lk];
+#pragma unroll
+        for (int t = 0; t < KM_TILES; ++t) {
+          if (t < ntile) {
+            const float b = cs[(t * 32 + li) * KM_PITCH + ks * 2 + lk];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // D[i = point][j = centroid]: lane holds column j = li of tile t, rows (r&3) + 8*(r>>2) + 4*lk
+#pragma unroll
+    for (int t = 0; t < KM_TILES; ++t) {
+      if (t < ntile) {
+        const int j = k0 + t * 32 + li;
+        const float cj = (j < K) ? cn[j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (j < K) {
+            const float v = cj - 2.f * acc[t][r];
+            if (km_less(v, j, best_v[r], best_j[r])) { best_v[r] = v; best_j[r] = j; }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // reduce over the 32 lanes that share lk
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = best_v[r];
+    int j = best_j[r];
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oj = __shfl_xor(j, o, 64);
+      if (km_less(ov, oj, v, j)) { v = ov; j = oj; }
+    }
+    if (li == 0) {
+      const int p = p0 + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (p < N) labels[p] = (long long)j;
+    }
+  }
+}
+
+// csum[K][D] += x rows by label; counts[K] += 1.  grid = (point chunks, D / DS); LDS holds [K][DS] partial sums.
+template <int DS>
+__global__ __launch_bounds__(256) void kmeans_update_kernel(const float* __restrict__ x, const long long* __restrict__ labels,
+                                                            float* __restrict__ csum, float* __restrict__ counts, int N, int D,
+                                                            int K, int pts_per_block) {
+  extern __shared__ float part[];  // [K][DS] then [K] counts
+  float* pc = part + (size_t)K * DS;
+  const int tid = threadIdx.x;
+  const int d0 = blockIdx.y * DS;
+  const int pb = blockIdx.x * pts_per_block;
+  const int pe = min(N, pb + pts_per_block);
+  for (int i = tid; i < K * DS + K; i += 256) part[i] = 0.f;
+  __syncthreads();
+  constexpr int PPI = 256 / DS;  // points per iteration
+  const int sub = tid / DS, d = tid % DS;
+  for (int p = pb + sub; p < pe; p += PPI) {
+    const int l = (int)labels[p];
+    if (d0 + d < D) atomicAdd(&part[l * DS + d], x[(size_t)p * D + d0 + d]);
+    if (d == 0 && blockIdx.y == 0) atomicAdd(&pc[l], 1.f);
+  }
+  __syncthreads();
+  for (int i = tid; i < K * DS; i += 256) {
+    const float v = part[i];
+    const int j = i / DS, dd = i % DS;
+    if (v != 0.f && d0 + dd < D) atomicAdd(csum + (size_t)j * D + d0 + dd, v);
+  }
+  if (blockIdx.y == 0)
+    for (int j = tid; j < K; j += 256)
+      if (pc[j] != 0.f) atomicAdd(counts + j, pc[j]);
+}
+
+__global__ void kmeans_finalize_kernel(const float* __restrict__ csum, const float* __restrict__ counts, float* __restrict__ c,
+                                       int D, int K) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)K * D) return;
+  c[i] = csum[i] / counts[i / D];
+}
+
+}  // namespace
+
+extern "C" int u2_kmeans_assign(const float* x, const float* c, float* cnorm_ws, long long* labels, int N, int D, int K,
+                                void* stream) {
+  if (D % KM_BD != 0 || K < 1 || !cnorm_ws) return -1;
+  if (N <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(cnorm_kernel, dim3((K + 3) / 4), dim3(256), 0, s, c, cnorm_ws, D, K);
+  U2_CHECK_LAUNCH();
+  hipLaunchKernelGGL(kmeans_assign_kernel, dim3((N + KM_PTS - 1) / KM_PTS), dim3(256), 0, s, x, c, cnorm_ws, labels, N, D, K);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_kmeans_update(const float* x, const long long* labels, float* csum, float* counts, int N, int D, int K,
+                                void* stream) {
+  if (N <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  int DS = 64;
+  while (DS > 16 && (size_t)K * (DS + 1) * 4 > 144 * 1024) DS >>= 1;
+  if ((size_t)K * (DS + 1) * 4 > 144 * 1024) return -1;
+  const size_t lds = (size_t)K * (DS + 1) * 4;
+  const int ppb = 8192;
+  const dim3 grid((N + ppb - 1) / ppb, (D + DS - 1) / DS);
+  hipError_t e;
+  if (DS == 64) {
+    e = hipFuncSetAttribute((const void*)kmeans_update_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kmeans_update_kernel<64>, grid, dim3(256), lds, s, x, labels, csum, counts, N, D, K, ppb);
+  } else if (DS == 32) {
+    e = hipFuncSetAttribute((const void*)kmeans_update_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kmeans_update_kernel<32>, grid, dim3(256), lds, s, x, labels, csum, counts, N, D, K, ppb);
+  } else {
+    e = hipFuncSetAttribute((const void*)kmeans_update_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kmeans_update_kernel<16>, grid, dim3(256), lds, s, x, labels, csum, counts, N, D, K, ppb);
+  }
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_kmeans_finalize(const float* csum, const float* counts, float* c, int D, int K, void* stream) {
+  const size_t n = (size_t)K * D;
+  hipLaunchKernelGGL(kmeans_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, csum,
+                     counts, c, D, K);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_abi_version(void) { return 1; }

@@ -1,0 +1,374 @@
+// Loss kernels (fp32 arithmetic on bf16 logits; forward and the logit gradient produced in one pass).
+//
+// Replaces (reference file:line):
+//   SemSegFPNHead.losses: bilinear x4 + F.cross_entropy(mean, ignore 255)   meta_arch/semantic_seg.py:255-267
+//   FastRCNNOutputLayers.losses: cross_entropy(mean) + box_reg_loss (L1)     roi_heads/fast_rcnn.py:307-347,424-463
+//   mask_rcnn_loss: gt-class channel gather + BCE-with-logits(mean)          roi_heads/mask_head.py:33-112
+//     (fused with the 1x1 predictor conv of mask_head.py:258 so only the gt-class channel is computed)
+//   RPN.losses: BCE-with-logits(sum) + L1 over positives, / (batch_per_image * N)   proposal_generator/rpn.py:366-429
+//   Box2BoxTransform.get_deltas                                               modeling/box_regression.py:43-76
+#include "common.h"
+#include "u2seg_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Semantic head loss: logits [B][h][w][LP] bf16 at stride 4, targets uint8 [B][4h][4w].
+// One workgroup = 64x16 full-resolution pixels; the 18x6 low-resolution taps it touches are staged
+// in LDS as fp32, the logit gradient is accumulated in LDS with ds atomics and flushed once.
+// ------------------------------------------------------------------------------------------------
+constexpr int SS_TW = 64, SS_TH = 16, SS_LW = 18, SS_LH = 6, SS_MAXC = 32;
+
+__global__ __launch_bounds__(256) void semseg_ce_kernel(const bf16_t* __restrict__ logits, const uint8_t* __restrict__ target,
+                                                        float* __restrict__ grad_acc, float* __restrict__ loss_sum,
+                                                        float* __restrict__ valid_cnt, int B, int h, int w, int LP, int NC,
+                                                        int ignore) {
+  __shared__ float zt[SS_LH * SS_LW * SS_MAXC];
+  __shared__ float gt[SS_LH * SS_LW * SS_MAXC];
+  __shared__ float red[4];
+  const int H = 4 * h, W = 4 * w;
+  const int b = blockIdx.z;
+  const int X0 = blockIdx.x * SS_TW, Y0 = blockIdx.y * SS_TH;
+  const int lx0 = X0 / 4 - 1, ly0 = Y0 / 4 - 1;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < SS_LH * SS_LW * SS_MAXC; i += 256) {
+    const int c = i % SS_MAXC;
+    const int t = i / SS_MAXC;
+    const int tx = t % SS_LW, ty = t / SS_LW;
+    const int lx = min(max(lx0 + tx, 0), w - 1), ly = min(max(ly0 + ty, 0), h - 1);
+    zt[i] = (c < NC) ? bf2f(logits[(((size_t)b * h + ly) * w + lx) * LP + c]) : 0.f;
+    gt[i] = 0.f;
+  }
+  __syncthreads();
+  float my_loss = 0.f, my_cnt = 0.f;
+  const int px = tid & 63;
+  const int x = X0 + px;
+#pragma unroll 1
+  for (int r = 0; r < 4; ++r) {
+    const int y = Y0 + (tid >> 6) + r * 4;
+    if (x >= W || y >= H) continue;
+    const int t = target[((size_t)b * H + y) * W + x];
+    if (t == ignore) continue;
+    float sx = (x + 0.5f) * 0.25f - 0.5f, sy = (y + 0.5f) * 0.25f - 0.5f;
+    sx = fmaxf(sx, 0.f); sy = fmaxf(sy, 0.f);
+    const int x0 = (int)sx, y0 = (int)sy;
+    const int x1 = x0 + (x0 < w - 1 ? 1 : 0), y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float lx = sx - x0, ly = sy - y0, hx = 1.f - lx, hy = 1.f - ly;
+    const int i00 = ((y0 - ly0) * SS_LW + (x0 - lx0)) * SS_MAXC;
+    const int i01 = ((y0 - ly0) * SS_LW + (x1 - lx0)) * SS_MAXC;
+    const int i10 = ((y1 - ly0) * SS_LW + (x0 - lx0)) * SS_MAXC;
+    const int i11 = ((y1 - ly0) * SS_LW + (x1 - lx0)) * SS_MAXC;
+    const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
+    float z[SS_MAXC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < SS_MAXC; ++c) {
+      if (c < NC) {
+        // same association as ATen's upsample_bilinear2d: hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11)
+        z[c] = hy * (hx * zt[i00 + c] + lx * zt[i01 + c]) + ly * (hx * zt[i10 + c] + lx * zt[i11 + c]);
+        mx = fmaxf(mx, z[c]);
+      } else {
+        z[c] = -INFINITY;
+      }
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < SS_MAXC; ++c)
+      if (c < NC) se += __expf(z[c] - mx);
+    const float lse = mx + __logf(se);
+    float zt_t = 0.f;
+#pragma unroll
+    for (int c = 0; c < SS_MAXC; ++c)
+      if (c == t) zt_t = z[c];
+    my_loss += lse - zt_t;
+    my_cnt += 1.f;
+    const float inv = 1.f / se;
+#pragma unroll
+    for (int c = 0; c < SS_MAXC; ++c) {
+      if (c < NC) {
+        const float g = __expf(z[c] - mx) * inv - (c == t ? 1.f : 0.f);
+        atomicAdd(&gt[i00 + c], w00 * g);
+        atomicAdd(&gt[i01 + c], w01 * g);
+        atomicAdd(&gt[i10 + c], w10 * g);
+        atomicAdd(&gt[i11 + c], w11 * g);
+      }
+    }
+  }
+  const float bl = block_sum_256(my_loss, red);
+  const float bc = block_sum_256(my_cnt, red);
+  if (tid == 0 && bc > 0.f) { atomicAdd(loss_sum, bl); atomicAdd(valid_cnt, bc); }
+  __syncthreads();
+  for (int i = tid; i < SS_LH * SS_LW * SS_MAXC; i += 256) {
+    const int c = i % SS_MAXC;
+    if (c >= NC) continue;
+    const float g = gt[i];
+    if (g == 0.f) continue;
+    const int t = i / SS_MAXC;
+    const int lx = lx0 + t % SS_LW, ly = ly0 + t / SS_LW;
+    if (lx < 0 || lx >= w || ly < 0 || ly >= h) continue;
+    atomicAdd(grad_acc + (((size_t)b * h + ly) * w + lx) * LP + c, g);
+  }
+}
+
+// dlogits(bf16) = grad_acc * (*gscale) / (*valid_cnt)
+__global__ __launch_bounds__(256) void scale_to_bf16_kernel(const float* __restrict__ acc, const float* __restrict__ num,
+                                                            const float* __restrict__ den, float mult,
+                                                            bf16_t* __restrict__ out, size_t n) {
+  const float s = mult * (num ? *num : 1.f) / (den ? *den : 1.f);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = f2bf(acc[i] * s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row softmax cross-entropy: logits [R][LP] bf16 (NC valid columns), labels int64; one wave per row.
+// loss_sum += sum_r (lse - z[label]);  dlogits[r][c] = (softmax - onehot) * gscale  (pad columns = 0)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const bf16_t* __restrict__ logits, const long long* __restrict__ labels,
+                                                         bf16_t* __restrict__ dlogits, float* __restrict__ loss_sum, int R,
+                                                         int NC, int LP, float gscale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const bf16_t* zr = logits + (size_t)row * LP;
+  float mx = -INFINITY;
+  for (int c = lane; c < NC; c += 64) mx = fmaxf(mx, bf2f(zr[c]));
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int c = lane; c < NC; c += 64) se += __expf(bf2f(zr[c]) - mx);
+  se = wave_sum(se);
+  const int t = (int)labels[row];
+  const float inv = 1.f / se;
+  bf16_t* dr = dlogits + (size_t)row * LP;
+  for (int c = lane; c < LP; c += 64) {
+    float g = 0.f;
+    if (c < NC) g = (__expf(bf2f(zr[c]) - mx) * inv - (c == t ? 1.f : 0.f)) * gscale;
+    dr[c] = f2bf(g);
+  }
+  if (lane == 0) atomicAdd(loss_sum, mx + __logf(se) - bf2f(zr[t]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mask head: logit[n][p] = x[n][p][:] . Wp[cls_n][:] + bp[cls_n] (rounded to bf16 like the autocast conv),
+// loss_sum += BCEwithLogits(logit, target);  dx = dlogit * Wp[cls];  dWp[cls] += sum_p dlogit x;  dbp[cls] += sum dlogit
+// x: [N][P][C] bf16 (C = 256), target uint8 [N][P].  One workgroup per ROI, one wave per position.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_predict_bce_kernel(const bf16_t* __restrict__ x, const float* __restrict__ Wp,
+                                                               const float* __restrict__ bp, const long long* __restrict__ cls,
+                                                               const uint8_t* __restrict__ target, bf16_t* __restrict__ dx,
+                                                               float* __restrict__ dWp, float* __restrict__ dbp,
+                                                               float* __restrict__ loss_sum, bf16_t* __restrict__ logit_out,
+                                                               int P, int C, float gscale) {
+  __shared__ float red[4][260];
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int k = (int)cls[n];
+  // C == 256: 4 channels per lane; weights are rounded to bf16 like the autocast conv operand
+  float wq[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) wq[e] = bf2f(f2bf(Wp[(size_t)k * C + lane * 4 + e]));
+  const float bias = bf2f(f2bf(bp[k]));
+  float dw[4] = {0.f, 0.f, 0.f, 0.f};
+  float db = 0.f, ls = 0.f;
+  for (int p = wv; p < P; p += 4) {
+    const size_t off = ((size_t)n * P + p) * C + lane * 4;
+    bf16_t xv[4];
+    *reinterpret_cast<uint2*>(xv) = *reinterpret_cast<const uint2*>(x + off);
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d += bf2f(xv[e]) * wq[e];
+    d = wave_sum(d);
+    const float z = bf2f(f2bf(d + bias));
+    const float t = (float)target[(size_t)n * P + p];
+    // max(z,0) - z*t + log1p(exp(-|z|))
+    ls += fmaxf(z, 0.f) - z * t + log1pf(__expf(-fabsf(z)));
+    const float sg = 1.f / (1.f + __expf(-z));
+    const float g = (sg - t) * gscale;
+    bf16_t ov[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ov[e] = f2bf(g * wq[e]);
+      dw[e] += g * bf2f(xv[e]);
+    }
+    *reinterpret_cast<uint2*>(dx + off) = *reinterpret_cast<const uint2*>(ov);
+    db += g;
+    if (logit_out && lane == 0) logit_out[(size_t)n * P + p] = f2bf(z);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wv][lane * 4 + e] = dw[e];
+  if (lane == 0) { red[wv][256] = db; red[wv][257] = ls; }
+  __syncthreads();
+  const int t = threadIdx.x;
+  const float s = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+  atomicAdd(dWp + (size_t)k * C + t, s);
+  if (t == 0) {
+    atomicAdd(dbp + k, red[0][256] + red[1][256] + red[2][256] + red[3][256]);
+    atomicAdd(loss_sum, red[0][257] + red[1][257] + red[2][257] + red[3][257]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Box coding helpers (fp32, same operation order as box_regression.py:43-116)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void get_deltas(const float* s, const float* t, float wx, float wy, float ww, float wh, float* d) {
+  const float sw = s[2] - s[0], sh = s[3] - s[1];
+  const float scx = s[0] + 0.5f * sw, scy = s[1] + 0.5f * sh;
+  const float tw = t[2] - t[0], th = t[3] - t[1];
+  const float tcx = t[0] + 0.5f * tw, tcy = t[1] + 0.5f * th;
+  d[0] = wx * (tcx - scx) / sw;
+  d[1] = wy * (tcy - scy) / sh;
+  d[2] = ww * logf(tw / sw);
+  d[3] = wh * logf(th / sh);
+}
+
+// RPN losses for one FPN level.  obj: [B][HW][LPo] (A valid cols), dlt: [B][HW][LPd] (4A valid cols),
+// labels int8 [B][Atot] (-1 ignore / 0 / 1, already subsampled), match int32 [B][Atot], gt fp32 [B][G][4],
+// anchors fp32 [HW*A][4] of this level.  Writes dobj/ddlt (bf16, same layouts, pads zero) and adds to loss[0:2].
+__global__ __launch_bounds__(256) void rpn_loss_level_kernel(const bf16_t* __restrict__ obj, const bf16_t* __restrict__ dlt,
+                                                             const int8_t* __restrict__ labels, const int* __restrict__ match,
+                                                             const float* __restrict__ gt, const float* __restrict__ anchors,
+                                                             bf16_t* __restrict__ dobj, bf16_t* __restrict__ ddlt,
+                                                             float* __restrict__ loss, int B, int HW, int A, int LPo, int LPd,
+                                                             int Atot, int lvl_off, int G, float gscale) {
+  __shared__ float red[4];
+  float lc = 0.f, ll = 0.f;
+  const size_t total = (size_t)B * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int b = (int)(i / HW);
+    const int pix = (int)(i - (size_t)b * HW);
+    bf16_t go_l[8], gd_l[16];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) go_l[c] = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) gd_l[c] = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (a >= A) break;
+      const int aidx = pix * A + a;
+      const int lab = labels[(size_t)b * Atot + lvl_off + aidx];
+      if (lab < 0) continue;
+      const float z = bf2f(obj[i * LPo + a]);
+      const float t = (float)lab;
+      lc += fmaxf(z, 0.f) - z * t + log1pf(__expf(-fabsf(z)));
+      go_l[a] = f2bf((1.f / (1.f + __expf(-z)) - t) * gscale);
+      if (lab == 1) {
+        const int g = match[(size_t)b * Atot + lvl_off + aidx];
+        float d[4];
+        get_deltas(anchors + (size_t)aidx * 4, gt + ((size_t)b * G + g) * 4, 1.f, 1.f, 1.f, 1.f, d);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float pr = bf2f(dlt[i * LPd + a * 4 + q]);
+          const float df = pr - d[q];
+          ll += fabsf(df);
+          gd_l[a * 4 + q] = f2bf((df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * gscale);
+        }
+      }
+    }
+    uint4* go = reinterpret_cast<uint4*>(dobj + i * LPo);
+    uint4* gd = reinterpret_cast<uint4*>(ddlt + i * LPd);
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    go[0] = *reinterpret_cast<const uint4*>(go_l);
+    for (int c = 1; c < LPo / 8; ++c) go[c] = zero4;
+    gd[0] = *reinterpret_cast<const uint4*>(gd_l);
+    gd[1] = *reinterpret_cast<const uint4*>(gd_l + 8);
+    for (int c = 2; c < LPd / 8; ++c) gd[c] = zero4;
+  }
+  const float s0 = block_sum_256(lc, red);
+  const float s1 = block_sum_256(ll, red);
+  if (threadIdx.x == 0) { atomicAdd(loss + 0, s0); atomicAdd(loss + 1, s1); }
+}
+
+// Box-head regression loss (class agnostic): pred [R][LP] bf16 (4 valid), proposals/gt fp32 [R][4],
+// labels int64 [R]; fg = 0 <= label < bg_label.  loss += sum_fg |pred - target|; dpred = sign * gscale.
+__global__ __launch_bounds__(256) void box_reg_l1_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ prop,
+                                                         const float* __restrict__ gtb, const long long* __restrict__ labels,
+                                                         bf16_t* __restrict__ dpred, float* __restrict__ loss, int R, int LP,
+                                                         int bg_label, float wx, float wy, float ww, float wh, float gscale) {
+  __shared__ float red[4];
+  float l = 0.f;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256) {
+    bf16_t* gp = dpred + (size_t)r * LP;
+    for (int c = 0; c < LP; ++c) gp[c] = 0;
+    const long long lab = labels[r];
+    if (lab < 0 || lab >= bg_label) continue;
+    float d[4];
+    get_deltas(prop + (size_t)r * 4, gtb + (size_t)r * 4, wx, wy, ww, wh, d);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float df = bf2f(pred[(size_t)r * LP + q]) - d[q];
+      l += fabsf(df);
+      gp[q] = f2bf((df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * gscale);
+    }
+  }
+  const float s = block_sum_256(l, red);
+  if (threadIdx.x == 0) atomicAdd(loss, s);
+}
+
+}  // namespace
+
+extern "C" int u2_semseg_upsample_ce(const void* logits, const void* target, float* grad_acc, float* loss_sum,
+                                     float* valid_cnt, int B, int h, int w, int LP, int NC, int ignore, void* stream) {
+  if (NC > SS_MAXC || LP < NC) return -1;
+  if (B <= 0) return 0;
+  const dim3 grid((4 * w + SS_TW - 1) / SS_TW, (4 * h + SS_TH - 1) / SS_TH, B);
+  hipLaunchKernelGGL(semseg_ce_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits,
+                     (const uint8_t*)target, grad_acc, loss_sum, valid_cnt, B, h, w, LP, NC, ignore);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_scale_to_bf16(const float* acc, const float* num, const float* den, float mult, void* out,
+                                long long n, void* stream) {
+  if (n <= 0) return 0;
+  size_t g = ((size_t)n + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(scale_to_bf16_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, acc, num, den, mult,
+                     (bf16_t*)out, (size_t)n);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_softmax_ce(const void* logits, const void* labels, void* dlogits, float* loss_sum, int R, int NC,
+                             int LP, float gscale, void* stream) {
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits,
+                     (const long long*)labels, (bf16_t*)dlogits, loss_sum, R, NC, LP, gscale);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_mask_predict_bce(const void* x, const float* Wp, const float* bp, const void* cls, const void* target,
+                                   void* dx, float* dWp, float* dbp, float* loss_sum, void* logit_out, int N, int P,
+                                   int C, float gscale, void* stream) {
+  if (C != 256) return -1;
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(mask_predict_bce_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, Wp, bp,
+                     (const long long*)cls, (const uint8_t*)target, (bf16_t*)dx, dWp, dbp, loss_sum, (bf16_t*)logit_out,
+                     P, C, gscale);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_rpn_loss_level(const void* obj, const void* dlt, const void* labels, const int* match, const float* gt,
+                                 const float* anchors, void* dobj, void* ddlt, float* loss, int B, int HW, int A, int LPo,
+                                 int LPd, int Atot, int lvl_off, int G, float gscale, void* stream) {
+  if (A > 4 || (LPo & 7) || LPd < 16 || (LPd & 7)) return -1;
+  if (B <= 0 || HW <= 0) return 0;
+  size_t g = ((size_t)B * HW + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(rpn_loss_level_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)obj,
+                     (const bf16_t*)dlt, (const int8_t*)labels, match, gt, anchors, (bf16_t*)dobj, (bf16_t*)ddlt, loss, B,
+                     HW, A, LPo, LPd, Atot, lvl_off, G, gscale);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_box_reg_l1(const void* pred, const float* prop, const float* gtb, const void* labels, void* dpred,
+                             float* loss, int R, int LP, int bg_label, float wx, float wy, float ww, float wh, float gscale,
+                             void* stream) {
+  if (R <= 0) return 0;
+  int g = (R + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(box_reg_l1_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred, prop, gtb,
+                     (const long long*)labels, (bf16_t*)dpred, loss, R, LP, bg_label, wx, wy, ww, wh, gscale);
+  U2_CHECK_LAUNCH();
+  return 0;
+}

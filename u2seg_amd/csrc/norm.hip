@@ -1,0 +1,292 @@
+// Normalisation / activation kernels over NHWC bf16 activations (HBM-bound; 16-byte accesses).
+//
+// Replaces nn.SyncBatchNorm / nn.GroupNorm / F.relu_ as selected by
+//   detectron2/layers/batch_norm.py:169-197 (get_norm) and applied in
+//   detectron2/layers/wrappers.py:131-134, backbone/resnet.py:194-210 (residual add + relu_).
+// The batch statistics themselves (sum, sum of squares per channel) are produced by the conv
+// epilogue (conv_igemm.hip) or by u2_colstats below; cross-rank reduction (SyncBN) is an RCCL
+// all-reduce of the [2][C] sums issued by the host between the stats and finalize kernels.
+#include "common.h"
+#include "u2seg_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Column reductions over an [M][C] bf16 matrix, optionally split into `slots` equal row ranges
+// (slot = image for GroupNorm).  out[slot][q][C], q = quantity index.
+// MODE 0: q0 = sum x, q1 = sum x^2
+// MODE 1: (norm backward) dz = dout * (mask>0 if relu); q0 = sum dz, q1 = sum dz*(x-mean)*invstd
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dout,
+                                                        const bf16_t* __restrict__ mask, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, float* __restrict__ out,
+                                                        int rows_per_slot, int C, int ld, int rows_per_block, int relu) {
+  __shared__ float part[2][2048];
+  const int cpr = C >> 3;
+  const int slot = blockIdx.y;
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(rows_per_slot, r_begin + rows_per_block);
+  const size_t row0 = (size_t)slot * rows_per_slot;
+  const int tid = threadIdx.x;
+
+  for (int cbase = 0; cbase < cpr; cbase += 256) {
+    const int ncol = min(256, cpr - cbase);
+    const int rows_par = 256 / ncol;
+    const int chunk = tid % ncol;
+    const int rl = tid / ncol;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+    if (rl < rows_par) {
+      const int c = (cbase + chunk) * 8;
+      float mu[8], is[8];
+      if (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mu[e] = mean[(size_t)slot * C + c + e]; is[e] = invstd[(size_t)slot * C + c + e]; }
+      }
+      for (int r = r_begin + rl; r < r_end; r += rows_par) {
+        const size_t off = (row0 + r) * ld + c;
+        bf16_t xv[8];
+        *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + off);
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float f = bf2f(xv[e]); s0[e] += f; s1[e] += f * f; }
+        } else {
+          bf16_t dv[8], mv[8];
+          *reinterpret_cast<uint4*>(dv) = *reinterpret_cast<const uint4*>(dout + off);
+          if (relu) *reinterpret_cast<uint4*>(mv) = *reinterpret_cast<const uint4*>(mask + off);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float dz = bf2f(dv[e]);
+            if (relu && !(bf2f(mv[e]) > 0.f)) dz = 0.f;
+            s0[e] += dz;
+            s1[e] += dz * (bf2f(xv[e]) - mu[e]) * is[e];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (rl < rows_par) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        part[0][rl * ncol * 8 + chunk * 8 + e] = s0[e];
+        part[1][rl * ncol * 8 + chunk * 8 + e] = s1[e];
+      }
+    }
+    __syncthreads();
+    for (int j = tid; j < ncol * 8; j += 256) {
+      float t0 = 0.f, t1 = 0.f;
+      for (int q = 0; q < rows_par; ++q) { t0 += part[0][q * ncol * 8 + j]; t1 += part[1][q * ncol * 8 + j]; }
+      atomicAdd(out + ((size_t)slot * 2 + 0) * C + cbase * 8 + j, t0);
+      atomicAdd(out + ((size_t)slot * 2 + 1) * C + cbase * 8 + j, t1);
+    }
+    __syncthreads();
+  }
+}
+
+// y = act(x * scale[slot][c] + shift[slot][c] (+ resid))
+__global__ __launch_bounds__(256) void affine_act_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const bf16_t* __restrict__ resid,
+                                                         bf16_t* __restrict__ out, int rows_per_slot, size_t M, int C, int ld,
+                                                         int relu) {
+  const int cpr = C >> 3;
+  const size_t total = M * (size_t)cpr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / cpr;
+    const int c = (int)(i - row * cpr) * 8;
+    const int slot = (int)(row / rows_per_slot);
+    const size_t off = row * ld + c;
+    bf16_t xv[8], rv[8], ov[8];
+    *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + off);
+    if (resid) *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(resid + off);
+    const float4 sc0 = *reinterpret_cast<const float4*>(scale + (size_t)slot * C + c);
+    const float4 sc1 = *reinterpret_cast<const float4*>(scale + (size_t)slot * C + c + 4);
+    const float4 sh0 = *reinterpret_cast<const float4*>(shift + (size_t)slot * C + c);
+    const float4 sh1 = *reinterpret_cast<const float4*>(shift + (size_t)slot * C + c + 4);
+    const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+    const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = bf2f(xv[e]) * sc[e] + sh[e];
+      if (resid) f += bf2f(rv[e]);
+      if (relu) f = fmaxf(f, 0.f);
+      ov[e] = f2bf(f);
+    }
+    *reinterpret_cast<uint4*>(out + off) = *reinterpret_cast<const uint4*>(ov);
+  }
+}
+
+// dz = dout * (mask > 0 if relu);  dx = k1*dz + k2*x + k3 ;  dres = dz (optional)
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ mask,
+                                                             const bf16_t* __restrict__ x, const float* __restrict__ k1,
+                                                             const float* __restrict__ k2, const float* __restrict__ k3,
+                                                             bf16_t* __restrict__ dx, bf16_t* __restrict__ dres,
+                                                             int rows_per_slot, size_t M, int C, int ld, int relu) {
+  const int cpr = C >> 3;
+  const size_t total = M * (size_t)cpr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / cpr;
+    const int c = (int)(i - row * cpr) * 8;
+    const int slot = (int)(row / rows_per_slot);
+    const size_t off = row * ld + c;
+    bf16_t dv[8], mv[8], xv[8], ov[8], zv[8];
+    *reinterpret_cast<uint4*>(dv) = *reinterpret_cast<const uint4*>(dout + off);
+    *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + off);
+    if (relu) *reinterpret_cast<uint4*>(mv) = *reinterpret_cast<const uint4*>(mask + off);
+    const float* a1 = k1 + (size_t)slot * C + c;
+    const float* a2 = k2 + (size_t)slot * C + c;
+    const float* a3 = k3 + (size_t)slot * C + c;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float dz = bf2f(dv[e]);
+      if (relu && !(bf2f(mv[e]) > 0.f)) dz = 0.f;
+      ov[e] = f2bf(a1[e] * dz + a2[e] * bf2f(xv[e]) + a3[e]);
+      zv[e] = f2bf(dz);
+    }
+    *reinterpret_cast<uint4*>(dx + off) = *reinterpret_cast<const uint4*>(ov);
+    if (dres) *reinterpret_cast<uint4*>(dres + off) = *reinterpret_cast<const uint4*>(zv);
+  }
+}
+
+// dz = dout * (out > 0)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
+                                                       bf16_t* __restrict__ dz, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    bf16_t dv[8], ov[8];
+    *reinterpret_cast<uint4*>(dv) = reinterpret_cast<const uint4*>(dout)[i];
+    *reinterpret_cast<uint4*>(ov) = reinterpret_cast<const uint4*>(out)[i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (!(bf2f(ov[e]) > 0.f)) dv[e] = 0;
+    reinterpret_cast<uint4*>(dz)[i] = *reinterpret_cast<const uint4*>(dv);
+  }
+}
+
+// BatchNorm forward finalize: sums -> mean/invstd/scale/shift, running-stat update (momentum).
+__global__ void bn_finalize_fwd_kernel(const float* __restrict__ sums, float count, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ running_mean,
+                                       float* __restrict__ running_var, float momentum, float eps, float* __restrict__ mean,
+                                       float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mu = sums[c] / count;
+  float var = sums[C + c] / count - mu * mu;
+  var = fmaxf(var, 0.f);
+  const float is = rsqrtf(var + eps);
+  mean[c] = mu;
+  invstd[c] = is;
+  const float g = gamma[c];
+  scale[c] = g * is;
+  shift[c] = beta[c] - mu * g * is;
+  if (running_mean) {
+    const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+// BatchNorm backward finalize: S1 = sum dz, S2 = sum dz*xhat -> dgamma, dbeta and the dx coefficients.
+__global__ void bn_finalize_bwd_kernel(const float* __restrict__ sums, float count, const float* __restrict__ gamma,
+                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                       const float* __restrict__ local_sums, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ k1, float* __restrict__ k2,
+                                       float* __restrict__ k3, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float s1 = sums[c], s2 = sums[C + c];
+  const float g = gamma[c], is = invstd[c], mu = mean[c];
+  dbeta[c] = local_sums[c];
+  dgamma[c] = local_sums[C + c];
+  const float a = g * is;
+  const float b = a * is * s2 / count;
+  k1[c] = a;
+  k2[c] = -b;
+  k3[c] = -a * s1 / count + b * mu;
+}
+
+int ew_grid(size_t total) {
+  size_t g = (total + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int u2_colstats(const void* x, float* out, int slots, int rows_per_slot, int C, int ld, void* stream) {
+  if ((C & 7) || (ld & 7)) return -1;
+  if (slots <= 0 || rows_per_slot <= 0) return 0;
+  int rpb = (rows_per_slot + 511) / 512;  // ~512 blocks per slot
+  if (rpb < 64) rpb = 64;
+  const dim3 grid((rows_per_slot + rpb - 1) / rpb, slots);
+  hipLaunchKernelGGL(colreduce_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, nullptr, nullptr,
+                     nullptr, nullptr, out, rows_per_slot, C, ld, rpb, 0);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_norm_bwd_reduce(const void* dout, const void* mask, const void* x, const float* mean, const float* invstd,
+                                  float* out, int slots, int rows_per_slot, int C, int ld, int relu, void* stream) {
+  if ((C & 7) || (ld & 7)) return -1;
+  if (slots <= 0 || rows_per_slot <= 0) return 0;
+  int rpb = (rows_per_slot + 511) / 512;
+  if (rpb < 64) rpb = 64;
+  const dim3 grid((rows_per_slot + rpb - 1) / rpb, slots);
+  hipLaunchKernelGGL(colreduce_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dout,
+                     (const bf16_t*)mask, mean, invstd, out, rows_per_slot, C, ld, rpb, relu);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_affine_act(const void* x, const float* scale, const float* shift, const void* resid, void* out,
+                             int slots, int rows_per_slot, int C, int ld, int relu, void* stream) {
+  if ((C & 7) || (ld & 7)) return -1;
+  const size_t M = (size_t)slots * rows_per_slot;
+  if (M == 0) return 0;
+  hipLaunchKernelGGL(affine_act_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     scale, shift, (const bf16_t*)resid, (bf16_t*)out, rows_per_slot, M, C, ld, relu);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_norm_bwd_apply(const void* dout, const void* mask, const void* x, const float* k1, const float* k2,
+                                 const float* k3, void* dx, void* dres, int slots, int rows_per_slot, int C, int ld,
+                                 int relu, void* stream) {
+  if ((C & 7) || (ld & 7)) return -1;
+  const size_t M = (size_t)slots * rows_per_slot;
+  if (M == 0) return 0;
+  hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dout, (const bf16_t*)mask, (const bf16_t*)x, k1, k2, k3, (bf16_t*)dx, (bf16_t*)dres,
+                     rows_per_slot, M, C, ld, relu);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_relu_bwd(const void* dout, const void* out, void* dz, long long numel, void* stream) {
+  if (numel & 7) return -1;
+  if (numel == 0) return 0;
+  const size_t n8 = (size_t)numel >> 3;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
+                     (const bf16_t*)out, (bf16_t*)dz, n8);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_bn_finalize_fwd(const float* sums, float count, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                                  float* invstd, float* scale, float* shift, int C, void* stream) {
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, gamma,
+                     beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_bn_finalize_bwd(const float* sums, float count, const float* gamma, const float* mean,
+                                  const float* invstd, const float* local_sums, float* dgamma, float* dbeta, float* k1,
+                                  float* k2, float* k3, int C, void* stream) {
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, gamma,
+                     mean, invstd, local_sums, dgamma, dbeta, k1, k2, k3, C);
+  U2_CHECK_LAUNCH();
+  return 0;
+}

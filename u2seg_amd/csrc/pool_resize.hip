@@ -1,0 +1,361 @@
+// Pooling / resampling kernels over NHWC bf16 activations (HBM-bound, 16-byte accesses).
+//
+// Replaces (reference file:line):
+//   F.max_pool2d 3x3 s2 p1 in the stem            detectron2/modeling/backbone/resnet.py:358
+//   nearest x2 upsample + lateral add             detectron2/modeling/backbone/fpn.py:153-155
+//   nn.Upsample(scale 2, bilinear, ac=False)      detectron2/modeling/meta_arch/semantic_seg.py:206-211
+//   image normalisation + zero pad + im2col       detectron2/modeling/meta_arch/rcnn.py:223-234 feeding the
+//                                                 7x7 s2 stem conv of backbone/resnet.py:355-357
+#include "common.h"
+#include "u2seg_hip.h"
+
+namespace {
+
+int ew_grid(size_t total) {
+  size_t g = (total + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---- max pool 3x3 stride 2 pad 1; records the winning window slot (0..8, first max wins) ----
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                          uint8_t* __restrict__ idx, int B, int H, int W, int C, int Ho,
+                                                          int Wo) {
+  const int cpr = C >> 3;
+  const size_t total = (size_t)B * Ho * Wo * cpr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    size_t p = i / cpr;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    float best[8];
+    uint8_t bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        bf16_t v[8];
+        *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * C + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = bf2f(v[e]);
+          if (f > best[e] || f != f) { best[e] = f; bi[e] = (uint8_t)(ky * 3 + kx); }
+        }
+      }
+    }
+    bf16_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(best[e]);
+    const size_t off = (((size_t)b * Ho + oy) * Wo + ox) * C + cc * 8;
+    *reinterpret_cast<uint4*>(y + off) = *reinterpret_cast<const uint4*>(o);
+    *reinterpret_cast<uint2*>(idx + off) = *reinterpret_cast<const uint2*>(bi);
+  }
+}
+
+// gather form of the backward: every input pixel visits the <=4 windows that contain it
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16_t* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                          bf16_t* __restrict__ dx, int B, int H, int W, int C, int Ho,
+                                                          int Wo) {
+  const int cpr = C >> 3;
+  const size_t total = (size_t)B * H * W * cpr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    size_t p = i / cpr;
+    const int ix = (int)(p % W); p /= W;
+    const int iy = (int)(p % H);
+    const int b = (int)(p / H);
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = 0.f;
+    // windows oy with oy*2-1 <= iy <= oy*2+1
+    const int oy_lo = iy >> 1, oy_hi = (iy + 1) >> 1;
+    const int ox_lo = ix >> 1, ox_hi = (ix + 1) >> 1;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      if (oy >= Ho) continue;
+      const int ky = iy - (oy * 2 - 1);
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        if (ox >= Wo) continue;
+        const int kx = ix - (ox * 2 - 1);
+        const uint8_t slot = (uint8_t)(ky * 3 + kx);
+        const size_t off = (((size_t)b * Ho + oy) * Wo + ox) * C + cc * 8;
+        uint8_t bi[8];
+        bf16_t dv[8];
+        *reinterpret_cast<uint2*>(bi) = *reinterpret_cast<const uint2*>(idx + off);
+        *reinterpret_cast<uint4*>(dv) = *reinterpret_cast<const uint4*>(dy + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (bi[e] == slot) g[e] += bf2f(dv[e]);
+      }
+    }
+    bf16_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(g[e]);
+    *reinterpret_cast<uint4*>(dx + i * 8) = *reinterpret_cast<const uint4*>(o);
+  }
+}
+
+// ---- FPN top-down: out = lateral + nearest_x2(top) ----
+__global__ __launch_bounds__(256) void upadd_fwd_kernel(const bf16_t* __restrict__ lat, const bf16_t* __restrict__ top,
+                                                        bf16_t* __restrict__ out, int B, int H, int W, int C) {
+  const int cpr = C >> 3;
+  const int Ht = H >> 1, Wt = W >> 1;
+  const size_t total = (size_t)B * H * W * cpr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    size_t p = i / cpr;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    bf16_t a[8], t[8], o[8];
+    *reinterpret_cast<uint4*>(a) = *reinterpret_cast<const uint4*>(lat + i * 8);
+    *reinterpret_cast<uint4*>(t) =
+        *reinterpret_cast<const uint4*>(top + (((size_t)b * Ht + (y >> 1)) * Wt + (x >> 1)) * C + cc * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(a[e]) + bf2f(t[e]));
+    *reinterpret_cast<uint4*>(out + i * 8) = *reinterpret_cast<const uint4*>(o);
+  }
+}
+
+// dtop[y][x] = sum of the 2x2 block of dout
+__global__ __launch_bounds__(256) void upadd_bwd_kernel(const bf16_t* __restrict__ dout, bf16_t* __restrict__ dtop, int B,
+                                                        int H, int W, int C) {
+  const int cpr = C >> 3;
+  const int Ht = H >> 1, Wt = W >> 1;
+  const size_t total = (size_t)B * Ht * Wt * cpr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    size_t p = i / cpr;
+    const int x = (int)(p % Wt); p /= Wt;
+    const int y = (int)(p % Ht);
+    const int b = (int)(p / Ht);
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        bf16_t v[8];
+        *reinterpret_cast<uint4*>(v) =
+            *reinterpret_cast<const uint4*>(dout + (((size_t)b * H + 2 * y + dy) * W + 2 * x + dx) * C + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] += bf2f(v[e]);
+      }
+    bf16_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(g[e]);
+    *reinterpret_cast<uint4*>(dtop + i * 8) = *reinterpret_cast<const uint4*>(o);
+  }
+}
+
+// ---- bilinear x2, align_corners=False: src = (dst + 0.5)/2 - 0.5 clamped at 0 ----
+__device__ __forceinline__ void bil2_src(int d, int n_in, int& i0, int& i1, float& l1) {
+  float s = (d + 0.5f) * 0.5f - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void bilinear2_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B,
+                                                            int H, int W, int C, int accumulate) {
+  const int cpr = C >> 3;
+  const int Ho = H * 2, Wo = W * 2;
+  const size_t total = (size_t)B * Ho * Wo * cpr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    size_t p = i / cpr;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bil2_src(oy, H, y0, y1, ly);
+    bil2_src(ox, W, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    bf16_t v00[8], v01[8], v10[8], v11[8], o[8];
+    const bf16_t* base = x + (size_t)b * H * W * C + cc * 8;
+    *reinterpret_cast<uint4*>(v00) = *reinterpret_cast<const uint4*>(base + ((size_t)y0 * W + x0) * C);
+    *reinterpret_cast<uint4*>(v01) = *reinterpret_cast<const uint4*>(base + ((size_t)y0 * W + x1) * C);
+    *reinterpret_cast<uint4*>(v10) = *reinterpret_cast<const uint4*>(base + ((size_t)y1 * W + x0) * C);
+    *reinterpret_cast<uint4*>(v11) = *reinterpret_cast<const uint4*>(base + ((size_t)y1 * W + x1) * C);
+    if (accumulate) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(out + i * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = hy * (hx * bf2f(v00[e]) + lx * bf2f(v01[e])) + ly * (hx * bf2f(v10[e]) + lx * bf2f(v11[e]));
+      if (accumulate) f += bf2f(o[e]);
+      o[e] = f2bf(f);
+    }
+    *reinterpret_cast<uint4*>(out + i * 8) = *reinterpret_cast<const uint4*>(o);
+  }
+}
+
+// gather form of the transpose: input pixel (y,x) collects from output rows {2y-1..2y+2} that reference it
+__global__ __launch_bounds__(256) void bilinear2_bwd_kernel(const bf16_t* __restrict__ dout, bf16_t* __restrict__ dx, int B,
+                                                            int H, int W, int C) {
+  const int cpr = C >> 3;
+  const int Ho = H * 2, Wo = W * 2;
+  const size_t total = (size_t)B * H * W * cpr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    size_t p = i / cpr;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = 0.f;
+    for (int oy = max(0, 2 * y - 2); oy <= min(Ho - 1, 2 * y + 2); ++oy) {
+      int y0, y1; float ly;
+      bil2_src(oy, H, y0, y1, ly);
+      float wy = 0.f;
+      if (y0 == y) wy += 1.f - ly;
+      if (y1 == y) wy += ly;
+      if (wy == 0.f) continue;
+      for (int ox = max(0, 2 * x - 2); ox <= min(Wo - 1, 2 * x + 2); ++ox) {
+        int x0, x1; float lx;
+        bil2_src(ox, W, x0, x1, lx);
+        float wx = 0.f;
+        if (x0 == x) wx += 1.f - lx;
+        if (x1 == x) wx += lx;
+        if (wx == 0.f) continue;
+        bf16_t v[8];
+        *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(dout + (((size_t)b * Ho + oy) * Wo + ox) * C + cc * 8);
+        const float wgt = wy * wx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] += wgt * bf2f(v[e]);
+      }
+    }
+    bf16_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(g[e]);
+    *reinterpret_cast<uint4*>(dx + i * 8) = *reinterpret_cast<const uint4*>(o);
+  }
+}
+
+// ---- stem im2col: uint8/float CHW image -> (x-mean)/std -> zero pad -> [B*Ho*Wo][KP] bf16 rows with
+//      K ordered (kh, kw, c) to match weights permuted to [64][7][7][3] and zero padded to KP ----
+template <typename T>
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const T* __restrict__ img, const float* __restrict__ mean,
+                                                          const float* __restrict__ stdv, bf16_t* __restrict__ col, int b,
+                                                          int h, int w, int Ho, int Wo, int KP) {
+  // one thread per (output pixel, kh): writes the 7*3 = 21 values of that filter row
+  const size_t total = (size_t)Ho * Wo * 8;
+  const float m0 = mean[0], m1 = mean[1], m2 = mean[2];
+  const float s0 = stdv[0], s1 = stdv[1], s2 = stdv[2];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int kh = (int)(i & 7);
+    const size_t p = i >> 3;
+    const int ox = (int)(p % Wo);
+    const int oy = (int)(p / Wo);
+    bf16_t* dst = col + ((size_t)b * Ho * Wo + p) * KP;
+    if (kh == 7) {  // zero the K padding [147, KP)
+      for (int k = 147; k < KP; ++k) dst[k] = 0;
+      continue;
+    }
+    const int iy = oy * 2 - 3 + kh;
+    const bool yok = iy >= 0 && iy < h;
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+      const int ix = ox * 2 - 3 + kw;
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+      if (yok && ix >= 0 && ix < w) {
+        const size_t o = (size_t)iy * w + ix;
+        v0 = ((float)img[o] - m0) / s0;
+        v1 = ((float)img[(size_t)h * w + o] - m1) / s1;
+        v2 = ((float)img[2 * (size_t)h * w + o] - m2) / s2;
+      }
+      dst[(kh * 7 + kw) * 3 + 0] = f2bf(v0);
+      dst[(kh * 7 + kw) * 3 + 1] = f2bf(v1);
+      dst[(kh * 7 + kw) * 3 + 2] = f2bf(v2);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int u2_maxpool3x3s2_fwd(const void* x, void* y, void* idx, int B, int H, int W, int C, void* stream) {
+  if (C & 7) return -1;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)B * Ho * Wo * (C >> 3);
+  if (!total) return 0;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)y, (uint8_t*)idx, B, H, W, C, Ho, Wo);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, int B, int H, int W, int C, void* stream) {
+  if (C & 7) return -1;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)B * H * W * (C >> 3);
+  if (!total) return 0;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                     (const uint8_t*)idx, (bf16_t*)dx, B, H, W, C, Ho, Wo);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_fpn_upsample_add_fwd(const void* lateral, const void* top, void* out, int B, int H, int W, int C,
+                                       void* stream) {
+  if ((C & 7) || (H & 1) || (W & 1)) return -1;
+  const size_t total = (size_t)B * H * W * (C >> 3);
+  if (!total) return 0;
+  hipLaunchKernelGGL(upadd_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)lateral,
+                     (const bf16_t*)top, (bf16_t*)out, B, H, W, C);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_fpn_upsample_add_bwd(const void* dout, void* dtop, int B, int H, int W, int C, void* stream) {
+  if ((C & 7) || (H & 1) || (W & 1)) return -1;
+  const size_t total = (size_t)B * (H / 2) * (W / 2) * (C >> 3);
+  if (!total) return 0;
+  hipLaunchKernelGGL(upadd_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
+                     (bf16_t*)dtop, B, H, W, C);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_bilinear_up2_fwd(const void* x, void* out, int B, int H, int W, int C, int accumulate, void* stream) {
+  if (C & 7) return -1;
+  const size_t total = (size_t)B * H * 2 * W * 2 * (C >> 3);
+  if (!total) return 0;
+  hipLaunchKernelGGL(bilinear2_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)out, B, H, W, C, accumulate);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_bilinear_up2_bwd(const void* dout, void* dx, int B, int H, int W, int C, void* stream) {
+  if (C & 7) return -1;
+  const size_t total = (size_t)B * H * W * (C >> 3);
+  if (!total) return 0;
+  hipLaunchKernelGGL(bilinear2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
+                     (bf16_t*)dx, B, H, W, C);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_stem_im2col(const void* img, int is_uint8, const float* mean, const float* stdv, void* col, int b, int h,
+                              int w, int Hpad, int Wpad, int KP, void* stream) {
+  if (KP < 147 || (KP & 31)) return -1;
+  const int Ho = (Hpad + 6 - 7) / 2 + 1, Wo = (Wpad + 6 - 7) / 2 + 1;
+  const size_t total = (size_t)Ho * Wo * 8;
+  if (is_uint8)
+    hipLaunchKernelGGL(stem_im2col_kernel<uint8_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)img, mean, stdv, (bf16_t*)col, b, h, w, Ho, Wo, KP);
+  else
+    hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)img, mean, stdv, (bf16_t*)col, b, h, w, Ho, Wo, KP);
+  U2_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,454 @@
+// ROI bookkeeping kernels: ROIAlign (fwd/bwd), IoU matching, box decoding, NMS, FPN level assignment.
+// Integer outputs (match indices, labels, NMS keep lists, levels) are meant to be bit-identical to the
+// CPU oracle on identical fp32 inputs, so this file must be compiled with -ffp-contract=off.
+//
+// Replaces (reference file:line):
+//   ROIAlign -> torchvision.ops.roi_align(aligned=True, sampling_ratio=0)  detectron2/layers/roi_align.py:49-65
+//      (arithmetic restated from layers/csrc/ROIAlignRotated/ROIAlignRotated_cpu.cpp:27-129,201-416 at angle 0)
+//   assign_boxes_to_levels                                                  detectron2/modeling/poolers.py:23-59
+//   pairwise_iou + Matcher                                                  structures/boxes.py:312-358, modeling/matcher.py:62-127
+//   Box2BoxTransform.apply_deltas + Boxes.clip                              modeling/box_regression.py:78-116, structures/boxes.py:172-181
+//   batched_nms (per-group NMS, suppress iff IoU > thr)                      detectron2/layers/nms.py:9-20
+#include "common.h"
+#include "u2seg_hip.h"
+
+namespace {
+
+struct RoiLevels {
+  const bf16_t* feat[4];
+  float* gfeat[4];
+  int H[4], W[4];
+  float scale[4];
+};
+
+__device__ __forceinline__ bool bil_prep(float y, float x, int H, int W, int& yl, int& xl, int& yh, int& xh, float& w1,
+                                         float& w2, float& w3, float& w4) {
+  if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return false;
+  if (y <= 0.f) y = 0.f;
+  if (x <= 0.f) x = 0.f;
+  yl = (int)y;
+  xl = (int)x;
+  if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else { yh = yl + 1; }
+  if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else { xh = xl + 1; }
+  const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+  w1 = hy * hx; w2 = hy * lx; w3 = ly * hx; w4 = ly * lx;
+  return true;
+}
+
+// rois: [R][5] fp32 (batch, x0, y0, x1, y1); level[R] int32 in [0,4); out [R][PH][PW][C] bf16
+template <bool BWD>
+__global__ __launch_bounds__(256) void roi_align_kernel(const RoiLevels lv, const float* __restrict__ rois,
+                                                        const int* __restrict__ level, bf16_t* __restrict__ out,
+                                                        const bf16_t* __restrict__ dout, int R, int C, int PH, int PW,
+                                                        float gscale) {
+  const int cpr = C >> 3;
+  const size_t total = (size_t)R * PH * PW * cpr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    size_t p = i / cpr;
+    const int pw = (int)(p % PW); p /= PW;
+    const int ph = (int)(p % PH);
+    const int r = (int)(p / PH);
+    const int l = level[r];
+    const int H = lv.H[l], W = lv.W[l];
+    const float sc = lv.scale[l];
+    const float* roi = rois + (size_t)r * 5;
+    const int b = (int)roi[0];
+    const float sw = roi[1] * sc - 0.5f, sh = roi[2] * sc - 0.5f;
+    const float ew = roi[3] * sc - 0.5f, eh = roi[4] * sc - 0.5f;
+    const float rw = ew - sw, rh = eh - sh;
+    const float bh = rh / (float)PH, bw = rw / (float)PW;
+    const int gh = (int)ceilf(rh / (float)PH), gw = (int)ceilf(rw / (float)PW);
+    const float cnt = (float)max(gh * gw, 1);
+    float acc[8];
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (BWD) {
+      bf16_t dv[8];
+      *reinterpret_cast<uint4*>(dv) = *reinterpret_cast<const uint4*>(dout + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = bf2f(dv[e]) * gscale / cnt;
+    }
+    const size_t plane = (size_t)b * H * W;
+    for (int iy = 0; iy < gh; ++iy) {
+      const float y = sh + ph * bh + (iy + 0.5f) * bh / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        const float x = sw + pw * bw + (ix + 0.5f) * bw / (float)gw;
+        int yl, xl, yh, xh;
+        float w1, w2, w3, w4;
+        if (!bil_prep(y, x, H, W, yl, xl, yh, xh, w1, w2, w3, w4)) continue;
+        const size_t o1 = (plane + (size_t)yl * W + xl) * C + cc * 8;
+        const size_t o2 = (plane + (size_t)yl * W + xh) * C + cc * 8;
+        const size_t o3 = (plane + (size_t)yh * W + xl) * C + cc * 8;
+        const size_t o4 = (plane + (size_t)yh * W + xh) * C + cc * 8;
+        if (!BWD) {
+          bf16_t v1[8], v2[8], v3[8], v4[8];
+          const bf16_t* f = lv.feat[l];
+          *reinterpret_cast<uint4*>(v1) = *reinterpret_cast<const uint4*>(f + o1);
+          *reinterpret_cast<uint4*>(v2) = *reinterpret_cast<const uint4*>(f + o2);
+          *reinterpret_cast<uint4*>(v3) = *reinterpret_cast<const uint4*>(f + o3);
+          *reinterpret_cast<uint4*>(v4) = *reinterpret_cast<const uint4*>(f + o4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            acc[e] += w1 * bf2f(v1[e]) + w2 * bf2f(v2[e]) + w3 * bf2f(v3[e]) + w4 * bf2f(v4[e]);
+        } else {
+          float* gf = lv.gfeat[l];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            atomicAdd(gf + o1 + e, w1 * g[e]);
+            atomicAdd(gf + o2 + e, w2 * g[e]);
+            atomicAdd(gf + o3 + e, w3 * g[e]);
+            atomicAdd(gf + o4 + e, w4 * g[e]);
+          }
+        }
+      }
+    }
+    if (!BWD) {
+      bf16_t o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e] / cnt);
+      *reinterpret_cast<uint4*>(out + i * 8) = *reinterpret_cast<const uint4*>(o);
+    }
+  }
+}
+
+// single-channel fp32 ROIAlign used for ground-truth mask crops (BitMasks.crop_and_resize,
+// structures/masks.py:191-218): mask uint8 [Nm][H][W], rois [R][5] (mask index, box), out uint8 = (val >= 0.5)
+__global__ __launch_bounds__(256) void mask_crop_kernel(const uint8_t* __restrict__ masks, const float* __restrict__ rois,
+                                                        uint8_t* __restrict__ out, int R, int H, int W, int P) {
+  const size_t total = (size_t)R * P * P;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    size_t p = i;
+    const int pw = (int)(p % P); p /= P;
+    const int ph = (int)(p % P);
+    const int r = (int)(p / P);
+    const float* roi = rois + (size_t)r * 5;
+    const int b = (int)roi[0];
+    const float sw = roi[1] - 0.5f, sh = roi[2] - 0.5f, ew = roi[3] - 0.5f, eh = roi[4] - 0.5f;
+    const float rw = ew - sw, rh = eh - sh;
+    const float bh = rh / (float)P, bw = rw / (float)P;
+    const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
+    const float cnt = (float)max(gh * gw, 1);
+    float acc = 0.f;
+    const uint8_t* m = masks + (size_t)b * H * W;
+    for (int iy = 0; iy < gh; ++iy) {
+      const float y = sh + ph * bh + (iy + 0.5f) * bh / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        const float x = sw + pw * bw + (ix + 0.5f) * bw / (float)gw;
+        int yl, xl, yh, xh;
+        float w1, w2, w3, w4;
+        if (!bil_prep(y, x, H, W, yl, xl, yh, xh, w1, w2, w3, w4)) continue;
+        acc += w1 * (float)m[(size_t)yl * W + xl] + w2 * (float)m[(size_t)yl * W + xh] + w3 * (float)m[(size_t)yh * W + xl] +
+               w4 * (float)m[(size_t)yh * W + xh];
+      }
+    }
+    out[i] = (acc / cnt >= 0.5f) ? 1 : 0;
+  }
+}
+
+__global__ void assign_levels_kernel(const float* __restrict__ boxes, int* __restrict__ level, int n, int min_level,
+                                     int max_level, float canonical_size, int canonical_level) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* b = boxes + (size_t)i * 4;
+  const float area = (b[2] - b[0]) * (b[3] - b[1]);
+  const float s = sqrtf(area);
+  float l = floorf((float)canonical_level + log2f(s / canonical_size + 1e-8f));
+  l = fminf(fmaxf(l, (float)min_level), (float)max_level);
+  level[i] = (int)l - min_level;
+}
+
+__device__ __forceinline__ float box_iou(const float* a, const float* b) {
+  const float aa = (a[2] - a[0]) * (a[3] - a[1]);
+  const float ab = (b[2] - b[0]) * (b[3] - b[1]);
+  const float w = fminf(a[2], b[2]) - fmaxf(a[0], b[0]);
+  const float h = fminf(a[3], b[3]) - fmaxf(a[1], b[1]);
+  const float inter = fmaxf(w, 0.f) * fmaxf(h, 0.f);
+  return inter > 0.f ? inter / (aa + ab - inter) : 0.f;
+}
+
+// pass 1: per candidate box the best gt (first maximum) and its IoU; per gt the max IoU over candidates.
+// boxes [B][n][4] (per_image_boxes) or [n][4] shared by all images (anchors); gt [B][G][4]; ngt [B].
+__global__ __launch_bounds__(256) void iou_match_kernel(const float* __restrict__ boxes, int per_image_boxes,
+                                                        const float* __restrict__ gt, const int* __restrict__ ngt,
+                                                        int* __restrict__ match, float* __restrict__ mval,
+                                                        unsigned int* __restrict__ gt_max, int n, int G) {
+  const int b = blockIdx.y;
+  const int ng = ngt[b];
+  extern __shared__ float sgt[];  // [G][4]
+  for (int i = threadIdx.x; i < ng * 4; i += 256) sgt[i] = gt[(size_t)b * G * 4 + i];
+  __syncthreads();
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float* bx = boxes + ((size_t)(per_image_boxes ? b : 0) * n + i) * 4;
+    const float a[4] = {bx[0], bx[1], bx[2], bx[3]};
+    float best = 0.f;
+    int bi = 0;
+    for (int g = 0; g < ng; ++g) {
+      const float v = box_iou(sgt + g * 4, a);
+      if (g == 0 || v > best) { best = v; bi = g; }
+      if (gt_max) atomicMax(gt_max + (size_t)b * G + g, __float_as_uint(v));
+    }
+    match[(size_t)b * n + i] = bi;
+    mval[(size_t)b * n + i] = best;
+  }
+}
+
+// pass 2: labels from thresholds (val < lo -> 0, lo <= val < hi -> -1, val >= hi -> 1) and, when
+// allow_low_quality, label 1 for every candidate whose IoU with some gt equals that gt's maximum.
+__global__ __launch_bounds__(256) void match_label_kernel(const float* __restrict__ boxes, int per_image_boxes,
+                                                          const float* __restrict__ gt, const int* __restrict__ ngt,
+                                                          const float* __restrict__ mval,
+                                                          const unsigned int* __restrict__ gt_max,
+                                                          int8_t* __restrict__ labels, int n, int G, float lo, float hi,
+                                                          int allow_low_quality) {
+  const int b = blockIdx.y;
+  const int ng = ngt[b];
+  extern __shared__ float sgt[];  // [G][4] boxes then [G] maxima
+  float* smax = sgt + G * 4;
+  for (int i = threadIdx.x; i < ng * 4; i += 256) sgt[i] = gt[(size_t)b * G * 4 + i];
+  if (allow_low_quality)
+    for (int i = threadIdx.x; i < ng; i += 256) smax[i] = __uint_as_float(gt_max[(size_t)b * G + i]);
+  __syncthreads();
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    int8_t lab;
+    if (ng == 0) {
+      lab = 0;
+    } else {
+      const float v = mval[(size_t)b * n + i];
+      lab = v < lo ? 0 : (v < hi ? -1 : 1);
+      if (allow_low_quality) {
+        const float* bx = boxes + ((size_t)(per_image_boxes ? b : 0) * n + i) * 4;
+        const float a[4] = {bx[0], bx[1], bx[2], bx[3]};
+        for (int g = 0; g < ng; ++g)
+          if (box_iou(sgt + g * 4, a) == smax[g]) lab = 1;
+      }
+    }
+    labels[(size_t)b * n + i] = lab;
+  }
+}
+
+// boxes = apply_deltas(deltas, src) then clip to (h, w) of the image `img[i]`
+__global__ void apply_deltas_kernel(const float* __restrict__ src, const float* __restrict__ deltas,
+                                    const int* __restrict__ img, const float* __restrict__ sizes, float* __restrict__ out,
+                                    int n, float wx, float wy, float ww, float wh, float clamp, int do_clip) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* s = src + (size_t)i * 4;
+  const float* d = deltas + (size_t)i * 4;
+  const float w = s[2] - s[0], h = s[3] - s[1];
+  const float cx = s[0] + 0.5f * w, cy = s[1] + 0.5f * h;
+  const float dx = d[0] / wx, dy = d[1] / wy;
+  float dw = d[2] / ww, dh = d[3] / wh;
+  dw = fminf(dw, clamp);
+  dh = fminf(dh, clamp);
+  const float pcx = dx * w + cx, pcy = dy * h + cy;
+  const float pw = expf(dw) * w, ph = expf(dh) * h;
+  float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+  if (do_clip) {
+    const int b = img ? img[i] : 0;
+    const float H = sizes[b * 2 + 0], W = sizes[b * 2 + 1];
+    x1 = fminf(fmaxf(x1, 0.f), W); x2 = fminf(fmaxf(x2, 0.f), W);
+    y1 = fminf(fmaxf(y1, 0.f), H); y2 = fminf(fmaxf(y2, 0.f), H);
+  }
+  float* o = out + (size_t)i * 4;
+  o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2;
+}
+
+// ---- NMS: suppression bit matrix, then an in-order scan (64 rows at a time) ----
+// boxes [B][n][4] sorted by descending score, group [B][n] int32, cnt [B]
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ group,
+                                                      const int* __restrict__ cnt, unsigned long long* __restrict__ mask,
+                                                      int n, int NB, float thr) {
+  const int b = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;
+  const int nb = cnt[b];
+  if (rb * 64 >= nb || cb * 64 >= nb) return;
+  __shared__ float cbx[64][4];
+  __shared__ int cgr[64];
+  const int t = threadIdx.x;
+  const int j = cb * 64 + t;
+  if (j < nb) {
+    const float* q = boxes + ((size_t)b * n + j) * 4;
+    cbx[t][0] = q[0]; cbx[t][1] = q[1]; cbx[t][2] = q[2]; cbx[t][3] = q[3];
+    cgr[t] = group[(size_t)b * n + j];
+  }
+  __syncthreads();
+  const int i = rb * 64 + t;
+  if (i >= nb) return;
+  const float* q = boxes + ((size_t)b * n + i) * 4;
+  const float a[4] = {q[0], q[1], q[2], q[3]};
+  const float aa = (a[2] - a[0]) * (a[3] - a[1]);
+  const int gi = group[(size_t)b * n + i];
+  unsigned long long bits = 0;
+  const int jn = min(64, nb - cb * 64);
+  for (int k = (rb == cb ? t + 1 : 0); k < jn; ++k) {
+    if (cgr[k] != gi) continue;
+    const float w = fmaxf(fminf(a[2], cbx[k][2]) - fmaxf(a[0], cbx[k][0]), 0.f);
+    const float h = fmaxf(fminf(a[3], cbx[k][3]) - fmaxf(a[1], cbx[k][1]), 0.f);
+    const float inter = w * h;
+    const float ab = (cbx[k][2] - cbx[k][0]) * (cbx[k][3] - cbx[k][1]);
+    if (inter / (aa + ab - inter) > thr) bits |= 1ull << k;
+  }
+  mask[((size_t)b * n + i) * NB + cb] = bits;
+}
+
+__global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ cnt,
+                                                       int* __restrict__ keep, int* __restrict__ nkeep, int n, int NB,
+                                                       int max_keep) {
+  extern __shared__ unsigned long long removed[];  // [NB]
+  __shared__ unsigned long long s_keep;
+  __shared__ int s_count;
+  const int b = blockIdx.x;
+  const int nb = cnt[b];
+  const int nblk = (nb + 63) / 64;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NB; i += 256) removed[i] = 0;
+  if (tid == 0) s_count = 0;
+  __syncthreads();
+  for (int cb = 0; cb < nblk; ++cb) {
+    if (tid < 64) {
+      const int i = cb * 64 + tid;
+      // rows of the diagonal block; bits only for columns > row, rows past nb contribute nothing
+      const unsigned long long dm = (i < nb) ? mask[((size_t)b * n + i) * NB + cb] : 0ull;
+      unsigned long long rem = removed[cb];
+      if (nb - cb * 64 < 64) rem |= ~0ull << (nb - cb * 64);
+      unsigned long long kept = 0;
+      for (int t = 0; t < 64; ++t) {
+        const unsigned long long row = __shfl(dm, t, 64);
+        if (!((rem >> t) & 1ull)) { kept |= 1ull << t; rem |= row; }
+      }
+      const int base = s_count;
+      if ((kept >> tid) & 1ull) {
+        const int pos = base + __popcll(kept & ((1ull << tid) - 1ull));
+        if (pos < max_keep) keep[(size_t)b * max_keep + pos] = cb * 64 + tid;
+      }
+      if (tid == 0) { s_keep = kept; s_count = base + __popcll(kept); }
+    }
+    __syncthreads();
+    const unsigned long long kept = s_keep;
+    if (s_count >= max_keep) break;
+    for (int wd = cb + 1 + tid; wd < nblk; wd += 256) {
+      unsigned long long acc = removed[wd];
+      unsigned long long k = kept;
+      while (k) {
+        const int t = __ffsll((long long)k) - 1;
+        k &= k - 1;
+        acc |= mask[((size_t)b * n + cb * 64 + t) * NB + wd];
+      }
+      removed[wd] = acc;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) nkeep[b] = min(s_count, max_keep);
+}
+
+}  // namespace
+
+static int ew_blocks(size_t total) {
+  size_t g = (total + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int u2_roi_align_fwd(const void* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels,
+                                const float* rois, const int* level, void* out, int R, int C, int PH, int PW, void* stream) {
+  if (nlevels < 1 || nlevels > 4 || (C & 7)) return -1;
+  if (R <= 0) return 0;
+  RoiLevels lv;
+  for (int l = 0; l < 4; ++l) {
+    const int s = l < nlevels ? l : 0;
+    lv.feat[l] = (const bf16_t*)feats[s]; lv.gfeat[l] = nullptr; lv.H[l] = Hs[s]; lv.W[l] = Ws[s]; lv.scale[l] = scales[s];
+  }
+  const size_t total = (size_t)R * PH * PW * (C >> 3);
+  hipLaunchKernelGGL(roi_align_kernel<false>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, lv, rois, level,
+                     (bf16_t*)out, nullptr, R, C, PH, PW, 1.f);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_roi_align_bwd(float* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,
+                                const float* rois, const int* level, const void* dout, int R, int C, int PH, int PW,
+                                float gscale, void* stream) {
+  if (nlevels < 1 || nlevels > 4 || (C & 7)) return -1;
+  if (R <= 0) return 0;
+  RoiLevels lv;
+  for (int l = 0; l < 4; ++l) {
+    const int s = l < nlevels ? l : 0;
+    lv.feat[l] = nullptr; lv.gfeat[l] = gfeats[s]; lv.H[l] = Hs[s]; lv.W[l] = Ws[s]; lv.scale[l] = scales[s];
+  }
+  const size_t total = (size_t)R * PH * PW * (C >> 3);
+  hipLaunchKernelGGL(roi_align_kernel<true>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, lv, rois, level,
+                     nullptr, (const bf16_t*)dout, R, C, PH, PW, gscale);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_mask_crop(const void* masks, const float* rois, void* out, int R, int H, int W, int P, void* stream) {
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL(mask_crop_kernel, dim3(ew_blocks((size_t)R * P * P)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)masks, rois, (uint8_t*)out, R, H, W, P);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_assign_levels(const float* boxes, int* level, int n, int min_level, int max_level, float canonical_size,
+                                int canonical_level, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(assign_levels_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, boxes, level, n,
+                     min_level, max_level, canonical_size, canonical_level);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_iou_match(const float* boxes, int per_image_boxes, const float* gt, const int* ngt, int* match,
+                            float* mval, unsigned int* gt_max, signed char* labels, int B, int n, int G, float lo, float hi,
+                            int allow_low_quality, void* stream) {
+  if (B <= 0 || n <= 0) return 0;
+  if (G < 1) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  int gx = (n + 255) / 256;
+  if (gx > 1024) gx = 1024;
+  const size_t lds = (size_t)G * 5 * sizeof(float);
+  if (allow_low_quality) {
+    if (!gt_max) return -1;
+    hipError_t e = hipMemsetAsync(gt_max, 0, (size_t)B * G * sizeof(unsigned int), s);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(iou_match_kernel, dim3(gx, B), dim3(256), lds, s, boxes, per_image_boxes, gt, ngt, match, mval,
+                     allow_low_quality ? gt_max : nullptr, n, G);
+  U2_CHECK_LAUNCH();
+  hipLaunchKernelGGL(match_label_kernel, dim3(gx, B), dim3(256), lds, s, boxes, per_image_boxes, gt, ngt, mval, gt_max,
+                     (int8_t*)labels, n, G, lo, hi, allow_low_quality);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_apply_deltas(const float* src, const float* deltas, const int* img, const float* sizes, float* out, int n,
+                               float wx, float wy, float ww, float wh, float clamp, int do_clip, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(apply_deltas_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, deltas, img, sizes,
+                     out, n, wx, wy, ww, wh, clamp, do_clip);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" long long u2_nms_workspace_bytes(int B, int n) {
+  const long long NB = (n + 63) / 64;
+  return (long long)B * n * NB * 8;
+}
+
+extern "C" int u2_batched_nms(const float* boxes, const int* group, const int* cnt, void* workspace, int* keep, int* nkeep,
+                              int B, int n, float thr, int max_keep, void* stream) {
+  if (B <= 0 || n <= 0) return 0;
+  const int NB = (n + 63) / 64;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(NB, NB, B), dim3(64), 0, s, boxes, group, cnt, (unsigned long long*)workspace, n,
+                     NB, thr);
+  U2_CHECK_LAUNCH();
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(256), (size_t)NB * 8, s, (const unsigned long long*)workspace, cnt, keep,
+                     nkeep, n, NB, max_keep);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
