@@ -61,7 +61,8 @@ int u2_maxpool3x3s2_fwd(const void* x, void* y, void* idx, int B, int H, int W, 
 int u2_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, int B, int H, int W, int C, void* stream);
 int u2_fpn_upsample_add_fwd(const void* lateral, const void* top, void* out, int B, int H, int W, int C, void* stream);
 int u2_fpn_upsample_add_bwd(const void* dout, void* dtop, int B, int H, int W, int C, void* stream);
-int u2_bilinear_up2_fwd(const void* x, void* out, int B, int H, int W, int C, int accumulate, void* stream);
+int u2_bilinear_up2_fwd(const void* x, const void* addend /*nullable, out = up2(x) + addend*/, void* out, int B, int H,
+                        int W, int C, void* stream);
 int u2_bilinear_up2_bwd(const void* dout, void* dx, int B, int H, int W, int C, void* stream);
 int u2_stem_im2col(const void* img, int is_uint8, const float* mean, const float* stdv, void* col, int b, int h, int w,
                    int Hpad, int Wpad, int KP, void* stream);

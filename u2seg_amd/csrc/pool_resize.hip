@@ -165,8 +165,8 @@ __device__ __forceinline__ void bil2_src(int d, int n_in, int& i0, int& i1, floa
   l1 = s - (float)i0;
 }
 
-__global__ __launch_bounds__(256) void bilinear2_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B,
-                                                            int H, int W, int C, int accumulate) {
+__global__ __launch_bounds__(256) void bilinear2_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ addend,
+                                                            bf16_t* __restrict__ out, int B, int H, int W, int C) {
   const int cpr = C >> 3;
   const int Ho = H * 2, Wo = W * 2;
   const size_t total = (size_t)B * Ho * Wo * cpr;
@@ -187,11 +187,11 @@ __global__ __launch_bounds__(256) void bilinear2_fwd_kernel(const bf16_t* __rest
     *reinterpret_cast<uint4*>(v01) = *reinterpret_cast<const uint4*>(base + ((size_t)y0 * W + x1) * C);
     *reinterpret_cast<uint4*>(v10) = *reinterpret_cast<const uint4*>(base + ((size_t)y1 * W + x0) * C);
     *reinterpret_cast<uint4*>(v11) = *reinterpret_cast<const uint4*>(base + ((size_t)y1 * W + x1) * C);
-    if (accumulate) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(out + i * 8);
+    if (addend) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(addend + i * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float f = hy * (hx * bf2f(v00[e]) + lx * bf2f(v01[e])) + ly * (hx * bf2f(v10[e]) + lx * bf2f(v11[e]));
-      if (accumulate) f += bf2f(o[e]);
+      if (addend) f += bf2f(o[e]);
       o[e] = f2bf(f);
     }
     *reinterpret_cast<uint4*>(out + i * 8) = *reinterpret_cast<const uint4*>(o);
@@ -325,12 +325,12 @@ extern "C" int u2_fpn_upsample_add_bwd(const void* dout, void* dtop, int B, int 
   return 0;
 }
 
-extern "C" int u2_bilinear_up2_fwd(const void* x, void* out, int B, int H, int W, int C, int accumulate, void* stream) {
+extern "C" int u2_bilinear_up2_fwd(const void* x, const void* addend, void* out, int B, int H, int W, int C, void* stream) {
   if (C & 7) return -1;
   const size_t total = (size_t)B * H * 2 * W * 2 * (C >> 3);
   if (!total) return 0;
   hipLaunchKernelGGL(bilinear2_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                     (bf16_t*)out, B, H, W, C, accumulate);
+                     (const bf16_t*)addend, (bf16_t*)out, B, H, W, C);
   U2_CHECK_LAUNCH();
   return 0;
 }

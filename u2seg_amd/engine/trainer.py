@@ -1,0 +1,60 @@
+"""Training step driver with the contract of detectron2's AMPTrainer.run_step (engine/train_loop.py:479-521):
+forward -> dict of losses -> sum -> backward -> gradient exchange -> per-parameter clip + SGD -> LR schedule.
+
+bf16 needs no GradScaler (the reference's fp16 path scales/unscales, train_loop.py:504-521).  One process per GPU;
+gradients are summed with RCCL all-reduce over the flat gradient arena (solver/build.py) after backward."""
+import argparse
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def launch_info():
+    """(rank, local_rank, world_size) from the torchrun environment."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+class SimpleTrainer:
+    def __init__(self, model, optimizer, scheduler=None):
+        self.model, self.optimizer, self.scheduler = model, optimizer, scheduler
+        self.iter = 0
+        self.last_losses = None
+
+    def run_step(self, batched_inputs):
+        assert self.model.training, "[SimpleTrainer] model was changed to eval mode!"
+        self.optimizer.zero_grad()
+        loss_dict = self.model(batched_inputs)
+        losses = sum(loss_dict.values())
+        losses.backward()
+        grad_scale = self.optimizer.all_reduce_grads()
+        self.optimizer.step(grad_scale)
+        if self.scheduler is not None:
+            self.scheduler.step()
+        self.iter += 1
+        self.last_losses = loss_dict
+        return loss_dict
+
+    def check_finite(self):
+        """train_loop.py:411-415 raises on non-finite total loss; call off the critical path."""
+        total = float(sum(v.detach() for v in self.last_losses.values()))
+        if not (total == total and abs(total) != float("inf")):
+            raise FloatingPointError("Loss became infinite or NaN at iteration={}!\nloss_dict = {}".format(
+                self.iter, {k: float(v) for k, v in self.last_losses.items()}))
+        return total
+
+
+def default_argument_parser():
+    """Flags of detectron2.engine.default_argument_parser (engine/defaults.py:82-144).  Deviation recorded in
+    DESIGN.md: the reference edits --eval-only to default=True; here it defaults to False so training runs."""
+    p = argparse.ArgumentParser(description="u2seg_amd training / evaluation")
+    p.add_argument("--config-file", default="configs/COCO-PanopticSegmentation/u2seg_R50_800.yaml", metavar="FILE")
+    p.add_argument("--resume", action="store_true")
+    p.add_argument("--eval-only", action="store_true")
+    p.add_argument("--eval-mode", default="hungarian_matching")
+    p.add_argument("--num-gpus", type=int, default=1)
+    p.add_argument("--num-machines", type=int, default=1)
+    p.add_argument("--machine-rank", type=int, default=0)
+    p.add_argument("--dist-url", default="tcp://127.0.0.1:29500")
+    p.add_argument("opts", default=None, nargs=argparse.REMAINDER)
+    return p

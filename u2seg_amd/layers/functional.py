@@ -1,0 +1,619 @@
+"""torch.autograd.Function wrappers over the C-ABI HIP launchers (include/u2seg_hip.h).
+
+Activations are NHWC bfloat16 tensors ``[B, H, W, C]`` whose physical channel count is a multiple
+of 32 (logical channel counts such as 28 / 3 / 12 / 801 / 4 are zero padded on the right and the
+consumer is told the logical width).  Parameters stay fp32 in the reference layout
+(``[Cout, Cin, kh, kw]``, state-dict compatible with detectron2) and are re-laid-out to the kernel
+layout (``[Cout][kh*kw][Cin]`` bf16) on the fly.
+
+Every function here launches HIP kernels; none has a CPU or ATen compute fallback.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+from torch.autograd import Function
+
+from .. import _hip
+
+BF16 = torch.bfloat16
+
+
+def ceil32(n):
+    return (n + 31) // 32 * 32
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _check_act(x):
+    assert x.is_cuda and x.dtype == BF16 and x.is_contiguous() and x.dim() == 4 and x.shape[3] % 32 == 0, (
+        "expected contiguous NHWC bf16 activation with C % 32 == 0, got %s %s" % (tuple(x.shape), x.dtype)
+    )
+
+
+# --------------------------------------------------------------------------------------------
+# weight layouts
+# --------------------------------------------------------------------------------------------
+def weight_fwd_layout(w, cp):
+    """[N, Cin, KH, KW] fp32 -> [N, KH*KW, cp] bf16 (channels zero padded to cp)."""
+    n, cin, kh, kw = w.shape
+    if cin == cp:
+        return w.detach().to(BF16).permute(0, 2, 3, 1).contiguous().view(n, kh * kw, cp)
+    out = torch.zeros((n, kh * kw, cp), dtype=BF16, device=w.device)
+    out[:, :, :cin] = w.detach().permute(0, 2, 3, 1).reshape(n, kh * kw, cin)
+    return out
+
+
+def weight_dgrad_layout(w, cp, npad):
+    """[N, Cin, KH, KW] fp32 -> [cp, KH*KW, npad] bf16 with the filter flipped in both spatial axes."""
+    n, cin, kh, kw = w.shape
+    src = w.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(cin, kh * kw, n)
+    if cin == cp and n == npad:
+        return src.to(BF16).contiguous()
+    out = torch.zeros((cp, kh * kw, npad), dtype=BF16, device=w.device)
+    out[:cin, :, :n] = src
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# convolution / linear
+# --------------------------------------------------------------------------------------------
+class _Conv2dFn(Function):
+    """F.conv2d (+bias)(+ReLU) with optional per-channel sum / sum-of-squares of the output
+    (reference: detectron2/layers/wrappers.py:127-134)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, relu, want_stats):
+        _check_act(x)
+        n, cin, kh, kw = weight.shape
+        b, h, w_, cp = x.shape
+        assert cin <= cp
+        ho = (h + 2 * pad - kh) // stride + 1
+        wo = (w_ + 2 * pad - kw) // stride + 1
+        npad = ceil32(n)
+        wk = weight_fwd_layout(weight, cp)
+        alloc = torch.zeros if npad != n else torch.empty
+        out = alloc((b, ho, wo, npad), dtype=BF16, device=x.device)
+        stats = torch.zeros((2, n), dtype=torch.float32, device=x.device) if want_stats else None
+        bias_f = bias.detach().float().contiguous() if bias is not None else None
+        _hip.call("u2_conv_igemm", x, wk, out, bias_f, stats, b, h, w_, cp, cp, ho, wo, n, npad, kh, kw, pad, pad,
+                  stride, 1, int(relu), 0, 0)
+        ctx.save_for_backward(x, weight, out if relu else None)
+        ctx.cfg = (stride, pad, relu, bias is not None)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, dout, _dstats):
+        x, weight, out = ctx.saved_tensors
+        stride, pad, relu, has_bias = ctx.cfg
+        n, cin, kh, kw = weight.shape
+        b, h, w_, cp = x.shape
+        _, ho, wo, npad = dout.shape
+        dout = dout.contiguous()
+        if relu:
+            dz = torch.empty_like(dout)
+            _hip.call("u2_relu_bwd", dout, out, dz, dout.numel())
+        else:
+            dz = dout
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wd = weight_dgrad_layout(weight, cp, npad)
+            dx = torch.empty_like(x)
+            _hip.call("u2_conv_igemm", dz, wd, dx, None, None, b, ho, wo, npad, npad, h, w_, cp, cp, kh, kw,
+                      kh - 1 - pad, kw - 1 - pad, 1, stride, 0, 0, 0)
+        if ctx.needs_input_grad[1]:
+            dwk = torch.zeros((npad, kh * kw, cp), dtype=torch.float32, device=x.device)
+            _hip.call("u2_conv_wgrad", x, dz, dwk, b, h, w_, cp, cp, ho, wo, npad, npad, kh, kw, pad, pad, stride, 0)
+            dw = dwk[:n, :, :cin].view(n, kh, kw, cin).permute(0, 3, 1, 2)
+        if has_bias and ctx.needs_input_grad[2]:
+            sums = torch.zeros((1, 2, npad), dtype=torch.float32, device=x.device)
+            _hip.call("u2_colstats", dz, sums, 1, b * ho * wo, npad, npad)
+            db = sums[0, 0, :n]
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, want_stats=False):
+    out, stats = _Conv2dFn.apply(x, weight, bias, stride, pad, relu, want_stats)
+    return (out, stats) if want_stats else out
+
+
+def linear(x2d, weight, bias=None, relu=False):
+    """nn.Linear on a [R, K] bf16 matrix (K % 32 == 0); returns [R, ceil32(N)]."""
+    r, k = x2d.shape
+    n = weight.shape[0]
+    out = conv2d(x2d.view(1, r, 1, k), weight.view(n, weight.shape[1], 1, 1), bias, 1, 0, relu)
+    return out.view(r, -1)
+
+
+class _StemConvFn(Function):
+    """(x - mean)/std, zero pad to the batch canvas, 7x7 stride-2 pad-3 conv of 3 -> 64 channels as an
+    im2col GEMM (rcnn.py:223-234 + backbone/resnet.py:355-357). Images need no gradient."""
+
+    KP = 160
+
+    @staticmethod
+    def forward(ctx, weight, images, pixel_mean, pixel_std, hpad, wpad):
+        n = weight.shape[0]
+        b = len(images)
+        ho, wo = (hpad + 6 - 7) // 2 + 1, (wpad + 6 - 7) // 2 + 1
+        kp = _StemConvFn.KP
+        col = torch.empty((b * ho * wo, kp), dtype=BF16, device=weight.device)
+        for i, img in enumerate(images):
+            assert img.is_cuda and img.is_contiguous() and img.shape[0] == 3
+            is_u8 = img.dtype == torch.uint8
+            if not is_u8:
+                assert img.dtype == torch.float32
+            _hip.call("u2_stem_im2col", img, int(is_u8), pixel_mean, pixel_std, col, i, img.shape[1], img.shape[2],
+                      hpad, wpad, kp)
+        wk = torch.zeros((n, 1, kp), dtype=BF16, device=weight.device)
+        wk[:, 0, :147] = weight.detach().permute(0, 2, 3, 1).reshape(n, 147)
+        out = torch.empty((b, ho, wo, n), dtype=BF16, device=weight.device)
+        stats = torch.zeros((2, n), dtype=torch.float32, device=weight.device)
+        m = b * ho * wo
+        _hip.call("u2_conv_igemm", col, wk, out, None, stats, 1, m, 1, kp, kp, m, 1, n, n, 1, 1, 0, 0, 1, 1, 0, 0, 0)
+        ctx.save_for_backward(col)
+        ctx.n = n
+        ctx.mark_non_differentiable(stats)
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, dout, _ds):
+        (col,) = ctx.saved_tensors
+        n, kp = ctx.n, _StemConvFn.KP
+        dout = dout.contiguous()
+        m = col.shape[0]
+        dwk = torch.zeros((n, 1, kp), dtype=torch.float32, device=col.device)
+        _hip.call("u2_conv_wgrad", col, dout, dwk, 1, m, 1, kp, kp, m, 1, n, n, 1, 1, 0, 0, 1, 0)
+        dw = dwk[:, 0, :147].view(n, 7, 7, 3).permute(0, 3, 1, 2)
+        return dw, None, None, None, None, None
+
+
+def stem_conv(weight, images, pixel_mean, pixel_std, hpad, wpad):
+    return _StemConvFn.apply(weight, images, pixel_mean, pixel_std, hpad, wpad)
+
+
+# --------------------------------------------------------------------------------------------
+# normalisation
+# --------------------------------------------------------------------------------------------
+class _BatchNormActFn(Function):
+    """Training-mode (Sync)BatchNorm (+residual)(+ReLU) on a conv output whose column statistics were
+    produced by the conv epilogue (reference: nn.SyncBatchNorm chosen at layers/batch_norm.py:187,
+    residual add + relu_ at backbone/resnet.py:204-210)."""
+
+    @staticmethod
+    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps):
+        _check_act(y)
+        b, h, w, c = y.shape
+        m = b * h * w
+        world = _world()
+        if world > 1:
+            dist.all_reduce(stats)
+        count = float(m * world)
+        mean = torch.empty(c, dtype=torch.float32, device=y.device)
+        invstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+        _hip.call("u2_bn_finalize_fwd", stats, count, gamma, beta, running_mean, running_var, momentum, eps, mean,
+                  invstd, scale, shift, c)
+        out = torch.empty_like(y)
+        _hip.call("u2_affine_act", y, scale, shift, residual, out, 1, m, c, c, int(relu))
+        ctx.save_for_backward(y, out if relu else None, gamma, mean, invstd)
+        ctx.cfg = (relu, count, world, residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, out, gamma, mean, invstd = ctx.saved_tensors
+        relu, count, world, has_res = ctx.cfg
+        b, h, w, c = y.shape
+        m = b * h * w
+        dout = dout.contiguous()
+        sums = torch.zeros((2, c), dtype=torch.float32, device=y.device)
+        _hip.call("u2_norm_bwd_reduce", dout, out, y, mean, invstd, sums, 1, m, c, c, int(relu))
+        local = sums
+        if world > 1:
+            local = sums.clone()
+            dist.all_reduce(sums)
+        coef = torch.empty((5, c), dtype=torch.float32, device=y.device)
+        _hip.call("u2_bn_finalize_bwd", sums, count, gamma, mean, invstd, local, coef[0], coef[1], coef[2], coef[3],
+                  coef[4], c)
+        dx = torch.empty_like(y)
+        dres = torch.empty_like(y) if has_res else None
+        _hip.call("u2_norm_bwd_apply", dout, out, y, coef[2], coef[3], coef[4], dx, dres, 1, m, c, c, int(relu))
+        return dx, None, coef[0], coef[1], None, None, dres, None, None, None
+
+
+def batch_norm_act(y, stats, gamma, beta, running_mean, running_var, residual=None, relu=False, momentum=0.1,
+                   eps=1e-5):
+    return _BatchNormActFn.apply(y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps)
+
+
+def affine_act(y, scale, shift, residual=None, relu=False):
+    """Inference-mode normalisation: y*scale + shift (+res)(relu); no autograd."""
+    b, h, w, c = y.shape
+    out = torch.empty_like(y)
+    _hip.call("u2_affine_act", y, scale.contiguous(), shift.contiguous(), residual, out, 1, b * h * w, c, c, int(relu))
+    return out
+
+
+class _GroupNormActFn(Function):
+    """nn.GroupNorm(G, C) (+ReLU) on NHWC (reference: layers/batch_norm.py:189, semantic_seg.py:196-205)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, groups, relu, eps):
+        _check_act(y)
+        b, h, w, c = y.shape
+        hw = h * w
+        cg = c // groups
+        stats = torch.zeros((b, 2, c), dtype=torch.float32, device=y.device)
+        _hip.call("u2_colstats", y, stats, b, hw, c, c)
+        n = float(hw * cg)
+        s = stats.view(b, 2, groups, cg).sum(-1)
+        mean_g = s[:, 0] / n
+        var_g = (s[:, 1] / n - mean_g * mean_g).clamp_(min=0)
+        invstd_g = torch.rsqrt(var_g + eps)
+        mean = mean_g.repeat_interleave(cg, dim=1).contiguous()
+        invstd = invstd_g.repeat_interleave(cg, dim=1).contiguous()
+        scale = (gamma.detach()[None] * invstd).contiguous()
+        shift = (beta.detach()[None] - mean * scale).contiguous()
+        out = torch.empty_like(y)
+        _hip.call("u2_affine_act", y, scale, shift, None, out, b, hw, c, c, int(relu))
+        ctx.save_for_backward(y, out if relu else None, gamma, mean, invstd)
+        ctx.cfg = (groups, relu)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, out, gamma, mean, invstd = ctx.saved_tensors
+        groups, relu = ctx.cfg
+        b, h, w, c = y.shape
+        hw, cg = h * w, c // groups
+        n = float(hw * cg)
+        dout = dout.contiguous()
+        sums = torch.zeros((b, 2, c), dtype=torch.float32, device=y.device)
+        _hip.call("u2_norm_bwd_reduce", dout, out, y, mean, invstd, sums, b, hw, c, c, int(relu))
+        s1, s2 = sums[:, 0], sums[:, 1]
+        g = gamma.detach()[None]
+        a = ((g * s1).view(b, groups, cg).sum(-1) / n).repeat_interleave(cg, dim=1)
+        bq = ((g * s2).view(b, groups, cg).sum(-1) / n).repeat_interleave(cg, dim=1)
+        k1 = (invstd * g).contiguous()
+        k2 = (-invstd * invstd * bq).contiguous()
+        k3 = (-invstd * a + invstd * invstd * bq * mean).contiguous()
+        dx = torch.empty_like(y)
+        _hip.call("u2_norm_bwd_apply", dout, out, y, k1, k2, k3, dx, None, b, hw, c, c, int(relu))
+        return dx, s2.sum(0), s1.sum(0), None, None, None
+
+
+def group_norm_act(y, gamma, beta, groups, relu=False, eps=1e-5):
+    return _GroupNormActFn.apply(y, gamma, beta, groups, relu, eps)
+
+
+# --------------------------------------------------------------------------------------------
+# pooling / resampling
+# --------------------------------------------------------------------------------------------
+class _MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _check_act(x)
+        b, h, w, c = x.shape
+        ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        y = torch.empty((b, ho, wo, c), dtype=BF16, device=x.device)
+        idx = torch.empty((b, ho, wo, c), dtype=torch.uint8, device=x.device)
+        _hip.call("u2_maxpool3x3s2_fwd", x, y, idx, b, h, w, c)
+        ctx.save_for_backward(idx)
+        ctx.shape = (b, h, w, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        b, h, w, c = ctx.shape
+        dx = torch.empty((b, h, w, c), dtype=BF16, device=dy.device)
+        _hip.call("u2_maxpool3x3s2_bwd", dy.contiguous(), idx, dx, b, h, w, c)
+        return dx
+
+
+def max_pool_3x3_s2(x):
+    return _MaxPoolFn.apply(x)
+
+
+class _UpsampleAddFn(Function):
+    @staticmethod
+    def forward(ctx, lateral, top):
+        _check_act(lateral)
+        b, h, w, c = lateral.shape
+        assert top.shape == (b, h // 2, w // 2, c), (lateral.shape, top.shape)
+        out = torch.empty_like(lateral)
+        _hip.call("u2_fpn_upsample_add_fwd", lateral, top.contiguous(), out, b, h, w, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        b, h, w, c = dout.shape
+        dtop = torch.empty((b, h // 2, w // 2, c), dtype=BF16, device=dout.device)
+        _hip.call("u2_fpn_upsample_add_bwd", dout, dtop, b, h, w, c)
+        return dout, dtop
+
+
+def fpn_upsample_add(lateral, top):
+    return _UpsampleAddFn.apply(lateral, top)
+
+
+class _BilinearUp2Fn(Function):
+    @staticmethod
+    def forward(ctx, x, addend):
+        _check_act(x)
+        b, h, w, c = x.shape
+        out = torch.empty((b, 2 * h, 2 * w, c), dtype=BF16, device=x.device)
+        _hip.call("u2_bilinear_up2_fwd", x, addend, out, b, h, w, c)
+        ctx.shape = (b, h, w, c)
+        ctx.has_add = addend is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        b, h, w, c = ctx.shape
+        dout = dout.contiguous()
+        dx = torch.empty((b, h, w, c), dtype=BF16, device=dout.device)
+        _hip.call("u2_bilinear_up2_bwd", dout, dx, b, h, w, c)
+        return dx, (dout if ctx.has_add else None)
+
+
+def bilinear_up2(x, addend=None):
+    return _BilinearUp2Fn.apply(x, addend)
+
+
+# --------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------
+class _SemSegLossFn(Function):
+    """bilinear x4 + cross_entropy(mean, ignore) fused (meta_arch/semantic_seg.py:255-267)."""
+
+    @staticmethod
+    def forward(ctx, logits, target_u8, num_classes, ignore):
+        _check_act(logits)
+        b, h, w, lp = logits.shape
+        assert target_u8.dtype == torch.uint8 and target_u8.shape == (b, 4 * h, 4 * w)
+        acc = torch.zeros((b, h, w, lp), dtype=torch.float32, device=logits.device)
+        sc = torch.zeros(2, dtype=torch.float32, device=logits.device)
+        _hip.call("u2_semseg_upsample_ce", logits, target_u8.contiguous(), acc, sc[0:1], sc[1:2], b, h, w, lp,
+                  num_classes, ignore)
+        ctx.save_for_backward(acc, sc)
+        return sc[0] / sc[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        acc, sc = ctx.saved_tensors
+        d = torch.empty(acc.shape, dtype=BF16, device=acc.device)
+        gg = g.detach().float().reshape(1).contiguous()
+        _hip.call("u2_scale_to_bf16", acc, gg, sc[1:2], 1.0, d, acc.numel())
+        return d, None, None, None
+
+
+def sem_seg_loss(logits, target_u8, num_classes, ignore=255):
+    return _SemSegLossFn.apply(logits, target_u8, num_classes, ignore)
+
+
+class _SoftmaxCEFn(Function):
+    """cross_entropy(scores, labels, reduction='mean') (roi_heads/fast_rcnn.py:344)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, num_classes):
+        r, lp = logits.shape
+        d = torch.empty_like(logits)
+        loss = torch.zeros(1, dtype=torch.float32, device=logits.device)
+        _hip.call("u2_softmax_ce", logits.contiguous(), labels.contiguous(), d, loss, r, num_classes, lp,
+                  1.0 / max(r, 1))
+        ctx.save_for_backward(d)
+        return loss[0] / max(r, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return d * g.to(d.dtype), None, None
+
+
+def softmax_cross_entropy(logits, labels, num_classes):
+    return _SoftmaxCEFn.apply(logits, labels, num_classes)
+
+
+class _BoxRegL1Fn(Function):
+    """smooth_l1(beta=0) = L1 over foreground rows, summed, / normalizer (roi_heads/fast_rcnn.py:424-463)."""
+
+    @staticmethod
+    def forward(ctx, pred, proposals, gt_boxes, labels, bg_label, weights, normalizer):
+        r, lp = pred.shape
+        d = torch.empty_like(pred)
+        loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+        _hip.call("u2_box_reg_l1", pred.contiguous(), proposals.contiguous(), gt_boxes.contiguous(),
+                  labels.contiguous(), d, loss, r, lp, bg_label, weights[0], weights[1], weights[2], weights[3],
+                  1.0 / normalizer)
+        ctx.save_for_backward(d)
+        return loss[0] / normalizer
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return d * g.to(d.dtype), None, None, None, None, None, None
+
+
+def box_reg_l1_loss(pred, proposals, gt_boxes, labels, bg_label, weights, normalizer):
+    return _BoxRegL1Fn.apply(pred, proposals, gt_boxes, labels, bg_label, weights, float(normalizer))
+
+
+class _MaskPredictBCEFn(Function):
+    """1x1 predictor restricted to the gt-class channel + BCE-with-logits(mean)
+    (roi_heads/mask_head.py:258 + :33-112)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, classes, target_u8):
+        n, ph, pw, c = x.shape
+        p = ph * pw
+        k = weight.shape[0]
+        w2 = weight.detach().reshape(k, c).float().contiguous()
+        dx = torch.empty_like(x)
+        dw = torch.zeros((k, c), dtype=torch.float32, device=x.device)
+        db = torch.zeros(k, dtype=torch.float32, device=x.device)
+        loss = torch.zeros(1, dtype=torch.float32, device=x.device)
+        denom = float(max(n * p, 1))
+        _hip.call("u2_mask_predict_bce", x.contiguous(), w2, bias.detach().float().contiguous(), classes.contiguous(),
+                  target_u8.contiguous(), dx, dw, db, loss, None, n, p, c, 1.0 / denom)
+        ctx.save_for_backward(dx, dw, db)
+        ctx.wshape = weight.shape
+        return loss[0] / denom
+
+    @staticmethod
+    def backward(ctx, g):
+        dx, dw, db = ctx.saved_tensors
+        return dx * g.to(dx.dtype), (dw * g).view(ctx.wshape), db * g, None, None
+
+
+def mask_predict_bce_loss(x, weight, bias, classes, target_u8):
+    return _MaskPredictBCEFn.apply(x, weight, bias, classes, target_u8)
+
+
+class _RPNLossFn(Function):
+    """RPN objectness BCE(sum) + localisation L1(sum) over all levels, both / normalizer
+    (proposal_generator/rpn.py:366-429)."""
+
+    @staticmethod
+    def forward(ctx, labels, match, gt_boxes, anchors_per_level, num_anchors, normalizer, *obj_and_deltas):
+        nl = len(anchors_per_level)
+        objs, dlts = obj_and_deltas[:nl], obj_and_deltas[nl:]
+        b, atot = labels.shape
+        g = gt_boxes.shape[1]
+        loss = torch.zeros(2, dtype=torch.float32, device=labels.device)
+        grads = []
+        off = 0
+        for lvl in range(nl):
+            o, d = objs[lvl], dlts[lvl]
+            hw = o.shape[1] * o.shape[2]
+            go, gd = torch.empty_like(o), torch.empty_like(d)
+            _hip.call("u2_rpn_loss_level", o, d, labels, match, gt_boxes, anchors_per_level[lvl], go, gd, loss, b, hw,
+                      num_anchors, o.shape[3], d.shape[3], atot, off, g, 1.0 / normalizer)
+            grads.append((go, gd))
+            off += hw * num_anchors
+        assert off == atot
+        ctx.grads = grads
+        return loss[0] / normalizer, loss[1] / normalizer
+
+    @staticmethod
+    def backward(ctx, g_cls, g_loc):
+        gos = [go * g_cls.to(go.dtype) for go, _ in ctx.grads]
+        gds = [gd * g_loc.to(gd.dtype) for _, gd in ctx.grads]
+        return (None, None, None, None, None, None, *gos, *gds)
+
+
+def rpn_losses(labels, match, gt_boxes, anchors_per_level, num_anchors, normalizer, objs, deltas):
+    return _RPNLossFn.apply(labels, match, gt_boxes, anchors_per_level, num_anchors, float(normalizer), *objs, *deltas)
+
+
+# --------------------------------------------------------------------------------------------
+# ROI ops
+# --------------------------------------------------------------------------------------------
+def _level_arrays(feats, scales):
+    import ctypes
+
+    nl = len(feats)
+    hs = (ctypes.c_int * nl)(*[f.shape[1] for f in feats])
+    ws = (ctypes.c_int * nl)(*[f.shape[2] for f in feats])
+    sc = (ctypes.c_float * nl)(*scales)
+    return hs, ws, sc
+
+
+class _ROIAlignFn(Function):
+    """Multi-level ROIAlign(aligned=True, sampling_ratio=0) (modeling/poolers.py:206-263)."""
+
+    @staticmethod
+    def forward(ctx, rois, levels, out_size, scales, grad_scale, *feats):
+        import ctypes
+
+        nl = len(feats)
+        for f in feats:
+            _check_act(f)
+        c = feats[0].shape[3]
+        r = rois.shape[0]
+        ptrs = (ctypes.c_void_p * nl)(*[f.data_ptr() for f in feats])
+        hs, ws, sc = _level_arrays(feats, scales)
+        out = torch.empty((r, out_size, out_size, c), dtype=BF16, device=rois.device)
+        _hip.call("u2_roi_align_fwd", ptrs, hs, ws, sc, nl, rois.contiguous(), levels.contiguous(), out, r, c, out_size,
+                  out_size)
+        ctx.save_for_backward(rois, levels)
+        ctx.cfg = (out_size, scales, grad_scale, [tuple(f.shape) for f in feats])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes
+
+        rois, levels = ctx.saved_tensors
+        out_size, scales, grad_scale, shapes = ctx.cfg
+        nl = len(shapes)
+        gbuf = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in shapes]
+        ptrs = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gbuf])
+        hs = (ctypes.c_int * nl)(*[s[1] for s in shapes])
+        ws = (ctypes.c_int * nl)(*[s[2] for s in shapes])
+        sc = (ctypes.c_float * nl)(*scales)
+        r, c = rois.shape[0], shapes[0][3]
+        _hip.call("u2_roi_align_bwd", ptrs, hs, ws, sc, nl, rois.contiguous(), levels.contiguous(), dout.contiguous(),
+                  r, c, out_size, out_size, float(grad_scale))
+        return (None, None, None, None, None, *[g.to(BF16) for g in gbuf])
+
+
+def roi_align(feats, rois, levels, out_size, scales, grad_scale=1.0):
+    return _ROIAlignFn.apply(rois, levels, out_size, tuple(scales), grad_scale, *feats)
+
+
+def assign_levels(boxes, min_level, max_level, canonical_size=224, canonical_level=4):
+    n = boxes.shape[0]
+    lv = torch.empty(n, dtype=torch.int32, device=boxes.device)
+    _hip.call("u2_assign_levels", boxes.contiguous(), lv, n, min_level, max_level, float(canonical_size), canonical_level)
+    return lv
+
+
+def mask_crop(masks_u8, rois, size):
+    """BitMasks.crop_and_resize (structures/masks.py:191-218): masks [Nm,H,W] uint8, rois [R,5]."""
+    r = rois.shape[0]
+    out = torch.empty((r, size, size), dtype=torch.uint8, device=rois.device)
+    _hip.call("u2_mask_crop", masks_u8.contiguous(), rois.contiguous(), out, r, masks_u8.shape[1], masks_u8.shape[2], size)
+    return out
+
+
+def iou_match(boxes, gt, ngt, lo, hi, allow_low_quality):
+    """boxes [n,4] (shared) or [B,n,4]; gt [B,G,4]; ngt [B] int32 -> match [B,n] int32, labels [B,n] int8."""
+    per_image = boxes.dim() == 3
+    b, g = gt.shape[0], gt.shape[1]
+    n = boxes.shape[-2]
+    dev = gt.device
+    match = torch.empty((b, n), dtype=torch.int32, device=dev)
+    mval = torch.empty((b, n), dtype=torch.float32, device=dev)
+    labels = torch.empty((b, n), dtype=torch.int8, device=dev)
+    gmax = torch.empty((b, g), dtype=torch.int32, device=dev) if allow_low_quality else None
+    _hip.call("u2_iou_match", boxes.contiguous(), int(per_image), gt.contiguous(), ngt.contiguous(), match, mval, gmax,
+              labels, b, n, g, float(lo), float(hi), int(allow_low_quality))
+    return match, labels, mval
+
+
+def apply_deltas(src, deltas, weights, img_idx=None, sizes=None, clamp=math.log(1000.0 / 16)):
+    n = src.shape[0]
+    out = torch.empty((n, 4), dtype=torch.float32, device=src.device)
+    do_clip = sizes is not None
+    _hip.call("u2_apply_deltas", src.contiguous(), deltas.contiguous(), img_idx, sizes, out, n, weights[0], weights[1],
+              weights[2], weights[3], float(clamp), int(do_clip))
+    return out
+
+
+def batched_nms(boxes, group, counts, thr, max_keep):
+    """boxes [B,n,4] sorted by descending score, group [B,n] int32, counts [B] int32 ->
+    keep [B,max_keep] int32 (positions in the sorted order), nkeep [B] int32."""
+    b, n = boxes.shape[0], boxes.shape[1]
+    ws_bytes = _hip.call_nostream("u2_nms_workspace_bytes", b, n)
+    ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.int64, device=boxes.device)
+    keep = torch.zeros((b, max_keep), dtype=torch.int32, device=boxes.device)
+    nkeep = torch.zeros(b, dtype=torch.int32, device=boxes.device)
+    _hip.call("u2_batched_nms", boxes.contiguous(), group.contiguous(), counts.contiguous(), ws, keep, nkeep, b, n,
+              float(thr), max_keep)
+    return keep, nkeep

@@ -1,0 +1,238 @@
+"""ResNet-50 + FPN backbone with detectron2's module tree and registry entries
+(detectron2/modeling/backbone/{backbone.py:11, resnet.py:100-694, fpn.py:17-268, build.py:7-33}).
+
+Activations are NHWC bf16; the stem consumes the raw image list directly (normalisation, padding and the
+7x7 stride-2 conv are one im2col GEMM)."""
+import math
+
+import torch
+from torch import nn
+
+from ..layers import Conv2d, ShapeSpec, c2_msra_fill, c2_xavier_fill, get_norm
+from ..layers import functional as F
+from ..utils.registry import Registry
+
+BACKBONE_REGISTRY = Registry("BACKBONE")
+
+
+class Backbone(nn.Module):
+    def __init__(self):
+        super().__init__()
+
+    @property
+    def size_divisibility(self):
+        return 0
+
+    @property
+    def padding_constraints(self):
+        return {}
+
+    def output_shape(self):
+        return {
+            name: ShapeSpec(channels=self._out_feature_channels[name], stride=self._out_feature_strides[name])
+            for name in self._out_features
+        }
+
+
+class BasicStem(nn.Module):
+    """conv7x7 s2 (3 -> 64) + norm + ReLU + maxpool 3x3 s2 (resnet.py:330-359)."""
+
+    def __init__(self, in_channels=3, out_channels=64, norm="BN"):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, 4
+        self.conv1 = Conv2d(in_channels, out_channels, kernel_size=7, stride=2, padding=3, bias=False,
+                            norm=get_norm(norm, out_channels))
+        c2_msra_fill(self.conv1)
+
+    def forward(self, images, pixel_mean, pixel_std, padded_hw):
+        conv, norm = self.conv1, self.conv1.norm
+        y, stats = F.stem_conv(conv.weight, images, pixel_mean, pixel_std, padded_hw[0], padded_hw[1])
+        if self.training and hasattr(norm, "momentum"):
+            norm.num_batches_tracked += 1
+            x = F.batch_norm_act(y, stats, norm.weight, norm.bias, norm.running_mean, norm.running_var, None, True,
+                                 norm.momentum, norm.eps)
+        else:
+            scale, shift = norm.eval_scale_shift()
+            x = F.affine_act(y, scale.float(), shift.float(), None, True)
+        return F.max_pool_3x3_s2(x)
+
+
+class BottleneckBlock(nn.Module):
+    """1x1 -> 3x3 -> 1x1 with optional projection shortcut (resnet.py:100-210)."""
+
+    def __init__(self, in_channels, out_channels, *, bottleneck_channels, stride=1, num_groups=1, norm="BN",
+                 stride_in_1x1=False, dilation=1):
+        super().__init__()
+        assert num_groups == 1 and dilation == 1, "grouped / dilated bottlenecks are not used by the U2Seg configs"
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+        if in_channels != out_channels:
+            self.shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=stride, bias=False,
+                                   norm=get_norm(norm, out_channels))
+        else:
+            self.shortcut = None
+        stride_1x1, stride_3x3 = (stride, 1) if stride_in_1x1 else (1, stride)
+        self.conv1 = Conv2d(in_channels, bottleneck_channels, kernel_size=1, stride=stride_1x1, bias=False,
+                            norm=get_norm(norm, bottleneck_channels), activation="relu")
+        self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, kernel_size=3, stride=stride_3x3, padding=1,
+                            bias=False, norm=get_norm(norm, bottleneck_channels), activation="relu")
+        self.conv3 = Conv2d(bottleneck_channels, out_channels, kernel_size=1, bias=False,
+                            norm=get_norm(norm, out_channels))
+        for layer in [self.conv1, self.conv2, self.conv3, self.shortcut]:
+            if layer is not None:
+                c2_msra_fill(layer)
+
+    def forward(self, x):
+        out = self.conv1(x)
+        out = self.conv2(out)
+        shortcut = self.shortcut(x) if self.shortcut is not None else x
+        return self.conv3(out, residual=shortcut, relu=True)  # out += shortcut; relu_
+
+
+class ResNet(Backbone):
+    def __init__(self, stem, stages, out_features=None, freeze_at=0):
+        super().__init__()
+        self.stem = stem
+        current_stride = stem.stride
+        self._out_feature_strides = {"stem": current_stride}
+        self._out_feature_channels = {"stem": stem.out_channels}
+        self.stage_names, self.stages = [], []
+        for i, blocks in enumerate(stages):
+            name = "res" + str(i + 2)
+            stage = nn.Sequential(*blocks)
+            self.add_module(name, stage)
+            self.stage_names.append(name)
+            self.stages.append(stage)
+            current_stride = int(current_stride * math.prod([k.stride for k in blocks]))
+            self._out_feature_strides[name] = current_stride
+            self._out_feature_channels[name] = blocks[-1].out_channels
+        self.stage_names = tuple(self.stage_names)
+        self._out_features = out_features if out_features is not None else [name]
+        assert freeze_at == 0, "BACKBONE.FREEZE_AT > 0 is not used by the U2Seg configs"
+
+    def forward(self, images, pixel_mean, pixel_std, padded_hw):
+        outputs = {}
+        x = self.stem(images, pixel_mean, pixel_std, padded_hw)
+        for name, stage in zip(self.stage_names, self.stages):
+            x = stage(x)
+            if name in self._out_features:
+                outputs[name] = x
+        return outputs
+
+    @staticmethod
+    def make_stage(block_class, num_blocks, *, in_channels, out_channels, stride_per_block, **kwargs):
+        blocks = []
+        for i in range(num_blocks):
+            blocks.append(block_class(in_channels=in_channels, out_channels=out_channels, stride=stride_per_block[i],
+                                      **kwargs))
+            in_channels = out_channels
+        return blocks
+
+
+@BACKBONE_REGISTRY.register()
+def build_resnet_backbone(cfg, input_shape):
+    """resnet.py:613-694 for the bottleneck depths."""
+    r = cfg.MODEL.RESNETS
+    norm = r.NORM
+    stem = BasicStem(in_channels=input_shape.channels, out_channels=r.STEM_OUT_CHANNELS, norm=norm)
+    depth = r.DEPTH
+    blocks_per_stage = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}[depth]
+    bottleneck_channels = r.NUM_GROUPS * r.WIDTH_PER_GROUP
+    in_channels, out_channels = r.STEM_OUT_CHANNELS, r.RES2_OUT_CHANNELS
+    assert r.RES5_DILATION == 1 and not any(r.DEFORM_ON_PER_STAGE)
+    stages = []
+    for idx in range(4):
+        first_stride = 1 if idx == 0 else 2
+        stages.append(ResNet.make_stage(
+            BottleneckBlock, blocks_per_stage[idx], in_channels=in_channels, out_channels=out_channels,
+            stride_per_block=[first_stride] + [1] * (blocks_per_stage[idx] - 1),
+            bottleneck_channels=bottleneck_channels, stride_in_1x1=r.STRIDE_IN_1X1, num_groups=r.NUM_GROUPS, norm=norm))
+        in_channels = out_channels
+        out_channels *= 2
+        bottleneck_channels *= 2
+    return ResNet(stem, stages, out_features=r.OUT_FEATURES, freeze_at=cfg.MODEL.BACKBONE.FREEZE_AT)
+
+
+class LastLevelMaxPool(nn.Module):
+    """p6 = max_pool2d(p5, kernel 1, stride 2) = a stride-2 subsample (fpn.py:188-200)."""
+
+    def __init__(self):
+        super().__init__()
+        self.num_levels = 1
+        self.in_feature = "p5"
+
+    def forward(self, x):
+        return [x[:, ::2, ::2, :].contiguous()]
+
+
+class FPN(Backbone):
+    def __init__(self, bottom_up, in_features, out_channels, norm="", top_block=None, fuse_type="sum"):
+        super().__init__()
+        assert fuse_type == "sum"
+        input_shapes = bottom_up.output_shape()
+        strides = [input_shapes[f].stride for f in in_features]
+        in_channels_per_feature = [input_shapes[f].channels for f in in_features]
+        lateral_convs, output_convs = [], []
+        use_bias = norm == ""
+        for idx, in_channels in enumerate(in_channels_per_feature):
+            lateral_conv = Conv2d(in_channels, out_channels, kernel_size=1, bias=use_bias, norm=get_norm(norm, out_channels))
+            output_conv = Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=use_bias,
+                                 norm=get_norm(norm, out_channels))
+            c2_xavier_fill(lateral_conv)
+            c2_xavier_fill(output_conv)
+            stage = int(math.log2(strides[idx]))
+            self.add_module("fpn_lateral{}".format(stage), lateral_conv)
+            self.add_module("fpn_output{}".format(stage), output_conv)
+            lateral_convs.append(lateral_conv)
+            output_convs.append(output_conv)
+        self.lateral_convs = lateral_convs[::-1]  # top-down order
+        self.output_convs = output_convs[::-1]
+        self.top_block = top_block
+        self.in_features = tuple(in_features)
+        self.bottom_up = bottom_up
+        self._out_feature_strides = {"p{}".format(int(math.log2(s))): s for s in strides}
+        if self.top_block is not None:
+            for s in range(stage, stage + self.top_block.num_levels):
+                self._out_feature_strides["p{}".format(s + 1)] = 2 ** (s + 1)
+        self._out_features = list(self._out_feature_strides.keys())
+        self._out_feature_channels = {k: out_channels for k in self._out_features}
+        self._size_divisibility = strides[-1]
+
+    @property
+    def size_divisibility(self):
+        return self._size_divisibility
+
+    @property
+    def padding_constraints(self):
+        return {"square_size": 0}
+
+    def forward(self, images, pixel_mean, pixel_std, padded_hw):
+        """fpn.py:126-167: lateral 1x1, nearest x2 of the coarser level + add, output 3x3."""
+        bottom_up_features = self.bottom_up(images, pixel_mean, pixel_std, padded_hw)
+        results = []
+        prev = self.lateral_convs[0](bottom_up_features[self.in_features[-1]])
+        results.append(self.output_convs[0](prev))
+        for idx, (lateral_conv, output_conv) in enumerate(zip(self.lateral_convs, self.output_convs)):
+            if idx > 0:
+                lateral = lateral_conv(bottom_up_features[self.in_features[-idx - 1]])
+                prev = F.fpn_upsample_add(lateral, prev)
+                results.insert(0, output_conv(prev))
+        if self.top_block is not None:
+            top_in = results[self._out_features.index(self.top_block.in_feature)]
+            results.extend(self.top_block(top_in))
+        assert len(self._out_features) == len(results)
+        return {f: res for f, res in zip(self._out_features, results)}
+
+
+@BACKBONE_REGISTRY.register()
+def build_resnet_fpn_backbone(cfg, input_shape):
+    bottom_up = build_resnet_backbone(cfg, input_shape)
+    return FPN(bottom_up=bottom_up, in_features=cfg.MODEL.FPN.IN_FEATURES, out_channels=cfg.MODEL.FPN.OUT_CHANNELS,
+               norm=cfg.MODEL.FPN.NORM, top_block=LastLevelMaxPool(), fuse_type=cfg.MODEL.FPN.FUSE_TYPE)
+
+
+def build_backbone(cfg, input_shape=None):
+    if input_shape is None:
+        input_shape = ShapeSpec(channels=len(cfg.MODEL.PIXEL_MEAN))
+    backbone = BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg, input_shape)
+    assert isinstance(backbone, Backbone)
+    return backbone

@@ -1,0 +1,162 @@
+"""Meta-architectures: GeneralizedRCNN and PanopticFPN with detectron2's forward contract
+(detectron2/modeling/meta_arch/rcnn.py:25-234, meta_arch/panoptic_fpn.py:21-181, meta_arch/build.py:7-25)."""
+import torch
+from torch import nn
+
+from ..config import configurable
+from ..structures import ImageList
+from ..utils.registry import Registry
+from .backbone import build_backbone
+from .inference import combine_semantic_and_instance_outputs, detector_postprocess, sem_seg_postprocess
+from .roi_heads import build_roi_heads
+from .rpn import build_proposal_generator
+from .semantic_seg import build_sem_seg_head
+
+META_ARCH_REGISTRY = Registry("META_ARCH")
+
+
+@META_ARCH_REGISTRY.register()
+class GeneralizedRCNN(nn.Module):
+    @configurable
+    def __init__(self, *, backbone, proposal_generator, roi_heads, pixel_mean, pixel_std, input_format=None, vis_period=0):
+        super().__init__()
+        self.backbone, self.proposal_generator, self.roi_heads = backbone, proposal_generator, roi_heads
+        self.input_format, self.vis_period = input_format, vis_period
+        self.register_buffer("pixel_mean", torch.tensor(pixel_mean).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(pixel_std).view(-1, 1, 1), False)
+        assert self.pixel_mean.shape == self.pixel_std.shape
+
+    @classmethod
+    def from_config(cls, cfg):
+        backbone = build_backbone(cfg)
+        return {
+            "backbone": backbone,
+            "proposal_generator": build_proposal_generator(cfg, backbone.output_shape()),
+            "roi_heads": build_roi_heads(cfg, backbone.output_shape()),
+            "input_format": cfg.INPUT.FORMAT,
+            "vis_period": cfg.VIS_PERIOD,
+            "pixel_mean": cfg.MODEL.PIXEL_MEAN,
+            "pixel_std": cfg.MODEL.PIXEL_STD,
+        }
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def _backbone_features(self, batched_inputs):
+        """rcnn.py:223-234 + backbone: the stem kernel normalises, pads and convolves in one pass."""
+        images = [x["image"].to(self.device).contiguous() for x in batched_inputs]
+        image_sizes = [(im.shape[-2], im.shape[-1]) for im in images]
+        padded_hw = ImageList.padded_size(image_sizes, self.backbone.size_divisibility)
+        mean = self.pixel_mean.view(-1).float().contiguous()
+        std = self.pixel_std.view(-1).float().contiguous()
+        return self.backbone(images, mean, std, padded_hw), image_sizes, padded_hw
+
+    def forward(self, batched_inputs):
+        if not self.training:
+            return self.inference(batched_inputs)
+        features, image_sizes, _ = self._backbone_features(batched_inputs)
+        gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+        proposals, proposal_losses = self.proposal_generator(image_sizes, features, gt_instances)
+        _, detector_losses = self.roi_heads(None, features, proposals, gt_instances)
+        losses = {}
+        losses.update(detector_losses)
+        losses.update(proposal_losses)
+        return losses
+
+    def inference(self, batched_inputs, do_postprocess=True):
+        assert not self.training
+        features, image_sizes, _ = self._backbone_features(batched_inputs)
+        proposals, _ = self.proposal_generator(image_sizes, features, None)
+        results, _ = self.roi_heads(None, features, proposals, None)
+        if not do_postprocess:
+            return results
+        out = []
+        for r, inp, size in zip(results, batched_inputs, image_sizes):
+            out.append({"instances": detector_postprocess(r, inp.get("height", size[0]), inp.get("width", size[1]))})
+        return out
+
+
+@META_ARCH_REGISTRY.register()
+class PanopticFPN(GeneralizedRCNN):
+    @configurable
+    def __init__(self, *, sem_seg_head, combine_overlap_thresh=0.5, combine_stuff_area_thresh=4096,
+                 combine_instances_score_thresh=0.5, **kwargs):
+        super().__init__(**kwargs)
+        self.sem_seg_head = sem_seg_head
+        self.combine_overlap_thresh = combine_overlap_thresh
+        self.combine_stuff_area_thresh = combine_stuff_area_thresh
+        self.combine_instances_score_thresh = combine_instances_score_thresh
+
+    @classmethod
+    def from_config(cls, cfg):
+        ret = super().from_config(cfg)
+        ret.update({
+            "combine_overlap_thresh": cfg.MODEL.PANOPTIC_FPN.COMBINE.OVERLAP_THRESH,
+            "combine_stuff_area_thresh": cfg.MODEL.PANOPTIC_FPN.COMBINE.STUFF_AREA_LIMIT,
+            "combine_instances_score_thresh": cfg.MODEL.PANOPTIC_FPN.COMBINE.INSTANCES_CONFIDENCE_THRESH,
+        })
+        ret["sem_seg_head"] = build_sem_seg_head(cfg, ret["backbone"].output_shape())
+        if cfg.MODEL.PANOPTIC_FPN.INSTANCE_LOSS_WEIGHT != 1.0:
+            w = cfg.MODEL.PANOPTIC_FPN.INSTANCE_LOSS_WEIGHT
+
+            def update_weight(x):
+                return {k: v * w for k, v in x.items()} if isinstance(x, dict) else x * w
+
+            roi_heads = ret["roi_heads"]
+            for p in roi_heads.box_predictor if isinstance(roi_heads.box_predictor, nn.ModuleList) else [roi_heads.box_predictor]:
+                p.loss_weight = update_weight(p.loss_weight)
+            roi_heads.mask_head.loss_weight = update_weight(roi_heads.mask_head.loss_weight)
+        return ret
+
+    def _sem_seg_targets(self, batched_inputs, padded_hw):
+        """ImageList.from_tensors(gt_sem_seg, size_divisibility, ignore_value) (panoptic_fpn.py:118-126) as uint8."""
+        ignore = self.sem_seg_head.ignore_value
+        b = len(batched_inputs)
+        out = torch.full((b, padded_hw[0], padded_hw[1]), ignore, dtype=torch.uint8, device=self.device)
+        for i, x in enumerate(batched_inputs):
+            t = x["sem_seg"].to(self.device)
+            out[i, : t.shape[0], : t.shape[1]] = t.to(torch.uint8)
+        return out
+
+    def forward(self, batched_inputs):
+        """panoptic_fpn.py:90-138: training returns the 10 loss entries of the cascade Panoptic-FPN."""
+        if not self.training:
+            return self.inference(batched_inputs)
+        features, image_sizes, padded_hw = self._backbone_features(batched_inputs)
+        assert "sem_seg" in batched_inputs[0]
+        gt_sem_seg = self._sem_seg_targets(batched_inputs, padded_hw)
+        _, sem_seg_losses = self.sem_seg_head(features, gt_sem_seg)
+        gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+        proposals, proposal_losses = self.proposal_generator(image_sizes, features, gt_instances)
+        _, detector_losses = self.roi_heads(None, features, proposals, gt_instances)
+        losses = sem_seg_losses
+        losses.update(proposal_losses)
+        losses.update(detector_losses)
+        return losses
+
+    def inference(self, batched_inputs, do_postprocess=True):
+        features, image_sizes, _ = self._backbone_features(batched_inputs)
+        sem_seg_results, _ = self.sem_seg_head(features, None)
+        proposals, _ = self.proposal_generator(image_sizes, features, None)
+        detector_results, _ = self.roi_heads(None, features, proposals, None)
+        if not do_postprocess:
+            return detector_results, sem_seg_results
+        processed = []
+        for sem_seg_result, detector_result, inp, image_size in zip(sem_seg_results, detector_results, batched_inputs, image_sizes):
+            height, width = inp.get("height", image_size[0]), inp.get("width", image_size[1])
+            sem_seg_r = sem_seg_postprocess(sem_seg_result, image_size, height, width)
+            detector_r = detector_postprocess(detector_result, height, width)
+            processed.append({"sem_seg": sem_seg_r, "instances": detector_r})
+            panoptic_r = combine_semantic_and_instance_outputs(
+                detector_r, sem_seg_r.argmax(dim=0), self.combine_overlap_thresh, self.combine_stuff_area_thresh,
+                self.combine_instances_score_thresh)
+            processed[-1]["panoptic_seg"] = panoptic_r
+        return processed
+
+
+def build_model(cfg):
+    """meta_arch/build.py:16-25."""
+    model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+    model.to(torch.device(cfg.MODEL.DEVICE))
+    return model

@@ -1,0 +1,31 @@
+"""Random fg/bg subsampling (detectron2/modeling/sampling.py:9-54) with an injectable permutation source.
+
+The reference draws ``torch.randperm(n, device=labels.device)``, which is not reproducible across devices; parity
+tests install a deterministic ``perm_fn`` (shared with the CPU oracle) through ``set_permutation_source``."""
+import torch
+
+_perm_fn = None
+
+
+def set_permutation_source(fn):
+    """fn(n: int, device) -> LongTensor permutation of range(n); None restores torch.randperm on the device."""
+    global _perm_fn
+    _perm_fn = fn
+
+
+def _perm(n, device):
+    if _perm_fn is not None:
+        return _perm_fn(n, device).to(device)
+    return torch.randperm(n, device=device)
+
+
+def subsample_labels(labels, num_samples, positive_fraction, bg_label):
+    positive = torch.nonzero((labels != -1) & (labels != bg_label), as_tuple=True)[0]
+    negative = torch.nonzero(labels == bg_label, as_tuple=True)[0]
+    num_pos = int(num_samples * positive_fraction)
+    num_pos = min(positive.numel(), num_pos)
+    num_neg = num_samples - num_pos
+    num_neg = min(negative.numel(), num_neg)
+    perm1 = _perm(positive.numel(), positive.device)[:num_pos]
+    perm2 = _perm(negative.numel(), negative.device)[:num_neg]
+    return positive[perm1], negative[perm2]
