@@ -93,6 +93,11 @@ int u2_roi_align_fwd(const void* const* feats, const int* Hs, const int* Ws, con
 int u2_roi_align_bwd(float* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,
                      const float* rois, const int* level, const void* dout, int R, int C, int PH, int PW, float gscale,
                      void* stream);
+/* atomics-free backward: `order` lists ROI ids grouped by (image, level), seg[b*nlevels + l] .. seg[.. + 1] is the
+ * group's range; gfeats[l] are bf16 NHWC gradient maps written in full (no pre-zeroing needed). */
+int u2_roi_align_bwd_gather(void* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,
+                            const float* rois, const int* order, const int* seg, const void* dout, int B, int C, int PH,
+                            int PW, float gscale, void* stream);
 int u2_mask_crop(const void* masks, const float* rois, void* out, int R, int H, int W, int P, void* stream);
 int u2_assign_levels(const float* boxes, int* level, int n, int min_level, int max_level, float canonical_size,
                      int canonical_level, void* stream);

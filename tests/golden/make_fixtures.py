@@ -1,0 +1,615 @@
+"""Generates the golden fixtures under tests/golden/ by running the REFERENCE itself (imported from
+/root/reference through small stand-ins for its missing third-party dependencies).  Runs only in the build
+container (the reference does not travel to the GPU box); the resulting .npz / .json files are committed.
+
+    python tests/golden/make_fixtures.py [--only NAME]
+
+Stand-ins (none of them carries hot-path arithmetic except the two torchvision ops):
+  * fvcore / iopath / yacs / omegaconf / termcolor / cv2 ... : registry, config node, weight init, smooth_l1 etc.
+  * torchvision.ops.roi_align -> the reference's own vendored C++ op ROIAlignRotated (layers/csrc/ROIAlignRotated/
+    ROIAlignRotated_cpu.cpp) compiled with torch.utils.cpp_extension and called at angle 0,
+  * torchvision.ops.nms / batched_nms -> the rule stated in the reference's tests (tests/layers/test_nms_rotated.py:44-66).
+"""
+import argparse
+import copy
+import glob
+import importlib.abc
+import importlib.machinery
+import importlib.util
+import json
+import math
+import os
+import sys
+import types
+import zlib
+from unittest import mock
+
+import numpy as np
+import torch
+import yaml
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+
+# ------------------------------------------------------------------------------------------------
+# third-party stand-ins
+# ------------------------------------------------------------------------------------------------
+class _AutoMod(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        m = mock.MagicMock(name="%s.%s" % (self.__name__, name))
+        setattr(self, name, m)
+        return m
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    ROOTS = ("fvcore", "iopath", "yacs", "omegaconf", "hydra", "torchvision", "pycocotools", "termcolor", "cv2",
+             "panopticapi", "tensorboard", "lvis", "shapely", "timm", "fairscale", "black", "pykeops", "clip", "faiss")
+
+    def find_spec(self, name, path, target=None):
+        if name.split(".")[0] in self.ROOTS:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+
+    def create_module(self, spec):
+        m = _AutoMod(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def install_standins():
+    sys.meta_path.insert(0, _Finder())
+    from torch import nn
+
+    import fvcore.common.registry as R
+
+    class Registry:
+        def __init__(self, name):
+            self._name, self._obj_map = name, {}
+
+        def _do_register(self, name, obj):
+            assert name not in self._obj_map, name
+            self._obj_map[name] = obj
+
+        def register(self, obj=None):
+            if obj is None:
+                def deco(f):
+                    self._do_register(f.__name__, f)
+                    return f
+                return deco
+            self._do_register(obj.__name__, obj)
+
+        def get(self, name):
+            return self._obj_map[name]
+
+    R.Registry = Registry
+
+    import fvcore.common.config as C
+
+    class CfgNode(dict):
+        def __init__(self, init=None, **kw):
+            super().__init__()
+            for k, v in (init or {}).items():
+                self[k] = CfgNode(v) if isinstance(v, dict) and not isinstance(v, CfgNode) else v
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+        def clone(self):
+            return copy.deepcopy(self)
+
+        def freeze(self):
+            pass
+
+        def defrost(self):
+            pass
+
+        def is_frozen(self):
+            return False
+
+        def merge_from_other(self, o):
+            for k, v in o.items():
+                if isinstance(v, dict) and k in self and isinstance(self[k], dict):
+                    self[k].merge_from_other(v)
+                else:
+                    self[k] = CfgNode(v) if isinstance(v, dict) else v
+
+        @classmethod
+        def load_yaml_with_base(cls, fn, allow_unsafe=False):
+            d = yaml.unsafe_load(open(fn))
+
+            def fix(x):
+                if isinstance(x, dict):
+                    return {k: fix(v) for k, v in x.items()}
+                if isinstance(x, str) and x.startswith("("):
+                    return eval(x)
+                return x
+
+            d = fix(d)
+            base = d.pop("_BASE_", None)
+            if base:
+                b = cls.load_yaml_with_base(os.path.join(os.path.dirname(fn), base))
+
+                def mrg(a, b_):
+                    for k, v in a.items():
+                        if isinstance(v, dict) and isinstance(b_.get(k), dict):
+                            mrg(v, b_[k])
+                        else:
+                            b_[k] = v
+
+                mrg(d, b)
+                return b
+            return d
+
+        def merge_from_other_cfg(self, o):
+            self.merge_from_other(o)
+
+        def merge_from_list(self, l):
+            for k, v in zip(l[0::2], l[1::2]):
+                d = self
+                ks = k.split(".")
+                for kk in ks[:-1]:
+                    d = d[kk]
+                d[ks[-1]] = v
+
+        def dump(self, **kw):
+            return yaml.safe_dump(json.loads(json.dumps(self)))
+
+    C.CfgNode = CfgNode
+
+    import fvcore.nn.weight_init as W
+
+    def c2_xavier_fill(m):
+        nn.init.kaiming_uniform_(m.weight, a=1)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+
+    def c2_msra_fill(m):
+        nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+
+    W.c2_xavier_fill, W.c2_msra_fill = c2_xavier_fill, c2_msra_fill
+
+    import fvcore.nn as FN
+
+    def smooth_l1_loss(input, target, beta, reduction="none"):
+        if beta < 1e-5:
+            loss = torch.abs(input - target)
+        else:
+            n = torch.abs(input - target)
+            loss = torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta)
+        if reduction == "mean":
+            return loss.mean() if loss.numel() > 0 else 0.0 * loss.sum()
+        if reduction == "sum":
+            return loss.sum()
+        return loss
+
+    FN.smooth_l1_loss = smooth_l1_loss
+
+    import fvcore.common.history_buffer as HB
+
+    class HistoryBuffer:
+        def __init__(self, max_length=1000000):
+            self._d = []
+
+        def update(self, v, it=None):
+            self._d.append((v, it))
+
+        def latest(self):
+            return self._d[-1][0]
+
+        def values(self):
+            return self._d
+
+    HB.HistoryBuffer = HistoryBuffer
+
+    import iopath.common.file_io as IO
+
+    class PathManagerBase:
+        def register_handler(self, *a, **k):
+            pass
+
+        def open(self, p, mode="r", **k):
+            return open(p, mode)
+
+        def isfile(self, p):
+            return os.path.isfile(p)
+
+        def exists(self, p):
+            return os.path.exists(p)
+
+        def get_local_path(self, p, **k):
+            return p
+
+    class PathHandler:
+        pass
+
+    IO.PathManager, IO.PathHandler = PathManagerBase, PathHandler
+    IO.HTTPURLHandler = IO.OneDrivePathHandler = PathHandler
+
+    import fvcore.transforms.transform as FT
+
+    class Transform:
+        def _set_attributes(self, params=None):
+            if params:
+                for k, v in params.items():
+                    if k != "self" and not k.startswith("_"):
+                        setattr(self, k, v)
+
+        @classmethod
+        def register_type(cls, *a, **k):
+            return lambda f: f
+
+    class TransformList(Transform):
+        def __init__(self, t):
+            self.transforms = t
+
+    names = ["Transform", "TransformList", "BlendTransform", "CropTransform", "PadTransform", "GridSampleTransform",
+             "HFlipTransform", "VFlipTransform", "NoOpTransform", "ScaleTransform"]
+    for n in names:
+        setattr(FT, n, {"Transform": Transform, "TransformList": TransformList}.get(n) or type(n, (Transform,), {}))
+    FT.__all__ = names
+    import fvcore.transforms as FTT
+
+    FTT.HFlipTransform, FTT.NoOpTransform = FT.HFlipTransform, FT.NoOpTransform
+
+    import fvcore.common.checkpoint as CK
+
+    class Checkpointer:
+        def __init__(self, model, save_dir="", **kw):
+            self.model = model
+
+    CK.Checkpointer = Checkpointer
+    CK.PeriodicCheckpointer = type("PeriodicCheckpointer", (), {})
+    import fvcore.common.param_scheduler as PS
+
+    class ParamScheduler:
+        pass
+
+    for n in ["ParamScheduler", "CosineParamScheduler", "MultiStepParamScheduler", "StepWithFixedGammaParamScheduler",
+              "CompositeParamScheduler", "ConstantParamScheduler", "LinearParamScheduler"]:
+        setattr(PS, n, type(n, (ParamScheduler,), {}))
+
+    import torchvision
+    import torchvision.ops as OPS
+    import torchvision.ops.boxes as BOX
+
+    torchvision.__version__ = "0.25.0"
+
+    def nms(boxes, scores, thr):
+        """torchvision rule as stated in the reference tests (test_nms_rotated.py:44-66): survivors have iou <= thr."""
+        if boxes.numel() == 0:
+            return torch.empty((0,), dtype=torch.int64)
+        order = scores.argsort(descending=True, stable=True)
+        b = boxes[order]
+        n = len(b)
+        area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        keep, sup = [], torch.zeros(n, dtype=torch.bool)
+        for i in range(n):
+            if sup[i]:
+                continue
+            keep.append(i)
+            xx1, yy1 = torch.maximum(b[i, 0], b[i + 1:, 0]), torch.maximum(b[i, 1], b[i + 1:, 1])
+            xx2, yy2 = torch.minimum(b[i, 2], b[i + 1:, 2]), torch.minimum(b[i, 3], b[i + 1:, 3])
+            inter = (xx2 - xx1).clamp(min=0) * (yy2 - yy1).clamp(min=0)
+            sup[i + 1:] |= inter / (area[i] + area[i + 1:] - inter) > thr
+        return order[torch.tensor(keep, dtype=torch.int64)]
+
+    def batched_nms(boxes, scores, idxs, thr):
+        """per-group NMS on un-offset boxes (torchvision's _batched_nms_vanilla), merged by descending score."""
+        if boxes.numel() == 0:
+            return torch.empty((0,), dtype=torch.int64)
+        keep_mask = torch.zeros_like(scores, dtype=torch.bool)
+        for cid in torch.unique(idxs):
+            cur = torch.where(idxs == cid)[0]
+            keep_mask[cur[nms(boxes[cur], scores[cur], thr)]] = True
+        kept = torch.where(keep_mask)[0]
+        return kept[scores[kept].argsort(descending=True, stable=True)]
+
+    def box_iou(b1, b2):
+        """torchvision.ops.box_iou: inter / (area1 + area2 - inter)."""
+        a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+        a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+        wh = (torch.min(b1[:, None, 2:], b2[:, 2:]) - torch.max(b1[:, None, :2], b2[:, :2])).clamp(min=0)
+        inter = wh[..., 0] * wh[..., 1]
+        return inter / (a1[:, None] + a2 - inter)
+
+    OPS.nms, BOX.batched_nms, BOX.nms, OPS.boxes, OPS.box_iou, BOX.box_iou = nms, batched_nms, nms, BOX, box_iou, box_iou
+
+    class RoIPool(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    OPS.RoIPool = RoIPool
+    OPS.roi_align = None  # patched after detectron2._C is built
+    import termcolor
+
+    termcolor.colored = lambda s, *a, **k: s
+    import cv2
+    import fvcore
+    import iopath
+
+    cv2.__version__, fvcore.__version__, iopath.__version__ = "4.8.0", "0.1.5", "0.1.9"
+    import omegaconf
+
+    omegaconf.DictConfig = type("DictConfig", (dict,), {})
+    omegaconf.ListConfig = type("ListConfig", (list,), {})
+
+
+def import_reference():
+    """Imports detectron2 from /root/reference with roi_align served by the vendored C++ ROIAlignRotated at 0 deg."""
+    install_standins()
+    sys.path.insert(0, REF)
+    from torch.utils.cpp_extension import load
+
+    csrc = os.path.join(REF, "detectron2", "layers", "csrc")
+    srcs = [os.path.join(csrc, "vision.cpp")] + [s for s in glob.glob(os.path.join(csrc, "**", "*.cpp"), recursive=True)
+                                                  if not s.endswith("vision.cpp")]
+    ext = load(name="_C", sources=srcs, extra_include_paths=[csrc], build_directory=_build_dir(), verbose=False)
+    sys.modules["detectron2._C"] = ext
+    import detectron2  # noqa: F401
+    from detectron2.layers.roi_align_rotated import roi_align_rotated
+    RA = sys.modules["detectron2.layers.roi_align"]
+
+    def roi_align(input, rois, output_size, spatial_scale=1.0, sampling_ratio=-1, aligned=False):
+        assert aligned, "only the aligned=True form is on the U2Seg path"
+        if isinstance(output_size, int):
+            output_size = (output_size, output_size)
+        # (b, x0, y0, x1, y1) -> (b, cx, cy, w, h, 0): the rotated op centres at (cx, cy)*scale - 0.5 like aligned ROIAlign
+        r = torch.stack([rois[:, 0], (rois[:, 1] + rois[:, 3]) / 2, (rois[:, 2] + rois[:, 4]) / 2, rois[:, 3] - rois[:, 1],
+                         rois[:, 4] - rois[:, 2], torch.zeros_like(rois[:, 0])], dim=1)
+        return roi_align_rotated(input, r, output_size, spatial_scale, max(sampling_ratio, 0))
+
+    RA.roi_align = roi_align
+    return roi_align
+
+
+def _build_dir():
+    d = "/tmp/u2seg_ref_ext"
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+# ------------------------------------------------------------------------------------------------
+def det_fill(name, tensor):
+    """Deterministic, name-keyed parameter fill shared by the fixture generator and the tests."""
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    if name.endswith("running_var"):
+        return 0.5 + torch.rand(tensor.shape, generator=g)
+    if name.endswith("running_mean"):
+        return 0.1 * torch.randn(tensor.shape, generator=g)
+    if name.endswith("num_batches_tracked"):
+        return torch.zeros_like(tensor)
+    if tensor.dim() == 1:
+        if name.endswith(".bias"):
+            return 0.05 * torch.randn(tensor.shape, generator=g)
+        return 1.0 + 0.1 * torch.randn(tensor.shape, generator=g)  # norm weights
+    fan_in = tensor[0].numel()
+    return torch.randn(tensor.shape, generator=g) * (1.0 / math.sqrt(fan_in))
+
+
+def to_ref_batch(batch):
+    from detectron2.structures import BitMasks, Boxes, Instances
+
+    out = []
+    for x in batch:
+        inst = Instances(x["instances"].image_size)
+        inst.gt_boxes = Boxes(x["instances"].gt_boxes.tensor.clone())
+        inst.gt_classes = x["instances"].gt_classes.clone()
+        inst.gt_masks = BitMasks(x["instances"].gt_masks.tensor.clone())
+        out.append({"image": x["image"], "instances": inst, "sem_seg": x["sem_seg"], "height": x["height"], "width": x["width"]})
+    return out
+
+
+def gen_model_fixture(name, hw, nimg, seed):
+    os.environ.setdefault("CLUSTER_NUM", "800")
+    from detectron2.config import get_cfg
+    from detectron2.modeling import build_model
+    from detectron2.utils.events import EventStorage
+
+    from u2seg_amd.data import make_synthetic_batch
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(REF, "configs/COCO-PanopticSegmentation/u2seg_R50_800.yaml"))
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.MODEL.WEIGHTS = ""
+    model = build_model(cfg)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            v.copy_(det_fill(k, v))
+    model.train()
+    batch = to_ref_batch(make_synthetic_batch(nimg, height=hw[0], width=hw[1]))
+    torch.manual_seed(seed)
+    with EventStorage():
+        losses = model(batch)
+        total = sum(losses.values())
+        total.backward()
+    grads = {}
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            grads[k] = float(p.grad.double().norm())
+    picked = ["backbone.bottom_up.stem.conv1.weight", "backbone.bottom_up.res2.0.conv1.weight",
+              "backbone.bottom_up.res3.0.shortcut.weight", "backbone.bottom_up.res4.5.conv3.norm.weight",
+              "backbone.bottom_up.res5.2.conv2.weight", "backbone.fpn_lateral3.weight", "backbone.fpn_output2.weight",
+              "proposal_generator.rpn_head.conv.weight", "proposal_generator.rpn_head.anchor_deltas.bias",
+              "roi_heads.box_head.0.fc1.weight", "roi_heads.box_head.2.fc2.bias", "roi_heads.box_predictor.1.cls_score.weight",
+              "roi_heads.box_predictor.0.bbox_pred.weight", "roi_heads.mask_head.mask_fcn1.weight",
+              "roi_heads.mask_head.deconv.weight", "roi_heads.mask_head.predictor.weight", "sem_seg_head.p2.0.weight",
+              "sem_seg_head.p5.4.norm.weight", "sem_seg_head.predictor.weight"]
+    out = {"config": "u2seg_R50_800.yaml", "image_hw": list(hw), "num_images": nimg, "seed": seed,
+           "weights": "tests/golden/make_fixtures.py:det_fill", "data": "u2seg_amd.data.make_synthetic_batch(start_index=0)",
+           "losses": {k: float(v) for k, v in losses.items()}, "num_params": sum(p.numel() for p in model.parameters()),
+           "grad_norms": {k: grads[k] for k in picked}, "num_state_entries": len(sd),
+           "state_dict_keys_crc32": zlib.crc32("\n".join(sd.keys()).encode())}
+    json.dump(out, open(os.path.join(HERE, name + ".json"), "w"), indent=1)
+    print("wrote", name, out["losses"])
+
+
+def gen_op_fixtures(roi_align_ref):
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    # --- ROIAlign fwd/bwd from the vendored C++ op ------------------------------------------------
+    feat = torch.randn((2, 6, 20, 24), generator=g)
+    rois = torch.tensor([[0, 4.0, 4.0, 60.0, 50.0], [1, -10.0, -8.0, 30.0, 20.0], [0, 0.0, 0.0, 96.0, 80.0],
+                         [1, 50.2, 33.7, 50.9, 34.1], [0, 90.0, 70.0, 120.0, 100.0], [1, 10.0, 10.0, 10.0, 10.0],
+                         [0, 13.3, 7.7, 77.1, 41.9], [1, 200.0, 200.0, 260.0, 240.0]])
+    for ps, tag in ((7, "p7"), (14, "p14")):
+        f = feat.clone().requires_grad_(True)
+        y = roi_align_ref(f, rois, ps, 0.25, 0, True)
+        w = torch.randn(y.shape, generator=g)
+        (y * w).sum().backward()
+        out["roi_%s_out" % tag], out["roi_%s_w" % tag], out["roi_%s_grad" % tag] = y.detach().numpy(), w.numpy(), f.grad.numpy()
+    out["roi_feat"], out["roi_rois"] = feat.numpy(), rois.numpy()
+    # reference unit-test known answer (tests/layers/test_roi_align.py:14-47)
+    ramp = torch.arange(25, dtype=torch.float32).reshape(1, 1, 5, 5)
+    out["roi_ramp_out"] = roi_align_ref(ramp, torch.tensor([[0, 1.0, 1.0, 3.0, 3.0]]), 4, 1.0, 0, True).numpy()
+    out["roi_ramp_expected"] = np.array([[4.5, 5.0, 5.5, 6.0], [7.0, 7.5, 8.0, 8.5], [9.5, 10.0, 10.5, 11.0],
+                                         [12.0, 12.5, 13.0, 13.5]], dtype=np.float32)
+    # mask crop (BitMasks.crop_and_resize, structures/masks.py:191-218)
+    from detectron2.structures import BitMasks
+
+    masks = torch.rand((5, 40, 52), generator=g) > 0.45
+    mboxes = torch.tensor([[2.0, 3.0, 30.0, 33.0], [0.0, 0.0, 52.0, 40.0], [10.5, 7.25, 20.75, 30.5], [40.0, 30.0, 60.0, 45.0],
+                           [5.0, 5.0, 6.0, 6.5]])
+    out["crop_masks"], out["crop_boxes"] = masks.numpy(), mboxes.numpy()
+    out["crop_out"] = BitMasks(masks).crop_and_resize(mboxes, 28).numpy()
+    # --- Matcher ----------------------------------------------------------------------------------
+    from detectron2.modeling.matcher import Matcher
+    from detectron2.structures import Boxes, pairwise_iou
+
+    gtb = torch.tensor([[10.0, 10, 60, 70], [30, 20, 100, 90], [100, 100, 140, 130], [0, 0, 20, 20]])
+    cand = torch.rand((300, 2), generator=g) * 120
+    cand = torch.cat([cand, cand + 5 + torch.rand((300, 2), generator=g) * 60], dim=1)
+    cand = torch.cat([cand, gtb[:2]], dim=0)
+    iou = pairwise_iou(Boxes(gtb), Boxes(cand))
+    m1 = Matcher([0.3, 0.7], [0, -1, 1], allow_low_quality_matches=True)(iou)
+    m2 = Matcher([0.5], [0, 1], allow_low_quality_matches=False)(iou)
+    out.update(match_gt=gtb.numpy(), match_cand=cand.numpy(), match_iou=iou.numpy(), match_rpn_idx=m1[0].numpy(),
+               match_rpn_lab=m1[1].numpy(), match_roi_idx=m2[0].numpy(), match_roi_lab=m2[1].numpy())
+    # known answer of tests/modeling/test_matcher.py:12-25
+    kq = torch.tensor([[0.15, 0.45, 0.2, 0.6], [0.3, 0.65, 0.05, 0.1], [0.05, 0.4, 0.25, 0.4]])
+    km = Matcher([0.3, 0.5], [0, -1, 1], allow_low_quality_matches=True)(kq)
+    out.update(match_known_q=kq.numpy(), match_known_idx=km[0].numpy(), match_known_lab=km[1].numpy())
+    # --- anchors ----------------------------------------------------------------------------------
+    from detectron2.config import get_cfg
+    from detectron2.layers import ShapeSpec
+    from detectron2.modeling.anchor_generator import DefaultAnchorGenerator
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(REF, "configs/COCO-PanopticSegmentation/u2seg_R50_800.yaml"))
+    ag = DefaultAnchorGenerator(cfg, [ShapeSpec(stride=s) for s in (4, 8, 16, 32, 64)])
+    grids = [(12, 16), (6, 8), (3, 4), (2, 2), (1, 1)]
+    anc = ag([torch.zeros(1, 1, h, w) for h, w in grids])
+    for i, a in enumerate(anc):
+        out["anchors_l%d" % i] = a.tensor.numpy()
+    # --- box coding, clip, levels ------------------------------------------------------------------
+    from detectron2.modeling.box_regression import Box2BoxTransform
+    from detectron2.modeling.poolers import assign_boxes_to_levels
+
+    src = cand[:64]
+    tgt = src + torch.randn((64, 4), generator=g) * 4
+    tgt[:, 2:] = torch.maximum(tgt[:, 2:], tgt[:, :2] + 1)
+    for wts, tag in (((1.0, 1.0, 1.0, 1.0), "rpn"), ((10.0, 10.0, 5.0, 5.0), "s0"), ((30.0, 30.0, 15.0, 15.0), "s2")):
+        t = Box2BoxTransform(weights=wts)
+        d = t.get_deltas(src, tgt)
+        dn = d + torch.randn(d.shape, generator=g) * 0.5
+        dn[0, 2] = 40.0  # exercises the log(1000/16) clamp
+        out["b2b_%s_deltas" % tag], out["b2b_%s_noisy" % tag] = d.numpy(), dn.numpy()
+        out["b2b_%s_applied" % tag] = t.apply_deltas(dn, src).numpy()
+    out["b2b_src"], out["b2b_tgt"] = src.numpy(), tgt.numpy()
+    lv_boxes = torch.cat([cand[:200], torch.tensor([[0, 0, 112.0, 112.0], [0, 0, 224.0, 224.0], [0, 0, 448, 448], [0, 0, 896, 896.0],
+                                                     [0, 0, 111.99, 112.0], [0, 0, 1333, 800], [5, 5, 5, 5]])])
+    out["lvl_boxes"] = lv_boxes.numpy()
+    out["lvl_out"] = assign_boxes_to_levels([Boxes(lv_boxes)], 2, 5, 224, 4).numpy()
+    # --- subsample_labels (seeded CPU randperm) ----------------------------------------------------
+    from detectron2.modeling.sampling import subsample_labels
+
+    labels = torch.randint(-1, 3, (500,), generator=g)
+    torch.manual_seed(11)
+    pos, neg = subsample_labels(labels, 64, 0.25, 2)
+    out.update(sub_labels=labels.numpy(), sub_pos=pos.numpy(), sub_neg=neg.numpy())
+    # --- NMS by the reference tests' python rule ---------------------------------------------------
+    spec = importlib.util.spec_from_file_location("ref_test_nms_rotated", os.path.join(REF, "tests/layers/test_nms_rotated.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    nb = torch.rand((400, 2), generator=g) * 200
+    nb = torch.cat([nb, nb + 10 + torch.rand((400, 2), generator=g) * 80], dim=1)
+    ns = torch.rand(400, generator=g)
+    out.update(nms_boxes=nb.numpy(), nms_scores=ns.numpy())
+    for thr in (0.5, 0.65):
+        out["nms_keep_%02d" % int(thr * 100)] = mod.TestNMSRotated().reference_horizontal_nms(nb, ns, thr).numpy()
+    # --- panoptic merge ---------------------------------------------------------------------------
+    from detectron2.modeling.meta_arch.panoptic_fpn import combine_semantic_and_instance_outputs
+    from detectron2.structures import Instances
+
+    H, W = 96, 128
+    sem = torch.randint(0, 6, (H // 16, W // 16), generator=g).repeat_interleave(16, 0).repeat_interleave(16, 1)
+    pm = torch.zeros((6, H, W), dtype=torch.bool)
+    rects = [(5, 5, 60, 70), (30, 40, 90, 120), (0, 0, 20, 20), (50, 60, 95, 127), (10, 10, 58, 68), (70, 5, 90, 30)]
+    for i, (y0, x0, y1, x1) in enumerate(rects):
+        pm[i, y0:y1, x0:x1] = True
+    inst = Instances((H, W))
+    inst.pred_masks, inst.scores = pm, torch.tensor([0.9, 0.8, 0.3, 0.75, 0.95, 0.6])
+    inst.pred_classes = torch.tensor([3, 7, 1, 2, 9, 4])
+    pan, info = combine_semantic_and_instance_outputs(inst, sem, 0.5, 4096 // 8, 0.5)
+    out.update(pan_sem=sem.numpy(), pan_masks=pm.numpy(), pan_scores=inst.scores.numpy(), pan_classes=inst.pred_classes.numpy(),
+               pan_out=pan.numpy(), pan_info=np.array(json.dumps(info)))
+    np.savez_compressed(os.path.join(HERE, "ops_golden.npz"), **out)
+    print("wrote ops_golden.npz with", len(out), "arrays")
+
+
+def gen_kmeans_fixture():
+    """Reference KMeans (u2seg/Instance_Clustering/shared/utils/nn_utils.py:304-379) through its plain-torch branch."""
+    for m in ["pykeops", "pykeops.torch", "torchvision", "torchvision.transforms", "torchvision.datasets", "torchvision.models",
+              "yacs", "yacs.config", "termcolor", "clip"]:
+        sys.modules.setdefault(m, mock.MagicMock())
+    pkg = types.ModuleType("u")
+    pkg.__path__ = []
+    sys.modules["u"] = pkg
+    cu = types.ModuleType("u.config_utils")
+    cu.cfg, cu.logger = mock.MagicMock(), mock.MagicMock()
+    sys.modules["u.config_utils"] = cu
+    path = os.path.join(REF, "u2seg/Instance_Clustering/shared/utils/nn_utils.py")
+    src = open(path).read().replace("from .config_utils", "from u.config_utils")
+    mod = types.ModuleType("u.nn_utils")
+    mod.__package__ = "u"
+    exec(compile(src, path, "exec"), mod.__dict__)
+    g = torch.Generator().manual_seed(3)
+    K, D, N = 12, 64, 3000
+    centers = torch.randn((K, D), generator=g) * 3
+    x = centers[torch.randint(0, K, (N,), generator=g)] + 0.5 * torch.randn((N, D), generator=g)
+    seed = 0
+    torch.manual_seed(seed)
+    init = torch.randperm(N)[:K]  # what KMeans draws first after manual_seed(seed) (:337-340)
+    cl, c = mod.KMeans(x, seed=seed, K=K, Niter=6, verbose=False, force_no_lazy_tensor=True)
+    np.savez_compressed(os.path.join(HERE, "kmeans_golden.npz"), x=x.numpy(), init=init.numpy(), labels=cl.numpy(),
+                        centroids=c.numpy(), niter=np.array(6))
+    print("wrote kmeans_golden.npz", cl.shape, c.shape)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    if a.only in ("", "kmeans"):
+        gen_kmeans_fixture()
+    if a.only in ("", "ops", "model", "model_small"):
+        ra = import_reference()
+        if a.only in ("", "ops"):
+            gen_op_fixtures(ra)
+        if a.only in ("", "model", "model_small"):
+            gen_model_fixture("model_small", (192, 256), 2, 5)

@@ -1,0 +1,145 @@
+"""Pins the CPU oracle (oracle/) against fixtures produced by the reference itself (tests/golden/make_fixtures.py)
+and against the known answers of the reference's own unit tests.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops
+from oracle.model import OracleModel
+from tests.golden.make_fixtures import det_fill
+from u2seg_amd.data import make_synthetic_batch
+
+CFG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "COCO-PanopticSegmentation",
+                   "u2seg_R50_800.yaml")
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops_golden.npz"))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_roi_align_known_answer(G):
+    """tests/layers/test_roi_align.py:14-47 (aligned 4x4 pooling of a 5x5 ramp)."""
+    ramp = torch.arange(25, dtype=torch.float32).reshape(1, 1, 5, 5)
+    out = ops.roi_align(ramp, torch.tensor([[0, 1.0, 1.0, 3.0, 3.0]]), 4, 1.0)
+    np.testing.assert_allclose(out[0, 0].numpy(), G["roi_ramp_expected"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(G["roi_ramp_out"][0, 0], G["roi_ramp_expected"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,ps", [("p7", 7), ("p14", 14)])
+def test_roi_align_vs_vendored_cpp(G, tag, ps):
+    """forward + backward == the reference's vendored ROIAlignRotated_cpu.cpp at angle 0."""
+    f = T(G["roi_feat"]).clone().requires_grad_(True)
+    y = ops.roi_align(f, T(G["roi_rois"]), ps, 0.25)
+    np.testing.assert_allclose(y.detach().numpy(), G["roi_%s_out" % tag], rtol=1e-5, atol=1e-5)
+    (y * T(G["roi_%s_w" % tag])).sum().backward()
+    np.testing.assert_allclose(f.grad.numpy(), G["roi_%s_grad" % tag], rtol=1e-4, atol=1e-4)
+
+
+def test_mask_crop(G):
+    out = ops.crop_and_resize_masks(T(G["crop_masks"]), T(G["crop_boxes"]), 28)
+    # The golden comes from the vendored *rotated* op (sample positions computed relative to the box centre), so a
+    # pooled value that lands exactly on the 0.5 threshold may round to the other side; everything else is exact.
+    m, b = T(G["crop_masks"])[:, None].float(), T(G["crop_boxes"])
+    vals = ops.roi_align(m, torch.cat([torch.arange(len(b), dtype=torch.float32)[:, None], b], 1), 28, 1.0).squeeze(1)
+    diff = out.numpy() != G["crop_out"]
+    assert diff.sum() <= 2 and np.all(np.abs(vals.numpy()[diff] - 0.5) < 1e-5)
+
+
+def test_matcher(G):
+    iou = ops.pairwise_iou(T(G["match_gt"]), T(G["match_cand"]))
+    assert np.array_equal(iou.numpy(), G["match_iou"])  # bit exact IoU
+    idx, lab = ops.matcher(iou, [0.3, 0.7], [0, -1, 1], True)
+    assert np.array_equal(idx.numpy(), G["match_rpn_idx"]) and np.array_equal(lab.numpy(), G["match_rpn_lab"])
+    idx, lab = ops.matcher(iou, [0.5], [0, 1], False)
+    assert np.array_equal(idx.numpy(), G["match_roi_idx"]) and np.array_equal(lab.numpy(), G["match_roi_lab"])
+    # tests/modeling/test_matcher.py:12-25
+    idx, lab = ops.matcher(T(G["match_known_q"]), [0.3, 0.5], [0, -1, 1], True)
+    assert idx.tolist() == [1, 1, 2, 0] and lab.tolist() == [-1, 1, 0, 1]
+    assert np.array_equal(idx.numpy(), G["match_known_idx"]) and np.array_equal(lab.numpy(), G["match_known_lab"])
+
+
+def test_anchors(G):
+    cells = [ops.generate_cell_anchors(s, (0.5, 1.0, 2.0)).float() for s in ([32], [64], [128], [256], [512])]
+    anc = ops.grid_anchors([(12, 16), (6, 8), (3, 4), (2, 2), (1, 1)], [4, 8, 16, 32, 64], cells, 0.0)
+    for i, a in enumerate(anc):
+        assert np.array_equal(a.numpy(), G["anchors_l%d" % i])
+
+
+def test_anchor_known_answer():
+    """tests/modeling/test_anchor_generator.py:13-43 (sizes 32/64, ratios .25/1/4, stride 4, 1x2 grid, offset 0)."""
+    cell = ops.generate_cell_anchors([32, 64], [0.25, 1, 4]).float()
+    anc = ops.grid_anchors([(1, 2)], [4], [cell], 0.0)[0]
+    expected = torch.tensor([[-32.0, -8.0, 32.0, 8.0], [-16.0, -16.0, 16.0, 16.0], [-8.0, -32.0, 8.0, 32.0],
+                             [-64.0, -16.0, 64.0, 16.0], [-32.0, -32.0, 32.0, 32.0], [-16.0, -64.0, 16.0, 64.0],
+                             [-28.0, -8.0, 36.0, 8.0], [-12.0, -16.0, 20.0, 16.0], [-4.0, -32.0, 12.0, 32.0],
+                             [-60.0, -16.0, 68.0, 16.0], [-28.0, -32.0, 36.0, 32.0], [-12.0, -64.0, 20.0, 64.0]])
+    assert torch.allclose(anc, expected)
+
+
+def test_box_coding(G):
+    src, tgt = T(G["b2b_src"]), T(G["b2b_tgt"])
+    for wts, tag in (((1.0, 1.0, 1.0, 1.0), "rpn"), ((10.0, 10.0, 5.0, 5.0), "s0"), ((30.0, 30.0, 15.0, 15.0), "s2")):
+        assert np.array_equal(ops.get_deltas(src, tgt, wts).numpy(), G["b2b_%s_deltas" % tag])
+        assert np.array_equal(ops.apply_deltas(T(G["b2b_%s_noisy" % tag]), src, wts).numpy(), G["b2b_%s_applied" % tag])
+    # tests/modeling/test_box2box_transform.py:17-31 round trip
+    back = ops.apply_deltas(ops.get_deltas(src, tgt, (10.0, 10.0, 5.0, 5.0)), src, (10.0, 10.0, 5.0, 5.0))
+    assert torch.allclose(back, tgt, atol=1e-3)
+
+
+def test_levels_and_sampling(G):
+    assert np.array_equal(ops.assign_boxes_to_levels(T(G["lvl_boxes"]), 2, 5).numpy(), G["lvl_out"])
+    torch.manual_seed(11)
+    pos, neg = ops.subsample_labels(T(G["sub_labels"]), 64, 0.25, 2)
+    assert np.array_equal(pos.numpy(), G["sub_pos"]) and np.array_equal(neg.numpy(), G["sub_neg"])
+
+
+def test_nms(G):
+    b, s = T(G["nms_boxes"]), T(G["nms_scores"])
+    for thr in (0.5, 0.65):
+        assert np.array_equal(ops.nms(b, s, thr).numpy(), G["nms_keep_%02d" % int(thr * 100)])
+    # batched == per-group nms merged by score
+    grp = torch.arange(b.shape[0]) % 3
+    keep = ops.nms(b, s, 0.5, grp)
+    ref = torch.cat([torch.nonzero(grp == g)[:, 0][ops.nms(b[grp == g], s[grp == g], 0.5)] for g in range(3)])
+    ref = ref[s[ref].argsort(descending=True)]
+    assert keep.tolist() == ref.tolist()
+    assert ops.nms(torch.zeros((0, 4)), torch.zeros(0), 0.5).numel() == 0
+
+
+def test_kmeans(golden_dir):
+    g = np.load(os.path.join(golden_dir, "kmeans_golden.npz"))
+    cl, c = ops.kmeans(T(g["x"]), T(g["init"]), int(g["niter"]))
+    assert np.array_equal(cl.numpy(), g["labels"])
+    np.testing.assert_allclose(c.numpy(), g["centroids"], rtol=1e-6, atol=1e-6)
+    # empty cluster -> NaN centroid, like the reference (usl-imagenet.py:135)
+    x = torch.tensor([[0.0, 0.0], [1.0, 0.0], [10.0, 0.0]])
+    c2, _ = ops.kmeans_update(x, torch.tensor([0, 0, 2]), 3)
+    assert torch.isnan(c2[1]).all() and torch.allclose(c2[0], torch.tensor([0.5, 0.0]))
+
+
+def test_whole_model_losses_and_grads(golden_dir):
+    """fp32 oracle == reference PanopticFPN (u2seg_R50_800) on 2 synthetic 192x256 images: the 10 losses and a
+    sample of parameter-gradient norms (same name-keyed weights, same CPU randperm stream)."""
+    fx = json.load(open(os.path.join(golden_dir, "model_small.json")))
+    om = OracleModel.from_config_file(CFG)
+    assert len(om.p) == fx["num_state_entries"]
+    with torch.no_grad():
+        for k, v in om.p.items():
+            v.copy_(det_fill(k, v))
+    batch = make_synthetic_batch(fx["num_images"], height=fx["image_hw"][0], width=fx["image_hw"][1])
+    torch.manual_seed(fx["seed"])
+    losses = om.train_forward(batch)
+    assert sorted(losses) == sorted(fx["losses"])
+    for k, v in fx["losses"].items():
+        assert float(losses[k]) == pytest.approx(v, rel=2e-4, abs=1e-5), k
+    sum(losses.values()).backward()
+    for k, v in fx["grad_norms"].items():
+        assert float(om.p[k].grad.double().norm()) == pytest.approx(v, rel=2e-3, abs=1e-6), k

@@ -113,6 +113,134 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiLevels lv, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ROIAlign backward as a per-pixel gather (no atomics, deterministic): every feature pixel of level l of
+// image b visits the ROIs assigned to (b, l) (list `order`, segment offsets `seg`), and for those whose
+// sampling footprint touches the pixel accumulates  sum_{samples} w_y * w_x * dout[r][ph][pw][:] / count.
+// One workgroup = an 8x8 pixel tile; ROIs overlapping the tile are compacted into LDS first.
+// ---------------------------------------------------------------------------------------------
+struct RoiGeom { float sh, sw, bh, bw; int gh, gw, r; float inv_cnt; };
+
+// weight with which sample position `pos` (one axis, extent n) feeds pixel `p`; 0 if the sample is skipped
+__device__ __forceinline__ float axis_weight(float pos, int n, int p) {
+  if (pos < -1.0f || pos > (float)n) return 0.f;
+  if (pos <= 0.f) pos = 0.f;
+  int lo = (int)pos, hi;
+  if (lo >= n - 1) { hi = lo = n - 1; pos = (float)lo; } else { hi = lo + 1; }
+  const float l = pos - (float)lo, h = 1.f - l;
+  float w = 0.f;
+  if (lo == p) w += h;
+  if (hi == p) w += l;
+  return w;
+}
+
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* __restrict__ rois, const int* __restrict__ order,
+                                                                   const int* __restrict__ seg, const bf16_t* __restrict__ dout,
+                                                                   bf16_t* __restrict__ gfeat, int level, int nlevels, int H, int W,
+                                                                   int C, int PH, int PW, float scale, float gscale) {
+  constexpr int TS = 8, MAXL = 256;
+  __shared__ RoiGeom list[MAXL];
+  __shared__ int nlist;
+  const int b = blockIdx.z;
+  const int ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
+  const int tid = threadIdx.x;
+  const int beg = seg[b * nlevels + level], end = seg[b * nlevels + level + 1];
+  const int cpr = C >> 3;             // 16-byte chunks per pixel
+  const int items = TS * TS * cpr;    // work items per tile
+  // register accumulators: item i handled by thread (i % 256), up to 8 items per thread (C <= 256)
+  float acc[8][8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
+
+  for (int base = beg; base < end; base += MAXL) {
+    __syncthreads();
+    if (tid == 0) nlist = 0;
+    __syncthreads();
+    const int idx = base + tid;
+    if (idx < end) {
+      const int r = order[idx];
+      const float* roi = rois + (size_t)r * 5;
+      RoiGeom g;
+      g.sw = roi[1] * scale - 0.5f; g.sh = roi[2] * scale - 0.5f;
+      const float ew = roi[3] * scale - 0.5f, eh = roi[4] * scale - 0.5f;
+      const float rw = ew - g.sw, rh = eh - g.sh;
+      g.bh = rh / (float)PH; g.bw = rw / (float)PW;
+      g.gh = (int)ceilf(rh / (float)PH); g.gw = (int)ceilf(rw / (float)PW);
+      g.r = r;
+      g.inv_cnt = gscale / (float)max(g.gh * g.gw, 1);
+      // conservative footprint test against the tile (samples lie in [s, e]; taps reach one pixel further)
+      const float y_lo = g.sh - 1.f, y_hi = eh + 1.f, x_lo = g.sw - 1.f, x_hi = ew + 1.f;
+      if (g.gh > 0 && g.gw > 0 && y_hi >= (float)ty0 && y_lo <= (float)(ty0 + TS) && x_hi >= (float)tx0 && x_lo <= (float)(tx0 + TS)) {
+        const int slot = atomicAdd(&nlist, 1);
+        list[slot] = g;
+      }
+    }
+    __syncthreads();
+    const int n = nlist;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int item = q * 256 + tid;
+      const int cc = item % cpr;
+      const int pix = item / cpr;
+      const int py = ty0 + pix / TS, px = tx0 + pix % TS;
+      if (item >= items || py >= H || px >= W) continue;
+      for (int k = 0; k < n; ++k) {
+        const RoiGeom g = list[k];
+        // candidate sample indices along y: positions pos(s) = sh + (s + .5) * bh / gh within (py-1, py+1)
+        const float step_y = g.bh / (float)g.gh, step_x = g.bw / (float)g.gw;
+        const int ny = PH * g.gh, nx = PW * g.gw;
+        int sy0 = 0, sy1 = ny - 1, sx0 = 0, sx1 = nx - 1;
+        if (step_y > 0.f) {
+          sy0 = max(0, (int)floorf(((float)py - 1.f - g.sh) / step_y - 0.5f) - 1);
+          sy1 = min(ny - 1, (int)ceilf(((float)py + 1.f - g.sh) / step_y - 0.5f) + 1);
+        }
+        if (step_x > 0.f) {
+          sx0 = max(0, (int)floorf(((float)px - 1.f - g.sw) / step_x - 0.5f) - 1);
+          sx1 = min(nx - 1, (int)ceilf(((float)px + 1.f - g.sw) / step_x - 0.5f) + 1);
+        }
+        if (py == H - 1 && step_y > 0.f) sy1 = ny - 1;   // clamped samples beyond the last row land on it
+        if (px == W - 1 && step_x > 0.f) sx1 = nx - 1;
+        if (py == 0) sy0 = 0;
+        if (px == 0) sx0 = 0;
+        for (int sy = sy0; sy <= sy1; ++sy) {
+          const int ph = sy / g.gh, iy = sy - ph * g.gh;
+          const float ypos = g.sh + ph * g.bh + (iy + 0.5f) * g.bh / (float)g.gh;
+          const float wy = axis_weight(ypos, H, py);
+          if (wy == 0.f) continue;
+          const bool y_in = !(ypos < -1.0f || ypos > (float)H);
+          if (!y_in) continue;
+          for (int sx = sx0; sx <= sx1; ++sx) {
+            const int pw = sx / g.gw, ix = sx - pw * g.gw;
+            const float xpos = g.sw + pw * g.bw + (ix + 0.5f) * g.bw / (float)g.gw;
+            const float wx = axis_weight(xpos, W, px);
+            if (wx == 0.f) continue;
+            bf16_t dv[8];
+            *reinterpret_cast<uint4*>(dv) =
+                *reinterpret_cast<const uint4*>(dout + (((size_t)g.r * PH + ph) * PW + pw) * C + cc * 8);
+            const float wgt = wy * wx * g.inv_cnt;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[q][e] += wgt * bf2f(dv[e]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int item = q * 256 + tid;
+    const int cc = item % cpr;
+    const int pix = item / cpr;
+    const int py = ty0 + pix / TS, px = tx0 + pix % TS;
+    if (item >= items || py >= H || px >= W) continue;
+    bf16_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[q][e]);
+    *reinterpret_cast<uint4*>(gfeat + (((size_t)b * H + py) * W + px) * C + cc * 8) = *reinterpret_cast<const uint4*>(o);
+  }
+}
+
 // single-channel fp32 ROIAlign used for ground-truth mask crops (BitMasks.crop_and_resize,
 // structures/masks.py:191-218): mask uint8 [Nm][H][W], rois [R][5] (mask index, box), out uint8 = (val >= 0.5)
 __global__ __launch_bounds__(256) void mask_crop_kernel(const uint8_t* __restrict__ masks, const float* __restrict__ rois,
@@ -450,5 +578,19 @@ extern "C" int u2_batched_nms(const float* boxes, const int* group, const int* c
   hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(256), (size_t)NB * 8, s, (const unsigned long long*)workspace, cnt, keep,
                      nkeep, n, NB, max_keep);
   U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_roi_align_bwd_gather(void* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,
+                                       const float* rois, const int* order, const int* seg, const void* dout, int B, int C,
+                                       int PH, int PW, float gscale, void* stream) {
+  if (nlevels < 1 || nlevels > 4 || (C & 7) || C > 256) return -1;
+  if (B <= 0) return 0;
+  for (int l = 0; l < nlevels; ++l) {
+    const dim3 grid((Ws[l] + 7) / 8, (Hs[l] + 7) / 8, B);
+    hipLaunchKernelGGL(roi_align_bwd_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, rois, order, seg,
+                       (const bf16_t*)dout, (bf16_t*)gfeats[l], l, nlevels, Hs[l], Ws[l], C, PH, PW, scales[l], gscale);
+    U2_CHECK_LAUNCH();
+  }
   return 0;
 }

@@ -552,15 +552,30 @@ class _ROIAlignFn(Function):
         rois, levels = ctx.saved_tensors
         out_size, scales, grad_scale, shapes = ctx.cfg
         nl = len(shapes)
-        gbuf = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in shapes]
-        ptrs = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gbuf])
+        b = shapes[0][0]
+        r, c = rois.shape[0], shapes[0][3]
         hs = (ctypes.c_int * nl)(*[s[1] for s in shapes])
         ws = (ctypes.c_int * nl)(*[s[2] for s in shapes])
         sc = (ctypes.c_float * nl)(*scales)
-        r, c = rois.shape[0], shapes[0][3]
-        _hip.call("u2_roi_align_bwd", ptrs, hs, ws, sc, nl, rois.contiguous(), levels.contiguous(), dout.contiguous(),
-                  r, c, out_size, out_size, float(grad_scale))
-        return (None, None, None, None, None, *[g.to(BF16) for g in gbuf])
+        if ROI_ALIGN_BWD_ATOMIC:
+            gbuf = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in shapes]
+            ptrs = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gbuf])
+            _hip.call("u2_roi_align_bwd", ptrs, hs, ws, sc, nl, rois.contiguous(), levels.contiguous(), dout.contiguous(),
+                      r, c, out_size, out_size, float(grad_scale))
+            return (None, None, None, None, None, *[g.to(BF16) for g in gbuf])
+        # group the ROIs by (image, level) for the atomics-free per-pixel gather
+        key = rois[:, 0].to(torch.int64) * nl + levels.to(torch.int64)
+        order = torch.argsort(key, stable=True).to(torch.int32)
+        seg = torch.zeros(b * nl + 1, dtype=torch.int32, device=dout.device)
+        seg[1:] = torch.cumsum(torch.bincount(key, minlength=b * nl), 0)
+        gbuf = [torch.empty(s, dtype=BF16, device=dout.device) for s in shapes]
+        ptrs = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gbuf])
+        _hip.call("u2_roi_align_bwd_gather", ptrs, hs, ws, sc, nl, rois.contiguous(), order, seg, dout.contiguous(), b, c,
+                  out_size, out_size, float(grad_scale))
+        return (None, None, None, None, None, *gbuf)
+
+
+ROI_ALIGN_BWD_ATOMIC = False  # True selects the fp32-atomic scatter variant (kept for A/B tests)
 
 
 def roi_align(feats, rois, levels, out_size, scales, grad_scale=1.0):
