@@ -108,10 +108,12 @@ class OracleModel:
         return self.q(y)
 
     # ---- backbone -----------------------------------------------------------------------------
-    def backbone(self, images):
+    def backbone(self, images, capture=None):
         pre = "backbone.bottom_up."
         x = self.bn(self.conv(images, pre + "stem.conv1", 2, 3), pre + "stem.conv1.norm", relu=True)
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        if capture is not None:
+            capture["stem"] = x
         res = {}
         for si, nblocks in zip(range(2, 6), [3, 4, 6, 3]):
             for bi in range(nblocks):
@@ -125,8 +127,13 @@ class OracleModel:
                 else:
                     sc = x
                 x = self.bn(out, n + "conv3.norm", residual=sc, relu=True)
+                if capture is not None:
+                    capture["res%d.%d" % (si, bi)] = x
             res["res%d" % si] = x
-        # FPN (fpn.py:126-167)
+        return self.fpn(res)
+
+    def fpn(self, res):
+        """fpn.py:126-167."""
         feats = {}
         prev = self.bn(self.conv(res["res5"], "backbone.fpn_lateral5"), "backbone.fpn_lateral5.norm")
         feats["p5"] = self.bn(self.conv(prev, "backbone.fpn_output5", 1, 1), "backbone.fpn_output5.norm")

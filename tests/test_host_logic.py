@@ -1,0 +1,174 @@
+"""CPU tests of the host side: config tree, registries, model construction (names / counts pinned by the reference
+fixture), structures, schedule, synthetic data, and that the C-ABI library exports what include/u2seg_hip.h declares."""
+import ctypes
+import json
+import os
+import zlib
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG_DIR = os.path.join(ROOT, "configs", "COCO-PanopticSegmentation")
+
+
+def _cfg(name="u2seg_R50_800.yaml", opts=()):
+    from u2seg_amd.config import get_cfg
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(CFG_DIR, name))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu"] + list(opts))
+    return cfg
+
+
+def test_config_chain_and_overrides():
+    cfg = _cfg()
+    assert cfg.MODEL.META_ARCHITECTURE == "PanopticFPN" and cfg.MODEL.ROI_HEADS.NAME == "CascadeROIHeads"
+    assert cfg.MODEL.ROI_HEADS.NUM_CLASSES == 800 and cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES == 28
+    assert cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN == 4000 and cfg.MODEL.RPN.NMS_THRESH == 0.65
+    assert cfg.SOLVER.STEPS == (210000, 250000) and cfg.SOLVER.CLIP_GRADIENTS.ENABLED
+    assert _cfg("u2seg_R50_300.yaml").MODEL.ROI_HEADS.NUM_CLASSES == 300
+    assert _cfg("u2seg_eval_800.yaml").MODEL.ROI_HEADS.NUM_CLASSES == 800
+    cfg.freeze()
+    with pytest.raises(AttributeError):
+        cfg.SOLVER.BASE_LR = 1.0
+    c2 = cfg.clone()
+    c2.defrost()
+    c2.merge_from_list(["SOLVER.BASE_LR", "0.5", "MODEL.RPN.IN_FEATURES", "['p2','p3']"])
+    assert c2.SOLVER.BASE_LR == 0.5 and c2.MODEL.RPN.IN_FEATURES == ["p2", "p3"]
+    with pytest.raises(KeyError):
+        c2.merge_from_list(["SOLVER.NOT_A_KEY", 1])
+    with pytest.raises(ValueError):
+        c2.merge_from_list(["SOLVER.MAX_ITER", "abc"])
+    assert "PanopticFPN" in cfg.dump()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="reference tree not present")
+def test_reference_yaml_chain_loads_unchanged():
+    """The reference's own 3-file _BASE_ chain gives the same tree as this repo's flat files."""
+    from u2seg_amd.config import get_cfg
+
+    for name in ("u2seg_R50_800.yaml", "u2seg_R50_300.yaml", "u2seg_eval_800.yaml"):
+        ref = get_cfg()
+        ref.merge_from_file(os.path.join("/root/reference/configs/COCO-PanopticSegmentation", name))
+        mine = _cfg(name)
+        for k in ("WEIGHTS", "DEVICE"):
+            mine.MODEL[k] = ref.MODEL[k]
+        mine.OUTPUT_DIR = ref.OUTPUT_DIR
+        assert mine.dump() == ref.dump(), name
+
+
+def test_registries_and_model_tree():
+    from u2seg_amd.modeling import (BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, ROI_BOX_HEAD_REGISTRY,
+                                    ROI_HEADS_REGISTRY, ROI_MASK_HEAD_REGISTRY, RPN_HEAD_REGISTRY, SEM_SEG_HEADS_REGISTRY,
+                                    ANCHOR_GENERATOR_REGISTRY, build_model)
+
+    for reg, name in ((META_ARCH_REGISTRY, "PanopticFPN"), (BACKBONE_REGISTRY, "build_resnet_fpn_backbone"),
+                      (PROPOSAL_GENERATOR_REGISTRY, "RPN"), (RPN_HEAD_REGISTRY, "StandardRPNHead"),
+                      (ANCHOR_GENERATOR_REGISTRY, "DefaultAnchorGenerator"), (ROI_HEADS_REGISTRY, "CascadeROIHeads"),
+                      (ROI_BOX_HEAD_REGISTRY, "FastRCNNConvFCHead"), (ROI_MASK_HEAD_REGISTRY, "MaskRCNNConvUpsampleHead"),
+                      (SEM_SEG_HEADS_REGISTRY, "SemSegFPNHead")):
+        assert reg.get(name) is not None
+    with pytest.raises(KeyError):
+        META_ARCH_REGISTRY.get("NoSuchArch")
+    model = build_model(_cfg())
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "model_small.json")))
+    sd = model.state_dict()
+    assert sum(p.numel() for p in model.parameters()) == fx["num_params"] == 76066554
+    assert len(sd) == fx["num_state_entries"] == 431
+    # identical key names, in the identical order, as the reference model's state_dict
+    assert zlib.crc32("\n".join(sd.keys()).encode()) == fx["state_dict_keys_crc32"]
+    assert model.backbone.size_divisibility == 32 and model.sem_seg_head.ignore_value == 255
+    assert sum(p.numel() for p in build_model(_cfg("u2seg_R50_300.yaml")).parameters()) == 74400554
+    model.eval()
+    assert not model.training
+
+
+def test_structures():
+    from u2seg_amd.structures import BitMasks, Boxes, ImageList, Instances, pairwise_iou
+
+    b = Boxes(torch.tensor([[0.0, 0, 10, 10], [5, 5, 15, 15], [3, 3, 3, 9]]))
+    assert b.area().tolist() == [100.0, 100.0, 0.0] and b.nonempty().tolist() == [True, True, False]
+    iou = pairwise_iou(b[:2], b[:2])
+    assert iou[0, 1] == pytest.approx(25 / 175)  # tests/structures/test_boxes.py-style known value
+    b.clip((8, 12))
+    assert b.tensor[1].tolist() == [5, 5, 12, 8]
+    inst = Instances((20, 30), gt_boxes=Boxes(torch.zeros(3, 4)), gt_classes=torch.tensor([1, 2, 3]))
+    assert len(inst[torch.tensor([True, False, True])]) == 2 and inst.image_size == (20, 30)
+    with pytest.raises(AssertionError):
+        inst.bad = torch.zeros(5)
+    cat = Instances.cat([inst, inst])
+    assert len(cat) == 6 and cat.gt_classes.tolist() == [1, 2, 3, 1, 2, 3]
+    il = ImageList.from_tensors([torch.ones(3, 20, 31), torch.ones(3, 33, 17)], 32)
+    assert tuple(il.tensor.shape) == (2, 3, 64, 32) and il.image_sizes == [(20, 31), (33, 17)]
+    assert float(il.tensor[0, :, 20:, :].abs().sum()) == 0
+    assert ImageList.padded_size([(800, 1333)], 32) == (800, 1344)
+    bm = BitMasks(torch.zeros(2, 4, 4, dtype=torch.bool))
+    assert len(bm) == 2 and bm.nonempty().tolist() == [False, False]
+
+
+def test_anchor_generator_and_sampling():
+    from u2seg_amd.modeling import subsample_labels
+    from u2seg_amd.modeling.rpn import DefaultAnchorGenerator
+
+    ag = DefaultAnchorGenerator(sizes=[[32, 64]], aspect_ratios=[[0.25, 1, 4]], strides=[4], offset=0.0)
+    anc = ag.grid_anchors([(1, 2)])[0]
+    # tests/modeling/test_anchor_generator.py:13-43
+    expected = torch.tensor([[-32.0, -8.0, 32.0, 8.0], [-16.0, -16.0, 16.0, 16.0], [-8.0, -32.0, 8.0, 32.0],
+                             [-64.0, -16.0, 64.0, 16.0], [-32.0, -32.0, 32.0, 32.0], [-16.0, -64.0, 16.0, 64.0],
+                             [-28.0, -8.0, 36.0, 8.0], [-12.0, -16.0, 20.0, 16.0], [-4.0, -32.0, 12.0, 32.0],
+                             [-60.0, -16.0, 68.0, 16.0], [-28.0, -32.0, 36.0, 32.0], [-12.0, -64.0, 20.0, 64.0]])
+    assert torch.allclose(anc, expected)
+    import numpy as np
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ops_golden.npz"))
+    torch.manual_seed(11)
+    from u2seg_amd.modeling import set_permutation_source
+
+    set_permutation_source(lambda n, device=None: torch.randperm(n))
+    pos, neg = subsample_labels(torch.from_numpy(g["sub_labels"]), 64, 0.25, 2)
+    set_permutation_source(None)
+    assert np.array_equal(pos.numpy(), g["sub_pos"]) and np.array_equal(neg.numpy(), g["sub_neg"])
+
+
+def test_lr_schedule_and_synthetic_data():
+    from u2seg_amd.data import make_synthetic_batch
+    from u2seg_amd.solver import WarmupMultiStepLR
+
+    class Opt:
+        lr = 0.0
+
+    s = WarmupMultiStepLR(Opt(), 0.01, [210000, 250000], 0.02, 0.001, 1000)
+    assert s.get_lr(0) == pytest.approx(1e-5) and s.get_lr(500) == pytest.approx(0.5 * 1e-5 + 0.5 * 0.01)
+    assert s.get_lr(1000) == pytest.approx(0.01) and s.get_lr(210000) == pytest.approx(2e-4)
+    assert s.get_lr(260000) == pytest.approx(0.01 * 0.02 ** 2)
+    a, b = make_synthetic_batch(2, height=64, width=96), make_synthetic_batch(2, height=64, width=96)
+    assert torch.equal(a[1]["image"], b[1]["image"]) and a[0]["image"].dtype == torch.uint8
+    x = a[0]
+    assert x["sem_seg"].shape == (64, 96) and set(x["sem_seg"].unique().tolist()) <= set(range(28)) | {255}
+    inst = x["instances"]
+    assert 3 <= len(inst) <= 12 and inst.gt_masks.tensor.shape[1:] == (64, 96) and int(inst.gt_classes.max()) < 800
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    from u2seg_amd import _hip
+
+    decl = _hip.declared_symbols()
+    assert len(decl) >= 36 and "u2_conv_igemm" in decl and "u2_kmeans_assign" in decl
+    assert os.path.exists(_hip.lib_path()), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(_hip.lib_path())
+    for name in decl:
+        assert hasattr(lib, name), name
+    lib.u2_abi_version.restype = ctypes.c_int
+    assert lib.u2_abi_version() == 1
+    assert _hip.call_nostream("u2_nms_workspace_bytes", 2, 130) == 2 * 130 * 3 * 8
+
+
+def test_hot_path_fails_loudly_without_gpu():
+    """No CPU fallback: a HIP function on CPU tensors is an error, not a silent ATen path."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from u2seg_amd.layers import functional as F
+
+    with pytest.raises((AssertionError, RuntimeError)):
+        F.conv2d(torch.zeros((1, 4, 4, 32), dtype=torch.bfloat16), torch.zeros(32, 32, 1, 1))

@@ -1,0 +1,46 @@
+"""Lloyd k-means over DINO embeddings on the GPU (u2seg/Instance_Clustering/shared/utils/nn_utils.py:304-405).
+
+``run_kmeans`` mirrors the reference's ``run_kMeans`` / ``KMeans`` contract: initial centroids are
+``x[randperm(N)[:K]]`` drawn from the CPU generator after ``torch.manual_seed(seed)``, a fixed number of iterations,
+no convergence test, empty clusters turn into NaN rows (the reference notes this at usl-imagenet.py:135)."""
+import torch
+
+from .. import _hip
+
+
+def assign(x, c):
+    """argmin_j sum_d (x_id - c_jd)^2 -> int64 [N] (u2_kmeans_assign: exact-fp32 MFMA dot products)."""
+    n, d = x.shape
+    k = c.shape[0]
+    labels = torch.empty(n, dtype=torch.int64, device=x.device)
+    ws = torch.empty(k, dtype=torch.float32, device=x.device)
+    _hip.call("u2_kmeans_assign", x.contiguous(), c.contiguous(), ws, labels, n, d, k)
+    return labels
+
+
+def update(x, labels, k):
+    """c = scatter_add(x by label) / bincount(label) -> (centroids [K, D], counts [K])."""
+    n, d = x.shape
+    csum = torch.zeros((k, d), dtype=torch.float32, device=x.device)
+    counts = torch.zeros(k, dtype=torch.float32, device=x.device)
+    _hip.call("u2_kmeans_update", x.contiguous(), labels, csum, counts, n, d, k)
+    c = torch.empty_like(csum)
+    _hip.call("u2_kmeans_finalize", csum, counts, c, d, k)
+    return c, counts
+
+
+def kmeans(x, init_idx, niter):
+    c = x[init_idx].clone()
+    cl = None
+    for _ in range(niter):
+        cl = assign(x, c)
+        c, _ = update(x, cl, c.shape[0])
+    return cl, c
+
+
+def run_kmeans(x, num_centroids, niter=100, seed=0):
+    """nn_utils.py:382-405 (run_kMeans): returns (cluster labels int64 [N], centroids fp32 [K, D])."""
+    x = x.float().cuda() if not x.is_cuda else x.float()
+    torch.manual_seed(seed)
+    r = torch.randperm(x.shape[0])[:num_centroids]
+    return kmeans(x, r.to(x.device), niter)

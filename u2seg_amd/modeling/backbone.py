@@ -207,7 +207,9 @@ class FPN(Backbone):
 
     def forward(self, images, pixel_mean, pixel_std, padded_hw):
         """fpn.py:126-167: lateral 1x1, nearest x2 of the coarser level + add, output 3x3."""
-        bottom_up_features = self.bottom_up(images, pixel_mean, pixel_std, padded_hw)
+        return self.forward_features(self.bottom_up(images, pixel_mean, pixel_std, padded_hw))
+
+    def forward_features(self, bottom_up_features):
         results = []
         prev = self.lateral_convs[0](bottom_up_features[self.in_features[-1]])
         results.append(self.output_convs[0](prev))
