@@ -29,7 +29,7 @@ def _world():
 
 def _check_act(x):
     assert x.is_cuda and x.dtype == BF16 and x.is_contiguous() and x.dim() == 4 and x.shape[3] % 32 == 0, (
-        "expected contiguous NHWC bf16 activation with C % 32 == 0, got %s %s" % (tuple(x.shape), x.dtype)
+        "expected contiguous NHWC bf16 activation with C %% 32 == 0, got %s %s" % (tuple(x.shape), x.dtype)
     )
 
 
