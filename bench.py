@@ -45,7 +45,7 @@ class KernelTimer:
             s.record()
             orig(name, *args)
             e.record()
-            timer.records.append((name, timer.flops(name, args), s, e))
+            timer.records.append((name, timer.flops(name, args), s, e, tuple(a for a in args if isinstance(a, int))))
 
         _hip.call = timed_call
         import u2seg_amd.layers.functional as F
@@ -66,7 +66,7 @@ class KernelTimer:
 
     def summary(self):
         out = {}
-        for name, fl, s, e in self.records:
+        for name, fl, s, e, _ in self.records:
             d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-layer", action="store_true", help="debug: print the conv launches grouped by shape")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -192,6 +193,16 @@ def main():
             "final_total_loss": total,
             "roofline": roofline,
         }
+        if args.per_layer:
+            agg = {}
+            for name, fl, s, e, shape in timer.records:
+                d = agg.setdefault((name, shape), [0, 0.0, 0.0])
+                d[0] += 1
+                d[1] += s.elapsed_time(e)
+                d[2] += fl
+            for (name, shape), d in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+                print("LAYER %-14s %-70s n=%3d  %7.3f ms/step  %7.1f TF/s" % (name, shape, d[0] / args.steps, d[1] / args.steps,
+                                                                             d[2] / (d[1] * 1e-3) / 1e12), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

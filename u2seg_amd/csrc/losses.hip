@@ -17,80 +17,105 @@ namespace {
 // One workgroup = 64x16 full-resolution pixels; the 18x6 low-resolution taps it touches are staged
 // in LDS as fp32, the logit gradient is accumulated in LDS with ds atomics and flushed once.
 // ------------------------------------------------------------------------------------------------
-constexpr int SS_TW = 64, SS_TH = 16, SS_LW = 18, SS_LH = 6, SS_MAXC = 32;
+constexpr int SS_GW = 16, SS_TH = 16, SS_LW = 17, SS_LH = 6, SS_MAXC = 32, SS_PITCH = 33;
 
+// Work split: with scale 4 and align_corners=False the four pixels x = 4g+2 .. 4g+5 share their two x taps
+// (g, g+1), so one thread owns such a quad of one row: it merges the quad's gradient along x in registers and
+// issues 4 x NC LDS atomics per quad instead of per pixel; the LDS tile pitch (33 floats) keeps the 16 quads of a
+// wave on different banks.
 __global__ __launch_bounds__(256) void semseg_ce_kernel(const bf16_t* __restrict__ logits, const uint8_t* __restrict__ target,
                                                         float* __restrict__ grad_acc, float* __restrict__ loss_sum,
                                                         float* __restrict__ valid_cnt, int B, int h, int w, int LP, int NC,
                                                         int ignore) {
-  __shared__ float zt[SS_LH * SS_LW * SS_MAXC];
-  __shared__ float gt[SS_LH * SS_LW * SS_MAXC];
+  __shared__ float zt[SS_LH * SS_LW * SS_PITCH];
+  __shared__ float gt[SS_LH * SS_LW * SS_PITCH];
   __shared__ float red[4];
   const int H = 4 * h, W = 4 * w;
   const int b = blockIdx.z;
-  const int X0 = blockIdx.x * SS_TW, Y0 = blockIdx.y * SS_TH;
-  const int lx0 = X0 / 4 - 1, ly0 = Y0 / 4 - 1;
+  const int GX0 = (int)blockIdx.x * SS_GW - 1;  // first quad index of the block (quad -1 holds pixels 0, 1)
+  const int Y0 = blockIdx.y * SS_TH;
+  const int lx0 = GX0, ly0 = Y0 / 4 - 1;
   const int tid = threadIdx.x;
   for (int i = tid; i < SS_LH * SS_LW * SS_MAXC; i += 256) {
     const int c = i % SS_MAXC;
     const int t = i / SS_MAXC;
     const int tx = t % SS_LW, ty = t / SS_LW;
     const int lx = min(max(lx0 + tx, 0), w - 1), ly = min(max(ly0 + ty, 0), h - 1);
-    zt[i] = (c < NC) ? bf2f(logits[(((size_t)b * h + ly) * w + lx) * LP + c]) : 0.f;
-    gt[i] = 0.f;
+    zt[t * SS_PITCH + c] = (c < NC) ? bf2f(logits[(((size_t)b * h + ly) * w + lx) * LP + c]) : 0.f;
+    gt[t * SS_PITCH + c] = 0.f;
   }
   __syncthreads();
   float my_loss = 0.f, my_cnt = 0.f;
-  const int px = tid & 63;
-  const int x = X0 + px;
-#pragma unroll 1
-  for (int r = 0; r < 4; ++r) {
-    const int y = Y0 + (tid >> 6) + r * 4;
-    if (x >= W || y >= H) continue;
-    const int t = target[((size_t)b * H + y) * W + x];
-    if (t == ignore) continue;
-    float sx = (x + 0.5f) * 0.25f - 0.5f, sy = (y + 0.5f) * 0.25f - 0.5f;
-    sx = fmaxf(sx, 0.f); sy = fmaxf(sy, 0.f);
-    const int x0 = (int)sx, y0 = (int)sy;
-    const int x1 = x0 + (x0 < w - 1 ? 1 : 0), y1 = y0 + (y0 < h - 1 ? 1 : 0);
-    const float lx = sx - x0, ly = sy - y0, hx = 1.f - lx, hy = 1.f - ly;
-    const int i00 = ((y0 - ly0) * SS_LW + (x0 - lx0)) * SS_MAXC;
-    const int i01 = ((y0 - ly0) * SS_LW + (x1 - lx0)) * SS_MAXC;
-    const int i10 = ((y1 - ly0) * SS_LW + (x0 - lx0)) * SS_MAXC;
-    const int i11 = ((y1 - ly0) * SS_LW + (x1 - lx0)) * SS_MAXC;
-    const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
-    float z[SS_MAXC];
-    float mx = -INFINITY;
+  const int gx = GX0 + (tid & 15);
+  const int y = Y0 + (tid >> 4);
+  if (y < H && gx < w) {
+    float sy = fmaxf((y + 0.5f) * 0.25f - 0.5f, 0.f);
+    const int y0 = (int)sy;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly = sy - y0, hy = 1.f - ly;
+    float a0[SS_MAXC], a1[SS_MAXC];  // x-merged gradient for the left / right tap column
 #pragma unroll
-    for (int c = 0; c < SS_MAXC; ++c) {
-      if (c < NC) {
-        // same association as ATen's upsample_bilinear2d: hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11)
-        z[c] = hy * (hx * zt[i00 + c] + lx * zt[i01 + c]) + ly * (hx * zt[i10 + c] + lx * zt[i11 + c]);
-        mx = fmaxf(mx, z[c]);
-      } else {
-        z[c] = -INFINITY;
+    for (int c = 0; c < SS_MAXC; ++c) { a0[c] = 0.f; a1[c] = 0.f; }
+    int tx0 = -1, tx1 = -1;
+    bool any = false;
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+      const int x = 4 * gx + 2 + i;
+      if (x < 0 || x >= W) continue;
+      float sx = fmaxf((x + 0.5f) * 0.25f - 0.5f, 0.f);
+      const int x0 = (int)sx;
+      const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+      const float lx = sx - x0, hx = 1.f - lx;
+      tx0 = x0; tx1 = x1;  // identical for the whole quad
+      const int t = target[((size_t)b * H + y) * W + x];
+      if (t == ignore) continue;
+      any = true;
+      const int i00 = ((y0 - ly0) * SS_LW + (x0 - lx0)) * SS_PITCH;
+      const int i01 = ((y0 - ly0) * SS_LW + (x1 - lx0)) * SS_PITCH;
+      const int i10 = ((y1 - ly0) * SS_LW + (x0 - lx0)) * SS_PITCH;
+      const int i11 = ((y1 - ly0) * SS_LW + (x1 - lx0)) * SS_PITCH;
+      float z[SS_MAXC];
+      float mx = -INFINITY, z_t = 0.f;
+#pragma unroll
+      for (int c = 0; c < SS_MAXC; ++c) {
+        if (c < NC) {
+          // same association as ATen's upsample_bilinear2d: hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11)
+          z[c] = hy * (hx * zt[i00 + c] + lx * zt[i01 + c]) + ly * (hx * zt[i10 + c] + lx * zt[i11 + c]);
+          mx = fmaxf(mx, z[c]);
+          if (c == t) z_t = z[c];
+        } else {
+          z[c] = -INFINITY;
+        }
+      }
+      float se = 0.f;
+#pragma unroll
+      for (int c = 0; c < SS_MAXC; ++c)
+        if (c < NC) { z[c] = __expf(z[c] - mx); se += z[c]; }  // z now holds exp(logit - max)
+      my_loss += mx + __logf(se) - z_t;
+      my_cnt += 1.f;
+      const float inv = 1.f / se;
+#pragma unroll
+      for (int c = 0; c < SS_MAXC; ++c) {
+        if (c < NC) {
+          const float g = z[c] * inv - (c == t ? 1.f : 0.f);
+          a0[c] += hx * g;
+          a1[c] += lx * g;
+        }
       }
     }
-    float se = 0.f;
+    if (any) {
+      const int i00 = ((y0 - ly0) * SS_LW + (tx0 - lx0)) * SS_PITCH;
+      const int i01 = ((y0 - ly0) * SS_LW + (tx1 - lx0)) * SS_PITCH;
+      const int i10 = ((y1 - ly0) * SS_LW + (tx0 - lx0)) * SS_PITCH;
+      const int i11 = ((y1 - ly0) * SS_LW + (tx1 - lx0)) * SS_PITCH;
 #pragma unroll
-    for (int c = 0; c < SS_MAXC; ++c)
-      if (c < NC) se += __expf(z[c] - mx);
-    const float lse = mx + __logf(se);
-    float zt_t = 0.f;
-#pragma unroll
-    for (int c = 0; c < SS_MAXC; ++c)
-      if (c == t) zt_t = z[c];
-    my_loss += lse - zt_t;
-    my_cnt += 1.f;
-    const float inv = 1.f / se;
-#pragma unroll
-    for (int c = 0; c < SS_MAXC; ++c) {
-      if (c < NC) {
-        const float g = __expf(z[c] - mx) * inv - (c == t ? 1.f : 0.f);
-        atomicAdd(&gt[i00 + c], w00 * g);
-        atomicAdd(&gt[i01 + c], w01 * g);
-        atomicAdd(&gt[i10 + c], w10 * g);
-        atomicAdd(&gt[i11 + c], w11 * g);
+      for (int c = 0; c < SS_MAXC; ++c) {
+        if (c < NC) {
+          atomicAdd(&gt[i00 + c], hy * a0[c]);
+          atomicAdd(&gt[i01 + c], hy * a1[c]);
+          atomicAdd(&gt[i10 + c], ly * a0[c]);
+          atomicAdd(&gt[i11 + c], ly * a1[c]);
+        }
       }
     }
   }
@@ -101,9 +126,9 @@ __global__ __launch_bounds__(256) void semseg_ce_kernel(const bf16_t* __restrict
   for (int i = tid; i < SS_LH * SS_LW * SS_MAXC; i += 256) {
     const int c = i % SS_MAXC;
     if (c >= NC) continue;
-    const float g = gt[i];
-    if (g == 0.f) continue;
     const int t = i / SS_MAXC;
+    const float g = gt[t * SS_PITCH + c];
+    if (g == 0.f) continue;
     const int lx = lx0 + t % SS_LW, ly = ly0 + t / SS_LW;
     if (lx < 0 || lx >= w || ly < 0 || ly >= h) continue;
     atomicAdd(grad_acc + (((size_t)b * h + ly) * w + lx) * LP + c, g);
@@ -308,7 +333,7 @@ extern "C" int u2_semseg_upsample_ce(const void* logits, const void* target, flo
                                      float* valid_cnt, int B, int h, int w, int LP, int NC, int ignore, void* stream) {
   if (NC > SS_MAXC || LP < NC) return -1;
   if (B <= 0) return 0;
-  const dim3 grid((4 * w + SS_TW - 1) / SS_TW, (4 * h + SS_TH - 1) / SS_TH, B);
+  const dim3 grid((w + 1 + SS_GW - 1) / SS_GW, (4 * h + SS_TH - 1) / SS_TH, B);
   hipLaunchKernelGGL(semseg_ce_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits,
                      (const uint8_t*)target, grad_acc, loss_sum, valid_cnt, B, h, w, LP, NC, ignore);
   U2_CHECK_LAUNCH();

@@ -163,6 +163,81 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const bf16_t* __restrict_
   }
 }
 
+
+// ---- fast paths: C/8 divides 256, so a thread keeps one 8-channel column chunk for its whole life and the
+//      per-channel coefficients live in registers; grid.y = slot, rows of a slot are strided over grid.x ----
+__global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const bf16_t* __restrict__ resid,
+                                                              bf16_t* __restrict__ out, int rows_per_slot, int C, int ld,
+                                                              int relu) {
+  const int cpr = C >> 3;
+  const int rows_par = 256 / cpr;
+  const int cc = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  const int slot = blockIdx.y;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = scale[(size_t)slot * C + cc * 8 + e]; sh[e] = shift[(size_t)slot * C + cc * 8 + e]; }
+  const size_t base = (size_t)slot * rows_per_slot;
+  for (int r = blockIdx.x * rows_par + rl; r < rows_per_slot; r += gridDim.x * rows_par) {
+    const size_t off = (base + r) * ld + cc * 8;
+    bf16_t xv[8], rv[8], ov[8];
+    *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + off);
+    if (resid) *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(resid + off);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = bf2f(xv[e]) * sc[e] + sh[e];
+      if (resid) f += bf2f(rv[e]);
+      if (relu) f = fmaxf(f, 0.f);
+      ov[e] = f2bf(f);
+    }
+    *reinterpret_cast<uint4*>(out + off) = *reinterpret_cast<const uint4*>(ov);
+  }
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_apply_fast_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ mask,
+                                                                  const bf16_t* __restrict__ x, const float* __restrict__ k1,
+                                                                  const float* __restrict__ k2, const float* __restrict__ k3,
+                                                                  bf16_t* __restrict__ dx, bf16_t* __restrict__ dres,
+                                                                  int rows_per_slot, int C, int ld, int relu) {
+  const int cpr = C >> 3;
+  const int rows_par = 256 / cpr;
+  const int cc = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  const int slot = blockIdx.y;
+  float a1[8], a2[8], a3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    a1[e] = k1[(size_t)slot * C + cc * 8 + e];
+    a2[e] = k2[(size_t)slot * C + cc * 8 + e];
+    a3[e] = k3[(size_t)slot * C + cc * 8 + e];
+  }
+  const size_t base = (size_t)slot * rows_per_slot;
+  for (int r = blockIdx.x * rows_par + rl; r < rows_per_slot; r += gridDim.x * rows_par) {
+    const size_t off = (base + r) * ld + cc * 8;
+    bf16_t dv[8], mv[8], xv[8], ov[8], zv[8];
+    *reinterpret_cast<uint4*>(dv) = *reinterpret_cast<const uint4*>(dout + off);
+    *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + off);
+    if (relu) *reinterpret_cast<uint4*>(mv) = *reinterpret_cast<const uint4*>(mask + off);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float dz = bf2f(dv[e]);
+      if (relu && !(bf2f(mv[e]) > 0.f)) dz = 0.f;
+      ov[e] = f2bf(a1[e] * dz + a2[e] * bf2f(xv[e]) + a3[e]);
+      zv[e] = f2bf(dz);
+    }
+    *reinterpret_cast<uint4*>(dx + off) = *reinterpret_cast<const uint4*>(ov);
+    if (dres) *reinterpret_cast<uint4*>(dres + off) = *reinterpret_cast<const uint4*>(zv);
+  }
+}
+
+static bool fast_ok(int C) { const int cpr = C >> 3; return cpr >= 1 && cpr <= 256 && (256 % cpr) == 0; }
+static dim3 fast_grid(int slots, int rows_per_slot, int C) {
+  const int rows_par = 256 / (C >> 3);
+  int gx = (rows_per_slot + rows_par - 1) / rows_par;
+  const int cap = max(1, 4096 / slots);
+  if (gx > cap) gx = cap;
+  return dim3(gx, slots);
+}
+
 // BatchNorm forward finalize: sums -> mean/invstd/scale/shift, running-stat update (momentum).
 __global__ void bn_finalize_fwd_kernel(const float* __restrict__ sums, float count, const float* __restrict__ gamma,
                                        const float* __restrict__ beta, float* __restrict__ running_mean,
@@ -244,6 +319,12 @@ extern "C" int u2_affine_act(const void* x, const float* scale, const float* shi
   if ((C & 7) || (ld & 7)) return -1;
   const size_t M = (size_t)slots * rows_per_slot;
   if (M == 0) return 0;
+  if (fast_ok(C)) {
+    hipLaunchKernelGGL(affine_act_fast_kernel, fast_grid(slots, rows_per_slot, C), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, scale, shift, (const bf16_t*)resid, (bf16_t*)out, rows_per_slot, C, ld, relu);
+    U2_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(affine_act_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      scale, shift, (const bf16_t*)resid, (bf16_t*)out, rows_per_slot, M, C, ld, relu);
   U2_CHECK_LAUNCH();
@@ -256,6 +337,13 @@ extern "C" int u2_norm_bwd_apply(const void* dout, const void* mask, const void*
   if ((C & 7) || (ld & 7)) return -1;
   const size_t M = (size_t)slots * rows_per_slot;
   if (M == 0) return 0;
+  if (fast_ok(C)) {
+    hipLaunchKernelGGL(norm_bwd_apply_fast_kernel, fast_grid(slots, rows_per_slot, C), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dout, (const bf16_t*)mask, (const bf16_t*)x, k1, k2, k3, (bf16_t*)dx, (bf16_t*)dres,
+                       rows_per_slot, C, ld, relu);
+    U2_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dout, (const bf16_t*)mask, (const bf16_t*)x, k1, k2, k3, (bf16_t*)dx, (bf16_t*)dres,
                      rows_per_slot, M, C, ld, relu);

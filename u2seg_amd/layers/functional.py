@@ -101,10 +101,18 @@ class _Conv2dFn(Function):
             dz = dout
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wd = weight_dgrad_layout(weight, cp, npad)
             dx = torch.empty_like(x)
-            _hip.call("u2_conv_igemm", dz, wd, dx, None, None, b, ho, wo, npad, npad, h, w_, cp, cp, kh, kw,
-                      kh - 1 - pad, kw - 1 - pad, 1, stride, 0, 0, 0)
+            if ho == 1 and wo == 1 and pad == 0 and h == kh and w_ == kw and kh * kw > 1:
+                # "fully connected" conv (box head fc1): every input pixel meets exactly one tap, so the data gradient
+                # is the plain GEMM dx[b, (kh,kw,c)] = dz[b, :] . W[:, (kh,kw,c)]
+                wt = torch.zeros((kh * kw * cp, 1, npad), dtype=BF16, device=x.device)
+                wt.view(kh * kw, cp, npad)[:, :cin, :n] = weight.detach().permute(2, 3, 1, 0).reshape(kh * kw, cin, n)
+                _hip.call("u2_conv_igemm", dz, wt, dx, None, None, 1, b, 1, npad, npad, b, 1, kh * kw * cp, kh * kw * cp,
+                          1, 1, 0, 0, 1, 1, 0, 0, 0)
+            else:
+                wd = weight_dgrad_layout(weight, cp, npad)
+                _hip.call("u2_conv_igemm", dz, wd, dx, None, None, b, ho, wo, npad, npad, h, w_, cp, cp, kh, kw,
+                          kh - 1 - pad, kw - 1 - pad, 1, stride, 0, 0, 0)
         if ctx.needs_input_grad[1]:
             dwk = torch.zeros((npad, kh * kw, cp), dtype=torch.float32, device=x.device)
             _hip.call("u2_conv_wgrad", x, dz, dwk, b, h, w_, cp, cp, ho, wo, npad, npad, kh, kw, pad, pad, stride, 0)
