@@ -169,7 +169,8 @@ int main(int argc, char** argv) {
       {1, 200, 1, 128, 801, 1, 1, 0, 1, 1, 0, 0, 1, 0, "linear k128 n801 bias"},
       {1, 9, 9, 64, 64, 3, 3, 1, 1, 1, 1, 1, 0, 0, "3x3 accumulate relu"},
   };
-  for (int v = 0; v < 2; ++v)
+  const int cvs[] = {0, 1, 32, 48, 4, 4 | 32};
+  for (int v : cvs)
     for (const auto& c : convs) fails += test_conv(c, v);
   const WgCase wgs[] = {
       {2, 9, 11, 64, 64, 1, 1, 0, 1, "wgrad 1x1 c64 n64"},
@@ -193,7 +194,14 @@ int main(int argc, char** argv) {
       bench_conv("fc1 12544->1024 M8192", 1, 8192, 1, 12544, 1024, 1, 0, 1, v);
       bench_conv("gemm 8192x8192x8192", 1, 8192, 1, 8192, 8192, 1, 0, 1, v);
     }
-    bench_conv("res4 3x3 256->256 B16 (regstage)", 16, 50, 84, 256, 256, 3, 1, 1, 1);
+    const int vs[] = {4 | 16, 4 | 32};  // BK=32 with a 2- / 3-deep ring
+    for (int v : vs) {
+      bench_conv("fpn_out2 3x3 256->256 B16", 16, 200, 336, 256, 256, 3, 1, 1, v);
+      bench_conv("res4 3x3 256->256 B16", 16, 50, 84, 256, 256, 3, 1, 1, v);
+      bench_conv("res4 1x1 1024->256 B16", 16, 50, 84, 1024, 256, 1, 0, 1, v);
+      bench_conv("res2 1x1 64->256 B16", 16, 200, 336, 64, 256, 1, 0, 1, v);
+      bench_conv("gemm 8192x8192x8192", 1, 8192, 1, 8192, 8192, 1, 0, 1, v);
+    }
   }
   return fails ? 1 : 0;
 }

@@ -35,9 +35,8 @@ struct ConvArgs {
   int M, tiles_m, tiles_n;
 };
 
-constexpr int TM = 128;  // pixels per tile
-constexpr int TN = 128;  // output channels per tile
-constexpr int OPITCH = TN + 8;  // bf16 elements per row of the staged output tile
+// Tile shapes: (TM pixels x TN output channels) = 128x128 (default) or 256x64 (layers with <= 64 output channels,
+// so no half of the MFMA work is spent on zero-padded channels).  4 waves, each a 64(n) x 64(m) sub-tile.
 
 template <int BK> __device__ __forceinline__ int swz(int row);
 template <> __device__ __forceinline__ int swz<64>(int row) { return row & 7; }
@@ -47,13 +46,17 @@ __device__ __forceinline__ void glds16(const bf16_t* src, void* lds_dst_wave_bas
   __builtin_amdgcn_global_load_lds(U2_GLB_PTR(src), U2_LDS_PTR(lds_dst_wave_base), 16, 0, 0);
 }
 
-template <int BK, bool GLDS>
+template <int BK, bool GLDS, int TM, int TN, int NST>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
-  constexpr int NCH = (TM * CPR) / 256;       // chunks per thread per operand
+  constexpr int NCHP = (TM * CPR) / 256;      // chunks per thread, pixel operand
+  constexpr int NCHW = (TN * CPR) / 256;      // chunks per thread, weight operand
   constexpr int ROWS_PER_WAVE_INSTR = 64 / CPR;
-  constexpr int TILE_BYTES = TM * BK * 2;     // one operand, one stage
-  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  constexpr int PTILE_BYTES = TM * BK * 2;
+  constexpr int WTILE_BYTES = TN * BK * 2;
+  constexpr int STAGE_BYTES = PTILE_BYTES + WTILE_BYTES;
+  constexpr int OPITCH = TN + 8;              // bf16 elements per row of the staged output tile
+  constexpr int WM = 4 / (TN / 64);           // waves along the pixel dimension
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -67,9 +70,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   const int n0 = tile_n * TN;
 
   // ---- per-thread chunk bookkeeping (rows are fixed across the K loop) ----
-  int p_img[NCH], p_by[NCH], p_bx[NCH];
-  bool p_ok[NCH];
-  const bf16_t* w_row[NCH];
+  int p_img[NCHP], p_by[NCHP], p_bx[NCHP];
+  bool p_ok[NCHP];
+  const bf16_t* w_row[NCHW];
   int cc;  // data chunk (8 channels) this lane fetches within a row; identical for all NCH rows
   {
     const int row_in_instr = lane / CPR;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     cc = slot ^ swz<BK>(row_in_instr);  // (instr,wave) offsets are multiples of the swizzle period
     const int hw = a.Hout * a.Wout;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
+    for (int i = 0; i < NCHP; ++i) {
       const int row = (i * 4 + w) * ROWS_PER_WAVE_INSTR + row_in_instr;
       const int m = m0 + row;
       p_ok[i] = m < a.M;
@@ -89,7 +92,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       p_img[i] = img;
       p_by[i] = oy * a.mul - a.pad_h;
       p_bx[i] = ox * a.mul - a.pad_w;
-      const int n = n0 + row;
+    }
+#pragma unroll
+    for (int i = 0; i < NCHW; ++i) {
+      const int n = n0 + (i * 4 + w) * ROWS_PER_WAVE_INSTR + row_in_instr;
       w_row[i] = (n < a.N) ? a.wt + (size_t)n * ((size_t)a.KH * a.KW * a.C) + cc * 8 : nullptr;
     }
   }
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   const int kc_per_tap = a.C / BK;
   const int nk = a.KH * a.KW * kc_per_tap;
 
-  uint4 stage_regs[GLDS ? 1 : 2 * NCH];
+  uint4 stage_regs[GLDS ? 1 : NCHP + NCHW];
 
   auto issue = [&](int kt, int buf) {
     const int tap = kt / kc_per_tap;
@@ -105,9 +111,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int kh = tap / a.KW;
     const int kw = tap - kh * a.KW;
     unsigned char* pbase = smem + buf * STAGE_BYTES;
-    unsigned char* wbase = pbase + TILE_BYTES;
+    unsigned char* wbase = pbase + PTILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
+    for (int i = 0; i < NCHP; ++i) {
       int sy = p_by[i] + kh, sx = p_bx[i] + kw;
       bool ok = p_ok[i] && sy >= 0 && sx >= 0;
       if (a.div > 1) {
@@ -118,25 +124,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       ok = ok && sy < a.Hin && sx < a.Win;
       const bf16_t* src = ok ? a.in + ((size_t)(p_img[i] * a.Hin + sy) * a.Win + sx) * a.in_ld + c0 + cc * 8
                              : a.zero;
+      if constexpr (GLDS) glds16(src, pbase + (i * 4 + w) * 1024);
+      else stage_regs[i] = *reinterpret_cast<const uint4*>(src);
+    }
+#pragma unroll
+    for (int i = 0; i < NCHW; ++i) {
       const bf16_t* wsrc = w_row[i] ? w_row[i] + (size_t)tap * a.C + c0 : a.zero;
-      if constexpr (GLDS) {
-        glds16(src, pbase + (i * 4 + w) * 1024);
-        glds16(wsrc, wbase + (i * 4 + w) * 1024);
-      } else {
-        stage_regs[2 * i] = *reinterpret_cast<const uint4*>(src);
-        stage_regs[2 * i + 1] = *reinterpret_cast<const uint4*>(wsrc);
-      }
+      if constexpr (GLDS) glds16(wsrc, wbase + (i * 4 + w) * 1024);
+      else stage_regs[NCHP + i] = *reinterpret_cast<const uint4*>(wsrc);
     }
   };
   auto commit = [&](int buf) {  // register-staged path only
     if constexpr (!GLDS) {
       unsigned char* pbase = smem + buf * STAGE_BYTES;
-      unsigned char* wbase = pbase + TILE_BYTES;
+      unsigned char* wbase = pbase + PTILE_BYTES;
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        *reinterpret_cast<uint4*>(pbase + (i * 4 + w) * 1024 + lane * 16) = stage_regs[2 * i];
-        *reinterpret_cast<uint4*>(wbase + (i * 4 + w) * 1024 + lane * 16) = stage_regs[2 * i + 1];
-      }
+      for (int i = 0; i < NCHP; ++i)
+        *reinterpret_cast<uint4*>(pbase + (i * 4 + w) * 1024 + lane * 16) = stage_regs[i];
+#pragma unroll
+      for (int i = 0; i < NCHW; ++i)
+        *reinterpret_cast<uint4*>(wbase + (i * 4 + w) * 1024 + lane * 16) = stage_regs[NCHP + i];
     }
   };
 
@@ -146,14 +153,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int wr = w >> 1;  // which 64-channel half of the tile
-  const int wc = w & 1;   // which 64-pixel half of the tile
+  const int wr = w / WM;  // which 64-channel slice of the tile
+  const int wc = w % WM;  // which 64-pixel slice of the tile
   const int fr = lane & 15;
   const int fg = lane >> 4;
 
   auto compute = [&](int buf) {
     const unsigned char* pbase = smem + buf * STAGE_BYTES;
-    const unsigned char* wbase = pbase + TILE_BYTES;
+    const unsigned char* wbase = pbase + PTILE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       s16x8 wf[4], pf[4];
@@ -174,12 +181,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   };
 
   if constexpr (GLDS) {
-    issue(0, 0);
+    // NST-deep LDS ring: tile kt+NST-1 is in flight while tile kt is multiplied.  LDS-DMA completion is tracked
+    // with counted vmcnt (each tile is LPT global_load_lds per thread, retired in order); a raw s_barrier (not
+    // __syncthreads, which would drain vmcnt to 0) publishes tile kt and frees the slot of tile kt-1.
+    constexpr int LPT = NCHP + NCHW;
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)
+      if (s0 < nk) issue(s0, s0);
     for (int kt = 0; kt < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-      compute(kt & 1);
+      const int ahead = min(nk, kt + NST - 1) - (kt + 1);
+      if (NST > 3 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+      else if (NST > 2 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + NST - 1 < nk) issue(kt + NST - 1, (kt + NST - 1) % NST);
+      compute(kt % NST);
     }
   } else {
     for (int kt = 0; kt < nk; ++kt) {
@@ -194,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   // ---- epilogue: accumulators -> LDS (bf16, [pixel][channel]) -> coalesced 16-byte stores ----
   __syncthreads();
   bf16_t* otile = reinterpret_cast<bf16_t*>(smem);
-  float* red = reinterpret_cast<float*>(smem + TM * OPITCH * 2);  // [2][4][128] floats
+  float* red = reinterpret_cast<float*>(smem + TM * OPITCH * 2);  // [2][4][TN] floats
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int nl = wr * 64 + i * 16 + fg * 4;
@@ -221,15 +239,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   }
   __syncthreads();
 
-  const int cchunk = tid & 15;
-  const int rbase = tid >> 4;
+  constexpr int CPO = TN / 8;           // 16-byte chunks per output row
+  constexpr int RPI = 256 / CPO;        // rows covered per iteration
+  const int cchunk = tid % CPO;
+  const int rbase = tid / CPO;
   float s[8], ss[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
   const bool vec_ok = ((a.out_ld & 7) == 0) && (n0 + cchunk * 8 + 8 <= a.N);
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int row = it * 16 + rbase;
+  for (int it = 0; it < TM / RPI; ++it) {
+    const int row = it * RPI + rbase;
     const int m = m0 + row;
     if (m >= a.M) continue;
     uint4 v = *reinterpret_cast<const uint4*>(otile + row * OPITCH + cchunk * 8);
@@ -263,28 +283,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     }
   }
   if (a.stats) {
-    // lanes sharing (lane & 15) hold partial sums of the same 8 channels
+    // lanes sharing (lane % CPO) hold partial sums of the same 8 channels
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      s[e] += __shfl_xor(s[e], 16, 64);
-      s[e] += __shfl_xor(s[e], 32, 64);
-      ss[e] += __shfl_xor(ss[e], 16, 64);
-      ss[e] += __shfl_xor(ss[e], 32, 64);
+#pragma unroll
+      for (int o = CPO; o < 64; o <<= 1) {
+        s[e] += __shfl_xor(s[e], o, 64);
+        ss[e] += __shfl_xor(ss[e], o, 64);
+      }
     }
-    if (lane < 16) {
+    if (lane < CPO) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        red[(0 * 4 + w) * 128 + lane * 8 + e] = s[e];
-        red[(1 * 4 + w) * 128 + lane * 8 + e] = ss[e];
+        red[(0 * 4 + w) * TN + lane * 8 + e] = s[e];
+        red[(1 * 4 + w) * TN + lane * 8 + e] = ss[e];
       }
     }
     __syncthreads();
-    if (tid < 128 && n0 + tid < a.N) {
+    if (tid < TN && n0 + tid < a.N) {
       float t0 = 0.f, t1 = 0.f;
 #pragma unroll
       for (int ww = 0; ww < 4; ++ww) {
-        t0 += red[(0 * 4 + ww) * 128 + tid];
-        t1 += red[(1 * 4 + ww) * 128 + tid];
+        t0 += red[(0 * 4 + ww) * TN + tid];
+        t1 += red[(1 * 4 + ww) * TN + tid];
       }
       atomicAdd(a.stats + n0 + tid, t0);
       atomicAdd(a.stats + a.N + n0 + tid, t1);
@@ -498,20 +519,47 @@ extern "C" int u2_conv_igemm(const void* in, const void* wt, void* out, const fl
   a.KH = KH; a.KW = KW; a.pad_h = pad_h; a.pad_w = pad_w; a.mul = mul; a.div = div;
   a.relu = relu; a.accumulate = accumulate;
   a.M = B * Hout * Wout;
+  const bool narrow = N <= 64;  // 256 x 64 tile
+  const int TM = narrow ? 256 : 128, TN = narrow ? 64 : 128;
   a.tiles_m = (a.M + TM - 1) / TM;
   a.tiles_n = (N + TN - 1) / TN;
   const dim3 grid(a.tiles_m * a.tiles_n), block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool glds = (variant & 1) == 0;
-  if (C % 64 == 0) {
-    const size_t lds = 2 * 2 * TM * 64 * 2;  // 64 KiB
-    if (glds) hipLaunchKernelGGL((conv_igemm_kernel<64, true>), grid, block, lds, s, a);
-    else      hipLaunchKernelGGL((conv_igemm_kernel<64, false>), grid, block, lds, s, a);
+  // variant: bit0 register staging, bit2 force BK = 32, bits 4-5 LDS ring depth override (0 = default)
+  const int bk = (C % 64 == 0 && !(variant & 4)) ? 64 : 32;
+  int nst = (variant >> 4) & 3;
+  if (nst == 0) nst = (bk == 64) ? 2 : 4;
+  else nst += 1;  // 1 -> 2 stages, 2 -> 3, 3 -> 4
+  if (!glds) nst = 2;
+  size_t lds = (size_t)nst * (TM + TN) * bk * 2;
+  const size_t epi = (size_t)TM * (TN + 8) * 2 + 2 * 4 * TN * 4;
+  if (lds < epi) lds = epi;
+  if (lds > 160 * 1024) return -3;
+#define U2_LAUNCH_CONV(BK_, GL_, TM_, TN_, NST_)                                                                 \
+  do {                                                                                                           \
+    static bool attr_set = false;                                                                                \
+    if (!attr_set) {                                                                                             \
+      (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BK_, GL_, TM_, TN_, NST_>,                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+      attr_set = true;                                                                                           \
+    }                                                                                                            \
+    hipLaunchKernelGGL((conv_igemm_kernel<BK_, GL_, TM_, TN_, NST_>), grid, block, lds, s, a);                   \
+  } while (0)
+#define U2_PICK_NST(BK_, TM_, TN_)                                                                               \
+  do {                                                                                                           \
+    if (!glds) U2_LAUNCH_CONV(BK_, false, TM_, TN_, 2);                                                          \
+    else if (nst == 2) U2_LAUNCH_CONV(BK_, true, TM_, TN_, 2);                                                   \
+    else if (nst == 3) U2_LAUNCH_CONV(BK_, true, TM_, TN_, 3);                                                   \
+    else U2_LAUNCH_CONV(BK_, true, TM_, TN_, 4);                                                                 \
+  } while (0)
+  if (narrow) {
+    if (bk == 64) U2_PICK_NST(64, 256, 64); else U2_PICK_NST(32, 256, 64);
   } else {
-    const size_t lds = TM * OPITCH * 2 + 2 * 4 * 128 * 4;  // epilogue footprint dominates (38 KiB)
-    if (glds) hipLaunchKernelGGL((conv_igemm_kernel<32, true>), grid, block, lds, s, a);
-    else      hipLaunchKernelGGL((conv_igemm_kernel<32, false>), grid, block, lds, s, a);
+    if (bk == 64) U2_PICK_NST(64, 128, 128); else U2_PICK_NST(32, 128, 128);
   }
+#undef U2_PICK_NST
+#undef U2_LAUNCH_CONV
   U2_CHECK_LAUNCH();
   return 0;
 }

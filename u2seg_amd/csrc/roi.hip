@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiLevels lv, cons
 // sampling footprint touches the pixel accumulates  sum_{samples} w_y * w_x * dout[r][ph][pw][:] / count.
 // One workgroup = an 8x8 pixel tile; ROIs overlapping the tile are compacted into LDS first.
 // ---------------------------------------------------------------------------------------------
-struct RoiGeom { float sh, sw, bh, bw; int gh, gw, r; float inv_cnt; };
+struct RoiGeom { float sh, sw, bh, bw; int gh, gw, r; float inv_cnt; int py0, py1, px0, px1; };
 
 // weight with which sample position `pos` (one axis, extent n) feeds pixel `p`; 0 if the sample is skipped
 __device__ __forceinline__ float axis_weight(float pos, int n, int p) {
@@ -172,6 +172,9 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
       g.inv_cnt = gscale / (float)max(g.gh * g.gw, 1);
       // conservative footprint test against the tile (samples lie in [s, e]; taps reach one pixel further)
       const float y_lo = g.sh - 1.f, y_hi = eh + 1.f, x_lo = g.sw - 1.f, x_hi = ew + 1.f;
+      // pixel footprint of the ROI's taps (clamped samples pile up on the border rows / columns)
+      g.py0 = max(0, (int)floorf(g.sh) - 1); g.py1 = min(H - 1, (int)ceilf(eh) + 1);
+      g.px0 = max(0, (int)floorf(g.sw) - 1); g.px1 = min(W - 1, (int)ceilf(ew) + 1);
       if (g.gh > 0 && g.gw > 0 && y_hi >= (float)ty0 && y_lo <= (float)(ty0 + TS) && x_hi >= (float)tx0 && x_lo <= (float)(tx0 + TS)) {
         const int slot = atomicAdd(&nlist, 1);
         list[slot] = g;
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
       const int py = ty0 + pix / TS, px = tx0 + pix % TS;
       if (item >= items || py >= H || px >= W) continue;
       for (int k = 0; k < n; ++k) {
+        if (py < list[k].py0 || py > list[k].py1 || px < list[k].px0 || px > list[k].px1) continue;
         const RoiGeom g = list[k];
         // candidate sample indices along y: positions pos(s) = sh + (s + .5) * bh / gh within (py-1, py+1)
         const float step_y = g.bh / (float)g.gh, step_x = g.bw / (float)g.gw;
