@@ -45,12 +45,24 @@ class KernelTimer:
             s.record()
             orig(name, *args)
             e.record()
-            timer.records.append((name, timer.flops(name, args), s, e, tuple(a for a in args if isinstance(a, int))))
+            timer.records.append((name, timer.flops(name, args), s, e, tuple(a for a in args if isinstance(a, int)),
+                                  timer.alg_bytes(name, args)))
 
         _hip.call = timed_call
         import u2seg_amd.layers.functional as F
 
         F._hip.call = timed_call
+
+    @staticmethod
+    def alg_bytes(name, a):
+        """Algorithmic HBM bytes of one launch: every operand read once, the result written once (bf16 activations)."""
+        if name == "u2_conv_igemm":
+            b, hin, win, c, ho, wo, n, kh, kw, accum = a[5], a[6], a[7], a[8], a[10], a[11], a[12], a[14], a[15], a[21]
+            return 2.0 * (b * hin * win * c + n * kh * kw * c + b * ho * wo * n * (2 if accum else 1))
+        if name == "u2_conv_wgrad":
+            b, hin, win, c, ho, wo, n, kh, kw = a[3], a[4], a[5], a[6], a[8], a[9], a[10], a[12], a[13]
+            return 2.0 * (b * hin * win * c + b * ho * wo * n) + 4.0 * n * kh * kw * c
+        return 0.0
 
     @staticmethod
     def flops(name, a):
@@ -66,11 +78,12 @@ class KernelTimer:
 
     def summary(self):
         out = {}
-        for name, fl, s, e, _ in self.records:
-            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        for name, fl, s, e, _, by in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
             d["flops"] += fl
+            d["bytes"] += by
         return out
 
 
@@ -173,10 +186,18 @@ def main():
         if dom is not None:
             name, d = dom
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            traffic, traffic_note = None, "no PMC profile committed"
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(pmc):
+                pj = json.load(open(pmc))
+                key = {"u2_conv_igemm": "conv_igemm", "u2_conv_wgrad": "conv_wgrad"}[name]
+                traffic = pj[key]["hbm_bytes_per_launch"]
+                traffic_note = "HBM bytes per launch from profiles/r01_pmc_traffic.json (" + pj["note"] + ")"
             roofline = {"kernel": {"u2_conv_igemm": "conv_igemm_kernel (fwd + dgrad launches)",
                                    "u2_conv_wgrad": "conv_wgrad_kernel"}[name],
                         "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                        "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                        "algorithmic_bytes_per_launch_avg": d["bytes"] / d["launches"],
                         "launches_per_step": d["launches"] / args.steps, "avg_launch_ms": d["ms"] / d["launches"],
                         "flop_per_launch_avg": d["flops"] / d["launches"],
                         "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in ks.items()},
@@ -195,7 +216,7 @@ def main():
         }
         if args.per_layer:
             agg = {}
-            for name, fl, s, e, shape in timer.records:
+            for name, fl, s, e, shape, _ in timer.records:
                 d = agg.setdefault((name, shape), [0, 0.0, 0.0])
                 d[0] += 1
                 d[1] += s.elapsed_time(e)

@@ -157,6 +157,11 @@ static void bench_conv(const char* name, int B, int H, int W, int C, int N, int 
 
 int main(int argc, char** argv) {
   int fails = 0;
+  if (argc > 1 && !strcmp(argv[1], "one")) {  // a single shape, for PMC profiling
+    const int v = argc > 2 ? atoi(argv[2]) : 0;
+    bench_conv("fpn_out2 3x3 256->256 B16", 16, 200, 336, 256, 256, 3, 1, 1, v);
+    return 0;
+  }
   hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs %d  abi %d\n", prop.gcnArchName, prop.multiProcessorCount, u2_abi_version());
   const ConvCase convs[] = {
@@ -194,7 +199,7 @@ int main(int argc, char** argv) {
       bench_conv("fc1 12544->1024 M8192", 1, 8192, 1, 12544, 1024, 1, 0, 1, v);
       bench_conv("gemm 8192x8192x8192", 1, 8192, 1, 8192, 8192, 1, 0, 1, v);
     }
-    const int vs[] = {4 | 16, 4 | 32};  // BK=32 with a 2- / 3-deep ring
+    const int vs[] = {4 | 32};
     for (int v : vs) {
       bench_conv("fpn_out2 3x3 256->256 B16", 16, 200, 336, 256, 256, 3, 1, 1, v);
       bench_conv("res4 3x3 256->256 B16", 16, 50, 84, 256, 256, 3, 1, 1, v);

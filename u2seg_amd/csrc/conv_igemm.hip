@@ -105,34 +105,49 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 
   uint4 stage_regs[GLDS ? 1 : NCHP + NCHW];
 
+  // Source pointers are (re)derived once per filter tap; inside a tap consecutive K tiles only advance by BK channels
+  // (rows that read the zero page do not advance).  issue() is always called with kt = 0, 1, 2, ... in order.
+  const bf16_t* p_src[NCHP];
+  int p_inc[NCHP];
+  const bf16_t* w_src[NCHW];
+#pragma unroll
+  for (int i = 0; i < NCHW; ++i) w_src[i] = w_row[i] ? w_row[i] : a.zero;
+  int kc_in_tap = 0, tap_cur = 0;
+
   auto issue = [&](int kt, int buf) {
-    const int tap = kt / kc_per_tap;
-    const int c0 = (kt - tap * kc_per_tap) * BK;
-    const int kh = tap / a.KW;
-    const int kw = tap - kh * a.KW;
+    (void)kt;
+    if (kc_in_tap == 0) {
+      const int kh = tap_cur / a.KW;
+      const int kw = tap_cur - kh * a.KW;
+#pragma unroll
+      for (int i = 0; i < NCHP; ++i) {
+        int sy = p_by[i] + kh, sx = p_bx[i] + kw;
+        bool ok = p_ok[i] && sy >= 0 && sx >= 0;
+        if (a.div > 1) {
+          ok = ok && (sy % a.div == 0) && (sx % a.div == 0);
+          sy /= a.div;
+          sx /= a.div;
+        }
+        ok = ok && sy < a.Hin && sx < a.Win;
+        p_src[i] = ok ? a.in + ((size_t)(p_img[i] * a.Hin + sy) * a.Win + sx) * a.in_ld + cc * 8 : a.zero;
+        p_inc[i] = ok ? BK : 0;
+      }
+    }
     unsigned char* pbase = smem + buf * STAGE_BYTES;
     unsigned char* wbase = pbase + PTILE_BYTES;
 #pragma unroll
     for (int i = 0; i < NCHP; ++i) {
-      int sy = p_by[i] + kh, sx = p_bx[i] + kw;
-      bool ok = p_ok[i] && sy >= 0 && sx >= 0;
-      if (a.div > 1) {
-        ok = ok && (sy % a.div == 0) && (sx % a.div == 0);
-        sy /= a.div;
-        sx /= a.div;
-      }
-      ok = ok && sy < a.Hin && sx < a.Win;
-      const bf16_t* src = ok ? a.in + ((size_t)(p_img[i] * a.Hin + sy) * a.Win + sx) * a.in_ld + c0 + cc * 8
-                             : a.zero;
-      if constexpr (GLDS) glds16(src, pbase + (i * 4 + w) * 1024);
-      else stage_regs[i] = *reinterpret_cast<const uint4*>(src);
+      if constexpr (GLDS) glds16(p_src[i], pbase + (i * 4 + w) * 1024);
+      else stage_regs[i] = *reinterpret_cast<const uint4*>(p_src[i]);
+      p_src[i] += p_inc[i];
     }
 #pragma unroll
     for (int i = 0; i < NCHW; ++i) {
-      const bf16_t* wsrc = w_row[i] ? w_row[i] + (size_t)tap * a.C + c0 : a.zero;
-      if constexpr (GLDS) glds16(wsrc, wbase + (i * 4 + w) * 1024);
-      else stage_regs[NCHP + i] = *reinterpret_cast<const uint4*>(wsrc);
+      if constexpr (GLDS) glds16(w_src[i], wbase + (i * 4 + w) * 1024);
+      else stage_regs[NCHP + i] = *reinterpret_cast<const uint4*>(w_src[i]);
+      if (w_row[i]) w_src[i] += BK;  // [N][T][C]: the reduction index is contiguous across taps
     }
+    if (++kc_in_tap == kc_per_tap) { kc_in_tap = 0; ++tap_cur; }
   };
   auto commit = [&](int buf) {  // register-staged path only
     if constexpr (!GLDS) {
@@ -329,8 +344,13 @@ struct WgradArgs {
 
 constexpr int WP = 32;  // pixels per reduction step
 
+// XOR swizzle of the 16-byte chunk index of the wgrad LDS image [32 px][16 chunks].  A half-wave of a
+// ds_read_b64_tr_b16 touches pixels {4h..4h+3, 8+4h..8+4h+3} x one 32-byte chunk pair; mapping those 8 pixels to 8
+// different chunk pairs (bits 1-3) makes the 8 x 32 B of a half-wave cover one 256-byte bank row exactly.
+__device__ __forceinline__ int wg_swz(int pix) { return ((pix & 3) << 1) | (pix & 8); }
+
 template <bool GLDS, bool TR>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int TILE_BYTES = WP * 128 * 2;  // 8 KB per operand per stage
   constexpr int STAGE_BYTES = 2 * TILE_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
@@ -356,14 +376,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   const int slot = lane & 15;
 
   uint4 stage_regs[GLDS ? 1 : 4];
+  // per-chunk pixel cursor, advanced by WP pixels per step with carries instead of divisions
+  int cm[2], cimg[2], coy[2], cox[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pix = (i * 4 + w) * 4 + pix_in_instr;
+    cm[i] = mbeg + pix;
+    cimg[i] = cm[i] / hw;
+    const int rem = cm[i] - cimg[i] * hw;
+    coy[i] = rem / a.Wout;
+    cox[i] = rem - coy[i] * a.Wout;
+  }
   auto issue = [&](int step, int buf) {
+    (void)step;
     unsigned char* ybase = smem + buf * STAGE_BYTES;
     unsigned char* xbase = ybase + TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pix = (i * 4 + w) * 4 + pix_in_instr;
-      const int cc = slot ^ (pix & 15);
-      const int m = mbeg + step * WP + pix;
+      const int cc = slot ^ wg_swz(pix);
+      const int m = cm[i];
       const bool mok = m < mend;
       const bf16_t* ysrc = (mok && n0 + cc * 8 < a.N) ? a.dy + (size_t)m * a.dy_ld + n0 + cc * 8 : a.zero;
       const bf16_t* xsrc = a.zero;
@@ -371,14 +403,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
         if (direct) {
           xsrc = a.x + (size_t)m * a.x_ld + c0 + cc * 8;
         } else {
-          const int img = m / hw;
-          const int rem = m - img * hw;
-          const int oy = rem / a.Wout;
-          const int ox = rem - oy * a.Wout;
-          const int sy = oy * a.stride - a.pad_h + kh;
-          const int sx = ox * a.stride - a.pad_w + kw;
+          const int sy = coy[i] * a.stride - a.pad_h + kh;
+          const int sx = cox[i] * a.stride - a.pad_w + kw;
           if (sy >= 0 && sy < a.Hin && sx >= 0 && sx < a.Win)
-            xsrc = a.x + ((size_t)(img * a.Hin + sy) * a.Win + sx) * a.x_ld + c0 + cc * 8;
+            xsrc = a.x + ((size_t)(cimg[i] * a.Hin + sy) * a.Win + sx) * a.x_ld + c0 + cc * 8;
         }
       }
       if constexpr (GLDS) {
@@ -387,6 +415,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
       } else {
         stage_regs[2 * i] = *reinterpret_cast<const uint4*>(ysrc);
         stage_regs[2 * i + 1] = *reinterpret_cast<const uint4*>(xsrc);
+      }
+      cm[i] += WP;
+      if (!direct) {
+        if (a.Wout >= WP) {
+          cox[i] += WP;
+          while (cox[i] >= a.Wout) { cox[i] -= a.Wout; if (++coy[i] == a.Hout) { coy[i] = 0; ++cimg[i]; } }
+        } else {
+          cimg[i] = cm[i] / hw;
+          const int rem = cm[i] - cimg[i] * hw;
+          coy[i] = rem / a.Wout;
+          cox[i] = rem - coy[i] * a.Wout;
+        }
       }
     }
   };
@@ -411,31 +451,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   const int wr = w >> 1, wc = w & 1;
   const int fr = lane & 15, fg = lane >> 4;
 
-  // fragment for channel block `cb` (16 channels starting at ch0): lane gets, for channel ch0+fr,
-  // the 8 pixels 8*fg .. 8*fg+7 of the step.  LDS image: [pix][128 ch] bf16, 16-byte chunks
-  // XOR-swizzled by (pix & 15).
-  auto load_frag = [&](const unsigned char* base, int ch0) -> s16x8 {
+  // Fragment for a 16-channel block starting at ch0: lane gets, for channel ch0+fr, the 8 pixels 8*fg .. 8*fg+7 of the
+  // step.  LDS image: [pix][128 ch] bf16, 16-byte chunks XOR-swizzled by wg_swz(pix).  All byte offsets are loop
+  // invariant and computed once.
+  // The 16-channel block index q only occupies bits 1-2 of the 16-byte chunk number (disjoint from the bits set by
+  // wr and the lane), so offset(q) = offset(0) ^ (q << 5): two base offsets per operand instead of a table.
+  constexpr int NOFF = TR ? 2 : 8;
+  int yoff0[NOFF], xoff0[NOFF];
+#pragma unroll
+  for (int e = 0; e < NOFF; ++e) {
+    // TR: ds_read_b64_tr_b16 - lane fr of a 16-lane group supplies the address of 4 contiguous bf16
+    // (pixel p0 + fr/4, channels ch0 + (fr%4)*4 ..+3) and receives channel ch0+fr of pixels p0..p0+3.
+    const int pix = TR ? fg * 8 + e * 4 + (fr >> 2) : fg * 8 + e;
+    const int chl = TR ? (fr & 3) * 4 : fr;
+    const int chy = wr * 64 + chl, chx = wc * 64 + chl;
+    yoff0[e] = pix * 256 + (((chy >> 3) ^ wg_swz(pix)) << 4) + (chy & 7) * 2;
+    xoff0[e] = pix * 256 + (((chx >> 3) ^ wg_swz(pix)) << 4) + (chx & 7) * 2;
+  }
+  auto load_frag = [&](const unsigned char* base, const int* off0, int q) -> s16x8 {
     s16x8 r;
     if constexpr (TR) {
-      // ds_read_b64_tr_b16: lane q (= fr) of a 16-lane group supplies the address of 4 contiguous
-      // bf16 (pixel p0 + q/4, channels ch0 + (q%4)*4 ..+3); it receives channel ch0+q of pixels p0..p0+3.
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int pix = fg * 8 + h * 4 + (fr >> 2);
-        const int ch = ch0 + (fr & 3) * 4;
-        const int chunk = (ch >> 3) ^ (pix & 15);
-        const unsigned char* p = base + pix * 256 + chunk * 16 + (ch & 7) * 2;
-        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(base + (off0[h] ^ (q << 5))));
         r[h * 4 + 0] = v[0]; r[h * 4 + 1] = v[1]; r[h * 4 + 2] = v[2]; r[h * 4 + 3] = v[3];
       }
     } else {
-      const int ch = ch0 + fr;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int pix = fg * 8 + e;
-        const int chunk = (ch >> 3) ^ (pix & 15);
-        r[e] = *reinterpret_cast<const short*>(base + pix * 256 + chunk * 16 + (ch & 7) * 2);
-      }
+      for (int e = 0; e < 8; ++e) r[e] = *reinterpret_cast<const short*>(base + (off0[e] ^ (q << 5)));
     }
     return r;
   };
@@ -446,8 +490,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     s16x8 yf[4], xf[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      yf[q] = load_frag(ybase, wr * 64 + q * 16);
-      xf[q] = load_frag(xbase, wc * 64 + q * 16);
+      yf[q] = load_frag(ybase, yoff0, q);
+      xf[q] = load_frag(xbase, xoff0, q);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
