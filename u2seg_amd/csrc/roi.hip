@@ -139,20 +139,21 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
                                                                    bf16_t* __restrict__ gfeat, int level, int nlevels, int H, int W,
                                                                    int C, int PH, int PW, float scale, float gscale) {
   constexpr int TS = 8, MAXL = 256;
+  constexpr int CPI = 4;   // 16-byte chunks (= 32 channels) per work item: the tap weights are computed once per item
+  constexpr int NQ = 2;    // items per thread (C <= 256: 64 pixels x 8 channel groups = 512 items)
   __shared__ RoiGeom list[MAXL];
   __shared__ int nlist;
   const int b = blockIdx.z;
   const int ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
   const int tid = threadIdx.x;
   const int beg = seg[b * nlevels + level], end = seg[b * nlevels + level + 1];
-  const int cpr = C >> 3;             // 16-byte chunks per pixel
-  const int items = TS * TS * cpr;    // work items per tile
-  // register accumulators: item i handled by thread (i % 256), up to 8 items per thread (C <= 256)
-  float acc[8][8];
+  const int gpp = (C >> 3) / CPI;     // channel groups per pixel
+  const int items = TS * TS * gpp;
+  float acc[NQ][CPI * 8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q)
+  for (int q = 0; q < NQ; ++q)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
+    for (int e = 0; e < CPI * 8; ++e) acc[q][e] = 0.f;
 
   for (int base = beg; base < end; base += MAXL) {
     __syncthreads();
@@ -170,12 +171,10 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
       g.gh = (int)ceilf(rh / (float)PH); g.gw = (int)ceilf(rw / (float)PW);
       g.r = r;
       g.inv_cnt = gscale / (float)max(g.gh * g.gw, 1);
-      // conservative footprint test against the tile (samples lie in [s, e]; taps reach one pixel further)
-      const float y_lo = g.sh - 1.f, y_hi = eh + 1.f, x_lo = g.sw - 1.f, x_hi = ew + 1.f;
       // pixel footprint of the ROI's taps (clamped samples pile up on the border rows / columns)
       g.py0 = max(0, (int)floorf(g.sh) - 1); g.py1 = min(H - 1, (int)ceilf(eh) + 1);
       g.px0 = max(0, (int)floorf(g.sw) - 1); g.px1 = min(W - 1, (int)ceilf(ew) + 1);
-      if (g.gh > 0 && g.gw > 0 && y_hi >= (float)ty0 && y_lo <= (float)(ty0 + TS) && x_hi >= (float)tx0 && x_lo <= (float)(tx0 + TS)) {
+      if (g.gh > 0 && g.gw > 0 && g.py1 >= ty0 && g.py0 < ty0 + TS && g.px1 >= tx0 && g.px0 < tx0 + TS) {
         const int slot = atomicAdd(&nlist, 1);
         list[slot] = g;
       }
@@ -183,16 +182,15 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
     __syncthreads();
     const int n = nlist;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int item = q * 256 + tid;
-      const int cc = item % cpr;
-      const int pix = item / cpr;
+      const int grp = item % gpp;
+      const int pix = item / gpp;
       const int py = ty0 + pix / TS, px = tx0 + pix % TS;
       if (item >= items || py >= H || px >= W) continue;
       for (int k = 0; k < n; ++k) {
         if (py < list[k].py0 || py > list[k].py1 || px < list[k].px0 || px > list[k].px1) continue;
         const RoiGeom g = list[k];
-        // candidate sample indices along y: positions pos(s) = sh + (s + .5) * bh / gh within (py-1, py+1)
         const float step_y = g.bh / (float)g.gh, step_x = g.bw / (float)g.gw;
         const int ny = PH * g.gh, nx = PW * g.gw;
         int sy0 = 0, sy1 = ny - 1, sx0 = 0, sx1 = nx - 1;
@@ -213,35 +211,40 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
           const float ypos = g.sh + ph * g.bh + (iy + 0.5f) * g.bh / (float)g.gh;
           const float wy = axis_weight(ypos, H, py);
           if (wy == 0.f) continue;
-          const bool y_in = !(ypos < -1.0f || ypos > (float)H);
-          if (!y_in) continue;
           for (int sx = sx0; sx <= sx1; ++sx) {
             const int pw = sx / g.gw, ix = sx - pw * g.gw;
             const float xpos = g.sw + pw * g.bw + (ix + 0.5f) * g.bw / (float)g.gw;
             const float wx = axis_weight(xpos, W, px);
             if (wx == 0.f) continue;
-            bf16_t dv[8];
-            *reinterpret_cast<uint4*>(dv) =
-                *reinterpret_cast<const uint4*>(dout + (((size_t)g.r * PH + ph) * PW + pw) * C + cc * 8);
             const float wgt = wy * wx * g.inv_cnt;
+            const bf16_t* src = dout + (((size_t)g.r * PH + ph) * PW + pw) * C + grp * (CPI * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[q][e] += wgt * bf2f(dv[e]);
+            for (int c4 = 0; c4 < CPI; ++c4) {
+              bf16_t dv[8];
+              *reinterpret_cast<uint4*>(dv) = *reinterpret_cast<const uint4*>(src + c4 * 8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[q][c4 * 8 + e] += wgt * bf2f(dv[e]);
+            }
           }
         }
       }
     }
   }
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     const int item = q * 256 + tid;
-    const int cc = item % cpr;
-    const int pix = item / cpr;
+    const int grp = item % gpp;
+    const int pix = item / gpp;
     const int py = ty0 + pix / TS, px = tx0 + pix % TS;
     if (item >= items || py >= H || px >= W) continue;
-    bf16_t o[8];
+    bf16_t* dst = gfeat + (((size_t)b * H + py) * W + px) * C + grp * (CPI * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[q][e]);
-    *reinterpret_cast<uint4*>(gfeat + (((size_t)b * H + py) * W + px) * C + cc * 8) = *reinterpret_cast<const uint4*>(o);
+    for (int c4 = 0; c4 < CPI; ++c4) {
+      bf16_t o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[q][c4 * 8 + e]);
+      *reinterpret_cast<uint4*>(dst + c4 * 8) = *reinterpret_cast<const uint4*>(o);
+    }
   }
 }
 
@@ -588,7 +591,7 @@ extern "C" int u2_batched_nms(const float* boxes, const int* group, const int* c
 extern "C" int u2_roi_align_bwd_gather(void* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,
                                        const float* rois, const int* order, const int* seg, const void* dout, int B, int C,
                                        int PH, int PW, float gscale, void* stream) {
-  if (nlevels < 1 || nlevels > 4 || (C & 7) || C > 256) return -1;
+  if (nlevels < 1 || nlevels > 4 || (C & 31) || C > 256) return -1;
   if (B <= 0) return 0;
   for (int l = 0; l < nlevels; ++l) {
     const dim3 grid((Ws[l] + 7) / 8, (Hs[l] + 7) / 8, B);
