@@ -57,12 +57,12 @@ class OracleModel:
         self.training = True
 
     @classmethod
-    def from_config_file(cls, path, state_dict=None, **kw):
+    def from_config_file(cls, path, state_dict=None, opts=(), **kw):
         from u2seg_amd.config import get_cfg  # host-side config parsing only (no compute)
 
         cfg = get_cfg()
         cfg.merge_from_file(path)
-        cfg.merge_from_list(["MODEL.DEVICE", "cpu"])
+        cfg.merge_from_list(["MODEL.DEVICE", "cpu"] + list(opts))
         if state_dict is None:
             from u2seg_amd.modeling import build_model  # module construction + init only (no forward)
 
@@ -419,3 +419,111 @@ class OracleModel:
             return losses, {"feats": feats, "proposals": proposals, "sampled": sampled, "rpn_labels": labels,
                             "objs": objs, "dlts": dlts}
         return losses
+
+    # ---- inference (panoptic_fpn.py:140-181) ---------------------------------------------------------
+    @staticmethod
+    def paste_masks(masks, boxes, image_shape, threshold=0.5):
+        """layers/mask_ops.py:17-147, full-image grid_sample form (the reference's GPU branch; its CPU branch
+        only skips empty regions and yields the same values)."""
+        n = masks.shape[0]
+        img_h, img_w = image_shape
+        if n == 0:
+            return torch.zeros((0, img_h, img_w), dtype=torch.bool)
+        x0, y0, x1, y1 = torch.split(boxes, 1, dim=1)
+        img_y = torch.arange(0, img_h, dtype=torch.float32) + 0.5
+        img_x = torch.arange(0, img_w, dtype=torch.float32) + 0.5
+        img_y = (img_y - y0) / (y1 - y0) * 2 - 1
+        img_x = (img_x - x0) / (x1 - x0) * 2 - 1
+        gx = img_x[:, None, :].expand(n, img_y.size(1), img_x.size(1))
+        gy = img_y[:, :, None].expand(n, img_y.size(1), img_x.size(1))
+        grid = torch.stack([gx, gy], dim=3)
+        img = F.grid_sample(masks[:, None].float(), grid, align_corners=False)
+        return img[:, 0] >= threshold
+
+    @staticmethod
+    def combine_panoptic(masks, scores, classes, sem, overlap_thr, stuff_area, inst_thr):
+        """meta_arch/panoptic_fpn.py:184-269."""
+        pan = torch.zeros_like(sem, dtype=torch.int32)
+        order = torch.argsort(-scores)
+        seg_id, info = 0, []
+        for i in order.tolist():
+            score = float(scores[i])
+            if score < inst_thr:
+                break
+            m = masks[i]
+            area = int(m.sum())
+            if area == 0:
+                continue
+            inter = int((m & (pan > 0)).sum())
+            if inter * 1.0 / area > overlap_thr:
+                continue
+            if inter > 0:
+                m = m & (pan == 0)
+            seg_id += 1
+            pan[m] = seg_id
+            info.append({"id": seg_id, "isthing": True, "score": score, "category_id": int(classes[i]), "instance_id": i})
+        for label in torch.unique(sem).tolist():
+            if label == 0:
+                continue
+            m = (sem == label) & (pan == 0)
+            area = int(m.sum())
+            if area < stuff_area:
+                continue
+            seg_id += 1
+            pan[m] = seg_id
+            info.append({"id": seg_id, "isthing": False, "category_id": label, "area": area})
+        return pan, info
+
+    def box_inference_single(self, boxes, scores, image_size):
+        """roi_heads/fast_rcnn.py:118-171 (class-agnostic boxes)."""
+        h = self.cfg.MODEL.ROI_HEADS
+        valid = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
+        boxes, scores = boxes[valid], scores[valid]
+        scores = scores[:, :-1]
+        boxes = ops.clip_boxes(boxes, image_size)
+        mask = scores > h.SCORE_THRESH_TEST
+        inds = mask.nonzero()
+        b, s = boxes[inds[:, 0]], scores[mask]
+        keep = ops.nms(b, s, h.NMS_THRESH_TEST, inds[:, 1])[: self.cfg.TEST.DETECTIONS_PER_IMAGE]
+        return b[keep], s[keep], inds[keep, 1]
+
+    @torch.no_grad()
+    def inference(self, batched_inputs):
+        self.training = False
+        m = self.cfg.MODEL
+        images, sizes, _ = self.preprocess(batched_inputs)
+        feats = self.backbone(images)
+        sem = F.interpolate(self.sem_seg_logits(feats).float(), scale_factor=4.0, mode="bilinear", align_corners=False)
+        anchors = self.anchors(feats)
+        objs, dlts = self.rpn_head(feats)
+        proposals = self.rpn_proposals(anchors, objs, dlts, sizes)
+        outs = self.forward_box(feats, proposals, None)
+        probs = sum(F.softmax(o[0].float(), dim=-1) for o in outs) * (1.0 / 3)
+        scores, deltas, props = outs[-1]
+        boxes = ops.apply_deltas(deltas, torch.cat([p["proposal_boxes"] for p in props]), m.ROI_BOX_CASCADE_HEAD.BBOX_REG_WEIGHTS[2])
+        counts = [len(p["proposal_boxes"]) for p in props]
+        results = []
+        scales = [1.0 / self.strides[f] for f in m.ROI_HEADS.IN_FEATURES]
+        feat_list = [feats[f] for f in m.ROI_HEADS.IN_FEATURES]
+        dets = [self.box_inference_single(b, s, sz) for b, s, sz in zip(boxes.split(counts), probs.split(counts), sizes)]
+        pooled = self.q(ops.roi_pool_multilevel(feat_list, [d[0] for d in dets], m.ROI_MASK_HEAD.POOLER_RESOLUTION, scales))
+        logits = self.conv(self.mask_head_features(pooled), "roi_heads.mask_head.predictor") if pooled.shape[0] else pooled
+        off = 0
+        for i, ((b, s, c), size, inp) in enumerate(zip(dets, sizes, batched_inputs)):
+            n = b.shape[0]
+            mp = logits[off : off + n][torch.arange(n), c].float().sigmoid() if n else torch.zeros((0, 28, 28))
+            off += n
+            oh, ow = inp.get("height", size[0]), inp.get("width", size[1])
+            sem_r = F.interpolate(sem[i, :, : size[0], : size[1]][None], size=(oh, ow), mode="bilinear", align_corners=False)[0]
+            bs = b.clone()
+            bs[:, 0::2] *= ow / size[1]
+            bs[:, 1::2] *= oh / size[0]
+            bs = ops.clip_boxes(bs, (oh, ow))
+            ne = ops.nonempty(bs)
+            bs, s2, c2, mp = bs[ne], s[ne], c[ne], mp[ne]
+            masks = self.paste_masks(mp, bs, (oh, ow))
+            pc = m.PANOPTIC_FPN.COMBINE
+            pan = self.combine_panoptic(masks, s2, c2, sem_r.argmax(dim=0), pc.OVERLAP_THRESH, pc.STUFF_AREA_LIMIT,
+                                        pc.INSTANCES_CONFIDENCE_THRESH)
+            results.append({"sem_seg": sem_r, "boxes": bs, "scores": s2, "classes": c2, "masks": masks, "panoptic_seg": pan})
+        return results

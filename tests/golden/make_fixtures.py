@@ -459,6 +459,42 @@ def gen_model_fixture(name, hw, nimg, seed):
     print("wrote", name, out["losses"])
 
 
+def gen_inference_fixture(name, hw, nimg):
+    """Reference PanopticFPN.inference on synthetic images with name-keyed weights (eval-mode BN)."""
+    os.environ.setdefault("CLUSTER_NUM", "800")
+    from detectron2.config import get_cfg
+    from detectron2.modeling import build_model
+
+    from u2seg_amd.data import make_synthetic_batch
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(REF, "configs/COCO-PanopticSegmentation/u2seg_R50_800.yaml"))
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.MODEL.WEIGHTS = ""
+    cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST = 0.0015  # random weights: ~uniform 1/801 scores, keep a useful number of boxes
+    model = build_model(cfg)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            v.copy_(det_fill(k, v))
+    model.eval()
+    batch = to_ref_batch(make_synthetic_batch(nimg, height=hw[0], width=hw[1]))
+    with torch.no_grad():
+        out = model([{k: v for k, v in x.items() if k != "instances"} for x in batch])
+    arrays = {"score_thresh": np.array(0.0015)}
+    for i, o in enumerate(out):
+        inst = o["instances"]
+        arrays["boxes_%d" % i] = inst.pred_boxes.tensor.numpy()
+        arrays["scores_%d" % i] = inst.scores.numpy()
+        arrays["classes_%d" % i] = inst.pred_classes.numpy()
+        arrays["mask_areas_%d" % i] = inst.pred_masks.flatten(1).sum(1).numpy()
+        arrays["sem_argmax_%d" % i] = o["sem_seg"].argmax(0).to(torch.uint8).numpy()
+        arrays["sem_logit_absmean_%d" % i] = np.array(float(o["sem_seg"].abs().mean()))
+        arrays["panoptic_%d" % i] = o["panoptic_seg"][0].numpy().astype(np.int16)
+        arrays["panoptic_info_%d" % i] = np.array(json.dumps(o["panoptic_seg"][1]))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    print("wrote", name, [len(o["instances"]) for o in out], [len(o["panoptic_seg"][1]) for o in out])
+
+
 def gen_op_fixtures(roi_align_ref):
     g = torch.Generator().manual_seed(7)
     out = {}
@@ -607,9 +643,11 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if a.only in ("", "kmeans"):
         gen_kmeans_fixture()
-    if a.only in ("", "ops", "model", "model_small"):
+    if a.only in ("", "ops", "model", "model_small", "inference"):
         ra = import_reference()
         if a.only in ("", "ops"):
             gen_op_fixtures(ra)
         if a.only in ("", "model", "model_small"):
             gen_model_fixture("model_small", (192, 256), 2, 5)
+        if a.only in ("", "inference"):
+            gen_inference_fixture("inference_small", (192, 256), 2)

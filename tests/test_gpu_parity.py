@@ -554,3 +554,73 @@ def test_backbone_and_heads_blockwise_vs_oracle(F):
     print(json.dumps(errs, indent=1))
     for k, v in errs.items():
         assert v < (6e-3 if k == "sem_logits" else 2e-3), (k, errs)
+
+
+def test_inference_tails_vs_oracle_and_reference(F, G):
+    """Inference bookkeeping on identical inputs: score filter + per-class NMS + top-k (bit-exact indices), mask paste
+    (exact except >= 0.5 ties), panoptic merge (bit-exact vs the reference golden), and the full eval forward of the HIP path
+    vs the bf16 oracle (semantic argmax agreement; detections are compared teacher-forced because random-weight scores sit
+    within 1e-6 of each other and their order is rounding noise)."""
+    from oracle.model import OracleModel
+    from tests.golden.make_fixtures import det_fill
+    from u2seg_amd.config import get_cfg
+    from u2seg_amd.data import make_synthetic_batch
+    from u2seg_amd.modeling import build_model
+    from u2seg_amd.modeling.inference import (combine_semantic_and_instance_outputs, fast_rcnn_inference_single_image,
+                                              paste_masks_in_image)
+    from u2seg_amd.structures import Instances
+
+    # 1. panoptic merge vs the reference's own output
+    inst = Instances((96, 128))
+    inst.pred_masks = torch.from_numpy(G["pan_masks"]).to(DEV)
+    inst.scores = torch.from_numpy(G["pan_scores"]).to(DEV)
+    inst.pred_classes = torch.from_numpy(G["pan_classes"]).to(DEV)
+    pan, info = combine_semantic_and_instance_outputs(inst, torch.from_numpy(G["pan_sem"]).to(DEV), 0.5, 4096 // 8, 0.5)
+    assert np.array_equal(pan.cpu().numpy(), G["pan_out"])
+    ref_info = json.loads(str(G["pan_info"]))
+    assert [(d["id"], d["isthing"], d["category_id"]) for d in info] == [(d["id"], d["isthing"], d["category_id"]) for d in ref_info]
+
+    # 2. box filtering + per-class NMS on the oracle's (fp32) boxes and scores
+    g = torch.Generator().manual_seed(21)
+    boxes = torch.rand((400, 2), generator=g) * 150
+    boxes = torch.cat([boxes, boxes + 5 + torch.rand((400, 2), generator=g) * 80], 1)
+    scores = torch.softmax(torch.randn((400, 12), generator=g) * 2, dim=1)
+    cfg = get_cfg()
+    cfg.merge_from_file(CFG)
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "MODEL.ROI_HEADS.SCORE_THRESH_TEST", 0.05])
+    om = OracleModel(cfg, {}, emulate_bf16=False)
+    rb, rs, rc = om.box_inference_single(boxes, scores, (180, 240))
+    res, kept = fast_rcnn_inference_single_image(boxes.to(DEV), scores.to(DEV), (180, 240), 0.05, 0.5, 100)
+    assert torch.equal(res.pred_classes.cpu(), rc) and torch.equal(res.scores.cpu(), rs) and torch.equal(res.pred_boxes.tensor.cpu(), rb)
+
+    # 3. mask paste
+    probs = torch.rand((7, 28, 28), generator=g)
+    pb = torch.tensor([[3.0, 4, 60, 50], [10.5, 2.25, 30.75, 44.5], [0, 0, 128, 96], [100, 70, 127.5, 95.5], [5, 5, 6, 6.5],
+                       [40, 30, 90, 80], [-5, -5, 20, 20]])
+    ref = OracleModel.paste_masks(probs, pb, (96, 128))
+    got = paste_masks_in_image(probs.to(DEV), pb.to(DEV), (96, 128)).cpu()
+    assert (got != ref).float().mean() < 1e-3
+
+    # 4. full eval forward: semantic argmax vs the bf16 oracle, detection count and field contract
+    cfg = get_cfg()
+    cfg.merge_from_file(CFG)
+    cfg.merge_from_list(["MODEL.DEVICE", DEV, "MODEL.ROI_HEADS.SCORE_THRESH_TEST", 0.0015])
+    model = build_model(cfg)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            v.copy_(det_fill(k, v.cpu()).to(DEV))
+    model.eval()
+    batch = [{k: v for k, v in x.items() if k != "instances"} for x in make_synthetic_batch(2, height=192, width=256, device=DEV)]
+    with torch.no_grad():
+        out = model(batch)
+    om = OracleModel(cfg, {k: v.cpu() for k, v in model.state_dict().items()}, emulate_bf16=True)
+    ref = om.inference([{k: v for k, v in x.items() if k != "instances"} for x in make_synthetic_batch(2, height=192, width=256)])
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "inference_small.npz"))
+    for i, (o, r) in enumerate(zip(out, ref)):
+        assert o["sem_seg"].shape == (28, 192, 256) and o["panoptic_seg"][0].dtype == torch.int32
+        agree = (o["sem_seg"].argmax(0).cpu() == r["sem_seg"].argmax(0)).float().mean()
+        agree_ref = (o["sem_seg"].argmax(0).cpu().numpy() == gold["sem_argmax_%d" % i]).mean()
+        assert agree > 0.97 and agree_ref > 0.95, (float(agree), float(agree_ref))
+        inst = o["instances"]
+        assert len(inst) == len(r["scores"]) == 100 and inst.pred_masks.shape == (100, 192, 256) and inst.pred_masks.dtype == torch.bool
+        assert float(inst.scores.max()) == pytest.approx(float(r["scores"].max()), rel=5e-2)

@@ -143,3 +143,28 @@ def test_whole_model_losses_and_grads(golden_dir):
     sum(losses.values()).backward()
     for k, v in fx["grad_norms"].items():
         assert float(om.p[k].grad.double().norm()) == pytest.approx(v, rel=2e-3, abs=1e-6), k
+
+
+def test_whole_model_inference(golden_dir):
+    """fp32 oracle inference == reference PanopticFPN.inference (eval BN, cascade score averaging, per-class NMS, mask
+    paste, panoptic merge) on 2 synthetic 192x256 images with the name-keyed weights."""
+    g = np.load(os.path.join(golden_dir, "inference_small.npz"))
+    om = OracleModel.from_config_file(CFG, opts=["MODEL.ROI_HEADS.SCORE_THRESH_TEST", float(g["score_thresh"])])
+    with torch.no_grad():
+        for k, v in om.p.items():
+            v.copy_(det_fill(k, v))
+    batch = make_synthetic_batch(2, height=192, width=256)
+    out = om.inference([{k: v for k, v in x.items() if k != "instances"} for x in batch])
+    for i, o in enumerate(out):
+        assert len(o["scores"]) == len(g["scores_%d" % i])
+        assert np.array_equal(o["classes"].numpy(), g["classes_%d" % i])       # same detections, same order
+        np.testing.assert_allclose(o["scores"].numpy(), g["scores_%d" % i], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(o["boxes"].numpy(), g["boxes_%d" % i], rtol=1e-4, atol=1e-2)
+        areas = o["masks"].flatten(1).sum(1).numpy()
+        assert np.abs(areas - g["mask_areas_%d" % i]).max() <= 2                  # >= 0.5 ties of the paste
+        sem = o["sem_seg"].argmax(0).numpy()
+        assert (sem != g["sem_argmax_%d" % i]).mean() < 1e-3
+        pan, info = o["panoptic_seg"]
+        ref_info = json.loads(str(g["panoptic_info_%d" % i]))
+        assert [(d["isthing"], d["category_id"]) for d in info] == [(d["isthing"], d["category_id"]) for d in ref_info]
+        assert (pan.numpy() != g["panoptic_%d" % i]).mean() < 1e-3

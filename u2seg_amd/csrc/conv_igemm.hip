@@ -193,6 +193,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], pf[j], acc[i][j], 0, 0, 0);
     }
+#ifdef U2_IGLP
+    __builtin_amdgcn_iglp_opt(U2_IGLP - 1);
+#endif
   };
 
   if constexpr (GLDS) {
