@@ -265,13 +265,15 @@ def build_mask_head(cfg, input_shape):
 
 # ---------------------------------------------------------------------------------------------
 def select_foreground_proposals(proposals, bg_label):
-    """roi_heads.py:46-75."""
-    fg, masks = [], []
-    for p in proposals:
-        gt_classes = p.gt_classes
-        sel = (gt_classes != -1) & (gt_classes != bg_label)
-        fg.append(p[sel.nonzero().squeeze(1)])
-        masks.append(sel)
+    """roi_heads.py:46-75 (one device->host sync for the whole batch instead of one per image)."""
+    masks = [(p.gt_classes != -1) & (p.gt_classes != bg_label) for p in proposals]
+    counts = torch.stack([m.sum() for m in masks]).tolist() if masks else []
+    idx_all = torch.nonzero(torch.cat(masks), as_tuple=True)[0] if masks else None
+    fg, off, start = [], 0, 0
+    for p, m, c in zip(proposals, masks, counts):
+        fg.append(p[idx_all[start : start + c] - off])
+        off += len(p)
+        start += c
     return fg, masks
 
 
@@ -324,9 +326,12 @@ class ROIHeads(nn.Module):
     @torch.no_grad()
     def label_and_sample_proposals(self, proposals, targets):
         """roi_heads.py:220-302."""
+        from . import sampling
+
         if self.proposal_append_gt:
             proposals = add_ground_truth_to_proposals(targets, proposals)
-        out = []
+        batched = sampling.permutation_source() is None
+        per_image = []
         for prop, tgt in zip(proposals, targets):
             has_gt = len(tgt) > 0
             matched_idxs, matched_labels = self._match(prop.proposal_boxes.tensor, tgt, self.proposal_iou_threshold)
@@ -336,8 +341,25 @@ class ROIHeads(nn.Module):
                 gt_classes[matched_labels == -1] = -1
             else:
                 gt_classes = torch.zeros_like(matched_idxs) + self.num_classes
-            fg_idx, bg_idx = subsample_labels(gt_classes, self.batch_size_per_image, self.positive_fraction, self.num_classes)
-            sampled = torch.cat([fg_idx, bg_idx], dim=0)
+            if batched:
+                cand, valid = self._sample_keys(gt_classes)
+                per_image.append((prop, tgt, has_gt, matched_idxs, gt_classes, cand, valid))
+            else:
+                fg_idx, bg_idx = subsample_labels(gt_classes, self.batch_size_per_image, self.positive_fraction, self.num_classes)
+                per_image.append((prop, tgt, has_gt, matched_idxs, gt_classes, torch.cat([fg_idx, bg_idx], dim=0), None))
+        if batched and per_image:
+            # two host synchronisations for the whole batch: the per-image sample counts and one nonzero
+            counts = torch.stack([v.sum() for *_, v in per_image]).tolist()
+            pos = torch.nonzero(torch.cat([v for *_, v in per_image]), as_tuple=True)[0]
+            off = start = 0
+            sampled_all = []
+            for (*_, cand, valid), c in zip(per_image, counts):
+                sampled_all.append(cand[pos[start : start + c] - off])
+                off += valid.numel()
+                start += c
+        out = []
+        for i, (prop, tgt, has_gt, matched_idxs, gt_classes, cand, valid) in enumerate(per_image):
+            sampled = sampled_all[i] if batched else cand
             res = prop[sampled]
             res.gt_classes = gt_classes[sampled]
             if has_gt:
@@ -347,6 +369,24 @@ class ROIHeads(nn.Module):
                         res.set(name, value[sampled_targets])
             out.append(res)
         return out
+
+    def _sample_keys(self, gt_classes):
+        """Random-key form of sampling.py:38-54 for one image without host synchronisation: candidate indices
+        (foreground first) and their validity (<= 128 foreground, background fills up to 512)."""
+        n = gt_classes.numel()
+        total = self.batch_size_per_image
+        max_fg = int(total * self.positive_fraction)
+        key = torch.rand(n, device=gt_classes.device)
+        big = torch.full_like(key, 2.0)
+        is_bg = gt_classes == self.num_classes
+        is_fg = (gt_classes != -1) & ~is_bg
+        kf, kb = min(max_fg, n), min(total, n)
+        fg_key, fg_idx = torch.where(is_fg, key, big).topk(kf, largest=False)
+        bg_key, bg_idx = torch.where(is_bg, key, big).topk(kb, largest=False)
+        fg_valid = fg_key < 1.5
+        num_bg = total - fg_valid.sum()
+        bg_valid = (bg_key < 1.5) & (torch.arange(kb, device=key.device) < num_bg)
+        return torch.cat([fg_idx, bg_idx]), torch.cat([fg_valid, bg_valid])
 
 
 class StandardROIHeads(ROIHeads):
@@ -539,11 +579,18 @@ class CascadeROIHeads(StandardROIHeads):
 
     def _create_proposals_from_boxes(self, boxes, image_sizes):
         out = []
+        clipped = []
         for b, image_size in zip(boxes, image_sizes):
             bx = Boxes(b.detach())
-            bx.clip(image_size)
-            if self.training:
-                bx = bx[bx.nonempty()]
+            bx.tensor = torch.stack((bx.tensor[:, 0].clamp(min=0, max=image_size[1]), bx.tensor[:, 1].clamp(min=0, max=image_size[0]),
+                                     bx.tensor[:, 2].clamp(min=0, max=image_size[1]), bx.tensor[:, 3].clamp(min=0, max=image_size[0])), dim=-1)
+            clipped.append(bx)
+        if self.training:
+            # drop empty boxes (cascade_rcnn.py:291-294); a single sync decides whether any image needs the filter
+            keeps = [bx.nonempty() for bx in clipped]
+            if not bool(torch.stack([k.all() for k in keeps]).all()):
+                clipped = [bx[k] for bx, k in zip(clipped, keeps)]
+        for bx, image_size in zip(clipped, image_sizes):
             prop = Instances(image_size)
             prop.proposal_boxes = bx
             out.append(prop)

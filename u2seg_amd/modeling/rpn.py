@@ -203,6 +203,10 @@ class RPN(nn.Module):
         batch_size_per_image subset (the rest becomes -1).  Returns labels int8 [B, A], match int32 [B, A]."""
         assert self.anchor_boundary_thresh < 0
         match, labels, _ = F.iou_match(anchors_cat, gt_boxes_pad, num_gt, self.iou_thresholds[0], self.iou_thresholds[1], True)
+        from . import sampling
+
+        if sampling.permutation_source() is None:
+            return self._subsample_batched(labels), match
         out = torch.full_like(labels, -1)
         for b in range(labels.shape[0]):
             lab = labels[b]
@@ -210,6 +214,24 @@ class RPN(nn.Module):
             out[b, pos_idx] = 1
             out[b, neg_idx] = 0
         return out, match
+
+    def _subsample_batched(self, labels):
+        """Same distribution as sampling.py:38-54 (a uniformly random subset of <= 128 positives, the rest of the 256
+        filled with uniformly random negatives) for the whole batch without host synchronisation: random keys + top-k."""
+        b, a = labels.shape
+        n = self.batch_size_per_image
+        max_pos = int(n * self.positive_fraction)
+        key = torch.rand((b, a), device=labels.device)
+        big = torch.full_like(key, 2.0)
+        pos_key, pos_idx = torch.where(labels == 1, key, big).topk(max_pos, dim=1, largest=False)
+        neg_key, neg_idx = torch.where(labels == 0, key, big).topk(n, dim=1, largest=False)
+        pos_valid = pos_key < 1.5
+        num_neg = n - pos_valid.sum(dim=1, keepdim=True)
+        neg_valid = (neg_key < 1.5) & (torch.arange(n, device=labels.device)[None] < num_neg)
+        out = torch.full_like(labels, -1)
+        out.scatter_(1, neg_idx, torch.where(neg_valid, 0, -1).to(out.dtype))
+        out.scatter_(1, pos_idx, torch.where(pos_valid, 1, -1).to(out.dtype))
+        return out
 
     def losses(self, anchors_per_level, objs, dlts, labels, match, gt_boxes_pad):
         b = labels.shape[0]

@@ -13,6 +13,10 @@ def set_permutation_source(fn):
     _perm_fn = fn
 
 
+def permutation_source():
+    return _perm_fn
+
+
 def _perm(n, device):
     if _perm_fn is not None:
         return _perm_fn(n, device).to(device)
