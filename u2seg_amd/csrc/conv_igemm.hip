@@ -47,16 +47,19 @@ __device__ __forceinline__ void glds16(const bf16_t* src, void* lds_dst_wave_bas
 }
 
 template <int BK, bool GLDS, int TM, int TN, int NST>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__((TM / 64) * (TN / 64) * 64, 2) void conv_igemm_kernel(const ConvArgs a) {
+  constexpr int NW = (TM / 64) * (TN / 64);   // waves per work-group, one 64x64 sub-tile each
+  constexpr int NT = NW * 64;
   constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
-  constexpr int NCHP = (TM * CPR) / 256;      // chunks per thread, pixel operand
-  constexpr int NCHW = (TN * CPR) / 256;      // chunks per thread, weight operand
+  constexpr int NCHP = (TM * CPR) / NT;       // chunks per thread, pixel operand
+  constexpr int NCHW = (TN * CPR) / NT;       // chunks per thread, weight operand
+  static_assert(NCHP >= 1 && NCHW >= 1, "tile too small for the thread count");
   constexpr int ROWS_PER_WAVE_INSTR = 64 / CPR;
   constexpr int PTILE_BYTES = TM * BK * 2;
   constexpr int WTILE_BYTES = TN * BK * 2;
   constexpr int STAGE_BYTES = PTILE_BYTES + WTILE_BYTES;
   constexpr int OPITCH = TN + 8;              // bf16 elements per row of the staged output tile
-  constexpr int WM = 4 / (TN / 64);           // waves along the pixel dimension
+  constexpr int WM = TM / 64;                 // waves along the pixel dimension
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int hw = a.Hout * a.Wout;
 #pragma unroll
     for (int i = 0; i < NCHP; ++i) {
-      const int row = (i * 4 + w) * ROWS_PER_WAVE_INSTR + row_in_instr;
+      const int row = (i * NW + w) * ROWS_PER_WAVE_INSTR + row_in_instr;
       const int m = m0 + row;
       p_ok[i] = m < a.M;
       const int mm = p_ok[i] ? m : 0;
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < NCHW; ++i) {
-      const int n = n0 + (i * 4 + w) * ROWS_PER_WAVE_INSTR + row_in_instr;
+      const int n = n0 + (i * NW + w) * ROWS_PER_WAVE_INSTR + row_in_instr;
       w_row[i] = (n < a.N) ? a.wt + (size_t)n * ((size_t)a.KH * a.KW * a.C) + cc * 8 : nullptr;
     }
   }
@@ -137,13 +140,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     unsigned char* wbase = pbase + PTILE_BYTES;
 #pragma unroll
     for (int i = 0; i < NCHP; ++i) {
-      if constexpr (GLDS) glds16(p_src[i], pbase + (i * 4 + w) * 1024);
+      if constexpr (GLDS) glds16(p_src[i], pbase + (i * NW + w) * 1024);
       else stage_regs[i] = *reinterpret_cast<const uint4*>(p_src[i]);
       p_src[i] += p_inc[i];
     }
 #pragma unroll
     for (int i = 0; i < NCHW; ++i) {
-      if constexpr (GLDS) glds16(w_src[i], wbase + (i * 4 + w) * 1024);
+      if constexpr (GLDS) glds16(w_src[i], wbase + (i * NW + w) * 1024);
       else stage_regs[NCHP + i] = *reinterpret_cast<const uint4*>(w_src[i]);
       if (w_row[i]) w_src[i] += BK;  // [N][T][C]: the reduction index is contiguous across taps
     }
@@ -155,10 +158,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       unsigned char* wbase = pbase + PTILE_BYTES;
 #pragma unroll
       for (int i = 0; i < NCHP; ++i)
-        *reinterpret_cast<uint4*>(pbase + (i * 4 + w) * 1024 + lane * 16) = stage_regs[i];
+        *reinterpret_cast<uint4*>(pbase + (i * NW + w) * 1024 + lane * 16) = stage_regs[i];
 #pragma unroll
       for (int i = 0; i < NCHW; ++i)
-        *reinterpret_cast<uint4*>(wbase + (i * 4 + w) * 1024 + lane * 16) = stage_regs[NCHP + i];
+        *reinterpret_cast<uint4*>(wbase + (i * NW + w) * 1024 + lane * 16) = stage_regs[NCHP + i];
     }
   };
 
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   // ---- epilogue: accumulators -> LDS (bf16, [pixel][channel]) -> coalesced 16-byte stores ----
   __syncthreads();
   bf16_t* otile = reinterpret_cast<bf16_t*>(smem);
-  float* red = reinterpret_cast<float*>(smem + TM * OPITCH * 2);  // [2][4][TN] floats
+  float* red = reinterpret_cast<float*>(smem + TM * OPITCH * 2);  // [2][NW][TN] floats
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int nl = wr * 64 + i * 16 + fg * 4;
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   __syncthreads();
 
   constexpr int CPO = TN / 8;           // 16-byte chunks per output row
-  constexpr int RPI = 256 / CPO;        // rows covered per iteration
+  constexpr int RPI = NT / CPO;         // rows covered per iteration
   const int cchunk = tid % CPO;
   const int rbase = tid / CPO;
   float s[8], ss[8];
@@ -313,17 +316,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     if (lane < CPO) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        red[(0 * 4 + w) * TN + lane * 8 + e] = s[e];
-        red[(1 * 4 + w) * TN + lane * 8 + e] = ss[e];
+        red[(0 * NW + w) * TN + lane * 8 + e] = s[e];
+        red[(1 * NW + w) * TN + lane * 8 + e] = ss[e];
       }
     }
     __syncthreads();
     if (tid < TN && n0 + tid < a.N) {
       float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < 4; ++ww) {
-        t0 += red[(0 * 4 + ww) * TN + tid];
-        t1 += red[(1 * 4 + ww) * TN + tid];
+      for (int ww = 0; ww < NW; ++ww) {
+        t0 += red[(0 * NW + ww) * TN + tid];
+        t1 += red[(1 * NW + ww) * TN + tid];
       }
       atomicAdd(a.stats + n0 + tid, t0);
       atomicAdd(a.stats + a.N + n0 + tid, t1);
@@ -567,20 +570,24 @@ extern "C" int u2_conv_igemm(const void* in, const void* wt, void* out, const fl
   a.relu = relu; a.accumulate = accumulate;
   a.M = B * Hout * Wout;
   const bool narrow = N <= 64;  // 256 x 64 tile
-  const int TM = narrow ? 256 : 128, TN = narrow ? 64 : 128;
+  const bool big = !narrow && (variant & 8);  // 256 x 128 tile, 8 waves
+  const int TM = (narrow || big) ? 256 : 128, TN = narrow ? 64 : 128;
   a.tiles_m = (a.M + TM - 1) / TM;
   a.tiles_n = (N + TN - 1) / TN;
-  const dim3 grid(a.tiles_m * a.tiles_n), block(256);
+  const dim3 grid(a.tiles_m * a.tiles_n), block(big ? 512 : 256);
   hipStream_t s = (hipStream_t)stream;
   const bool glds = (variant & 1) == 0;
   // variant: bit0 register staging, bit2 force BK = 32, bits 4-5 LDS ring depth override (0 = default)
-  const int bk = (C % 64 == 0 && !(variant & 4)) ? 64 : 32;
+  // Layers whose whole reduction is <= 128 deep (1x1 convs on 64 channels) are HBM-bound and never reach a steady
+  // K loop: a small BK = 32 / 2-stage footprint (38 KB) keeps 4 work-groups per CU in flight instead of 2.
+  const bool shallow = (long long)KH * KW * C <= 128;
+  const int bk = (C % 64 == 0 && !(variant & 4) && !shallow) ? 64 : 32;
   int nst = (variant >> 4) & 3;
-  if (nst == 0) nst = (bk == 64) ? 2 : 4;
+  if (nst == 0) nst = (bk == 64 || shallow) ? 2 : 4;
   else nst += 1;  // 1 -> 2 stages, 2 -> 3, 3 -> 4
   if (!glds) nst = 2;
   size_t lds = (size_t)nst * (TM + TN) * bk * 2;
-  const size_t epi = (size_t)TM * (TN + 8) * 2 + 2 * 4 * TN * 4;
+  const size_t epi = (size_t)TM * (TN + 8) * 2 + 2 * 8 * TN * 4;
   if (lds < epi) lds = epi;
   if (lds > 160 * 1024) return -3;
 #define U2_LAUNCH_CONV(BK_, GL_, TM_, TN_, NST_)                                                                 \
@@ -602,6 +609,8 @@ extern "C" int u2_conv_igemm(const void* in, const void* wt, void* out, const fl
   } while (0)
   if (narrow) {
     if (bk == 64) U2_PICK_NST(64, 256, 64); else U2_PICK_NST(32, 256, 64);
+  } else if (big) {
+    if (bk == 64) U2_PICK_NST(64, 256, 128); else U2_PICK_NST(32, 256, 128);
   } else {
     if (bk == 64) U2_PICK_NST(64, 128, 128); else U2_PICK_NST(32, 128, 128);
   }
