@@ -36,6 +36,10 @@ int u2_conv_wgrad(const void* x, const void* dy, float* dw, int B, int Hin, int 
                   int Hout, int Wout, int N, int dy_ld, int KH, int KW, int pad_h, int pad_w,
                   int stride, int variant, void* stream);
 
+/* fp32 master weights [N][Cin][T] -> bf16 kernel layouts: mode 0 [N][T][Cp] (forward / wgrad), mode 1 [Cp][T][Npad] with the
+ * taps reversed (data gradient), mode 2 [T][Cp][Npad] (data gradient of a fully connected conv). Zero padded. */
+int u2_weight_layout(const float* w, void* out, int N, int Cin, int T, int Cp, int Npad, int mode, void* stream);
+
 /* ---- normalisation / activation (norm.hip) ----------------------------------------------------
  * Replaces nn.SyncBatchNorm / nn.GroupNorm / relu_ chosen by detectron2/layers/batch_norm.py:169-197. */
 int u2_colstats(const void* x, float* out /*[slots][2][C]*/, int slots, int rows_per_slot, int C, int ld, void* stream);

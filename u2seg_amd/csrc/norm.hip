@@ -289,6 +289,40 @@ int ew_grid(size_t total) {
 
 }  // namespace
 
+// fp32 [N][Cin][T] master weights -> bf16 kernel layouts (zero padded):
+//   mode 0: [N][T][Cp]                     forward / wgrad layout
+//   mode 1: [Cp][T][Npad], taps reversed   data-gradient layout (transposed, spatially flipped filter)
+//   mode 2: [T][Cp][Npad]                  data gradient of a "fully connected" conv (plain GEMM)
+__global__ __launch_bounds__(256) void weight_layout_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int N, int Cin,
+                                                            int T, int Cp, int Npad, int mode) {
+  const size_t total = mode == 0 ? (size_t)N * T * Cp : (size_t)Cp * T * Npad;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int n, c, t;
+    if (mode == 0) {
+      c = (int)(i % Cp); const size_t r = i / Cp; t = (int)(r % T); n = (int)(r / T);
+    } else if (mode == 1) {
+      n = (int)(i % Npad); const size_t r = i / Npad; t = T - 1 - (int)(r % T); c = (int)(r / T);
+    } else {
+      n = (int)(i % Npad); const size_t r = i / Npad; c = (int)(r % Cp); t = (int)(r / Cp);
+    }
+    float v = 0.f;
+    if (n < N && c < Cin) v = w[((size_t)n * Cin + c) * T + t];
+    out[i] = f2bf(v);
+  }
+}
+
+extern "C" int u2_weight_layout(const float* w, void* out, int N, int Cin, int T, int Cp, int Npad, int mode, void* stream) {
+  if (mode < 0 || mode > 2) return -1;
+  const size_t total = mode == 0 ? (size_t)N * T * Cp : (size_t)Cp * T * Npad;
+  if (!total) return 0;
+  size_t g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(weight_layout_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)out, N, Cin, T, Cp,
+                     Npad, mode);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int u2_colstats(const void* x, float* out, int slots, int rows_per_slot, int C, int ld, void* stream) {
   if ((C & 7) || (ld & 7)) return -1;
   if (slots <= 0 || rows_per_slot <= 0) return 0;

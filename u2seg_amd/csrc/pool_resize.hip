@@ -247,36 +247,32 @@ template <typename T>
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const T* __restrict__ img, const float* __restrict__ mean,
                                                           const float* __restrict__ stdv, bf16_t* __restrict__ col, int b,
                                                           int h, int w, int Ho, int Wo, int KP) {
-  // one thread per (output pixel, kh): writes the 7*3 = 21 values of that filter row
-  const size_t total = (size_t)Ho * Wo * 8;
-  const float m0 = mean[0], m1 = mean[1], m2 = mean[2];
-  const float s0 = stdv[0], s1 = stdv[1], s2 = stdv[2];
+  // one thread per (output pixel, 16-byte chunk of the K row): 8 gathered taps -> one coalesced 16-byte store
+  const int cpr = KP >> 3;
+  const size_t total = (size_t)Ho * Wo * cpr;
+  const float m[3] = {mean[0], mean[1], mean[2]};
+  const float sd[3] = {stdv[0], stdv[1], stdv[2]};
+  const size_t plane = (size_t)h * w;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int kh = (int)(i & 7);
-    const size_t p = i >> 3;
+    const int cc = (int)(i % cpr);
+    const size_t p = i / cpr;
     const int ox = (int)(p % Wo);
     const int oy = (int)(p / Wo);
-    bf16_t* dst = col + ((size_t)b * Ho * Wo + p) * KP;
-    if (kh == 7) {  // zero the K padding [147, KP)
-      for (int k = 147; k < KP; ++k) dst[k] = 0;
-      continue;
-    }
-    const int iy = oy * 2 - 3 + kh;
-    const bool yok = iy >= 0 && iy < h;
+    bf16_t o[8];
 #pragma unroll
-    for (int kw = 0; kw < 7; ++kw) {
-      const int ix = ox * 2 - 3 + kw;
-      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-      if (yok && ix >= 0 && ix < w) {
-        const size_t o = (size_t)iy * w + ix;
-        v0 = ((float)img[o] - m0) / s0;
-        v1 = ((float)img[(size_t)h * w + o] - m1) / s1;
-        v2 = ((float)img[2 * (size_t)h * w + o] - m2) / s2;
+    for (int e = 0; e < 8; ++e) {
+      const int k = cc * 8 + e;  // k = (kh*7 + kw)*3 + c
+      float v = 0.f;
+      if (k < 147) {
+        const int c = k % 3;
+        const int t = k / 3;
+        const int kw = t % 7, kh = t / 7;
+        const int iy = oy * 2 - 3 + kh, ix = ox * 2 - 3 + kw;
+        if (iy >= 0 && iy < h && ix >= 0 && ix < w) v = ((float)img[c * plane + (size_t)iy * w + ix] - m[c]) / sd[c];
       }
-      dst[(kh * 7 + kw) * 3 + 0] = f2bf(v0);
-      dst[(kh * 7 + kw) * 3 + 1] = f2bf(v1);
-      dst[(kh * 7 + kw) * 3 + 2] = f2bf(v2);
+      o[e] = f2bf(v);
     }
+    *reinterpret_cast<uint4*>(col + ((size_t)b * Ho * Wo + p) * KP + cc * 8) = *reinterpret_cast<const uint4*>(o);
   }
 }
 
@@ -349,7 +345,7 @@ extern "C" int u2_stem_im2col(const void* img, int is_uint8, const float* mean, 
                               int w, int Hpad, int Wpad, int KP, void* stream) {
   if (KP < 147 || (KP & 31)) return -1;
   const int Ho = (Hpad + 6 - 7) / 2 + 1, Wo = (Wpad + 6 - 7) / 2 + 1;
-  const size_t total = (size_t)Ho * Wo * 8;
+  const size_t total = (size_t)Ho * Wo * (KP >> 3);
   if (is_uint8)
     hipLaunchKernelGGL(stem_im2col_kernel<uint8_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t*)img, mean, stdv, (bf16_t*)col, b, h, w, Ho, Wo, KP);

@@ -314,6 +314,11 @@ __global__ __launch_bounds__(256) void iou_match_kernel(const float* __restrict_
   extern __shared__ float sgt[];  // [G][4]
   for (int i = threadIdx.x; i < ng * 4; i += 256) sgt[i] = gt[(size_t)b * G * 4 + i];
   __syncthreads();
+  // per-gt maxima are first reduced inside the work-group (LDS atomics), then one global atomic per gt
+  unsigned int* smax = reinterpret_cast<unsigned int*>(sgt + G * 4);
+  if (gt_max)
+    for (int i = threadIdx.x; i < ng; i += 256) smax[i] = 0u;
+  __syncthreads();
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const float* bx = boxes + ((size_t)(per_image_boxes ? b : 0) * n + i) * 4;
     const float a[4] = {bx[0], bx[1], bx[2], bx[3]};
@@ -322,10 +327,15 @@ __global__ __launch_bounds__(256) void iou_match_kernel(const float* __restrict_
     for (int g = 0; g < ng; ++g) {
       const float v = box_iou(sgt + g * 4, a);
       if (g == 0 || v > best) { best = v; bi = g; }
-      if (gt_max) atomicMax(gt_max + (size_t)b * G + g, __float_as_uint(v));
+      if (gt_max && v > 0.f) atomicMax(smax + g, __float_as_uint(v));
     }
     match[(size_t)b * n + i] = bi;
     mval[(size_t)b * n + i] = best;
+  }
+  if (gt_max) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < ng; i += 256)
+      if (smax[i]) atomicMax(gt_max + (size_t)b * G + i, smax[i]);
   }
 }
 

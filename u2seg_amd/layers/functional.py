@@ -36,25 +36,28 @@ def _check_act(x):
 # --------------------------------------------------------------------------------------------
 # weight layouts
 # --------------------------------------------------------------------------------------------
+def _weight_layout(w, cp, npad, mode):
+    n, cin, kh, kw = w.shape
+    t = kh * kw
+    shape = (n, t, cp) if mode == 0 else ((cp, t, npad) if mode == 1 else (t * cp, 1, npad))
+    out = torch.empty(shape, dtype=BF16, device=w.device)
+    _hip.call("u2_weight_layout", w.detach().float().contiguous(), out, n, cin, t, cp, npad, mode)
+    return out
+
+
 def weight_fwd_layout(w, cp):
     """[N, Cin, KH, KW] fp32 -> [N, KH*KW, cp] bf16 (channels zero padded to cp)."""
-    n, cin, kh, kw = w.shape
-    if cin == cp:
-        return w.detach().to(BF16).permute(0, 2, 3, 1).contiguous().view(n, kh * kw, cp)
-    out = torch.zeros((n, kh * kw, cp), dtype=BF16, device=w.device)
-    out[:, :, :cin] = w.detach().permute(0, 2, 3, 1).reshape(n, kh * kw, cin)
-    return out
+    return _weight_layout(w, cp, 0, 0)
 
 
 def weight_dgrad_layout(w, cp, npad):
     """[N, Cin, KH, KW] fp32 -> [cp, KH*KW, npad] bf16 with the filter flipped in both spatial axes."""
-    n, cin, kh, kw = w.shape
-    src = w.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(cin, kh * kw, n)
-    if cin == cp and n == npad:
-        return src.to(BF16).contiguous()
-    out = torch.zeros((cp, kh * kw, npad), dtype=BF16, device=w.device)
-    out[:cin, :, :n] = src
-    return out
+    return _weight_layout(w, cp, npad, 1)
+
+
+def weight_fc_dgrad_layout(w, cp, npad):
+    """[N, Cin, KH, KW] fp32 -> [KH*KW*cp, 1, npad] bf16: dx[(kh,kw,c)] = sum_n dz[n] W[n, c, kh, kw]."""
+    return _weight_layout(w, cp, npad, 2)
 
 
 # --------------------------------------------------------------------------------------------
@@ -105,8 +108,7 @@ class _Conv2dFn(Function):
             if ho == 1 and wo == 1 and pad == 0 and h == kh and w_ == kw and kh * kw > 1:
                 # "fully connected" conv (box head fc1): every input pixel meets exactly one tap, so the data gradient
                 # is the plain GEMM dx[b, (kh,kw,c)] = dz[b, :] . W[:, (kh,kw,c)]
-                wt = torch.zeros((kh * kw * cp, 1, npad), dtype=BF16, device=x.device)
-                wt.view(kh * kw, cp, npad)[:, :cin, :n] = weight.detach().permute(2, 3, 1, 0).reshape(kh * kw, cin, n)
+                wt = weight_fc_dgrad_layout(weight, cp, npad)
                 _hip.call("u2_conv_igemm", dz, wt, dx, None, None, 1, b, 1, npad, npad, b, 1, kh * kw * cp, kh * kw * cp,
                           1, 1, 0, 0, 1, 1, 0, 0, 0)
             else:
@@ -157,6 +159,7 @@ class _StemConvFn(Function):
                 assert img.dtype == torch.float32
             _hip.call("u2_stem_im2col", img, int(is_u8), pixel_mean, pixel_std, col, i, img.shape[1], img.shape[2],
                       hpad, wpad, kp)
+        # [64, 3, 7, 7] -> K order (kh, kw, c), zero padded to kp: the forward layout of a 49-tap, 3-channel conv flattened
         wk = torch.zeros((n, 1, kp), dtype=BF16, device=weight.device)
         wk[:, 0, :147] = weight.detach().permute(0, 2, 3, 1).reshape(n, 147)
         out = torch.empty((b, ho, wo, n), dtype=BF16, device=weight.device)
