@@ -116,8 +116,9 @@ int u2_batched_nms(const float* boxes, const int* group, const int* cnt, void* w
 
 /* ---- optimizer (optim.hip): solver/build.py:36-37,63-73,119-139 ------------------------------- */
 int u2_sgd_clip_step(float* params, const float* grads, float* momentum_buf, const int* chunk_tensor,
-                     const long long* chunk_begin, const int* chunk_len, int n_chunks, float* norm2, int n_tensors,
-                     const float* wd_per_tensor, float lr, float momentum, float clip, float grad_scale, void* stream);
+                     const long long* chunk_begin, const int* chunk_len, int n_chunks, float* partial /*[n_chunks]*/,
+                     const int* tensor_first_chunk /*[n_tensors + 1]*/, const float* wd_per_tensor, float lr, float momentum,
+                     float clip, float grad_scale, void* stream);
 
 /* ---- k-means over DINO embeddings (kmeans.hip): u2seg/Instance_Clustering/shared/utils/nn_utils.py:304-379 ---- */
 int u2_kmeans_assign(const float* x, const float* c, float* cnorm_ws /*[K]*/, long long* labels, int N, int D, int K,

@@ -624,3 +624,57 @@ def test_inference_tails_vs_oracle_and_reference(F, G):
         inst = o["instances"]
         assert len(inst) == len(r["scores"]) == 100 and inst.pred_masks.shape == (100, 192, 256) and inst.pred_masks.dtype == torch.bool
         assert float(inst.scores.max()) == pytest.approx(float(r["scores"].max()), rel=5e-2)
+
+
+def _two_rank_worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.golden.make_fixtures import det_fill
+    from u2seg_amd.config import get_cfg
+    from u2seg_amd.data import make_synthetic_batch
+    from u2seg_amd.engine import SimpleTrainer
+    from u2seg_amd.modeling import build_model
+    from u2seg_amd.solver import build_optimizer
+
+    torch.cuda.set_device(0)
+    cfg = get_cfg()
+    cfg.merge_from_file(CFG)
+    cfg.merge_from_list(["MODEL.DEVICE", DEV])
+    model = build_model(cfg)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            v.copy_(det_fill(k, v.cpu()).to(DEV))
+    model.train()
+    trainer = SimpleTrainer(model, build_optimizer(cfg, model))
+    torch.manual_seed(100 + rank)
+    losses = trainer.run_step(make_synthetic_batch(1, start_index=rank, height=128, width=160, device=DEV))
+    torch.cuda.synchronize()
+    total = trainer.check_finite()
+    flat = trainer.optimizer.flat_param
+    sig = torch.stack([flat.double().sum(), flat.double().abs().sum(), model.backbone.bottom_up.stem.conv1.norm.running_mean.double().sum()]).cpu()
+    sigs = [torch.zeros_like(sig) for _ in range(world)]
+    dist.all_gather(sigs, sig)
+    out[rank] = (total, [s.tolist() for s in sigs])
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_on_one_gpu():
+    """The multi-process data-parallel path (SyncBN statistic all-reduce inside forward/backward, bucketed gradient
+    all-reduce, grad_scale = 1/world in the optimizer kernel) with two ranks sharing cuda:0 over gloo (RCCL refuses two
+    ranks on one device): both ranks must finish and hold bit-identical parameters and BN running statistics."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_two_rank_worker, args=(2, port, out), nprocs=2, join=True)
+        (t0, s0), (t1, s1) = out[0], out[1]
+    assert t0 == t0 and t1 == t1
+    assert s0[0] == s0[1] == s1[0] == s1[1], (s0, s1)  # identical parameter arena and running stats on both ranks

@@ -9,9 +9,10 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, const int* __restrict__ chunk_tensor,
-                                                    const long long* __restrict__ chunk_begin,
-                                                    const int* __restrict__ chunk_len, float* __restrict__ norm2) {
+// per-chunk sum of squares (no atomics: the per-tensor total is formed in a fixed order so that every data-parallel
+// rank computes bit-identical clip coefficients from the same all-reduced gradients)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, const long long* __restrict__ chunk_begin,
+                                                    const int* __restrict__ chunk_len, float* __restrict__ partial) {
   __shared__ float red[4];
   const int c = blockIdx.x;
   const float* p = g + chunk_begin[c];
@@ -19,13 +20,14 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) { const float v = p[i]; s += v * v; }
   s = block_sum_256(s, red);
-  if (threadIdx.x == 0) atomicAdd(norm2 + chunk_tensor[c], s);
+  if (threadIdx.x == 0) partial[c] = s;
 }
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                                                   const int* __restrict__ chunk_tensor,
                                                   const long long* __restrict__ chunk_begin,
-                                                  const int* __restrict__ chunk_len, const float* __restrict__ norm2,
+                                                  const int* __restrict__ chunk_len, const float* __restrict__ partial,
+                                                  const int* __restrict__ tensor_first_chunk,
                                                   const float* __restrict__ wd_per_tensor, float lr, float momentum,
                                                   float clip, float grad_scale) {
   const int c = blockIdx.x;
@@ -34,7 +36,9 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const f
   const int n = chunk_len[c];
   float coef = 1.f;
   if (clip > 0.f) {
-    const float total = sqrtf(norm2[t]) * grad_scale;
+    float n2 = 0.f;
+    for (int j = tensor_first_chunk[t]; j < tensor_first_chunk[t + 1]; ++j) n2 += partial[j];
+    const float total = sqrtf(n2) * grad_scale;
     coef = fminf(clip / (total + 1e-6f), 1.f);
   }
   coef *= grad_scale;
@@ -51,19 +55,17 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const f
 }  // namespace
 
 extern "C" int u2_sgd_clip_step(float* params, const float* grads, float* momentum_buf, const int* chunk_tensor,
-                                const long long* chunk_begin, const int* chunk_len, int n_chunks, float* norm2,
-                                int n_tensors, const float* wd_per_tensor, float lr, float momentum, float clip,
-                                float grad_scale, void* stream) {
+                                const long long* chunk_begin, const int* chunk_len, int n_chunks, float* partial,
+                                const int* tensor_first_chunk, const float* wd_per_tensor, float lr, float momentum,
+                                float clip, float grad_scale, void* stream) {
   if (n_chunks <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (clip > 0.f) {
-    hipError_t e = hipMemsetAsync(norm2, 0, (size_t)n_tensors * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, s, grads, chunk_tensor, chunk_begin, chunk_len, norm2);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, s, grads, chunk_begin, chunk_len, partial);
     U2_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(sgd_kernel, dim3(n_chunks), dim3(256), 0, s, params, grads, momentum_buf, chunk_tensor, chunk_begin,
-                     chunk_len, norm2, wd_per_tensor, lr, momentum, clip, grad_scale);
+                     chunk_len, partial, tensor_first_chunk, wd_per_tensor, lr, momentum, clip, grad_scale);
   U2_CHECK_LAUNCH();
   return 0;
 }

@@ -29,7 +29,7 @@ class FlatSGD:
         self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_mom = torch.zeros(total, dtype=torch.float32, device=dev)
-        chunk_tensor, chunk_begin, chunk_len, wds = [], [], [], []
+        chunk_tensor, chunk_begin, chunk_len, wds, first_chunk = [], [], [], [], []
         off = 0
         for t, (name_p) in enumerate(self.params):
             p = name_p
@@ -43,6 +43,7 @@ class FlatSGD:
                 wds.append(weight_decay_bias)
             else:
                 wds.append(weight_decay)
+            first_chunk.append(len(chunk_tensor))
             for s in range(0, n, CHUNK):
                 chunk_tensor.append(t)
                 chunk_begin.append(off + s)
@@ -52,7 +53,9 @@ class FlatSGD:
         self.chunk_begin = torch.tensor(chunk_begin, dtype=torch.int64, device=dev)
         self.chunk_len = torch.tensor(chunk_len, dtype=torch.int32, device=dev)
         self.wd = torch.tensor(wds, dtype=torch.float32, device=dev)
-        self.norm2 = torch.zeros(len(self.params), dtype=torch.float32, device=dev)
+        first_chunk.append(len(chunk_tensor))
+        self.first_chunk = torch.tensor(first_chunk, dtype=torch.int32, device=dev)
+        self.partial = torch.zeros(len(chunk_tensor), dtype=torch.float32, device=dev)
         self.lr, self.momentum, self.clip_value = lr, momentum, clip_value
         self.bucket_elems = bucket_bytes // 4
 
@@ -78,7 +81,7 @@ class FlatSGD:
 
     def step(self, grad_scale=1.0):
         _hip.call("u2_sgd_clip_step", self.flat_param, self.flat_grad, self.flat_mom, self.chunk_tensor, self.chunk_begin,
-                  self.chunk_len, self.chunk_tensor.numel(), self.norm2, len(self.params), self.wd, float(self.lr),
+                  self.chunk_len, self.chunk_tensor.numel(), self.partial, self.first_chunk, self.wd, float(self.lr),
                   float(self.momentum), float(self.clip_value), float(grad_scale))
 
     def state_dict(self):
