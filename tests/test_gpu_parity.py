@@ -678,3 +678,49 @@ def test_two_rank_step_on_one_gpu():
         (t0, s0), (t1, s1) = out[0], out[1]
     assert t0 == t0 and t1 == t1
     assert s0[0] == s0[1] == s1[0] == s1[1], (s0, s1)  # identical parameter arena and running stats on both ranks
+
+
+def test_edge_cases_empty_and_ragged_batches(F):
+    """Edge cases the reference exercises in tests/modeling/test_model_e2e.py:103-154: an image without instances
+    (half-empty and fully empty batches), images of different sizes in one batch, and a single tiny image."""
+    from u2seg_amd.config import get_cfg
+    from u2seg_amd.data import make_synthetic_batch
+    from u2seg_amd.modeling import build_model
+    from u2seg_amd.structures import BitMasks, Boxes, Instances
+
+    cfg = get_cfg()
+    cfg.merge_from_file(CFG)
+    cfg.merge_from_list(["MODEL.DEVICE", DEV])
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model.train()
+
+    def empty_like(sample):
+        h, w = sample["image"].shape[-2:]
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(torch.zeros((0, 4), device=DEV))
+        inst.gt_classes = torch.zeros(0, dtype=torch.int64, device=DEV)
+        inst.gt_masks = BitMasks(torch.zeros((0, h, w), dtype=torch.bool, device=DEV))
+        out = dict(sample)
+        out["instances"] = inst
+        return out
+
+    a = make_synthetic_batch(1, height=160, width=224, device=DEV)[0]
+    b = make_synthetic_batch(1, start_index=1, height=128, width=192, device=DEV)[0]  # ragged: padded to 160x224
+    for batch in ([a, empty_like(b)], [empty_like(a), empty_like(b)], [b]):
+        model.zero_grad()
+        losses = model(batch)
+        assert len(losses) == 10
+        total = sum(losses.values())
+        total.backward()
+        assert bool(torch.isfinite(total)), {k: float(v) for k, v in losses.items()}
+        g = model.backbone.bottom_up.res2[0].conv1.weight.grad
+        assert g is not None and bool(torch.isfinite(g).all())
+    # fully empty batch: no foreground anywhere -> mask and box-regression losses are exactly zero
+    losses = model([empty_like(a), empty_like(b)])
+    assert float(losses["loss_mask"]) == 0.0 and float(losses["loss_box_reg_stage0"]) == 0.0
+    model.eval()
+    with torch.no_grad():
+        out = model([{"image": a["image"]}, {"image": b["image"], "height": 256, "width": 384}])
+    assert out[0]["sem_seg"].shape == (28, 160, 224) and out[1]["sem_seg"].shape == (28, 256, 384)
+    assert out[1]["panoptic_seg"][0].shape == (256, 384)
