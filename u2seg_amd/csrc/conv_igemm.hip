@@ -30,9 +30,16 @@ struct ConvArgs {
   const bf16_t* zero;
   int B, Hin, Win, C, in_ld;
   int Hout, Wout, N, out_ld;
-  int KH, KW, pad_h, pad_w, mul, div;
+  int mul;                 // source pixel = output pixel * mul + tap offset
   int relu, accumulate;
   int M, tiles_m, tiles_n;
+  // tap table: tap t reads the source at (qy*mul + tap_dy[t], qx*mul + tap_dx[t]) and uses filter tap tap_w[t]
+  int ntaps, wt_taps;      // taps of this launch / taps in the weight layout ([N][wt_taps][C])
+  int KW, pad_h, pad_w;    // regular launches (remap_out == 0) derive tap t = (kh, kw) arithmetically, no table reads
+  short tap_dy[64], tap_dx[64], tap_w[64];
+  // output placement: pixel (img, qy, qx) of the Hout x Wout grid is written at
+  // (img, qy*out_sy + out_y0, qx*out_sx + out_x0) of the Hfull x Wfull map (identity for ordinary launches)
+  int remap_out, Hfull, Wfull, out_sy, out_sx, out_y0, out_x0;
 };
 
 // Tile shapes: (TM pixels x TN output channels) = 128x128 (default) or 256x64 (layers with <= 64 output channels,
@@ -93,18 +100,18 @@ __global__ __launch_bounds__((TM / 64) * (TN / 64) * 64, 2) void conv_igemm_kern
       const int oy = rem / a.Wout;
       const int ox = rem - oy * a.Wout;
       p_img[i] = img;
-      p_by[i] = oy * a.mul - a.pad_h;
-      p_bx[i] = ox * a.mul - a.pad_w;
+      p_by[i] = oy * a.mul;
+      p_bx[i] = ox * a.mul;
     }
 #pragma unroll
     for (int i = 0; i < NCHW; ++i) {
       const int n = n0 + (i * NW + w) * ROWS_PER_WAVE_INSTR + row_in_instr;
-      w_row[i] = (n < a.N) ? a.wt + (size_t)n * ((size_t)a.KH * a.KW * a.C) + cc * 8 : nullptr;
+      w_row[i] = (n < a.N) ? a.wt + (size_t)n * ((size_t)a.wt_taps * a.C) + cc * 8 : nullptr;
     }
   }
 
   const int kc_per_tap = a.C / BK;
-  const int nk = a.KH * a.KW * kc_per_tap;
+  const int nk = a.ntaps * kc_per_tap;
 
   uint4 stage_regs[GLDS ? 1 : NCHP + NCHW];
 
@@ -115,26 +122,27 @@ __global__ __launch_bounds__((TM / 64) * (TN / 64) * 64, 2) void conv_igemm_kern
   const bf16_t* w_src[NCHW];
 #pragma unroll
   for (int i = 0; i < NCHW; ++i) w_src[i] = w_row[i] ? w_row[i] : a.zero;
-  int kc_in_tap = 0, tap_cur = 0;
+  int kc_in_tap = 0, tap_cur = 0, reg_kh = 0, reg_kw = 0;
 
   auto issue = [&](int kt, int buf) {
     (void)kt;
     if (kc_in_tap == 0) {
-      const int kh = tap_cur / a.KW;
-      const int kw = tap_cur - kh * a.KW;
+      int dy, dx, wtap;
+      if (a.remap_out) {
+        dy = a.tap_dy[tap_cur]; dx = a.tap_dx[tap_cur]; wtap = a.tap_w[tap_cur];
+      } else {
+        dy = reg_kh - a.pad_h; dx = reg_kw - a.pad_w; wtap = tap_cur;
+        if (++reg_kw == a.KW) { reg_kw = 0; ++reg_kh; }
+      }
 #pragma unroll
       for (int i = 0; i < NCHP; ++i) {
-        int sy = p_by[i] + kh, sx = p_bx[i] + kw;
-        bool ok = p_ok[i] && sy >= 0 && sx >= 0;
-        if (a.div > 1) {
-          ok = ok && (sy % a.div == 0) && (sx % a.div == 0);
-          sy /= a.div;
-          sx /= a.div;
-        }
-        ok = ok && sy < a.Hin && sx < a.Win;
+        const int sy = p_by[i] + dy, sx = p_bx[i] + dx;
+        const bool ok = p_ok[i] && sy >= 0 && sx >= 0 && sy < a.Hin && sx < a.Win;
         p_src[i] = ok ? a.in + ((size_t)(p_img[i] * a.Hin + sy) * a.Win + sx) * a.in_ld + cc * 8 : a.zero;
         p_inc[i] = ok ? BK : 0;
       }
+#pragma unroll
+      for (int i = 0; i < NCHW; ++i) w_src[i] = w_row[i] ? w_row[i] + (size_t)wtap * a.C : a.zero;
     }
     unsigned char* pbase = smem + buf * STAGE_BYTES;
     unsigned char* wbase = pbase + PTILE_BYTES;
@@ -148,7 +156,7 @@ __global__ __launch_bounds__((TM / 64) * (TN / 64) * 64, 2) void conv_igemm_kern
     for (int i = 0; i < NCHW; ++i) {
       if constexpr (GLDS) glds16(w_src[i], wbase + (i * NW + w) * 1024);
       else stage_regs[NCHP + i] = *reinterpret_cast<const uint4*>(w_src[i]);
-      if (w_row[i]) w_src[i] += BK;  // [N][T][C]: the reduction index is contiguous across taps
+      if (w_row[i]) w_src[i] += BK;
     }
     if (++kc_in_tap == kc_per_tap) { kc_in_tap = 0; ++tap_cur; }
   };
@@ -276,7 +284,16 @@ __global__ __launch_bounds__((TM / 64) * (TN / 64) * 64, 2) void conv_igemm_kern
     uint4 v = *reinterpret_cast<const uint4*>(otile + row * OPITCH + cchunk * 8);
     bf16_t e8[8];
     *reinterpret_cast<uint4*>(e8) = v;
-    bf16_t* dst = a.out + (size_t)m * a.out_ld + n0 + cchunk * 8;
+    size_t orow = (size_t)m;
+    if (a.remap_out) {
+      const int hw = a.Hout * a.Wout;
+      const int img = m / hw;
+      const int rem = m - img * hw;
+      const int qy = rem / a.Wout;
+      const int qx = rem - qy * a.Wout;
+      orow = ((size_t)img * a.Hfull + qy * a.out_sy + a.out_y0) * a.Wfull + qx * a.out_sx + a.out_x0;
+    }
+    bf16_t* dst = a.out + orow * a.out_ld + n0 + cchunk * 8;
     if (a.accumulate) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -554,33 +571,20 @@ const bf16_t* zero_page_ptr() {
 
 }  // namespace
 
-extern "C" int u2_conv_igemm(const void* in, const void* wt, void* out, const float* bias, float* stats,
-                             int B, int Hin, int Win, int C, int in_ld, int Hout, int Wout, int N, int out_ld,
-                             int KH, int KW, int pad_h, int pad_w, int mul, int div, int relu, int accumulate,
-                             int variant, void* stream) {
-  if (C % 32 != 0 || (in_ld & 7) != 0) return -1;
-  if (B <= 0 || Hout <= 0 || Wout <= 0 || N <= 0) return 0;
-  ConvArgs a;
-  a.in = (const bf16_t*)in; a.wt = (const bf16_t*)wt; a.out = (bf16_t*)out; a.bias = bias; a.stats = stats;
-  a.zero = zero_page_ptr();
-  if (!a.zero) return -2;
-  a.B = B; a.Hin = Hin; a.Win = Win; a.C = C; a.in_ld = in_ld;
-  a.Hout = Hout; a.Wout = Wout; a.N = N; a.out_ld = out_ld;
-  a.KH = KH; a.KW = KW; a.pad_h = pad_h; a.pad_w = pad_w; a.mul = mul; a.div = div;
-  a.relu = relu; a.accumulate = accumulate;
-  a.M = B * Hout * Wout;
+namespace {
+
+int launch_conv(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   const bool narrow = N <= 64;  // 256 x 64 tile
   const bool big = !narrow && (variant & 8);  // 256 x 128 tile, 8 waves
   const int TM = (narrow || big) ? 256 : 128, TN = narrow ? 64 : 128;
   a.tiles_m = (a.M + TM - 1) / TM;
   a.tiles_n = (N + TN - 1) / TN;
   const dim3 grid(a.tiles_m * a.tiles_n), block(big ? 512 : 256);
-  hipStream_t s = (hipStream_t)stream;
   const bool glds = (variant & 1) == 0;
-  // variant: bit0 register staging, bit2 force BK = 32, bits 4-5 LDS ring depth override (0 = default)
+  // variant: bit0 register staging, bit2 force BK = 32, bit3 256x128 tile, bits 4-5 LDS ring depth override (0 = default)
   // Layers whose whole reduction is <= 128 deep (1x1 convs on 64 channels) are HBM-bound and never reach a steady
   // K loop: a small BK = 32 / 2-stage footprint (38 KB) keeps 4 work-groups per CU in flight instead of 2.
-  const bool shallow = (long long)KH * KW * C <= 128;
+  const bool shallow = (long long)a.ntaps * C <= 128;
   const int bk = (C % 64 == 0 && !(variant & 4) && !shallow) ? 64 : 32;
   int nst = (variant >> 4) & 3;
   if (nst == 0) nst = (bk == 64 || shallow) ? 2 : 4;
@@ -620,6 +624,65 @@ extern "C" int u2_conv_igemm(const void* in, const void* wt, void* out, const fl
   return 0;
 }
 
+inline int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+}  // namespace
+
+extern "C" int u2_conv_igemm(const void* in, const void* wt, void* out, const float* bias, float* stats,
+                             int B, int Hin, int Win, int C, int in_ld, int Hout, int Wout, int N, int out_ld,
+                             int KH, int KW, int pad_h, int pad_w, int mul, int div, int relu, int accumulate,
+                             int variant, void* stream) {
+  if (C % 32 != 0 || (in_ld & 7) != 0 || KH * KW > 64 || (div > 1 && mul != 1)) return -1;
+  if (B <= 0 || Hout <= 0 || Wout <= 0 || N <= 0) return 0;
+  ConvArgs a;
+  a.in = (const bf16_t*)in; a.wt = (const bf16_t*)wt; a.out = (bf16_t*)out; a.bias = bias; a.stats = stats;
+  a.zero = zero_page_ptr();
+  if (!a.zero) return -2;
+  a.B = B; a.Hin = Hin; a.Win = Win; a.C = C; a.in_ld = in_ld;
+  a.N = N; a.out_ld = out_ld; a.mul = mul; a.relu = relu; a.accumulate = accumulate;
+  a.wt_taps = KH * KW;
+  a.KW = KW; a.pad_h = pad_h; a.pad_w = pad_w;
+  a.Hfull = Hout; a.Wfull = Wout;
+  hipStream_t s = (hipStream_t)stream;
+  if (div <= 1) {
+    a.Hout = Hout; a.Wout = Wout; a.M = B * Hout * Wout;
+    a.ntaps = KH * KW;
+    for (int kh = 0; kh < KH; ++kh)
+      for (int kw = 0; kw < KW; ++kw) {
+        const int t = kh * KW + kw;
+        a.tap_dy[t] = (short)(kh - pad_h); a.tap_dx[t] = (short)(kw - pad_w); a.tap_w[t] = (short)t;
+      }
+    a.remap_out = 0; a.out_sy = a.out_sx = 1; a.out_y0 = a.out_x0 = 0;
+    return launch_conv(a, N, C, variant, s);
+  }
+  // Data gradient of a stride-`div` conv: output pixels of parity class (py, px) only meet the taps with
+  // (py - pad + kh) % div == 0, so each class is its own small stride-1 conv (1, 2, 2 and 4 taps for 3x3 / stride 2)
+  // instead of 9 taps of which 3/4 would multiply the zero page.
+  for (int py = 0; py < div; ++py)
+    for (int px = 0; px < div; ++px) {
+      const int Hq = (Hout - py + div - 1) / div, Wq = (Wout - px + div - 1) / div;
+      if (Hq <= 0 || Wq <= 0) continue;
+      int nt = 0;
+      for (int kh = 0; kh < KH; ++kh) {
+        const int vy = py - pad_h + kh;
+        if (((vy % div) + div) % div) continue;
+        for (int kw = 0; kw < KW; ++kw) {
+          const int vx = px - pad_w + kw;
+          if (((vx % div) + div) % div) continue;
+          a.tap_dy[nt] = (short)floor_div(vy, div); a.tap_dx[nt] = (short)floor_div(vx, div);
+          a.tap_w[nt] = (short)(kh * KW + kw);
+          ++nt;
+        }
+      }
+      a.ntaps = nt;
+      a.Hout = Hq; a.Wout = Wq; a.M = B * Hq * Wq;
+      a.remap_out = 1; a.out_sy = a.out_sx = div; a.out_y0 = py; a.out_x0 = px;
+      const int rc = launch_conv(a, N, C, variant, s);
+      if (rc) return rc;
+    }
+  return 0;
+}
+
 extern "C" int u2_conv_wgrad(const void* x, const void* dy, float* dw, int B, int Hin, int Win, int C, int x_ld,
                              int Hout, int Wout, int N, int dy_ld, int KH, int KW, int pad_h, int pad_w,
                              int stride, int variant, void* stream) {
@@ -635,11 +698,19 @@ extern "C" int u2_conv_wgrad(const void* x, const void* dy, float* dw, int B, in
   a.tiles_n = (N + 127) / 128;
   a.tiles_c = (C + 127) / 128;
   const int tiles = a.tiles_n * a.tiles_c * KH * KW;
-  // aim for ~8 workgroups per CU in total; each split handles a multiple of WP pixels
-  int splits = (2048 + tiles - 1) / tiles;
-  const int max_splits = (a.M + 4 * WP - 1) / (4 * WP);
-  if (splits > max_splits) splits = max_splits;
+  // Pixel splits: fill the chip once (4 resident work-groups per CU = 1024 slots) but keep >= 2048 pixels per
+  // work-group so that the 64 KB fp32-atomic epilogue stays a small fraction; tiny layers fall back to >= 512 groups.
+  int slots = 1024 >> ((variant >> 4) & 3);  // variant bits 4-5: tuning knob
+  int splits = slots / tiles;
   if (splits < 1) splits = 1;
+  const int by_pixels = a.M / 2048 > 1 ? a.M / 2048 : 1;
+  if (splits > by_pixels) splits = by_pixels;
+  if (tiles * splits < 512) {
+    int s2 = (512 + tiles - 1) / tiles;
+    const int cap = a.M / 512 > 1 ? a.M / 512 : 1;
+    if (s2 > cap) s2 = cap;
+    if (s2 > splits) splits = s2;
+  }
   int ppw = (a.M + splits - 1) / splits;
   ppw = ((ppw + WP - 1) / WP) * WP;
   splits = (a.M + ppw - 1) / ppw;
