@@ -35,10 +35,26 @@ int u2_conv_igemm(const void* in, const void* wt, void* out, const float* bias, 
 int u2_conv_wgrad(const void* x, const void* dy, float* dw, int B, int Hin, int Win, int C, int x_ld,
                   int Hout, int Wout, int N, int dy_ld, int KH, int KW, int pad_h, int pad_w,
                   int stride, int variant, void* stream);
+/* Same reduction accumulated into a caller-laid-out destination: dw[n * dw_stride_n + tap * dw_stride_tap + c * dw_stride_c]
+ * for n < n_valid, c < c_valid (tap = kh * KW + kw).  With (Cin*KH*KW, 1, KH*KW) the destination is the reference's
+ * own [N][Cin][KH][KW] parameter gradient (torch.nn.Conv2d.weight.grad, layers/wrappers.py:127-134), so the gradient
+ * lands in the optimizer's flat arena without a temporary, a permute or an accumulate pass. */
+int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int B, int Hin, int Win, int C, int x_ld,
+                       int Hout, int Wout, int N, int dy_ld, int KH, int KW, int pad_h, int pad_w,
+                       int stride, int n_valid, int c_valid, long long dw_stride_n, int dw_stride_tap,
+                       int dw_stride_c, int variant, void* stream);
 
 /* fp32 master weights [N][Cin][T] -> bf16 kernel layouts: mode 0 [N][T][Cp] (forward / wgrad), mode 1 [Cp][T][Npad] with the
  * taps reversed (data gradient), mode 2 [T][Cp][Npad] (data gradient of a fully connected conv). Zero padded. */
 int u2_weight_layout(const float* w, void* out, int N, int Cin, int T, int Cp, int Npad, int mode, void* stream);
+/* The same for a whole table of (parameter, layout) pairs in one launch - run once after the optimizer step on the flat
+ * parameter arena (base + src_offset floats), so that no per-layer layout launch is left in the forward/backward pass. */
+typedef struct U2LayoutDesc {
+  long long src_offset; /* floats from `base` to the [N][Cin][T] fp32 parameter */
+  void* dst;            /* device pointer of the bf16 layout */
+  int N, Cin, T, Cp, Npad, mode;
+} U2LayoutDesc;
+int u2_weight_layout_batched(const float* base, const U2LayoutDesc* table, int n_entries, void* stream);
 
 /* ---- normalisation / activation (norm.hip) ----------------------------------------------------
  * Replaces nn.SyncBatchNorm / nn.GroupNorm / relu_ chosen by detectron2/layers/batch_norm.py:169-197. */
@@ -52,7 +68,7 @@ int u2_norm_bwd_reduce(const void* dout, const void* mask, const void* x, const 
                        float* out /*[slots][2][C]*/, int slots, int rows_per_slot, int C, int ld, int relu, void* stream);
 int u2_bn_finalize_bwd(const float* sums, float count, const float* gamma, const float* mean, const float* invstd,
                        const float* local_sums, float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C,
-                       void* stream);
+                       int accumulate /* dgamma/dbeta += instead of = (parameter gradient arena) */, void* stream);
 int u2_norm_bwd_apply(const void* dout, const void* mask, const void* x, const float* k1, const float* k2,
                       const float* k3, void* dx, void* dres, int slots, int rows_per_slot, int C, int ld, int relu,
                       void* stream);

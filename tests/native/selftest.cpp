@@ -90,7 +90,7 @@ static int test_conv(const ConvCase& c, int variant) {
 
 struct WgCase { int B, Hin, Win, C, N, KH, KW, pad, stride; const char* name; };
 
-static int test_wgrad(const WgCase& c, int variant) {
+static int test_wgrad(const WgCase& c, int variant, bool into = false) {
   const int Hout = (c.Hin + 2 * c.pad - c.KH) / c.stride + 1, Wout = (c.Win + 2 * c.pad - c.KW) / c.stride + 1;
   const int M = c.B * Hout * Wout, T = c.KH * c.KW;
   std::vector<uint16_t> hx((size_t)c.B * c.Hin * c.Win * c.C), hdy((size_t)M * c.N);
@@ -99,11 +99,23 @@ static int test_wgrad(const WgCase& c, int variant) {
   DBuf<uint16_t> dx(hx.size()), ddy(hdy.size());
   DBuf<float> ddw((size_t)c.N * T * c.C);
   dx.up(hx); ddy.up(hdy);
-  int rc = u2_conv_wgrad(dx.d, ddy.d, ddw.d, c.B, c.Hin, c.Win, c.C, c.C, Hout, Wout, c.N, c.N, c.KH, c.KW, c.pad, c.pad,
-                         c.stride, variant, nullptr);
+  const int nv = into ? c.N - 5 : c.N, cv = into ? c.C - 3 : c.C;  // the reference's [N][Cin][KH][KW] with unpadded N, Cin
+  int rc = into ? u2_conv_wgrad_into(dx.d, ddy.d, ddw.d, c.B, c.Hin, c.Win, c.C, c.C, Hout, Wout, c.N, c.N, c.KH, c.KW, c.pad,
+                                     c.pad, c.stride, nv, cv, (long long)cv * T, 1, T, variant, nullptr)
+                : u2_conv_wgrad(dx.d, ddy.d, ddw.d, c.B, c.Hin, c.Win, c.C, c.C, Hout, Wout, c.N, c.N, c.KH, c.KW, c.pad, c.pad,
+                                c.stride, variant, nullptr);
   HIPCHK(hipDeviceSynchronize());
   if (rc) { printf("FAIL %-28s v%d launch rc=%d\n", c.name, variant, rc); return 1; }
   auto got = ddw.down();
+  if (into) {  // back to [N][T][C] for the comparison; everything past the valid block must still be zero
+    std::vector<float> re((size_t)c.N * T * c.C, 0.f);
+    for (int n = 0; n < nv; ++n)
+      for (int k = 0; k < cv; ++k)
+        for (int t = 0; t < T; ++t) re[((size_t)n * T + t) * c.C + k] = got[((size_t)n * cv + k) * T + t];
+    for (size_t i = (size_t)nv * cv * T; i < got.size(); ++i)
+      if (got[i] != 0.f) { printf("FAIL %-28s wrote past the valid block\n", c.name); return 1; }
+    got = re;
+  }
   std::vector<double> ref((size_t)c.N * T * c.C, 0.0);
   for (int m = 0; m < M; ++m) {
     const int img = m / (Hout * Wout), rem = m % (Hout * Wout), oy = rem / Wout, ox = rem % Wout;
@@ -120,9 +132,12 @@ static int test_wgrad(const WgCase& c, int variant) {
       }
   }
   double max_err = 0, max_ref = 0;
-  for (size_t i = 0; i < ref.size(); ++i) { max_err = fmax(max_err, fabs(ref[i] - got[i])); max_ref = fmax(max_ref, fabs(ref[i])); }
+  for (size_t i = 0; i < ref.size(); ++i) {
+    if (into && ((int)(i % c.C) >= cv || (int)(i / ((size_t)T * c.C)) >= nv)) continue;
+    max_err = fmax(max_err, fabs(ref[i] - got[i])); max_ref = fmax(max_ref, fabs(ref[i]));
+  }
   const bool ok = max_err <= 2e-3 * max_ref + 1e-3;
-  printf("%s %-28s v%d  max_err %.4g (max_ref %.4g)\n", ok ? "PASS" : "FAIL", c.name, variant, max_err, max_ref);
+  printf("%s %-28s v%d%s  max_err %.4g (max_ref %.4g)\n", ok ? "PASS" : "FAIL", c.name, variant, into ? " into" : "", max_err, max_ref);
   return ok ? 0 : 1;
 }
 
@@ -136,21 +151,28 @@ static void bench_conv(const char* name, int B, int H, int W, int C, int N, int 
   std::vector<uint16_t> hy(ddy.n); for (auto& v : hy) v = f2bf(frand()); ddy.up(hy);
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   const double flop = 2.0 * M * N * K * K * C;
-  for (int pass = 0; pass < 2; ++pass) {
+  auto wgrad_into = [&]() {
+    u2_conv_wgrad_into(din.d, ddy.d, dgw.d, B, H, W, C, C, Hout, Wout, N, N, K, K, pad, pad, stride, N, C, (long long)C * K * K, 1,
+                       K * K, variant, nullptr);
+  };
+  for (int pass = 0; pass < 3; ++pass) {
+    if (pass == 2 && K == 1) break;
     const int iters = 10;
     for (int i = 0; i < 2; ++i) {
       if (pass == 0) u2_conv_igemm(din.d, dw.d, dout.d, nullptr, dst.d, B, H, W, C, C, Hout, Wout, N, N, K, K, pad, pad, stride, 1, 0, 0, variant, nullptr);
-      else u2_conv_wgrad(din.d, ddy.d, dgw.d, B, H, W, C, C, Hout, Wout, N, N, K, K, pad, pad, stride, variant, nullptr);
+      else if (pass == 1) u2_conv_wgrad(din.d, ddy.d, dgw.d, B, H, W, C, C, Hout, Wout, N, N, K, K, pad, pad, stride, variant, nullptr);
+      else wgrad_into();
     }
     HIPCHK(hipEventRecord(e0));
     for (int i = 0; i < iters; ++i) {
       if (pass == 0) u2_conv_igemm(din.d, dw.d, dout.d, nullptr, dst.d, B, H, W, C, C, Hout, Wout, N, N, K, K, pad, pad, stride, 1, 0, 0, variant, nullptr);
-      else u2_conv_wgrad(din.d, ddy.d, dgw.d, B, H, W, C, C, Hout, Wout, N, N, K, K, pad, pad, stride, variant, nullptr);
+      else if (pass == 1) u2_conv_wgrad(din.d, ddy.d, dgw.d, B, H, W, C, C, Hout, Wout, N, N, K, K, pad, pad, stride, variant, nullptr);
+      else wgrad_into();
     }
     HIPCHK(hipEventRecord(e1)); HIPCHK(hipEventSynchronize(e1));
     float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
     const double bytes = pass == 0 ? 2.0 * ((double)B * H * W * C + (double)M * N) : 2.0 * ((double)B * H * W * C + (double)M * N);
-    printf("BENCH %-26s %-5s v%d  %8.3f ms  %8.1f TFLOP/s  %7.1f GB/s(min traffic)\n", name, pass == 0 ? "fwd" : "wgrad", variant, ms,
+    printf("BENCH %-26s %-5s v%d  %8.3f ms  %8.1f TFLOP/s  %7.1f GB/s(min traffic)\n", name, pass == 0 ? "fwd" : pass == 1 ? "wgrad" : "wginto", variant, ms,
            flop / ms * 1e-9, bytes / ms * 1e-6);
   }
 }
@@ -185,6 +207,7 @@ int main(int argc, char** argv) {
   };
   for (int v = 0; v < 4; ++v)
     for (const auto& c : wgs) fails += test_wgrad(c, v);
+  for (const auto& c : wgs) fails += test_wgrad(c, 0, true);
   printf("SELFTEST %s (%d failures)\n", fails ? "FAILED" : "OK", fails);
   if (argc > 1 && !strcmp(argv[1], "bench")) {
     for (int v = 0; v < 1; ++v) {

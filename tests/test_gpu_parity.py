@@ -403,6 +403,58 @@ def test_rpn_loss(F):
         assert rel_err(dd[i].grad[..., : 4 * A].float().cpu(), dv[i].grad) < 1e-2
 
 
+def test_arena_direct_grads_and_cached_layouts(F):
+    """Under solver.FlatSGD the 1x1-conv / linear weight gradients and the BN affine gradients are accumulated by the
+    kernels straight into the optimizer's arena, and the bf16 weight layouts are cached and rewritten in one launch per
+    step.  Both must be indistinguishable from the plain autograd path (no optimizer) on the same inputs."""
+    import copy
+
+    from u2seg_amd.layers.modules import BatchNorm2d, Conv2d, Linear
+    from u2seg_amd.solver import FlatSGD
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = Conv2d(64, 96, 1, bias=False, norm=BatchNorm2d(96), activation="relu")
+            self.c2 = Conv2d(96, 64, 3, padding=1, bias=False, norm=BatchNorm2d(64), activation="relu")
+            self.c3 = Conv2d(64, 40, 1, bias=True)
+            self.fc = Linear(64, 70)
+
+        def forward(self, x):
+            y = self.c3(self.c2(self.c1(x)))
+            z = self.fc(x.reshape(-1, 64))
+            return y.float().square().mean() + z.float().square().mean()
+
+    torch.manual_seed(0)
+    plain = Net().to(DEV).train()
+    arena = copy.deepcopy(plain)
+    opt = FlatSGD(arena, lr=0.05, momentum=0.9, weight_decay=1e-4, weight_decay_norm=1e-4, clip_value=0.0)
+    xs = [nhwc(torch.randn(2, 64, 12, 20)) for _ in range(3)]
+    popt = torch.optim.SGD(plain.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    for it, x in enumerate(xs):
+        opt.zero_grad()
+        popt.zero_grad()
+        la, lp = arena(x), plain(x)
+        # cached layouts == layouts built on the fly (fp32-atomic BN statistics may flip a few bf16 roundings)
+        assert float(la) == pytest.approx(float(lp), rel=2e-3), it
+        la.backward()
+        lp.backward()
+        for (k, a), (_, b) in zip(arena.named_parameters(), plain.named_parameters()):
+            assert a.grad.data_ptr() == a._u2_grad.data_ptr(), k  # still the arena view
+            assert rel_err(a.grad, b.grad) < 2e-2, (it, k)
+        opt.step(1.0)
+        popt.step()
+        for (k, a), (_, b) in zip(arena.named_parameters(), plain.named_parameters()):
+            assert rel_err(a.detach(), b.detach()) < 1e-3, (it, k)
+    assert len(opt._layout_entries) >= 6  # fwd + dgrad layouts were registered and refreshed by step()
+    # in-place edits through torch invalidate the cached layouts (autograd version check)
+    with torch.no_grad():
+        arena.c1.weight.mul_(2.0)
+        plain.c1.weight.mul_(2.0)
+    assert float(arena(xs[0])) == pytest.approx(float(plain(xs[0])), rel=2e-3)
+    assert int(arena.state_dict()["c1.norm.num_batches_tracked"]) == 4
+
+
 def test_sgd_clip_step():
     """per-parameter L2 clip to 1.0 + SGD(momentum .9, wd) vs torch on CPU (solver/build.py:36-37,63-73)."""
     from u2seg_amd.solver import FlatSGD

@@ -357,7 +357,9 @@ __global__ __launch_bounds__((TM / 64) * (TN / 64) * 64, 2) void conv_igemm_kern
 struct WgradArgs {
   const bf16_t* x;    // NHWC input of the forward conv (pixel pitch x_ld)
   const bf16_t* dy;   // [M][dy_ld] output gradient
-  float* dw;          // [N][T][C] fp32, accumulated atomically
+  float* dw;          // fp32, accumulated atomically at dw[n * dw_sn + tap * dw_st + c * dw_sc], n < n_valid, c < c_valid
+  long long dw_sn;
+  int dw_st, dw_sc, n_valid, c_valid;
   const bf16_t* zero;
   int B, Hin, Win, C, x_ld;
   int Hout, Wout, N, dy_ld;
@@ -548,11 +550,12 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = c0 + wc * 64 + j * 16 + fr;
-      if (c >= a.C) continue;
+      if (c >= a.c_valid) continue;
+      float* dst = a.dw + (size_t)tap * a.dw_st + (size_t)c * a.dw_sc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wr * 64 + i * 16 + fg * 4 + r;
-        if (n < a.N) atomicAdd(a.dw + ((size_t)n * T + tap) * a.C + c, acc[i][j][r]);
+        if (n < a.n_valid) atomicAdd(dst + n * a.dw_sn, acc[i][j][r]);
       }
     }
 }
@@ -686,11 +689,21 @@ extern "C" int u2_conv_igemm(const void* in, const void* wt, void* out, const fl
 extern "C" int u2_conv_wgrad(const void* x, const void* dy, float* dw, int B, int Hin, int Win, int C, int x_ld,
                              int Hout, int Wout, int N, int dy_ld, int KH, int KW, int pad_h, int pad_w,
                              int stride, int variant, void* stream) {
+  return u2_conv_wgrad_into(x, dy, dw, B, Hin, Win, C, x_ld, Hout, Wout, N, dy_ld, KH, KW, pad_h, pad_w, stride, N, C,
+                            (long long)KH * KW * C, C, 1, variant, stream);
+}
+
+extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int B, int Hin, int Win, int C, int x_ld,
+                                  int Hout, int Wout, int N, int dy_ld, int KH, int KW, int pad_h, int pad_w,
+                                  int stride, int n_valid, int c_valid, long long dw_stride_n, int dw_stride_tap,
+                                  int dw_stride_c, int variant, void* stream) {
   if ((C & 7) != 0 || (x_ld & 7) != 0 || (dy_ld & 7) != 0 || (N & 7) != 0) return -1;
+  if (n_valid > N || c_valid > C) return -1;
   if (B <= 0 || Hout <= 0 || Wout <= 0) return 0;
   WgradArgs a;
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw; a.zero = zero_page_ptr();
   if (!a.zero) return -2;
+  a.dw_sn = dw_stride_n; a.dw_st = dw_stride_tap; a.dw_sc = dw_stride_c; a.n_valid = n_valid; a.c_valid = c_valid;
   a.B = B; a.Hin = Hin; a.Win = Win; a.C = C; a.x_ld = x_ld;
   a.Hout = Hout; a.Wout = Wout; a.N = N; a.dy_ld = dy_ld;
   a.KH = KH; a.KW = KW; a.pad_h = pad_h; a.pad_w = pad_w; a.stride = stride;

@@ -266,13 +266,18 @@ __global__ void bn_finalize_bwd_kernel(const float* __restrict__ sums, float cou
                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                        const float* __restrict__ local_sums, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ k1, float* __restrict__ k2,
-                                       float* __restrict__ k3, int C) {
+                                       float* __restrict__ k3, int C, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float s1 = sums[c], s2 = sums[C + c];
   const float g = gamma[c], is = invstd[c], mu = mean[c];
-  dbeta[c] = local_sums[c];
-  dgamma[c] = local_sums[C + c];
+  if (accumulate) {
+    dbeta[c] += local_sums[c];
+    dgamma[c] += local_sums[C + c];
+  } else {
+    dbeta[c] = local_sums[c];
+    dgamma[c] = local_sums[C + c];
+  }
   const float a = g * is;
   const float b = a * is * s2 / count;
   k1[c] = a;
@@ -293,8 +298,8 @@ int ew_grid(size_t total) {
 //   mode 0: [N][T][Cp]                     forward / wgrad layout
 //   mode 1: [Cp][T][Npad], taps reversed   data-gradient layout (transposed, spatially flipped filter)
 //   mode 2: [T][Cp][Npad]                  data gradient of a "fully connected" conv (plain GEMM)
-__global__ __launch_bounds__(256) void weight_layout_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int N, int Cin,
-                                                            int T, int Cp, int Npad, int mode) {
+__device__ __forceinline__ void weight_layout_body(const float* __restrict__ w, bf16_t* __restrict__ out, int N, int Cin, int T,
+                                                   int Cp, int Npad, int mode) {
   const size_t total = mode == 0 ? (size_t)N * T * Cp : (size_t)Cp * T * Npad;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     int n, c, t;
@@ -309,6 +314,26 @@ __global__ __launch_bounds__(256) void weight_layout_kernel(const float* __restr
     if (n < N && c < Cin) v = w[((size_t)n * Cin + c) * T + t];
     out[i] = f2bf(v);
   }
+}
+
+__global__ __launch_bounds__(256) void weight_layout_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int N, int Cin,
+                                                            int T, int Cp, int Npad, int mode) {
+  weight_layout_body(w, out, N, Cin, T, Cp, Npad, mode);
+}
+
+// One launch for every cached layout of every parameter: blockIdx.y walks the descriptor table.
+__global__ __launch_bounds__(256) void weight_layout_batched_kernel(const float* __restrict__ base,
+                                                                    const U2LayoutDesc* __restrict__ table) {
+  const U2LayoutDesc d = table[blockIdx.y];
+  weight_layout_body(base + d.src_offset, (bf16_t*)d.dst, d.N, d.Cin, d.T, d.Cp, d.Npad, d.mode);
+}
+
+extern "C" int u2_weight_layout_batched(const float* base, const U2LayoutDesc* table, int n_entries, void* stream) {
+  if (n_entries <= 0) return 0;
+  if (n_entries > 65535) return -1;
+  hipLaunchKernelGGL(weight_layout_batched_kernel, dim3(128, n_entries), dim3(256), 0, (hipStream_t)stream, base, table);
+  U2_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int u2_weight_layout(const float* w, void* out, int N, int Cin, int T, int Cp, int Npad, int mode, void* stream) {
@@ -406,9 +431,9 @@ extern "C" int u2_bn_finalize_fwd(const float* sums, float count, const float* g
 
 extern "C" int u2_bn_finalize_bwd(const float* sums, float count, const float* gamma, const float* mean,
                                   const float* invstd, const float* local_sums, float* dgamma, float* dbeta, float* k1,
-                                  float* k2, float* k3, int C, void* stream) {
+                                  float* k2, float* k3, int C, int accumulate, void* stream) {
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, gamma,
-                     mean, invstd, local_sums, dgamma, dbeta, k1, k2, k3, C);
+                     mean, invstd, local_sums, dgamma, dbeta, k1, k2, k3, C, accumulate);
   U2_CHECK_LAUNCH();
   return 0;
 }

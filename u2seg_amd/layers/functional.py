@@ -27,6 +27,36 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+class _ZeroPool:
+    """Small zero-initialised fp32 scratch tensors (statistics, split-K gradient accumulators) carved out of 16 MB
+    chunks: one fill kernel per chunk instead of one per tensor.  Slices are handed out once and never recycled."""
+
+    CHUNK = 1 << 22
+
+    def __init__(self):
+        self.chunk, self.off = None, 0
+
+    def take(self, shape, device):
+        numel = 1
+        for d in shape:
+            numel *= d
+        if numel * 2 > self.CHUNK or numel == 0:
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        n = (numel + 63) // 64 * 64
+        if self.chunk is None or self.chunk.device != device or self.off + n > self.CHUNK:
+            self.chunk, self.off = torch.zeros(self.CHUNK, dtype=torch.float32, device=device), 0
+        v = self.chunk[self.off : self.off + numel].view(shape)
+        self.off += n
+        return v
+
+
+_zero_pool = _ZeroPool()
+
+
+def zeros_f32(shape, device):
+    return _zero_pool.take(tuple(shape), torch.device(device))
+
+
 def _check_act(x):
     assert x.is_cuda and x.dtype == BF16 and x.is_contiguous() and x.dim() == 4 and x.shape[3] % 32 == 0, (
         "expected contiguous NHWC bf16 activation with C %% 32 == 0, got %s %s" % (tuple(x.shape), x.dtype)
@@ -36,28 +66,46 @@ def _check_act(x):
 # --------------------------------------------------------------------------------------------
 # weight layouts
 # --------------------------------------------------------------------------------------------
-def _weight_layout(w, cp, npad, mode):
+def _weight_layout(w, cp, npad, mode, owner=None):
+    """bf16 kernel layout of an fp32 [N, Cin, KH, KW] weight.  `owner` is the nn.Parameter whose memory `w` is (w itself or a
+    reshaped view of it).  Parameters owned by solver.FlatSGD keep their layouts: the optimizer rewrites all of them in
+    one launch right after each step (u2_weight_layout_batched), so the training passes launch no layout kernels.  A cached
+    layout is trusted only while the parameter's autograd version and the optimizer's step stamp are unchanged."""
     n, cin, kh, kw = w.shape
     t = kh * kw
     shape = (n, t, cp) if mode == 0 else ((cp, t, npad) if mode == 1 else (t * cp, 1, npad))
-    out = torch.empty(shape, dtype=BF16, device=w.device)
+    stamp_ref = getattr(owner, "_u2_stamp", None) if owner is not None else None
+    ent = None
+    if stamp_ref is not None:
+        cache = owner.__dict__.setdefault("_u2_layouts", {})
+        key = (n, cin, t, cp, npad, mode)
+        ent = cache.get(key)
+        if ent is not None and ent[1] == owner._version and ent[2] == stamp_ref[0]:
+            return ent[0]
+    out = ent[0] if ent is not None else torch.empty(shape, dtype=BF16, device=w.device)
     _hip.call("u2_weight_layout", w.detach().float().contiguous(), out, n, cin, t, cp, npad, mode)
+    if stamp_ref is not None:
+        if ent is None:
+            ent = cache[key] = [out, owner._version, stamp_ref[0]]
+            owner._u2_layout_register(owner, key, ent)
+        else:
+            ent[1], ent[2] = owner._version, stamp_ref[0]
     return out
 
 
-def weight_fwd_layout(w, cp):
+def weight_fwd_layout(w, cp, owner=None):
     """[N, Cin, KH, KW] fp32 -> [N, KH*KW, cp] bf16 (channels zero padded to cp)."""
-    return _weight_layout(w, cp, 0, 0)
+    return _weight_layout(w, cp, 0, 0, owner)
 
 
-def weight_dgrad_layout(w, cp, npad):
+def weight_dgrad_layout(w, cp, npad, owner=None):
     """[N, Cin, KH, KW] fp32 -> [cp, KH*KW, npad] bf16 with the filter flipped in both spatial axes."""
-    return _weight_layout(w, cp, npad, 1)
+    return _weight_layout(w, cp, npad, 1, owner)
 
 
-def weight_fc_dgrad_layout(w, cp, npad):
+def weight_fc_dgrad_layout(w, cp, npad, owner=None):
     """[N, Cin, KH, KW] fp32 -> [KH*KW*cp, 1, npad] bf16: dx[(kh,kw,c)] = sum_n dz[n] W[n, c, kh, kw]."""
-    return _weight_layout(w, cp, npad, 2)
+    return _weight_layout(w, cp, npad, 2, owner)
 
 
 # --------------------------------------------------------------------------------------------
@@ -68,23 +116,28 @@ class _Conv2dFn(Function):
     (reference: detectron2/layers/wrappers.py:127-134)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu, want_stats):
+    def forward(ctx, x, weight, bias, stride, pad, relu, want_stats, param_ref=None):
         _check_act(x)
+        param = param_ref[0] if param_ref is not None else None  # boxed so that autograd does not treat it as an input
+        wgrad_dst = grad_slot(param) if param is not None else None
         n, cin, kh, kw = weight.shape
         b, h, w_, cp = x.shape
         assert cin <= cp
         ho = (h + 2 * pad - kh) // stride + 1
         wo = (w_ + 2 * pad - kw) // stride + 1
         npad = ceil32(n)
-        wk = weight_fwd_layout(weight, cp)
+        wk = weight_fwd_layout(weight, cp, param)
         alloc = torch.zeros if npad != n else torch.empty
         out = alloc((b, ho, wo, npad), dtype=BF16, device=x.device)
-        stats = torch.zeros((2, n), dtype=torch.float32, device=x.device) if want_stats else None
+        stats = zeros_f32((2, n), x.device) if want_stats else None
         bias_f = bias.detach().float().contiguous() if bias is not None else None
         _hip.call("u2_conv_igemm", x, wk, out, bias_f, stats, b, h, w_, cp, cp, ho, wo, n, npad, kh, kw, pad, pad,
                   stride, 1, int(relu), 0, 0)
         ctx.save_for_backward(x, weight, out if relu else None)
         ctx.cfg = (stride, pad, relu, bias is not None)
+        # 1x1 / linear weights: the gradient is accumulated straight into the optimizer's arena slice
+        ctx.wgrad_dst = wgrad_dst if (kh * kw == 1 and wgrad_dst is not None) else None
+        ctx.param = param
         if want_stats:
             ctx.mark_non_differentiable(stats)
         return out, stats
@@ -108,26 +161,42 @@ class _Conv2dFn(Function):
             if ho == 1 and wo == 1 and pad == 0 and h == kh and w_ == kw and kh * kw > 1:
                 # "fully connected" conv (box head fc1): every input pixel meets exactly one tap, so the data gradient
                 # is the plain GEMM dx[b, (kh,kw,c)] = dz[b, :] . W[:, (kh,kw,c)]
-                wt = weight_fc_dgrad_layout(weight, cp, npad)
+                wt = weight_fc_dgrad_layout(weight, cp, npad, ctx.param)
                 _hip.call("u2_conv_igemm", dz, wt, dx, None, None, 1, b, 1, npad, npad, b, 1, kh * kw * cp, kh * kw * cp,
                           1, 1, 0, 0, 1, 1, 0, 0, 0)
             else:
-                wd = weight_dgrad_layout(weight, cp, npad)
+                wd = weight_dgrad_layout(weight, cp, npad, ctx.param)
                 _hip.call("u2_conv_igemm", dz, wd, dx, None, None, b, ho, wo, npad, npad, h, w_, cp, cp, kh, kw,
                           kh - 1 - pad, kw - 1 - pad, 1, stride, 0, 0, 0)
         if ctx.needs_input_grad[1]:
-            dwk = torch.zeros((npad, kh * kw, cp), dtype=torch.float32, device=x.device)
-            _hip.call("u2_conv_wgrad", x, dz, dwk, b, h, w_, cp, cp, ho, wo, npad, npad, kh, kw, pad, pad, stride, 0)
-            dw = dwk[:n, :, :cin].view(n, kh, kw, cin).permute(0, 3, 1, 2)
+            dst = ctx.wgrad_dst
+            if dst is not None:
+                assert dst.is_contiguous() and dst.dtype == torch.float32 and dst.numel() == n * cin
+                _hip.call("u2_conv_wgrad_into", x, dz, dst, b, h, w_, cp, cp, ho, wo, npad, npad, kh, kw, pad, pad, stride,
+                          n, cin, cin, 1, 1, 0)
+            else:
+                dwk = zeros_f32((npad, kh * kw, cp), x.device)
+                _hip.call("u2_conv_wgrad", x, dz, dwk, b, h, w_, cp, cp, ho, wo, npad, npad, kh, kw, pad, pad, stride, 0)
+                dw = dwk[:n, :, :cin].view(n, kh, kw, cin).permute(0, 3, 1, 2)
         if has_bias and ctx.needs_input_grad[2]:
-            sums = torch.zeros((1, 2, npad), dtype=torch.float32, device=x.device)
+            sums = zeros_f32((1, 2, npad), x.device)
             _hip.call("u2_colstats", dz, sums, 1, b * ho * wo, npad, npad)
             db = sums[0, 0, :n]
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, want_stats=False):
-    out, stats = _Conv2dFn.apply(x, weight, bias, stride, pad, relu, want_stats)
+def grad_slot(param):
+    """The optimizer's flat-arena gradient view of a parameter (solver/build.py:FlatSGD), or None.  Kernels that can
+    accumulate into it directly do so and report no gradient to autograd (no temporary, no AccumulateGrad add)."""
+    return getattr(param, "_u2_grad", None) if torch.is_grad_enabled() and param.requires_grad else None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, want_stats=False, param=None):
+    """`param`: the nn.Parameter that owns `weight`'s memory when `weight` is a reshaped view of it (defaults to `weight`
+    itself when that is a Parameter); it carries the optimizer's gradient slot and the cached kernel layouts."""
+    if param is None and isinstance(weight, torch.nn.Parameter):
+        param = weight
+    out, stats = _Conv2dFn.apply(x, weight, bias, stride, pad, relu, want_stats, (param,) if param is not None else None)
     return (out, stats) if want_stats else out
 
 
@@ -135,7 +204,8 @@ def linear(x2d, weight, bias=None, relu=False):
     """nn.Linear on a [R, K] bf16 matrix (K % 32 == 0); returns [R, ceil32(N)]."""
     r, k = x2d.shape
     n = weight.shape[0]
-    out = conv2d(x2d.view(1, r, 1, k), weight.view(n, weight.shape[1], 1, 1), bias, 1, 0, relu)
+    param = weight if isinstance(weight, torch.nn.Parameter) else None
+    out = conv2d(x2d.view(1, r, 1, k), weight.view(n, weight.shape[1], 1, 1), bias, 1, 0, relu, False, param)
     return out.view(r, -1)
 
 
@@ -163,7 +233,7 @@ class _StemConvFn(Function):
         wk = torch.zeros((n, 1, kp), dtype=BF16, device=weight.device)
         wk[:, 0, :147] = weight.detach().permute(0, 2, 3, 1).reshape(n, 147)
         out = torch.empty((b, ho, wo, n), dtype=BF16, device=weight.device)
-        stats = torch.zeros((2, n), dtype=torch.float32, device=weight.device)
+        stats = zeros_f32((2, n), weight.device)
         m = b * ho * wo
         _hip.call("u2_conv_igemm", col, wk, out, None, stats, 1, m, 1, kp, kp, m, 1, n, n, 1, 1, 0, 0, 1, 1, 0, 0, 0)
         ctx.save_for_backward(col)
@@ -177,7 +247,7 @@ class _StemConvFn(Function):
         n, kp = ctx.n, _StemConvFn.KP
         dout = dout.contiguous()
         m = col.shape[0]
-        dwk = torch.zeros((n, 1, kp), dtype=torch.float32, device=col.device)
+        dwk = zeros_f32((n, 1, kp), col.device)
         _hip.call("u2_conv_wgrad", col, dout, dwk, 1, m, 1, kp, kp, m, 1, n, n, 1, 1, 0, 0, 1, 0)
         dw = dwk[:, 0, :147].view(n, 7, 7, 3).permute(0, 3, 1, 2)
         return dw, None, None, None, None, None
@@ -196,7 +266,7 @@ class _BatchNormActFn(Function):
     residual add + relu_ at backbone/resnet.py:204-210)."""
 
     @staticmethod
-    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps):
+    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, grad_dst=None):
         _check_act(y)
         b, h, w, c = y.shape
         m = b * h * w
@@ -212,6 +282,7 @@ class _BatchNormActFn(Function):
         _hip.call("u2_affine_act", y, scale, shift, residual, out, 1, m, c, c, int(relu))
         ctx.save_for_backward(y, out if relu else None, gamma, mean, invstd)
         ctx.cfg = (relu, count, world, residual is not None)
+        ctx.grad_dst = grad_dst  # (dgamma, dbeta) arena slices or None
         return out
 
     @staticmethod
@@ -221,24 +292,30 @@ class _BatchNormActFn(Function):
         b, h, w, c = y.shape
         m = b * h * w
         dout = dout.contiguous()
-        sums = torch.zeros((2, c), dtype=torch.float32, device=y.device)
+        sums = zeros_f32((2, c), y.device)
         _hip.call("u2_norm_bwd_reduce", dout, out, y, mean, invstd, sums, 1, m, c, c, int(relu))
         local = sums
         if world > 1:
             local = sums.clone()
             dist.all_reduce(sums)
         coef = torch.empty((5, c), dtype=torch.float32, device=y.device)
-        _hip.call("u2_bn_finalize_bwd", sums, count, gamma, mean, invstd, local, coef[0], coef[1], coef[2], coef[3],
-                  coef[4], c)
+        direct = ctx.grad_dst is not None
+        dgamma, dbeta = ctx.grad_dst if direct else (coef[0], coef[1])
+        _hip.call("u2_bn_finalize_bwd", sums, count, gamma, mean, invstd, local, dgamma, dbeta, coef[2], coef[3],
+                  coef[4], c, int(direct))
         dx = torch.empty_like(y)
         dres = torch.empty_like(y) if has_res else None
         _hip.call("u2_norm_bwd_apply", dout, out, y, coef[2], coef[3], coef[4], dx, dres, 1, m, c, c, int(relu))
-        return dx, None, coef[0], coef[1], None, None, dres, None, None, None
+        if direct:
+            dgamma = dbeta = None
+        return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None
 
 
 def batch_norm_act(y, stats, gamma, beta, running_mean, running_var, residual=None, relu=False, momentum=0.1,
                    eps=1e-5):
-    return _BatchNormActFn.apply(y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps)
+    gd, bd = grad_slot(gamma), grad_slot(beta)
+    grad_dst = (gd, bd) if gd is not None and bd is not None else None
+    return _BatchNormActFn.apply(y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, grad_dst)
 
 
 def affine_act(y, scale, shift, residual=None, relu=False):
@@ -258,7 +335,7 @@ class _GroupNormActFn(Function):
         b, h, w, c = y.shape
         hw = h * w
         cg = c // groups
-        stats = torch.zeros((b, 2, c), dtype=torch.float32, device=y.device)
+        stats = zeros_f32((b, 2, c), y.device)
         _hip.call("u2_colstats", y, stats, b, hw, c, c)
         n = float(hw * cg)
         s = stats.view(b, 2, groups, cg).sum(-1)
@@ -283,7 +360,7 @@ class _GroupNormActFn(Function):
         hw, cg = h * w, c // groups
         n = float(hw * cg)
         dout = dout.contiguous()
-        sums = torch.zeros((b, 2, c), dtype=torch.float32, device=y.device)
+        sums = zeros_f32((b, 2, c), y.device)
         _hip.call("u2_norm_bwd_reduce", dout, out, y, mean, invstd, sums, b, hw, c, c, int(relu))
         s1, s2 = sums[:, 0], sums[:, 1]
         g = gamma.detach()[None]

@@ -54,6 +54,23 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._pending_batches = 0  # folded into the buffer when it is read (state_dict): no per-step device op
+
+    def count_batch(self):
+        self._pending_batches += 1
+
+    def _flush_batches(self):
+        if self._pending_batches:
+            self.num_batches_tracked += self._pending_batches
+            self._pending_batches = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._flush_batches()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._pending_batches = 0
+        super()._load_from_state_dict(*args, **kwargs)
 
     def eval_scale_shift(self):
         scale = self.weight.detach() * torch.rsqrt(self.running_var + self.eps)
@@ -126,7 +143,7 @@ class Conv2d(nn.Module):
         assert self.bias is None, "a conv followed by a norm layer carries no bias in this graph"
         if isinstance(norm, BatchNorm2d) and self.training:
             y, stats = F.conv2d(x, self.weight, None, self.stride, self.padding, relu=False, want_stats=True)
-            norm.num_batches_tracked += 1
+            norm.count_batch()
             return F.batch_norm_act(y, stats, norm.weight, norm.bias, norm.running_mean, norm.running_var, residual,
                                     relu, norm.momentum, norm.eps)
         y = F.conv2d(x, self.weight, None, self.stride, self.padding, relu=False)

@@ -48,7 +48,7 @@ class BasicStem(nn.Module):
         conv, norm = self.conv1, self.conv1.norm
         y, stats = F.stem_conv(conv.weight, images, pixel_mean, pixel_std, padded_hw[0], padded_hw[1])
         if self.training and hasattr(norm, "momentum"):
-            norm.num_batches_tracked += 1
+            norm.count_batch()
             x = F.batch_norm_act(y, stats, norm.weight, norm.bias, norm.running_mean, norm.running_var, None, True,
                                  norm.momentum, norm.eps)
         else:

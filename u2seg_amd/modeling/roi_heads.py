@@ -88,7 +88,7 @@ class FastRCNNConvFCHead(nn.Module):
     def forward(self, x):
         c, h, w = self._in
         fc1 = self.fcs[0]
-        y = F.conv2d(x, fc1.weight.view(fc1.out_features, c, h, w), fc1.bias, 1, 0, relu=True)
+        y = F.conv2d(x, fc1.weight.view(fc1.out_features, c, h, w), fc1.bias, 1, 0, relu=True, param=fc1.weight)
         y = y.view(y.shape[0], -1)
         for fc in self.fcs[1:]:
             y = fc(y, relu=True)

@@ -37,6 +37,7 @@ class FlatSGD:
             self.flat_param[off : off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_param[off : off + n].view(p.shape)
             p.grad = self.flat_grad[off : off + n].view(p.shape)
+            p._u2_grad = p.grad  # layers/functional.py:grad_slot - kernels accumulate into the arena directly
             if id(p) in norm_params:
                 wds.append(weight_decay_norm)
             elif p.dim() == 1 and weight_decay_bias is not None:
@@ -58,6 +59,16 @@ class FlatSGD:
         self.partial = torch.zeros(len(chunk_tensor), dtype=torch.float32, device=dev)
         self.lr, self.momentum, self.clip_value = lr, momentum, clip_value
         self.bucket_elems = bucket_bytes // 4
+        # bf16 kernel layouts cached on the parameters (layers/functional.py:_weight_layout): [stamp] is shared with every
+        # parameter; step() bumps it and rewrites all registered layouts with one launch.
+        self._stamp = [0]
+        self._layout_entries = []  # (param, key, entry)
+        self._layout_table = None
+        self._layout_table_len = -1
+        for p in self.params:
+            p._u2_stamp = self._stamp
+            p._u2_layout_register = self._register_layout
+            p.__dict__.pop("_u2_layouts", None)
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -83,6 +94,34 @@ class FlatSGD:
         _hip.call("u2_sgd_clip_step", self.flat_param, self.flat_grad, self.flat_mom, self.chunk_tensor, self.chunk_begin,
                   self.chunk_len, self.chunk_tensor.numel(), self.partial, self.first_chunk, self.wd, float(self.lr),
                   float(self.momentum), float(self.clip_value), float(grad_scale))
+        self.refresh_layouts()
+
+    def _register_layout(self, param, key, entry):
+        self._layout_entries.append((param, key, entry))
+
+    def refresh_layouts(self):
+        """The parameters changed under the kernels' feet: new stamp, then rewrite every cached layout in one launch."""
+        self._stamp[0] += 1
+        ents = self._layout_entries
+        if not ents:
+            return
+        if self._layout_table_len != len(ents):
+            import numpy as np
+
+            desc = np.zeros(len(ents), dtype=np.dtype([("src", "<i8"), ("dst", "<u8"), ("N", "<i4"), ("Cin", "<i4"), ("T", "<i4"),
+                                                       ("Cp", "<i4"), ("Npad", "<i4"), ("mode", "<i4")], align=True))
+            assert desc.dtype.itemsize == 40
+            base = self.flat_param.data_ptr()
+            for i, (p, key, ent) in enumerate(ents):
+                off = p.data_ptr() - base
+                assert 0 <= off < self.total * 4 and off % 4 == 0
+                desc[i] = (off // 4, ent[0].data_ptr()) + tuple(key)
+            self._layout_table = torch.from_numpy(desc.view(np.uint8).copy()).to(self.flat_param.device)
+            self._layout_table_len = len(ents)
+        _hip.call("u2_weight_layout_batched", self.flat_param, self._layout_table, len(ents))
+        stamp = self._stamp[0]
+        for p, _, ent in ents:
+            ent[1], ent[2] = p._version, stamp
 
     def state_dict(self):
         return {"momentum": self.flat_mom.clone(), "lr": self.lr}
