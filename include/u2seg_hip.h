@@ -53,8 +53,10 @@ typedef struct U2LayoutDesc {
   long long src_offset; /* floats from `base` to the [N][Cin][T] fp32 parameter */
   void* dst;            /* device pointer of the bf16 layout */
   int N, Cin, T, Cp, Npad, mode;
+  int block_begin;      /* first work-group of this entry: prefix sum of ceil(layout elements / 2048) */
+  int reserved;
 } U2LayoutDesc;
-int u2_weight_layout_batched(const float* base, const U2LayoutDesc* table, int n_entries, void* stream);
+int u2_weight_layout_batched(const float* base, const U2LayoutDesc* table, int n_entries, int total_blocks, void* stream);
 
 /* ---- normalisation / activation (norm.hip) ----------------------------------------------------
  * Replaces nn.SyncBatchNorm / nn.GroupNorm / relu_ chosen by detectron2/layers/batch_norm.py:169-197. */
@@ -65,13 +67,16 @@ int u2_bn_finalize_fwd(const float* sums, float count, const float* gamma, const
 int u2_affine_act(const void* x, const float* scale, const float* shift, const void* resid, void* out, int slots,
                   int rows_per_slot, int C, int ld, int relu, void* stream);
 int u2_norm_bwd_reduce(const void* dout, const void* mask, const void* x, const float* mean, const float* invstd,
-                       float* out /*[slots][2][C]*/, int slots, int rows_per_slot, int C, int ld, int relu, void* stream);
+                       float* out /*[slots][2][C]*/, int slots, int rows_per_slot, int C, int ld, int relu,
+                       const float* mask_scale, const float* mask_shift, void* stream);
+/* mask_scale/mask_shift [slots][C] (optional, both or neither): recompute the ReLU mask as x*scale+shift > 0 - the
+ * expression u2_affine_act evaluated in the forward pass - instead of reading the activation `mask` (which may be NULL). */
 int u2_bn_finalize_bwd(const float* sums, float count, const float* gamma, const float* mean, const float* invstd,
                        const float* local_sums, float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C,
                        int accumulate /* dgamma/dbeta += instead of = (parameter gradient arena) */, void* stream);
 int u2_norm_bwd_apply(const void* dout, const void* mask, const void* x, const float* k1, const float* k2,
                       const float* k3, void* dx, void* dres, int slots, int rows_per_slot, int C, int ld, int relu,
-                      void* stream);
+                      const float* mask_scale, const float* mask_shift, void* stream);
 int u2_relu_bwd(const void* dout, const void* out, void* dz, long long numel, void* stream);
 
 /* ---- pooling / resampling (pool_resize.hip) ----------------------------------------------------

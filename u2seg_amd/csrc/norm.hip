@@ -16,13 +16,18 @@ namespace {
 // (slot = image for GroupNorm).  out[slot][q][C], q = quantity index.
 // MODE 0: q0 = sum x, q1 = sum x^2
 // MODE 1: (norm backward) dz = dout * (mask>0 if relu); q0 = sum dz, q1 = sum dz*(x-mean)*invstd
+//         When msc/msh are given the ReLU mask is recomputed as (x*msc + msh > 0) - the very expression the forward
+//         affine_act evaluated (fp contraction is off, so it is bit-identical) - and the activation is not read at all.
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
+// MASK (MODE 1): 0 no ReLU, 1 read the activation, 2 recompute x*msc + msh > 0
+template <int MODE, int MASK>
 __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dout,
                                                         const bf16_t* __restrict__ mask, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, float* __restrict__ out,
-                                                        int rows_per_slot, int C, int ld, int rows_per_block, int relu) {
+                                                        int rows_per_slot, int C, int ld, int rows_per_block,
+                                                        const float* __restrict__ msc, const float* __restrict__ msh) {
   __shared__ float part[2][2048];
+  constexpr int U = 2;  // rows in flight per thread
   const int cpr = C >> 3;
   const int slot = blockIdx.y;
   const int r_begin = blockIdx.x * rows_per_block;
@@ -40,28 +45,50 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
     for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
     if (rl < rows_par) {
       const int c = (cbase + chunk) * 8;
-      float mu[8], is[8];
+      float mu[8], is[8], ms[8], mh[8];
       if (MODE == 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { mu[e] = mean[(size_t)slot * C + c + e]; is[e] = invstd[(size_t)slot * C + c + e]; }
+        if (MASK == 2) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { ms[e] = msc[(size_t)slot * C + c + e]; mh[e] = msh[(size_t)slot * C + c + e]; }
+        }
       }
-      for (int r = r_begin + rl; r < r_end; r += rows_par) {
-        const size_t off = (row0 + r) * ld + c;
-        bf16_t xv[8];
-        *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + off);
-        if (MODE == 0) {
+      for (int r0 = r_begin + rl; r0 < r_end; r0 += U * rows_par) {
+        uint4 xq[U], dq[U], mq[U];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { const float f = bf2f(xv[e]); s0[e] += f; s1[e] += f * f; }
-        } else {
-          bf16_t dv[8], mv[8];
-          *reinterpret_cast<uint4*>(dv) = *reinterpret_cast<const uint4*>(dout + off);
-          if (relu) *reinterpret_cast<uint4*>(mv) = *reinterpret_cast<const uint4*>(mask + off);
+        for (int u = 0; u < U; ++u) {
+          const int r = r0 + u * rows_par;
+          if (r < r_end) {
+            const size_t off = (row0 + r) * ld + c;
+            xq[u] = *reinterpret_cast<const uint4*>(x + off);
+            if (MODE == 1) {
+              dq[u] = *reinterpret_cast<const uint4*>(dout + off);
+              if (MASK == 1) mq[u] = *reinterpret_cast<const uint4*>(mask + off);
+            }
+          }
+        }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float dz = bf2f(dv[e]);
-            if (relu && !(bf2f(mv[e]) > 0.f)) dz = 0.f;
-            s0[e] += dz;
-            s1[e] += dz * (bf2f(xv[e]) - mu[e]) * is[e];
+        for (int u = 0; u < U; ++u) {
+          const int r = r0 + u * rows_par;
+          if (r < r_end) {
+            const bf16_t* xv = reinterpret_cast<const bf16_t*>(&xq[u]);
+            const bf16_t* dv = reinterpret_cast<const bf16_t*>(&dq[u]);
+            const bf16_t* mv = reinterpret_cast<const bf16_t*>(&mq[u]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float xf = bf2f(xv[e]);
+              if (MODE == 0) {
+                s0[e] += xf;
+                s1[e] += xf * xf;
+              } else {
+                float dz = bf2f(dv[e]);
+                if (MASK == 1 && !(bf2f(mv[e]) > 0.f)) dz = 0.f;
+                if (MASK == 2 && !(xf * ms[e] + mh[e] > 0.f)) dz = 0.f;
+                s0[e] += dz;
+                s1[e] += dz * (xf - mu[e]) * is[e];
+              }
+            }
           }
         }
       }
@@ -122,9 +149,11 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ x, const float* __restrict__ k1,
                                                              const float* __restrict__ k2, const float* __restrict__ k3,
                                                              bf16_t* __restrict__ dx, bf16_t* __restrict__ dres,
-                                                             int rows_per_slot, size_t M, int C, int ld, int relu) {
+                                                             int rows_per_slot, size_t M, int C, int ld, int relu,
+                                                             const float* __restrict__ msc, const float* __restrict__ msh) {
   const int cpr = C >> 3;
   const size_t total = M * (size_t)cpr;
+  const bool remask = relu && msc != nullptr;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t row = i / cpr;
     const int c = (int)(i - row * cpr) * 8;
@@ -133,14 +162,18 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const bf16_t* __res
     bf16_t dv[8], mv[8], xv[8], ov[8], zv[8];
     *reinterpret_cast<uint4*>(dv) = *reinterpret_cast<const uint4*>(dout + off);
     *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + off);
-    if (relu) *reinterpret_cast<uint4*>(mv) = *reinterpret_cast<const uint4*>(mask + off);
+    if (relu && !remask) *reinterpret_cast<uint4*>(mv) = *reinterpret_cast<const uint4*>(mask + off);
     const float* a1 = k1 + (size_t)slot * C + c;
     const float* a2 = k2 + (size_t)slot * C + c;
     const float* a3 = k3 + (size_t)slot * C + c;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float dz = bf2f(dv[e]);
-      if (relu && !(bf2f(mv[e]) > 0.f)) dz = 0.f;
+      if (relu) {
+        const bool on = remask ? (bf2f(xv[e]) * msc[(size_t)slot * C + c + e] + msh[(size_t)slot * C + c + e] > 0.f)
+                               : (bf2f(mv[e]) > 0.f);
+        if (!on) dz = 0.f;
+      }
       ov[e] = f2bf(a1[e] * dz + a2[e] * bf2f(xv[e]) + a3[e]);
       zv[e] = f2bf(dz);
     }
@@ -165,11 +198,14 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const bf16_t* __restrict_
 
 
 // ---- fast paths: C/8 divides 256, so a thread keeps one 8-channel column chunk for its whole life and the
-//      per-channel coefficients live in registers; grid.y = slot, rows of a slot are strided over grid.x ----
+//      per-channel coefficients live in registers; grid.y = slot, rows of a slot are strided over grid.x.
+//      Two rows are in flight per thread (all loads issued before the first use) to cover the HBM latency. ----
+constexpr int EW_UNROLL = 2;
+
+template <bool RESID, bool RELU>
 __global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const bf16_t* __restrict__ resid,
-                                                              bf16_t* __restrict__ out, int rows_per_slot, int C, int ld,
-                                                              int relu) {
+                                                              bf16_t* __restrict__ out, int rows_per_slot, int C, int ld) {
   const int cpr = C >> 3;
   const int rows_par = 256 / cpr;
   const int cc = threadIdx.x % cpr, rl = threadIdx.x / cpr;
@@ -178,61 +214,101 @@ __global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __re
 #pragma unroll
   for (int e = 0; e < 8; ++e) { sc[e] = scale[(size_t)slot * C + cc * 8 + e]; sh[e] = shift[(size_t)slot * C + cc * 8 + e]; }
   const size_t base = (size_t)slot * rows_per_slot;
-  for (int r = blockIdx.x * rows_par + rl; r < rows_per_slot; r += gridDim.x * rows_par) {
-    const size_t off = (base + r) * ld + cc * 8;
-    bf16_t xv[8], rv[8], ov[8];
-    *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + off);
-    if (resid) *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(resid + off);
+  const int stride = gridDim.x * rows_par;
+  for (int r0 = blockIdx.x * rows_par + rl; r0 < rows_per_slot; r0 += EW_UNROLL * stride) {
+    uint4 xq[EW_UNROLL], rq[EW_UNROLL];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float f = bf2f(xv[e]) * sc[e] + sh[e];
-      if (resid) f += bf2f(rv[e]);
-      if (relu) f = fmaxf(f, 0.f);
-      ov[e] = f2bf(f);
+    for (int u = 0; u < EW_UNROLL; ++u) {
+      const int r = r0 + u * stride;
+      if (r < rows_per_slot) {
+        const size_t off = (base + r) * ld + cc * 8;
+        xq[u] = *reinterpret_cast<const uint4*>(x + off);
+        if (RESID) rq[u] = *reinterpret_cast<const uint4*>(resid + off);
+      }
     }
-    *reinterpret_cast<uint4*>(out + off) = *reinterpret_cast<const uint4*>(ov);
+#pragma unroll
+    for (int u = 0; u < EW_UNROLL; ++u) {
+      const int r = r0 + u * stride;
+      if (r < rows_per_slot) {
+        const bf16_t* xv = reinterpret_cast<const bf16_t*>(&xq[u]);
+        const bf16_t* rv = reinterpret_cast<const bf16_t*>(&rq[u]);
+        bf16_t ov[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = bf2f(xv[e]) * sc[e] + sh[e];
+          if (RESID) f += bf2f(rv[e]);
+          if (RELU) f = fmaxf(f, 0.f);
+          ov[e] = f2bf(f);
+        }
+        *reinterpret_cast<uint4*>(out + (base + r) * ld + cc * 8) = *reinterpret_cast<const uint4*>(ov);
+      }
+    }
   }
 }
 
+// MASK: 0 no ReLU, 1 read the activation, 2 recompute x*ms + mh > 0
+template <int MASK, bool DRES>
 __global__ __launch_bounds__(256) void norm_bwd_apply_fast_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ mask,
                                                                   const bf16_t* __restrict__ x, const float* __restrict__ k1,
                                                                   const float* __restrict__ k2, const float* __restrict__ k3,
                                                                   bf16_t* __restrict__ dx, bf16_t* __restrict__ dres,
-                                                                  int rows_per_slot, int C, int ld, int relu) {
+                                                                  int rows_per_slot, int C, int ld,
+                                                                  const float* __restrict__ msc, const float* __restrict__ msh) {
   const int cpr = C >> 3;
   const int rows_par = 256 / cpr;
   const int cc = threadIdx.x % cpr, rl = threadIdx.x / cpr;
   const int slot = blockIdx.y;
-  float a1[8], a2[8], a3[8];
+  float a1[8], a2[8], a3[8], ms[8], mh[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     a1[e] = k1[(size_t)slot * C + cc * 8 + e];
     a2[e] = k2[(size_t)slot * C + cc * 8 + e];
     a3[e] = k3[(size_t)slot * C + cc * 8 + e];
+    if (MASK == 2) { ms[e] = msc[(size_t)slot * C + cc * 8 + e]; mh[e] = msh[(size_t)slot * C + cc * 8 + e]; }
   }
   const size_t base = (size_t)slot * rows_per_slot;
-  for (int r = blockIdx.x * rows_par + rl; r < rows_per_slot; r += gridDim.x * rows_par) {
-    const size_t off = (base + r) * ld + cc * 8;
-    bf16_t dv[8], mv[8], xv[8], ov[8], zv[8];
-    *reinterpret_cast<uint4*>(dv) = *reinterpret_cast<const uint4*>(dout + off);
-    *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + off);
-    if (relu) *reinterpret_cast<uint4*>(mv) = *reinterpret_cast<const uint4*>(mask + off);
+  const int stride = gridDim.x * rows_par;
+  for (int r0 = blockIdx.x * rows_par + rl; r0 < rows_per_slot; r0 += EW_UNROLL * stride) {
+    uint4 dq[EW_UNROLL], xq[EW_UNROLL], mq[EW_UNROLL];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float dz = bf2f(dv[e]);
-      if (relu && !(bf2f(mv[e]) > 0.f)) dz = 0.f;
-      ov[e] = f2bf(a1[e] * dz + a2[e] * bf2f(xv[e]) + a3[e]);
-      zv[e] = f2bf(dz);
+    for (int u = 0; u < EW_UNROLL; ++u) {
+      const int r = r0 + u * stride;
+      if (r < rows_per_slot) {
+        const size_t off = (base + r) * ld + cc * 8;
+        dq[u] = *reinterpret_cast<const uint4*>(dout + off);
+        xq[u] = *reinterpret_cast<const uint4*>(x + off);
+        if (MASK == 1) mq[u] = *reinterpret_cast<const uint4*>(mask + off);
+      }
     }
-    *reinterpret_cast<uint4*>(dx + off) = *reinterpret_cast<const uint4*>(ov);
-    if (dres) *reinterpret_cast<uint4*>(dres + off) = *reinterpret_cast<const uint4*>(zv);
+#pragma unroll
+    for (int u = 0; u < EW_UNROLL; ++u) {
+      const int r = r0 + u * stride;
+      if (r < rows_per_slot) {
+        const bf16_t* dv = reinterpret_cast<const bf16_t*>(&dq[u]);
+        const bf16_t* xv = reinterpret_cast<const bf16_t*>(&xq[u]);
+        const bf16_t* mv = reinterpret_cast<const bf16_t*>(&mq[u]);
+        bf16_t ov[8], zv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float dz = bf2f(dv[e]);
+          const float xf = bf2f(xv[e]);
+          if (MASK == 1 && !(bf2f(mv[e]) > 0.f)) dz = 0.f;
+          if (MASK == 2 && !(xf * ms[e] + mh[e] > 0.f)) dz = 0.f;
+          ov[e] = f2bf(a1[e] * dz + a2[e] * xf + a3[e]);
+          zv[e] = f2bf(dz);
+        }
+        const size_t off = (base + r) * ld + cc * 8;
+        *reinterpret_cast<uint4*>(dx + off) = *reinterpret_cast<const uint4*>(ov);
+        if (DRES) *reinterpret_cast<uint4*>(dres + off) = *reinterpret_cast<const uint4*>(zv);
+      }
+    }
   }
 }
 
 static bool fast_ok(int C) { const int cpr = C >> 3; return cpr >= 1 && cpr <= 256 && (256 % cpr) == 0; }
 static dim3 fast_grid(int slots, int rows_per_slot, int C) {
   const int rows_par = 256 / (C >> 3);
-  int gx = (rows_per_slot + rows_par - 1) / rows_par;
+  int gx = (rows_per_slot + rows_par * EW_UNROLL - 1) / (rows_par * EW_UNROLL);
   const int cap = max(1, 4096 / slots);
   if (gx > cap) gx = cap;
   return dim3(gx, slots);
@@ -321,17 +397,45 @@ __global__ __launch_bounds__(256) void weight_layout_kernel(const float* __restr
   weight_layout_body(w, out, N, Cin, T, Cp, Npad, mode);
 }
 
-// One launch for every cached layout of every parameter: blockIdx.y walks the descriptor table.
+// One launch for every cached layout of every parameter.  A block converts 2048 consecutive output elements of one
+// table entry; entries own the block range [block_begin, next entry's block_begin).
 __global__ __launch_bounds__(256) void weight_layout_batched_kernel(const float* __restrict__ base,
-                                                                    const U2LayoutDesc* __restrict__ table) {
-  const U2LayoutDesc d = table[blockIdx.y];
-  weight_layout_body(base + d.src_offset, (bf16_t*)d.dst, d.N, d.Cin, d.T, d.Cp, d.Npad, d.mode);
+                                                                    const U2LayoutDesc* __restrict__ table, int n_entries) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = n_entries - 1;
+  while (lo < hi) {  // last entry with block_begin <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block_begin <= b) lo = mid; else hi = mid - 1;
+  }
+  const U2LayoutDesc d = table[lo];
+  const float* __restrict__ w = base + d.src_offset;
+  bf16_t* __restrict__ out = (bf16_t*)d.dst;
+  const int N = d.N, Cin = d.Cin, T = d.T, Cp = d.Cp, Npad = d.Npad, mode = d.mode;
+  const size_t total = mode == 0 ? (size_t)N * T * Cp : (size_t)Cp * T * Npad;
+  const size_t i0 = (size_t)(b - d.block_begin) * 2048;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const size_t i = i0 + k * 256 + threadIdx.x;
+    if (i >= total) break;
+    int n, c, t;
+    if (mode == 0) {
+      c = (int)(i % Cp); const size_t r = i / Cp; t = (int)(r % T); n = (int)(r / T);
+    } else if (mode == 1) {
+      n = (int)(i % Npad); const size_t r = i / Npad; t = T - 1 - (int)(r % T); c = (int)(r / T);
+    } else {
+      n = (int)(i % Npad); const size_t r = i / Npad; c = (int)(r % Cp); t = (int)(r / Cp);
+    }
+    float v = 0.f;
+    if (n < N && c < Cin) v = w[((size_t)n * Cin + c) * T + t];
+    out[i] = f2bf(v);
+  }
 }
 
-extern "C" int u2_weight_layout_batched(const float* base, const U2LayoutDesc* table, int n_entries, void* stream) {
-  if (n_entries <= 0) return 0;
-  if (n_entries > 65535) return -1;
-  hipLaunchKernelGGL(weight_layout_batched_kernel, dim3(128, n_entries), dim3(256), 0, (hipStream_t)stream, base, table);
+extern "C" int u2_weight_layout_batched(const float* base, const U2LayoutDesc* table, int n_entries, int total_blocks,
+                                        void* stream) {
+  if (n_entries <= 0 || total_blocks <= 0) return 0;
+  hipLaunchKernelGGL(weight_layout_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, base, table,
+                     n_entries);
   U2_CHECK_LAUNCH();
   return 0;
 }
@@ -354,21 +458,27 @@ extern "C" int u2_colstats(const void* x, float* out, int slots, int rows_per_sl
   int rpb = (rows_per_slot + 511) / 512;  // ~512 blocks per slot
   if (rpb < 64) rpb = 64;
   const dim3 grid((rows_per_slot + rpb - 1) / rpb, slots);
-  hipLaunchKernelGGL(colreduce_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, nullptr, nullptr,
-                     nullptr, nullptr, out, rows_per_slot, C, ld, rpb, 0);
+  hipLaunchKernelGGL((colreduce_kernel<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, nullptr, nullptr,
+                     nullptr, nullptr, out, rows_per_slot, C, ld, rpb, nullptr, nullptr);
   U2_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int u2_norm_bwd_reduce(const void* dout, const void* mask, const void* x, const float* mean, const float* invstd,
-                                  float* out, int slots, int rows_per_slot, int C, int ld, int relu, void* stream) {
+                                  float* out, int slots, int rows_per_slot, int C, int ld, int relu,
+                                  const float* mask_scale, const float* mask_shift, void* stream) {
   if ((C & 7) || (ld & 7)) return -1;
   if (slots <= 0 || rows_per_slot <= 0) return 0;
   int rpb = (rows_per_slot + 511) / 512;
   if (rpb < 64) rpb = 64;
   const dim3 grid((rows_per_slot + rpb - 1) / rpb, slots);
-  hipLaunchKernelGGL(colreduce_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dout,
-                     (const bf16_t*)mask, mean, invstd, out, rows_per_slot, C, ld, rpb, relu);
+  if (relu && !mask && !mask_scale) return -1;
+#define U2_REDUCE(MM_)                                                                                               \
+  hipLaunchKernelGGL((colreduce_kernel<1, MM_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,           \
+                     (const bf16_t*)dout, (const bf16_t*)mask, mean, invstd, out, rows_per_slot, C, ld, rpb, mask_scale, \
+                     mask_shift)
+  if (!relu) U2_REDUCE(0); else if (mask_scale) U2_REDUCE(2); else U2_REDUCE(1);
+#undef U2_REDUCE
   U2_CHECK_LAUNCH();
   return 0;
 }
@@ -379,8 +489,12 @@ extern "C" int u2_affine_act(const void* x, const float* scale, const float* shi
   const size_t M = (size_t)slots * rows_per_slot;
   if (M == 0) return 0;
   if (fast_ok(C)) {
-    hipLaunchKernelGGL(affine_act_fast_kernel, fast_grid(slots, rows_per_slot, C), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, scale, shift, (const bf16_t*)resid, (bf16_t*)out, rows_per_slot, C, ld, relu);
+#define U2_AFFINE(RS_, RL_)                                                                                          \
+  hipLaunchKernelGGL((affine_act_fast_kernel<RS_, RL_>), fast_grid(slots, rows_per_slot, C), dim3(256), 0, (hipStream_t)stream, \
+                     (const bf16_t*)x, scale, shift, (const bf16_t*)resid, (bf16_t*)out, rows_per_slot, C, ld)
+    if (resid) { if (relu) U2_AFFINE(true, true); else U2_AFFINE(true, false); }
+    else { if (relu) U2_AFFINE(false, true); else U2_AFFINE(false, false); }
+#undef U2_AFFINE
     U2_CHECK_LAUNCH();
     return 0;
   }
@@ -392,20 +506,26 @@ extern "C" int u2_affine_act(const void* x, const float* scale, const float* shi
 
 extern "C" int u2_norm_bwd_apply(const void* dout, const void* mask, const void* x, const float* k1, const float* k2,
                                  const float* k3, void* dx, void* dres, int slots, int rows_per_slot, int C, int ld,
-                                 int relu, void* stream) {
+                                 int relu, const float* mask_scale, const float* mask_shift, void* stream) {
   if ((C & 7) || (ld & 7)) return -1;
+  if (relu && !mask && !mask_scale) return -1;
   const size_t M = (size_t)slots * rows_per_slot;
   if (M == 0) return 0;
   if (fast_ok(C)) {
-    hipLaunchKernelGGL(norm_bwd_apply_fast_kernel, fast_grid(slots, rows_per_slot, C), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)dout, (const bf16_t*)mask, (const bf16_t*)x, k1, k2, k3, (bf16_t*)dx, (bf16_t*)dres,
-                       rows_per_slot, C, ld, relu);
+    const int mm = !relu ? 0 : (mask_scale ? 2 : 1);
+#define U2_APPLY(MM_, DR_)                                                                                           \
+  hipLaunchKernelGGL((norm_bwd_apply_fast_kernel<MM_, DR_>), fast_grid(slots, rows_per_slot, C), dim3(256), 0,            \
+                     (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)mask, (const bf16_t*)x, k1, k2, k3, (bf16_t*)dx, \
+                     (bf16_t*)dres, rows_per_slot, C, ld, mask_scale, mask_shift)
+    if (dres) { if (mm == 0) U2_APPLY(0, true); else if (mm == 1) U2_APPLY(1, true); else U2_APPLY(2, true); }
+    else { if (mm == 0) U2_APPLY(0, false); else if (mm == 1) U2_APPLY(1, false); else U2_APPLY(2, false); }
+#undef U2_APPLY
     U2_CHECK_LAUNCH();
     return 0;
   }
   hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dout, (const bf16_t*)mask, (const bf16_t*)x, k1, k2, k3, (bf16_t*)dx, (bf16_t*)dres,
-                     rows_per_slot, M, C, ld, relu);
+                     rows_per_slot, M, C, ld, relu, mask_scale, mask_shift);
   U2_CHECK_LAUNCH();
   return 0;
 }

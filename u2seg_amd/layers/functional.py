@@ -280,20 +280,23 @@ class _BatchNormActFn(Function):
                   invstd, scale, shift, c)
         out = torch.empty_like(y)
         _hip.call("u2_affine_act", y, scale, shift, residual, out, 1, m, c, c, int(relu))
-        ctx.save_for_backward(y, out if relu else None, gamma, mean, invstd)
+        # ReLU mask in backward: without a residual it is recomputed from y (one activation read less per pass)
+        remask = relu and residual is None
+        ctx.save_for_backward(y, out if (relu and not remask) else None, gamma, mean, invstd,
+                              scale if remask else None, shift if remask else None)
         ctx.cfg = (relu, count, world, residual is not None)
         ctx.grad_dst = grad_dst  # (dgamma, dbeta) arena slices or None
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        y, out, gamma, mean, invstd = ctx.saved_tensors
+        y, out, gamma, mean, invstd, msc, msh = ctx.saved_tensors
         relu, count, world, has_res = ctx.cfg
         b, h, w, c = y.shape
         m = b * h * w
         dout = dout.contiguous()
         sums = zeros_f32((2, c), y.device)
-        _hip.call("u2_norm_bwd_reduce", dout, out, y, mean, invstd, sums, 1, m, c, c, int(relu))
+        _hip.call("u2_norm_bwd_reduce", dout, out, y, mean, invstd, sums, 1, m, c, c, int(relu), msc, msh)
         local = sums
         if world > 1:
             local = sums.clone()
@@ -305,7 +308,7 @@ class _BatchNormActFn(Function):
                   coef[4], c, int(direct))
         dx = torch.empty_like(y)
         dres = torch.empty_like(y) if has_res else None
-        _hip.call("u2_norm_bwd_apply", dout, out, y, coef[2], coef[3], coef[4], dx, dres, 1, m, c, c, int(relu))
+        _hip.call("u2_norm_bwd_apply", dout, out, y, coef[2], coef[3], coef[4], dx, dres, 1, m, c, c, int(relu), msc, msh)
         if direct:
             dgamma = dbeta = None
         return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None
@@ -348,20 +351,20 @@ class _GroupNormActFn(Function):
         shift = (beta.detach()[None] - mean * scale).contiguous()
         out = torch.empty_like(y)
         _hip.call("u2_affine_act", y, scale, shift, None, out, b, hw, c, c, int(relu))
-        ctx.save_for_backward(y, out if relu else None, gamma, mean, invstd)
+        ctx.save_for_backward(y, gamma, mean, invstd, scale if relu else None, shift if relu else None)
         ctx.cfg = (groups, relu)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        y, out, gamma, mean, invstd = ctx.saved_tensors
+        y, gamma, mean, invstd, msc, msh = ctx.saved_tensors
         groups, relu = ctx.cfg
         b, h, w, c = y.shape
         hw, cg = h * w, c // groups
         n = float(hw * cg)
         dout = dout.contiguous()
         sums = zeros_f32((b, 2, c), y.device)
-        _hip.call("u2_norm_bwd_reduce", dout, out, y, mean, invstd, sums, b, hw, c, c, int(relu))
+        _hip.call("u2_norm_bwd_reduce", dout, None, y, mean, invstd, sums, b, hw, c, c, int(relu), msc, msh)
         s1, s2 = sums[:, 0], sums[:, 1]
         g = gamma.detach()[None]
         a = ((g * s1).view(b, groups, cg).sum(-1) / n).repeat_interleave(cg, dim=1)
@@ -370,7 +373,7 @@ class _GroupNormActFn(Function):
         k2 = (-invstd * invstd * bq).contiguous()
         k3 = (-invstd * a + invstd * invstd * bq * mean).contiguous()
         dx = torch.empty_like(y)
-        _hip.call("u2_norm_bwd_apply", dout, out, y, k1, k2, k3, dx, None, b, hw, c, c, int(relu))
+        _hip.call("u2_norm_bwd_apply", dout, None, y, k1, k2, k3, dx, None, b, hw, c, c, int(relu), msc, msh)
         return dx, s2.sum(0), s1.sum(0), None, None, None
 
 

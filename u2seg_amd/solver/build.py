@@ -109,16 +109,20 @@ class FlatSGD:
             import numpy as np
 
             desc = np.zeros(len(ents), dtype=np.dtype([("src", "<i8"), ("dst", "<u8"), ("N", "<i4"), ("Cin", "<i4"), ("T", "<i4"),
-                                                       ("Cp", "<i4"), ("Npad", "<i4"), ("mode", "<i4")], align=True))
-            assert desc.dtype.itemsize == 40
+                                                       ("Cp", "<i4"), ("Npad", "<i4"), ("mode", "<i4"), ("blk", "<i4"),
+                                                       ("rsv", "<i4")], align=True))
+            assert desc.dtype.itemsize == 48
             base = self.flat_param.data_ptr()
+            blocks = 0
             for i, (p, key, ent) in enumerate(ents):
                 off = p.data_ptr() - base
                 assert 0 <= off < self.total * 4 and off % 4 == 0
-                desc[i] = (off // 4, ent[0].data_ptr()) + tuple(key)
+                desc[i] = (off // 4, ent[0].data_ptr()) + tuple(key) + (blocks, 0)
+                blocks += (ent[0].numel() + 2047) // 2048
             self._layout_table = torch.from_numpy(desc.view(np.uint8).copy()).to(self.flat_param.device)
             self._layout_table_len = len(ents)
-        _hip.call("u2_weight_layout_batched", self.flat_param, self._layout_table, len(ents))
+            self._layout_blocks = blocks
+        _hip.call("u2_weight_layout_batched", self.flat_param, self._layout_table, len(ents), self._layout_blocks)
         stamp = self._stamp[0]
         for p, _, ent in ents:
             ent[1], ent[2] = p._version, stamp
