@@ -95,6 +95,8 @@ int u2_stem_im2col(const void* img, int is_uint8, const float* mean, const float
 /* ---- losses (losses.hip) -----------------------------------------------------------------------
  * meta_arch/semantic_seg.py:255-267, roi_heads/fast_rcnn.py:307-347,424-463, roi_heads/mask_head.py:33-112,
  * proposal_generator/rpn.py:366-429, modeling/box_regression.py:43-76. */
+/* grad_acc [B][h][w][LP] fp32 is overwritten with the un-normalised logit gradient (no pre-zeroing needed);
+ * loss_sum / valid_cnt are accumulated (pre-zeroed by the caller). */
 int u2_semseg_upsample_ce(const void* logits, const void* target, float* grad_acc, float* loss_sum, float* valid_cnt,
                           int B, int h, int w, int LP, int NC, int ignore, void* stream);
 int u2_scale_to_bf16(const float* acc, const float* num, const float* den, float mult, void* out, long long n,

@@ -14,107 +14,188 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------
 // Semantic head loss: logits [B][h][w][LP] bf16 at stride 4, targets uint8 [B][4h][4w].
-// One workgroup = 64x16 full-resolution pixels; the 18x6 low-resolution taps it touches are staged
-// in LDS as fp32, the logit gradient is accumulated in LDS with ds atomics and flushed once.
+//
+// "Owner computes": a work-group owns a 15 x 7 block of low-resolution logits and evaluates every full-resolution
+// pixel that touches them (64 x 32 pixels: 60 x 28 of its own plus a halo its neighbours evaluate too, 1.22x the
+// minimum work).  The logit gradient of the owned block is accumulated in LDS and written once with plain stores:
+// no global atomics, no pre-zeroed accumulator.  A pixel's loss is counted by the group owning its upper-left tap.
+//
+// Work split: with scale 4 and align_corners=False the 4 x 4 pixels x = 4g+2..4g+5, y = 4k+2..4k+5 share one 2 x 2
+// set of taps (g, g+1) x (k, k+1).  Four adjacent lanes take such a cell, 8 classes each (softmax max / sum cross the
+// four lanes with two DPP shuffles): the 4 taps x 8 classes are read from LDS once, the 16 pixels run out of
+// registers, and the cell's gradient is merged in registers into 4 taps x 8 values before it touches LDS.
 // ------------------------------------------------------------------------------------------------
-constexpr int SS_GW = 16, SS_TH = 16, SS_LW = 17, SS_LH = 6, SS_MAXC = 32, SS_PITCH = 33;
+constexpr int SS_OW = 15, SS_OH = 7;                 // owned taps per work-group
+constexpr int SS_LW = SS_OW + 2, SS_LH = SS_OH + 2;  // staged taps (one halo ring)
+constexpr int SS_MAXC = 32, SS_PITCH = 36;           // 36 floats: 16-byte aligned rows, tap columns on distinct banks
 
-// Work split: with scale 4 and align_corners=False the four pixels x = 4g+2 .. 4g+5 share their two x taps
-// (g, g+1), so one thread owns such a quad of one row: it merges the quad's gradient along x in registers and
-// issues 4 x NC LDS atomics per quad instead of per pixel; the LDS tile pitch (33 floats) keeps the 16 quads of a
-// wave on different banks.
+// reductions over the 4 lanes of a quad: DPP quad_perm [1,0,3,2] (0xB1) and [2,3,0,1] (0x4E)
+template <int CTRL>
+__device__ __forceinline__ float quad_swap(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, quad_swap<0xB1>(v));
+  return fmaxf(v, quad_swap<0x4E>(v));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += quad_swap<0xB1>(v);
+  return v + quad_swap<0x4E>(v);
+}
+
 __global__ __launch_bounds__(256) void semseg_ce_kernel(const bf16_t* __restrict__ logits, const uint8_t* __restrict__ target,
                                                         float* __restrict__ grad_acc, float* __restrict__ loss_sum,
                                                         float* __restrict__ valid_cnt, int B, int h, int w, int LP, int NC,
                                                         int ignore) {
-  __shared__ float zt[SS_LH * SS_LW * SS_PITCH];
-  __shared__ float gt[SS_LH * SS_LW * SS_PITCH];
+  __shared__ __attribute__((aligned(16))) float zt[SS_LH * SS_LW * SS_PITCH];
+  __shared__ __attribute__((aligned(16))) float gt[SS_LH * SS_LW * SS_PITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t lab[32 * 64];  // the tile's labels; `ignore` outside the image
   __shared__ float red[4];
   const int H = 4 * h, W = 4 * w;
   const int b = blockIdx.z;
-  const int GX0 = (int)blockIdx.x * SS_GW - 1;  // first quad index of the block (quad -1 holds pixels 0, 1)
-  const int Y0 = blockIdx.y * SS_TH;
-  const int lx0 = GX0, ly0 = Y0 / 4 - 1;
+  const int ox0 = (int)blockIdx.x * SS_OW, oy0 = (int)blockIdx.y * SS_OH;  // first owned tap
+  const int lx0 = ox0 - 1, ly0 = oy0 - 1;                                  // first staged tap
   const int tid = threadIdx.x;
-  for (int i = tid; i < SS_LH * SS_LW * SS_MAXC; i += 256) {
-    const int c = i % SS_MAXC;
-    const int t = i / SS_MAXC;
+  {  // labels: 32 rows x 64 pixels starting at (4*oy0 - 2, 4*ox0 - 2); rows are 2-byte aligned in memory
+    const int px0 = 4 * ox0 - 2, py0 = 4 * oy0 - 2;
+    for (int i = tid; i < 32 * 32; i += 256) {
+      const int r = i >> 5, cpair = (i & 31) * 2;
+      const int y = py0 + r, x = px0 + cpair;
+      uint8_t l0 = (uint8_t)ignore, l1 = (uint8_t)ignore;
+      if (y >= 0 && y < H && x >= 0 && x + 1 < W) {
+        const unsigned short two = *reinterpret_cast<const unsigned short*>(target + ((size_t)b * H + y) * W + x);
+        l0 = (uint8_t)(two & 0xFF);
+        l1 = (uint8_t)(two >> 8);
+      }
+      lab[r * 64 + cpair] = l0;
+      lab[r * 64 + cpair + 1] = l1;
+    }
+  }
+  for (int i = tid; i < SS_LH * SS_LW * (SS_MAXC / 8); i += 256) {  // logits: 16-byte chunks -> fp32, zero past NC
+    const int ch = i % (SS_MAXC / 8);
+    const int t = i / (SS_MAXC / 8);
     const int tx = t % SS_LW, ty = t / SS_LW;
     const int lx = min(max(lx0 + tx, 0), w - 1), ly = min(max(ly0 + ty, 0), h - 1);
-    zt[t * SS_PITCH + c] = (c < NC) ? bf2f(logits[(((size_t)b * h + ly) * w + lx) * LP + c]) : 0.f;
-    gt[t * SS_PITCH + c] = 0.f;
+    float f[8];
+    if (ch * 8 < LP) {
+      bf16_t v[8];
+      *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(logits + (((size_t)b * h + ly) * w + lx) * LP + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = (ch * 8 + e < NC) ? bf2f(v[e]) : 0.f;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = 0.f;
+    }
+    float* zd = zt + t * SS_PITCH + ch * 8;
+    float* gd = gt + t * SS_PITCH + ch * 8;
+    *reinterpret_cast<float4*>(zd) = make_float4(f[0], f[1], f[2], f[3]);
+    *reinterpret_cast<float4*>(zd + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    *reinterpret_cast<float4*>(gd) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(gd + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
-  float my_loss = 0.f, my_cnt = 0.f;
-  const int gx = GX0 + (tid & 15);
-  const int y = Y0 + (tid >> 4);
-  if (y < H && gx < w) {
-    float sy = fmaxf((y + 0.5f) * 0.25f - 0.5f, 0.f);
-    const int y0 = (int)sy;
-    const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
-    const float ly = sy - y0, hy = 1.f - ly;
-    float a0[SS_MAXC], a1[SS_MAXC];  // x-merged gradient for the left / right tap column
+
+  const int cj = tid & 3;          // class group: classes 8cj .. 8cj+7
+  const int qx = (tid >> 2) & 15;  // cell column inside the tile
+  const int wv = tid >> 6;
+  const int gx = lx0 + qx;         // cell column: pixels 4gx+2 .. 4gx+5, taps gx and gx+1
+  bool cvalid[8];
 #pragma unroll
-    for (int c = 0; c < SS_MAXC; ++c) { a0[c] = 0.f; a1[c] = 0.f; }
-    int tx0 = -1, tx1 = -1;
+  for (int e = 0; e < 8; ++e) cvalid[e] = cj * 8 + e < NC;
+  float my_loss = 0.f, my_cnt = 0.f;
+
+#pragma unroll 1
+  for (int cy = wv; cy < SS_OH + 1; cy += 4) {  // cell row: pixels 4gy+2 .. 4gy+5, taps gy and gy+1
+    const int gy = ly0 + cy;
+    if (gx >= w || gy >= h) continue;
+    // tap coordinates of the cell (clamped exactly as the per-pixel formulas below would produce them)
+    const int x0 = max(gx, 0), y0 = max(gy, 0);
+    const int x1 = x0 + (x0 < w - 1 ? 1 : 0), y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const int i00 = ((y0 - ly0) * SS_LW + (x0 - lx0)) * SS_PITCH + cj * 8;
+    const int i01 = ((y0 - ly0) * SS_LW + (x1 - lx0)) * SS_PITCH + cj * 8;
+    const int i10 = ((y1 - ly0) * SS_LW + (x0 - lx0)) * SS_PITCH + cj * 8;
+    const int i11 = ((y1 - ly0) * SS_LW + (x1 - lx0)) * SS_PITCH + cj * 8;
+    float v00[8], v01[8], v10[8], v11[8];
+#pragma unroll
+    for (int e = 0; e < 8; e += 4) {
+      *reinterpret_cast<float4*>(v00 + e) = *reinterpret_cast<const float4*>(zt + i00 + e);
+      *reinterpret_cast<float4*>(v01 + e) = *reinterpret_cast<const float4*>(zt + i01 + e);
+      *reinterpret_cast<float4*>(v10 + e) = *reinterpret_cast<const float4*>(zt + i10 + e);
+      *reinterpret_cast<float4*>(v11 + e) = *reinterpret_cast<const float4*>(zt + i11 + e);
+    }
+    const bool own_cell = y0 >= oy0 && y0 < oy0 + SS_OH && x0 >= ox0 && x0 < ox0 + SS_OW;
+    unsigned labrow[4];  // the cell's 4 x 4 labels: row r = bytes of labrow[r]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) labrow[r] = *reinterpret_cast<const unsigned*>(lab + (cy * 4 + r) * 64 + qx * 4);
+    float a00[8], a01[8], a10[8], a11[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a00[e] = 0.f; a01[e] = 0.f; a10[e] = 0.f; a11[e] = 0.f; }
     bool any = false;
 #pragma unroll 1
     for (int i = 0; i < 4; ++i) {
       const int x = 4 * gx + 2 + i;
-      if (x < 0 || x >= W) continue;
-      float sx = fmaxf((x + 0.5f) * 0.25f - 0.5f, 0.f);
-      const int x0 = (int)sx;
-      const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
-      const float lx = sx - x0, hx = 1.f - lx;
-      tx0 = x0; tx1 = x1;  // identical for the whole quad
-      const int t = target[((size_t)b * H + y) * W + x];
-      if (t == ignore) continue;
-      any = true;
-      const int i00 = ((y0 - ly0) * SS_LW + (x0 - lx0)) * SS_PITCH;
-      const int i01 = ((y0 - ly0) * SS_LW + (x1 - lx0)) * SS_PITCH;
-      const int i10 = ((y1 - ly0) * SS_LW + (x0 - lx0)) * SS_PITCH;
-      const int i11 = ((y1 - ly0) * SS_LW + (x1 - lx0)) * SS_PITCH;
-      float z[SS_MAXC];
-      float mx = -INFINITY, z_t = 0.f;
+      const float sx = fmaxf((x + 0.5f) * 0.25f - 0.5f, 0.f);
+      const float lx = sx - (float)(int)sx, hx = 1.f - lx;
+      float p[8], q[8], u0[8], u1[8];
 #pragma unroll
-      for (int c = 0; c < SS_MAXC; ++c) {
-        if (c < NC) {
-          // same association as ATen's upsample_bilinear2d: hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11)
-          z[c] = hy * (hx * zt[i00 + c] + lx * zt[i01 + c]) + ly * (hx * zt[i10 + c] + lx * zt[i11 + c]);
-          mx = fmaxf(mx, z[c]);
-          if (c == t) z_t = z[c];
-        } else {
-          z[c] = -INFINITY;
+      for (int e = 0; e < 8; ++e) {
+        // same association as ATen's upsample_bilinear2d: hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11)
+        p[e] = hx * v00[e] + lx * v01[e];
+        q[e] = hx * v10[e] + lx * v11[e];
+        u0[e] = 0.f;
+        u1[e] = 0.f;
+      }
+#pragma unroll 1
+      for (int r = 0; r < 4; ++r) {
+        const int y = 4 * gy + 2 + r;
+        const int t = (labrow[r] >> (8 * i)) & 0xFF;
+        if (t == ignore) continue;  // also pixels outside the image; uniform over the four class lanes of the pixel
+        any = true;
+        const float sy = fmaxf((y + 0.5f) * 0.25f - 0.5f, 0.f);
+        const float ly = sy - (float)(int)sy, hy = 1.f - ly;
+        float z[8];
+        float mx = -INFINITY, z_t = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          z[e] = cvalid[e] ? hy * p[e] + ly * q[e] : -INFINITY;
+          mx = fmaxf(mx, z[e]);
+          if (cj * 8 + e == t) z_t = z[e];
+        }
+        mx = quad_max(mx);
+        float se = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { z[e] = __expf(z[e] - mx); se += z[e]; }  // exp(-inf) = 0 for the padding classes
+        se = quad_sum(se);
+        if (own_cell) {  // the lane holding class t subtracts z_t, lane 0 of the pixel adds the log-sum-exp
+          my_loss -= z_t;
+          if (cj == 0) { my_loss += mx + __logf(se); my_cnt += 1.f; }
+        }
+        const float inv = 1.f / se;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float g = z[e] * inv - (cj * 8 + e == t ? 1.f : 0.f);
+          u0[e] += hy * g;
+          u1[e] += ly * g;
         }
       }
-      float se = 0.f;
 #pragma unroll
-      for (int c = 0; c < SS_MAXC; ++c)
-        if (c < NC) { z[c] = __expf(z[c] - mx); se += z[c]; }  // z now holds exp(logit - max)
-      my_loss += mx + __logf(se) - z_t;
-      my_cnt += 1.f;
-      const float inv = 1.f / se;
-#pragma unroll
-      for (int c = 0; c < SS_MAXC; ++c) {
-        if (c < NC) {
-          const float g = z[c] * inv - (c == t ? 1.f : 0.f);
-          a0[c] += hx * g;
-          a1[c] += lx * g;
-        }
+      for (int e = 0; e < 8; ++e) {
+        a00[e] += hx * u0[e];
+        a01[e] += lx * u0[e];
+        a10[e] += hx * u1[e];
+        a11[e] += lx * u1[e];
       }
     }
     if (any) {
-      const int i00 = ((y0 - ly0) * SS_LW + (tx0 - lx0)) * SS_PITCH;
-      const int i01 = ((y0 - ly0) * SS_LW + (tx1 - lx0)) * SS_PITCH;
-      const int i10 = ((y1 - ly0) * SS_LW + (tx0 - lx0)) * SS_PITCH;
-      const int i11 = ((y1 - ly0) * SS_LW + (tx1 - lx0)) * SS_PITCH;
+      // contributions to taps outside the owned block land in the (discarded) halo ring of gt
+      const int o00 = i00, o01 = i01, o10 = i10, o11 = i11;
 #pragma unroll
-      for (int c = 0; c < SS_MAXC; ++c) {
-        if (c < NC) {
-          atomicAdd(&gt[i00 + c], hy * a0[c]);
-          atomicAdd(&gt[i01 + c], hy * a1[c]);
-          atomicAdd(&gt[i10 + c], ly * a0[c]);
-          atomicAdd(&gt[i11 + c], ly * a1[c]);
+      for (int e = 0; e < 8; ++e) {
+        if (cvalid[e]) {
+          atomicAdd(&gt[o00 + e], a00[e]);
+          atomicAdd(&gt[o01 + e], a01[e]);
+          atomicAdd(&gt[o10 + e], a10[e]);
+          atomicAdd(&gt[o11 + e], a11[e]);
         }
       }
     }
@@ -123,15 +204,15 @@ __global__ __launch_bounds__(256) void semseg_ce_kernel(const bf16_t* __restrict
   const float bc = block_sum_256(my_cnt, red);
   if (tid == 0 && bc > 0.f) { atomicAdd(loss_sum, bl); atomicAdd(valid_cnt, bc); }
   __syncthreads();
-  for (int i = tid; i < SS_LH * SS_LW * SS_MAXC; i += 256) {
-    const int c = i % SS_MAXC;
-    if (c >= NC) continue;
-    const int t = i / SS_MAXC;
-    const float g = gt[t * SS_PITCH + c];
-    if (g == 0.f) continue;
-    const int lx = lx0 + t % SS_LW, ly = ly0 + t / SS_LW;
-    if (lx < 0 || lx >= w || ly < 0 || ly >= h) continue;
-    atomicAdd(grad_acc + (((size_t)b * h + ly) * w + lx) * LP + c, g);
+  // every logit of the owned block is written exactly once (channels NC..LP-1 as zeros)
+  for (int i = tid; i < SS_OH * SS_OW * LP; i += 256) {
+    const int c = i % LP;
+    const int t = i / LP;
+    const int ox = t % SS_OW, oy = t / SS_OW;
+    const int lx = ox0 + ox, ly = oy0 + oy;
+    if (lx >= w || ly >= h) continue;
+    const float g = c < NC ? gt[((oy + 1) * SS_LW + (ox + 1)) * SS_PITCH + c] : 0.f;
+    grad_acc[(((size_t)b * h + ly) * w + lx) * LP + c] = g;
   }
 }
 
@@ -331,9 +412,9 @@ __global__ __launch_bounds__(256) void box_reg_l1_kernel(const bf16_t* __restric
 
 extern "C" int u2_semseg_upsample_ce(const void* logits, const void* target, float* grad_acc, float* loss_sum,
                                      float* valid_cnt, int B, int h, int w, int LP, int NC, int ignore, void* stream) {
-  if (NC > SS_MAXC || LP < NC) return -1;
+  if (NC > SS_MAXC || LP < NC || (LP & 7) || ignore < 0 || ignore > 255) return -1;
   if (B <= 0) return 0;
-  const dim3 grid((w + 1 + SS_GW - 1) / SS_GW, (4 * h + SS_TH - 1) / SS_TH, B);
+  const dim3 grid((w + SS_OW - 1) / SS_OW, (h + SS_OH - 1) / SS_OH, B);
   hipLaunchKernelGGL(semseg_ce_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits,
                      (const uint8_t*)target, grad_acc, loss_sum, valid_cnt, B, h, w, LP, NC, ignore);
   U2_CHECK_LAUNCH();

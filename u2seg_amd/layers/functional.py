@@ -468,7 +468,7 @@ class _SemSegLossFn(Function):
         _check_act(logits)
         b, h, w, lp = logits.shape
         assert target_u8.dtype == torch.uint8 and target_u8.shape == (b, 4 * h, 4 * w)
-        acc = torch.zeros((b, h, w, lp), dtype=torch.float32, device=logits.device)
+        acc = torch.empty((b, h, w, lp), dtype=torch.float32, device=logits.device)  # every element is written
         sc = torch.zeros(2, dtype=torch.float32, device=logits.device)
         _hip.call("u2_semseg_upsample_ce", logits, target_u8.contiguous(), acc, sc[0:1], sc[1:2], b, h, w, lp,
                   num_classes, ignore)
