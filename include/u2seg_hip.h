@@ -125,6 +125,12 @@ int u2_roi_align_bwd(float* const* gfeats, const int* Hs, const int* Ws, const f
 int u2_roi_align_bwd_gather(void* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,
                             const float* rois, const int* order, const int* seg, const void* dout, int B, int C, int PH,
                             int PW, float gscale, void* stream);
+/* The same gather over up to four ROI sets at once (the cascade's three box poolers and the mask pooler share the FPN
+ * maps): set i has its own rois / order / seg / dout, pooled size P[i] x P[i] and gradient scale.  Each level's gradient
+ * map is written once; the per-set gradient maps and their sums (autograd's accumulation) are never formed. */
+int u2_roi_align_bwd_gather_multi(void* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,
+                                  int nsets, const void* const* rois, const void* const* order, const void* const* seg,
+                                  const void* const* dout, const int* P, const float* gscale, int B, int C, void* stream);
 int u2_mask_crop(const void* masks, const float* rois, void* out, int R, int H, int W, int P, void* stream);
 int u2_assign_levels(const float* boxes, int* level, int n, int min_level, int max_level, float canonical_size,
                      int canonical_level, void* stream);

@@ -310,6 +310,39 @@ def test_roi_align_fwd_bwd(F, G):
     assert torch.equal(out.cpu().bool(), ref)
 
 
+def test_roi_grad_tap_combines_poolers(F):
+    """Three 7x7 poolers (gradient scale 1/3) and one 14x14 pooler on tapped FPN maps: the single deferred multi-set gather
+    must give the sum of the four separate ROIAlign backward passes (what autograd forms without the tap)."""
+    torch.manual_seed(3)
+    shapes = [(2, 40, 56, 64), (2, 20, 28, 64), (2, 10, 14, 64), (2, 5, 7, 64)]
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+
+    def boxes(n):
+        xy = torch.rand(n, 2) * torch.tensor([150.0, 100.0])
+        wh = 4 + torch.rand(n, 2) * torch.tensor([120.0, 90.0])
+        img = torch.randint(0, 2, (n, 1)).float()
+        return torch.cat([img, xy, xy + wh], 1).to(DEV)
+
+    sets = [(boxes(60), 7, 1.0 / 3), (boxes(50), 7, 1.0 / 3), (boxes(40), 7, 1.0 / 3), (boxes(30), 14, 1.0)]
+    base = [torch.randn(s, device=DEV).bfloat16() for s in shapes]
+    douts = [torch.randn((r.shape[0], p, p, 64), device=DEV).bfloat16() for r, p, _ in sets]
+
+    def run(tapped):
+        feats = [f.clone().requires_grad_() for f in base]
+        use = F.roi_grad_tap(feats) if tapped else feats
+        total = 0.0
+        for (rois, p, gs), d in zip(sets, douts):
+            lv = F.assign_levels(rois[:, 1:].contiguous(), 2, 5)
+            out = F.roi_align(use, rois, lv, p, scales, gs)
+            total = total + (out.float() * d.float()).sum()
+        total.backward()
+        return [f.grad.float().cpu() for f in feats]
+
+    ref, got = run(False), run(True)
+    for l, (a, b) in enumerate(zip(got, ref)):
+        assert rel_err(a, b) < 1e-2, l  # bf16 rounding of one sum instead of four partial maps
+
+
 def test_index_bookkeeping_bit_exact(F, G):
     """levels, IoU matching (+low-quality), NMS keep lists: identical integers to the oracle and the reference goldens."""
     lv = F.assign_levels(torch.from_numpy(G["lvl_boxes"]).to(DEV), 2, 5)

@@ -134,19 +134,29 @@ __device__ __forceinline__ float axis_weight(float pos, int n, int p) {
   return w;
 }
 
-__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* __restrict__ rois, const int* __restrict__ order,
-                                                                   const int* __restrict__ seg, const bf16_t* __restrict__ dout,
-                                                                   bf16_t* __restrict__ gfeat, int level, int nlevels, int H, int W,
-                                                                   int C, int PH, int PW, float scale, float gscale) {
-  constexpr int TS = 8, MAXL = 256;
-  constexpr int CPI = 4;   // 16-byte chunks (= 32 channels) per work item: the tap weights are computed once per item
+// Separable form.  The samples of a bin form a product grid and a bilinear weight is w_y * w_x, so
+//   sum_{iy, ix} w_y(iy) w_x(ix) = (sum_iy w_y(iy)) * (sum_ix w_x(ix)):
+// per (ROI, pixel row, bin row) and (ROI, pixel column, bin column) the 1-D sums are tabulated in LDS by a few threads,
+// and a pixel then needs one dout read per (bin row, bin column) pair it touches (typically 2 x 2) instead of one per
+// sample (gh * gw per bin).  Up to four ROI sets (the three cascade box stages and the mask pooler; each with its own
+// pooled size and gradient scale) are folded into one pass, so the level's gradient map is written exactly once.
+struct RoiSetDev { const float* rois; const int* order; const int* seg; const bf16_t* dout; int P; float gscale; };
+struct RoiSetsDev { RoiSetDev s[4]; int n; };
+
+constexpr int GS_TS = 8, GS_MAXL = 256, GS_KB = 4, GS_MAXP = 14;
+
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const RoiSetsDev sets, bf16_t* __restrict__ gfeat, int level,
+                                                                   int nlevels, int H, int W, int C, float scale) {
+  constexpr int TS = GS_TS;
+  constexpr int CPI = 4;   // 16-byte chunks (= 32 channels) per work item
   constexpr int NQ = 2;    // items per thread (C <= 256: 64 pixels x 8 channel groups = 512 items)
-  __shared__ RoiGeom list[MAXL];
+  __shared__ RoiGeom list[GS_MAXL];
   __shared__ int nlist;
+  __shared__ float tabY[GS_KB][TS][GS_MAXP];  // sum over a bin row's samples of w_y, per pixel row of the tile
+  __shared__ float tabX[GS_KB][TS][GS_MAXP];
   const int b = blockIdx.z;
   const int ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
   const int tid = threadIdx.x;
-  const int beg = seg[b * nlevels + level], end = seg[b * nlevels + level + 1];
   const int gpp = (C >> 3) / CPI;     // channel groups per pixel
   const int items = TS * TS * gpp;
   float acc[NQ][CPI * 8];
@@ -155,78 +165,91 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
 #pragma unroll
     for (int e = 0; e < CPI * 8; ++e) acc[q][e] = 0.f;
 
-  for (int base = beg; base < end; base += MAXL) {
-    __syncthreads();
-    if (tid == 0) nlist = 0;
-    __syncthreads();
-    const int idx = base + tid;
-    if (idx < end) {
-      const int r = order[idx];
-      const float* roi = rois + (size_t)r * 5;
-      RoiGeom g;
-      g.sw = roi[1] * scale - 0.5f; g.sh = roi[2] * scale - 0.5f;
-      const float ew = roi[3] * scale - 0.5f, eh = roi[4] * scale - 0.5f;
-      const float rw = ew - g.sw, rh = eh - g.sh;
-      g.bh = rh / (float)PH; g.bw = rw / (float)PW;
-      g.gh = (int)ceilf(rh / (float)PH); g.gw = (int)ceilf(rw / (float)PW);
-      g.r = r;
-      g.inv_cnt = gscale / (float)max(g.gh * g.gw, 1);
-      // pixel footprint of the ROI's taps (clamped samples pile up on the border rows / columns)
-      g.py0 = max(0, (int)floorf(g.sh) - 1); g.py1 = min(H - 1, (int)ceilf(eh) + 1);
-      g.px0 = max(0, (int)floorf(g.sw) - 1); g.px1 = min(W - 1, (int)ceilf(ew) + 1);
-      if (g.gh > 0 && g.gw > 0 && g.py1 >= ty0 && g.py0 < ty0 + TS && g.px1 >= tx0 && g.px0 < tx0 + TS) {
-        const int slot = atomicAdd(&nlist, 1);
-        list[slot] = g;
+  for (int si = 0; si < sets.n; ++si) {
+    const RoiSetDev st = sets.s[si];
+    const int P = st.P;
+    const int beg = st.seg[b * nlevels + level], end = st.seg[b * nlevels + level + 1];
+    for (int base = beg; base < end; base += GS_MAXL) {
+      __syncthreads();
+      if (tid == 0) nlist = 0;
+      __syncthreads();
+      const int idx = base + tid;
+      if (idx < end) {
+        const int r = st.order[idx];
+        const float* roi = st.rois + (size_t)r * 5;
+        RoiGeom g;
+        g.sw = roi[1] * scale - 0.5f; g.sh = roi[2] * scale - 0.5f;
+        const float ew = roi[3] * scale - 0.5f, eh = roi[4] * scale - 0.5f;
+        const float rw = ew - g.sw, rh = eh - g.sh;
+        g.bh = rh / (float)P; g.bw = rw / (float)P;
+        g.gh = (int)ceilf(rh / (float)P); g.gw = (int)ceilf(rw / (float)P);
+        g.r = r;
+        g.inv_cnt = st.gscale / (float)max(g.gh * g.gw, 1);
+        // pixel footprint of the ROI's taps (clamped samples pile up on the border rows / columns)
+        g.py0 = max(0, (int)floorf(g.sh) - 1); g.py1 = min(H - 1, (int)ceilf(eh) + 1);
+        g.px0 = max(0, (int)floorf(g.sw) - 1); g.px1 = min(W - 1, (int)ceilf(ew) + 1);
+        if (g.gh > 0 && g.gw > 0 && g.py1 >= ty0 && g.py0 < ty0 + TS && g.px1 >= tx0 && g.px0 < tx0 + TS) {
+          const int slot = atomicAdd(&nlist, 1);
+          list[slot] = g;
+        }
       }
-    }
-    __syncthreads();
-    const int n = nlist;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int item = q * 256 + tid;
-      const int grp = item % gpp;
-      const int pix = item / gpp;
-      const int py = ty0 + pix / TS, px = tx0 + pix % TS;
-      if (item >= items || py >= H || px >= W) continue;
-      for (int k = 0; k < n; ++k) {
-        if (py < list[k].py0 || py > list[k].py1 || px < list[k].px0 || px > list[k].px1) continue;
-        const RoiGeom g = list[k];
-        const float step_y = g.bh / (float)g.gh, step_x = g.bw / (float)g.gw;
-        const int ny = PH * g.gh, nx = PW * g.gw;
-        int sy0 = 0, sy1 = ny - 1, sx0 = 0, sx1 = nx - 1;
-        if (step_y > 0.f) {
-          sy0 = max(0, (int)floorf(((float)py - 1.f - g.sh) / step_y - 0.5f) - 1);
-          sy1 = min(ny - 1, (int)ceilf(((float)py + 1.f - g.sh) / step_y - 0.5f) + 1);
+      __syncthreads();
+      const int n = nlist;
+      for (int k0 = 0; k0 < n; k0 += GS_KB) {
+        const int nb = min(GS_KB, n - k0);
+        // 1-D weight sums of this batch of ROIs for the tile's 8 pixel rows and 8 pixel columns
+        for (int t = tid; t < nb * 2 * TS * P; t += 256) {
+          const int bin = t % P;
+          int rest = t / P;
+          const int rc = rest % TS; rest /= TS;
+          const int axis = rest & 1, kk = rest >> 1;
+          const RoiGeom& g = list[k0 + kk];
+          float sum = 0.f;
+          if (axis == 0) {
+            const float inv_g = g.bh / (float)g.gh;
+            for (int iy = 0; iy < g.gh; ++iy) sum += axis_weight(g.sh + bin * g.bh + (iy + 0.5f) * inv_g, H, ty0 + rc);
+            tabY[kk][rc][bin] = sum;
+          } else {
+            const float inv_g = g.bw / (float)g.gw;
+            for (int ix = 0; ix < g.gw; ++ix) sum += axis_weight(g.sw + bin * g.bw + (ix + 0.5f) * inv_g, W, tx0 + rc);
+            tabX[kk][rc][bin] = sum;
+          }
         }
-        if (step_x > 0.f) {
-          sx0 = max(0, (int)floorf(((float)px - 1.f - g.sw) / step_x - 0.5f) - 1);
-          sx1 = min(nx - 1, (int)ceilf(((float)px + 1.f - g.sw) / step_x - 0.5f) + 1);
-        }
-        if (py == H - 1 && step_y > 0.f) sy1 = ny - 1;   // clamped samples beyond the last row land on it
-        if (px == W - 1 && step_x > 0.f) sx1 = nx - 1;
-        if (py == 0) sy0 = 0;
-        if (px == 0) sx0 = 0;
-        for (int sy = sy0; sy <= sy1; ++sy) {
-          const int ph = sy / g.gh, iy = sy - ph * g.gh;
-          const float ypos = g.sh + ph * g.bh + (iy + 0.5f) * g.bh / (float)g.gh;
-          const float wy = axis_weight(ypos, H, py);
-          if (wy == 0.f) continue;
-          for (int sx = sx0; sx <= sx1; ++sx) {
-            const int pw = sx / g.gw, ix = sx - pw * g.gw;
-            const float xpos = g.sw + pw * g.bw + (ix + 0.5f) * g.bw / (float)g.gw;
-            const float wx = axis_weight(xpos, W, px);
-            if (wx == 0.f) continue;
-            const float wgt = wy * wx * g.inv_cnt;
-            const bf16_t* src = dout + (((size_t)g.r * PH + ph) * PW + pw) * C + grp * (CPI * 8);
+        __syncthreads();
 #pragma unroll
-            for (int c4 = 0; c4 < CPI; ++c4) {
-              bf16_t dv[8];
-              *reinterpret_cast<uint4*>(dv) = *reinterpret_cast<const uint4*>(src + c4 * 8);
+        for (int q = 0; q < NQ; ++q) {
+          const int item = q * 256 + tid;
+          const int grp = item % gpp;
+          const int pix = item / gpp;
+          const int row = pix / TS, col = pix % TS;
+          const int py = ty0 + row, px = tx0 + col;
+          if (item >= items || py >= H || px >= W) continue;
+          for (int kk = 0; kk < nb; ++kk) {
+            const RoiGeom& g = list[k0 + kk];
+            if (py < g.py0 || py > g.py1 || px < g.px0 || px > g.px1) continue;
+            const float ic = g.inv_cnt;
+            const bf16_t* rbase = st.dout + (size_t)g.r * P * P * C + grp * (CPI * 8);
+            for (int ph = 0; ph < P; ++ph) {
+              const float ay = tabY[kk][row][ph];
+              if (ay == 0.f) continue;
+              const float ayc = ay * ic;
+              for (int pw = 0; pw < P; ++pw) {
+                const float ax = tabX[kk][col][pw];
+                if (ax == 0.f) continue;
+                const float wgt = ayc * ax;
+                const bf16_t* src = rbase + (size_t)(ph * P + pw) * C;
 #pragma unroll
-              for (int e = 0; e < 8; ++e) acc[q][c4 * 8 + e] += wgt * bf2f(dv[e]);
+                for (int c4 = 0; c4 < CPI; ++c4) {
+                  bf16_t dv[8];
+                  *reinterpret_cast<uint4*>(dv) = *reinterpret_cast<const uint4*>(src + c4 * 8);
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) acc[q][c4 * 8 + e] += wgt * bf2f(dv[e]);
+                }
+              }
             }
           }
         }
+        __syncthreads();
       }
     }
   }
@@ -598,16 +621,32 @@ extern "C" int u2_batched_nms(const float* boxes, const int* group, const int* c
   return 0;
 }
 
-extern "C" int u2_roi_align_bwd_gather(void* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,
-                                       const float* rois, const int* order, const int* seg, const void* dout, int B, int C,
-                                       int PH, int PW, float gscale, void* stream) {
-  if (nlevels < 1 || nlevels > 4 || (C & 31) || C > 256) return -1;
+extern "C" int u2_roi_align_bwd_gather_multi(void* const* gfeats, const int* Hs, const int* Ws, const float* scales,
+                                             int nlevels, int nsets, const void* const* rois, const void* const* order,
+                                             const void* const* seg, const void* const* dout, const int* P,
+                                             const float* gscale, int B, int C, void* stream) {
+  if (nlevels < 1 || nlevels > 4 || (C & 31) || C > 256 || nsets < 1 || nsets > 4) return -1;
   if (B <= 0) return 0;
+  RoiSetsDev sets;
+  sets.n = nsets;
+  for (int i = 0; i < nsets; ++i) {
+    if (P[i] < 1 || P[i] > GS_MAXP) return -1;
+    sets.s[i].rois = (const float*)rois[i]; sets.s[i].order = (const int*)order[i]; sets.s[i].seg = (const int*)seg[i];
+    sets.s[i].dout = (const bf16_t*)dout[i]; sets.s[i].P = P[i]; sets.s[i].gscale = gscale[i];
+  }
   for (int l = 0; l < nlevels; ++l) {
     const dim3 grid((Ws[l] + 7) / 8, (Hs[l] + 7) / 8, B);
-    hipLaunchKernelGGL(roi_align_bwd_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, rois, order, seg,
-                       (const bf16_t*)dout, (bf16_t*)gfeats[l], l, nlevels, Hs[l], Ws[l], C, PH, PW, scales[l], gscale);
+    hipLaunchKernelGGL(roi_align_bwd_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, sets, (bf16_t*)gfeats[l], l,
+                       nlevels, Hs[l], Ws[l], C, scales[l]);
     U2_CHECK_LAUNCH();
   }
   return 0;
+}
+
+extern "C" int u2_roi_align_bwd_gather(void* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,
+                                       const float* rois, const int* order, const int* seg, const void* dout, int B, int C,
+                                       int PH, int PW, float gscale, void* stream) {
+  if (PH != PW) return -1;
+  const void* r[1] = {rois}; const void* o[1] = {order}; const void* sg[1] = {seg}; const void* d[1] = {dout};
+  return u2_roi_align_bwd_gather_multi(gfeats, Hs, Ws, scales, nlevels, 1, r, o, sg, d, &PH, &gscale, B, C, stream);
 }

@@ -615,11 +615,80 @@ def _level_arrays(feats, scales):
     return hs, ws, sc
 
 
+def _roi_group(rois, levels, b, nl):
+    """ROIs grouped by (image, level) for the per-pixel gather: order int32 [R], segment offsets int32 [b*nl+1]."""
+    key = rois[:, 0].to(torch.int64) * nl + levels.to(torch.int64)
+    order = torch.argsort(key, stable=True).to(torch.int32)
+    seg = torch.zeros(b * nl + 1, dtype=torch.int32, device=rois.device)
+    seg[1:] = torch.cumsum(torch.bincount(key, minlength=b * nl), 0)
+    return order, seg
+
+
+def _roi_gather(shapes, scales, sets, device):
+    """sets: [(rois, order, seg, dout, P, gscale)] (at most 4) -> per-level bf16 gradient maps, each written once."""
+    import ctypes
+
+    nl, ns = len(shapes), len(sets)
+    hs = (ctypes.c_int * nl)(*[s[1] for s in shapes])
+    ws = (ctypes.c_int * nl)(*[s[2] for s in shapes])
+    sc = (ctypes.c_float * nl)(*scales)
+    gbuf = [torch.empty(s, dtype=BF16, device=device) for s in shapes]
+    ptrs = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gbuf])
+    keep = [tuple(t.contiguous() if isinstance(t, torch.Tensor) else t for t in st) for st in sets]
+    arr = lambda k: (ctypes.c_void_p * ns)(*[st[k].data_ptr() for st in keep])
+    ps = (ctypes.c_int * ns)(*[st[4] for st in keep])
+    gs = (ctypes.c_float * ns)(*[float(st[5]) for st in keep])
+    _hip.call("u2_roi_align_bwd_gather_multi", ptrs, hs, ws, sc, nl, ns, arr(0), arr(1), arr(2), arr(3), ps, gs,
+              shapes[0][0], shapes[0][3])
+    return gbuf
+
+
+class RoiGradTap:
+    """Shared state of one roi_grad_tap(): the ROIAlign calls made on the tapped maps leave their (rois, dout) here in
+    backward, and the tap's own backward turns all of them into the maps' gradient with one gather pass."""
+
+    def __init__(self, feats, scales_hint=None):
+        self.shapes = [tuple(f.shape) for f in feats]
+        self.pending = []
+        self.scales = None
+        self.ids = None
+
+
+class _RoiGradTapFn(Function):
+    @staticmethod
+    def forward(ctx, state, *feats):
+        ctx.state = state
+        ctx.set_materialize_grads(False)
+        return tuple(f.detach() for f in feats)
+
+    @staticmethod
+    def backward(ctx, *gfeats):
+        st = ctx.state
+        grads = list(gfeats)
+        pend, st.pending = st.pending, []
+        for i in range(0, len(pend), 4):
+            gbuf = _roi_gather(st.shapes, st.scales, pend[i : i + 4], pend[i][3].device)
+            grads = [g if old is None else old + g for old, g in zip(grads, gbuf)]
+        return (None, *grads)
+
+
+def roi_grad_tap(feats):
+    """Identity on the FPN maps that defers the backward of every roi_align() made on its outputs: the cascade's three
+    box poolers and the mask pooler (modeling/poolers.py:206-263 x 4) then cost one gather pass per level, and the four
+    gradient maps per level that autograd would otherwise materialise and sum are never formed."""
+    state = RoiGradTap(feats)
+    outs = _RoiGradTapFn.apply(state, *feats)
+    state.ids = [id(o) for o in outs]
+    for o in outs:
+        o._u2_roi_tap = state
+    return list(outs)
+
+
 class _ROIAlignFn(Function):
     """Multi-level ROIAlign(aligned=True, sampling_ratio=0) (modeling/poolers.py:206-263)."""
 
     @staticmethod
-    def forward(ctx, rois, levels, out_size, scales, grad_scale, *feats):
+    def forward(ctx, rois, levels, out_size, scales, grad_scale, tap, *feats):
         import ctypes
 
         nl = len(feats)
@@ -634,6 +703,7 @@ class _ROIAlignFn(Function):
                   out_size)
         ctx.save_for_backward(rois, levels)
         ctx.cfg = (out_size, scales, grad_scale, [tuple(f.shape) for f in feats])
+        ctx.tap = tap
         return out
 
     @staticmethod
@@ -645,32 +715,34 @@ class _ROIAlignFn(Function):
         nl = len(shapes)
         b = shapes[0][0]
         r, c = rois.shape[0], shapes[0][3]
-        hs = (ctypes.c_int * nl)(*[s[1] for s in shapes])
-        ws = (ctypes.c_int * nl)(*[s[2] for s in shapes])
-        sc = (ctypes.c_float * nl)(*scales)
+        none = (None,) * 6
         if ROI_ALIGN_BWD_ATOMIC:
+            hs = (ctypes.c_int * nl)(*[s[1] for s in shapes])
+            ws = (ctypes.c_int * nl)(*[s[2] for s in shapes])
+            sc = (ctypes.c_float * nl)(*scales)
             gbuf = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in shapes]
             ptrs = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gbuf])
             _hip.call("u2_roi_align_bwd", ptrs, hs, ws, sc, nl, rois.contiguous(), levels.contiguous(), dout.contiguous(),
                       r, c, out_size, out_size, float(grad_scale))
-            return (None, None, None, None, None, *[g.to(BF16) for g in gbuf])
-        # group the ROIs by (image, level) for the atomics-free per-pixel gather
-        key = rois[:, 0].to(torch.int64) * nl + levels.to(torch.int64)
-        order = torch.argsort(key, stable=True).to(torch.int32)
-        seg = torch.zeros(b * nl + 1, dtype=torch.int32, device=dout.device)
-        seg[1:] = torch.cumsum(torch.bincount(key, minlength=b * nl), 0)
-        gbuf = [torch.empty(s, dtype=BF16, device=dout.device) for s in shapes]
-        ptrs = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gbuf])
-        _hip.call("u2_roi_align_bwd_gather", ptrs, hs, ws, sc, nl, rois.contiguous(), order, seg, dout.contiguous(), b, c,
-                  out_size, out_size, float(grad_scale))
-        return (None, None, None, None, None, *gbuf)
+            return (*none, *[g.to(BF16) for g in gbuf])
+        order, seg = _roi_group(rois, levels, b, nl)
+        entry = (rois, order, seg, dout, out_size, grad_scale)
+        tap = ctx.tap
+        if tap is not None:  # deferred: the tap's backward gathers all pending sets at once
+            tap.scales = scales
+            tap.pending.append(entry)
+            return (*none, *([None] * nl))
+        return (*none, *_roi_gather(shapes, scales, [entry], dout.device))
 
 
 ROI_ALIGN_BWD_ATOMIC = False  # True selects the fp32-atomic scatter variant (kept for A/B tests)
 
 
 def roi_align(feats, rois, levels, out_size, scales, grad_scale=1.0):
-    return _ROIAlignFn.apply(rois, levels, out_size, tuple(scales), grad_scale, *feats)
+    tap = getattr(feats[0], "_u2_roi_tap", None)
+    if tap is not None and (ROI_ALIGN_BWD_ATOMIC or tap.ids != [id(f) for f in feats]):
+        tap = None  # not exactly the tapped list of maps: gather on the spot
+    return _ROIAlignFn.apply(rois, levels, out_size, tuple(scales), grad_scale, tap, *feats)
 
 
 def assign_levels(boxes, min_level, max_level, canonical_size=224, canonical_level=4):

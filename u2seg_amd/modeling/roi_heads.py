@@ -438,6 +438,7 @@ class StandardROIHeads(ROIHeads):
         if self.training:
             assert targets, "'targets' argument is required during training"
             proposals = self.label_and_sample_proposals(proposals, targets)
+            features = self._tap_pooled_features(features)
             losses = self._forward_box(features, proposals)
             losses.update(self._forward_mask(features, proposals))
             return proposals, losses
@@ -463,6 +464,15 @@ class StandardROIHeads(ROIHeads):
         pred, _ = fast_rcnn_inference(boxes, scores, [x.image_size for x in proposals], self.box_predictor.test_score_thresh,
                                       self.box_predictor.test_nms_thresh, self.box_predictor.test_topk_per_image)
         return pred
+
+    def _tap_pooled_features(self, features):
+        """All poolers of these heads read the same FPN maps: defer their ROIAlign backward passes to one gather."""
+        names = list(self.box_in_features)
+        if torch.is_grad_enabled() and (not self.mask_on or list(self.mask_in_features) == names):
+            tapped = F.roi_grad_tap([features[f] for f in names])
+            features = dict(features)
+            features.update(zip(names, tapped))
+        return features
 
     def _forward_mask(self, features, instances):
         if not self.mask_on:
@@ -521,6 +531,7 @@ class CascadeROIHeads(StandardROIHeads):
     def forward(self, images, features, proposals, targets=None):
         if self.training:
             proposals = self.label_and_sample_proposals(proposals, targets)
+            features = self._tap_pooled_features(features)
             losses = self._forward_box(features, proposals, targets)
             losses.update(self._forward_mask(features, proposals))
             return proposals, losses
