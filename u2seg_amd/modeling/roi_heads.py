@@ -13,6 +13,7 @@ from ..layers import Conv2d, ConvTranspose2d, Linear, ShapeSpec, c2_msra_fill, c
 from ..layers import functional as F
 from ..structures import Boxes, Instances
 from ..utils.registry import Registry
+from .batched import BatchList, PaddedTargets, check_finite, device_constant, image_index, proposals_from_list
 from .sampling import subsample_labels
 
 ROI_HEADS_REGISTRY = Registry("ROI_HEADS")
@@ -42,10 +43,14 @@ class ROIPooler(nn.Module):
     def forward(self, x, box_lists, grad_scale=1.0):
         """x: list of NHWC maps; box_lists: list[Boxes] per image -> [R, P, P, C] bf16."""
         dev = x[0].device
-        sizes = [len(b) for b in box_lists]
-        boxes = torch.cat([b.tensor for b in box_lists], dim=0)
-        idx = torch.repeat_interleave(torch.arange(len(box_lists), device=dev, dtype=torch.float32),
-                                      torch.tensor(sizes, device=dev))
+        if isinstance(box_lists, torch.Tensor):  # stacked [B, S, 4]
+            nb, ns = box_lists.shape[:2]
+            boxes = box_lists.reshape(-1, 4)
+            idx = torch.arange(nb, device=dev, dtype=torch.float32)[:, None].expand(nb, ns).reshape(-1)
+        else:
+            sizes = [len(b) for b in box_lists]
+            boxes = torch.cat([b.tensor for b in box_lists], dim=0)
+            idx = image_index(sizes, dev)
         rois = torch.cat([idx[:, None], boxes], dim=1).contiguous()
         if len(self.scales) == 1:
             levels = torch.zeros(rois.shape[0], dtype=torch.int32, device=dev)
@@ -152,9 +157,13 @@ class FastRCNNOutputLayers(nn.Module):
 
     def losses(self, predictions, proposals):
         scores, deltas = predictions
-        gt_classes = torch.cat([p.gt_classes for p in proposals], dim=0) if len(proposals) else torch.empty(0)
-        proposal_boxes = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
-        gt_boxes = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals], dim=0)
+        if isinstance(proposals, BatchList) and proposals.stacked and proposals.gt_boxes is not None:
+            gt_classes = proposals.gt_classes.reshape(-1)
+            proposal_boxes, gt_boxes = proposals.boxes.reshape(-1, 4), proposals.gt_boxes.reshape(-1, 4)
+        else:
+            gt_classes = torch.cat([p.gt_classes for p in proposals], dim=0) if len(proposals) else torch.empty(0)
+            proposal_boxes = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+            gt_boxes = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals], dim=0)
         r = gt_classes.numel()
         if r == 0:
             z = scores.float().sum() * 0.0
@@ -165,14 +174,21 @@ class FastRCNNOutputLayers(nn.Module):
         losses = {"loss_cls": loss_cls, "loss_box_reg": loss_box}
         return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
 
-    def predict_boxes(self, predictions, proposals):
+    def predict_boxes(self, predictions, proposals, stacked=False):
+        """stacked=True (BatchList input): one [B, S, 4] tensor instead of the per-image tuple."""
         _, deltas = predictions
         num_prop = [len(p) for p in proposals]
-        proposal_boxes = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+        if isinstance(proposals, BatchList) and proposals.stacked:
+            proposal_boxes = proposals.boxes.reshape(-1, 4)
+        else:
+            assert not stacked
+            proposal_boxes = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
         if proposal_boxes.shape[0] == 0:
             return [proposal_boxes.new_zeros((0, 4)) for _ in proposals]
         boxes = F.apply_deltas(proposal_boxes, deltas[:, :4].float().contiguous(), self.box2box_weights, None, None,
                                _SCALE_CLAMP)
+        if stacked:
+            return boxes.view(len(num_prop), num_prop[0], 4)
         return boxes.split(num_prop)
 
     def predict_probs(self, predictions, proposals):
@@ -266,6 +282,13 @@ def build_mask_head(cfg, input_shape):
 # ---------------------------------------------------------------------------------------------
 def select_foreground_proposals(proposals, bg_label):
     """roi_heads.py:46-75 (one device->host sync for the whole batch instead of one per image)."""
+    if isinstance(proposals, BatchList) and proposals.stacked and len(proposals):
+        # stacked: compact the foreground rows of every image to the front with one stable sort, one count transfer
+        gc = proposals.gt_classes
+        fgm = (gc != -1) & (gc != bg_label)
+        order = torch.argsort((~fgm).to(torch.int8), dim=1, stable=True)
+        counts = fgm.sum(dim=1).tolist()
+        return [p[order[i, :c]] for i, (p, c) in enumerate(zip(proposals, counts))], list(fgm)
     masks = [(p.gt_classes != -1) & (p.gt_classes != bg_label) for p in proposals]
     counts = torch.stack([m.sum() for m in masks]).tolist() if masks else []
     idx_all = torch.nonzero(torch.cat(masks), as_tuple=True)[0] if masks else None
@@ -319,19 +342,21 @@ class ROIHeads(nn.Module):
         if len(targets) == 0 or n == 0:
             return torch.zeros(n, dtype=torch.int64, device=dev), torch.zeros(n, dtype=torch.int8, device=dev)
         gt = targets.gt_boxes.tensor[None].contiguous()
-        ngt = torch.tensor([len(targets)], dtype=torch.int32, device=dev)
+        ngt = device_constant([len(targets)], torch.int32, dev)
         match, labels, _ = F.iou_match(boxes[None].contiguous(), gt, ngt, thr, thr, False)
         return match[0].long(), labels[0]
 
     @torch.no_grad()
     def label_and_sample_proposals(self, proposals, targets):
-        """roi_heads.py:220-302."""
+        """roi_heads.py:220-302.  Without an injected permutation source (parity tests) the whole batch is labelled and
+        sampled on padded tensors: one IoU-match launch, two top-k, one host synchronisation (the sample counts)."""
         from . import sampling
 
+        if sampling.permutation_source() is None and len(proposals) and all(t.has("gt_classes") for t in targets):
+            return self._label_and_sample_padded(proposals_from_list(proposals, self.training), targets)
         if self.proposal_append_gt:
             proposals = add_ground_truth_to_proposals(targets, proposals)
-        batched = sampling.permutation_source() is None
-        per_image = []
+        out = []
         for prop, tgt in zip(proposals, targets):
             has_gt = len(tgt) > 0
             matched_idxs, matched_labels = self._match(prop.proposal_boxes.tensor, tgt, self.proposal_iou_threshold)
@@ -341,25 +366,8 @@ class ROIHeads(nn.Module):
                 gt_classes[matched_labels == -1] = -1
             else:
                 gt_classes = torch.zeros_like(matched_idxs) + self.num_classes
-            if batched:
-                cand, valid = self._sample_keys(gt_classes)
-                per_image.append((prop, tgt, has_gt, matched_idxs, gt_classes, cand, valid))
-            else:
-                fg_idx, bg_idx = subsample_labels(gt_classes, self.batch_size_per_image, self.positive_fraction, self.num_classes)
-                per_image.append((prop, tgt, has_gt, matched_idxs, gt_classes, torch.cat([fg_idx, bg_idx], dim=0), None))
-        if batched and per_image:
-            # two host synchronisations for the whole batch: the per-image sample counts and one nonzero
-            counts = torch.stack([v.sum() for *_, v in per_image]).tolist()
-            pos = torch.nonzero(torch.cat([v for *_, v in per_image]), as_tuple=True)[0]
-            off = start = 0
-            sampled_all = []
-            for (*_, cand, valid), c in zip(per_image, counts):
-                sampled_all.append(cand[pos[start : start + c] - off])
-                off += valid.numel()
-                start += c
-        out = []
-        for i, (prop, tgt, has_gt, matched_idxs, gt_classes, cand, valid) in enumerate(per_image):
-            sampled = sampled_all[i] if batched else cand
+            fg_idx, bg_idx = subsample_labels(gt_classes, self.batch_size_per_image, self.positive_fraction, self.num_classes)
+            sampled = torch.cat([fg_idx, bg_idx], dim=0)
             res = prop[sampled]
             res.gt_classes = gt_classes[sampled]
             if has_gt:
@@ -370,23 +378,70 @@ class ROIHeads(nn.Module):
             out.append(res)
         return out
 
-    def _sample_keys(self, gt_classes):
-        """Random-key form of sampling.py:38-54 for one image without host synchronisation: candidate indices
-        (foreground first) and their validity (<= 128 foreground, background fills up to 512)."""
-        n = gt_classes.numel()
+    def _label_and_sample_padded(self, lp, targets):
+        dev = lp.boxes.device
+        nb, npad = lp.boxes.shape[:2]
+        pt = PaddedTargets.of(targets, dev)
+        g = pt.boxes.shape[1]
+        if self.proposal_append_gt:  # proposal_utils.py:138-205; the gt rows follow the (padded) proposal rows
+            gt_logit = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
+            boxes = torch.cat([lp.boxes, pt.boxes], dim=1)
+            logits = torch.cat([lp.logits, lp.logits.new_full((nb, g), gt_logit)], dim=1)
+            ar = torch.arange(npad + g, device=dev)[None]
+            valid = (ar < lp.counts[:, None]) | ((ar >= npad) & (ar < npad + pt.counts[:, None]))
+        else:
+            boxes, logits = lp.boxes, lp.logits
+            valid = torch.arange(npad, device=dev)[None] < lp.counts[:, None]
+        n = boxes.shape[1]
+        thr = self.proposal_iou_threshold
+        match, labels, _ = F.iou_match(boxes, pt.boxes, pt.counts, thr, thr, False)
+        match = match.long()
+        gt_classes = torch.gather(pt.classes, 1, match)
+        gt_classes = torch.where(labels == 1, gt_classes, torch.where(labels == 0, self.num_classes, -1))
+        gt_classes = torch.where(valid, gt_classes, -1)  # padding rows are never sampled
+        # sampling.py:38-54 as random keys + top-k: <= 128 random foreground rows, background fills up to 512
         total = self.batch_size_per_image
         max_fg = int(total * self.positive_fraction)
-        key = torch.rand(n, device=gt_classes.device)
+        key = torch.rand((nb, n), device=dev)
         big = torch.full_like(key, 2.0)
         is_bg = gt_classes == self.num_classes
-        is_fg = (gt_classes != -1) & ~is_bg
+        is_fg = (gt_classes >= 0) & ~is_bg
         kf, kb = min(max_fg, n), min(total, n)
-        fg_key, fg_idx = torch.where(is_fg, key, big).topk(kf, largest=False)
-        bg_key, bg_idx = torch.where(is_bg, key, big).topk(kb, largest=False)
+        fg_key, fg_idx = torch.where(is_fg, key, big).topk(kf, dim=1, largest=False)
+        bg_key, bg_idx = torch.where(is_bg, key, big).topk(kb, dim=1, largest=False)
         fg_valid = fg_key < 1.5
-        num_bg = total - fg_valid.sum()
-        bg_valid = (bg_key < 1.5) & (torch.arange(kb, device=key.device) < num_bg)
-        return torch.cat([fg_idx, bg_idx]), torch.cat([fg_valid, bg_valid])
+        num_bg = total - fg_valid.sum(dim=1, keepdim=True)
+        bg_valid = (bg_key < 1.5) & (torch.arange(kb, device=dev)[None] < num_bg)
+        cand, cvalid = torch.cat([fg_idx, bg_idx], dim=1), torch.cat([fg_valid, bg_valid], dim=1)
+        order = torch.argsort((~cvalid).to(torch.int8), dim=1, stable=True)[:, :total]
+        sampled = torch.gather(cand, 1, order)  # [B, S]; rows >= count are padding
+        s = sampled.shape[1]
+        flags = [cvalid.sum(dim=1)] + ([lp.finite.reshape(1).to(torch.int64)] if lp.finite is not None else [])
+        vals = torch.cat(flags).tolist()  # the one host synchronisation of the sampler
+        if lp.finite is not None:
+            check_finite(bool(vals[-1]), self.training)
+            lp.finite = None
+        counts = vals[:nb]
+        s_boxes = torch.gather(boxes, 1, sampled[..., None].expand(-1, -1, 4))
+        s_logits = torch.gather(logits, 1, sampled)
+        s_cls = torch.gather(gt_classes, 1, sampled)
+        s_match = torch.gather(match, 1, sampled)
+        s_gtb = torch.gather(pt.boxes, 1, s_match[..., None].expand(-1, -1, 4))
+        out = BatchList()
+        for i, (size, tgt, c) in enumerate(zip(lp.image_sizes, targets, counts)):
+            res = Instances(size)
+            res.proposal_boxes = Boxes(s_boxes[i, :c])
+            res.objectness_logits = s_logits[i, :c]
+            res.gt_classes = s_cls[i, :c]
+            if len(tgt) > 0:
+                res.gt_boxes = Boxes(s_gtb[i, :c])
+                for name, value in tgt.get_fields().items():
+                    if name.startswith("gt_") and not res.has(name):
+                        res.set(name, value[s_match[i, :c]])
+            out.append(res)
+        if all(c == s for c in counts):
+            out.boxes, out.gt_classes, out.gt_boxes = s_boxes, s_cls, s_gtb
+        return out
 
 
 class StandardROIHeads(ROIHeads):
@@ -546,11 +601,15 @@ class CascadeROIHeads(StandardROIHeads):
         image_sizes = [x.image_size for x in proposals]
         for k in range(self.num_cascade_stages):
             if k > 0:
-                proposals = self._create_proposals_from_boxes(prev_pred_boxes, image_sizes)
-                if self.training:
-                    proposals = self._match_and_label_boxes(proposals, k, targets)
+                if isinstance(prev_pred_boxes, torch.Tensor):  # stacked [B, S, 4] (training, equal counts per image)
+                    proposals = self._next_stage_stacked(prev_pred_boxes, image_sizes, k, targets)
+                else:
+                    proposals = self._create_proposals_from_boxes(prev_pred_boxes, image_sizes)
+                    if self.training:
+                        proposals = self._match_and_label_boxes(proposals, k, targets)
             predictions = self._run_stage(feats, proposals, k)
-            prev_pred_boxes = self.box_predictor[k].predict_boxes(predictions, proposals)
+            stacked = self.training and isinstance(proposals, BatchList) and proposals.stacked
+            prev_pred_boxes = self.box_predictor[k].predict_boxes(predictions, proposals, stacked=stacked)
             head_outputs.append((self.box_predictor[k], predictions, proposals))
         if self.training:
             losses = {}
@@ -583,8 +642,39 @@ class CascadeROIHeads(StandardROIHeads):
             prop.gt_boxes = gt_boxes
         return proposals
 
+    @torch.no_grad()
+    def _next_stage_stacked(self, boxes, image_sizes, stage, targets):
+        """cascade_rcnn.py:226-299 for a batch whose images all carry S boxes: clip, (rarely) drop empty boxes, IoU-match
+        and label with a handful of batched launches and one host synchronisation (the any-empty flag)."""
+        nb, ns = boxes.shape[:2]
+        dev = boxes.device
+        lim = device_constant([[[w, h, w, h]] for h, w in image_sizes], torch.float32, dev)
+        boxes = torch.minimum(boxes.detach().clamp(min=0), lim)
+        nonempty = (boxes[..., 2:] > boxes[..., :2]).all(dim=-1)
+        if not bool(nonempty.all()):  # cascade_rcnn.py:291-294: ragged result, take the per-image path
+            props = self._create_proposals_from_boxes(list(boxes), image_sizes)
+            return self._match_and_label_boxes(props, stage, targets)
+        pt = PaddedTargets.of(targets, dev)
+        thr = self.cascade_ious[stage]
+        match, labels, _ = F.iou_match(boxes.contiguous(), pt.boxes, pt.counts, thr, thr, False)
+        match = match.long()
+        gt_classes = torch.where(labels == 1, torch.gather(pt.classes, 1, match), self.num_classes)
+        gt_boxes = torch.gather(pt.boxes, 1, match[..., None].expand(-1, -1, 4))
+        out = BatchList()
+        for i, size in enumerate(image_sizes):
+            prop = Instances(size)
+            prop.proposal_boxes = Boxes(boxes[i])
+            prop.gt_classes = gt_classes[i]
+            prop.gt_boxes = Boxes(gt_boxes[i])
+            out.append(prop)
+        out.boxes, out.gt_classes, out.gt_boxes = boxes, gt_classes, gt_boxes
+        return out
+
     def _run_stage(self, feats, proposals, stage):
         gs = 1.0 / self.num_cascade_stages if self.training else 1.0
+        if isinstance(proposals, BatchList) and proposals.stacked:
+            box_features = self.box_pooler(feats, proposals.boxes, grad_scale=gs)
+            return self.box_predictor[stage](self.box_head[stage](box_features))
         box_features = self.box_pooler(feats, [x.proposal_boxes for x in proposals], grad_scale=gs)
         return self.box_predictor[stage](self.box_head[stage](box_features))
 

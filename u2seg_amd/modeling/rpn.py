@@ -15,6 +15,7 @@ from ..layers import Conv2d
 from ..layers import functional as F
 from ..structures import Boxes, Instances
 from ..utils.registry import Registry
+from .batched import LazyProposals, PaddedTargets, device_constant
 from .sampling import subsample_labels
 
 ANCHOR_GENERATOR_REGISTRY = Registry("ANCHOR_GENERATOR")
@@ -249,7 +250,7 @@ class RPN(nn.Module):
         b = objs[0].shape[0]
         dev = objs[0].device
         pre, post = self.pre_nms_topk[self.training], self.post_nms_topk[self.training]
-        sizes = torch.tensor(image_sizes, dtype=torch.float32, device=dev)
+        sizes = device_constant([list(x) for x in image_sizes], torch.float32, dev)
         scores_l, boxes_l, lvl_l = [], [], []
         for lvl, (anc, o, d) in enumerate(zip(anchors_per_level, objs, dlts)):
             hwa = o.shape[1] * o.shape[2] * a
@@ -268,8 +269,7 @@ class RPN(nn.Module):
         boxes = torch.cat(boxes_l, dim=1)
         lvls = torch.cat(lvl_l)[None].expand(b, -1)
         finite = torch.isfinite(boxes).all(dim=2) & torch.isfinite(scores)
-        if self.training and not bool(finite.all()):
-            raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
+        all_finite = finite.all()  # raised as FloatingPointError when the counts are first read on the host
         keep = finite & ((boxes[..., 2] - boxes[..., 0]) > self.min_box_size) & ((boxes[..., 3] - boxes[..., 1]) > self.min_box_size)
         order_key = torch.where(keep, scores, torch.full_like(scores, -float("inf")))
         order = torch.sort(order_key, dim=1, descending=True, stable=True)[1]
@@ -278,15 +278,10 @@ class RPN(nn.Module):
         s_lvls = torch.gather(lvls, 1, order).contiguous()
         counts = keep.sum(dim=1).to(torch.int32)
         kept, nkeep = F.batched_nms(s_boxes, s_lvls, counts, self.nms_thresh, post)
-        nk = nkeep.tolist()
-        out = []
-        for i, image_size in enumerate(image_sizes):
-            idx = kept[i, : nk[i]].long()
-            res = Instances(image_size)
-            res.proposal_boxes = Boxes(s_boxes[i, idx])
-            res.objectness_logits = s_scores[i, idx]
-            out.append(res)
-        return out
+        idx = kept.long()  # rows >= nkeep[i] are zero: padding that points at a valid row
+        p_boxes = torch.gather(s_boxes, 1, idx[..., None].expand(-1, -1, 4))
+        p_scores = torch.gather(s_scores, 1, idx)
+        return LazyProposals(image_sizes, p_boxes, p_scores, nkeep, all_finite, self.training)
 
     def forward(self, image_sizes, features, gt_instances=None):
         feats = [features[f] for f in self.in_features]
@@ -295,7 +290,8 @@ class RPN(nn.Module):
         objs, dlts = self.rpn_head(feats)
         if self.training:
             assert gt_instances is not None, "RPN requires gt_instances in training!"
-            gt_pad, num_gt = pad_gt_boxes(gt_instances, objs[0].device)
+            padded = PaddedTargets.of(gt_instances, objs[0].device)
+            gt_pad, num_gt = padded.boxes, padded.counts
             anchors_cat = torch.cat(anchors_per_level, dim=0)
             labels, match = self.label_and_sample_anchors(anchors_cat, gt_pad, num_gt)
             losses = self.losses(anchors_per_level, objs, dlts, labels, match, gt_pad)
@@ -313,7 +309,7 @@ def pad_gt_boxes(gt_instances, device):
     for i, inst in enumerate(gt_instances):
         if len(inst):
             out[i, : len(inst)] = inst.gt_boxes.tensor
-    cnt = torch.tensor([len(x) for x in gt_instances], dtype=torch.int32, device=device)
+    cnt = device_constant([len(x) for x in gt_instances], torch.int32, device)
     return out, cnt
 
 
