@@ -68,9 +68,13 @@ int u2_affine_act(const void* x, const float* scale, const float* shift, const v
                   int rows_per_slot, int C, int ld, int relu, void* stream);
 int u2_norm_bwd_reduce(const void* dout, const void* mask, const void* x, const float* mean, const float* invstd,
                        float* out /*[slots][2][C]*/, int slots, int rows_per_slot, int C, int ld, int relu,
-                       const float* mask_scale, const float* mask_shift, void* stream);
+                       const float* mask_scale, const float* mask_shift, const void* dout2, void* dz_out, void* stream);
 /* mask_scale/mask_shift [slots][C] (optional, both or neither): recompute the ReLU mask as x*scale+shift > 0 - the
- * expression u2_affine_act evaluated in the forward pass - instead of reading the activation `mask` (which may be NULL). */
+ * expression u2_affine_act evaluated in the forward pass - instead of reading the activation `mask` (which may be NULL).
+ * u2_norm_bwd_reduce only: dz_out (optional) receives the masked gradient dz = (dout [+ dout2]) * mask, so that
+ * u2_norm_bwd_apply can run on (dz, x) with relu = 0 and dz doubles as the residual branch's gradient; dout2 (optional,
+ * needs dz_out) is a second incoming gradient summed on the fly (resnet.py:204-210: the block output feeds the next
+ * block's conv1 and its identity shortcut). */
 int u2_bn_finalize_bwd(const float* sums, float count, const float* gamma, const float* mean, const float* invstd,
                        const float* local_sums, float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C,
                        int accumulate /* dgamma/dbeta += instead of = (parameter gradient arena) */, void* stream);

@@ -20,12 +20,16 @@ namespace {
 //         affine_act evaluated (fp contraction is off, so it is bit-identical) - and the activation is not read at all.
 // ---------------------------------------------------------------------------------------------
 // MASK (MODE 1): 0 no ReLU, 1 read the activation, 2 recompute x*msc + msh > 0
-template <int MODE, int MASK>
+// DZ (MODE 1): the incoming gradient is dout (+ dout2 when given: the two consumers of a residual block's output, summed
+//         here instead of by a separate pass) and the masked gradient dz is also written out - it is the gradient of
+//         the residual input as it stands, and the apply pass then reads dz and x only.
+template <int MODE, int MASK, bool DZ>
 __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dout,
                                                         const bf16_t* __restrict__ mask, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, float* __restrict__ out,
                                                         int rows_per_slot, int C, int ld, int rows_per_block,
-                                                        const float* __restrict__ msc, const float* __restrict__ msh) {
+                                                        const float* __restrict__ msc, const float* __restrict__ msh,
+                                                        const bf16_t* __restrict__ dout2, bf16_t* __restrict__ dz_out) {
   __shared__ float part[2][2048];
   constexpr int U = 2;  // rows in flight per thread
   const int cpr = C >> 3;
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
         }
       }
       for (int r0 = r_begin + rl; r0 < r_end; r0 += U * rows_par) {
-        uint4 xq[U], dq[U], mq[U];
+        uint4 xq[U], dq[U], mq[U], eq[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int r = r0 + u * rows_par;
@@ -65,6 +69,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
             if (MODE == 1) {
               dq[u] = *reinterpret_cast<const uint4*>(dout + off);
               if (MASK == 1) mq[u] = *reinterpret_cast<const uint4*>(mask + off);
+              if (DZ && dout2) eq[u] = *reinterpret_cast<const uint4*>(dout2 + off);
             }
           }
         }
@@ -75,6 +80,8 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
             const bf16_t* xv = reinterpret_cast<const bf16_t*>(&xq[u]);
             const bf16_t* dv = reinterpret_cast<const bf16_t*>(&dq[u]);
             const bf16_t* mv = reinterpret_cast<const bf16_t*>(&mq[u]);
+            const bf16_t* ev = reinterpret_cast<const bf16_t*>(&eq[u]);
+            bf16_t zv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const float xf = bf2f(xv[e]);
@@ -83,12 +90,15 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
                 s1[e] += xf * xf;
               } else {
                 float dz = bf2f(dv[e]);
+                if (DZ && dout2) dz = bf2f(f2bf(dz + bf2f(ev[e])));  // rounded like the bf16 sum autograd would form
                 if (MASK == 1 && !(bf2f(mv[e]) > 0.f)) dz = 0.f;
                 if (MASK == 2 && !(xf * ms[e] + mh[e] > 0.f)) dz = 0.f;
+                if (DZ) zv[e] = f2bf(dz);
                 s0[e] += dz;
                 s1[e] += dz * (xf - mu[e]) * is[e];
               }
             }
+            if (DZ) *reinterpret_cast<uint4*>(dz_out + (row0 + r) * ld + c) = *reinterpret_cast<const uint4*>(zv);
           }
         }
       }
@@ -458,26 +468,29 @@ extern "C" int u2_colstats(const void* x, float* out, int slots, int rows_per_sl
   int rpb = (rows_per_slot + 511) / 512;  // ~512 blocks per slot
   if (rpb < 64) rpb = 64;
   const dim3 grid((rows_per_slot + rpb - 1) / rpb, slots);
-  hipLaunchKernelGGL((colreduce_kernel<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, nullptr, nullptr,
-                     nullptr, nullptr, out, rows_per_slot, C, ld, rpb, nullptr, nullptr);
+  hipLaunchKernelGGL((colreduce_kernel<0, 0, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, nullptr,
+                     nullptr, nullptr, nullptr, out, rows_per_slot, C, ld, rpb, nullptr, nullptr, nullptr, nullptr);
   U2_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int u2_norm_bwd_reduce(const void* dout, const void* mask, const void* x, const float* mean, const float* invstd,
                                   float* out, int slots, int rows_per_slot, int C, int ld, int relu,
-                                  const float* mask_scale, const float* mask_shift, void* stream) {
+                                  const float* mask_scale, const float* mask_shift, const void* dout2, void* dz_out,
+                                  void* stream) {
   if ((C & 7) || (ld & 7)) return -1;
+  if (dout2 && !dz_out) return -1;
   if (slots <= 0 || rows_per_slot <= 0) return 0;
   int rpb = (rows_per_slot + 511) / 512;
   if (rpb < 64) rpb = 64;
   const dim3 grid((rows_per_slot + rpb - 1) / rpb, slots);
   if (relu && !mask && !mask_scale) return -1;
-#define U2_REDUCE(MM_)                                                                                               \
-  hipLaunchKernelGGL((colreduce_kernel<1, MM_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,           \
+#define U2_REDUCE(MM_, DZ_)                                                                                          \
+  hipLaunchKernelGGL((colreduce_kernel<1, MM_, DZ_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,      \
                      (const bf16_t*)dout, (const bf16_t*)mask, mean, invstd, out, rows_per_slot, C, ld, rpb, mask_scale, \
-                     mask_shift)
-  if (!relu) U2_REDUCE(0); else if (mask_scale) U2_REDUCE(2); else U2_REDUCE(1);
+                     mask_shift, (const bf16_t*)dout2, (bf16_t*)dz_out)
+  if (dz_out) { if (!relu) U2_REDUCE(0, true); else if (mask_scale) U2_REDUCE(2, true); else U2_REDUCE(1, true); }
+  else { if (!relu) U2_REDUCE(0, false); else if (mask_scale) U2_REDUCE(2, false); else U2_REDUCE(1, false); }
 #undef U2_REDUCE
   U2_CHECK_LAUNCH();
   return 0;

@@ -266,7 +266,8 @@ class _BatchNormActFn(Function):
     residual add + relu_ at backbone/resnet.py:204-210)."""
 
     @staticmethod
-    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, grad_dst=None):
+    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, grad_dst=None,
+                twin=False):
         _check_act(y)
         b, h, w, c = y.shape
         m = b * h * w
@@ -286,17 +287,32 @@ class _BatchNormActFn(Function):
                               scale if remask else None, shift if remask else None)
         ctx.cfg = (relu, count, world, residual is not None)
         ctx.grad_dst = grad_dst  # (dgamma, dbeta) arena slices or None
+        ctx.twin = twin
+        if twin:  # two handles on the same activation: their gradients arrive separately and are summed in the kernel
+            ctx.set_materialize_grads(False)
+            return out, out.detach()
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dout2=None):
         y, out, gamma, mean, invstd, msc, msh = ctx.saved_tensors
         relu, count, world, has_res = ctx.cfg
         b, h, w, c = y.shape
         m = b * h * w
+        nret = 12
+        if dout is None:
+            dout, dout2 = dout2, None
+        if dout is None:
+            return (None,) * nret
         dout = dout.contiguous()
+        fuse = has_res and relu  # residual block tail: dz is materialised by the reduce pass and is the residual gradient
+        if dout2 is not None:
+            dout2 = dout2.contiguous()
+            if not fuse:
+                dout, dout2 = dout + dout2, None
+        dz = torch.empty_like(y) if fuse else None
         sums = zeros_f32((2, c), y.device)
-        _hip.call("u2_norm_bwd_reduce", dout, out, y, mean, invstd, sums, 1, m, c, c, int(relu), msc, msh)
+        _hip.call("u2_norm_bwd_reduce", dout, out, y, mean, invstd, sums, 1, m, c, c, int(relu), msc, msh, dout2, dz)
         local = sums
         if world > 1:
             local = sums.clone()
@@ -307,18 +323,31 @@ class _BatchNormActFn(Function):
         _hip.call("u2_bn_finalize_bwd", sums, count, gamma, mean, invstd, local, dgamma, dbeta, coef[2], coef[3],
                   coef[4], c, int(direct))
         dx = torch.empty_like(y)
-        dres = torch.empty_like(y) if has_res else None
-        _hip.call("u2_norm_bwd_apply", dout, out, y, coef[2], coef[3], coef[4], dx, dres, 1, m, c, c, int(relu), msc, msh)
+        if fuse:
+            _hip.call("u2_norm_bwd_apply", dz, None, y, coef[2], coef[3], coef[4], dx, None, 1, m, c, c, 0, None, None)
+            dres = dz
+        else:
+            dres = torch.empty_like(y) if has_res else None
+            _hip.call("u2_norm_bwd_apply", dout, out, y, coef[2], coef[3], coef[4], dx, dres, 1, m, c, c, int(relu), msc, msh)
         if direct:
             dgamma = dbeta = None
-        return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None
+        return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
 
 def batch_norm_act(y, stats, gamma, beta, running_mean, running_var, residual=None, relu=False, momentum=0.1,
-                   eps=1e-5):
+                   eps=1e-5, twin=False):
+    """twin=True: returns the activation with a second autograd handle on the same memory in `._u2_twin` (for a consumer
+    pair such as the next residual block's conv1 and identity shortcut); the two gradients are summed inside the
+    backward kernel instead of by autograd."""
     gd, bd = grad_slot(gamma), grad_slot(beta)
     grad_dst = (gd, bd) if gd is not None and bd is not None else None
-    return _BatchNormActFn.apply(y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, grad_dst)
+    twin = bool(twin) and torch.is_grad_enabled()
+    out = _BatchNormActFn.apply(y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, grad_dst,
+                                twin)
+    if twin:
+        out, other = out
+        out._u2_twin = other
+    return out
 
 
 def affine_act(y, scale, shift, residual=None, relu=False):
@@ -364,7 +393,7 @@ class _GroupNormActFn(Function):
         n = float(hw * cg)
         dout = dout.contiguous()
         sums = zeros_f32((b, 2, c), y.device)
-        _hip.call("u2_norm_bwd_reduce", dout, None, y, mean, invstd, sums, b, hw, c, c, int(relu), msc, msh)
+        _hip.call("u2_norm_bwd_reduce", dout, None, y, mean, invstd, sums, b, hw, c, c, int(relu), msc, msh, None, None)
         s1, s2 = sums[:, 0], sums[:, 1]
         g = gamma.detach()[None]
         a = ((g * s1).view(b, groups, cg).sum(-1) / n).repeat_interleave(cg, dim=1)

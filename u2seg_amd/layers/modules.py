@@ -134,7 +134,7 @@ class Conv2d(nn.Module):
         assert activation in (None, "relu"), "only ReLU is fused (the U2Seg graph uses nothing else)"
         self.activation = activation
 
-    def forward(self, x, residual=None, relu=None):
+    def forward(self, x, residual=None, relu=None, twin=False):
         relu = (self.activation == "relu") if relu is None else relu
         norm = self.norm
         if norm is None:
@@ -145,7 +145,7 @@ class Conv2d(nn.Module):
             y, stats = F.conv2d(x, self.weight, None, self.stride, self.padding, relu=False, want_stats=True)
             norm.count_batch()
             return F.batch_norm_act(y, stats, norm.weight, norm.bias, norm.running_mean, norm.running_var, residual,
-                                    relu, norm.momentum, norm.eps)
+                                    relu, norm.momentum, norm.eps, twin=twin)
         y = F.conv2d(x, self.weight, None, self.stride, self.padding, relu=False)
         if isinstance(norm, GroupNorm):
             assert residual is None

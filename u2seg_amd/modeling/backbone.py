@@ -82,10 +82,13 @@ class BottleneckBlock(nn.Module):
                 c2_msra_fill(layer)
 
     def forward(self, x):
+        # the block input feeds conv1 and the shortcut; when the previous block handed out two autograd handles of it
+        # (functional.batch_norm_act(twin=True)) the two gradients meet inside that block's BN backward kernel
+        x_sc = getattr(x, "_u2_twin", x)
         out = self.conv1(x)
         out = self.conv2(out)
-        shortcut = self.shortcut(x) if self.shortcut is not None else x
-        return self.conv3(out, residual=shortcut, relu=True)  # out += shortcut; relu_
+        shortcut = self.shortcut(x_sc) if self.shortcut is not None else x_sc
+        return self.conv3(out, residual=shortcut, relu=True, twin=True)  # out += shortcut; relu_
 
 
 class ResNet(Backbone):
