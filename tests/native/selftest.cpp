@@ -207,6 +207,7 @@ int main(int argc, char** argv) {
   };
   for (int v = 0; v < 4; ++v)
     for (const auto& c : wgs) fails += test_wgrad(c, v);
+  for (const auto& c : wgs) fails += test_wgrad(c, 64);
   for (const auto& c : wgs) fails += test_wgrad(c, 0, true);
   printf("SELFTEST %s (%d failures)\n", fails ? "FAILED" : "OK", fails);
   if (argc > 1 && !strcmp(argv[1], "bench")) {
@@ -222,12 +223,16 @@ int main(int argc, char** argv) {
       bench_conv("fc1 12544->1024 M8192", 1, 8192, 1, 12544, 1024, 1, 0, 1, v);
       bench_conv("gemm 8192x8192x8192", 1, 8192, 1, 8192, 8192, 1, 0, 1, v);
     }
-    const int vs[] = {16};  // wgrad: half the split slots
+    const int vs[] = {64};  // wgrad: all tiles of a pixel split on one XCD
     for (int v : vs) {
+      bench_conv("res2 3x3 64->64 B16", 16, 200, 336, 64, 64, 3, 1, 1, v);
+      bench_conv("res3 3x3 128->128 B16", 16, 100, 168, 128, 128, 3, 1, 1, v);
       bench_conv("fpn_out2 3x3 256->256 B16", 16, 200, 336, 256, 256, 3, 1, 1, v);
       bench_conv("res4 3x3 256->256 B16", 16, 50, 84, 256, 256, 3, 1, 1, v);
       bench_conv("res4 1x1 1024->256 B16", 16, 50, 84, 1024, 256, 1, 0, 1, v);
+      bench_conv("res5 3x3 512->512 B16", 16, 25, 42, 512, 512, 3, 1, 1, v);
       bench_conv("res2 1x1 64->256 B16", 16, 200, 336, 64, 256, 1, 0, 1, v);
+      bench_conv("fc1 12544->1024 M8192", 1, 8192, 1, 12544, 1024, 1, 0, 1, v);
       bench_conv("gemm 8192x8192x8192", 1, 8192, 1, 8192, 8192, 1, 0, 1, v);
     }
   }

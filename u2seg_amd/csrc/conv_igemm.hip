@@ -365,6 +365,7 @@ struct WgradArgs {
   int Hout, Wout, N, dy_ld;
   int KH, KW, pad_h, pad_w, stride;
   int M, tiles_n, tiles_c, pix_per_wg;
+  int tiles, xcd_group;  // tiles = tiles_n * tiles_c * taps; xcd_group: 1-D launch, all tiles of a pixel split on one XCD
 };
 
 constexpr int WP = 32;  // pixels per reduction step
@@ -383,13 +384,20 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int t = blockIdx.x;
+  int t = blockIdx.x, split = blockIdx.y;
+  if (a.xcd_group) {
+    // every (n-tile, c-tile, tap) of one pixel split streams the same pixels: keep them on one XCD so that its L2 serves
+    // all but the first read (hardware sends work-group i to XCD i % 8)
+    const int logical = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    split = logical / a.tiles;
+    t = logical - split * a.tiles;
+  }
   const int tile_c = t % a.tiles_c; t /= a.tiles_c;
   const int tile_n = t % a.tiles_n; t /= a.tiles_n;
   const int tap = t;
   const int kh = tap / a.KW, kw = tap - kh * a.KW;
   const int n0 = tile_n * 128, c0 = tile_c * 128;
-  const int mbeg = blockIdx.y * a.pix_per_wg;
+  const int mbeg = split * a.pix_per_wg;
   const int mend = min(a.M, mbeg + a.pix_per_wg);
   if (mbeg >= mend) return;
   const int nsteps = (mend - mbeg + WP - 1) / WP;
@@ -728,7 +736,11 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
   ppw = ((ppw + WP - 1) / WP) * WP;
   splits = (a.M + ppw - 1) / ppw;
   a.pix_per_wg = ppw;
-  const dim3 grid(tiles, splits), block(256);
+  a.tiles = tiles;
+  // measured: +29% on res3 3x3, +6% on the 200x336 3x3 layers, -3..-10% on small-M layers and plain GEMMs
+  a.xcd_group = ((variant & 64) || (!(variant & 128) && KH * KW > 1 && a.M >= 200000)) ? 1 : 0;
+  const dim3 grid = a.xcd_group ? dim3(tiles * splits) : dim3(tiles, splits);
+  const dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool glds = (variant & 1) == 0, tr = (variant & 2) == 0;
   if (glds && tr)       hipLaunchKernelGGL((conv_wgrad_kernel<true, true>), grid, block, 0, s, a);
