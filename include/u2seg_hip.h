@@ -54,7 +54,8 @@ typedef struct U2LayoutDesc {
   long long src_offset; /* floats from `base` to the [N][Cin][T] fp32 parameter */
   void* dst;            /* device pointer of the bf16 layout */
   int N, Cin, T, Cp, Npad, mode;
-  int block_begin;      /* first work-group of this entry: prefix sum of ceil(layout elements / 2048) */
+  int block_begin;      /* first work-group of this entry: prefix sum of blocks(entry) = mode 0: N * ceil(Cp/64);
+                           modes 1, 2 (need Cp == Cin): ceil(Npad/64) * ceil(Cin*T/64) */
   int reserved;
 } U2LayoutDesc;
 int u2_weight_layout_batched(const float* base, const U2LayoutDesc* table, int n_entries, int total_blocks, void* stream);
@@ -96,6 +97,9 @@ int u2_bilinear_up2_fwd(const void* x, const void* addend /*nullable, out = up2(
 int u2_bilinear_up2_bwd(const void* dout, void* dx, int B, int H, int W, int C, void* stream);
 int u2_stem_im2col(const void* img, int is_uint8, const float* mean, const float* stdv, void* col, int b, int h, int w,
                    int Hpad, int Wpad, int KP, void* stream);
+/* All images of the batch (host arrays of device pointers / sizes; images may differ in size) in one launch. */
+int u2_stem_im2col_batch(const void* const* imgs, const int* hs, const int* ws, int n_imgs, int is_uint8, const float* mean,
+                         const float* stdv, void* col, int Hpad, int Wpad, int KP, void* stream);
 
 /* ---- losses (losses.hip) -----------------------------------------------------------------------
  * meta_arch/semantic_seg.py:255-267, roi_heads/fast_rcnn.py:307-347,424-463, roi_heads/mask_head.py:33-112,

@@ -452,17 +452,20 @@ def test_arena_direct_grads_and_cached_layouts(F):
             self.c2 = Conv2d(96, 64, 3, padding=1, bias=False, norm=BatchNorm2d(64), activation="relu")
             self.c3 = Conv2d(64, 40, 1, bias=True)
             self.fc = Linear(64, 70)
+            self.fc1 = Linear(64 * 3 * 5, 48)  # applied as a 3x5 "fully connected" conv like FastRCNNConvFCHead.fc1
 
         def forward(self, x):
             y = self.c3(self.c2(self.c1(x)))
             z = self.fc(x.reshape(-1, 64))
-            return y.float().square().mean() + z.float().square().mean()
+            u = F.conv2d(x[:, :3, :5].contiguous(), self.fc1.weight.view(48, 64, 3, 5), self.fc1.bias, 1, 0, relu=True,
+                         param=self.fc1.weight)
+            return y.float().square().mean() + z.float().square().mean() + u.float().square().mean()
 
     torch.manual_seed(0)
     plain = Net().to(DEV).train()
     arena = copy.deepcopy(plain)
     opt = FlatSGD(arena, lr=0.05, momentum=0.9, weight_decay=1e-4, weight_decay_norm=1e-4, clip_value=0.0)
-    xs = [nhwc(torch.randn(2, 64, 12, 20)) for _ in range(3)]
+    xs = [nhwc(torch.randn(2, 64, 12, 20)).requires_grad_() for _ in range(3)]  # data gradients too (dgrad layouts)
     popt = torch.optim.SGD(plain.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
     for it, x in enumerate(xs):
         opt.zero_grad()
@@ -483,7 +486,14 @@ def test_arena_direct_grads_and_cached_layouts(F):
         if it == 0:
             for (k, a), (_, b) in zip(arena.named_parameters(), plain.named_parameters()):
                 assert rel_err(a.detach(), b.detach()) < 2e-2, (it, k)  # zero-initialised parameters are lr * gradient
-    assert len(opt._layout_entries) >= 6  # fwd + dgrad layouts were registered and refreshed by step()
+    assert len(opt._layout_entries) >= 10  # fwd + dgrad layouts were registered and refreshed by step()
+    modes = set()
+    for p_, key, ent in opt._layout_entries:  # the batched LDS-tiled refresh == the per-tensor kernel, bit for bit
+        n_, cin_, t_, cp_, npad_, mode_ = key
+        modes.add(mode_)
+        fresh = F._weight_layout(p_.detach().reshape(n_, cin_, t_, 1), cp_, npad_, mode_)
+        assert torch.equal(fresh.reshape(-1), ent[0].reshape(-1)), key
+    assert modes == {0, 1, 2}
     # in-place edits through torch invalidate the cached layouts (autograd version check)
     with torch.no_grad():
         arena.c1.weight.mul_(2.0)

@@ -407,10 +407,14 @@ __global__ __launch_bounds__(256) void weight_layout_kernel(const float* __restr
   weight_layout_body(w, out, N, Cin, T, Cp, Npad, mode);
 }
 
-// One launch for every cached layout of every parameter.  A block converts 2048 consecutive output elements of one
-// table entry; entries own the block range [block_begin, next entry's block_begin).
+// One launch for every cached layout of every parameter, as LDS-tiled transposes (both sides move whole 128-byte
+// segments).  Entries own the block range [block_begin, next entry's block_begin):
+//   mode 0:    N * ceil(Cp / 64) blocks - block (n, 64 input channels): reads 64*T contiguous floats, writes T rows of 64 c
+//   mode 1, 2: ceil(Npad / 64) * ceil(Cin*T / 64) blocks - block (64 n, 64 contiguous (c,t) columns): reads 64 rows of
+//              256 B, writes 64 output rows of 64 n (requires Cp == Cin: no all-zero output rows)
 __global__ __launch_bounds__(256) void weight_layout_batched_kernel(const float* __restrict__ base,
                                                                     const U2LayoutDesc* __restrict__ table, int n_entries) {
+  __shared__ float tile[64 * 65];
   const int b = blockIdx.x;
   int lo = 0, hi = n_entries - 1;
   while (lo < hi) {  // last entry with block_begin <= b
@@ -421,23 +425,48 @@ __global__ __launch_bounds__(256) void weight_layout_batched_kernel(const float*
   const float* __restrict__ w = base + d.src_offset;
   bf16_t* __restrict__ out = (bf16_t*)d.dst;
   const int N = d.N, Cin = d.Cin, T = d.T, Cp = d.Cp, Npad = d.Npad, mode = d.mode;
-  const size_t total = mode == 0 ? (size_t)N * T * Cp : (size_t)Cp * T * Npad;
-  const size_t i0 = (size_t)(b - d.block_begin) * 2048;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const size_t i = i0 + k * 256 + threadIdx.x;
-    if (i >= total) break;
-    int n, c, t;
-    if (mode == 0) {
-      c = (int)(i % Cp); const size_t r = i / Cp; t = (int)(r % T); n = (int)(r / T);
-    } else if (mode == 1) {
-      n = (int)(i % Npad); const size_t r = i / Npad; t = T - 1 - (int)(r % T); c = (int)(r / T);
-    } else {
-      n = (int)(i % Npad); const size_t r = i / Npad; c = (int)(r % Cp); t = (int)(r / Cp);
+  const int lb = b - d.block_begin;
+  const int tid = threadIdx.x;
+  if (mode == 0) {
+    const int cchunks = (Cp + 63) >> 6;
+    const int n = lb / cchunks, c0 = (lb - n * cchunks) * 64;
+    const int cn = min(64, Cin - c0);  // valid input channels of this chunk (<= 0: pure padding)
+    const float* src = w + ((size_t)n * Cin + c0) * T;
+    for (int t0 = 0; t0 < T; t0 += 64) {  // taps in groups of 64 (T <= 64 in this model: one pass)
+      const int tn = min(64, T - t0);
+      __syncthreads();
+      for (int i = tid; i < cn * tn; i += 256) {
+        // element (c, t) of the [cn][T] source block; consecutive i are consecutive addresses when tn == T
+        const int c = i / tn, t = i - c * tn;
+        tile[c * 65 + t] = src[(size_t)c * T + t0 + t];
+      }
+      __syncthreads();
+      const int cw = min(64, Cp - c0);
+      for (int i = tid; i < tn * cw; i += 256) {
+        const int t = i / cw, c = i - t * cw;
+        out[((size_t)n * T + t0 + t) * Cp + c0 + c] = f2bf(c < cn ? tile[c * 65 + t] : 0.f);
+      }
     }
-    float v = 0.f;
-    if (n < N && c < Cin) v = w[((size_t)n * Cin + c) * T + t];
-    out[i] = f2bf(v);
+  } else {
+    const int J = Cin * T;
+    const int jchunks = (J + 63) >> 6;
+    const int nb = lb / jchunks, j0 = (lb - nb * jchunks) * 64, n0 = nb * 64;
+    const int jn = min(64, J - j0);
+    for (int i = tid; i < 64 * 64; i += 256) {
+      const int r = i >> 6, j = i & 63;
+      float v = 0.f;
+      if (n0 + r < N && j < jn) v = w[(size_t)(n0 + r) * J + j0 + j];
+      tile[r * 65 + j] = v;
+    }
+    __syncthreads();
+    const int nw = min(64, Npad - n0);
+    for (int i = tid; i < jn * 64; i += 256) {
+      const int j = i >> 6, r = i & 63;
+      if (r >= nw) continue;
+      const int jj = j0 + j, c = jj / T, t = jj - c * T;
+      const size_t row = mode == 1 ? (size_t)c * T + (T - 1 - t) : (size_t)t * Cp + c;
+      out[row * Npad + n0 + r] = f2bf(tile[r * 65 + j]);
+    }
   }
 }
 

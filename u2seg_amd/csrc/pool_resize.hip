@@ -242,37 +242,59 @@ __global__ __launch_bounds__(256) void bilinear2_bwd_kernel(const bf16_t* __rest
 }
 
 // ---- stem im2col: uint8/float CHW image -> (x-mean)/std -> zero pad -> [B*Ho*Wo][KP] bf16 rows with
-//      K ordered (kh, kw, c) to match weights permuted to [64][7][7][3] and zero padded to KP ----
+//      K ordered (kh, kw, c) to match weights permuted to [64][7][7][3] and zero padded to KP.
+//      One work-group = 8 x 32 output pixels of one image: the 21 x 69 x 3 input window is normalised once into LDS
+//      (zero outside the image), then every 16-byte chunk of the 256 K-rows is assembled from LDS through a k -> offset
+//      table and stored coalesced (320 B per pixel row). ----
+constexpr int ST_TH = 8, ST_TW = 32, ST_IH = 2 * ST_TH + 5, ST_IW = 2 * ST_TW + 5, ST_IWP = ST_IW + 1;
+struct StemImages { const void* img[32]; int h[32]; int w[32]; };
+
 template <typename T>
-__global__ __launch_bounds__(256) void stem_im2col_kernel(const T* __restrict__ img, const float* __restrict__ mean,
-                                                          const float* __restrict__ stdv, bf16_t* __restrict__ col, int b,
-                                                          int h, int w, int Ho, int Wo, int KP) {
-  // one thread per (output pixel, 16-byte chunk of the K row): 8 gathered taps -> one coalesced 16-byte store
-  const int cpr = KP >> 3;
-  const size_t total = (size_t)Ho * Wo * cpr;
-  const float m[3] = {mean[0], mean[1], mean[2]};
-  const float sd[3] = {stdv[0], stdv[1], stdv[2]};
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const StemImages imgs, const float* __restrict__ mean,
+                                                          const float* __restrict__ stdv, bf16_t* __restrict__ col, int b0,
+                                                          int Ho, int Wo, int KP) {
+  __shared__ bf16_t tile[3 * ST_IH * ST_IWP];
+  __shared__ __attribute__((aligned(16))) short koff[512];  // K index -> offset inside the tile, -1 = zero padding
+  const int tid = threadIdx.x;
+  const int bi = blockIdx.z;
+  const T* __restrict__ img = reinterpret_cast<const T*>(imgs.img[bi]);
+  const int h = imgs.h[bi], w = imgs.w[bi];
+  const int oy0 = blockIdx.y * ST_TH, ox0 = blockIdx.x * ST_TW;
+  const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
   const size_t plane = (size_t)h * w;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int cc = (int)(i % cpr);
-    const size_t p = i / cpr;
-    const int ox = (int)(p % Wo);
-    const int oy = (int)(p / Wo);
+  for (int i = tid; i < 3 * ST_IH * ST_IW; i += 256) {
+    const int x = i % ST_IW;
+    const int r = (i / ST_IW) % ST_IH;
+    const int c = i / (ST_IW * ST_IH);
+    const int iy = iy0 + r, ix = ix0 + x;
+    float v = 0.f;
+    if (iy >= 0 && iy < h && ix >= 0 && ix < w) v = ((float)img[c * plane + (size_t)iy * w + ix] - mean[c]) / stdv[c];
+    tile[(c * ST_IH + r) * ST_IWP + x] = f2bf(v);
+  }
+  for (int k = tid; k < KP; k += 256) {
+    short o = -1;
+    if (k < 147) {
+      const int c = k % 3, t = k / 3;
+      o = (short)((c * ST_IH + t / 7) * ST_IWP + t % 7);
+    }
+    koff[k] = o;
+  }
+  __syncthreads();
+  const int cpr = KP >> 3;
+  for (int i = tid; i < ST_TH * ST_TW * cpr; i += 256) {
+    const int cc = i % cpr;
+    const int p = i / cpr;
+    const int lx = p % ST_TW, ly = p / ST_TW;
+    const int oy = oy0 + ly, ox = ox0 + lx;
+    if (oy >= Ho || ox >= Wo) continue;
+    const int base = (2 * ly) * ST_IWP + 2 * lx;
+    short ko[8];
+    *reinterpret_cast<uint4*>(ko) = *reinterpret_cast<const uint4*>(koff + cc * 8);
     bf16_t o[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = cc * 8 + e;  // k = (kh*7 + kw)*3 + c
-      float v = 0.f;
-      if (k < 147) {
-        const int c = k % 3;
-        const int t = k / 3;
-        const int kw = t % 7, kh = t / 7;
-        const int iy = oy * 2 - 3 + kh, ix = ox * 2 - 3 + kw;
-        if (iy >= 0 && iy < h && ix >= 0 && ix < w) v = ((float)img[c * plane + (size_t)iy * w + ix] - m[c]) / sd[c];
-      }
-      o[e] = f2bf(v);
-    }
-    *reinterpret_cast<uint4*>(col + ((size_t)b * Ho * Wo + p) * KP + cc * 8) = *reinterpret_cast<const uint4*>(o);
+    for (int e = 0; e < 8; ++e) o[e] = ko[e] >= 0 ? tile[base + ko[e]] : (bf16_t)0;
+    *reinterpret_cast<uint4*>(col + ((size_t)(b0 + bi) * Ho * Wo + (size_t)oy * Wo + ox) * KP + cc * 8) =
+        *reinterpret_cast<const uint4*>(o);
   }
 }
 
@@ -341,17 +363,32 @@ extern "C" int u2_bilinear_up2_bwd(const void* dout, void* dx, int B, int H, int
   return 0;
 }
 
+extern "C" int u2_stem_im2col_batch(const void* const* imgs, const int* hs, const int* ws, int n_imgs, int is_uint8,
+                                    const float* mean, const float* stdv, void* col, int Hpad, int Wpad, int KP,
+                                    void* stream) {
+  if (KP < 147 || (KP & 31) || KP > 512) return -1;
+  const int Ho = (Hpad + 6 - 7) / 2 + 1, Wo = (Wpad + 6 - 7) / 2 + 1;
+  for (int b0 = 0; b0 < n_imgs; b0 += 32) {
+    const int nb = n_imgs - b0 < 32 ? n_imgs - b0 : 32;
+    StemImages si;
+    for (int i = 0; i < nb; ++i) { si.img[i] = imgs[b0 + i]; si.h[i] = hs[b0 + i]; si.w[i] = ws[b0 + i]; }
+    const dim3 grid((Wo + ST_TW - 1) / ST_TW, (Ho + ST_TH - 1) / ST_TH, nb);
+    if (is_uint8)
+      hipLaunchKernelGGL(stem_im2col_kernel<uint8_t>, grid, dim3(256), 0, (hipStream_t)stream, si, mean, stdv, (bf16_t*)col,
+                         b0, Ho, Wo, KP);
+    else
+      hipLaunchKernelGGL(stem_im2col_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, si, mean, stdv, (bf16_t*)col, b0,
+                         Ho, Wo, KP);
+    U2_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
 extern "C" int u2_stem_im2col(const void* img, int is_uint8, const float* mean, const float* stdv, void* col, int b, int h,
                               int w, int Hpad, int Wpad, int KP, void* stream) {
-  if (KP < 147 || (KP & 31)) return -1;
+  // single image written to batch slot b: shift the column base instead of the batch index
   const int Ho = (Hpad + 6 - 7) / 2 + 1, Wo = (Wpad + 6 - 7) / 2 + 1;
-  const size_t total = (size_t)Ho * Wo * (KP >> 3);
-  if (is_uint8)
-    hipLaunchKernelGGL(stem_im2col_kernel<uint8_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint8_t*)img, mean, stdv, (bf16_t*)col, b, h, w, Ho, Wo, KP);
-  else
-    hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)img, mean, stdv, (bf16_t*)col, b, h, w, Ho, Wo, KP);
-  U2_CHECK_LAUNCH();
-  return 0;
+  const void* imgs[1] = {img};
+  return u2_stem_im2col_batch(imgs, &h, &w, 1, is_uint8, mean, stdv, (unsigned short*)col + (size_t)b * Ho * Wo * KP, Hpad, Wpad,
+                              KP, stream);
 }

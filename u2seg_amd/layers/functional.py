@@ -75,6 +75,8 @@ def _weight_layout(w, cp, npad, mode, owner=None):
     t = kh * kw
     shape = (n, t, cp) if mode == 0 else ((cp, t, npad) if mode == 1 else (t * cp, 1, npad))
     stamp_ref = getattr(owner, "_u2_stamp", None) if owner is not None else None
+    if mode != 0 and cp != cin:
+        stamp_ref = None  # the batched transposer has no all-zero output rows; such layouts are built on the fly
     ent = None
     if stamp_ref is not None:
         cache = owner.__dict__.setdefault("_u2_layouts", {})
@@ -221,14 +223,17 @@ class _StemConvFn(Function):
         b = len(images)
         ho, wo = (hpad + 6 - 7) // 2 + 1, (wpad + 6 - 7) // 2 + 1
         kp = _StemConvFn.KP
+        import ctypes
+
         col = torch.empty((b * ho * wo, kp), dtype=BF16, device=weight.device)
-        for i, img in enumerate(images):
+        is_u8 = images[0].dtype == torch.uint8
+        for img in images:
             assert img.is_cuda and img.is_contiguous() and img.shape[0] == 3
-            is_u8 = img.dtype == torch.uint8
-            if not is_u8:
-                assert img.dtype == torch.float32
-            _hip.call("u2_stem_im2col", img, int(is_u8), pixel_mean, pixel_std, col, i, img.shape[1], img.shape[2],
-                      hpad, wpad, kp)
+            assert img.dtype == (torch.uint8 if is_u8 else torch.float32), "one pixel type per batch"
+        ptrs = (ctypes.c_void_p * b)(*[img.data_ptr() for img in images])
+        hs = (ctypes.c_int * b)(*[img.shape[1] for img in images])
+        ws = (ctypes.c_int * b)(*[img.shape[2] for img in images])
+        _hip.call("u2_stem_im2col_batch", ptrs, hs, ws, b, int(is_u8), pixel_mean, pixel_std, col, hpad, wpad, kp)
         # [64, 3, 7, 7] -> K order (kh, kw, c), zero padded to kp: the forward layout of a 49-tap, 3-channel conv flattened
         wk = torch.zeros((n, 1, kp), dtype=BF16, device=weight.device)
         wk[:, 0, :147] = weight.detach().permute(0, 2, 3, 1).reshape(n, 147)
