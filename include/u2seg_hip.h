@@ -152,6 +152,31 @@ long long u2_nms_workspace_bytes(int B, int n);
 int u2_batched_nms(const float* boxes, const int* group, const int* cnt, void* workspace, int* keep, int* nkeep, int B,
                    int n, float thr, int max_keep, void* stream);
 
+/* ---- inference tails (postprocess.hip) -------------------------------------------------------
+ * layers/mask_ops.py:17-147 (paste_masks_in_image, GPU branch), meta_arch/panoptic_fpn.py:184-269. */
+/* out[k][y][x] (uint8 0/1) = bilinear sample of probs[k] (P x P fp32) on F.grid_sample(align_corners=False)'s grid over
+ * boxes[k] = (x0, y0, x1, y1), zero outside the map, >= threshold. */
+int u2_paste_masks(const float* probs, const float* boxes, void* out, int n, int P, int H, int W, float threshold,
+                   void* stream);
+/* Panoptic merge of a batch of images (one work-group each); `images` is a HOST array of descriptors holding device
+ * pointers.  inst_segment[rank] = segment id given to the rank-th highest scoring instance (0 = rejected); stuff_segment /
+ * stuff_area [num_sem] = id (0 = rejected) and free-pixel area per semantic label.  boxes (optional) + mask_res bound the
+ * pixels a pasted mask can occupy (half a source texel past the box); boxes == NULL scans the whole image. */
+typedef struct U2PanopticImage {
+  const unsigned char* masks; /* [K][H][W] 0/1 */
+  const int* order;           /* [K] instance index by descending score */
+  const float* scores_sorted; /* [K] */
+  const float* boxes;         /* [K][4] or NULL */
+  const long long* semantic;  /* [H][W] argmax of the semantic head */
+  int* panoptic;              /* [H][W] out */
+  int* inst_segment;          /* [K] out */
+  int* stuff_segment;         /* [num_sem] out */
+  int* stuff_area;            /* [num_sem] out */
+  int K, H, W, num_sem;
+} U2PanopticImage;
+int u2_panoptic_merge(const U2PanopticImage* images, int n_images, float overlap_thr, int stuff_area_thr, float score_thr,
+                      int mask_res, void* stream);
+
 /* ---- optimizer (optim.hip): solver/build.py:36-37,63-73,119-139 ------------------------------- */
 int u2_sgd_clip_step(float* params, const float* grads, float* momentum_buf, const int* chunk_tensor,
                      const long long* chunk_begin, const int* chunk_len, int n_chunks, float* partial /*[n_chunks]*/,

@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I. -I../../include -Wno-unused-result"
 OBJS=""
-for f in conv_igemm norm pool_resize losses roi optim kmeans; do
+for f in conv_igemm norm pool_resize losses roi optim kmeans postprocess; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ ../../include/u2seg_hip.h -nt $f.o ]; then
     $HIPCC $FLAGS "$@" -c $f.hip -o $f.o &
   fi

@@ -1,0 +1,213 @@
+// Inference tails of the panoptic step (HBM-bound byte / integer work).
+//
+// Replaces (reference file:line):
+//   paste_masks_in_image / _do_paste_mask (GPU branch)          detectron2/layers/mask_ops.py:17-147
+//   combine_semantic_and_instance_outputs                       detectron2/modeling/meta_arch/panoptic_fpn.py:184-269
+#include "common.h"
+#include "u2seg_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Mask paste: out[k][y][x] = bilinear(prob[k], grid) >= thr with the sampling grid of F.grid_sample(align_corners=False)
+// over the box, zero outside the P x P map.  The output is walked as a flat byte array, 8 bytes per thread (one aligned
+// 64-bit store); pixels farther than one source texel from the box are written as 0 without sampling.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float paste_axis_coord(float pix, float lo, float hi, int P) {
+  const float g = (pix + 0.5f - lo) / (hi - lo) * 2.f - 1.f;   // the normalised grid value the reference builds
+  return ((g + 1.f) * (float)P - 1.f) / 2.f;                   // grid_sample's unnormalisation, align_corners=False
+}
+
+__global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restrict__ probs, const float* __restrict__ boxes,
+                                                          uint8_t* __restrict__ out, long long total, int P, int H, int W,
+                                                          float thr) {
+  const long long i8 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i8 >= total) return;
+  const long long hw = (long long)H * W;
+  int k = (int)(i8 / hw);
+  const long long rem = i8 - (long long)k * hw;
+  int y = (int)(rem / W);
+  int x = (int)(rem - (long long)y * W);
+  unsigned long long bits = 0ull;
+  int cur_k = -1, cur_y = -1;
+  float x0 = 0.f, y0 = 0.f, x1 = 0.f, y1 = 0.f, iy = 0.f, wy_n = 0.f, wy_s = 0.f;
+  int yn = 0;
+  bool row_in = false;
+  const float* pk = probs;
+  const int nvalid = (int)((total - i8) < 8 ? (total - i8) : 8);
+  for (int e = 0; e < nvalid; ++e) {
+    if (k != cur_k) {
+      cur_k = k; cur_y = -1;
+      x0 = boxes[(size_t)k * 4 + 0]; y0 = boxes[(size_t)k * 4 + 1]; x1 = boxes[(size_t)k * 4 + 2]; y1 = boxes[(size_t)k * 4 + 3];
+      pk = probs + (size_t)k * P * P;
+    }
+    if (y != cur_y) {
+      cur_y = y;
+      iy = paste_axis_coord((float)y, y0, y1, P);
+      const float fy = floorf(iy);
+      yn = (int)fy;
+      wy_s = iy - fy;          // weight of row yn + 1
+      wy_n = (fy + 1.f) - iy;  // weight of row yn
+      row_in = iy > -1.f && iy < (float)P;
+    }
+    bool on = false;
+    if (row_in) {
+      const float ix = paste_axis_coord((float)x, x0, x1, P);
+      if (ix > -1.f && ix < (float)P) {
+        const float fx = floorf(ix);
+        const int xw = (int)fx;
+        const float wx_e = ix - fx, wx_w = (fx + 1.f) - ix;
+        const bool yn_ok = yn >= 0 && yn < P, ys_ok = yn + 1 >= 0 && yn + 1 < P;
+        const bool xw_ok = xw >= 0 && xw < P, xe_ok = xw + 1 >= 0 && xw + 1 < P;
+        float v = 0.f;
+        if (yn_ok && xw_ok) v += pk[yn * P + xw] * (wx_w * wy_n);
+        if (yn_ok && xe_ok) v += pk[yn * P + xw + 1] * (wx_e * wy_n);
+        if (ys_ok && xw_ok) v += pk[(yn + 1) * P + xw] * (wx_w * wy_s);
+        if (ys_ok && xe_ok) v += pk[(yn + 1) * P + xw + 1] * (wx_e * wy_s);
+        on = v >= thr;
+      }
+    }
+    if (on) bits |= 1ull << (8 * e);
+    if (++x == W) { x = 0; if (++y == H) { y = 0; ++k; } }
+  }
+  if (nvalid == 8) {
+    *reinterpret_cast<unsigned long long*>(out + i8) = bits;
+  } else {
+    for (int e = 0; e < nvalid; ++e) out[i8 + e] = (uint8_t)((bits >> (8 * e)) & 1ull);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Panoptic merge (panoptic_fpn.py:184-269): one work-group per image walks the instances in descending score order.
+// Per instance it counts, inside the region the pasted mask can occupy, the mask area and its overlap with what is
+// already claimed; rejects it when overlap / area > overlap_thr (double arithmetic, as the reference's Python floats);
+// otherwise claims the still-free mask pixels for the next segment id.  Stuff: areas of the free pixels per semantic
+// label by an LDS histogram, ids handed out in ascending label order (torch.unique is sorted), one more pass to write.
+// Every decision is integer / exact, so the map is bit-identical to the reference's.
+// ---------------------------------------------------------------------------------------------
+constexpr int PM_THREADS = 1024, PM_MAXSEM = 256;
+struct PanopticBatch { U2PanopticImage im[24]; };
+
+__device__ __forceinline__ void block_sum2_1024(int& a, int& b, int* red /*[34]*/) {
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) { red[wid * 2] = a; red[wid * 2 + 1] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int sa = 0, sb = 0;
+    for (int i = 0; i < PM_THREADS / 64; ++i) { sa += red[i * 2]; sb += red[i * 2 + 1]; }
+    red[32] = sa; red[33] = sb;
+  }
+  __syncthreads();
+  a = red[32]; b = red[33];
+}
+
+__global__ __launch_bounds__(PM_THREADS) void panoptic_merge_kernel(const PanopticBatch batch, float overlap_thr,
+                                                                    int stuff_area_thr, float score_thr, int mask_res) {
+  __shared__ int red[34];
+  __shared__ int hist_all[PM_MAXSEM], hist_free[PM_MAXSEM], stuff_id[PM_MAXSEM];
+  __shared__ int s_seg;
+  const U2PanopticImage im = batch.im[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int H = im.H, W = im.W;
+  const long long hw = (long long)H * W;
+  for (long long p = tid; p < hw; p += PM_THREADS) im.panoptic[p] = 0;
+  for (int i = tid; i < PM_MAXSEM; i += PM_THREADS) { hist_all[i] = 0; hist_free[i] = 0; stuff_id[i] = 0; }
+  if (tid == 0) s_seg = 0;
+  __syncthreads();
+  int seg = 0;
+  for (int rank = 0; rank < im.K; ++rank) {
+    if (tid == 0) im.inst_segment[rank] = 0;
+    if (im.scores_sorted[rank] < score_thr) {  // sorted: nothing after this one qualifies either
+      for (int r = rank + 1 + tid; r < im.K; r += PM_THREADS) im.inst_segment[r] = 0;
+      break;
+    }
+    const int inst = im.order[rank];
+    int ry0 = 0, ry1 = H, rx0 = 0, rx1 = W;
+    if (im.boxes && mask_res > 0) {  // a pasted mask reaches at most half a source texel (+ rounding slack) past its box
+      const float x0 = im.boxes[inst * 4 + 0], y0 = im.boxes[inst * 4 + 1], x1 = im.boxes[inst * 4 + 2], y1 = im.boxes[inst * 4 + 3];
+      const float ex = 0.5f * (x1 - x0) / (float)mask_res + 2.f, ey = 0.5f * (y1 - y0) / (float)mask_res + 2.f;
+      rx0 = max(0, (int)floorf(x0 - ex)); rx1 = min(W, (int)ceilf(x1 + ex) + 1);
+      ry0 = max(0, (int)floorf(y0 - ey)); ry1 = min(H, (int)ceilf(y1 + ey) + 1);
+    }
+    const int rw = max(rx1 - rx0, 0), rh = max(ry1 - ry0, 0);
+    const unsigned char* m = im.masks + (size_t)inst * hw;
+    int area = 0, inter = 0;
+    for (int i = tid; i < rw * rh; i += PM_THREADS) {
+      const int y = ry0 + i / rw, x = rx0 + i % rw;
+      const size_t p = (size_t)y * W + x;
+      if (m[p]) { ++area; if (im.panoptic[p] > 0) ++inter; }
+    }
+    block_sum2_1024(area, inter, red);
+    if (area == 0) continue;
+    if ((double)inter * 1.0 / (double)area > (double)overlap_thr) continue;
+    ++seg;
+    for (int i = tid; i < rw * rh; i += PM_THREADS) {
+      const int y = ry0 + i / rw, x = rx0 + i % rw;
+      const size_t p = (size_t)y * W + x;
+      if (m[p] && im.panoptic[p] == 0) im.panoptic[p] = seg;
+    }
+    if (tid == 0) im.inst_segment[rank] = seg;
+    __syncthreads();
+  }
+  __syncthreads();
+  // stuff
+  for (long long p = tid; p < hw; p += PM_THREADS) {
+    const long long lab = im.semantic[p];
+    if (lab >= 0 && lab < PM_MAXSEM) {
+      atomicAdd(&hist_all[(int)lab], 1);
+      if (im.panoptic[p] == 0) atomicAdd(&hist_free[(int)lab], 1);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int lab = 1; lab < PM_MAXSEM; ++lab) {  // label 0 = "thing" pixels of the semantic head
+      int id = 0;
+      if (hist_all[lab] > 0 && hist_free[lab] >= stuff_area_thr) id = ++seg;
+      stuff_id[lab] = id;
+      if (lab < im.num_sem) { im.stuff_segment[lab] = id; im.stuff_area[lab] = hist_free[lab]; }
+    }
+    if (im.num_sem > 0) { im.stuff_segment[0] = 0; im.stuff_area[0] = hist_free[0]; }
+  }
+  __syncthreads();
+  for (long long p = tid; p < hw; p += PM_THREADS) {
+    const long long lab = im.semantic[p];
+    if (lab > 0 && lab < PM_MAXSEM && im.panoptic[p] == 0) {
+      const int id = stuff_id[(int)lab];
+      if (id) im.panoptic[p] = id;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int u2_panoptic_merge(const U2PanopticImage* images, int n_images, float overlap_thr, int stuff_area_thr,
+                                 float score_thr, int mask_res, void* stream) {
+  for (int b0 = 0; b0 < n_images; b0 += 24) {
+    const int nb = n_images - b0 < 24 ? n_images - b0 : 24;
+    PanopticBatch batch;
+    for (int i = 0; i < nb; ++i) {
+      batch.im[i] = images[b0 + i];
+      if (batch.im[i].num_sem > PM_MAXSEM || batch.im[i].H <= 0 || batch.im[i].W <= 0) return -1;
+    }
+    hipLaunchKernelGGL(panoptic_merge_kernel, dim3(nb), dim3(PM_THREADS), 0, (hipStream_t)stream, batch, overlap_thr,
+                       stuff_area_thr, score_thr, mask_res);
+    U2_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+extern "C" int u2_paste_masks(const float* probs, const float* boxes, void* out, int n, int P, int H, int W, float threshold,
+                              void* stream) {
+  if (n <= 0 || H <= 0 || W <= 0) return 0;
+  if (P < 1) return -1;
+  const long long total = (long long)n * H * W;
+  const long long threads = (total + 7) / 8;
+  const long long blocks = (threads + 255) / 256;
+  if (blocks > 0x7fffffffLL) return -1;
+  hipLaunchKernelGGL(paste_masks_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, probs, boxes,
+                     (uint8_t*)out, total, P, H, W, threshold);
+  U2_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,10 +1,14 @@
 """Inference-only tails: box filtering + per-class NMS, mask pasting, output rescaling and the panoptic merge
 (detectron2/modeling/roi_heads/fast_rcnn.py:46-171, layers/mask_ops.py:17-147, modeling/postprocessing.py:9-100,
 meta_arch/panoptic_fpn.py:184-269).  NMS runs in the HIP kernel; the remaining index plumbing is device-side torch."""
+import ctypes
+
 import torch
 
+from .. import _hip
 from ..layers import functional as F
 from ..structures import Boxes, Instances
+from .batched import device_constant
 
 
 def nms_single(boxes, scores, groups, thr, topk):
@@ -22,55 +26,84 @@ def nms_single(boxes, scores, groups, thr, topk):
 
 
 def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image):
-    valid = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
-    if not bool(valid.all()):
-        boxes, scores = boxes[valid], scores[valid]
-    scores = scores[:, :-1]
-    num_bbox_reg_classes = boxes.shape[1] // 4
-    b = Boxes(boxes.reshape(-1, 4))
-    b.clip(image_shape)
-    boxes = b.tensor.view(-1, num_bbox_reg_classes, 4)
-    filter_mask = scores > score_thresh
-    filter_inds = filter_mask.nonzero()
-    boxes = boxes[filter_inds[:, 0], 0] if num_bbox_reg_classes == 1 else boxes[filter_mask]
-    scores = scores[filter_mask]
-    keep = nms_single(boxes, scores, filter_inds[:, 1], nms_thresh, topk_per_image)
-    boxes, scores, filter_inds = boxes[keep], scores[keep], filter_inds[keep]
-    result = Instances(image_shape)
-    result.pred_boxes = Boxes(boxes)
-    result.scores = scores
-    result.pred_classes = filter_inds[:, 1]
-    return result, filter_inds[:, 0]
+    """fast_rcnn.py:117-171 for one image (the batched routine below with a batch of one)."""
+    res, kept = fast_rcnn_inference([boxes], [scores], [image_shape], score_thresh, nms_thresh, topk_per_image)
+    return res[0], kept[0]
 
 
 def fast_rcnn_inference(boxes, scores, image_shapes, score_thresh, nms_thresh, topk_per_image):
-    out = [fast_rcnn_inference_single_image(b, s, shp, score_thresh, nms_thresh, topk_per_image)
-           for s, b, shp in zip(scores, boxes, image_shapes)]
-    return [x[0] for x in out], [x[1] for x in out]
+    """fast_rcnn.py:46-171 for the whole batch at once: score filter, per-class NMS and top-k with three host
+    synchronisations per batch (candidate counts, the candidate list, keep counts) instead of four per image.
+    boxes: per image [R_i, 4] (class agnostic) or [R_i, K*4]; scores: per image [R_i, K+1]."""
+    nimg = len(boxes)
+    if nimg == 0:
+        return [], []
+    dev = boxes[0].device
+    k = scores[0].shape[1] - 1
+    nreg = boxes[0].shape[1] // 4
+    counts_r = [b.shape[0] for b in boxes]
+    rmax = max(max(counts_r), 1)
+    if len(set(counts_r)) == 1 and counts_r[0] > 0:
+        bx, sc = torch.stack(list(boxes)), torch.stack(list(scores))
+        rvalid = None
+    else:  # ragged: pad with rows that never pass the score filter
+        bx = torch.zeros((nimg, rmax, boxes[0].shape[1]), dtype=boxes[0].dtype, device=dev)
+        sc = torch.full((nimg, rmax, k + 1), -1.0, dtype=scores[0].dtype, device=dev)
+        for i, (b_, s_) in enumerate(zip(boxes, scores)):
+            bx[i, : b_.shape[0]], sc[i, : s_.shape[0]] = b_, s_
+        rvalid = torch.arange(rmax, device=dev)[None] < device_constant(counts_r, torch.int64, dev)[:, None]
+    valid = torch.isfinite(bx).all(dim=2) & torch.isfinite(sc).all(dim=2)
+    if rvalid is not None:
+        valid = valid & rvalid
+    lim = device_constant([[[w, h] * 2] for h, w in image_shapes], torch.float32, dev)  # Boxes.clip per image
+    bx = torch.minimum(bx.float().view(nimg, rmax, nreg, 4).clamp(min=0), lim[:, :, None, :])
+    cand = (sc[..., :k] > score_thresh) & valid[..., None]  # [B, R, K]
+    ncand = cand.flatten(1).sum(dim=1)
+    cnt = ncand.tolist()  # sync 1
+    idx = cand.nonzero()  # sync 2; rows ordered by (image, roi, class) like the reference's per-image nonzero
+    total = idx.shape[0]
+    c_img, c_roi, c_cls = idx[:, 0], idx[:, 1], idx[:, 2]
+    c_scores = sc[c_img, c_roi, c_cls]
+    c_boxes = bx[c_img, c_roi, 0] if nreg == 1 else bx[c_img, c_roi, c_cls]
+    # per image: descending score, ties in candidate order (torch.sort(descending, stable) of the reference's NMS)
+    o1 = torch.sort(c_scores, descending=True, stable=True)[1]
+    o2 = torch.sort(c_img[o1], stable=True)[1]
+    order = o1[o2]
+    offs = [0]
+    for c in cnt:
+        offs.append(offs[-1] + c)
+    nmax = max(max(cnt), 1)
+    s_img = c_img[order]
+    pos = torch.arange(total, device=dev) - device_constant(offs[:-1], torch.int64, dev)[s_img]
+    pb = torch.zeros((nimg, nmax, 4), dtype=torch.float32, device=dev)
+    pg = torch.zeros((nimg, nmax), dtype=torch.int32, device=dev)
+    pb[s_img, pos] = c_boxes[order]
+    pg[s_img, pos] = c_cls[order].to(torch.int32)
+    max_keep = nmax if topk_per_image < 0 else min(nmax, topk_per_image)
+    keep, nkeep = F.batched_nms(pb, pg, ncand.to(torch.int32), nms_thresh, max_keep)
+    nk = nkeep.tolist()  # sync 3
+    results, kept_rows = [], []
+    for i, shape in enumerate(image_shapes):
+        sel = order[offs[i] + keep[i, : nk[i]].long()]
+        res = Instances(shape)
+        res.pred_boxes = Boxes(c_boxes[sel])
+        res.scores = c_scores[sel]
+        res.pred_classes = c_cls[sel]
+        results.append(res)
+        kept_rows.append(c_roi[sel])
+    return results, kept_rows
 
 
 def paste_masks_in_image(masks, boxes, image_shape, threshold=0.5):
-    """mask_ops.py:17-147 (GPU branch: full-image grid_sample, aligned at pixel centres)."""
+    """mask_ops.py:17-147 (GPU branch: full-image grid_sample, aligned at pixel centres) as one HIP kernel that samples
+    and thresholds in place: the fp32 [n, H, W] sampled image of the reference is never formed."""
     n = masks.shape[0]
     img_h, img_w = image_shape
     if n == 0:
         return masks.new_empty((0, img_h, img_w), dtype=torch.bool)
-    device = masks.device
-    out = torch.empty((n, img_h, img_w), dtype=torch.bool, device=device)
-    chunk = max(1, int((1 << 28) // max(img_h * img_w, 1)))
-    for s in range(0, n, chunk):
-        m = masks[s : s + chunk, None].float()
-        bx = boxes[s : s + chunk]
-        x0, y0, x1, y1 = torch.split(bx, 1, dim=1)
-        img_y = torch.arange(0, img_h, device=device, dtype=torch.float32) + 0.5
-        img_x = torch.arange(0, img_w, device=device, dtype=torch.float32) + 0.5
-        img_y = (img_y - y0) / (y1 - y0) * 2 - 1
-        img_x = (img_x - x0) / (x1 - x0) * 2 - 1
-        gx = img_x[:, None, :].expand(m.shape[0], img_y.size(1), img_x.size(1))
-        gy = img_y[:, :, None].expand(m.shape[0], img_y.size(1), img_x.size(1))
-        grid = torch.stack([gx, gy], dim=3)
-        img = torch.nn.functional.grid_sample(m, grid, align_corners=False)
-        out[s : s + chunk] = img[:, 0] >= threshold
+    out = torch.empty((n, img_h, img_w), dtype=torch.bool, device=masks.device)
+    _hip.call("u2_paste_masks", masks.float().contiguous(), boxes.float().contiguous(), out, n, masks.shape[-1], img_h, img_w,
+              float(threshold))
     return out
 
 
@@ -88,48 +121,92 @@ def detector_postprocess(results, output_height, output_width, mask_threshold=0.
 
 
 def sem_seg_postprocess(result, img_size, output_height, output_width):
-    result = result[:, : img_size[0], : img_size[1]].expand(1, -1, -1, -1)
+    result = result[:, : img_size[0], : img_size[1]]
+    if (output_height, output_width) == tuple(img_size):
+        return result  # bilinear resampling to the same size (align_corners=False) is the identity
+    result = result.expand(1, -1, -1, -1)
     return torch.nn.functional.interpolate(result, size=(output_height, output_width), mode="bilinear", align_corners=False)[0]
+
+
+class _PanopticImage(ctypes.Structure):
+    """Mirror of U2PanopticImage (include/u2seg_hip.h)."""
+
+    _fields_ = [("masks", ctypes.c_void_p), ("order", ctypes.c_void_p), ("scores_sorted", ctypes.c_void_p),
+                ("boxes", ctypes.c_void_p), ("semantic", ctypes.c_void_p), ("panoptic", ctypes.c_void_p),
+                ("inst_segment", ctypes.c_void_p), ("stuff_segment", ctypes.c_void_p), ("stuff_area", ctypes.c_void_p),
+                ("K", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("num_sem", ctypes.c_int)]
+
+
+_NUM_SEM_SLOTS = 256  # semantic labels the merge kernel can number (PM_MAXSEM)
+
+
+def combine_semantic_and_instance_outputs_batch(instance_results, semantic_results, overlap_threshold, stuff_area_thresh,
+                                                instances_score_thresh, mask_res=0):
+    """panoptic_fpn.py:184-269 for a list of images in one kernel launch and one device->host transfer.
+
+    instance_results: list[Instances] with pred_masks [K, H, W] bool (pasted), scores, pred_classes (and pred_boxes, used
+    with mask_res > 0 to bound the pixels each pasted mask can touch); semantic_results: list of [H, W] int64 argmax maps.
+    Returns list[(panoptic_seg int32 [H, W], segments_info)] identical to the reference's per-image routine."""
+    n = len(instance_results)
+    if n == 0:
+        return []
+    dev = semantic_results[0].device
+    descs = (_PanopticImage * n)()
+    keep_alive, per_image = [], []
+    ints = []  # per image: order | inst_segment | stuff_segment | stuff_area | classes (read back together)
+    for i, (inst, sem) in enumerate(zip(instance_results, semantic_results)):
+        h, w = sem.shape
+        k = len(inst)
+        sem = sem.to(torch.int64).contiguous()
+        masks = inst.pred_masks.to(device=dev)
+        masks = (masks if masks.dtype in (torch.bool, torch.uint8) else masks > 0).contiguous()
+        assert masks.shape == (k, h, w), (masks.shape, (k, h, w))
+        scores = inst.scores.float()
+        order = torch.argsort(-scores).to(torch.int32)  # the reference's order, ties included
+        s_sorted = scores[order.long()].contiguous()
+        boxes = inst.pred_boxes.tensor.float().contiguous() if (mask_res > 0 and inst.has("pred_boxes")) else None
+        pan = torch.empty((h, w), dtype=torch.int32, device=dev)
+        out = torch.zeros(k + 2 * _NUM_SEM_SLOTS, dtype=torch.int32, device=dev)
+        d = descs[i]
+        d.masks, d.order, d.scores_sorted = masks.data_ptr(), order.data_ptr(), s_sorted.data_ptr()
+        d.boxes = boxes.data_ptr() if boxes is not None else None
+        d.semantic, d.panoptic = sem.data_ptr(), pan.data_ptr()
+        d.inst_segment = out.data_ptr()
+        d.stuff_segment = out.data_ptr() + 4 * k
+        d.stuff_area = out.data_ptr() + 4 * (k + _NUM_SEM_SLOTS)
+        d.K, d.H, d.W, d.num_sem = k, h, w, _NUM_SEM_SLOTS
+        keep_alive.append((masks, order, s_sorted, boxes, sem, out))
+        per_image.append((pan, k))
+        ints.append((out, order, inst.pred_classes.to(torch.int32)))
+    _hip.call("u2_panoptic_merge", descs, n, float(overlap_threshold), int(stuff_area_thresh), float(instances_score_thresh),
+              int(mask_res))
+    flat = torch.cat([t for trip in ints for t in trip]).tolist()  # (after the launch) the one host synchronisation
+    score_lists = torch.cat([ka[2] for ka in keep_alive]).tolist() if any(k for _, k in per_image) else []
+    results, pos, spos = [], 0, 0
+    for pan, k in per_image:
+        inst_seg = flat[pos : pos + k]
+        stuff_seg = flat[pos + k : pos + k + _NUM_SEM_SLOTS]
+        stuff_area = flat[pos + k + _NUM_SEM_SLOTS : pos + k + 2 * _NUM_SEM_SLOTS]
+        order = flat[pos + k + 2 * _NUM_SEM_SLOTS : pos + 2 * k + 2 * _NUM_SEM_SLOTS]
+        classes = flat[pos + 2 * k + 2 * _NUM_SEM_SLOTS : pos + 3 * k + 2 * _NUM_SEM_SLOTS]
+        pos += 3 * k + 2 * _NUM_SEM_SLOTS
+        scores = score_lists[spos : spos + k]
+        spos += k
+        info = []
+        for rank in range(k):
+            if inst_seg[rank] > 0:
+                inst_id = order[rank]
+                info.append({"id": inst_seg[rank], "isthing": True, "score": scores[rank], "category_id": classes[inst_id],
+                             "instance_id": inst_id})
+        for label in range(1, _NUM_SEM_SLOTS):
+            if stuff_seg[label] > 0:
+                info.append({"id": stuff_seg[label], "isthing": False, "category_id": label, "area": stuff_area[label]})
+        results.append((pan, info))
+    return results
 
 
 def combine_semantic_and_instance_outputs(instance_results, semantic_results, overlap_threshold, stuff_area_thresh,
                                           instances_score_thresh):
-    """panoptic_fpn.py:184-269.  Areas are reduced on the device in one batch and read back once; the greedy
-    paste order (descending score) and every integer decision follow the reference."""
-    panoptic_seg = torch.zeros_like(semantic_results, dtype=torch.int32)
-    sorted_inds = torch.argsort(-instance_results.scores)
-    current_segment_id = 0
-    segments_info = []
-    instance_masks = instance_results.pred_masks.to(dtype=torch.bool, device=panoptic_seg.device)
-    scores = instance_results.scores[sorted_inds].tolist()
-    classes = instance_results.pred_classes[sorted_inds].tolist()
-    areas = instance_masks.flatten(1).sum(1)[sorted_inds].tolist() if len(scores) else []
-    for rank, inst_id in enumerate(sorted_inds.tolist()):
-        score = scores[rank]
-        if score < instances_score_thresh:
-            break
-        mask = instance_masks[inst_id]
-        mask_area = areas[rank]
-        if mask_area == 0:
-            continue
-        intersect_area = int((mask & (panoptic_seg > 0)).sum())
-        if intersect_area * 1.0 / mask_area > overlap_threshold:
-            continue
-        if intersect_area > 0:
-            mask = mask & (panoptic_seg == 0)
-        current_segment_id += 1
-        panoptic_seg[mask] = current_segment_id
-        segments_info.append({"id": current_segment_id, "isthing": True, "score": score, "category_id": classes[rank],
-                              "instance_id": inst_id})
-    semantic_labels = torch.unique(semantic_results).cpu().tolist()
-    for semantic_label in semantic_labels:
-        if semantic_label == 0:
-            continue
-        mask = (semantic_results == semantic_label) & (panoptic_seg == 0)
-        mask_area = int(mask.sum())
-        if mask_area < stuff_area_thresh:
-            continue
-        current_segment_id += 1
-        panoptic_seg[mask] = current_segment_id
-        segments_info.append({"id": current_segment_id, "isthing": False, "category_id": semantic_label, "area": mask_area})
-    return panoptic_seg, segments_info
+    """panoptic_fpn.py:184-269 (the batch routine above with one image)."""
+    return combine_semantic_and_instance_outputs_batch([instance_results], [semantic_results], overlap_threshold,
+                                                       stuff_area_thresh, instances_score_thresh)[0]

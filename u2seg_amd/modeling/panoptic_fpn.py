@@ -7,7 +7,8 @@ from ..config import configurable
 from ..structures import ImageList
 from ..utils.registry import Registry
 from .backbone import build_backbone
-from .inference import combine_semantic_and_instance_outputs, detector_postprocess, sem_seg_postprocess
+from .inference import (combine_semantic_and_instance_outputs, combine_semantic_and_instance_outputs_batch,
+                        detector_postprocess, sem_seg_postprocess)
 from .roi_heads import build_roi_heads
 from .rpn import build_proposal_generator
 from .semantic_seg import build_sem_seg_head
@@ -148,10 +149,13 @@ class PanopticFPN(GeneralizedRCNN):
             sem_seg_r = sem_seg_postprocess(sem_seg_result, image_size, height, width)
             detector_r = detector_postprocess(detector_result, height, width)
             processed.append({"sem_seg": sem_seg_r, "instances": detector_r})
-            panoptic_r = combine_semantic_and_instance_outputs(
-                detector_r, sem_seg_r.argmax(dim=0), self.combine_overlap_thresh, self.combine_stuff_area_thresh,
-                self.combine_instances_score_thresh)
-            processed[-1]["panoptic_seg"] = panoptic_r
+        # the merge of all images: one launch, one host synchronisation (the reference loops and syncs per instance)
+        mask_res = 2 * self.roi_heads.mask_pooler.output_size if getattr(self.roi_heads, "mask_on", False) else 0
+        merged = combine_semantic_and_instance_outputs_batch(
+            [p["instances"] for p in processed], [p["sem_seg"].argmax(dim=0) for p in processed], self.combine_overlap_thresh,
+            self.combine_stuff_area_thresh, self.combine_instances_score_thresh, mask_res)
+        for p, panoptic_r in zip(processed, merged):
+            p["panoptic_seg"] = panoptic_r
         return processed
 
 
