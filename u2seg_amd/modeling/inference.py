@@ -107,17 +107,39 @@ def paste_masks_in_image(masks, boxes, image_shape, threshold=0.5):
     return out
 
 
+def detector_postprocess_batch(results_list, sizes, mask_threshold=0.5):
+    """postprocessing.py:9-74 for a batch: rescale + clip the boxes, drop empty ones, paste the masks.  The "is any box
+    empty" question is answered for all images with one host synchronisation (the reference indexes with a boolean mask,
+    i.e. synchronises, per image)."""
+    staged = []
+    for results, (output_height, output_width) in zip(results_list, sizes):
+        scale_x, scale_y = output_width / results.image_size[1], output_height / results.image_size[0]
+        results = Instances((output_height, output_width), **results.get_fields())
+        name = "pred_boxes" if results.has("pred_boxes") else "proposal_boxes"
+        t = results.get(name).tensor
+        dev = t.device
+        # Boxes.scale + Boxes.clip (structures/boxes.py:27-34,58-60) without the per-call finiteness synchronisation
+        t = t * device_constant([scale_x, scale_y, scale_x, scale_y], torch.float32, dev)
+        finite = torch.isfinite(t).all()
+        t = torch.minimum(t.clamp(min=0), device_constant([output_width, output_height] * 2, torch.float32, dev))
+        boxes = Boxes(t)
+        results.set(name, boxes)
+        staged.append((results, boxes.nonempty(), finite))
+    flags = torch.stack([torch.stack([k.all(), f]) for _, k, f in staged]).tolist() if staged else []
+    out = []
+    for (results, keep, _), (all_ok, finite) in zip(staged, flags):
+        assert finite, "Box tensor contains infinite or NaN!"
+        if not all_ok:
+            results = results[keep]
+        if results.has("pred_masks"):
+            results.pred_masks = paste_masks_in_image(results.pred_masks[:, 0, :, :], results.pred_boxes.tensor,
+                                                      results.image_size, mask_threshold)
+        out.append(results)
+    return out
+
+
 def detector_postprocess(results, output_height, output_width, mask_threshold=0.5):
-    scale_x, scale_y = output_width / results.image_size[1], output_height / results.image_size[0]
-    results = Instances((output_height, output_width), **results.get_fields())
-    output_boxes = results.pred_boxes if results.has("pred_boxes") else results.proposal_boxes
-    output_boxes.scale(scale_x, scale_y)
-    output_boxes.clip(results.image_size)
-    results = results[output_boxes.nonempty()]
-    if results.has("pred_masks"):
-        results.pred_masks = paste_masks_in_image(results.pred_masks[:, 0, :, :], results.pred_boxes.tensor,
-                                                  (output_height, output_width), mask_threshold)
-    return results
+    return detector_postprocess_batch([results], [(output_height, output_width)], mask_threshold)[0]
 
 
 def sem_seg_postprocess(result, img_size, output_height, output_width):

@@ -8,7 +8,7 @@ from ..structures import ImageList
 from ..utils.registry import Registry
 from .backbone import build_backbone
 from .inference import (combine_semantic_and_instance_outputs, combine_semantic_and_instance_outputs_batch,
-                        detector_postprocess, sem_seg_postprocess)
+                        detector_postprocess, detector_postprocess_batch, sem_seg_postprocess)
 from .roi_heads import build_roi_heads
 from .rpn import build_proposal_generator
 from .semantic_seg import build_sem_seg_head
@@ -72,10 +72,8 @@ class GeneralizedRCNN(nn.Module):
         results, _ = self.roi_heads(None, features, proposals, None)
         if not do_postprocess:
             return results
-        out = []
-        for r, inp, size in zip(results, batched_inputs, image_sizes):
-            out.append({"instances": detector_postprocess(r, inp.get("height", size[0]), inp.get("width", size[1]))})
-        return out
+        out_sizes = [(inp.get("height", size[0]), inp.get("width", size[1])) for inp, size in zip(batched_inputs, image_sizes)]
+        return [{"instances": r} for r in detector_postprocess_batch(results, out_sizes)]
 
 
 @META_ARCH_REGISTRY.register()
@@ -143,11 +141,11 @@ class PanopticFPN(GeneralizedRCNN):
         detector_results, _ = self.roi_heads(None, features, proposals, None)
         if not do_postprocess:
             return detector_results, sem_seg_results
+        out_sizes = [(inp.get("height", size[0]), inp.get("width", size[1])) for inp, size in zip(batched_inputs, image_sizes)]
+        detector_rs = detector_postprocess_batch(detector_results, out_sizes)
         processed = []
-        for sem_seg_result, detector_result, inp, image_size in zip(sem_seg_results, detector_results, batched_inputs, image_sizes):
-            height, width = inp.get("height", image_size[0]), inp.get("width", image_size[1])
+        for sem_seg_result, detector_r, image_size, (height, width) in zip(sem_seg_results, detector_rs, image_sizes, out_sizes):
             sem_seg_r = sem_seg_postprocess(sem_seg_result, image_size, height, width)
-            detector_r = detector_postprocess(detector_result, height, width)
             processed.append({"sem_seg": sem_seg_r, "instances": detector_r})
         # the merge of all images: one launch, one host synchronisation (the reference loops and syncs per instance)
         mask_res = 2 * self.roi_heads.mask_pooler.output_size if getattr(self.roi_heads, "mask_on", False) else 0
