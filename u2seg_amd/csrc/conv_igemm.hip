@@ -352,6 +352,277 @@ __global__ __launch_bounds__((TM / 64) * (TN / 64) * 64, 2) void conv_igemm_kern
 }
 
 // ------------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves (4 along channels x 2 along pixels, 64 x 128 per wave), for the wide layers.
+//
+// Why a second structure: with 64 x 64 wave tiles a K step needs 16 ds_read_b128 per 32 MFMA and a barrier pair
+// per K tile; here a wave needs 12 reads per 32 MFMA, the reduction advances in half K tiles (32 channels) through FOUR
+// LDS buffers (global_load_lds runs four half tiles = two K tiles ahead, counted vmcnt(8), never drained in the loop),
+// there is ONE raw barrier per half tile, and the fragments of the next phase are read from LDS before the MFMAs of
+// the current one are issued (register double buffering), so LDS latency hides behind the wave's own MFMA clusters.
+//
+//   phase A(h): read W fragments (channels 32-63 of the wave) of half tile h; stage 2nd half of half tile h+3; 16 MFMA
+//   phase B(h): vmcnt(8), barrier [publishes h+1, frees buffer h]; read W (channels 0-31) + 8 pixel fragments of h+1;
+//               stage 1st half of half tile h+4 into the freed buffer; 16 MFMA
+// ------------------------------------------------------------------------------------------------
+constexpr int C256_THREADS = 512;
+constexpr int C256_HALF_BYTES = 256 * 64;                       // one operand, one half K tile: 256 rows x 32 bf16
+constexpr int C256_BUF_BYTES = 2 * C256_HALF_BYTES;             // pixels + weights
+constexpr int C256_OPITCH = 256 + 8;
+constexpr int C256_LDS_BYTES = 256 * C256_OPITCH * 2 + 2 * 8 * 256 * 4;  // epilogue staging + stats scratch (151 KB)
+static_assert(C256_LDS_BYTES >= 4 * C256_BUF_BYTES, "ring must fit in the epilogue allocation");
+
+__global__ __launch_bounds__(C256_THREADS, 2) void conv_igemm256_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = a.tiles_m * a.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int tile_m = tile / a.tiles_n;
+  const int tile_n = tile - tile_m * a.tiles_n;
+  const int m0 = tile_m * 256;
+  const int n0 = tile_n * 256;
+
+  // ---- staging bookkeeping: per half tile a thread moves 2 pixel chunks and 2 weight chunks (rows fixed) ----
+  int p_img[2], p_by[2], p_bx[2];
+  bool p_ok[2];
+  const bf16_t* w_src[2];  // weights are [n][tap][C]: consecutive half tiles are consecutive 32-channel slabs, across taps too
+  int w_inc[2];
+  const int row_in = lane >> 2;
+  const int cc = (lane & 3) ^ swz<32>(row_in);
+  {
+    const int hw = a.Hout * a.Wout;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (i * 8 + w) * 16 + row_in;
+      const int m = m0 + row;
+      p_ok[i] = m < a.M;
+      const int mm = p_ok[i] ? m : 0;
+      const int img = mm / hw;
+      const int rem = mm - img * hw;
+      const int oy = rem / a.Wout;
+      p_img[i] = img;
+      p_by[i] = oy * a.mul;
+      p_bx[i] = (rem - oy * a.Wout) * a.mul;
+      const int n = n0 + row;
+      w_src[i] = (n < a.N) ? a.wt + (size_t)n * ((size_t)a.wt_taps * a.C) + cc * 8 : a.zero;
+      w_inc[i] = (n < a.N) ? 32 : 0;
+    }
+  }
+  const int kh_per_tap = a.C >> 5;      // half tiles (32 channels) per filter tap
+  const int nkh = a.ntaps * kh_per_tap; // even (C % 64 == 0), >= 4
+  const bf16_t* p_src[2];
+  int p_inc[2];
+  int kc_in_tap = 0, reg_kh = 0, reg_kw = 0;
+  // Staging order is P(0) W(0) P(1) W(1) ...: the pixel half carries the (branchy, once per tap) pointer set-up and is
+  // issued right after a barrier, where no LDS read is outstanding; the weight half is straight-line code.
+  auto stage_pixels = [&](int hb) {
+    if (kc_in_tap == 0) {
+      const int dy = reg_kh - a.pad_h, dx = reg_kw - a.pad_w;
+      if (++reg_kw == a.KW) { reg_kw = 0; ++reg_kh; }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int sy = p_by[i] + dy, sx = p_bx[i] + dx;
+        const bool ok = p_ok[i] && sy >= 0 && sx >= 0 && sy < a.Hin && sx < a.Win;
+        p_src[i] = ok ? a.in + ((size_t)(p_img[i] * a.Hin + sy) * a.Win + sx) * a.in_ld + cc * 8 : a.zero;
+        p_inc[i] = ok ? 32 : 0;
+      }
+    }
+    if (++kc_in_tap == kh_per_tap) kc_in_tap = 0;
+    unsigned char* pbase = smem + hb * C256_BUF_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      glds16(p_src[i], pbase + (i * 8 + w) * 1024);
+      p_src[i] += p_inc[i];
+    }
+  };
+  auto stage_weights = [&](int hb) {
+    unsigned char* wbase = smem + hb * C256_BUF_BYTES + C256_HALF_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      glds16(w_src[i], wbase + (i * 8 + w) * 1024);
+      w_src[i] += w_inc[i];
+    }
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int wr = w >> 1;  // 64-channel slice
+  const int wc = w & 1;   // 128-pixel slice
+  const int fr = lane & 15;
+  const int fg = lane >> 4;
+  // the swizzle term has a period of 16 rows, so fragment t of a wave is fragment 0 + t * 1024 bytes (an immediate offset)
+  const int wbase0 = C256_HALF_BYTES + (wr * 64 + fr) * 64 + ((fg ^ swz<32>(fr)) << 4);
+  const int pbase0 = (wc * 128 + fr) * 64 + ((fg ^ swz<32>(fr)) << 4);
+  auto ldw = [&](int hb, int t) { return *reinterpret_cast<const s16x8*>(smem + hb * C256_BUF_BYTES + wbase0 + t * 1024); };
+  auto ldp = [&](int hb, int t) { return *reinterpret_cast<const s16x8*>(smem + hb * C256_BUF_BYTES + pbase0 + t * 1024); };
+
+  // ---- prologue: P0 W0 P1 W1 P2 W2 P3 in flight (W3 follows in phase A of half tile 0), publish half tile 0 ----
+  stage_pixels(0); stage_weights(0);
+  stage_pixels(1); stage_weights(1);
+  stage_pixels(2); stage_weights(2);
+  stage_pixels(3);
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  s16x8 wfA[2], wfB[2], pf[8];
+  wfA[0] = ldw(0, 0); wfA[1] = ldw(0, 1);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) pf[j] = ldp(0, j);
+
+  // One half tile.  SW / SP: stage weights(h+3) / pixels(h+4); VMC: loads that may stay in flight at the barrier;
+  // NEXT: half tile h+1 exists.  LDS reads are placed so that nothing waits on a read issued less than ~8 MFMAs
+  // earlier: phase A starts with MFMAs on fragments loaded in the middle of the previous phase B, reloads pixel
+  // fragments 4-7 and the second weight pair after its first four MFMAs, and phase B reloads pixel fragments 0-3
+  // (for the next half tile) between its two MFMA groups.
+#define U2_C256_MFMA(I, WF, J)                                                                             \
+  acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF, pf[J], acc[I][J], 0, 0, 0)
+#define U2_C256_HALF(H, SW, SP, VMC, NEXT)                                                                  \
+  do {                                                                                                     \
+    const int hb_ = (H) & 3, nb_ = ((H) + 1) & 3;                                                          \
+    /* phase A */                                                                                          \
+    __builtin_amdgcn_s_setprio(1);                                                                         \
+    U2_C256_MFMA(0, wfA[0], 0); U2_C256_MFMA(1, wfA[1], 0); U2_C256_MFMA(0, wfA[0], 1); U2_C256_MFMA(1, wfA[1], 1); \
+    __builtin_amdgcn_s_setprio(0);                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    pf[4] = ldp(hb_, 4); pf[5] = ldp(hb_, 5); pf[6] = ldp(hb_, 6); pf[7] = ldp(hb_, 7);                    \
+    wfB[0] = ldw(hb_, 2); wfB[1] = ldw(hb_, 3);                                                            \
+    if (SW) stage_weights(((H) + 3) & 3);                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                         \
+    U2_C256_MFMA(0, wfA[0], 2); U2_C256_MFMA(1, wfA[1], 2); U2_C256_MFMA(0, wfA[0], 3); U2_C256_MFMA(1, wfA[1], 3); \
+    _Pragma("unroll") for (int j = 4; j < 8; ++j) { U2_C256_MFMA(0, wfA[0], j); U2_C256_MFMA(1, wfA[1], j); } \
+    __builtin_amdgcn_s_setprio(0);                                                                         \
+    /* phase B */                                                                                          \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMC) : "memory");                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    asm volatile("" ::: "memory");                                                                         \
+    if (SP) stage_pixels(hb_);                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) { U2_C256_MFMA(2, wfB[0], j); U2_C256_MFMA(3, wfB[1], j); } \
+    __builtin_amdgcn_s_setprio(0);                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    if (NEXT) {                                                                                            \
+      wfA[0] = ldw(nb_, 0); wfA[1] = ldw(nb_, 1);                                                          \
+      pf[0] = ldp(nb_, 0); pf[1] = ldp(nb_, 1); pf[2] = ldp(nb_, 2); pf[3] = ldp(nb_, 3);                  \
+    }                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                         \
+    _Pragma("unroll") for (int j = 4; j < 8; ++j) { U2_C256_MFMA(2, wfB[0], j); U2_C256_MFMA(3, wfB[1], j); } \
+    __builtin_amdgcn_s_setprio(0);                                                                         \
+  } while (0)
+
+  int h = 0;
+  for (; h + 4 < nkh; ++h) U2_C256_HALF(h, true, true, 8, true);
+  U2_C256_HALF(h, true, false, 8, true); ++h;    // h = nkh - 4: weights(nkh-1) are the last loads issued
+  U2_C256_HALF(h, false, false, 4, true); ++h;   // h = nkh - 3
+  U2_C256_HALF(h, false, false, 0, true); ++h;   // h = nkh - 2
+  U2_C256_HALF(h, false, false, 0, false);       // h = nkh - 1
+#undef U2_C256_HALF
+#undef U2_C256_MFMA
+
+  // ---- epilogue: accumulators -> LDS (bf16, [pixel][channel]) -> coalesced 16-byte stores ----
+  __syncthreads();
+  bf16_t* otile = reinterpret_cast<bf16_t*>(smem);
+  float* red = reinterpret_cast<float*>(smem + 256 * C256_OPITCH * 2);  // [2][8][256] floats
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int nl = wr * 64 + i * 16 + fg * 4;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (a.bias) {
+      const int n = n0 + nl;
+      b0 = (n + 0 < a.N) ? a.bias[n + 0] : 0.f;
+      b1 = (n + 1 < a.N) ? a.bias[n + 1] : 0.f;
+      b2 = (n + 2 < a.N) ? a.bias[n + 2] : 0.f;
+      b3 = (n + 3 < a.N) ? a.bias[n + 3] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ml = wc * 128 + j * 16 + fr;
+      float v0 = acc[i][j][0] + b0, v1 = acc[i][j][1] + b1, v2 = acc[i][j][2] + b2, v3 = acc[i][j][3] + b3;
+      if (a.relu && !a.accumulate) {
+        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+      }
+      uint2 pk;
+      pk.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+      pk.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+      *reinterpret_cast<uint2*>(otile + ml * C256_OPITCH + nl) = pk;
+    }
+  }
+  __syncthreads();
+  const int cchunk = tid & 31;   // 32 chunks of 8 channels per output row
+  const int rbase = tid >> 5;    // 16 rows per iteration
+  float s[8], ss[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+  const bool vec_ok = ((a.out_ld & 7) == 0) && (n0 + cchunk * 8 + 8 <= a.N);
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 16 + rbase;
+    const int m = m0 + row;
+    if (m >= a.M) continue;
+    bf16_t e8[8];
+    *reinterpret_cast<uint4*>(e8) = *reinterpret_cast<const uint4*>(otile + row * C256_OPITCH + cchunk * 8);
+    bf16_t* dst = a.out + (size_t)m * a.out_ld + n0 + cchunk * 8;
+    if (a.accumulate) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (n0 + cchunk * 8 + e < a.N) {
+          float f = bf2f(e8[e]) + bf2f(dst[e]);
+          if (a.relu) f = fmaxf(f, 0.f);
+          e8[e] = f2bf(f);
+        }
+      }
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = bf2f(e8[e]);
+        s[e] += f;
+        ss[e] += f * f;
+      }
+    }
+    if (vec_ok) {
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(e8);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n0 + cchunk * 8 + e < a.N) dst[e] = e8[e];
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {  // lanes l and l ^ 32 hold the same 8 channels
+      s[e] += __shfl_xor(s[e], 32, 64);
+      ss[e] += __shfl_xor(ss[e], 32, 64);
+    }
+    if (lane < 32) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(0 * 8 + w) * 256 + lane * 8 + e] = s[e];
+        red[(1 * 8 + w) * 256 + lane * 8 + e] = ss[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 256 && n0 + tid < a.N) {
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) {
+        t0 += red[(0 * 8 + ww) * 256 + tid];
+        t1 += red[(1 * 8 + ww) * 256 + tid];
+      }
+      atomicAdd(a.stats + n0 + tid, t0);
+      atomicAdd(a.stats + a.N + n0 + tid, t1);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad: dW[n][tap][c] += sum_m dY[m][n] * X[src(m,tap)][c]    (fp32 atomics, split over pixels)
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -585,6 +856,22 @@ const bf16_t* zero_page_ptr() {
 namespace {
 
 int launch_conv(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
+  // wide layers: 256 x 256 tile, 8 waves, four-deep half-K-tile ring (variant bit 8 forces it, bit 9 forbids it)
+  const bool wide_ok = !a.remap_out && C % 64 == 0 && a.ntaps * (C / 32) >= 4;
+  // measured win: deep reductions (K >= 1024) with at least two full waves of 256 x 256 tiles; short-K 1x1 layers lose
+  const bool wide_auto = N % 256 == 0 && a.ntaps * C >= 1024 && (long long)a.M * N >= 256LL * 256 * 512;
+  if (wide_ok && !(variant & 512) && ((variant & 256) || wide_auto)) {
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (N + 255) / 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv_igemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_igemm256_kernel, dim3(a.tiles_m * a.tiles_n), dim3(C256_THREADS), C256_LDS_BYTES, s, a);
+    U2_CHECK_LAUNCH();
+    return 0;
+  }
   const bool narrow = N <= 64;  // 256 x 64 tile
   const bool big = !narrow && (variant & 8);  // 256 x 128 tile, 8 waves
   const int TM = (narrow || big) ? 256 : 128, TN = narrow ? 64 : 128;
