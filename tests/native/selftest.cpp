@@ -196,7 +196,7 @@ int main(int argc, char** argv) {
       {1, 200, 1, 128, 801, 1, 1, 0, 1, 1, 0, 0, 1, 0, "linear k128 n801 bias"},
       {1, 9, 9, 64, 64, 3, 3, 1, 1, 1, 1, 1, 0, 0, "3x3 accumulate relu"},
   };
-  const int cvs[] = {0, 1, 32, 48, 4, 4 | 32, 8, 8 | 4 | 32, 256};
+  const int cvs[] = {0, 1, 32, 48, 4, 4 | 32, 8, 8 | 4 | 32, 256, 256 | 1024};
   for (int v : cvs)
     for (const auto& c : convs) fails += test_conv(c, v);
   const WgCase wgs[] = {
@@ -225,7 +225,7 @@ int main(int argc, char** argv) {
       bench_conv("fc1 12544->1024 M8192", 1, 8192, 1, 12544, 1024, 1, 0, 1, v | 512);
       bench_conv("gemm 8192x8192x8192", 1, 8192, 1, 8192, 8192, 1, 0, 1, v | 512);
     }
-    for (int v : {256}) {  // 256 x 256 tile, 8 waves
+    for (int v : {256, 256 | 1024}) {  // 256 x 256 tile, 8 waves; | 1024: staggered wave groups
       bench_conv("fpn_out2 3x3 256->256 B16", 16, 200, 336, 256, 256, 3, 1, 1, v);
       bench_conv("fpn_out3 3x3 256->256 B16", 16, 100, 168, 256, 256, 3, 1, 1, v);
       bench_conv("res4 3x3 256->256 B16", 16, 50, 84, 256, 256, 3, 1, 1, v);

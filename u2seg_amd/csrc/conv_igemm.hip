@@ -371,6 +371,7 @@ constexpr int C256_OPITCH = 256 + 8;
 constexpr int C256_LDS_BYTES = 256 * C256_OPITCH * 2 + 2 * 8 * 256 * 4;  // epilogue staging + stats scratch (151 KB)
 static_assert(C256_LDS_BYTES >= 4 * C256_BUF_BYTES, "ring must fit in the epilogue allocation");
 
+template <bool STAGGER>
 __global__ __launch_bounds__(C256_THREADS, 2) void conv_igemm256_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -461,6 +462,66 @@ __global__ __launch_bounds__(C256_THREADS, 2) void conv_igemm256_kernel(const Co
   auto ldw = [&](int hb, int t) { return *reinterpret_cast<const s16x8*>(smem + hb * C256_BUF_BYTES + wbase0 + t * 1024); };
   auto ldp = [&](int hb, int t) { return *reinterpret_cast<const s16x8*>(smem + hb * C256_BUF_BYTES + pbase0 + t * 1024); };
 
+  s16x8 wfA[2], wfB[2], pf[8];
+#define U2_C256_MFMA(I, WF, J)                                                                             \
+  acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF, pf[J], acc[I][J], 0, 0, 0)
+#define U2_BAR()                                                                                           \
+  do {                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    asm volatile("" ::: "memory");                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    asm volatile("" ::: "memory");                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+  } while (0)
+  if constexpr (STAGGER) {
+    // Two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run the same LOAD | MFMA | LOAD | MFMA sequence one
+    // barrier apart, so that while one group issues LDS reads and LDS-DMA the other keeps the matrix pipe busy:
+    //   L_A(h): read W frags (ch 0-31) + 8 pixel frags of half tile h; stage weights(h+2)
+    //   M_A(h): 16 MFMA
+    //   L_B(h): read W frags (ch 32-63); stage pixels(h+3)      [group 1: vmcnt for half tile h+1]
+    //   M_B(h): 16 MFMA                                         [group 0: vmcnt for half tile h+1]
+    // with a raw barrier after every part.  Half tile k's pixels are staged in L_B(k-3) and its weights in L_A(k-2),
+    // into the buffer of half tile k-4, whose last reads (group 1's L_B(k-4)) retired two barriers earlier.
+    const int grp = w >> 2;
+    stage_pixels(0); stage_weights(0);
+    stage_pixels(1); stage_weights(1);
+    stage_pixels(2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    U2_BAR();
+    if (grp == 1) U2_BAR();  // the lag: group 1 starts one part later
+#define U2_C256_HALF(H, SW, SP, VMC, NEXT)                                                                  \
+  do {                                                                                                     \
+    const int hb_ = (H) & 3;                                                                               \
+    /* L_A */                                                                                              \
+    wfA[0] = ldw(hb_, 0); wfA[1] = ldw(hb_, 1);                                                            \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) pf[j] = ldp(hb_, j);                                     \
+    if (SW) stage_weights(((H) + 2) & 3);                                                                  \
+    U2_BAR();                                                                                              \
+    /* M_A */                                                                                              \
+    __builtin_amdgcn_s_setprio(1);                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) { U2_C256_MFMA(0, wfA[0], j); U2_C256_MFMA(1, wfA[1], j); } \
+    __builtin_amdgcn_s_setprio(0);                                                                         \
+    U2_BAR();                                                                                              \
+    /* L_B */                                                                                              \
+    wfB[0] = ldw(hb_, 2); wfB[1] = ldw(hb_, 3);                                                            \
+    if (SP) stage_pixels(((H) + 3) & 3);                                                                   \
+    if (NEXT && grp == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMC) : "memory");                       \
+    U2_BAR();                                                                                              \
+    /* M_B */                                                                                              \
+    __builtin_amdgcn_s_setprio(1);                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) { U2_C256_MFMA(2, wfB[0], j); U2_C256_MFMA(3, wfB[1], j); } \
+    __builtin_amdgcn_s_setprio(0);                                                                         \
+    if (NEXT && grp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMC) : "memory");                       \
+    U2_BAR();                                                                                              \
+  } while (0)
+    int h = 0;
+    for (; h + 3 < nkh; ++h) U2_C256_HALF(h, true, true, 6, true);
+    U2_C256_HALF(h, true, false, 4, true); ++h;    // h = nkh - 3: weights(nkh-1) are the last loads issued
+    U2_C256_HALF(h, false, false, 0, true); ++h;   // h = nkh - 2
+    U2_C256_HALF(h, false, false, 0, false);       // h = nkh - 1
+#undef U2_C256_HALF
+    if (grp == 0) U2_BAR();  // pairs with group 1's last barrier
+  } else {
   // ---- prologue: P0 W0 P1 W1 P2 W2 P3 in flight (W3 follows in phase A of half tile 0), publish half tile 0 ----
   stage_pixels(0); stage_weights(0);
   stage_pixels(1); stage_weights(1);
@@ -469,7 +530,6 @@ __global__ __launch_bounds__(C256_THREADS, 2) void conv_igemm256_kernel(const Co
   asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  s16x8 wfA[2], wfB[2], pf[8];
   wfA[0] = ldw(0, 0); wfA[1] = ldw(0, 1);
 #pragma unroll
   for (int j = 0; j < 8; ++j) pf[j] = ldp(0, j);
@@ -479,8 +539,6 @@ __global__ __launch_bounds__(C256_THREADS, 2) void conv_igemm256_kernel(const Co
   // earlier: phase A starts with MFMAs on fragments loaded in the middle of the previous phase B, reloads pixel
   // fragments 4-7 and the second weight pair after its first four MFMAs, and phase B reloads pixel fragments 0-3
   // (for the next half tile) between its two MFMA groups.
-#define U2_C256_MFMA(I, WF, J)                                                                             \
-  acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF, pf[J], acc[I][J], 0, 0, 0)
 #define U2_C256_HALF(H, SW, SP, VMC, NEXT)                                                                  \
   do {                                                                                                     \
     const int hb_ = (H) & 3, nb_ = ((H) + 1) & 3;                                                          \
@@ -525,7 +583,9 @@ __global__ __launch_bounds__(C256_THREADS, 2) void conv_igemm256_kernel(const Co
   U2_C256_HALF(h, false, false, 0, true); ++h;   // h = nkh - 2
   U2_C256_HALF(h, false, false, 0, false);       // h = nkh - 1
 #undef U2_C256_HALF
+  }
 #undef U2_C256_MFMA
+#undef U2_BAR
 
   // ---- epilogue: accumulators -> LDS (bf16, [pixel][channel]) -> coalesced 16-byte stores ----
   __syncthreads();
@@ -865,10 +925,14 @@ int launch_conv(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
     a.tiles_n = (N + 255) / 256;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)conv_igemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_igemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_igemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
-    hipLaunchKernelGGL(conv_igemm256_kernel, dim3(a.tiles_m * a.tiles_n), dim3(C256_THREADS), C256_LDS_BYTES, s, a);
+    if (variant & 1024)  // staggered two-group schedule
+      hipLaunchKernelGGL(conv_igemm256_kernel<true>, dim3(a.tiles_m * a.tiles_n), dim3(C256_THREADS), C256_LDS_BYTES, s, a);
+    else
+      hipLaunchKernelGGL(conv_igemm256_kernel<false>, dim3(a.tiles_m * a.tiles_n), dim3(C256_THREADS), C256_LDS_BYTES, s, a);
     U2_CHECK_LAUNCH();
     return 0;
   }
