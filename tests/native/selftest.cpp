@@ -225,7 +225,7 @@ int main(int argc, char** argv) {
       bench_conv("fc1 12544->1024 M8192", 1, 8192, 1, 12544, 1024, 1, 0, 1, v | 512);
       bench_conv("gemm 8192x8192x8192", 1, 8192, 1, 8192, 8192, 1, 0, 1, v | 512);
     }
-    for (int v : {256, 256 | 1024}) {  // 256 x 256 tile, 8 waves; | 1024: staggered wave groups
+    for (int v : {256, 256 | 1024, 256 | 1024 | 2048}) {  // 256 x 256 tile, 8 waves; | 1024: staggered wave groups
       bench_conv("fpn_out2 3x3 256->256 B16", 16, 200, 336, 256, 256, 3, 1, 1, v);
       bench_conv("fpn_out3 3x3 256->256 B16", 16, 100, 168, 256, 256, 3, 1, 1, v);
       bench_conv("res4 3x3 256->256 B16", 16, 50, 84, 256, 256, 3, 1, 1, v);

@@ -172,3 +172,59 @@ def test_hot_path_fails_loudly_without_gpu():
 
     with pytest.raises((AssertionError, RuntimeError)):
         F.conv2d(torch.zeros((1, 4, 4, 32), dtype=torch.bfloat16), torch.zeros(32, 32, 1, 1))
+
+
+def test_lazy_bitmasks_and_batched_views():
+    """Host-side structures behind the batched bookkeeping: lazy BitMasks selection (composition of index vectors, no
+    gather until .tensor is read), the lazy proposal list, padded targets and the device-constant cache."""
+    from u2seg_amd.modeling.batched import BatchList, LazyProposals, PaddedTargets, device_constant, image_index, proposals_from_list
+    from u2seg_amd.structures import BitMasks, Boxes, Instances
+
+    g = torch.Generator().manual_seed(0)
+    base = torch.rand((5, 6, 7), generator=g) > 0.5
+    bm = BitMasks(base)
+    sel = bm[torch.tensor([4, 1, 1, 0])]
+    assert len(sel) == 4 and sel._base is bm._base  # nothing gathered yet
+    sub = sel[torch.tensor([True, False, True, True])]
+    assert len(sub) == 3 and torch.equal(sub.tensor, base[torch.tensor([4, 1, 0])])
+    assert torch.equal(sel[2:3].tensor if False else sel.tensor[2:3], base[1:2])
+    assert torch.equal(BitMasks.cat([sel, sub]).tensor, torch.cat([base[torch.tensor([4, 1, 1, 0])], base[torch.tensor([4, 1, 0])]]))
+
+    # LazyProposals: padded tensors + counts -> ragged list[Instances] on demand; FloatingPointError on non-finite flag
+    boxes = torch.arange(2 * 3 * 4, dtype=torch.float32).view(2, 3, 4)
+    logits = torch.arange(6, dtype=torch.float32).view(2, 3)
+    lp = LazyProposals([(10, 12), (8, 9)], boxes, logits, torch.tensor([2, 3], dtype=torch.int32), torch.tensor(True), True)
+    assert len(lp) == 2 and lp._items is None
+    assert [len(p) for p in lp] == [2, 3] and lp[1].image_size == (8, 9)
+    assert torch.equal(lp[0].proposal_boxes.tensor, boxes[0, :2]) and torch.equal(lp[1].objectness_logits, logits[1])
+    bad = LazyProposals([(10, 12)], boxes[:1], logits[:1], torch.tensor([1], dtype=torch.int32), torch.tensor(False), True)
+    with pytest.raises(FloatingPointError):
+        bad[0]
+    back = proposals_from_list(list(lp))
+    assert back.counts.tolist() == [2, 3] and torch.equal(back.boxes[1], boxes[1]) and float(back.boxes[0, 2].abs().sum()) == 0
+
+    # PaddedTargets: zero padded, cached per gt list
+    t0, t1 = Instances((10, 12)), Instances((8, 9))
+    t0.gt_boxes, t0.gt_classes = Boxes(torch.tensor([[1.0, 2, 3, 4]])), torch.tensor([7])
+    t1.gt_boxes, t1.gt_classes = Boxes(torch.zeros((0, 4))), torch.zeros(0, dtype=torch.int64)
+    pt = PaddedTargets.of([t0, t1], "cpu")
+    assert pt.boxes.shape == (2, 1, 4) and pt.counts.tolist() == [1, 0] and pt.classes.tolist() == [[7], [0]]
+    assert PaddedTargets.of([t0, t1], "cpu") is pt
+
+    assert device_constant([1, 2, 3], torch.int32, "cpu") is device_constant([1, 2, 3], torch.int32, "cpu")
+    assert image_index([2, 0, 3], "cpu").tolist() == [0, 0, 2, 2, 2]
+    bl = BatchList([t0])
+    assert not bl.stacked and len(bl) == 1
+
+
+def test_batchnorm_counts_batches_lazily():
+    from u2seg_amd.layers.modules import BatchNorm2d
+
+    bn = BatchNorm2d(8)
+    for _ in range(3):
+        bn.count_batch()
+    assert int(bn.num_batches_tracked) == 0  # no per-step device op ...
+    assert int(bn.state_dict()["num_batches_tracked"]) == 3  # ... folded in when the buffer is read
+    bn.load_state_dict(bn.state_dict())
+    bn.count_batch()
+    assert int(bn.state_dict()["num_batches_tracked"]) == 4

@@ -40,6 +40,7 @@ struct ConvArgs {
   // output placement: pixel (img, qy, qx) of the Hout x Wout grid is written at
   // (img, qy*out_sy + out_y0, qx*out_sx + out_x0) of the Hfull x Wfull map (identity for ordinary launches)
   int remap_out, Hfull, Wfull, out_sy, out_sx, out_y0, out_x0;
+  int stagger_by_parity;   // conv_igemm256<true>: wave groups = even / odd waves instead of waves 0-3 / 4-7
 };
 
 // Tile shapes: (TM pixels x TN output channels) = 128x128 (default) or 256x64 (layers with <= 64 output channels,
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(C256_THREADS, 2) void conv_igemm256_kernel(const Co
     //   M_B(h): 16 MFMA                                         [group 0: vmcnt for half tile h+1]
     // with a raw barrier after every part.  Half tile k's pixels are staged in L_B(k-3) and its weights in L_A(k-2),
     // into the buffer of half tile k-4, whose last reads (group 1's L_B(k-4)) retired two barriers earlier.
-    const int grp = w >> 2;
+    const int grp = a.stagger_by_parity ? (w & 1) : (w >> 2);
     stage_pixels(0); stage_weights(0);
     stage_pixels(1); stage_weights(1);
     stage_pixels(2);
@@ -929,6 +930,7 @@ int launch_conv(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
       (void)hipFuncSetAttribute((const void*)conv_igemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
+    a.stagger_by_parity = (variant & 2048) ? 1 : 0;
     if (variant & 1024)  // staggered two-group schedule
       hipLaunchKernelGGL(conv_igemm256_kernel<true>, dim3(a.tiles_m * a.tiles_n), dim3(C256_THREADS), C256_LDS_BYTES, s, a);
     else
