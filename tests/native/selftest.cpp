@@ -208,6 +208,8 @@ int main(int argc, char** argv) {
   for (int v = 0; v < 4; ++v)
     for (const auto& c : wgs) fails += test_wgrad(c, v);
   for (const auto& c : wgs) fails += test_wgrad(c, 64);
+  for (const auto& c : wgs) fails += test_wgrad(c, 256);
+  for (const auto& c : wgs) fails += test_wgrad(c, 256, true);
   for (const auto& c : wgs) fails += test_wgrad(c, 0, true);
   printf("SELFTEST %s (%d failures)\n", fails ? "FAILED" : "OK", fails);
   if (argc > 1 && !strcmp(argv[1], "bench")) {
@@ -235,7 +237,7 @@ int main(int argc, char** argv) {
       bench_conv("fc1 12544->1024 M8192", 1, 8192, 1, 12544, 1024, 1, 0, 1, v);
       bench_conv("gemm 8192x8192x8192", 1, 8192, 1, 8192, 8192, 1, 0, 1, v);
     }
-    const int vs[] = {64};  // wgrad: all tiles of a pixel split on one XCD
+    const int vs[] = {512};  // wgrad: 128 x 128 tiles only (the default picks 256 x 256 when N and C are multiples of 256)
     for (int v : vs) {
       bench_conv("res2 3x3 64->64 B16", 16, 200, 336, 64, 64, 3, 1, 1, v);
       bench_conv("res3 3x3 128->128 B16", 16, 100, 168, 128, 128, 3, 1, 1, v);

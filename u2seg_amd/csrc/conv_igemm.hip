@@ -833,9 +833,23 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradArgs a) {
     yoff0[e] = pix * 256 + (((chy >> 3) ^ wg_swz(pix)) << 4) + (chy & 7) * 2;
     xoff0[e] = pix * 256 + (((chx >> 3) ^ wg_swz(pix)) << 4) + (chx & 7) * 2;
   }
+  // GLDS + TR: the transposing reads are inline asm.  Through the builtin the compiler assumes every LDS read may alias
+  // the LDS-DMA writes in flight and drains them (vmcnt(0)) right after they are issued, i.e. the next step's loads
+  // never overlap this step's MFMAs.  Ordering is explicit instead: vmcnt(0) + barrier before a step is read (the only
+  // loads in flight at that point are that step's), lgkmcnt(0) after the reads.
+  constexpr bool ASM_TR = GLDS && TR;
+  const unsigned lds0 = (unsigned)(size_t)U2_LDS_PTR(smem);
   auto load_frag = [&](const unsigned char* base, const int* off0, int q) -> s16x8 {
     s16x8 r;
-    if constexpr (TR) {
+    if constexpr (ASM_TR) {
+      union { unsigned long long u[2]; s16x8 v; } rr;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned addr = lds0 + (unsigned)(base - smem) + (unsigned)(off0[h] ^ (q << 5));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(rr.u[h]) : "v"(addr) : "memory");
+      }
+      r = rr.v;
+    } else if constexpr (TR) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -857,6 +871,10 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradArgs a) {
     for (int q = 0; q < 4; ++q) {
       yf[q] = load_frag(ybase, yoff0, q);
       xf[q] = load_frag(xbase, xoff0, q);
+    }
+    if constexpr (ASM_TR) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -890,6 +908,169 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = c0 + wc * 64 + j * 16 + fr;
+      if (c >= a.c_valid) continue;
+      float* dst = a.dw + (size_t)tap * a.dw_st + (size_t)c * a.dw_sc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wr * 64 + i * 16 + fg * 4 + r;
+        if (n < a.n_valid) atomicAdd(dst + n * a.dw_sn, acc[i][j][r]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad, 256(n) x 256(c) tile per tap, 8 waves of 64(n) x 128(c).  The 128 x 128 kernel re-streams its pixel range for every
+// (n-tile, c-tile) pair - PMC: 829 MB fetched per launch against ~250 MB algorithmic - so for layers with >= 256 channels
+// on both sides this halves (256 x 256 layers: both operands once per tap) the traffic that bounds it.  Each operand's
+// [32 px][256 ch] step image is stored as two of the 128-channel images of the kernel above (same swizzle, same transposing
+// reads); three-stage LDS ring, counted vmcnt, one raw barrier per step (one resident work-group per CU cannot hide a
+// drained pipeline behind another group).
+// ------------------------------------------------------------------------------------------------
+constexpr int WG256_IMG = WP * 128 * 2;          // 8 KB: one [32 px][128 ch] image
+constexpr int WG256_STAGE = 4 * WG256_IMG;       // dy lo / dy hi / x lo / x hi
+constexpr int WG256_STAGES = 3;
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = blockIdx.x, split = blockIdx.y;
+  if (a.xcd_group) {
+    const int logical = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    split = logical / a.tiles;
+    t = logical - split * a.tiles;
+  }
+  const int tile_c = t % a.tiles_c; t /= a.tiles_c;
+  const int tile_n = t % a.tiles_n; t /= a.tiles_n;
+  const int tap = t;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int n0 = tile_n * 256, c0 = tile_c * 256;
+  const int mbeg = split * a.pix_per_wg;
+  const int mend = min(a.M, mbeg + a.pix_per_wg);
+  if (mbeg >= mend) return;
+  const int nsteps = (mend - mbeg + WP - 1) / WP;
+  const int hw = a.Hout * a.Wout;
+  const bool direct = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad_h == 0 && a.pad_w == 0);
+
+  // staging: wave w moves pixels 4w .. 4w+3 of the step (16 chunks each) of all four images
+  const int pix = w * 4 + (lane >> 4);
+  const int cc = (lane & 15) ^ wg_swz(pix);
+  int cm = mbeg + pix, cimg, coy, cox;
+  {
+    cimg = cm / hw;
+    const int rem = cm - cimg * hw;
+    coy = rem / a.Wout;
+    cox = rem - coy * a.Wout;
+  }
+  auto issue = [&](int buf) {
+    unsigned char* base = smem + buf * WG256_STAGE;
+    const bool mok = cm < mend;
+    const bf16_t* xrow = nullptr;
+    if (mok) {
+      if (direct) {
+        xrow = a.x + (size_t)cm * a.x_ld;
+      } else {
+        const int sy = coy * a.stride - a.pad_h + kh;
+        const int sx = cox * a.stride - a.pad_w + kw;
+        if (sy >= 0 && sy < a.Hin && sx >= 0 && sx < a.Win) xrow = a.x + ((size_t)(cimg * a.Hin + sy) * a.Win + sx) * a.x_ld;
+      }
+    }
+#pragma unroll
+    for (int im = 0; im < 2; ++im) {
+      const int nch = n0 + im * 128 + cc * 8, cch = c0 + im * 128 + cc * 8;
+      const bf16_t* ysrc = (mok && nch < a.N) ? a.dy + (size_t)cm * a.dy_ld + nch : a.zero;
+      const bf16_t* xsrc = (xrow && cch < a.C) ? xrow + cch : a.zero;
+      glds16(ysrc, base + im * WG256_IMG + w * 1024);
+      glds16(xsrc, base + (2 + im) * WG256_IMG + w * 1024);
+    }
+    cm += WP;
+    if (!direct) {
+      if (a.Wout >= WP) {
+        cox += WP;
+        while (cox >= a.Wout) { cox -= a.Wout; if (++coy == a.Hout) { coy = 0; ++cimg; } }
+      } else {
+        cimg = cm / hw;
+        const int rem = cm - cimg * hw;
+        coy = rem / a.Wout;
+        cox = rem - coy * a.Wout;
+      }
+    }
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int wr = w >> 1, wc = w & 1;  // wr: 64-channel slice of dy (image wr >> 1, half wr & 1); wc: x image (128 channels)
+  const int fr = lane & 15, fg = lane >> 4;
+  // transposing-read offsets inside one image (see conv_wgrad_kernel); the 16-channel block q is offset ^ (q << 5)
+  int yoff0[2], xoff0[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int px = fg * 8 + e * 4 + (fr >> 2);
+    const int chl = (fr & 3) * 4;
+    const int chy = (wr & 1) * 64 + chl;
+    yoff0[e] = (wr >> 1) * WG256_IMG + px * 256 + (((chy >> 3) ^ wg_swz(px)) << 4) + (chy & 7) * 2;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int chx = hh * 64 + chl;
+      xoff0[hh][e] = (2 + wc) * WG256_IMG + px * 256 + (((chx >> 3) ^ wg_swz(px)) << 4) + (chx & 7) * 2;
+    }
+  }
+  // The transposing reads are issued as inline asm: for the builtin the compiler assumes that an LDS read may alias the
+  // LDS-DMA writes still in flight and drains them (s_waitcnt vmcnt(0)) before every step, which turns the ring into a
+  // synchronous load.  Ordering is explicit instead: counted vmcnt + barrier before the reads, lgkmcnt(0) after them.
+  const unsigned lds0 = (unsigned)(size_t)U2_LDS_PTR(smem);
+  auto load_frag = [&](unsigned base, const int* off0, int q) -> s16x8 {
+    union { unsigned long long u[2]; s16x8 v; } r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const unsigned addr = base + (unsigned)(off0[h] ^ (q << 5));
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r.u[h]) : "v"(addr) : "memory");
+    }
+    return r.v;
+  };
+  auto compute = [&](int buf) {
+    const unsigned base = lds0 + buf * WG256_STAGE;
+    s16x8 yf[4], xf[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      yf[q] = load_frag(base, yoff0, q);
+      xf[q] = load_frag(base, xoff0[0], q);
+      xf[4 + q] = load_frag(base, xoff0[1], q);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // three-stage ring: steps st+1 and st+2 are in flight while step st is multiplied (4 LDS-DMA loads per thread per step)
+  issue(0);
+  if (nsteps > 1) issue(1);
+  for (int st = 0; st < nsteps; ++st) {
+    if (st + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (st + 2 < nsteps) issue((st + 2) % WG256_STAGES);
+    compute(st % WG256_STAGES);
+  }
+
+  // D[i = n][j = c]: lane holds column c = fr, rows n = fg*4 + r
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + wc * 128 + (j >> 2) * 64 + (j & 3) * 16 + fr;
       if (c >= a.c_valid) continue;
       float* dst = a.dw + (size_t)tap * a.dw_st + (size_t)c * a.dw_sc;
 #pragma unroll
@@ -1069,18 +1250,24 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
   a.Hout = Hout; a.Wout = Wout; a.N = N; a.dy_ld = dy_ld;
   a.KH = KH; a.KW = KW; a.pad_h = pad_h; a.pad_w = pad_w; a.stride = stride;
   a.M = B * Hout * Wout;
-  a.tiles_n = (N + 127) / 128;
-  a.tiles_c = (C + 127) / 128;
+  // 256 x 256 tiles: only on request (variant bit 8).  Measured 516 vs 805 TFLOP/s on the 200x336 3x3 256->256 layer: with
+  // one resident work-group per CU the transposing reads of a step are not hidden behind anything, while four resident
+  // 128 x 128 groups hide them behind each other, which outweighs the halved operand traffic.
+  const bool wide = (variant & 256) && (variant & 3) == 0;
+  const int tw = wide ? 256 : 128;
+  a.tiles_n = (N + tw - 1) / tw;
+  a.tiles_c = (C + tw - 1) / tw;
   const int tiles = a.tiles_n * a.tiles_c * KH * KW;
   // Pixel splits: fill the chip once (4 resident work-groups per CU = 1024 slots) but keep >= 2048 pixels per
   // work-group so that the 64 KB fp32-atomic epilogue stays a small fraction; tiny layers fall back to >= 512 groups.
-  int slots = 1024 >> ((variant >> 4) & 3);  // variant bits 4-5: tuning knob
+  int slots = (wide ? 256 : 1024) >> ((variant >> 4) & 3);  // resident work-groups; variant bits 4-5: tuning knob
   int splits = slots / tiles;
   if (splits < 1) splits = 1;
   const int by_pixels = a.M / 2048 > 1 ? a.M / 2048 : 1;
   if (splits > by_pixels) splits = by_pixels;
-  if (tiles * splits < 512) {
-    int s2 = (512 + tiles - 1) / tiles;
+  const int min_groups = wide ? 256 : 512;
+  if (tiles * splits < min_groups) {
+    int s2 = (min_groups + tiles - 1) / tiles;
     const int cap = a.M / 512 > 1 ? a.M / 512 : 1;
     if (s2 > cap) s2 = cap;
     if (s2 > splits) splits = s2;
@@ -1096,6 +1283,16 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
   const dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool glds = (variant & 1) == 0, tr = (variant & 2) == 0;
+  if (wide) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad256_kernel, grid, dim3(512), WG256_STAGES * WG256_STAGE, s, a);
+    U2_CHECK_LAUNCH();
+    return 0;
+  }
   if (glds && tr)       hipLaunchKernelGGL((conv_wgrad_kernel<true, true>), grid, block, 0, s, a);
   else if (glds && !tr) hipLaunchKernelGGL((conv_wgrad_kernel<true, false>), grid, block, 0, s, a);
   else if (!glds && tr) hipLaunchKernelGGL((conv_wgrad_kernel<false, true>), grid, block, 0, s, a);
