@@ -141,6 +141,10 @@ int u2_roi_align_bwd_gather_multi(void* const* gfeats, const int* Hs, const int*
                                   int nsets, const void* const* rois, const void* const* order, const void* const* seg,
                                   const void* const* dout, const int* P, const float* gscale, int B, int C, void* stream);
 int u2_mask_crop(const void* masks, const float* rois, void* out, int R, int H, int W, int P, void* stream);
+/* The crops of a whole batch in one launch: image i's bitmaps are mask_bases[i] ([K_i][Hs[i]][Ws[i]] uint8, host arrays of
+ * device pointers / sizes), roi_image[r] (device) is the image of ROI r, rois[r] = (bitmap row in that image, x0, y0, x1, y1). */
+int u2_mask_crop_batch(const void* const* mask_bases, const int* Hs, const int* Ws, int n_images, const float* rois,
+                       const int* roi_image, void* out, int R, int P, void* stream);
 int u2_assign_levels(const float* boxes, int* level, int n, int min_level, int max_level, float canonical_size,
                      int canonical_level, void* stream);
 int u2_iou_match(const float* boxes, int per_image_boxes, const float* gt, const int* ngt, int* match, float* mval,

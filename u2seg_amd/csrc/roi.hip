@@ -305,6 +305,46 @@ __global__ __launch_bounds__(256) void mask_crop_kernel(const uint8_t* __restric
   }
 }
 
+// the same crop for a batch of images whose bitmaps live in separate tensors (possibly of different sizes): one launch,
+// roi_image[r] selects the image of ROI r, rois[r][0] the bitmap row inside that image's tensor
+struct MaskImages { const uint8_t* base[32]; int H[32]; int W[32]; };
+
+__global__ __launch_bounds__(256) void mask_crop_batch_kernel(const MaskImages imgs, const float* __restrict__ rois,
+                                                              const int* __restrict__ roi_image, uint8_t* __restrict__ out,
+                                                              int R, int P, int img0) {
+  const size_t total = (size_t)R * P * P;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    size_t p = i;
+    const int pw = (int)(p % P); p /= P;
+    const int ph = (int)(p % P);
+    const int r = (int)(p / P);
+    const int im = roi_image[r] - img0;
+    if (im < 0 || im >= 32) continue;  // belongs to another chunk of images
+    const int H = imgs.H[im], W = imgs.W[im];
+    const float* roi = rois + (size_t)r * 5;
+    const int b = (int)roi[0];
+    const float sw = roi[1] - 0.5f, sh = roi[2] - 0.5f, ew = roi[3] - 0.5f, eh = roi[4] - 0.5f;
+    const float rw = ew - sw, rh = eh - sh;
+    const float bh = rh / (float)P, bw = rw / (float)P;
+    const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
+    const float cnt = (float)max(gh * gw, 1);
+    float acc = 0.f;
+    const uint8_t* m = imgs.base[im] + (size_t)b * H * W;
+    for (int iy = 0; iy < gh; ++iy) {
+      const float y = sh + ph * bh + (iy + 0.5f) * bh / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        const float x = sw + pw * bw + (ix + 0.5f) * bw / (float)gw;
+        int yl, xl, yh, xh;
+        float w1, w2, w3, w4;
+        if (!bil_prep(y, x, H, W, yl, xl, yh, xh, w1, w2, w3, w4)) continue;
+        acc += w1 * (float)m[(size_t)yl * W + xl] + w2 * (float)m[(size_t)yl * W + xh] + w3 * (float)m[(size_t)yh * W + xl] +
+               w4 * (float)m[(size_t)yh * W + xh];
+      }
+    }
+    out[i] = (acc / cnt >= 0.5f) ? 1 : 0;
+  }
+}
+
 __global__ void assign_levels_kernel(const float* __restrict__ boxes, int* __restrict__ level, int n, int min_level,
                                      int max_level, float canonical_size, int canonical_level) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -558,6 +598,20 @@ extern "C" int u2_mask_crop(const void* masks, const float* rois, void* out, int
   hipLaunchKernelGGL(mask_crop_kernel, dim3(ew_blocks((size_t)R * P * P)), dim3(256), 0, (hipStream_t)stream,
                      (const uint8_t*)masks, rois, (uint8_t*)out, R, H, W, P);
   U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_mask_crop_batch(const void* const* mask_bases, const int* Hs, const int* Ws, int n_images, const float* rois,
+                                  const int* roi_image, void* out, int R, int P, void* stream) {
+  if (R <= 0 || n_images <= 0) return 0;
+  for (int i0 = 0; i0 < n_images; i0 += 32) {
+    const int nb = n_images - i0 < 32 ? n_images - i0 : 32;
+    MaskImages mi;
+    for (int i = 0; i < nb; ++i) { mi.base[i] = (const uint8_t*)mask_bases[i0 + i]; mi.H[i] = Hs[i0 + i]; mi.W[i] = Ws[i0 + i]; }
+    hipLaunchKernelGGL(mask_crop_batch_kernel, dim3(ew_blocks((size_t)R * P * P)), dim3(256), 0, (hipStream_t)stream, mi, rois,
+                       roi_image, (uint8_t*)out, R, P, i0);
+    U2_CHECK_LAUNCH();
+  }
   return 0;
 }
 

@@ -247,16 +247,14 @@ class MaskRCNNConvUpsampleHead(nn.Module):
     def mask_loss(self, x, instances):
         """mask_rcnn_loss (mask_head.py:33-112) fused with the predictor: only the gt-class channel is formed."""
         side = x.shape[1]
-        gt_classes, gt_masks = [], []
-        for inst in instances:
-            if len(inst) == 0:
-                continue
-            gt_classes.append(inst.gt_classes.to(torch.int64))
-            gt_masks.append(inst.gt_masks.crop_and_resize(inst.proposal_boxes.tensor, side))
-        if len(gt_masks) == 0:
+        from ..structures.masks import crop_and_resize_batch
+
+        keep = [inst for inst in instances if len(inst) > 0]
+        if len(keep) == 0:
             return x.float().sum() * 0.0 + self.predictor.weight.sum() * 0.0
-        gt_classes = torch.cat(gt_classes, dim=0)
-        gt_masks = torch.cat(gt_masks, dim=0).to(torch.uint8)
+        gt_classes = torch.cat([inst.gt_classes.to(torch.int64) for inst in keep], dim=0)
+        gt_masks = crop_and_resize_batch([inst.gt_masks for inst in keep], [inst.proposal_boxes.tensor for inst in keep],
+                                         side).to(torch.uint8)
         if self.num_classes == 1:
             gt_classes = torch.zeros_like(gt_classes)
         return F.mask_predict_bce_loss(x, self.predictor.weight, self.predictor.bias, gt_classes, gt_masks)

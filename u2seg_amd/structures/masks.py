@@ -72,3 +72,34 @@ class BitMasks:
         rows = torch.arange(len(boxes), device=device) if self._index is None else self._index
         rois = torch.cat([rows.to(dtype=torch.float32)[:, None], boxes.float()], dim=1)
         return F.mask_crop(self._base.contiguous().view(torch.uint8), rois, mask_size).to(torch.bool)
+
+
+def crop_and_resize_batch(bitmasks_list, boxes_list, mask_size):
+    """BitMasks.crop_and_resize of several images (structures/masks.py:191-218) in ONE kernel launch: the bitmaps of
+    each image stay where they are (a table of base pointers goes to the kernel), the lazy row selections become the
+    per-ROI bitmap index.  Returns bool [sum_i len(boxes_i), mask_size, mask_size]."""
+    import ctypes
+
+    from .. import _hip
+    from ..modeling.batched import image_index
+
+    n = len(bitmasks_list)
+    sizes = [len(b) for b in boxes_list]
+    total = sum(sizes)
+    dev = bitmasks_list[0].device
+    out = torch.empty((total, mask_size, mask_size), dtype=torch.uint8, device=dev)
+    if total == 0:
+        return out.to(torch.bool)
+    bases, rows = [], []
+    for bm, k in zip(bitmasks_list, sizes):
+        assert len(bm) == k, "{} != {}".format(len(bm), k)
+        bases.append(bm._base.contiguous())
+        rows.append(torch.arange(k, device=dev) if bm._index is None else bm._index)
+    boxes = torch.cat([b.float() for b in boxes_list], dim=0)
+    rois = torch.cat([torch.cat(rows).to(torch.float32)[:, None], boxes], dim=1).contiguous()
+    roi_image = image_index(sizes, dev).to(torch.int32)
+    ptrs = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bases])
+    hs = (ctypes.c_int * n)(*[b.shape[1] for b in bases])
+    ws = (ctypes.c_int * n)(*[b.shape[2] for b in bases])
+    _hip.call("u2_mask_crop_batch", ptrs, hs, ws, n, rois, roi_image, out, total, mask_size)
+    return out.to(torch.bool)
