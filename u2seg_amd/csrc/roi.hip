@@ -501,51 +501,68 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   mask[((size_t)b * n + i) * NB + cb] = bits;
 }
 
+// In-order scan.  Greedy NMS is serial over the candidates, so the kernel is organised around the length of the
+// dependent chain per 64-candidate block: wave 0 resolves the block in registers (64 shuffle steps); meanwhile waves 1-3
+// already OR together, for the NEXT block's column word, the suppression rows of every box kept before this block (a
+// lazy column-wise update: nothing that is not about to be consumed is touched); after one barrier all threads add the
+// rows kept in this block (<= 64 loads, one latency) and the next block's "removed" word is final.  The diagonal rows
+// of the next block are fetched in the same shadow.  The previous version updated all later column words eagerly after
+// every block (64 dependent loads per thread, ~22 us per block); this one needs ~4 us per block.
 __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ cnt,
                                                        int* __restrict__ keep, int* __restrict__ nkeep, int n, int NB,
                                                        int max_keep) {
-  extern __shared__ unsigned long long removed[];  // [NB]
-  __shared__ unsigned long long s_keep;
-  __shared__ int s_count;
+  extern __shared__ int kept_rows[];  // [max_keep] candidate indices kept so far
+  __shared__ unsigned long long s_removed;   // final "removed" word of the block about to be scanned
+  __shared__ unsigned long long s_partial;   // OR of older kept rows for the next block's word
+  __shared__ unsigned long long s_diag[64];  // diagonal rows of the block about to be scanned
+  __shared__ int s_count, s_prev;
   const int b = blockIdx.x;
   const int nb = cnt[b];
   const int nblk = (nb + 63) / 64;
   const int tid = threadIdx.x;
-  for (int i = tid; i < NB; i += 256) removed[i] = 0;
-  if (tid == 0) s_count = 0;
+  const size_t rowbase = (size_t)b * n;
+  if (tid == 0) { s_count = 0; s_prev = 0; s_removed = 0ull; s_partial = 0ull; }
+  if (tid < 64) s_diag[tid] = (tid < nb) ? mask[(rowbase + tid) * NB + 0] : 0ull;
   __syncthreads();
   for (int cb = 0; cb < nblk; ++cb) {
+    const int kprev = s_count;  // boxes kept before this block
     if (tid < 64) {
-      const int i = cb * 64 + tid;
-      // rows of the diagonal block; bits only for columns > row, rows past nb contribute nothing
-      const unsigned long long dm = (i < nb) ? mask[((size_t)b * n + i) * NB + cb] : 0ull;
-      unsigned long long rem = removed[cb];
+      // ---- wave 0: resolve block cb ----
+      const unsigned long long dm = s_diag[tid];
+      unsigned long long rem = s_removed;
       if (nb - cb * 64 < 64) rem |= ~0ull << (nb - cb * 64);
       unsigned long long kept = 0;
       for (int t = 0; t < 64; ++t) {
         const unsigned long long row = __shfl(dm, t, 64);
         if (!((rem >> t) & 1ull)) { kept |= 1ull << t; rem |= row; }
       }
-      const int base = s_count;
       if ((kept >> tid) & 1ull) {
-        const int pos = base + __popcll(kept & ((1ull << tid) - 1ull));
-        if (pos < max_keep) keep[(size_t)b * max_keep + pos] = cb * 64 + tid;
+        const int pos = kprev + __popcll(kept & ((1ull << tid) - 1ull));
+        if (pos < max_keep) { keep[(size_t)b * max_keep + pos] = cb * 64 + tid; kept_rows[pos] = cb * 64 + tid; }
       }
-      if (tid == 0) { s_keep = kept; s_count = base + __popcll(kept); }
+      if (tid == 0) { s_prev = kprev; s_count = min(kprev + __popcll(kept), max_keep + 64); }
+    } else if (cb + 1 < nblk) {
+      // ---- waves 1-3: older kept rows, next block's column word ----
+      unsigned long long acc = 0ull;
+      for (int k = tid - 64; k < min(kprev, max_keep); k += 192) acc |= mask[(rowbase + kept_rows[k]) * NB + cb + 1];
+      for (int off = 32; off > 0; off >>= 1) acc |= __shfl_xor(acc, off, 64);
+      if ((tid & 63) == 0 && acc) atomicOr(&s_partial, acc);
     }
     __syncthreads();
-    const unsigned long long kept = s_keep;
-    if (s_count >= max_keep) break;
-    for (int wd = cb + 1 + tid; wd < nblk; wd += 256) {
-      unsigned long long acc = removed[wd];
-      unsigned long long k = kept;
-      while (k) {
-        const int t = __ffsll((long long)k) - 1;
-        k &= k - 1;
-        acc |= mask[((size_t)b * n + cb * 64 + t) * NB + wd];
+    const int knew = min(s_count, max_keep);
+    if (s_count >= max_keep || cb + 1 >= nblk) break;
+    // ---- everybody: rows kept in this block, next block's word; fetch the next diagonal block ----
+    {
+      unsigned long long acc = 0ull;
+      for (int k = s_prev + tid; k < knew; k += 256) acc |= mask[(rowbase + kept_rows[k]) * NB + cb + 1];
+      if (acc) atomicOr(&s_partial, acc);
+      if (tid >= 192) {
+        const int i = (cb + 1) * 64 + (tid - 192);
+        s_diag[tid - 192] = (i < nb) ? mask[(rowbase + i) * NB + cb + 1] : 0ull;
       }
-      removed[wd] = acc;
     }
+    __syncthreads();
+    if (tid == 0) { s_removed = s_partial; s_partial = 0ull; }
     __syncthreads();
   }
   if (tid == 0) nkeep[b] = min(s_count, max_keep);
@@ -664,13 +681,14 @@ extern "C" long long u2_nms_workspace_bytes(int B, int n) {
 extern "C" int u2_batched_nms(const float* boxes, const int* group, const int* cnt, void* workspace, int* keep, int* nkeep,
                               int B, int n, float thr, int max_keep, void* stream) {
   if (B <= 0 || n <= 0) return 0;
+  if (max_keep > 16384) return -1;  // the scan keeps the kept list (4 B per box) in LDS
   const int NB = (n + 63) / 64;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(nms_mask_kernel, dim3(NB, NB, B), dim3(64), 0, s, boxes, group, cnt, (unsigned long long*)workspace, n,
                      NB, thr);
   U2_CHECK_LAUNCH();
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(256), (size_t)NB * 8, s, (const unsigned long long*)workspace, cnt, keep,
-                     nkeep, n, NB, max_keep);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(256), (size_t)(max_keep > 0 ? max_keep : 1) * 4, s,
+                     (const unsigned long long*)workspace, cnt, keep, nkeep, n, NB, max_keep);
   U2_CHECK_LAUNCH();
   return 0;
 }
