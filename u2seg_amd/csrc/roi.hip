@@ -148,22 +148,23 @@ constexpr int GS_TS = 8, GS_MAXL = 256, GS_KB = 4, GS_MAXP = 14;
 __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const RoiSetsDev sets, bf16_t* __restrict__ gfeat, int level,
                                                                    int nlevels, int H, int W, int C, float scale) {
   constexpr int TS = GS_TS;
-  constexpr int CPI = 4;   // 16-byte chunks (= 32 channels) per work item
-  constexpr int NQ = 2;    // items per thread (C <= 256: 64 pixels x 8 channel groups = 512 items)
+  constexpr int NQ = 2;    // items per thread: an item = (tile row, 4-pixel quad of that row, 8-channel chunk)
   __shared__ RoiGeom list[GS_MAXL];
   __shared__ int nlist;
-  __shared__ float tabY[GS_KB][TS][GS_MAXP];  // sum over a bin row's samples of w_y, per pixel row of the tile
-  __shared__ float tabX[GS_KB][TS][GS_MAXP];
+  __shared__ float tabY[GS_KB][TS][GS_MAXP];                                  // [roi][tile row][bin row]
+  __shared__ __attribute__((aligned(16))) float tabX[GS_KB][GS_MAXP][TS];     // [roi][bin column][tile column]
   const int b = blockIdx.z;
   const int ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
   const int tid = threadIdx.x;
-  const int gpp = (C >> 3) / CPI;     // channel groups per pixel
-  const int items = TS * TS * gpp;
-  float acc[NQ][CPI * 8];
+  const int cpr = C >> 3;             // 16-byte chunks per pixel
+  const int items = TS * 2 * cpr;     // C <= 256: at most 512
+  float acc[NQ][4][8];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
-    for (int e = 0; e < CPI * 8; ++e) acc[q][e] = 0.f;
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[q][j][e] = 0.f;
 
   for (int si = 0; si < sets.n; ++si) {
     const RoiSetDev st = sets.s[si];
@@ -212,38 +213,40 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const RoiSets
           } else {
             const float inv_g = g.bw / (float)g.gw;
             for (int ix = 0; ix < g.gw; ++ix) sum += axis_weight(g.sw + bin * g.bw + (ix + 0.5f) * inv_g, W, tx0 + rc);
-            tabX[kk][rc][bin] = sum;
+            tabX[kk][bin][rc] = sum;
           }
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const int item = q * 256 + tid;
-          const int grp = item % gpp;
-          const int pix = item / gpp;
-          const int row = pix / TS, col = pix % TS;
-          const int py = ty0 + row, px = tx0 + col;
+          const int ch = item % cpr;
+          const int rq = item / cpr;
+          const int row = rq >> 1, quad = rq & 1;
+          const int py = ty0 + row, px = tx0 + quad * 4;
           if (item >= items || py >= H || px >= W) continue;
           for (int kk = 0; kk < nb; ++kk) {
             const RoiGeom& g = list[k0 + kk];
-            if (py < g.py0 || py > g.py1 || px < g.px0 || px > g.px1) continue;
+            if (py < g.py0 || py > g.py1 || px + 3 < g.px0 || px > g.px1) continue;
             const float ic = g.inv_cnt;
-            const bf16_t* rbase = st.dout + (size_t)g.r * P * P * C + grp * (CPI * 8);
+            const bf16_t* rbase = st.dout + (size_t)g.r * P * P * C + ch * 8;
             for (int ph = 0; ph < P; ++ph) {
               const float ay = tabY[kk][row][ph];
               if (ay == 0.f) continue;
               const float ayc = ay * ic;
               for (int pw = 0; pw < P; ++pw) {
-                const float ax = tabX[kk][col][pw];
-                if (ax == 0.f) continue;
-                const float wgt = ayc * ax;
-                const bf16_t* src = rbase + (size_t)(ph * P + pw) * C;
+                const float4 ax = *reinterpret_cast<const float4*>(&tabX[kk][pw][quad * 4]);
+                if (ax.x == 0.f && ax.y == 0.f && ax.z == 0.f && ax.w == 0.f) continue;
+                bf16_t dv[8];
+                *reinterpret_cast<uint4*>(dv) = *reinterpret_cast<const uint4*>(rbase + (size_t)(ph * P + pw) * C);
+                const float w0 = ayc * ax.x, w1 = ayc * ax.y, w2 = ayc * ax.z, w3 = ayc * ax.w;
 #pragma unroll
-                for (int c4 = 0; c4 < CPI; ++c4) {
-                  bf16_t dv[8];
-                  *reinterpret_cast<uint4*>(dv) = *reinterpret_cast<const uint4*>(src + c4 * 8);
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) acc[q][c4 * 8 + e] += wgt * bf2f(dv[e]);
+                for (int e = 0; e < 8; ++e) {
+                  const float d = bf2f(dv[e]);
+                  acc[q][0][e] += w0 * d;
+                  acc[q][1][e] += w1 * d;
+                  acc[q][2][e] += w2 * d;
+                  acc[q][3][e] += w3 * d;
                 }
               }
             }
@@ -256,17 +259,19 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const RoiSets
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int item = q * 256 + tid;
-    const int grp = item % gpp;
-    const int pix = item / gpp;
-    const int py = ty0 + pix / TS, px = tx0 + pix % TS;
-    if (item >= items || py >= H || px >= W) continue;
-    bf16_t* dst = gfeat + (((size_t)b * H + py) * W + px) * C + grp * (CPI * 8);
+    const int ch = item % cpr;
+    const int rq = item / cpr;
+    const int row = rq >> 1, quad = rq & 1;
+    const int py = ty0 + row;
+    if (item >= items || py >= H) continue;
 #pragma unroll
-    for (int c4 = 0; c4 < CPI; ++c4) {
+    for (int j = 0; j < 4; ++j) {
+      const int px = tx0 + quad * 4 + j;
+      if (px >= W) continue;
       bf16_t o[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[q][c4 * 8 + e]);
-      *reinterpret_cast<uint4*>(dst + c4 * 8) = *reinterpret_cast<const uint4*>(o);
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[q][j][e]);
+      *reinterpret_cast<uint4*>(gfeat + (((size_t)b * H + py) * W + px) * C + ch * 8) = *reinterpret_cast<const uint4*>(o);
     }
   }
 }
@@ -697,7 +702,7 @@ extern "C" int u2_roi_align_bwd_gather_multi(void* const* gfeats, const int* Hs,
                                              int nlevels, int nsets, const void* const* rois, const void* const* order,
                                              const void* const* seg, const void* const* dout, const int* P,
                                              const float* gscale, int B, int C, void* stream) {
-  if (nlevels < 1 || nlevels > 4 || (C & 31) || C > 256 || nsets < 1 || nsets > 4) return -1;
+  if (nlevels < 1 || nlevels > 4 || (C & 7) || C > 256 || nsets < 1 || nsets > 4) return -1;
   if (B <= 0) return 0;
   RoiSetsDev sets;
   sets.n = nsets;
