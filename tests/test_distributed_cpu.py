@@ -34,6 +34,18 @@ def _worker(rank, world, port, out):
     ok = torch.allclose(opt.flat_grad, sum(gathered)) and scale == 1.0 / world
     # parameters are views into the arena and grads accumulate in place into it
     ok = ok and model[0].weight.grad.data_ptr() == opt.flat_grad.data_ptr()
+    # overlapped exchange: the tail of the arena (the "head" parameters) starts its all-reduce early, the rest follows
+    opt.zero_grad()
+    model(x).sum().backward()
+    local = opt.flat_grad.clone()
+    tail = opt.offset_of(model[1].weight)
+    ok = ok and tail == model[0].weight.numel() + model[0].bias.numel()
+    opt.begin_all_reduce_tail(tail)
+    opt.begin_all_reduce_tail(tail)  # idempotent within a step
+    scale = opt.all_reduce_grads()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    ok = ok and torch.allclose(opt.flat_grad, sum(gathered)) and scale == 1.0 / world and opt._tail_from is None
     from u2seg_amd.data import make_synthetic_batch
 
     a = make_synthetic_batch(2, start_index=rank * 2, height=32, width=48)

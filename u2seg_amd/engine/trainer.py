@@ -20,6 +20,15 @@ class SimpleTrainer:
         self.model, self.optimizer, self.scheduler = model, optimizer, scheduler
         self.iter = 0
         self.last_losses = None
+        # gradient exchange overlapped with backward: the model calls this when the gradients of the FPN outputs exist,
+        # i.e. when every head parameter's gradient is final (the heads come after the backbone in the arena)
+        heads = [m for name, m in model.named_children() if name != "backbone"]
+        first = [p for m in heads for p in m.parameters() if p.requires_grad]
+        if first and hasattr(optimizer, "begin_all_reduce_tail") and hasattr(model, "on_heads_backward_done"):
+            tail = min(optimizer.offset_of(p) for p in first)
+            back = [optimizer.offset_of(p) for p in model.backbone.parameters() if p.requires_grad]
+            if not back or max(back) < tail:  # the heads really form the tail of the arena
+                model.on_heads_backward_done = lambda: optimizer.begin_all_reduce_tail(tail)
 
     def run_step(self, batched_inputs):
         assert self.model.training, "[SimpleTrainer] model was changed to eval mode!"

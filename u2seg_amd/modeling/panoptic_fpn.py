@@ -23,6 +23,7 @@ class GeneralizedRCNN(nn.Module):
         super().__init__()
         self.backbone, self.proposal_generator, self.roi_heads = backbone, proposal_generator, roi_heads
         self.input_format, self.vis_period = input_format, vis_period
+        self.on_heads_backward_done = None  # optional callback (engine/trainer.py): all head gradients are final
         self.register_buffer("pixel_mean", torch.tensor(pixel_mean).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(pixel_std).view(-1, 1, 1), False)
         assert self.pixel_mean.shape == self.pixel_std.shape
@@ -44,6 +45,22 @@ class GeneralizedRCNN(nn.Module):
     def device(self):
         return self.pixel_mean.device
 
+    def _watch_feature_grads(self, features):
+        """Fire on_heads_backward_done once the gradient of every FPN output has been computed in backward."""
+        cb = self.on_heads_backward_done
+        if cb is None or not torch.is_grad_enabled():
+            return
+        watched = [f for f in features.values() if f.requires_grad]
+        state = {"left": len(watched)}
+
+        def hook(_grad):
+            state["left"] -= 1
+            if state["left"] == 0:
+                cb()
+
+        for f in watched:
+            f.register_hook(hook)
+
     def _backbone_features(self, batched_inputs):
         """rcnn.py:223-234 + backbone: the stem kernel normalises, pads and convolves in one pass."""
         images = [x["image"].to(self.device).contiguous() for x in batched_inputs]
@@ -57,6 +74,7 @@ class GeneralizedRCNN(nn.Module):
         if not self.training:
             return self.inference(batched_inputs)
         features, image_sizes, _ = self._backbone_features(batched_inputs)
+        self._watch_feature_grads(features)
         gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         proposals, proposal_losses = self.proposal_generator(image_sizes, features, gt_instances)
         _, detector_losses = self.roi_heads(None, features, proposals, gt_instances)
@@ -123,6 +141,7 @@ class PanopticFPN(GeneralizedRCNN):
         if not self.training:
             return self.inference(batched_inputs)
         features, image_sizes, padded_hw = self._backbone_features(batched_inputs)
+        self._watch_feature_grads(features)
         assert "sem_seg" in batched_inputs[0]
         gt_sem_seg = self._sem_seg_targets(batched_inputs, padded_hw)
         _, sem_seg_losses = self.sem_seg_head(features, gt_sem_seg)

@@ -59,6 +59,7 @@ class FlatSGD:
         self.partial = torch.zeros(len(chunk_tensor), dtype=torch.float32, device=dev)
         self.lr, self.momentum, self.clip_value = lr, momentum, clip_value
         self.bucket_elems = bucket_bytes // 4
+        self._pending, self._tail_from = [], None
         # bf16 kernel layouts cached on the parameters (layers/functional.py:_weight_layout): [stamp] is shared with every
         # parameter; step() bumps it and rewrites all registered layouts with one launch.
         self._stamp = [0]
@@ -70,6 +71,10 @@ class FlatSGD:
             p._u2_layout_register = self._register_layout
             p.__dict__.pop("_u2_layouts", None)
 
+    def offset_of(self, param):
+        """Element offset of a parameter inside the flat arena."""
+        return (param.data_ptr() - self.flat_param.data_ptr()) // 4
+
     def zero_grad(self):
         self.flat_grad.zero_()
         for p in self.params:  # autograd may have replaced .grad with a fresh tensor
@@ -79,15 +84,30 @@ class FlatSGD:
     def _grad_view_ptr(self, p):
         return p.grad.data_ptr() if p.grad is not None else 0
 
+    def _distributed(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _launch_all_reduce(self, lo, hi):
+        for s in range(lo, hi, self.bucket_elems):
+            self._pending.append(dist.all_reduce(self.flat_grad[s : min(s + self.bucket_elems, hi)], async_op=True))
+
+    def begin_all_reduce_tail(self, first_elem):
+        """Start summing the gradients of the arena's tail [first_elem, total) while backward is still running: the tail
+        holds the head parameters (RPN, ROI heads, semantic head), which are final once the gradients of the FPN outputs
+        exist; RCCL works on them over xGMI while the backbone backward (~40 % of the step) keeps the CUs busy."""
+        if not self._distributed() or self._tail_from is not None:
+            return
+        self._tail_from = int(first_elem)
+        self._launch_all_reduce(self._tail_from, self.total)
+
     def all_reduce_grads(self):
         """Sum gradients over ranks in a few large buckets (mean is folded into the step's grad_scale)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not self._distributed():
             return 1.0
-        handles = []
-        for s in range(0, self.total, self.bucket_elems):
-            handles.append(dist.all_reduce(self.flat_grad[s : s + self.bucket_elems], async_op=True))
-        for h in handles:
+        self._launch_all_reduce(0, self.total if self._tail_from is None else self._tail_from)
+        for h in self._pending:
             h.wait()
+        self._pending, self._tail_from = [], None
         return 1.0 / dist.get_world_size()
 
     def step(self, grad_scale=1.0):
