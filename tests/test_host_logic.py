@@ -5,6 +5,7 @@ import json
 import os
 import zlib
 
+import numpy as np
 import pytest
 import torch
 
@@ -228,3 +229,43 @@ def test_batchnorm_counts_batches_lazily():
     bn.load_state_dict(bn.state_dict())
     bn.count_batch()
     assert int(bn.state_dict()["num_batches_tracked"]) == 4
+
+
+def test_detection_checkpointer_formats(tmp_path):
+    """checkpoint/detection_checkpoint.py:70-143: Detectron2-zoo .pkl (ndarray dict, suffix matching heuristics, shape
+    mismatches skipped and reported) and torch .pth round trips into the reference's state-dict names."""
+    import pickle
+
+    from u2seg_amd.checkpoint import DetectionCheckpointer
+    from u2seg_amd.modeling import build_model
+
+    torch.manual_seed(0)
+    model = build_model(_cfg())
+    ref = {k: v.clone() for k, v in model.state_dict().items()}
+    # 1. a backbone-only zoo file whose names lack the 'backbone.bottom_up.' prefix, one tensor with a wrong shape
+    prefix = "backbone.bottom_up."
+    blob = {k[len(prefix):]: (v.numpy() + 1.0) for k, v in ref.items() if k.startswith(prefix) and v.dtype == torch.float32}
+    bad = "res2.0.conv1.weight"
+    blob[bad] = np.zeros((3, 3), dtype=np.float32)
+    p = tmp_path / "dino_like.pkl"
+    with open(p, "wb") as f:
+        pickle.dump({"model": blob, "__author__": "test", "matching_heuristics": True}, f)
+    ck = DetectionCheckpointer(model)
+    rest = ck.load(str(p))
+    assert "model" not in rest and rest.get("__author__") == "test"
+    inc = ck.last_incompatible
+    assert [x[0] for x in inc.incorrect_shapes] == [prefix + bad]
+    assert any(k.startswith("roi_heads.") for k in inc.missing_keys) and not inc.unexpected_keys
+    sd = model.state_dict()
+    assert torch.equal(sd[prefix + "res3.1.conv2.weight"], ref[prefix + "res3.1.conv2.weight"] + 1.0)
+    assert torch.equal(sd[prefix + bad], ref[prefix + bad])  # skipped
+    assert torch.equal(sd["roi_heads.mask_head.predictor.weight"], ref["roi_heads.mask_head.predictor.weight"])
+    # 2. full .pth round trip (with an extra item, as the reference's periodic checkpointer writes)
+    ck2 = DetectionCheckpointer(model, str(tmp_path))
+    path = ck2.save("model_0000009", iteration=9)
+    with torch.no_grad():
+        for v in model.parameters():
+            v.zero_()
+    rest = DetectionCheckpointer(model, str(tmp_path)).resume_or_load("", resume=True)
+    assert rest["iteration"] == 9 and os.path.basename(path) == "model_0000009.pth"
+    assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), sd.values()))

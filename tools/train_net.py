@@ -14,6 +14,7 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+from u2seg_amd.checkpoint import DetectionCheckpointer  # noqa: E402
 from u2seg_amd.config import get_cfg  # noqa: E402
 from u2seg_amd.data import make_synthetic_batch  # noqa: E402
 from u2seg_amd.engine import SimpleTrainer, default_argument_parser, launch_info  # noqa: E402
@@ -44,6 +45,9 @@ def main(args):
     model = build_model(c)
     per_gpu = max(1, cfg.SOLVER.IMS_PER_BATCH // world)
     if args.eval_only:
+        # tools/train_net.py:135-141 of the reference: weights from MODEL.WEIGHTS (or the last checkpoint with --resume)
+        if cfg.MODEL.WEIGHTS and os.path.isfile(cfg.MODEL.WEIGHTS):
+            DetectionCheckpointer(model, cfg.OUTPUT_DIR).resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume)
         model.eval()
         with torch.no_grad():
             out = model(make_synthetic_batch(per_gpu, start_index=rank * per_gpu, device=c.MODEL.DEVICE))
@@ -54,13 +58,22 @@ def main(args):
     opt = build_optimizer(cfg, model)
     sched = build_lr_scheduler(cfg, opt)
     trainer = SimpleTrainer(model, opt, sched)
+    checkpointer = DetectionCheckpointer(model, cfg.OUTPUT_DIR, save_to_disk=rank == 0, optimizer=opt)
+    start_iter = 0
+    if (cfg.MODEL.WEIGHTS and os.path.isfile(cfg.MODEL.WEIGHTS)) or args.resume:
+        rest = checkpointer.resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume)
+        start_iter = int(rest.get("iteration", -1)) + 1 if args.resume else 0
+    elif cfg.MODEL.WEIGHTS and rank == 0:
+        print("MODEL.WEIGHTS %s not found: random initialisation" % cfg.MODEL.WEIGHTS)
     t0 = time.time()
-    for it in range(cfg.SOLVER.MAX_ITER):
+    for it in range(start_iter, cfg.SOLVER.MAX_ITER):
         batch = make_synthetic_batch(per_gpu, start_index=(it * world + rank) * per_gpu, device=c.MODEL.DEVICE)
         trainer.run_step(batch)
         if rank == 0 and (it % 20 == 0 or it == cfg.SOLVER.MAX_ITER - 1):
             total = trainer.check_finite()
-            print("iter %d  total_loss %.4f  lr %.6f  %.2f s/iter" % (it, total, opt.lr, (time.time() - t0) / (it + 1)))
+            print("iter %d  total_loss %.4f  lr %.6f  %.2f s/iter" % (it, total, opt.lr, (time.time() - t0) / (it - start_iter + 1)))
+        if (it + 1) % cfg.SOLVER.CHECKPOINT_PERIOD == 0 or it == cfg.SOLVER.MAX_ITER - 1:
+            checkpointer.save("model_%07d" % it if it < cfg.SOLVER.MAX_ITER - 1 else "model_final", iteration=it)
     if world > 1:
         dist.destroy_process_group()
 
