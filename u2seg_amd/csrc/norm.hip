@@ -11,6 +11,26 @@
 
 namespace {
 
+// streaming accesses: every activation is touched once per pass, so keep it out of the way of L2 / MALL residents
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+// (nt only for tensors far larger than the 256 MB MALL: smaller ones are re-read by the next pass / the next conv from cache)
+__device__ __forceinline__ uint4 ld_stream(const bf16_t* p, bool nt) {
+  if (nt) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  }
+  return *reinterpret_cast<const uint4*>(p);
+}
+__device__ __forceinline__ void st_stream(bf16_t* p, uint4 v, bool nt) {
+  if (nt) {
+    u32x4_t t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t*>(p));
+  } else {
+    *reinterpret_cast<uint4*>(p) = v;
+  }
+}
+constexpr size_t NT_BYTES = 160u << 20;
+
 // ---------------------------------------------------------------------------------------------
 // Column reductions over an [M][C] bf16 matrix, optionally split into `slots` equal row ranges
 // (slot = image for GroupNorm).  out[slot][q][C], q = quantity index.
@@ -38,6 +58,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
   const int r_end = min(rows_per_slot, r_begin + rows_per_block);
   const size_t row0 = (size_t)slot * rows_per_slot;
   const int tid = threadIdx.x;
+  const bool nt = (size_t)rows_per_slot * gridDim.y * ld * 2 > NT_BYTES;
 
   for (int cbase = 0; cbase < cpr; cbase += 256) {
     const int ncol = min(256, cpr - cbase);
@@ -65,11 +86,11 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
           const int r = r0 + u * rows_par;
           if (r < r_end) {
             const size_t off = (row0 + r) * ld + c;
-            xq[u] = *reinterpret_cast<const uint4*>(x + off);
+            xq[u] = ld_stream(x + off, nt);
             if (MODE == 1) {
-              dq[u] = *reinterpret_cast<const uint4*>(dout + off);
-              if (MASK == 1) mq[u] = *reinterpret_cast<const uint4*>(mask + off);
-              if (DZ && dout2) eq[u] = *reinterpret_cast<const uint4*>(dout2 + off);
+              dq[u] = ld_stream(dout + off, nt);
+              if (MASK == 1) mq[u] = ld_stream(mask + off, nt);
+              if (DZ && dout2) eq[u] = ld_stream(dout2 + off, nt);
             }
           }
         }
@@ -225,6 +246,7 @@ __global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __re
   for (int e = 0; e < 8; ++e) { sc[e] = scale[(size_t)slot * C + cc * 8 + e]; sh[e] = shift[(size_t)slot * C + cc * 8 + e]; }
   const size_t base = (size_t)slot * rows_per_slot;
   const int stride = gridDim.x * rows_par;
+  const bool nt = (size_t)rows_per_slot * gridDim.y * ld * 2 > NT_BYTES;
   for (int r0 = blockIdx.x * rows_par + rl; r0 < rows_per_slot; r0 += EW_UNROLL * stride) {
     uint4 xq[EW_UNROLL], rq[EW_UNROLL];
 #pragma unroll
@@ -232,8 +254,8 @@ __global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __re
       const int r = r0 + u * stride;
       if (r < rows_per_slot) {
         const size_t off = (base + r) * ld + cc * 8;
-        xq[u] = *reinterpret_cast<const uint4*>(x + off);
-        if (RESID) rq[u] = *reinterpret_cast<const uint4*>(resid + off);
+        xq[u] = ld_stream(x + off, nt);
+        if (RESID) rq[u] = ld_stream(resid + off, nt);
       }
     }
 #pragma unroll
@@ -250,7 +272,7 @@ __global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __re
           if (RELU) f = fmaxf(f, 0.f);
           ov[e] = f2bf(f);
         }
-        *reinterpret_cast<uint4*>(out + (base + r) * ld + cc * 8) = *reinterpret_cast<const uint4*>(ov);
+        st_stream(out + (base + r) * ld + cc * 8, *reinterpret_cast<const uint4*>(ov), nt);
       }
     }
   }
@@ -278,6 +300,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_fast_kernel(const bf16_t* 
   }
   const size_t base = (size_t)slot * rows_per_slot;
   const int stride = gridDim.x * rows_par;
+  const bool nt = (size_t)rows_per_slot * gridDim.y * ld * 2 > NT_BYTES;
   for (int r0 = blockIdx.x * rows_par + rl; r0 < rows_per_slot; r0 += EW_UNROLL * stride) {
     uint4 dq[EW_UNROLL], xq[EW_UNROLL], mq[EW_UNROLL];
 #pragma unroll
@@ -285,9 +308,9 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_fast_kernel(const bf16_t* 
       const int r = r0 + u * stride;
       if (r < rows_per_slot) {
         const size_t off = (base + r) * ld + cc * 8;
-        dq[u] = *reinterpret_cast<const uint4*>(dout + off);
-        xq[u] = *reinterpret_cast<const uint4*>(x + off);
-        if (MASK == 1) mq[u] = *reinterpret_cast<const uint4*>(mask + off);
+        dq[u] = ld_stream(dout + off, nt);
+        xq[u] = ld_stream(x + off, nt);
+        if (MASK == 1) mq[u] = ld_stream(mask + off, nt);
       }
     }
 #pragma unroll
@@ -308,8 +331,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_fast_kernel(const bf16_t* 
           zv[e] = f2bf(dz);
         }
         const size_t off = (base + r) * ld + cc * 8;
-        *reinterpret_cast<uint4*>(dx + off) = *reinterpret_cast<const uint4*>(ov);
-        if (DRES) *reinterpret_cast<uint4*>(dres + off) = *reinterpret_cast<const uint4*>(zv);
+        st_stream(dx + off, *reinterpret_cast<const uint4*>(ov), nt);
+        if (DRES) st_stream(dres + off, *reinterpret_cast<const uint4*>(zv), nt);
       }
     }
   }
