@@ -277,6 +277,7 @@ __global__ __launch_bounds__((TM / 64) * (TN / 64) * 64, 2) void conv_igemm_kern
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
   const bool vec_ok = ((a.out_ld & 7) == 0) && (n0 + cchunk * 8 + 8 <= a.N);
+  const bool nt_out = !a.accumulate && (size_t)a.M * a.out_ld * 2 > ((size_t)160 << 20);
 #pragma unroll
   for (int it = 0; it < TM / RPI; ++it) {
     const int row = it * RPI + rbase;
@@ -314,7 +315,14 @@ __global__ __launch_bounds__((TM / 64) * (TN / 64) * 64, 2) void conv_igemm_kern
       }
     }
     if (vec_ok) {
-      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(e8);
+      if (nt_out) {  // outputs far beyond the MALL size: do not let them evict what the next layer can still reuse
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+        const uint4 v = *reinterpret_cast<const uint4*>(e8);
+        u32x4_t t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t*>(dst));
+      } else {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(e8);
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e)
@@ -623,6 +631,7 @@ __global__ __launch_bounds__(C256_THREADS, 2) void conv_igemm256_kernel(const Co
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
   const bool vec_ok = ((a.out_ld & 7) == 0) && (n0 + cchunk * 8 + 8 <= a.N);
+  const bool nt_out = !a.accumulate && (size_t)a.M * a.out_ld * 2 > ((size_t)160 << 20);
   for (int it = 0; it < 16; ++it) {
     const int row = it * 16 + rbase;
     const int m = m0 + row;
@@ -649,7 +658,14 @@ __global__ __launch_bounds__(C256_THREADS, 2) void conv_igemm256_kernel(const Co
       }
     }
     if (vec_ok) {
-      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(e8);
+      if (nt_out) {  // outputs far beyond the MALL size: do not let them evict what the next layer can still reuse
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+        const uint4 v = *reinterpret_cast<const uint4*>(e8);
+        u32x4_t t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t*>(dst));
+      } else {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(e8);
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e)
