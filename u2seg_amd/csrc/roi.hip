@@ -134,6 +134,129 @@ __device__ __forceinline__ float axis_weight(float pos, int n, int p) {
   return w;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ROIAlign forward in the same separable form: out[ph][pw] = (1/count) * sum_y sum_x Wy[ph][y] * Wx[pw][x] * feat[y][x]
+// with Wy[ph][y] = sum over the bin row's samples of their bilinear weight on pixel row y.  One work-group per ROI:
+// the per-axis tables (<= 16 pixels per bin) are built once in LDS, then every (bin, 8-channel chunk) item reads each
+// feature pixel its bin touches exactly once (~25-36 reads) instead of 4 per sample (64 at 4 x 4 samples per bin).
+// ---------------------------------------------------------------------------------------------
+constexpr int FS_MAXP = 14, FS_MAXR = 16;
+
+__global__ __launch_bounds__(256) void roi_align_fwd_sep_kernel(const RoiLevels lv, const float* __restrict__ rois,
+                                                                const int* __restrict__ level, bf16_t* __restrict__ out, int C,
+                                                                int P) {
+  __shared__ float wtab[2][FS_MAXP][FS_MAXR];
+  __shared__ int lo[2][FS_MAXP], cnt[2][FS_MAXP];
+  __shared__ int s_fallback;
+  const int r = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int l = level[r];
+  const int H = lv.H[l], W = lv.W[l];
+  const float sc = lv.scale[l];
+  const float* roi = rois + (size_t)r * 5;
+  const int b = (int)roi[0];
+  const float sw = roi[1] * sc - 0.5f, sh = roi[2] * sc - 0.5f;
+  const float ew = roi[3] * sc - 0.5f, eh = roi[4] * sc - 0.5f;
+  const float rw = ew - sw, rh = eh - sh;
+  const float bh = rh / (float)P, bw = rw / (float)P;
+  const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
+  const float inv_cnt = 1.f / (float)max(gh * gw, 1);
+  if (tid == 0) s_fallback = 0;
+  __syncthreads();
+  if (tid < 2 * P) {
+    const int axis = tid / P, bin = tid - axis * P;
+    const int n = axis ? W : H, g = axis ? gw : gh;
+    const float s0 = axis ? sw : sh, bs = axis ? bw : bh;
+    int a = 0, c = 0;
+    if (g > 0) {
+      const float first = s0 + bin * bs + 0.5f * bs / (float)g;
+      const float last = s0 + bin * bs + ((float)g - 0.5f) * bs / (float)g;
+      a = min(max((int)floorf(first), 0), n - 1);
+      const int z = min(max((int)floorf(last) + 1, 0), n - 1);
+      c = z - a + 1;
+      if (c > FS_MAXR) atomicOr(&s_fallback, 1);
+    }
+    lo[axis][bin] = a;
+    cnt[axis][bin] = c;
+  }
+  __syncthreads();
+  const int cpr = C >> 3;
+  const size_t plane = (size_t)b * H * W;
+  const bf16_t* f = lv.feat[l];
+  if (s_fallback) {
+    // a bin wider than the table (never with FPN level assignment, kept for generality): sample by sample
+    for (int it = tid; it < P * P * cpr; it += 256) {
+      const int cc = it % cpr;
+      const int pw = (it / cpr) % P, ph = it / (cpr * P);
+      float acc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+      for (int iy = 0; iy < gh; ++iy) {
+        const float y = sh + ph * bh + (iy + 0.5f) * bh / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+          const float x = sw + pw * bw + (ix + 0.5f) * bw / (float)gw;
+          int yl, xl, yh, xh;
+          float w1, w2, w3, w4;
+          if (!bil_prep(y, x, H, W, yl, xl, yh, xh, w1, w2, w3, w4)) continue;
+          const int ys[4] = {yl, yl, yh, yh}, xs[4] = {xl, xh, xl, xh};
+          const float ws[4] = {w1, w2, w3, w4};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            bf16_t v[8];
+            *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(f + (plane + (size_t)ys[t] * W + xs[t]) * C + cc * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += ws[t] * bf2f(v[e]);
+          }
+        }
+      }
+      bf16_t o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e] * inv_cnt);
+      *reinterpret_cast<uint4*>(out + (((size_t)r * P + ph) * P + pw) * C + cc * 8) = *reinterpret_cast<const uint4*>(o);
+    }
+    return;
+  }
+  for (int t = tid; t < 2 * P * FS_MAXR; t += 256) {
+    const int k = t % FS_MAXR;
+    const int bin = (t / FS_MAXR) % P, axis = t / (FS_MAXR * P);
+    float sum = 0.f;
+    if (k < cnt[axis][bin]) {
+      const int n = axis ? W : H, g = axis ? gw : gh;
+      const float s0 = axis ? sw : sh, bs = axis ? bw : bh;
+      const float step = bs / (float)g;
+      const int pix = lo[axis][bin] + k;
+      for (int i = 0; i < g; ++i) sum += axis_weight(s0 + bin * bs + (i + 0.5f) * step, n, pix);
+    }
+    wtab[axis][bin][k] = sum;
+  }
+  __syncthreads();
+  for (int it = tid; it < P * P * cpr; it += 256) {
+    const int cc = it % cpr;
+    const int pw = (it / cpr) % P, ph = it / (cpr * P);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const int ny = cnt[0][ph], nx = cnt[1][pw], y0 = lo[0][ph], x0 = lo[1][pw];
+    for (int ky = 0; ky < ny; ++ky) {
+      const float a = wtab[0][ph][ky];
+      if (a == 0.f) continue;
+      const bf16_t* rowp = f + (plane + (size_t)(y0 + ky) * W + x0) * C + cc * 8;
+      for (int kx = 0; kx < nx; ++kx) {
+        const float wgt = a * wtab[1][pw][kx];
+        if (wgt == 0.f) continue;
+        bf16_t v[8];
+        *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(rowp + (size_t)kx * C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += wgt * bf2f(v[e]);
+      }
+    }
+    bf16_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e] * inv_cnt);
+    *reinterpret_cast<uint4*>(out + (((size_t)r * P + ph) * P + pw) * C + cc * 8) = *reinterpret_cast<const uint4*>(o);
+  }
+}
+
 // Separable form.  The samples of a bin form a product grid and a bilinear weight is w_y * w_x, so
 //   sum_{iy, ix} w_y(iy) w_x(ix) = (sum_iy w_y(iy)) * (sum_ix w_x(ix)):
 // per (ROI, pixel row, bin row) and (ROI, pixel column, bin column) the 1-D sums are tabulated in LDS by a few threads,
@@ -590,6 +713,12 @@ extern "C" int u2_roi_align_fwd(const void* const* feats, const int* Hs, const i
   for (int l = 0; l < 4; ++l) {
     const int s = l < nlevels ? l : 0;
     lv.feat[l] = (const bf16_t*)feats[s]; lv.gfeat[l] = nullptr; lv.H[l] = Hs[s]; lv.W[l] = Ws[s]; lv.scale[l] = scales[s];
+  }
+  if (PH == PW && PH <= FS_MAXP) {  // separable per-ROI kernel
+    hipLaunchKernelGGL(roi_align_fwd_sep_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, lv, rois, level, (bf16_t*)out, C,
+                       PH);
+    U2_CHECK_LAUNCH();
+    return 0;
   }
   const size_t total = (size_t)R * PH * PW * (C >> 3);
   hipLaunchKernelGGL(roi_align_kernel<false>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, lv, rois, level,
