@@ -776,6 +776,44 @@ def _two_rank_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _kmeans_shard_worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from u2seg_amd.cluster import kmeans as KM
+
+    torch.cuda.set_device(0)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "kmeans_golden.npz"))
+    x, init = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["init"]).to(DEV)
+    n = x.shape[0]
+    lo, hi = (0, n // 3) if rank == 0 else (n // 3, n)  # uneven shards
+    cl, c = KM.kmeans_sharded(x[lo:hi], x[init].clone(), int(g["niter"]))
+    out[rank] = (cl.cpu().numpy(), c.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_kmeans_row_sharded_two_ranks():
+    """k-means with the rows of x sharded over two ranks (one all-reduce of the K*D + K partial sums per iteration):
+    concatenated labels and the centroids of both ranks must equal the reference-generated single-process golden."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_kmeans_shard_worker, args=(2, port, out), nprocs=2, join=True)
+        (l0, c0), (l1, c1) = out[0], out[1]
+    g = np.load(os.path.join(ROOT, "tests", "golden", "kmeans_golden.npz"))
+    assert np.array_equal(np.concatenate([l0, l1]), g["labels"])
+    np.testing.assert_allclose(c0, g["centroids"], rtol=1e-5, atol=1e-5)
+    assert np.array_equal(c0, c1)  # identical on both ranks
+
+
 def test_two_rank_step_on_one_gpu():
     """The multi-process data-parallel path (SyncBN statistic all-reduce inside forward/backward, bucketed gradient
     all-reduce, grad_scale = 1/world in the optimizer kernel) with two ranks sharing cuda:0 over gloo (RCCL refuses two

@@ -4,6 +4,7 @@
 ``x[randperm(N)[:K]]`` drawn from the CPU generator after ``torch.manual_seed(seed)``, a fixed number of iterations,
 no convergence test, empty clusters turn into NaN rows (the reference notes this at usl-imagenet.py:135)."""
 import torch
+import torch.distributed as dist
 
 from .. import _hip
 
@@ -35,6 +36,33 @@ def kmeans(x, init_idx, niter):
     for _ in range(niter):
         cl = assign(x, c)
         c, _ = update(x, cl, c.shape[0])
+    return cl, c
+
+
+def update_sharded(x_local, labels_local, k, group=None):
+    """The M step when the rows of x are sharded over the ranks of `group`: local partial sums and
+    counts, one all-reduce of (K*D + K) floats (0.92 MB at K = 300, D = 768), then the division - every rank ends up
+    with the same centroids, labels stay sharded."""
+    n, d = x_local.shape
+    buf = torch.zeros(k * d + k, dtype=torch.float32, device=x_local.device)
+    csum, counts = buf[: k * d].view(k, d), buf[k * d :]
+    if n:
+        _hip.call("u2_kmeans_update", x_local.contiguous(), labels_local, csum, counts, n, d, k)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(buf, group=group)
+    c = torch.empty((k, d), dtype=torch.float32, device=x_local.device)
+    _hip.call("u2_kmeans_finalize", csum, counts, c, d, k)
+    return c, counts
+
+
+def kmeans_sharded(x_local, init_centroids, niter, group=None):
+    """Lloyd iterations over a row shard; `init_centroids` [K, D] must be identical on every rank (e.g. rank 0 draws
+    x[randperm(N)[:K]] and broadcasts it).  Returns (labels of the local rows, centroids)."""
+    c = init_centroids.clone()
+    cl = None
+    for _ in range(niter):
+        cl = assign(x_local, c)
+        c, _ = update_sharded(x_local, cl, c.shape[0], group)
     return cl, c
 
 
