@@ -692,6 +692,19 @@ def test_inference_tails_vs_oracle_and_reference(F, G):
     res, kept = fast_rcnn_inference_single_image(boxes.to(DEV), scores.to(DEV), (180, 240), 0.05, 0.5, 100)
     assert torch.equal(res.pred_classes.cpu(), rc) and torch.equal(res.scores.cpu(), rs) and torch.equal(res.pred_boxes.tensor.cpu(), rb)
 
+    # 2b. the batched routine on a ragged batch (different box counts, one image without boxes) == one image at a time
+    from u2seg_amd.modeling.inference import fast_rcnn_inference
+
+    bl = [boxes[:400].to(DEV), boxes[100:350].to(DEV), boxes[:0].to(DEV)]
+    sl = [scores[:400].to(DEV), scores[100:350].to(DEV), scores[:0].to(DEV)]
+    shapes = [(180, 240), (150, 200), (180, 240)]
+    batched, _ = fast_rcnn_inference(bl, sl, shapes, 0.05, 0.5, 100)
+    for i in range(3):
+        one, _ = fast_rcnn_inference_single_image(bl[i], sl[i], shapes[i], 0.05, 0.5, 100)
+        assert torch.equal(batched[i].pred_boxes.tensor, one.pred_boxes.tensor) and torch.equal(batched[i].scores, one.scores)
+        assert torch.equal(batched[i].pred_classes, one.pred_classes)
+    assert len(batched[2]) == 0 and len(batched[0]) == 100
+
     # 3. mask paste
     probs = torch.rand((7, 28, 28), generator=g)
     pb = torch.tensor([[3.0, 4, 60, 50], [10.5, 2.25, 30.75, 44.5], [0, 0, 128, 96], [100, 70, 127.5, 95.5], [5, 5, 6, 6.5],
