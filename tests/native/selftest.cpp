@@ -227,6 +227,18 @@ int main(int argc, char** argv) {
       bench_conv("fc1 12544->1024 M8192", 1, 8192, 1, 12544, 1024, 1, 0, 1, v | 512);
       bench_conv("gemm 8192x8192x8192", 1, 8192, 1, 8192, 8192, 1, 0, 1, v | 512);
     }
+    for (int v : {512 | 4 | 16}) {  // 128 x 128 tile, BK 32, two-stage ring: 32 KB LDS, three work-groups per CU
+      bench_conv("fpn_out2 3x3 256->256 B16", 16, 200, 336, 256, 256, 3, 1, 1, v);
+      bench_conv("res3 3x3 128->128 B16", 16, 100, 168, 128, 128, 3, 1, 1, v);
+      bench_conv("res4 3x3 256->256 B16", 16, 50, 84, 256, 256, 3, 1, 1, v);
+      bench_conv("res4 1x1 1024->256 B16", 16, 50, 84, 1024, 256, 1, 0, 1, v);
+      bench_conv("res4 1x1 256->1024 B16", 16, 50, 84, 256, 1024, 1, 0, 1, v);
+      bench_conv("res3 1x1 512->128 B16", 16, 100, 168, 512, 128, 1, 0, 1, v);
+    }
+    for (int v : {512}) {
+      bench_conv("res4 1x1 256->1024 B16", 16, 50, 84, 256, 1024, 1, 0, 1, v);
+      bench_conv("res3 1x1 512->128 B16", 16, 100, 168, 512, 128, 1, 0, 1, v);
+    }
     for (int v : {256, 256 | 1024, 256 | 1024 | 2048}) {  // 256 x 256 tile, 8 waves; | 1024: staggered wave groups
       bench_conv("fpn_out2 3x3 256->256 B16", 16, 200, 336, 256, 256, 3, 1, 1, v);
       bench_conv("fpn_out3 3x3 256->256 B16", 16, 100, 168, 256, 256, 3, 1, 1, v);
