@@ -11,20 +11,6 @@ from ..structures import Boxes, Instances
 from .batched import device_constant
 
 
-def nms_single(boxes, scores, groups, thr, topk):
-    """batched_nms for one image: returns kept indices sorted by descending score."""
-    n = boxes.shape[0]
-    if n == 0:
-        return torch.zeros(0, dtype=torch.int64, device=boxes.device)
-    order = torch.sort(scores, descending=True, stable=True)[1]
-    sb = boxes[order][None].contiguous()
-    sg = groups[order].to(torch.int32)[None].contiguous()
-    cnt = torch.tensor([n], dtype=torch.int32, device=boxes.device)
-    max_keep = n if topk < 0 else min(n, topk)
-    keep, nkeep = F.batched_nms(sb, sg, cnt, thr, max_keep)
-    return order[keep[0, : int(nkeep[0])].long()]
-
-
 def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image):
     """fast_rcnn.py:117-171 for one image (the batched routine below with a batch of one)."""
     res, kept = fast_rcnn_inference([boxes], [scores], [image_shape], score_thresh, nms_thresh, topk_per_image)

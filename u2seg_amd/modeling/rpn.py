@@ -302,17 +302,6 @@ class RPN(nn.Module):
         return proposals, losses
 
 
-def pad_gt_boxes(gt_instances, device):
-    """list[Instances] -> gt [B, G, 4] fp32 (zero padded, G >= 1) and counts [B] int32."""
-    g = max(1, max(len(x) for x in gt_instances))
-    out = torch.zeros((len(gt_instances), g, 4), dtype=torch.float32, device=device)
-    for i, inst in enumerate(gt_instances):
-        if len(inst):
-            out[i, : len(inst)] = inst.gt_boxes.tensor
-    cnt = device_constant([len(x) for x in gt_instances], torch.int32, device)
-    return out, cnt
-
-
 def build_proposal_generator(cfg, input_shape):
     name = cfg.MODEL.PROPOSAL_GENERATOR.NAME
     if name == "PrecomputedProposals":
