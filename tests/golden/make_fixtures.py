@@ -459,6 +459,72 @@ def gen_model_fixture(name, hw, nimg, seed):
     print("wrote", name, out["losses"])
 
 
+TRAJ_PARAMS = ["backbone.bottom_up.stem.conv1.weight", "backbone.bottom_up.res4.5.conv3.norm.weight",
+               "backbone.fpn_output2.weight", "roi_heads.box_predictor.1.cls_score.weight",
+               "roi_heads.mask_head.deconv.weight", "sem_seg_head.predictor.bias"]
+TRAJ_OVERRIDES = ["SOLVER.WARMUP_ITERS", 2, "SOLVER.WARMUP_FACTOR", 0.25, "SOLVER.STEPS", (3,), "SOLVER.MAX_ITER", 4,
+                  "SOLVER.WEIGHT_DECAY_NORM", 0.001]
+
+
+def gen_trajectory_fixture(name, hw, nimg, seed, steps=4):
+    """Four SGD steps of the reference: its PanopticFPN, its build_optimizer (per-parameter L2 clip wrapped around
+    torch.optim.SGD, solver/build.py:29-153) and its plain-python WarmupMultiStepLR (solver/lr_scheduler.py:141-173;
+    equal to the fvcore composite build_lr_scheduler assembles whenever no milestone falls inside the warm-up), fp32 on
+    the CPU.  The schedule is compressed (warm-up over 2 iterations from 0.25, one milestone at 3) so that warm-up, the
+    plateau and a decay are all inside four steps; a fresh batch (start_index = step * nimg) per step."""
+    os.environ.setdefault("CLUSTER_NUM", "800")
+    from detectron2.config import get_cfg
+    from detectron2.modeling import build_model
+    from detectron2.solver import build_optimizer
+    from detectron2.solver.lr_scheduler import WarmupMultiStepLR
+    from detectron2.utils.events import EventStorage
+
+    from u2seg_amd.data import make_synthetic_batch
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(REF, "configs/COCO-PanopticSegmentation/u2seg_R50_800.yaml"))
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.MODEL.WEIGHTS = ""
+    cfg.merge_from_list(list(TRAJ_OVERRIDES))
+    model = build_model(cfg)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            v.copy_(det_fill(k, v))
+    model.train()
+    opt = build_optimizer(cfg, model)
+    sched = WarmupMultiStepLR(opt, list(cfg.SOLVER.STEPS), cfg.SOLVER.GAMMA, cfg.SOLVER.WARMUP_FACTOR,
+                              cfg.SOLVER.WARMUP_ITERS, cfg.SOLVER.WARMUP_METHOD)
+    init = {k: dict(model.named_parameters())[k].detach().clone() for k in TRAJ_PARAMS}
+    torch.manual_seed(seed)
+    per_step, lrs = [], []
+    with EventStorage() as storage:
+        for it in range(steps):
+            batch = to_ref_batch(make_synthetic_batch(nimg, height=hw[0], width=hw[1], start_index=it * nimg))
+            losses = model(batch)
+            opt.zero_grad()
+            sum(losses.values()).backward()
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sched.step()
+            storage.step()
+            per_step.append({k: float(v) for k, v in losses.items()})
+            print("step", it, "lr", lrs[-1], "total", sum(per_step[-1].values()))
+    params = dict(model.named_parameters())
+    buffers = dict(model.named_buffers())
+    out = {"config": "u2seg_R50_800.yaml", "overrides": [list(x) if isinstance(x, tuple) else x for x in TRAJ_OVERRIDES],
+           "image_hw": list(hw), "num_images": nimg, "seed": seed, "steps": steps, "lr": lrs, "losses": per_step,
+           "param_norm": {k: float(params[k].double().norm()) for k in TRAJ_PARAMS},
+           "param_sum": {k: float(params[k].double().sum()) for k in TRAJ_PARAMS},
+           "param_delta_norm": {k: float((params[k].detach() - init[k]).double().norm()) for k in TRAJ_PARAMS},
+           "running_mean_norm": {k: float(buffers[k].double().norm()) for k in
+                                 ["backbone.bottom_up.stem.conv1.norm.running_mean",
+                                  "backbone.bottom_up.res5.2.conv3.norm.running_var"]},
+           "num_batches_tracked": int(buffers["backbone.bottom_up.stem.conv1.norm.num_batches_tracked"])}
+    json.dump(out, open(os.path.join(HERE, name + ".json"), "w"), indent=1)
+    print("wrote", name)
+
+
 def gen_inference_fixture(name, hw, nimg):
     """Reference PanopticFPN.inference on synthetic images with name-keyed weights (eval-mode BN)."""
     os.environ.setdefault("CLUSTER_NUM", "800")
@@ -643,11 +709,13 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if a.only in ("", "kmeans"):
         gen_kmeans_fixture()
-    if a.only in ("", "ops", "model", "model_small", "inference"):
+    if a.only in ("", "ops", "model", "model_small", "inference", "trajectory"):
         ra = import_reference()
         if a.only in ("", "ops"):
             gen_op_fixtures(ra)
         if a.only in ("", "model", "model_small"):
             gen_model_fixture("model_small", (192, 256), 2, 5)
+        if a.only in ("", "trajectory"):
+            gen_trajectory_fixture("trajectory_small", (192, 256), 2, 7)
         if a.only in ("", "inference"):
             gen_inference_fixture("inference_small", (192, 256), 2)
