@@ -194,6 +194,15 @@ int u2_kmeans_update(const float* x, const long long* labels, float* csum, float
                      void* stream);
 int u2_kmeans_finalize(const float* csum, const float* counts, float* c, int D, int K, void* stream);
 
+/* ---- k nearest neighbours over the same embeddings (knn.hip): nn_utils.py:204-299 (kNN, partitioned_kNN) ----
+ * d_knn[i][0..K) = the K smallest sum_d (x_query[i][d] - x_train[j][d])^2 in ascending order (ties: smaller j first),
+ * ind_knn[i][k] = the train row j it belongs to; what pykeops' Kmin_argKmin(K, dim=1) returns at nn_utils.py:216 and what
+ * partitioned_kNN's merge over 130 000-row partitions (:226-266) reduces to.  D % 16 == 0, 1 <= K <= 28, Nt >= K (else -2).
+ * workspace: u2_knn_workspace_ints() 4-byte words of device memory. */
+int u2_knn_workspace_ints(int Nq, int Nt, int D, int K, long long* n_ints);
+int u2_knn(const float* x_query, const float* x_train, void* workspace, float* d_knn /*[Nq][K]*/,
+           long long* ind_knn /*[Nq][K]*/, int Nq, int Nt, int D, int K, void* stream);
+
 /* library self-description */
 int u2_abi_version(void);
 

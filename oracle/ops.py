@@ -265,3 +265,39 @@ def kmeans(x, init_idx, niter):
         cl = kmeans_assign(x, c)
         c, _ = kmeans_update(x, cl, c.shape[0])
     return cl, c
+
+
+# ---------------------------------------------------------------------------------------------
+# kNN density (u2seg/Instance_Clustering/shared/utils/nn_utils.py:204-299)
+# ---------------------------------------------------------------------------------------------
+def knn(x_train, x_test, k=20, chunk=512):
+    """nn_utils.py:204-227.  D_ij = sum_d (x_test_id - x_train_jd)^2 in fp32 in the difference form the reference
+    writes (:210-214), then pykeops' Kmin_argKmin(K, dim=1) (:216; pykeops 2.x is not in this image - its documented
+    semantics restated: the K smallest values of each row in ascending order and their column indices; equal values are
+    listed smaller column first, which pykeops leaves open).  Returns (ind_knn, d_knn) like the reference."""
+    ind = torch.empty((x_test.shape[0], k), dtype=torch.int64)
+    dk = torch.empty((x_test.shape[0], k), dtype=torch.float32)
+    for s in range(0, x_test.shape[0], chunk):
+        d = ((x_test[s : s + chunk, None, :] - x_train[None, :, :]) ** 2).sum(-1)
+        v, i = torch.sort(d, dim=1, stable=True)
+        dk[s : s + chunk], ind[s : s + chunk] = v[:, :k], i[:, :k]
+    return ind, dk
+
+
+def partitioned_knn(feats, k=20, partitions_size=130000):
+    """nn_utils.py:230-266: every (train partition, test partition) pair contributes K candidates per test row, offset
+    to global row numbers (:252-253); the K best of the partitions * K candidates are picked by an argsort (:259-266).
+    Returns (d_knns, ind_knns)."""
+    n = feats.shape[0]
+    parts = -(-n // partitions_size)
+    ind_all = torch.zeros((n, parts * k), dtype=torch.int64)
+    d_all = torch.zeros((n, parts * k), dtype=torch.float32)
+    for i in range(parts):
+        tr = feats[i * partitions_size : (i + 1) * partitions_size]
+        for j in range(parts):
+            te = feats[j * partitions_size : (j + 1) * partitions_size]
+            ind, d = knn(tr, te, k)
+            ind_all[j * partitions_size : (j + 1) * partitions_size, i * k : (i + 1) * k] = i * partitions_size + ind
+            d_all[j * partitions_size : (j + 1) * partitions_size, i * k : (i + 1) * k] = d
+    sel = d_all.argsort(dim=1)[:, :k]
+    return torch.gather(d_all, 1, sel), torch.gather(ind_all, 1, sel)

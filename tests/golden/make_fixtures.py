@@ -674,8 +674,7 @@ def gen_op_fixtures(roi_align_ref):
     print("wrote ops_golden.npz with", len(out), "arrays")
 
 
-def gen_kmeans_fixture():
-    """Reference KMeans (u2seg/Instance_Clustering/shared/utils/nn_utils.py:304-379) through its plain-torch branch."""
+def _import_nn_utils():
     for m in ["pykeops", "pykeops.torch", "torchvision", "torchvision.transforms", "torchvision.datasets", "torchvision.models",
               "yacs", "yacs.config", "termcolor", "clip"]:
         sys.modules.setdefault(m, mock.MagicMock())
@@ -690,6 +689,58 @@ def gen_kmeans_fixture():
     mod = types.ModuleType("u.nn_utils")
     mod.__package__ = "u"
     exec(compile(src, path, "exec"), mod.__dict__)
+    return mod
+
+
+class _DenseLazyTensor:
+    """Stand-in for pykeops.torch.LazyTensor (pykeops is not in this image), covering exactly the expression kNN builds
+    (nn_utils.py:210-216): broadcasting `-`, `** 2`, `.sum(-1)` evaluated densely in fp32, and Kmin_argKmin(K, dim=1) =
+    the K smallest values of every row in ascending order with their column indices (pykeops' documented reduction;
+    equal values keep the smaller column first here, pykeops leaves that order unspecified)."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def __sub__(self, other):
+        return _DenseLazyTensor(self.t - other.t)
+
+    def __pow__(self, e):
+        return _DenseLazyTensor(self.t ** e)
+
+    def sum(self, dim):
+        return _DenseLazyTensor(self.t.sum(dim))
+
+    def Kmin_argKmin(self, K, dim, backend=None):
+        assert dim == 1
+        v, i = torch.sort(self.t, dim=1, stable=True)
+        return v[:, :K].contiguous(), i[:, :K].contiguous()
+
+
+def gen_knn_fixture():
+    """Reference partitioned_kNN (nn_utils.py:230-299): its own partition loop and argsort merge over 3 partitions
+    (300 + 300 + 100 rows), with pykeops' LazyTensor served by _DenseLazyTensor and .cuda() made the identity."""
+    mod = _import_nn_utils()
+    mod.LazyTensor = _DenseLazyTensor
+    mod.save_npy = lambda *a, **k: None
+    g = torch.Generator().manual_seed(11)
+    N, D, K = 700, 32, 20
+    centers = torch.randn((9, D), generator=g)
+    x = centers[torch.randint(0, 9, (N,), generator=g)] + 0.3 * torch.randn((N, D), generator=g)
+    x = torch.nn.functional.normalize(x, dim=1)
+    x[650] = x[5]      # exact duplicates across partitions: tied distances, both at 0 from each other
+    x[310] = x[305]
+    with mock.patch.object(torch.Tensor, "cuda", lambda self, *a, **k: self):
+        d_knns, ind_knns = mod.partitioned_kNN(x, K=K, recompute=True, partitions_size=300)
+        ind_one, d_one = mod.kNN(x, x, K=K)
+    assert torch.equal(d_knns, d_one)
+    np.savez_compressed(os.path.join(HERE, "knn_golden.npz"), x=x.numpy(), d_knns=d_knns.numpy(), ind_knns=ind_knns.numpy(),
+                        K=np.array(K), partitions_size=np.array(300))
+    print("wrote knn_golden.npz", d_knns.shape, float(d_knns.mean()))
+
+
+def gen_kmeans_fixture():
+    """Reference KMeans (u2seg/Instance_Clustering/shared/utils/nn_utils.py:304-379) through its plain-torch branch."""
+    mod = _import_nn_utils()
     g = torch.Generator().manual_seed(3)
     K, D, N = 12, 64, 3000
     centers = torch.randn((K, D), generator=g) * 3
@@ -709,6 +760,8 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if a.only in ("", "kmeans"):
         gen_kmeans_fixture()
+    if a.only in ("", "knn"):
+        gen_knn_fixture()
     if a.only in ("", "ops", "model", "model_small", "inference", "trajectory"):
         ra = import_reference()
         if a.only in ("", "ops"):

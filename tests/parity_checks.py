@@ -1,4 +1,5 @@
 """Small oracle checks reused by __graft_entry__.smoke() (one HIP launch each, compared with the CPU oracle)."""
+import numpy as np
 import torch
 
 
@@ -26,3 +27,15 @@ def smoke_oracle_check():
     got = order[keep[0, : int(nk[0])].long().cpu()]
     assert got.tolist() == O.nms(b, s, 0.5).tolist()
     print("smoke: oracle checks ok (roi_align rel err %.2e, nms keep list identical, %d kept)" % (err, len(got)))
+
+
+def knn_lists_agree(x, d_got, ind_got, d_want, ind_want, rtol=1e-5, atol=1e-6):
+    """The acceptance rule of the reference's own verify branch (nn_utils.py:268-287): distances equal; where the
+    neighbour ids differ, the distance from the row to either id must be the same (tied or duplicated rows)."""
+    np.testing.assert_allclose(d_got, d_want, rtol=rtol, atol=atol)
+    rows, cols = np.nonzero(ind_got != ind_want)
+    for r, c in zip(rows, cols):
+        a = float(((x[r] - x[ind_got[r, c]]) ** 2).sum())
+        b = float(((x[r] - x[ind_want[r, c]]) ** 2).sum())
+        assert abs(a - b) <= atol + rtol * abs(b), (r, c, a, b)
+    return len(rows)

@@ -544,6 +544,129 @@ def test_kmeans(golden_dir=None):
     assert torch.equal(lab.cpu(), ref)
     cn, cnt = KM.update(xs, lab, 5)
     assert torch.isnan(cn[3]).all() and float(cnt[3]) == 0
+    # K = 300 (the reference's setting: all ten 32-centroid tiles present, the branch-free pass) and K = 700 (two full
+    # passes + a partial one); labels may differ from the oracle only where the two nearest centroids are tied to 1e-5
+    gk = torch.Generator().manual_seed(4)
+    for k in (300, 700):
+        xs = torch.randn((5003, 64), generator=gk)
+        cs = xs[torch.randperm(5003, generator=gk)[:k]] + 0.05 * torch.randn((k, 64), generator=gk)
+        lab = KM.assign(xs.to(DEV), cs.to(DEV)).cpu()
+        ref = O.kmeans_assign(xs, cs)
+        bad = torch.nonzero(lab != ref)[:, 0]
+        d_lab = ((xs[bad] - cs[lab[bad]]) ** 2).sum(1)
+        d_ref = ((xs[bad] - cs[ref[bad]]) ** 2).sum(1)
+        assert bad.numel() <= 5 and torch.allclose(d_lab, d_ref, rtol=1e-5), (k, bad.numel())
+
+
+def _clustered_unit_rows(n, d, seed, nclusters=40):
+    g = torch.Generator().manual_seed(seed)
+    centers = torch.randn((nclusters, d), generator=g)
+    x = centers[torch.randint(0, nclusters, (n,), generator=g)] + 0.4 * torch.randn((n, d), generator=g)
+    return torch.nn.functional.normalize(x, dim=1)
+
+
+def test_knn_vs_oracle_and_reference():
+    """u2_knn (fp32-MFMA candidate selection + difference-form refinement) vs the reference-generated lists (its own
+    partition loop + merge, tests/golden/knn_golden.npz) and vs the oracle on ragged sizes: distances to 1e-5 relative,
+    neighbour ids identical except where two train rows are equidistant (the rule of the reference's verify branch)."""
+    from tests.parity_checks import knn_lists_agree
+    from u2seg_amd.cluster import knn as KN
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "knn_golden.npz"))
+    x = torch.from_numpy(g["x"]).to(DEV)
+    d, ind = KN.partitioned_kNN(x, K=int(g["K"]), partitions_size=int(g["partitions_size"]))
+    assert d.dtype == torch.float32 and ind.dtype == torch.int64
+    ind_np = ind.cpu().numpy()
+    knn_lists_agree(g["x"], d.cpu().numpy(), ind_np, g["d_knns"], g["ind_knns"])
+    # ids may only differ where the planted twin rows (5 = 650, 305 = 310) tie: the reference's merge is an unstable argsort
+    differs = ind_np != g["ind_knns"]
+    assert np.isin(ind_np[differs], [5, 650, 305, 310]).all() and np.isin(g["ind_knns"][differs], [5, 650, 305, 310]).all()
+    assert (d[:, 0] == 0).all()  # the row itself (or its exact twin), bit-exact zero like the difference form
+    np.testing.assert_allclose(KN.first_order_density(d).cpu().numpy(), 1 / g["d_knns"].mean(1), rtol=1e-5)
+
+    # separate query / train sets, D = 768, sizes off every tile boundary, several K
+    pool = _clustered_unit_rows(3011 + 777, 768, 1)
+    xt, xq = pool[:3011].contiguous(), pool[3011:].contiguous()
+    ind_o, d_o = O.knn(xt, xq, 28)  # the first k columns are the lists for every smaller k
+    for k in (1, 5, 20, 28):
+        ind_g, d_g = KN.kNN(xt.to(DEV), xq.to(DEV), K=k)
+        bad = knn_lists_agree(xq.numpy(), d_g.cpu().numpy(), ind_g.cpu().numpy(), d_o[:, :k].numpy(), ind_o[:, :k].numpy())
+        assert bad == 0, (k, bad)
+    # fewer train rows than the K + 4 candidate slots, and the K > N_train error of the reference's assumption
+    ind_o, d_o = O.knn(xt[:22], xq[:130], 20)
+    ind_g, d_g = KN.kNN(xt[:22].to(DEV), xq[:130].to(DEV), K=20)
+    assert torch.equal(ind_g.cpu(), ind_o)
+    np.testing.assert_allclose(d_g.cpu().numpy(), d_o.numpy(), rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        KN.kNN(xt[:10].to(DEV), xq[:4].to(DEV), K=20)
+    with pytest.raises(ValueError):
+        KN.kNN(xt.to(DEV), xq.to(DEV), K=29)
+    assert KN.kNN(xt.to(DEV), xq[:0].to(DEV), K=20)[0].shape == (0, 20)
+    # unnormalised rows with a large common offset: the expanded form used for selection loses digits here, the spare
+    # candidates + difference-form refinement must still return the oracle's lists
+    xo = (xt[:1500] * 3 + 5).contiguous()
+    ind_o, d_o = O.knn(xo, xo, 20)
+    ind_g, d_g = KN.kNN(xo.to(DEV), xo.to(DEV), K=20)
+    knn_lists_agree(xo.numpy(), d_g.cpu().numpy(), ind_g.cpu().numpy(), d_o.numpy(), ind_o.numpy(), rtol=1e-4)
+
+
+def test_knn_full_size_properties():
+    """N = 100 000 x 768 (the order of one reference partition): size-independent properties instead of an oracle run -
+    every list ascending with the row itself first at distance exactly 0; the reported distances equal a direct
+    recomputation; no sampled train row is closer than a row's K-th neighbour unless it is in the list."""
+    from u2seg_amd.cluster import knn as KN
+
+    n, dim, k = 100000, 768, 20
+    x = _clustered_unit_rows(n, dim, 3, nclusters=300).to(DEV)
+    d, ind = KN.partitioned_kNN(x, K=k)
+    assert bool((ind[:, 0] == torch.arange(n, device=DEV)).all()) and bool((d[:, 0] == 0).all())
+    assert bool((d[:, 1:] >= d[:, :-1]).all())
+    rows = torch.randperm(n, generator=torch.Generator().manual_seed(0))[:2000].to(DEV)
+    direct = ((x[rows][:, None, :] - x[ind[rows]]) ** 2).sum(-1)
+    assert torch.allclose(direct, d[rows], rtol=1e-5, atol=1e-6)
+    cols = torch.randperm(n, generator=torch.Generator().manual_seed(1))[:4000].to(DEV)
+    dd = torch.cdist(x[rows], x[cols]) ** 2
+    closer = dd < (d[rows, k - 1] * (1 - 1e-4) - 1e-6)[:, None]
+    listed = (ind[rows][:, None, :] == cols[None, :, None]).any(-1)
+    assert not bool((closer & ~listed).any())
+
+
+def _knn_shard_worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from u2seg_amd.cluster import knn as KN
+
+    torch.cuda.set_device(0)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "knn_golden.npz"))
+    x = torch.from_numpy(g["x"]).to(DEV)
+    lo, hi = (0, 250) if rank == 0 else (250, x.shape[0])  # uneven shards
+    d, ind = KN.partitioned_kNN_sharded(x[lo:hi], K=int(g["K"]))
+    out[rank] = (d.cpu().numpy(), ind.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_knn_row_sharded_two_ranks():
+    """kNN lists with the rows sharded over two ranks (one all-gather of the ragged shards, no other exchange): the
+    concatenated lists must equal the reference-generated single-process golden."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from tests.parity_checks import knn_lists_agree
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_knn_shard_worker, args=(2, port, out), nprocs=2, join=True)
+        (d0, i0), (d1, i1) = out[0], out[1]
+    g = np.load(os.path.join(ROOT, "tests", "golden", "knn_golden.npz"))
+    assert d0.shape[0] == 250 and d1.shape[0] == g["x"].shape[0] - 250
+    knn_lists_agree(g["x"], np.concatenate([d0, d1]), np.concatenate([i0, i1]), g["d_knns"], g["ind_knns"])
 
 
 def test_whole_model_vs_oracle(F):

@@ -125,6 +125,25 @@ def test_kmeans(golden_dir):
     assert torch.isnan(c2[1]).all() and torch.allclose(c2[0], torch.tensor([0.5, 0.0]))
 
 
+
+def test_knn_partitioned_merge(golden_dir):
+    """oracle kNN + partition merge == the reference's partitioned_kNN run over 3 partitions (its own loop and argsort
+    merge; pykeops' reduction served by the dense stand-in in make_fixtures.py), and == one unpartitioned pass."""
+    g = np.load(os.path.join(golden_dir, "knn_golden.npz"))
+    x = torch.from_numpy(g["x"])
+    k, ps = int(g["K"]), int(g["partitions_size"])
+    d, ind = ops.partitioned_knn(x, k, ps)
+    assert np.array_equal(d.numpy(), g["d_knns"])
+    from tests.parity_checks import knn_lists_agree
+
+    knn_lists_agree(g["x"], d.numpy(), ind.numpy(), g["d_knns"], g["ind_knns"], rtol=0, atol=0)
+    differs = ind.numpy() != g["ind_knns"]  # only the planted twin rows (5 = 650, 305 = 310) may swap places
+    assert np.isin(ind.numpy()[differs], [5, 650, 305, 310]).all()
+    ind1, d1 = ops.knn(x, x, k)
+    assert np.array_equal(d1.numpy(), g["d_knns"])
+    assert (d1[:, 0] == 0).all() and (ind1[:, 0] <= torch.arange(x.shape[0])).all()  # every row finds itself (or its twin)
+
+
 def test_whole_model_losses_and_grads(golden_dir):
     """fp32 oracle == reference PanopticFPN (u2seg_R50_800) on 2 synthetic 192x256 images: the 10 losses and a
     sample of parameter-gradient norms (same name-keyed weights, same CPU randperm stream)."""

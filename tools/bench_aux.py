@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Secondary measurements (BASELINE.json configs 4 and 5): k-means over synthetic DINO-sized embeddings and batch
-panoptic inference.  Prints one JSON line per measurement; numbers are quoted in DESIGN.md."""
+"""Secondary measurements (BASELINE.json configs 4 and 5): k-means and kNN lists over synthetic DINO-sized embeddings and
+batch panoptic inference.  Prints one JSON line per measurement; numbers are quoted in DESIGN.md."""
 import argparse
 import json
 import os
@@ -54,6 +54,35 @@ def bench_kmeans(n, d, k, iters):
                       (d, k, torch.get_num_threads()), "s_per_iter_scaled_to_N": dt * n / 50000}))
 
 
+def bench_knn(n, d, k):
+    """kNN lists of every row against all rows (partitioned_kNN): select kernel = 2 N^2 D flop on the fp32 MFMA."""
+    from u2seg_amd.cluster import knn as KN
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    centers = torch.randn((300, d), generator=g, device="cuda")
+    x = centers[torch.randint(0, 300, (n,), generator=g, device="cuda")] + 0.4 * torch.randn((n, d), generator=g, device="cuda")
+    x = torch.nn.functional.normalize(x, dim=1)
+    KN.partitioned_kNN(x[:4096], K=k)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    dk, ind = KN.partitioned_kNN(x, K=k)
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1])
+    flops = 2.0 * n * n * d
+    print(json.dumps({"metric": "kNN lists s", "N": n, "D": d, "K": k, "s": ms * 1e-3, "TFLOPs": flops / (ms * 1e-3) / 1e12,
+                      "frac_of_fp32_mfma_peak": flops / (ms * 1e-3) / 157.3e12, "self_first": bool((ind[:, 0] == torch.arange(n, device="cuda")).all())}))
+    from oracle import ops as O
+
+    xs = x[:20000].cpu()
+    t0 = time.time()
+    O.knn(xs, xs[:2000], k)
+    dt = time.time() - t0
+    print(json.dumps({"metric": "kNN cpu_baseline", "sample": "2000 query rows x 20000 train rows x %d (oracle, %d threads)" %
+                      (d, torch.get_num_threads()), "s_scaled_to_N_squared": dt * (n / 2000.0) * (n / 20000.0)}))
+
+
 def bench_inference(batch, iters):
     from u2seg_amd.config import get_cfg
     from u2seg_amd.data import make_synthetic_batch
@@ -81,12 +110,15 @@ def bench_inference(batch, iters):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["kmeans", "inference", "all"])
+    ap.add_argument("what", choices=["kmeans", "knn", "inference", "all"])
     ap.add_argument("--n", type=int, default=1000000)
+    ap.add_argument("--knn-n", type=int, default=200000)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     a = ap.parse_args()
     if a.what in ("kmeans", "all"):
         bench_kmeans(a.n, 768, 300, a.iters)
+    if a.what in ("knn", "all"):
+        bench_knn(a.knn_n, 768, 20)
     if a.what in ("inference", "all"):
         bench_inference(a.batch, max(1, a.iters // 2))

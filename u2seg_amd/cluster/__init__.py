@@ -1,3 +1,3 @@
-from . import kmeans
+from . import kmeans, knn
 
-__all__ = ["kmeans"]
+__all__ = ["kmeans", "knn"]

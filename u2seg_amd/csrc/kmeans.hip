@@ -7,6 +7,8 @@
 // the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, an fma chain in k order), so labels agree with the reference
 // except where two centroids are equidistant to within fp32 rounding of the two formulations.
 // Empty clusters give 0/0 = NaN centroids exactly like the reference (noted at usl-imagenet.py:135).
+#include <type_traits>
+
 #include "common.h"
 #include "u2seg_hip.h"
 
@@ -18,6 +20,7 @@ constexpr int KM_PTS = 128;    // points per workgroup (32 per wave)
 constexpr int KM_BD = 16;      // dims per staged chunk
 constexpr int KM_PITCH = 17;   // padded LDS row pitch (floats)
 constexpr int KM_TILES = 10;   // 32-centroid tiles per pass (320 centroids)
+constexpr int KM_STAGE = (KM_PTS + KM_TILES * 32) * KM_PITCH;  // floats of one staging buffer
 
 __global__ __launch_bounds__(256) void cnorm_kernel(const float* __restrict__ c, float* __restrict__ cn, int D, int K) {
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -39,8 +42,7 @@ __device__ __forceinline__ bool km_less(float v, int j, float bv, int bj) {
 __global__ __launch_bounds__(256, 1) void kmeans_assign_kernel(const float* __restrict__ x, const float* __restrict__ c,
                                                                const float* __restrict__ cn, long long* __restrict__ labels,
                                                                int N, int D, int K) {
-  __shared__ float xs[KM_PTS * KM_PITCH];
-  __shared__ float cs[KM_TILES * 32 * KM_PITCH];
+  __shared__ float stage[2 * KM_STAGE];  // [2][xs: KM_PTS x KM_PITCH | cs: 320 x KM_PITCH]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int p0 = blockIdx.x * KM_PTS;
   const int li = lane & 31, lk = lane >> 5;
@@ -76,7 +78,9 @@ __global__ __launch_bounds__(256, 1) void kmeans_assign_kernel(const float* __re
                                             : make_float4(0, 0, 0, 0);
       }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int buf) {
+      float* xs = stage + buf * KM_STAGE;
+      float* cs = xs + KM_PTS * KM_PITCH;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int f = q * 256 + tid;
@@ -91,24 +95,45 @@ __global__ __launch_bounds__(256, 1) void kmeans_assign_kernel(const float* __re
       }
     };
 
-    gload(0);
-    for (int d0 = 0; d0 < D; d0 += KM_BD) {
+    // One barrier per 16-dim chunk: the next chunk goes global -> registers at the top, registers -> the other LDS buffer
+    // late in the MFMA sequence (its readers finished before the previous barrier).  The LDS operands of step ks + 1 are
+    // read while the 10 MFMAs of step ks run; full passes (all 10 centroid tiles present) carry no per-tile branch.
+    auto dloop = [&](auto full) {
+      constexpr bool FULL = decltype(full)::value;
+      gload(0);
+      lstore(0);
       __syncthreads();
-      lstore();
-      __syncthreads();
-      if (d0 + KM_BD < D) gload(d0 + KM_BD);
+      int buf = 0;
+      for (int d0 = 0; d0 < D; d0 += KM_BD, buf ^= 1) {
+        const bool more = d0 + KM_BD < D;
+        if (more) gload(d0 + KM_BD);
+        const float* xa = stage + buf * KM_STAGE + (w * 32 + li) * KM_PITCH + lk;
+        const float* cb = stage + buf * KM_STAGE + KM_PTS * KM_PITCH + li * KM_PITCH + lk;
+        float a = xa[0], b[KM_TILES];
 #pragma unroll
-      for (int ks = 0; ks < KM_BD / 2; ++ks) {
-        const float a = xs[(w * 32 + li) * KM_PITCH + ks * 2 + lk];
+        for (int t = 0; t < KM_TILES; ++t) b[t] = (FULL || t < ntile) ? cb[t * 32 * KM_PITCH] : 0.f;
 #pragma unroll
-        for (int t = 0; t < KM_TILES; ++t) {
-          if (t < ntile) {
-            const float b = cs[(t * 32 + li) * KM_PITCH + ks * 2 + lk];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        for (int ks = 0; ks < KM_BD / 2; ++ks) {
+          float an = 0.f, bn[KM_TILES];
+          if (ks + 1 < KM_BD / 2) {
+            an = xa[(ks + 1) * 2];
+#pragma unroll
+            for (int t = 0; t < KM_TILES; ++t) bn[t] = (FULL || t < ntile) ? cb[t * 32 * KM_PITCH + (ks + 1) * 2] : 0.f;
+          }
+          if (ks == KM_BD / 2 - 3 && more) lstore(buf ^ 1);
+#pragma unroll
+          for (int t = 0; t < KM_TILES; ++t)
+            if (FULL || t < ntile) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+          if (ks + 1 < KM_BD / 2) {
+            a = an;
+#pragma unroll
+            for (int t = 0; t < KM_TILES; ++t) b[t] = bn[t];
           }
         }
+        __syncthreads();
       }
-    }
+    };
+    if (ntile == KM_TILES) dloop(std::true_type{}); else dloop(std::false_type{});
     // D[i = point][j = centroid]: lane holds column j = li of tile t, rows (r&3) + 8*(r>>2) + 4*lk
 #pragma unroll
     for (int t = 0; t < KM_TILES; ++t) {
