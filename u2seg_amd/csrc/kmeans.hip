@@ -60,23 +60,22 @@ __global__ __launch_bounds__(256, 1) void kmeans_assign_kernel(const float* __re
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // Staging registers for one 16-dim chunk: 128 points + 320 centroids x 4 float4 per row over 256 threads.  Rows past
+    // the end are clamped to the last row instead of predicated (the epilogue ignores them): the loads stay straight-line
+    // code, so the compiler can count them (s_waitcnt vmcnt(N)) instead of draining everything at a join.
     float4 xr[2], cr[5];
+    const int c4 = tid & 3;  // every float4 index f = q * 256 + tid below has f % 4 == tid % 4
+    const float* xrow[2];
+    const float* crow[5];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) xrow[q] = x + (size_t)min(p0 + ((q * 256 + tid) >> 2), N - 1) * D + c4 * 4;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) crow[q] = c + (size_t)min(k0 + ((q * 256 + tid) >> 2), K - 1) * D + c4 * 4;
     auto gload = [&](int d0) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int f = q * 256 + tid;           // float4 index: row = f/4, col4 = f%4
-        const int row = f >> 2, c4 = f & 3;
-        const int p = p0 + row;
-        xr[q] = (p < N) ? *reinterpret_cast<const float4*>(x + (size_t)p * D + d0 + c4 * 4) : make_float4(0, 0, 0, 0);
-      }
+      for (int q = 0; q < 2; ++q) xr[q] = *reinterpret_cast<const float4*>(xrow[q] + d0);
 #pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        const int f = q * 256 + tid;
-        const int row = f >> 2, c4 = f & 3;
-        const int j = k0 + row;
-        cr[q] = (row < ntile * 32 && j < K) ? *reinterpret_cast<const float4*>(c + (size_t)j * D + d0 + c4 * 4)
-                                            : make_float4(0, 0, 0, 0);
-      }
+      for (int q = 0; q < 5; ++q) cr[q] = *reinterpret_cast<const float4*>(crow[q] + d0);
     };
     auto lstore = [&](int buf) {
       float* xs = stage + buf * KM_STAGE;
@@ -95,18 +94,20 @@ __global__ __launch_bounds__(256, 1) void kmeans_assign_kernel(const float* __re
       }
     };
 
-    // One barrier per 16-dim chunk: the next chunk goes global -> registers at the top, registers -> the other LDS buffer
-    // late in the MFMA sequence (its readers finished before the previous barrier).  The LDS operands of step ks + 1 are
-    // read while the 10 MFMAs of step ks run; full passes (all 10 centroid tiles present) carry no per-tile branch.
+    // One barrier per 16-dim chunk and a global prefetch one full chunk ahead: late in the MFMA sequence of chunk c the
+    // registers holding chunk c + 1 (requested at the same point of chunk c - 1) move into the other LDS buffer (its
+    // readers finished before the previous barrier) and are immediately re-used to request chunk c + 2.  The LDS operands
+    // of step ks + 1 are read while the 10 MFMAs of step ks run; full passes (all 10 centroid tiles present) carry no
+    // per-tile branch.
     auto dloop = [&](auto full) {
       constexpr bool FULL = decltype(full)::value;
       gload(0);
       lstore(0);
+      if (KM_BD < D) gload(KM_BD);
       __syncthreads();
       int buf = 0;
       for (int d0 = 0; d0 < D; d0 += KM_BD, buf ^= 1) {
         const bool more = d0 + KM_BD < D;
-        if (more) gload(d0 + KM_BD);
         const float* xa = stage + buf * KM_STAGE + (w * 32 + li) * KM_PITCH + lk;
         const float* cb = stage + buf * KM_STAGE + KM_PTS * KM_PITCH + li * KM_PITCH + lk;
         float a = xa[0], b[KM_TILES];
@@ -120,7 +121,10 @@ __global__ __launch_bounds__(256, 1) void kmeans_assign_kernel(const float* __re
 #pragma unroll
             for (int t = 0; t < KM_TILES; ++t) bn[t] = (FULL || t < ntile) ? cb[t * 32 * KM_PITCH + (ks + 1) * 2] : 0.f;
           }
-          if (ks == KM_BD / 2 - 3 && more) lstore(buf ^ 1);
+          if (ks == KM_BD / 2 - 3 && more) {
+            lstore(buf ^ 1);
+            if (d0 + 2 * KM_BD < D) gload(d0 + 2 * KM_BD);
+          }
 #pragma unroll
           for (int t = 0; t < KM_TILES; ++t)
             if (FULL || t < ntile) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);

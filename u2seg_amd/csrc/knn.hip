@@ -109,56 +109,57 @@ __global__ __launch_bounds__(256, 1) void knn_select_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    float4 xr[2], cr[5];
-    float4 mreg;
-    auto gload = [&](int d0) {
-      mreg = *reinterpret_cast<const float4*>(mu + d0 + (tid & 3) * 4);  // every f below has f % 4 == tid % 4
+    // Staging registers for one 16-dim chunk: 128 query rows + 320 train rows x 4 float4 per row over 256 threads.  Rows
+    // past the end are clamped to the last row instead of predicated (they are never ranked): the loads stay straight-line
+    // code, so the compiler can count them (s_waitcnt vmcnt(N)) instead of draining everything at a join.
+    struct Chunk { float4 xr[2], cr[5], m; };
+    const int c4 = tid & 3;  // every float4 index f = q * 256 + tid below has f % 4 == tid % 4
+    const float* xrow[2];
+    const float* crow[5];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int f = q * 256 + tid;  // float4 index: row = f/4, col4 = f%4
-        const int row = f >> 2, c4 = f & 3;
-        const int p = p0 + row;
-        xr[q] = (p < Nq) ? *reinterpret_cast<const float4*>(xq + (size_t)p * D + d0 + c4 * 4) : make_float4(0, 0, 0, 0);
-      }
+    for (int q = 0; q < 2; ++q) xrow[q] = xq + (size_t)min(p0 + ((q * 256 + tid) >> 2), Nq - 1) * D + c4 * 4;
 #pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        const int f = q * 256 + tid;
-        const int row = f >> 2, c4 = f & 3;
-        const int j = k0 + row;
-        cr[q] = (row < ntile * 32 && j < Nt) ? *reinterpret_cast<const float4*>(xt + (size_t)j * D + d0 + c4 * 4)
-                                             : make_float4(0, 0, 0, 0);  // rows past the end are never ranked
-      }
+    for (int q = 0; q < 5; ++q) crow[q] = xt + (size_t)min(k0 + ((q * 256 + tid) >> 2), Nt - 1) * D + c4 * 4;
+    auto gload = [&](Chunk& R, int d0) {
+      R.m = *reinterpret_cast<const float4*>(mu + d0 + c4 * 4);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) R.xr[q] = *reinterpret_cast<const float4*>(xrow[q] + d0);
+#pragma unroll
+      for (int q = 0; q < 5; ++q) R.cr[q] = *reinterpret_cast<const float4*>(crow[q] + d0);
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const Chunk& R, int buf) {
       float* xs = stage + buf * KN_STAGE;
       float* cs = xs + KN_ROWS * KN_PITCH;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int f = q * 256 + tid;
         float* dst = xs + (f >> 2) * KN_PITCH + (f & 3) * 4;  // translated by the column mean here, not at load time:
-        dst[0] = xr[q].x - mreg.x; dst[1] = xr[q].y - mreg.y;  // the loads stay in flight across the MFMA sequence
-        dst[2] = xr[q].z - mreg.z; dst[3] = xr[q].w - mreg.w;
+        dst[0] = R.xr[q].x - R.m.x; dst[1] = R.xr[q].y - R.m.y;  // the loads stay in flight across the MFMA sequence
+        dst[2] = R.xr[q].z - R.m.z; dst[3] = R.xr[q].w - R.m.w;
       }
 #pragma unroll
       for (int q = 0; q < 5; ++q) {
         const int f = q * 256 + tid;
         float* dst = cs + (f >> 2) * KN_PITCH + (f & 3) * 4;
-        dst[0] = cr[q].x - mreg.x; dst[1] = cr[q].y - mreg.y; dst[2] = cr[q].z - mreg.z; dst[3] = cr[q].w - mreg.w;
+        dst[0] = R.cr[q].x - R.m.x; dst[1] = R.cr[q].y - R.m.y; dst[2] = R.cr[q].z - R.m.z; dst[3] = R.cr[q].w - R.m.w;
       }
     };
 
-    // One barrier per 16-dim chunk: the next chunk goes global -> registers at the top, registers -> the other LDS buffer
-    // late in the MFMA sequence (its readers finished before the previous barrier).  The LDS operands of step ks + 1 are
-    // read while the 10 MFMAs of step ks run; full passes (all 10 train tiles present) carry no per-tile branch.
+    // One barrier per 16-dim chunk and a global prefetch one full chunk ahead: late in the MFMA sequence of chunk c the
+    // registers holding chunk c + 1 (requested at the same point of chunk c - 1) move into the other LDS buffer (its
+    // readers finished before the previous barrier) and are immediately re-used to request chunk c + 2.  The LDS operands
+    // of step ks + 1 are read while the 10 MFMAs of step ks run; full passes (all 10 train tiles present) carry no per-tile
+    // branch.
     auto dloop = [&](auto full) {
       constexpr bool FULL = decltype(full)::value;
-      gload(0);
-      lstore(0);
+      Chunk R;
+      gload(R, 0);
+      lstore(R, 0);
+      if (KN_BD < D) gload(R, KN_BD);
       __syncthreads();
       int buf = 0;
       for (int d0 = 0; d0 < D; d0 += KN_BD, buf ^= 1) {
         const bool more = d0 + KN_BD < D;
-        if (more) gload(d0 + KN_BD);
         const float* xa = stage + buf * KN_STAGE + (w * 32 + li) * KN_PITCH + lk;
         const float* cb = stage + buf * KN_STAGE + KN_ROWS * KN_PITCH + li * KN_PITCH + lk;
         float a = xa[0], b[KN_TILES];
@@ -172,7 +173,10 @@ __global__ __launch_bounds__(256, 1) void knn_select_kernel(const float* __restr
 #pragma unroll
             for (int t = 0; t < KN_TILES; ++t) bn[t] = (FULL || t < ntile) ? cb[t * 32 * KN_PITCH + (ks + 1) * 2] : 0.f;
           }
-          if (ks == KN_BD / 2 - 3 && more) lstore(buf ^ 1);
+          if (ks == KN_BD / 2 - 3 && more) {
+            lstore(R, buf ^ 1);
+            if (d0 + 2 * KN_BD < D) gload(R, d0 + 2 * KN_BD);
+          }
 #pragma unroll
           for (int t = 0; t < KN_TILES; ++t)
             if (FULL || t < ntile) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
