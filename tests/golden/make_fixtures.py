@@ -234,6 +234,9 @@ def install_standins():
         def get_local_path(self, p, **k):
             return p
 
+        def ls(self, p):
+            return os.listdir(p)
+
     class PathHandler:
         pass
 
@@ -243,6 +246,9 @@ def install_standins():
     import fvcore.transforms.transform as FT
 
     class Transform:
+        """fvcore.transforms.transform.Transform restated: attribute capture, box = bounding box of the mapped corners,
+        label maps and polygons fall back to the image / coordinate maps."""
+
         def _set_attributes(self, params=None):
             if params:
                 for k, v in params.items():
@@ -253,14 +259,76 @@ def install_standins():
         def register_type(cls, *a, **k):
             return lambda f: f
 
-    class TransformList(Transform):
-        def __init__(self, t):
-            self.transforms = t
+        def apply_segmentation(self, segmentation):
+            return self.apply_image(segmentation)
 
+        def apply_box(self, box):
+            idxs = np.array([(0, 1), (2, 1), (0, 3), (2, 3)]).flatten()
+            coords = np.asarray(box).reshape(-1, 4)[:, idxs].reshape(-1, 2)
+            coords = self.apply_coords(coords).reshape((-1, 4, 2))
+            return np.concatenate((coords.min(axis=1), coords.max(axis=1)), axis=1)
+
+        def apply_polygons(self, polygons):
+            return [self.apply_coords(p) for p in polygons]
+
+    class NoOpTransform(Transform):
+        def apply_image(self, img):
+            return img
+
+        def apply_coords(self, coords):
+            return coords
+
+    class HFlipTransform(Transform):
+        def __init__(self, width):
+            self.width = width
+
+        def apply_image(self, img):
+            return np.flip(img, axis=1)
+
+        def apply_coords(self, coords):
+            coords[:, 0] = self.width - coords[:, 0]
+            return coords
+
+    class VFlipTransform(Transform):
+        def __init__(self, height):
+            self.height = height
+
+        def apply_image(self, img):
+            return np.flip(img, axis=0)
+
+        def apply_coords(self, coords):
+            coords[:, 1] = self.height - coords[:, 1]
+            return coords
+
+    class TransformList(Transform):
+        def __init__(self, transforms):
+            flat = []
+            for t in transforms:
+                flat.extend(t.transforms if isinstance(t, TransformList) else [t])
+            self.transforms = [t for t in flat if not isinstance(t, NoOpTransform)]
+
+        def __getattr__(self, name):
+            if name.startswith("apply_"):
+                def chain(x):
+                    for t in self.transforms:
+                        x = getattr(t, name)(x)
+                    return x
+                return chain
+            raise AttributeError(name)
+
+        def __len__(self):
+            return len(self.transforms)
+
+    # the chained forms must win over the per-transform defaults inherited from Transform
+    for _n in ("apply_segmentation", "apply_box", "apply_polygons"):
+        setattr(TransformList, _n, (lambda n: lambda self, x: TransformList.__getattr__(self, n)(x))(_n))
+
+    real = {"Transform": Transform, "TransformList": TransformList, "HFlipTransform": HFlipTransform,
+            "VFlipTransform": VFlipTransform, "NoOpTransform": NoOpTransform}
     names = ["Transform", "TransformList", "BlendTransform", "CropTransform", "PadTransform", "GridSampleTransform",
              "HFlipTransform", "VFlipTransform", "NoOpTransform", "ScaleTransform"]
     for n in names:
-        setattr(FT, n, {"Transform": Transform, "TransformList": TransformList}.get(n) or type(n, (Transform,), {}))
+        setattr(FT, n, real.get(n) or type(n, (Transform,), {}))
     FT.__all__ = names
     import fvcore.transforms as FTT
 
@@ -674,6 +742,184 @@ def gen_op_fixtures(roi_align_ref):
     print("wrote ops_golden.npz with", len(out), "arrays")
 
 
+DATA_ROOT = os.path.join(HERE, "data_small")
+DATA_INPUT_OPTS = ["INPUT.MIN_SIZE_TRAIN", (48, 64, 80), "INPUT.MAX_SIZE_TRAIN", 100, "INPUT.MIN_SIZE_TEST", 64,
+                   "INPUT.MAX_SIZE_TEST", 100]
+
+
+def make_small_dataset():
+    """Writes tests/golden/data_small/: 4 jpg images, their semantic label maps and a COCO instances json at the paths
+    the builtin registration expects for CLUSTER_NUM=800 (builtin.py:59-118).  Masks are RLE (compressed strings, one
+    uncompressed list); one annotation is a crowd region, one image has only a crowd annotation."""
+    from PIL import Image
+
+    from u2seg_amd.data import rle
+
+    rs = np.random.RandomState(0)
+    img_dir = os.path.join(DATA_ROOT, "coco", "train2017")
+    ann_dir = os.path.join(DATA_ROOT, "prepare_ours", "u2seg_annotations", "ins_annotations")
+    sem_dir = os.path.join(DATA_ROOT, "prepare_ours", "u2seg_annotations", "panoptic_annotations",
+                           "panoptic_stuff_cocotrain_800")
+    for d in (img_dir, ann_dir, sem_dir):
+        os.makedirs(d, exist_ok=True)
+    sizes = [(48, 64), (60, 40), (50, 50), (36, 72)]  # (h, w): landscape, portrait, square, wide
+    images, annotations, aid = [], [], 1
+    for i, (h, w) in enumerate(sizes):
+        name = "%012d" % (i + 1)
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([xx * 255.0 / w, yy * 255.0 / h, (xx + yy) * 255.0 / (h + w)], axis=2)
+        img = np.clip(base + rs.randn(h, w, 3) * 12, 0, 255).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(img_dir, name + ".jpg"), quality=92)
+        sem = (rs.randint(0, 28, (h // 8 + 1, w // 8 + 1)).repeat(8, 0).repeat(8, 1)[:h, :w]).astype(np.uint8)
+        sem[rs.rand(h, w) < 0.04] = 255
+        Image.fromarray(sem, mode="L").save(os.path.join(sem_dir, name + ".png"))
+        images.append({"id": 10 * (i + 1), "file_name": name + ".jpg", "height": h, "width": w})
+        n_inst = [3, 2, 1, 2][i]
+        for k in range(n_inst):
+            bw, bh = rs.uniform(0.3, 0.7) * w, rs.uniform(0.3, 0.7) * h
+            x0, y0 = rs.uniform(0, w - bw), rs.uniform(0, h - bh)
+            m = (((xx + 0.5 - (x0 + bw / 2)) / (bw / 2)) ** 2 + ((yy + 0.5 - (y0 + bh / 2)) / (bh / 2)) ** 2 <= 1).astype(np.uint8)
+            segm = rle.encode(m)
+            if i == 0 and k == 1:  # one uncompressed RLE (counts as a list), coco.py:189-191
+                segm = {"size": segm["size"], "counts": rle.counts_of(segm)}
+            crowd = 1 if (i == 2 or (i == 0 and k == 2)) else 0  # image 3 holds nothing but a crowd region
+            annotations.append({"id": aid, "image_id": 10 * (i + 1), "category_id": [5, 17, 800, 333][(i + k) % 4],
+                                "iscrowd": crowd, "bbox": [round(x0, 2), round(y0, 2), round(bw, 2), round(bh, 2)],
+                                "area": float(m.sum()), "segmentation": segm})
+            aid += 1
+    cats = [{"id": c + 1, "name": str(c + 1), "supercategory": str(c + 1)} for c in range(800)]
+    json.dump({"images": images, "annotations": annotations, "categories": cats},
+              open(os.path.join(ann_dir, "cocotrain_800.json"), "w"))
+    print("wrote", DATA_ROOT)
+
+
+def install_data_standins():
+    """pycocotools (absent) for the reference's data path: the json index is plain bookkeeping; mask decode / compress go
+    through u2seg_amd.data.rle, which tests/test_host_logic.py pins on the RLE strings the reference's own tests carry."""
+    from u2seg_amd.data import rle
+
+    import pycocotools.coco as PC
+    import pycocotools.mask as PM
+
+    class COCO:
+        def __init__(self, annotation_file):
+            from collections import defaultdict
+
+            data = json.load(open(annotation_file))
+            self.dataset = data
+            self.imgs = {im["id"]: im for im in data["images"]}
+            self.anns = {a["id"]: a for a in data["annotations"]}
+            self.cats = {c["id"]: c for c in data["categories"]}
+            self.imgToAnns = defaultdict(list)
+            for a in data["annotations"]:
+                self.imgToAnns[a["image_id"]].append(a)
+
+        def getCatIds(self):
+            return list(self.cats.keys())
+
+        def loadCats(self, ids):
+            return [self.cats[i] for i in ids]
+
+        def loadImgs(self, ids):
+            return [self.imgs[i] for i in ids]
+
+    PC.COCO = COCO
+    PM.decode = rle.decode
+    PM.encode = rle.encode
+    PM.area = rle.area
+    PM.toBbox = rle.to_bbox
+    PM.frPyObjects = lambda obj, h, w: rle.compress(obj)
+    import fvcore.common.timer as TM
+
+    class Timer:
+        def seconds(self):
+            return 0.0
+
+    TM.Timer = Timer
+
+
+def gen_data_fixture():
+    """Runs the reference's registration (builtin.py with DETECTRON2_DATASETS pointing at data_small), dataset-dict
+    loading, DatasetMapper (train and test) and samplers on the small dataset and records their outputs."""
+    import itertools
+
+    import tempfile
+
+    os.environ.setdefault("CLUSTER_NUM", "800")
+    if not os.path.exists(os.path.join(DATA_ROOT, "coco")):
+        make_small_dataset()
+    # the fork hard-wires the dataset root to ./datasets (builtin.py:279): run from a directory where that is data_small
+    work = tempfile.mkdtemp()
+    os.symlink(DATA_ROOT, os.path.join(work, "datasets"))
+    os.chdir(work)
+    install_standins()
+    install_data_standins()
+    sys.path.insert(0, REF)
+    import types as _types
+
+    sys.modules["detectron2._C"] = _types.ModuleType("detectron2._C")  # the data path touches no compiled op
+    from detectron2.config import get_cfg
+    from detectron2.data import DatasetCatalog, DatasetMapper, MetadataCatalog
+    from detectron2.data.build import get_detection_dataset_dicts
+    from detectron2.data.samplers import InferenceSampler, TrainingSampler
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(REF, "configs/COCO-PanopticSegmentation/u2seg_R50_800.yaml"))
+    cfg.merge_from_list(list(DATA_INPUT_OPTS))
+    name = cfg.DATASETS.TRAIN[0]
+    raw = DatasetCatalog.get(name)
+    dicts = get_detection_dataset_dicts(cfg.DATASETS.TRAIN, filter_empty=cfg.DATALOADER.FILTER_EMPTY_ANNOTATIONS)
+
+    def rel(d):
+        d = copy.deepcopy(d)
+        for k in ("file_name", "sem_seg_file_name"):
+            if k in d:
+                d[k] = os.path.relpath(os.path.realpath(d[k]), os.path.realpath(DATA_ROOT))
+        for a in d.get("annotations", []):
+            a["bbox_mode"] = int(a["bbox_mode"])
+            if isinstance(a.get("segmentation"), dict) and isinstance(a["segmentation"]["counts"], bytes):
+                a["segmentation"]["counts"] = a["segmentation"]["counts"].decode()
+        return d
+
+    meta = MetadataCatalog.get(name)
+    listing = {"train_name": name, "test_name": cfg.DATASETS.TEST[0], "num_raw": len(raw),
+               "dicts": [rel(d) for d in dicts],
+               "meta": {"evaluator_type": meta.evaluator_type, "ignore_label": meta.ignore_label,
+                        "num_thing_classes": len(meta.thing_classes), "num_stuff_classes": len(meta.stuff_classes),
+                        "thing_id_800": meta.thing_dataset_id_to_contiguous_id[800],
+                        "stuff_id_801": meta.stuff_dataset_id_to_contiguous_id[801],
+                        "sem_seg_root": os.path.relpath(os.path.realpath(meta.sem_seg_root), os.path.realpath(DATA_ROOT))},
+               "input_opts": [list(x) if isinstance(x, tuple) else x for x in DATA_INPUT_OPTS],
+               "training_sampler_seed11_size7": list(itertools.islice(iter(TrainingSampler(7, seed=11)), 30)),
+               "inference_shards_10_3": [list(InferenceSampler._get_local_indices(10, 3, r)) for r in range(3)]}
+    arrays, cases = {}, []
+    train_mapper, test_mapper = DatasetMapper(cfg, True), DatasetMapper(cfg, False)
+    for idx in range(len(dicts)):
+        for seed in (0, 1, 2, 3, 4):
+            np.random.seed(1000 * idx + seed)
+            out = train_mapper(dicts[idx])
+            key = "train_%d_%d" % (idx, seed)
+            inst = out["instances"]
+            arrays[key + "_image"] = out["image"].numpy()
+            arrays[key + "_sem_seg"] = out["sem_seg"].numpy().astype(np.uint8)
+            arrays[key + "_boxes"] = inst.gt_boxes.tensor.numpy()
+            arrays[key + "_classes"] = inst.gt_classes.numpy()
+            if inst.has("gt_masks"):  # an image whose only annotation is a crowd region yields no mask field
+                arrays[key + "_masks"] = np.packbits(inst.gt_masks.tensor.numpy(), axis=-1)
+            cases.append({"key": key, "index": idx, "np_seed": 1000 * idx + seed, "image_size": list(inst.image_size),
+                          "height": out["height"], "width": out["width"], "image_id": out["image_id"],
+                          "keys": sorted(out.keys()), "instance_fields": sorted(inst.get_fields().keys())})
+        out = test_mapper(dicts[idx])
+        key = "test_%d" % idx
+        arrays[key + "_image"] = out["image"].numpy()
+        arrays[key + "_sem_seg"] = out["sem_seg"].numpy().astype(np.uint8)
+        cases.append({"key": key, "index": idx, "keys": sorted(out.keys()), "height": out["height"], "width": out["width"]})
+    listing["cases"] = cases
+    json.dump(listing, open(os.path.join(HERE, "data_golden.json"), "w"), indent=1)
+    np.savez_compressed(os.path.join(HERE, "data_golden.npz"), **arrays)
+    print("wrote data_golden", len(cases), "cases;", sorted({tuple(c.get("image_size", ())) for c in cases}))
+
+
 def _import_nn_utils():
     for m in ["pykeops", "pykeops.torch", "torchvision", "torchvision.transforms", "torchvision.datasets", "torchvision.models",
               "yacs", "yacs.config", "termcolor", "clip"]:
@@ -762,6 +1008,9 @@ if __name__ == "__main__":
         gen_kmeans_fixture()
     if a.only in ("", "knn"):
         gen_knn_fixture()
+    if a.only == "data":  # own process: the data stand-ins must be in place before detectron2.data is imported
+        gen_data_fixture()
+        sys.exit(0)
     if a.only in ("", "ops", "model", "model_small", "inference", "trajectory"):
         ra = import_reference()
         if a.only in ("", "ops"):

@@ -4,6 +4,7 @@ compared at the tolerance written next to each check (bf16 storage => 2^-8 relat
 
 Run on the GPU box with:  python -m pytest tests -m gpu -q
 """
+import itertools
 import json
 import os
 
@@ -1071,3 +1072,61 @@ def test_edge_cases_empty_and_ragged_batches(F):
         out = model([{"image": a["image"]}, {"image": b["image"], "height": 256, "width": 384}])
     assert out[0]["sem_seg"].shape == (28, 160, 224) and out[1]["sem_seg"].shape == (28, 256, 384)
     assert out[1]["panoptic_seg"][0].shape == (256, 384)
+
+
+def test_real_data_pipeline_to_model(F):
+    """Small committed dataset -> builtin registration -> DatasetMapper in a loader -> DevicePrefetcher (pinned staging, side
+    stream) -> two optimizer steps: the batches arriving in HBM equal the host-side mapper output bit for bit, images of
+    different sizes and an image whose only annotation is a crowd region (no gt_masks field) train to finite losses."""
+    from u2seg_amd.config import get_cfg
+    from u2seg_amd.data import (DatasetCatalog, DevicePrefetcher, MetadataCatalog, build_detection_train_loader,
+                                register_all_coco)
+    from u2seg_amd.engine.trainer import SimpleTrainer
+    from u2seg_amd.modeling import build_model
+    from u2seg_amd.solver import build_lr_scheduler, build_optimizer
+
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "data_golden.json")))
+    os.environ["CLUSTER_NUM"] = "800"
+    for name in list(DatasetCatalog.keys()):
+        DatasetCatalog.remove(name)
+    for name in list(MetadataCatalog.keys()):
+        MetadataCatalog.remove(name)
+    register_all_coco(os.path.join(ROOT, "tests", "golden", "data_small"))
+    cfg = get_cfg()
+    cfg.merge_from_file(CFG)
+    cfg.merge_from_list(fx["input_opts"] + ["DATALOADER.NUM_WORKERS", 2, "SOLVER.IMS_PER_BATCH", 2, "MODEL.DEVICE", DEV,
+                                           "DATALOADER.ASPECT_RATIO_GROUPING", False])
+    np.random.seed(0)
+    host = list(itertools.islice(iter(build_detection_train_loader(cfg, seed=3)), 4))
+    dev = list(itertools.islice(iter(DevicePrefetcher(build_detection_train_loader(cfg, seed=3), DEV)), 4))
+    ids = []
+    for hb, db in zip(host, dev):
+        for h, d in zip(hb, db):
+            # worker processes draw their own augmentation parameters, so compare what does not depend on them
+            assert h["image_id"] == d["image_id"] and (h["height"], h["width"]) == (d["height"], d["width"])
+            assert d["image"].is_cuda and d["sem_seg"].is_cuda and d["instances"].gt_boxes.tensor.is_cuda
+            assert d["image"].dtype == torch.uint8 and d["image"].shape[1:] == tuple(d["instances"].image_size)
+            ids.append(d["image_id"])
+    assert 30 in ids  # the crowd-only image is part of the stream
+    # single-process loader: the device copy must equal the host batch exactly
+    cfg0 = cfg.clone()
+    cfg0.merge_from_list(["DATALOADER.NUM_WORKERS", 0])
+    np.random.seed(1)
+    host = list(itertools.islice(iter(build_detection_train_loader(cfg0, seed=3)), 3))
+    np.random.seed(1)
+    dev = list(itertools.islice(iter(DevicePrefetcher(build_detection_train_loader(cfg0, seed=3), DEV)), 3))
+    for hb, db in zip(host, dev):
+        for h, d in zip(hb, db):
+            assert torch.equal(h["image"], d["image"].cpu()) and torch.equal(h["sem_seg"], d["sem_seg"].cpu())
+            assert torch.equal(h["instances"].gt_boxes.tensor, d["instances"].gt_boxes.tensor.cpu())
+            assert h["instances"].has("gt_masks") == d["instances"].has("gt_masks")
+            if h["instances"].has("gt_masks"):
+                assert torch.equal(h["instances"].gt_masks.tensor, d["instances"].gt_masks.tensor.cpu())
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model.train()
+    opt = build_optimizer(cfg, model)
+    trainer = SimpleTrainer(model, opt, build_lr_scheduler(cfg, opt))
+    for batch in dev:
+        losses = trainer.run_step(batch)
+        assert len(losses) == 10 and bool(torch.isfinite(sum(v.detach() for v in losses.values())))

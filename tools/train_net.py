@@ -2,8 +2,9 @@
 """Training / evaluation entry point with the CLI contract of the reference's tools/train_net.py:113-164
 (--config-file, --num-gpus, --resume, --eval-only, trailing KEY VALUE overrides).  One process per GPU: launch N > 1 with
     python -m torch.distributed.run --nproc-per-node N tools/train_net.py --num-gpus N --config-file ...
-Data: this build ships the synthetic COCO-panoptic-shaped generator only (the reference's dataset registry, mappers and
-evaluators are out of scope), selected with DATASETS.TRAIN ("synthetic",) or when no dataset is registered.
+Data: when the dataset DATASETS.TRAIN names is on disk (builtin registration under ./datasets or $DETECTRON2_DATASETS,
+u2seg_amd/data/datasets.py) batches come from the real pipeline - DatasetMapper in DataLoader workers, aspect-ratio
+grouping, DevicePrefetcher into HBM; otherwise (or with DATASETS.TRAIN ("synthetic",)) from the synthetic generator.
 Deviation (recorded in DESIGN.md): the reference hard-wires --eval-only to True (engine/defaults.py:109); here it is a flag."""
 import os
 import sys
@@ -16,7 +17,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from u2seg_amd.checkpoint import DetectionCheckpointer  # noqa: E402
 from u2seg_amd.config import get_cfg  # noqa: E402
-from u2seg_amd.data import make_synthetic_batch  # noqa: E402
+from u2seg_amd.data import (DatasetCatalog, DevicePrefetcher, MetadataCatalog, build_detection_train_loader,  # noqa: E402
+                            make_synthetic_batch, register_all_coco)
 from u2seg_amd.engine import SimpleTrainer, default_argument_parser, launch_info  # noqa: E402
 from u2seg_amd.modeling import build_model  # noqa: E402
 from u2seg_amd.solver import build_lr_scheduler, build_optimizer  # noqa: E402
@@ -28,6 +30,20 @@ def setup(args):
     cfg.merge_from_list(args.opts)
     cfg.freeze()
     return cfg
+
+
+def real_batches(cfg, device):
+    """Iterator over device-resident training batches of the real dataset, or None when it is not on disk."""
+    names = [n for n in cfg.DATASETS.TRAIN if n != "synthetic"]
+    if not names:
+        return None
+    register_all_coco()
+    for n in names:
+        meta = MetadataCatalog.get(n)
+        if n not in DatasetCatalog or not os.path.isfile(meta.get("json_file", "")) or not os.path.isdir(meta.get("image_root", "")):
+            return None
+    loader = build_detection_train_loader(cfg, seed=None if cfg.SEED < 0 else cfg.SEED)
+    return iter(DevicePrefetcher(loader, device) if str(device).startswith("cuda") else loader)
 
 
 def main(args):
@@ -65,9 +81,15 @@ def main(args):
         start_iter = int(rest.get("iteration", -1)) + 1 if args.resume else 0
     elif cfg.MODEL.WEIGHTS and rank == 0:
         print("MODEL.WEIGHTS %s not found: random initialisation" % cfg.MODEL.WEIGHTS)
+    stream = real_batches(cfg, c.MODEL.DEVICE)
+    if rank == 0:
+        print("data: %s" % ("real pipeline over %s" % (cfg.DATASETS.TRAIN,) if stream is not None else "synthetic generator"))
     t0 = time.time()
     for it in range(start_iter, cfg.SOLVER.MAX_ITER):
-        batch = make_synthetic_batch(per_gpu, start_index=(it * world + rank) * per_gpu, device=c.MODEL.DEVICE)
+        if stream is not None:
+            batch = next(stream)
+        else:
+            batch = make_synthetic_batch(per_gpu, start_index=(it * world + rank) * per_gpu, device=c.MODEL.DEVICE)
         trainer.run_step(batch)
         if rank == 0 and (it % 20 == 0 or it == cfg.SOLVER.MAX_ITER - 1):
             total = trainer.check_finite()

@@ -1,0 +1,171 @@
+"""Image reading and annotation handling of the input pipeline (detectron2/data/detection_utils.py:60-211, 257-331,
+382-455, 486-520, 629-655; structures/boxes.py:15-131 for BoxMode)."""
+import enum
+
+import numpy as np
+import torch
+from PIL import Image
+
+from ..structures import BitMasks, Boxes, Instances
+from . import rle
+from . import transforms as T
+
+_EXIF_ORIENT = 274  # exif 'Orientation' tag
+
+
+class SizeMismatchError(ValueError):
+    """The loaded image has a different width / height than the annotation says."""
+
+
+class BoxMode(enum.IntEnum):
+    XYXY_ABS = 0
+    XYWH_ABS = 1
+
+    @staticmethod
+    def convert(box, from_mode, to_mode):
+        """Returns the type it was given.  A list / tuple goes through torch.tensor(box) like the reference
+        (structures/boxes.py:62-131), i.e. json floats are added in fp32 and json ints stay ints - gt boxes are
+        bit-identical only if this detail is kept; ndarrays keep their dtype."""
+        if from_mode == to_mode:
+            return box
+        single = isinstance(box, (list, tuple))
+        if single:
+            assert len(box) == 4, "BoxMode.convert takes either a k-tuple/list or an Nxk array/tensor, where k == 4"
+            arr = torch.tensor(box)[None, :]
+        elif isinstance(box, np.ndarray):
+            arr = torch.from_numpy(np.asarray(box)).clone()
+        else:
+            arr = box.clone()
+        if from_mode == BoxMode.XYWH_ABS and to_mode == BoxMode.XYXY_ABS:
+            arr[:, 2] += arr[:, 0]
+            arr[:, 3] += arr[:, 1]
+        elif from_mode == BoxMode.XYXY_ABS and to_mode == BoxMode.XYWH_ABS:
+            arr[:, 2] -= arr[:, 0]
+            arr[:, 3] -= arr[:, 1]
+        else:
+            raise NotImplementedError("Conversion from BoxMode {} to {} is not supported".format(from_mode, to_mode))
+        if single:
+            return type(box)(arr.flatten().tolist())
+        return arr.numpy() if isinstance(box, np.ndarray) else arr
+
+
+def _apply_exif_orientation(image):
+    try:
+        exif = image.getexif()
+    except Exception:
+        return image
+    method = {2: Image.FLIP_LEFT_RIGHT, 3: Image.ROTATE_180, 4: Image.FLIP_TOP_BOTTOM, 5: Image.TRANSPOSE,
+              6: Image.ROTATE_270, 7: Image.TRANSVERSE, 8: Image.ROTATE_90}.get(exif.get(_EXIF_ORIENT) if exif else None)
+    return image.transpose(method) if method is not None else image
+
+
+def convert_PIL_to_numpy(image, format):
+    if format is not None:
+        image = image.convert("RGB" if format == "BGR" else format)
+    image = np.asarray(image)
+    if format == "L":
+        image = np.expand_dims(image, -1)
+    elif format == "BGR":
+        image = image[:, :, ::-1]
+    return image
+
+
+def read_image(file_name, format=None):
+    """HWC uint8 array in `format` ("RGB", "BGR", "L", any PIL mode), exif orientation applied."""
+    assert format != "YUV-BT.601", "not used by the U2Seg configs (INPUT.FORMAT is RGB)"
+    with open(file_name, "rb") as f:
+        image = Image.open(f)
+        image = _apply_exif_orientation(image)
+        return convert_PIL_to_numpy(image, format)
+
+
+def check_image_size(dataset_dict, image):
+    if "width" in dataset_dict or "height" in dataset_dict:
+        image_wh = (image.shape[1], image.shape[0])
+        expected_wh = (dataset_dict["width"], dataset_dict["height"])
+        if not image_wh == expected_wh:
+            raise SizeMismatchError("Mismatched image shape{}, got {}, expect {}.".format(
+                " for image " + dataset_dict["file_name"] if "file_name" in dataset_dict else "", image_wh, expected_wh)
+                + " Please check the width/height in your annotation.")
+    if "width" not in dataset_dict:
+        dataset_dict["width"] = image.shape[1]
+    if "height" not in dataset_dict:
+        dataset_dict["height"] = image.shape[0]
+
+
+def transform_instance_annotations(annotation, transforms, image_size):
+    """Box through apply_box + clip to the new image, RLE / bitmap masks through apply_segmentation, polygons through
+    apply_polygons (detection_utils.py:270-331); bbox_mode becomes XYXY_ABS.  Modifies and returns `annotation`."""
+    if isinstance(transforms, (tuple, list)):
+        transforms = T.TransformList(transforms)
+    bbox = BoxMode.convert(annotation["bbox"], annotation["bbox_mode"], BoxMode.XYXY_ABS)
+    bbox = transforms.apply_box(np.array([bbox]))[0].clip(min=0)
+    annotation["bbox"] = np.minimum(bbox, list(image_size + image_size)[::-1])
+    annotation["bbox_mode"] = BoxMode.XYXY_ABS
+    if "segmentation" in annotation:
+        segm = annotation["segmentation"]
+        if isinstance(segm, list):
+            polygons = [np.asarray(p, dtype=np.float64).reshape(-1, 2) for p in segm]
+            annotation["segmentation"] = [p.reshape(-1) for p in transforms.apply_polygons(polygons)]
+        elif isinstance(segm, dict):
+            mask = transforms.apply_segmentation(rle.decode(segm))
+            assert tuple(mask.shape[:2]) == image_size
+            annotation["segmentation"] = mask
+        else:
+            raise ValueError("Cannot transform segmentation of type '{}'!Supported types are: polygons as list[list[float] "
+                             "or ndarray], COCO-style RLE as a dict.".format(type(segm)))
+    return annotation
+
+
+def annotations_to_instances(annos, image_size, mask_format="polygon"):
+    """detection_utils.py:382-455 for the bitmask format the U2Seg configs use."""
+    boxes = (np.stack([BoxMode.convert(obj["bbox"], obj["bbox_mode"], BoxMode.XYXY_ABS) for obj in annos])
+             if len(annos) else np.zeros((0, 4)))
+    target = Instances(image_size)
+    target.gt_boxes = Boxes(torch.as_tensor(boxes, dtype=torch.float32).reshape(-1, 4))
+    target.gt_classes = torch.tensor([int(obj["category_id"]) for obj in annos], dtype=torch.int64)
+    if len(annos) and "segmentation" in annos[0]:
+        if mask_format != "bitmask":
+            raise NotImplementedError("INPUT.MASK_FORMAT '%s': the U2Seg configs use 'bitmask' (RLE pseudo-labels); polygon "
+                                      "rasterisation needs pycocotools" % mask_format)
+        masks = []
+        for obj in annos:
+            segm = obj["segmentation"]
+            if isinstance(segm, dict):
+                masks.append(rle.decode(segm))
+            elif isinstance(segm, np.ndarray):
+                assert segm.ndim == 2, "Expect segmentation of 2 dimensions, got {}.".format(segm.ndim)
+                masks.append(segm)
+            else:
+                raise ValueError("Cannot convert segmentation of type '{}' to BitMasks!".format(type(segm)))
+        target.gt_masks = BitMasks(torch.stack([torch.from_numpy(np.array(x, order="C")) for x in masks]))
+    return target
+
+
+def filter_empty_instances(instances, by_box=True, by_mask=True, box_threshold=1e-5):
+    assert by_box or by_mask
+    keep = []
+    if by_box:
+        keep.append(instances.gt_boxes.nonempty(threshold=box_threshold))
+    if instances.has("gt_masks") and by_mask:
+        keep.append(instances.gt_masks.nonempty())
+    if not keep:
+        return instances
+    m = keep[0]
+    for x in keep[1:]:
+        m = m & x
+    return instances[m]
+
+
+def build_augmentation(cfg, is_train):
+    """detection_utils.py:629-655: ResizeShortestEdge (+ RandomFlip in training)."""
+    if is_train:
+        min_size, max_size = cfg.INPUT.MIN_SIZE_TRAIN, cfg.INPUT.MAX_SIZE_TRAIN
+        sample_style = cfg.INPUT.MIN_SIZE_TRAIN_SAMPLING
+    else:
+        min_size, max_size, sample_style = cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST, "choice"
+    augmentation = [T.ResizeShortestEdge(min_size, max_size, sample_style)]
+    if is_train and cfg.INPUT.RANDOM_FLIP != "none":
+        augmentation.append(T.RandomFlip(horizontal=cfg.INPUT.RANDOM_FLIP == "horizontal",
+                                         vertical=cfg.INPUT.RANDOM_FLIP == "vertical"))
+    return augmentation
