@@ -108,7 +108,8 @@ def transform_instance_annotations(annotation, transforms, image_size):
             polygons = [np.asarray(p, dtype=np.float64).reshape(-1, 2) for p in segm]
             annotation["segmentation"] = [p.reshape(-1) for p in transforms.apply_polygons(polygons)]
         elif isinstance(segm, dict):
-            mask = transforms.apply_segmentation(rle.decode(segm))
+            # row-major before resizing: PIL reads a column-major view (what the RLE scan order yields) twice as slowly
+            mask = transforms.apply_segmentation(np.ascontiguousarray(rle.decode(segm)))
             assert tuple(mask.shape[:2]) == image_size
             annotation["segmentation"] = mask
         else:
@@ -128,17 +129,17 @@ def annotations_to_instances(annos, image_size, mask_format="polygon"):
         if mask_format != "bitmask":
             raise NotImplementedError("INPUT.MASK_FORMAT '%s': the U2Seg configs use 'bitmask' (RLE pseudo-labels); polygon "
                                       "rasterisation needs pycocotools" % mask_format)
-        masks = []
-        for obj in annos:
+        out = torch.empty((len(annos),) + tuple(image_size), dtype=torch.bool)
+        view = out.numpy()  # written in place: one pass per mask, whatever its strides (flipped views, Fortran order)
+        for i, obj in enumerate(annos):
             segm = obj["segmentation"]
             if isinstance(segm, dict):
-                masks.append(rle.decode(segm))
-            elif isinstance(segm, np.ndarray):
-                assert segm.ndim == 2, "Expect segmentation of 2 dimensions, got {}.".format(segm.ndim)
-                masks.append(segm)
-            else:
+                segm = rle.decode(segm)
+            elif not isinstance(segm, np.ndarray):
                 raise ValueError("Cannot convert segmentation of type '{}' to BitMasks!".format(type(segm)))
-        target.gt_masks = BitMasks(torch.stack([torch.from_numpy(np.array(x, order="C")) for x in masks]))
+            assert segm.ndim == 2, "Expect segmentation of 2 dimensions, got {}.".format(segm.ndim)
+            np.not_equal(segm, 0, out=view[i])
+        target.gt_masks = BitMasks(out)
     return target
 
 
