@@ -245,3 +245,80 @@ def test_train_and_test_loaders(small):
     test_loader = build_detection_test_loader(cfg, cfg.DATASETS.TRAIN[0])
     seen = [b[0]["image_id"] for b in test_loader]
     assert seen == [d["image_id"] for d in fx["dicts"]]
+
+
+def test_prefetcher_staging_logic(small):
+    """DevicePrefetcher's packing into reusable staging blocks (here unpinned, target "cpu"; the GPU test runs the pinned /
+    side-stream form): five batches through three blocks come out equal to the loader's own output, label maps keep int64."""
+    from u2seg_amd.data import DevicePrefetcher
+
+    cfg, _, _ = small
+    cfg = cfg.clone()
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 2])
+    np.random.seed(1)
+    host = list(itertools.islice(iter(build_detection_train_loader(cfg, seed=3)), 5))
+    np.random.seed(1)
+    staged = list(itertools.islice(iter(DevicePrefetcher(build_detection_train_loader(cfg, seed=3), "cpu", _pinned=False)), 5))
+    assert len(staged) == 5
+    for hb, sb in zip(host, staged):
+        for h, d in zip(hb, sb):
+            assert sorted(h.keys()) == sorted(d.keys()) and h["file_name"] == d["file_name"]
+            assert torch.equal(h["image"], d["image"]) and torch.equal(h["sem_seg"], d["sem_seg"])
+            assert d["sem_seg"].dtype == torch.int64
+            hi, di = h["instances"], d["instances"]
+            assert sorted(hi.get_fields()) == sorted(di.get_fields()) and hi.image_size == di.image_size
+            assert torch.equal(hi.gt_boxes.tensor, di.gt_boxes.tensor) and torch.equal(hi.gt_classes, di.gt_classes)
+            if hi.has("gt_masks"):
+                assert torch.equal(hi.gt_masks.tensor, di.gt_masks.tensor)
+    with pytest.raises(AssertionError):
+        DevicePrefetcher([], "cpu")  # the product form needs a GPU
+
+
+def test_slot_transport_round_trip(small):
+    """data/slots.py: a mapped batch packed into a shared-memory slot (label maps as bytes, masks as bits) and rebuilt
+    from the block equals the original, field for field; an oversized batch falls back to the plain list; with loader
+    workers the batches keep one orientation each and arrive complete."""
+    from u2seg_amd.data.build import BatchIndexStream
+    from u2seg_amd.data.slots import BatchPacker, PackedBatch, SlotRing, unpack
+
+    cfg, _, _ = small
+    cfg = cfg.clone()
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 4, "DATALOADER.ASPECT_RATIO_GROUPING", False])
+    np.random.seed(7)
+    batches = list(itertools.islice(iter(build_detection_train_loader(cfg, seed=2)), 3))
+    ring = SlotRing(1, 4 << 20, 3)
+    packer = BatchPacker(ring)
+    for k, batch in enumerate(batches):
+        packed = packer(batch)
+        assert isinstance(packed, PackedBatch) and packed.slot == k % 3 and packed.nbytes % 256 == 0
+        rebuilt = unpack(torch.from_numpy(ring.view(packed.slot)[: packed.nbytes].copy()), packed.samples)
+        for h, d in zip(batch, rebuilt):
+            assert list(h.keys()) == list(d.keys())
+            for key in ("file_name", "height", "width", "image_id"):
+                assert h[key] == d[key]
+            assert torch.equal(h["image"], d["image"]) and d["image"].dtype == torch.uint8
+            assert torch.equal(h["sem_seg"], d["sem_seg"]) and d["sem_seg"].dtype == torch.int64
+            hi, di = h["instances"], d["instances"]
+            assert list(hi.get_fields()) == list(di.get_fields()) and hi.image_size == di.image_size
+            assert torch.equal(hi.gt_boxes.tensor, di.gt_boxes.tensor) and di.gt_boxes.tensor.dtype == torch.float32
+            assert torch.equal(hi.gt_classes, di.gt_classes) and di.gt_classes.dtype == torch.int64
+            if hi.has("gt_masks"):
+                assert di.gt_masks.tensor.dtype == torch.bool and torch.equal(hi.gt_masks.tensor, di.gt_masks.tensor)
+    assert BatchPacker(SlotRing(1, 1024, 3))(batches[0]) is batches[0]  # does not fit: plain list
+    assert BatchPacker(None)(batches[0]) is batches[0]
+    # index-level grouping == AspectRatioGroupedDataset on the mapped stream
+    land = [True, False, True, False, False, True]
+    assert list(BatchIndexStream([0, 1, 2, 3, 4, 5], 2, land)) == [[0, 2], [1, 3]]
+    assert list(BatchIndexStream(range(5), 2)) == [[0, 1], [2, 3]]
+    # through worker processes
+    cfg.merge_from_list(["DATALOADER.NUM_WORKERS", 2, "DATALOADER.ASPECT_RATIO_GROUPING", True, "SOLVER.IMS_PER_BATCH", 2])
+    loader = build_detection_train_loader(cfg, seed=5)
+    got = list(itertools.islice(iter(loader), 6))
+    sampler_order = list(itertools.islice(iter(TrainingSampler(4, seed=5)), 40))
+    ids = [10, 20, 30, 40]  # dataset order; 20 is the portrait image, 30 the square one (counts as portrait: w > h fails)
+    want = list(itertools.islice(iter(BatchIndexStream(sampler_order, 2, [True, False, False, True])), 6))
+    assert [[d["image_id"] for d in b] for b in got] == [[ids[i] for i in b] for b in want]
+    for b in got:
+        assert len({d["width"] > d["height"] for d in b}) == 1
+        for d in b:
+            assert d["image"].shape[1:] == tuple(d["instances"].image_size) == tuple(d["sem_seg"].shape)

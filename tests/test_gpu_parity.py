@@ -1122,6 +1122,23 @@ def test_real_data_pipeline_to_model(F):
             assert h["instances"].has("gt_masks") == d["instances"].has("gt_masks")
             if h["instances"].has("gt_masks"):
                 assert torch.equal(h["instances"].gt_masks.tensor, d["instances"].gt_masks.tensor.cpu())
+    # the shared-memory slot form (what worker processes send): packed on the host, rebuilt on the device from one block
+    from u2seg_amd.data.slots import BatchPacker, SlotRing
+
+    ring = SlotRing(1, 8 << 20, 3)
+    pre = DevicePrefetcher([], DEV)
+    pre.ring = ring
+    for hb in host:
+        moved, done = pre._stage_packed(BatchPacker(ring)(hb))
+        done.synchronize()
+        for h, d in zip(hb, moved):
+            assert torch.equal(h["image"], d["image"].cpu()) and torch.equal(h["sem_seg"], d["sem_seg"].cpu())
+            assert d["sem_seg"].dtype == torch.int64 and d["image"].is_cuda
+            assert torch.equal(h["instances"].gt_boxes.tensor, d["instances"].gt_boxes.tensor.cpu())
+            assert torch.equal(h["instances"].gt_classes, d["instances"].gt_classes.cpu())
+            if h["instances"].has("gt_masks"):
+                assert d["instances"].gt_masks.tensor.dtype == torch.bool
+                assert torch.equal(h["instances"].gt_masks.tensor, d["instances"].gt_masks.tensor.cpu())
     torch.manual_seed(0)
     model = build_model(cfg)
     model.train()

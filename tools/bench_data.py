@@ -74,8 +74,11 @@ def main():
         cfg.defrost()
         cfg.merge_from_list(["DATALOADER.NUM_WORKERS", nw])
         loader = build_detection_train_loader(cfg, seed=1)
-        stream = iter(DevicePrefetcher(loader, a.device) if a.device.startswith("cuda") else loader)
+        pre = DevicePrefetcher(loader, a.device) if a.device.startswith("cuda") else None
+        stream = iter(pre if pre is not None else loader)
         next(stream)  # worker start-up
+        if pre is not None:
+            pre.seconds_waiting_for_loader = pre.seconds_staging = 0.0
         t0, n, px = time.time(), 0, 0
         for _ in range(a.batches):
             batch = next(stream)
@@ -85,8 +88,11 @@ def main():
             torch.cuda.synchronize()
         dt = time.time() - t0
         print(json.dumps({"metric": "input pipeline img/s", "workers": nw, "batch": len(batch), "img_per_s": round(n / dt, 1),
-                          "mean_megapixels": round(px / n / 1e6, 2), "to_device": a.device}))
-        del stream, loader
+                          "mean_megapixels": round(px / n / 1e6, 2), "to_device": a.device,
+                          "host_s_waiting_for_loader": round(pre.seconds_waiting_for_loader, 2) if pre else None,
+                          "host_s_staging": round(pre.seconds_staging, 2) if pre else None, "wall_s": round(dt, 2),
+                          "host_threads": torch.get_num_threads()}))
+        del stream, loader, pre
 
 
 if __name__ == "__main__":

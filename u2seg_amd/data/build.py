@@ -4,8 +4,10 @@ samplers/distributed_sampler.py:16-95, 236-277; common.py:241-300), plus the hos
 One process per GPU: every rank walks the same seeded infinite permutation stream and keeps every world_size-th index
 (no exchange between ranks on the data path).  Decoding and resizing run in DataLoader worker processes; `DevicePrefetcher`
 moves the mapped batches through pinned buffers on a side stream so the copy of batch i + 1 overlaps the step on batch i."""
+import contextlib
 import itertools
 import logging
+import time
 
 import numpy as np
 import torch
@@ -199,13 +201,48 @@ def get_detection_dataset_dicts(names, filter_empty=True):
     return dataset_dicts
 
 
+class BatchIndexStream:
+    """Per-GPU batches of dataset indices in sampler order; with `landscape` (one bool per dataset index) the landscape and
+    portrait images fill separate buckets exactly like AspectRatioGroupedDataset does after mapping - the orientation
+    of an image is known from its dataset dict, so the grouping can happen before any pixel is read and a worker can map a
+    whole batch."""
+
+    def __init__(self, sampler, batch_size, landscape=None):
+        self.sampler, self.batch_size, self.landscape = sampler, batch_size, landscape
+        self._buckets = [[], []]
+
+    def __iter__(self):
+        for idx in self.sampler:
+            bucket = self._buckets[0 if (self.landscape is None or self.landscape[idx]) else 1]
+            bucket.append(idx)
+            if len(bucket) == self.batch_size:
+                batch = bucket[:]
+                del bucket[:]
+                yield batch
+
+
 def build_batch_data_loader(dataset, sampler, total_batch_size, *, aspect_ratio_grouping=False, num_workers=0,
-                            collate_fn=None, **kwargs):
-    """Iterable of lists of mapped dicts, total_batch_size / world_size per list (build.py:294-359)."""
+                            collate_fn=None, slot_megabytes=128, **kwargs):
+    """Iterable of lists of mapped dicts, total_batch_size / world_size per list (build.py:294-359).
+
+    num_workers == 0: the reference's sample-level structure.  With workers, and when every dataset dict carries its width
+    and height, batches are formed on the index stream and travel through shared-memory slots (data/slots.py)."""
     world = _rank_world()[1]
     assert total_batch_size > 0 and total_batch_size % world == 0, \
         "Total batch size ({}) must be divisible by the number of gpus ({}).".format(total_batch_size, world)
     batch_size = total_batch_size // world
+    base = getattr(dataset, "_dataset", None)
+    sized = base is not None and all("width" in d and "height" in d for d in base)
+    if num_workers > 0 and collate_fn is None and (sized or not aspect_ratio_grouping):
+        from .slots import BatchPacker, HostUnpacked, SlotRing
+
+        landscape = [d["width"] > d["height"] for d in base] if aspect_ratio_grouping else None
+        prefetch = kwargs.pop("prefetch_factor", 2)
+        ring = SlotRing(num_workers, slot_megabytes << 20, prefetch + 2)
+        loader = torchdata.DataLoader(dataset, batch_sampler=BatchIndexStream(sampler, batch_size, landscape),
+                                      num_workers=num_workers, collate_fn=BatchPacker(ring), prefetch_factor=prefetch,
+                                      worker_init_fn=worker_init_reset_seed, **kwargs)
+        return HostUnpacked(loader, ring)
     stream = _SampledStream(dataset, sampler, chunk=batch_size)
     if aspect_ratio_grouping:
         loader = torchdata.DataLoader(stream, num_workers=num_workers, collate_fn=_first, batch_size=1,
@@ -241,60 +278,159 @@ def build_detection_test_loader(cfg, dataset_name, mapper=None, batch_size=1):
                                 num_workers=cfg.DATALOADER.NUM_WORKERS, collate_fn=trivial_batch_collator)
 
 
+class _StagingArena:
+    """One reusable block of (pinned) host memory: the tensors of a batch are packed into it back to back and copied to
+    the device from there.  Pinning is paid once (hipHostMalloc costs milliseconds per call, a mapped batch is ~100 MB),
+    not per tensor per step."""
+
+    ALIGN = 256
+
+    def __init__(self, pinned):
+        self.pinned, self.buf, self.used, self.done = pinned, None, 0, None
+
+    def reset(self, nbytes):
+        if self.done is not None:
+            self.done.synchronize()  # the device copies that read this block have finished
+            self.done = None
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(int(nbytes * 1.25) + self.ALIGN, dtype=torch.uint8, pin_memory=self.pinned)
+        self.used = 0
+
+    def put(self, t):
+        """Copy of `t` inside the block (same dtype and shape).  The copy is a plain single-threaded numpy memcpy: a
+        torch copy_ fans a few MB out over every host core, which on a 128-thread box costs more than the copy."""
+        n = t.numel() * t.element_size()
+        start = self.used
+        self.used = (start + n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        dst = self.buf[start:start + n].view(t.dtype).view(t.shape)
+        np.copyto(dst.numpy(), t.numpy(), casting="no")
+        return dst
+
+    @classmethod
+    def footprint(cls, tensors):
+        return sum((t.numel() * t.element_size() + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN for t in tensors)
+
+
 class DevicePrefetcher:
     """Wraps an iterable of batches (lists of mapped dicts) and yields them with every tensor resident on `device`.
 
-    The next batch is staged through pinned host memory and copied on a dedicated HIP stream while the caller still
-    computes on the current one; before a batch is handed out the consumer stream waits on the copy's event, and the
-    tensors are recorded on the consumer stream so the caching allocator does not recycle them early."""
+    The next batch is packed into one of three reusable pinned staging blocks and copied on a dedicated HIP stream while
+    the caller still computes on the current one; before a batch is handed out the consumer stream waits on the copy's
+    event, and the tensors are recorded on the consumer stream so the caching allocator does not recycle them early.
+    Label maps travel as bytes (the mapper's int64 has 8x the volume for values 0..255) and are widened on the device."""
 
-    def __init__(self, loader, device):
-        self.loader, self.device = loader, torch.device(device)
-        assert self.device.type == "cuda", "DevicePrefetcher moves batches into HBM; it needs a GPU device"
-        self.stream = torch.cuda.Stream(device=self.device)
-
-    def _stage(self, batch):
-        with torch.cuda.stream(self.stream):
-            moved = [{k: self._to_device(v) for k, v in d.items()} for d in batch]
-            done = torch.cuda.Event()
-            done.record(self.stream)
-        return moved, done
-
-    def _to_device(self, v):
-        if isinstance(v, torch.Tensor):
-            return (v if v.is_pinned() else v.pin_memory()).to(self.device, non_blocking=True)
-        if hasattr(v, "to") and hasattr(v, "get_fields"):  # Instances: move field by field through pinned memory
-            out = type(v)(v.image_size)
-            for name, field in v.get_fields().items():
-                t = getattr(field, "tensor", field)
-                t = (t if t.is_pinned() else t.pin_memory()).to(self.device, non_blocking=True)
-                out.set(name, type(field)(t) if hasattr(field, "tensor") else t)
-            return out
-        return v
+    def __init__(self, loader, device, _pinned=True):
+        self.ring = getattr(loader, "ring", None)  # HostUnpacked: take the packed stream and unpack on the device instead
+        self.loader, self.device = getattr(loader, "packed", loader), torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
+        assert self.on_gpu or not _pinned, "DevicePrefetcher moves batches into HBM; it needs a GPU device"
+        self.stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        self.arenas = [_StagingArena(_pinned) for _ in range(3)]
+        self.turn = 0
+        self.seconds_waiting_for_loader = self.seconds_staging = 0.0  # where the host time of this iterator went
 
     @staticmethod
-    def _record(obj, stream):
-        if isinstance(obj, torch.Tensor):
-            obj.record_stream(stream)
-        elif hasattr(obj, "get_fields"):
-            for field in obj.get_fields().values():
-                getattr(field, "tensor", field).record_stream(stream)
+    def _tensors_of(v):
+        if isinstance(v, torch.Tensor):
+            return [v]
+        if hasattr(v, "get_fields"):
+            return [getattr(f, "tensor", f) for f in v.get_fields().values()]
+        return []
+
+    @staticmethod
+    def _narrow(t):
+        """Host-side representation that is copied: int64 label maps as uint8 when their values allow it (numpy, single
+        thread, for the reason given at _StagingArena.put)."""
+        if t.dtype == torch.int64 and t.dim() == 2 and t.numel() > 4096:
+            a = t.numpy()
+            if 0 <= int(a.min()) and int(a.max()) <= 255:
+                return torch.from_numpy(a.astype(np.uint8)), torch.int64
+        return t, None
+
+    def _move(self, arena, t):
+        host, widen = self._narrow(t)
+        staged = arena.put(host)
+        dev = staged.to(self.device, non_blocking=True) if self.on_gpu else staged.clone()  # (CPU: test configuration)
+        return dev.to(widen) if widen is not None else dev
+
+    def _stage_packed(self, packed):
+        """A batch that arrived in a shared-memory slot: one memcpy into the pinned block, one host-to-device copy, the
+        tensors rebuilt on the device as views of that block (label maps and bit-packed masks widened there)."""
+        from .slots import unpack
+
+        arena = self.arenas[self.turn]
+        self.turn = (self.turn + 1) % len(self.arenas)
+        arena.reset(packed.nbytes)
+        np.copyto(arena.buf[: packed.nbytes].numpy(), self.ring.view(packed.slot)[: packed.nbytes])
+        ctx = torch.cuda.stream(self.stream) if self.on_gpu else contextlib.nullcontext()
+        with ctx:
+            staged = arena.buf[: packed.nbytes]
+            block = staged.to(self.device, non_blocking=True) if self.on_gpu else staged.clone()
+            moved = unpack(block, packed.samples)
+            done = None
+            if self.on_gpu:
+                done = torch.cuda.Event()
+                done.record(self.stream)
+                arena.done = done
+                block.record_stream(torch.cuda.current_stream(self.device))
+        return moved, done
+
+    def _stage(self, batch):
+        if not isinstance(batch, list):
+            return self._stage_packed(batch)
+        arena = self.arenas[self.turn]
+        self.turn = (self.turn + 1) % len(self.arenas)
+        arena.reset(_StagingArena.footprint([t for d in batch for v in d.values() for t in self._tensors_of(v)]))
+        ctx = torch.cuda.stream(self.stream) if self.on_gpu else contextlib.nullcontext()
+        with ctx:
+            moved = []
+            for d in batch:
+                out = {}
+                for k, v in d.items():
+                    if isinstance(v, torch.Tensor):
+                        out[k] = self._move(arena, v)
+                    elif hasattr(v, "get_fields"):  # Instances: field by field, wrappers (Boxes, BitMasks) rebuilt
+                        inst = type(v)(v.image_size)
+                        for name, field in v.get_fields().items():
+                            t = self._move(arena, getattr(field, "tensor", field))
+                            inst.set(name, type(field)(t) if hasattr(field, "tensor") else t)
+                        out[k] = inst
+                    else:
+                        out[k] = v
+                moved.append(out)
+            done = None
+            if self.on_gpu:
+                done = torch.cuda.Event()
+                done.record(self.stream)
+                arena.done = done
+        return moved, done
+
+    def _record(self, batch):
+        cur = torch.cuda.current_stream(self.device)
+        for d in batch:
+            for v in d.values():
+                for t in self._tensors_of(v):
+                    t.record_stream(cur)
+
+    def _next_staged(self, it):
+        t0 = time.perf_counter()
+        try:
+            batch = next(it)
+        except StopIteration:
+            return None
+        t1 = time.perf_counter()
+        staged = self._stage(batch)
+        self.seconds_waiting_for_loader += t1 - t0
+        self.seconds_staging += time.perf_counter() - t1
+        return staged
 
     def __iter__(self):
         it = iter(self.loader)
-        try:
-            pending = self._stage(next(it))
-        except StopIteration:
-            return
+        pending = self._next_staged(it)
         while pending is not None:
             batch, done = pending
-            try:
-                pending = self._stage(next(it))
-            except StopIteration:
-                pending = None
-            cur = torch.cuda.current_stream(self.device)
-            cur.wait_event(done)
-            for d in batch:
-                for v in d.values():
-                    self._record(v, cur)
+            pending = self._next_staged(it)
+            if self.on_gpu:
+                torch.cuda.current_stream(self.device).wait_event(done)
+                self._record(batch)
             yield batch
