@@ -55,7 +55,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=48)
     ap.add_argument("--workers", type=int, nargs="+", default=[0, 8, 32])
-    ap.add_argument("--batches", type=int, default=12)
+    ap.add_argument("--batches", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--device", default="cuda:0" if torch.cuda.is_available() else "cpu")
     a = ap.parse_args()
     os.environ["CLUSTER_NUM"] = "800"
@@ -76,7 +77,8 @@ def main():
         loader = build_detection_train_loader(cfg, seed=1)
         pre = DevicePrefetcher(loader, a.device) if a.device.startswith("cuda") else None
         stream = iter(pre if pre is not None else loader)
-        next(stream)  # worker start-up
+        for _ in range(a.warmup):  # worker start-up, pinned staging blocks, and the batches the workers prefetched
+            next(stream)
         if pre is not None:
             pre.seconds_waiting_for_loader = pre.seconds_staging = 0.0
         t0, n, px = time.time(), 0, 0

@@ -360,7 +360,7 @@ class DevicePrefetcher:
 
         arena = self.arenas[self.turn]
         self.turn = (self.turn + 1) % len(self.arenas)
-        arena.reset(packed.nbytes)
+        arena.reset(self.ring.slot_bytes)  # full slot size from the start: the pinned block is allocated exactly once
         np.copyto(arena.buf[: packed.nbytes].numpy(), self.ring.view(packed.slot)[: packed.nbytes])
         ctx = torch.cuda.stream(self.stream) if self.on_gpu else contextlib.nullcontext()
         with ctx:
