@@ -718,67 +718,6 @@ def test_whole_model_vs_oracle(F):
     assert gn == gn and gn > 0
 
 
-def test_sgd_trajectory_vs_reference(F):
-    """Four training steps through the product path (HIP model, FlatSGD arena + u2_sgd_clip_step, WarmupMultiStepLR,
-    SimpleTrainer) against the reference's own four steps (tests/golden/trajectory_small.json: its PanopticFPN, its
-    clip-wrapped SGD, its LR schedule, fp32 CPU): the lr of every step exactly, the dense losses of every step within the
-    bf16 band of test_whole_model_vs_oracle, then where the parameters and BN running statistics ended up."""
-    from tests.golden.make_fixtures import det_fill
-    from u2seg_amd.config import get_cfg
-    from u2seg_amd.data import make_synthetic_batch
-    from u2seg_amd.engine.trainer import SimpleTrainer
-    from u2seg_amd.modeling import build_model, set_permutation_source
-    from u2seg_amd.solver import build_lr_scheduler, build_optimizer
-
-    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "trajectory_small.json")))
-    cfg = get_cfg()
-    cfg.merge_from_file(CFG)
-    cfg.merge_from_list(["MODEL.DEVICE", DEV] + fx["overrides"])
-    model = build_model(cfg)
-    with torch.no_grad():
-        for k, v in model.state_dict().items():
-            v.copy_(det_fill(k, v.cpu()).to(DEV))
-    model.train()
-    init = {k: dict(model.named_parameters())[k].detach().clone() for k in fx["param_norm"]}
-    opt = build_optimizer(cfg, model)
-    trainer = SimpleTrainer(model, opt, build_lr_scheduler(cfg, opt))
-    set_permutation_source(lambda n, device=None: torch.randperm(n))
-    torch.manual_seed(fx["seed"])
-    n, (h, w) = fx["num_images"], fx["image_hw"]
-    report = []
-    try:
-        for it in range(fx["steps"]):
-            assert opt.lr == pytest.approx(fx["lr"][it], rel=1e-12), it
-            losses = trainer.run_step(make_synthetic_batch(n, height=h, width=w, start_index=it * n, device=DEV))
-            report.append({k: (float(v.detach()), fx["losses"][it][k]) for k, v in losses.items()})
-    finally:
-        set_permutation_source(None)
-    print(json.dumps(report, indent=1))
-    # Steps 0-1 see (almost) the reference's parameters: the single-step band of test_whole_model_vs_oracle.  From step 2
-    # on the bf16 and fp32 trajectories have taken a full-lr step apart and sampling decisions differ (the oracle itself
-    # moves by 1-2 % there under a 3e-7 perturbation, tests/test_oracle_golden.py), and split-K gradient accumulation
-    # order varies from run to run: 10 % per loss, 5 % on the total (measured: <= 3 % and <= 0.2 %).
-    for it, row in enumerate(report):
-        for k in ("loss_sem_seg", "loss_rpn_cls", "loss_cls_stage0", "loss_cls_stage1", "loss_cls_stage2", "loss_mask"):
-            assert row[k][0] == pytest.approx(row[k][1], rel=4e-2 if it < 2 else 0.1), (it, k, row)
-        total = sum(v[0] for v in row.values())
-        assert total == pytest.approx(sum(v[1] for v in row.values()), rel=2e-2 if it < 2 else 5e-2), (it, row)
-    params = dict(model.named_parameters())
-    disp = {}
-    for k in fx["param_norm"]:
-        assert float(params[k].double().norm()) == pytest.approx(fx["param_norm"][k], rel=1e-4), k
-        disp[k] = (float((params[k].detach() - init[k]).double().norm()), fx["param_delta_norm"][k])
-    print(json.dumps(disp, indent=1))
-    for k, (got, want) in disp.items():
-        # every tensor is clipped to unit gradient norm, so its displacement is set by the lr schedule and the
-        # step-to-step alignment of the gradient directions; bf16 noise leaves that within 25 % (measured 0.01-8 %)
-        assert got == pytest.approx(want, rel=0.25), (k, disp)
-    sd = model.state_dict()
-    for k, v in fx["running_mean_norm"].items():
-        assert float(sd[k].double().norm()) == pytest.approx(v, rel=5e-2), k
-    assert int(sd["backbone.bottom_up.stem.conv1.norm.num_batches_tracked"]) == fx["num_batches_tracked"] == fx["steps"]
-
-
 def test_backbone_and_heads_blockwise_vs_oracle(F):
     """Teacher-forced block-level parity: every ResNet block, the FPN, the semantic head and the RPN head of the HIP path
     get the bf16 oracle's activations as input and must reproduce the oracle's output of that block to 2e-3 relative L2 (6e-3 for the 11-layer semantic head)
@@ -1151,3 +1090,64 @@ def test_real_data_pipeline_to_model(F):
     for batch in dev:
         losses = trainer.run_step(batch)
         assert len(losses) == 10 and bool(torch.isfinite(sum(v.detach() for v in losses.values())))
+
+
+def test_sgd_trajectory_vs_reference(F):
+    """Four training steps through the product path (HIP model, FlatSGD arena + u2_sgd_clip_step, WarmupMultiStepLR,
+    SimpleTrainer) against the reference's own four steps (tests/golden/trajectory_small.json: its PanopticFPN, its
+    clip-wrapped SGD, its LR schedule, fp32 CPU): the lr of every step exactly, the dense losses of every step within the
+    bf16 band of test_whole_model_vs_oracle, then where the parameters and BN running statistics ended up."""
+    from tests.golden.make_fixtures import det_fill
+    from u2seg_amd.config import get_cfg
+    from u2seg_amd.data import make_synthetic_batch
+    from u2seg_amd.engine.trainer import SimpleTrainer
+    from u2seg_amd.modeling import build_model, set_permutation_source
+    from u2seg_amd.solver import build_lr_scheduler, build_optimizer
+
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "trajectory_small.json")))
+    cfg = get_cfg()
+    cfg.merge_from_file(CFG)
+    cfg.merge_from_list(["MODEL.DEVICE", DEV] + fx["overrides"])
+    model = build_model(cfg)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            v.copy_(det_fill(k, v.cpu()).to(DEV))
+    model.train()
+    init = {k: dict(model.named_parameters())[k].detach().clone() for k in fx["param_norm"]}
+    opt = build_optimizer(cfg, model)
+    trainer = SimpleTrainer(model, opt, build_lr_scheduler(cfg, opt))
+    set_permutation_source(lambda n, device=None: torch.randperm(n))
+    torch.manual_seed(fx["seed"])
+    n, (h, w) = fx["num_images"], fx["image_hw"]
+    report = []
+    try:
+        for it in range(fx["steps"]):
+            assert opt.lr == pytest.approx(fx["lr"][it], rel=1e-12), it
+            losses = trainer.run_step(make_synthetic_batch(n, height=h, width=w, start_index=it * n, device=DEV))
+            report.append({k: (float(v.detach()), fx["losses"][it][k]) for k, v in losses.items()})
+    finally:
+        set_permutation_source(None)
+    print(json.dumps(report, indent=1))
+    # Steps 0-1 see (almost) the reference's parameters: the single-step band of test_whole_model_vs_oracle.  From step 2
+    # on the bf16 and fp32 trajectories have taken a full-lr step apart and sampling decisions differ (the oracle itself
+    # moves by 1-2 % there under a 3e-7 perturbation, tests/test_oracle_golden.py), and split-K gradient accumulation
+    # order varies from run to run: 10 % per loss, 5 % on the total (measured: <= 3 % and <= 0.2 %).
+    for it, row in enumerate(report):
+        for k in ("loss_sem_seg", "loss_rpn_cls", "loss_cls_stage0", "loss_cls_stage1", "loss_cls_stage2", "loss_mask"):
+            assert row[k][0] == pytest.approx(row[k][1], rel=4e-2 if it < 2 else 0.1), (it, k, row)
+        total = sum(v[0] for v in row.values())
+        assert total == pytest.approx(sum(v[1] for v in row.values()), rel=2e-2 if it < 2 else 5e-2), (it, row)
+    params = dict(model.named_parameters())
+    disp = {}
+    for k in fx["param_norm"]:
+        assert float(params[k].double().norm()) == pytest.approx(fx["param_norm"][k], rel=1e-4), k
+        disp[k] = (float((params[k].detach() - init[k]).double().norm()), fx["param_delta_norm"][k])
+    print(json.dumps(disp, indent=1))
+    for k, (got, want) in disp.items():
+        # every tensor is clipped to unit gradient norm, so its displacement is set by the lr schedule and the
+        # step-to-step alignment of the gradient directions; bf16 noise leaves that within 25 % (measured 0.01-8 %)
+        assert got == pytest.approx(want, rel=0.25), (k, disp)
+    sd = model.state_dict()
+    for k, v in fx["running_mean_norm"].items():
+        assert float(sd[k].double().norm()) == pytest.approx(v, rel=5e-2), k
+    assert int(sd["backbone.bottom_up.stem.conv1.norm.num_batches_tracked"]) == fx["num_batches_tracked"] == fx["steps"]
