@@ -920,6 +920,81 @@ def gen_data_fixture():
     print("wrote data_golden", len(cases), "cases;", sorted({tuple(c.get("image_size", ())) for c in cases}))
 
 
+def gen_pseudo_panoptic_fixture():
+    """Runs the reference script datasets/prepare_ours/generate_pseudo_panoptic.py (runpy, from a temp directory laid out
+    the way its relative paths expect) on three small images: overlapping pseudo instances (one completely covered by
+    later ones), a semantic class mostly hidden under instances (> 70 %: skipped), an image without pseudo instances.
+    Stand-ins: panopticapi's id2rgb / rgb2id (restated), pycocotools decode (u2seg_amd.data.rle), skimage (unused)."""
+    import runpy
+    import tempfile
+
+    from u2seg_amd.data import rle
+    from u2seg_amd.data.pseudo_panoptic import id2rgb, rgb2id
+
+    sys.meta_path.insert(0, _Finder())
+    _Finder.ROOTS = _Finder.ROOTS + ("skimage",)
+    import panopticapi.utils as PU
+    import pycocotools.mask as PM
+
+    PU.id2rgb, PU.rgb2id, PM.decode = id2rgb, rgb2id, rle.decode
+    rs = np.random.RandomState(5)
+    work = tempfile.mkdtemp()
+    ann_root = os.path.join(work, "datasets", "prepare_ours", "u2seg_annotations")
+    for d in ("ins_annotations", "semantic_annotations/stego_coco_train_semantic_seg_resized", "panoptic_annotations"):
+        os.makedirs(os.path.join(ann_root, d))
+    os.makedirs(os.path.join(work, "datasets", "datasets", "panoptic_anns"))
+    os.makedirs(os.path.join(work, "datasets", "datasets", "coco", "annotations"))
+    sizes = [(40, 56), (48, 32), (30, 30)]
+    images = [{"id": 100 + i, "file_name": "%012d.jpg" % (100 + i), "height": h, "width": w} for i, (h, w) in enumerate(sizes)]
+    template = {"images": images, "info": {"description": "small"}, "licenses": [{"id": 1}],
+                "annotations": [{"file_name": "%012d.png" % im["id"], "image_id": im["id"], "segments_info": []} for im in images]}
+    json.dump(template, open(os.path.join(work, "datasets/datasets/panoptic_anns/panoptic_train2017.json"), "w"))
+    json.dump({"images": images}, open(os.path.join(work, "datasets/datasets/coco/annotations/instances_train2017.json"), "w"))
+    semantic, pseudo = {}, {"annotations": {}}
+    with open(os.path.join(ann_root, "semantic_annotations", "coco_train_img_file_names.txt"), "w") as f:
+        for im in images:
+            f.write(im["file_name"] + "\n")
+    for i, (im, (h, w)) in enumerate(zip(images, sizes)):
+        sem = rs.randint(0, 27, (h // 8 + 1, w // 8 + 1)).repeat(8, 0).repeat(8, 1)[:h, :w].astype(np.int64)
+        yy, xx = np.mgrid[0:h, 0:w]
+
+        def box_inst(x0, y0, bw, bh, cat):
+            m = ((xx >= x0) & (xx < x0 + bw) & (yy >= y0) & (yy < y0 + bh)).astype(np.uint8)
+            return {"bbox": [x0, y0, bw, bh], "segmentation": rle.encode(m), "category_id": cat, "iscrowd": 0,
+                    "area": int(m.sum())}
+
+        if i == 0:
+            sem[:16, :24] = 7  # class 8 after the +1 shift: almost entirely under the first instance -> skipped
+            insts = [box_inst(0, 0, 24, 15, 12), box_inst(30, 10, 20, 20, 640), box_inst(32, 12, 8, 8, 3),
+                     box_inst(32, 12, 8, 4, 77), box_inst(32, 16, 8, 4, 78)]  # the 8x8 box vanishes under the two 8x4 ones
+            pseudo["annotations"][str(im["id"])] = {"segments_info": insts}
+        elif i == 1:
+            pseudo["annotations"][str(im["id"])] = {"segments_info": [box_inst(4, 6, 20, 30, 800), box_inst(10, 20, 18, 25, 1)]}
+        semantic[str(i)] = sem
+        np.save(os.path.join(ann_root, "semantic_annotations", "stego_coco_train_semantic_seg_resized", "%d.npy" % i), sem)
+    json.dump(pseudo, open(os.path.join(ann_root, "ins_annotations", "cocotrain_800_ins_panoptic.json"), "w"))
+    inputs = {"template": template, "pseudo": copy.deepcopy(pseudo), "names": [im["file_name"] for im in images]}
+    cwd, argv = os.getcwd(), sys.argv
+    os.chdir(work)
+    sys.argv = ["generate_pseudo_panoptic.py", "--class_num", "800", "--split", "train"]
+    try:
+        runpy.run_path(os.path.join(REF, "datasets/prepare_ours/generate_pseudo_panoptic.py"), run_name="__main__")
+    finally:
+        os.chdir(cwd)
+        sys.argv = argv
+    from PIL import Image
+
+    out_json = json.load(open(os.path.join(ann_root, "panoptic_annotations", "cocotrain_800.json")))
+    arrays = {"semantic_%s" % k: v for k, v in semantic.items()}
+    for a in out_json["annotations"]:
+        png = np.asarray(Image.open(os.path.join(ann_root, "panoptic_annotations", "cocotrain_800", a["file_name"])))
+        arrays["ids_" + a["file_name"]] = rgb2id(png)
+    inputs["expected"] = out_json
+    json.dump(inputs, open(os.path.join(HERE, "pseudo_panoptic_golden.json"), "w"))
+    np.savez_compressed(os.path.join(HERE, "pseudo_panoptic_golden.npz"), **arrays)
+    print("wrote pseudo_panoptic_golden:", [(a["file_name"], [s_["id"] for s_ in a["segments_info"]]) for a in out_json["annotations"]])
+
+
 def _import_nn_utils():
     for m in ["pykeops", "pykeops.torch", "torchvision", "torchvision.transforms", "torchvision.datasets", "torchvision.models",
               "yacs", "yacs.config", "termcolor", "clip"]:
@@ -1008,6 +1083,9 @@ if __name__ == "__main__":
         gen_kmeans_fixture()
     if a.only in ("", "knn"):
         gen_knn_fixture()
+    if a.only == "pseudo_panoptic":
+        gen_pseudo_panoptic_fixture()
+        sys.exit(0)
     if a.only == "data":  # own process: the data stand-ins must be in place before detectron2.data is imported
         gen_data_fixture()
         sys.exit(0)

@@ -322,3 +322,39 @@ def test_slot_transport_round_trip(small):
         assert len({d["width"] > d["height"] for d in b}) == 1
         for d in b:
             assert d["image"].shape[1:] == tuple(d["instances"].image_size) == tuple(d["sem_seg"].shape)
+
+
+def test_pseudo_panoptic_merge_matches_reference_script(tmp_path):
+    """u2seg_amd.data.pseudo_panoptic.generate == the reference script generate_pseudo_panoptic.py run on the same tree
+    (tests/golden/make_fixtures.py --only pseudo_panoptic): the json (segment ids running on across images, the covered
+    instance dropped, the mostly-hidden semantic class skipped, the image without pseudo instances left out) and every
+    pixel of the id maps."""
+    from PIL import Image
+
+    from u2seg_amd.data import pseudo_panoptic as PP
+
+    fx = json.load(open(os.path.join(GOLD, "pseudo_panoptic_golden.json")))
+    arrays = np.load(os.path.join(GOLD, "pseudo_panoptic_golden.npz"))
+    ann_root = tmp_path / "datasets" / "prepare_ours" / "u2seg_annotations"
+    sem_dir = ann_root / "semantic_annotations" / "stego_coco_train_semantic_seg_resized"
+    for d in (ann_root / "ins_annotations", sem_dir, ann_root / "panoptic_annotations",
+              tmp_path / "datasets" / "datasets" / "panoptic_anns"):
+        os.makedirs(d)
+    json.dump(fx["template"], open(tmp_path / "datasets" / "datasets" / "panoptic_anns" / "panoptic_train2017.json", "w"))
+    json.dump(fx["pseudo"], open(ann_root / "ins_annotations" / "cocotrain_800_ins_panoptic.json", "w"))
+    with open(ann_root / "semantic_annotations" / "coco_train_img_file_names.txt", "w") as f:
+        for i, name in enumerate(fx["names"]):
+            f.write(name + "\n")
+            np.save(sem_dir / ("%d.npy" % i), arrays["semantic_%d" % i])
+    out = PP.generate(str(tmp_path), 800, "train")
+    assert out == fx["expected"]
+    assert json.load(open(ann_root / "panoptic_annotations" / "cocotrain_800.json")) == fx["expected"]
+    assert [a["image_id"] for a in out["annotations"]] == [100, 101] and [im["id"] for im in out["images"]] == [100, 101]
+    for a in out["annotations"]:
+        png = np.asarray(Image.open(ann_root / "panoptic_annotations" / "cocotrain_800" / a["file_name"]))
+        ids = PP.rgb2id(png)
+        assert np.array_equal(ids, arrays["ids_" + a["file_name"]])
+        assert set(np.unique(ids).tolist()) - {0} == {s["id"] for s in a["segments_info"]}
+    assert len(out["categories"]) == 827 and out["categories"][799]["isthing"] == 1 and out["categories"][800]["isthing"] == 0
+    big = np.array([[0, 255, 256, 70000]], dtype=np.uint32)
+    assert np.array_equal(PP.rgb2id(PP.id2rgb(big)), big)
