@@ -995,6 +995,134 @@ def gen_pseudo_panoptic_fixture():
     print("wrote pseudo_panoptic_golden:", [(a["file_name"], [s_["id"] for s_ in a["segments_info"]]) for a in out_json["annotations"]])
 
 
+def gen_eval_fixture():
+    """The reference's evaluators on a tiny validation set, from a temp working directory (they write their mapping files
+    under ./hungarian_matching): COCOEvaluator.do_hangarain_mapping (instance clusters -> categories) and SemSegEvaluator
+    in both modes (votes -> semantic_mapping.json -> remapped confusion matrix -> mIoU / fwIoU / mACC / pACC).
+    Stand-ins: the pycocotools json index, maskUtils.iou for boxes (cocoapi's bbIou restated in
+    u2seg_amd/evaluation/hungarian.py), no OpenCV (boundary IoU off, as the reference does without cv2)."""
+    import tempfile
+
+    from PIL import Image
+
+    from u2seg_amd.evaluation.hungarian import box_iou_xywh
+
+    os.environ.setdefault("CLUSTER_NUM", "800")
+    work = tempfile.mkdtemp()
+    os.chdir(work)
+    install_standins()
+    install_data_standins()
+    import pycocotools.mask as PM
+
+    PM.iou = lambda dt, gt, iscrowd: (np.stack([box_iou_xywh(d, gt) for d in dt]) if len(gt) else [])
+    sys.path.insert(0, REF)
+    import types as _types
+
+    sys.modules["detectron2._C"] = _types.ModuleType("detectron2._C")
+    from detectron2.data import DatasetCatalog, MetadataCatalog
+    from detectron2.data.datasets import register_coco_instances
+    from detectron2.data.datasets.coco import load_sem_seg
+    from detectron2.evaluation import COCOEvaluator, SemSegEvaluator
+    from detectron2.structures import Boxes, Instances
+
+    rs = np.random.RandomState(9)
+    img_dir, gt_dir = os.path.join(work, "images"), os.path.join(work, "sem_gt")
+    os.makedirs(img_dir)
+    os.makedirs(gt_dir)
+    sizes = [(40, 48), (36, 36), (48, 40)]
+    images, anns, aid = [], [], 1
+    gt_maps, cat_ids = {}, [1, 2, 3, 17, 18, 44, 62, 90]
+    for i, (h, w) in enumerate(sizes):
+        name = "%06d" % (i + 1)
+        Image.fromarray(rs.randint(0, 255, (h, w, 3)).astype(np.uint8)).save(os.path.join(img_dir, name + ".jpg"))
+        gt = rs.randint(0, 54, (h // 6 + 1, w // 6 + 1)).repeat(6, 0).repeat(6, 1)[:h, :w].astype(np.uint8)
+        gt[rs.rand(h, w) < 0.05] = 255
+        Image.fromarray(gt, mode="L").save(os.path.join(gt_dir, name + ".png"))
+        gt_maps[name] = gt
+        images.append({"id": i + 1, "file_name": name + ".jpg", "height": h, "width": w})
+        for k in range(4):
+            bw, bh = rs.uniform(8, 20), rs.uniform(8, 20)
+            x0, y0 = rs.uniform(0, w - bw), rs.uniform(0, h - bh)
+            anns.append({"id": aid, "image_id": i + 1, "category_id": cat_ids[(i * 3 + k) % len(cat_ids)], "iscrowd": 0,
+                         "bbox": [float(x0), float(y0), float(bw), float(bh)], "area": float(bw * bh)})
+            aid += 1
+    cats = [{"id": c, "name": str(c), "supercategory": "x"} for c in range(1, 91)]
+    json_file = os.path.join(work, "val.json")
+    json.dump({"images": images, "annotations": anns, "categories": cats}, open(json_file, "w"))
+    register_coco_instances("tiny_val", {}, json_file, img_dir)
+    DatasetCatalog.get("tiny_val")  # fills thing_dataset_id_to_contiguous_id
+    DatasetCatalog.register("tiny_val_sem", lambda: load_sem_seg(gt_dir, img_dir))
+    MetadataCatalog.get("tiny_val_sem").set(stuff_classes=[str(c) for c in range(28)], ignore_label=255)
+
+    # predictions: per image 7 detections = jittered copies of the ground-truth boxes + strays; cluster ids 0..299
+    preds_in, outputs, inputs = [], [], []
+    cluster_of = {c: [11 * (j + 1), 11 * (j + 1) + 100] for j, c in enumerate(cat_ids)}
+    for im in images:
+        boxes, scores, classes = [], [], []
+        for a in [a for a in anns if a["image_id"] == im["id"]]:
+            x, y, bw, bh = a["bbox"]
+            for rep in range(2):
+                j = rs.uniform(-1.0, 1.0, 4) * (0.6 if rep == 0 else 3.5)
+                boxes.append([x + j[0], y + j[1], x + bw + j[2], y + bh + j[3]])
+                scores.append(float(rs.choice([0.95, 0.8, 0.62, 0.55, 0.3])))
+                classes.append(int(cluster_of[a["category_id"]][rep] if rs.rand() < 0.8 else rs.randint(0, 300)))
+        boxes.append([1.0, 1.0, 6.0, 6.0])
+        scores.append(0.9)
+        classes.append(299)
+        inst = Instances((im["height"], im["width"]))
+        inst.pred_boxes = Boxes(torch.tensor(boxes, dtype=torch.float32))
+        inst.scores = torch.tensor(scores, dtype=torch.float32)
+        inst.pred_classes = torch.tensor(classes, dtype=torch.int64)
+        logits = torch.from_numpy(rs.randn(28, im["height"] // 6 + 1, im["width"] // 6 + 1).astype(np.float32))
+        logits = logits.repeat_interleave(6, 1).repeat_interleave(6, 2)[:, : im["height"], : im["width"]].contiguous()
+        # make the prediction correlate with the ground truth so that votes exist: class (gt mod 27) + 1 gets a bonus
+        gt = torch.from_numpy(gt_maps[im["file_name"][:-4]].astype(np.int64))
+        bonus = torch.zeros_like(logits)
+        bonus.scatter_(0, ((gt % 27) + 1).clamp(max=27)[None], 2.5)
+        logits = logits + bonus * (gt != 255)[None]
+        outputs.append({"instances": inst, "sem_seg": logits})
+        inputs.append({"image_id": im["id"], "file_name": os.path.join(img_dir, im["file_name"]), "height": im["height"],
+                       "width": im["width"]})
+        preds_in.append({"boxes": boxes, "scores": scores, "classes": classes})
+    ev = COCOEvaluator("tiny_val", distributed=False, output_dir=None, mode="hungarian_matching")
+    ev.reset()
+    ev.process(inputs, outputs)
+    import itertools
+
+    coco_results = list(itertools.chain(*[x["instances"] for x in ev._predictions]))
+    inst_map = ev.do_hangarain_mapping(300, copy.deepcopy(coco_results), save_path=ev.hungarain_matching_save_path)
+    def load_gt(filename, dtype=None):  # the reference's loader passes copy=False, which NumPy 2 rejects when a copy is needed
+        return np.array(Image.open(filename), dtype=dtype)
+
+    sem = SemSegEvaluator("tiny_val_sem", distributed=False, output_dir=None, mode="hungarian_matching",
+                          sem_seg_loading_fn=load_gt)
+    sem._compute_boundary_iou = False
+    sem.reset()
+    sem.process(inputs, outputs)
+    sem.evaluate()
+    sem_map = json.load(open("./hungarian_matching/semantic_mapping.json"))
+    votes = sorted(zip(sem.pred_det_cate, sem.pseudo_gt_cate))
+    sem2 = SemSegEvaluator("tiny_val_sem", distributed=False, output_dir=None, mode="eval", sem_seg_loading_fn=load_gt)
+    sem2._compute_boundary_iou = False
+    sem2.reset()
+    sem2.process(inputs, outputs)
+    res = sem2.evaluate()["sem_seg"]
+    out = {"images": images, "annotations": anns, "categories": cats, "predictions": preds_in,
+           "coco_results": coco_results, "instance_mapping": {str(k): v for k, v in inst_map.items()},
+           "instance_mapping_file": json.load(open("./hungarian_matching/instance_mapping.json")),
+           "semantic_mapping_file": sem_map, "semantic_votes": [[int(a), int(b)] for a, b in votes],
+           "conf_matrix": sem2._conf_matrix.tolist(),
+           "sem_seg_results": {k: (None if v != v else float(v)) for k, v in res.items()},
+           "transfer_table": sem.transfer(np.concatenate([np.arange(54), [255]]).astype(int)).tolist()}
+    arrays = {"gt_%s" % k: v for k, v in gt_maps.items()}
+    for im, o in zip(images, outputs):
+        arrays["logits_%s" % im["file_name"][:-4]] = o["sem_seg"].numpy()
+    json.dump(out, open(os.path.join(HERE, "eval_golden.json"), "w"))
+    np.savez_compressed(os.path.join(HERE, "eval_golden.npz"), **arrays)
+    print("wrote eval_golden: instance mapping votes", sum(1 for v in inst_map.values() if v != -1), "semantic",
+          sum(1 for v in sem_map.values() if v != -1), "mIoU", res["mIoU"])
+
+
 def _import_nn_utils():
     for m in ["pykeops", "pykeops.torch", "torchvision", "torchvision.transforms", "torchvision.datasets", "torchvision.models",
               "yacs", "yacs.config", "termcolor", "clip"]:
@@ -1083,6 +1211,9 @@ if __name__ == "__main__":
         gen_kmeans_fixture()
     if a.only in ("", "knn"):
         gen_knn_fixture()
+    if a.only == "eval":
+        gen_eval_fixture()
+        sys.exit(0)
     if a.only == "pseudo_panoptic":
         gen_pseudo_panoptic_fixture()
         sys.exit(0)

@@ -1,0 +1,136 @@
+"""U2Seg evaluation front-end against the reference's own evaluators run on a tiny validation
+set (tests/golden/make_fixtures.py --only eval): instance cluster -> category mapping, semantic votes -> mapping ->
+remapped confusion matrix -> metrics.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from u2seg_amd.data import DatasetCatalog, MetadataCatalog, register_coco_instances
+from u2seg_amd.data.datasets import load_sem_seg
+from u2seg_amd.evaluation import COCOEvaluator, DatasetEvaluators, SemSegEvaluator, inference_on_dataset, instances_to_coco_json
+from u2seg_amd.evaluation import hungarian
+from u2seg_amd.evaluation.sem_seg_evaluation import to_supercategories
+from u2seg_amd.structures import Boxes, Instances
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture()
+def tiny_val(tmp_path, monkeypatch):
+    fx = json.load(open(os.path.join(GOLD, "eval_golden.json")))
+    arrays = np.load(os.path.join(GOLD, "eval_golden.npz"))
+    img_dir, gt_dir = tmp_path / "images", tmp_path / "sem_gt"
+    os.makedirs(img_dir)
+    os.makedirs(gt_dir)
+    for im in fx["images"]:
+        stem = im["file_name"][:-4]
+        Image.fromarray(np.zeros((im["height"], im["width"], 3), dtype=np.uint8)).save(img_dir / im["file_name"])
+        Image.fromarray(arrays["gt_" + stem], mode="L").save(gt_dir / (stem + ".png"))
+    json_file = str(tmp_path / "val.json")
+    json.dump({"images": fx["images"], "annotations": fx["annotations"], "categories": fx["categories"]}, open(json_file, "w"))
+    for name in ("tiny_val", "tiny_val_sem"):
+        if name in DatasetCatalog:
+            DatasetCatalog.remove(name)
+        if name in MetadataCatalog:
+            MetadataCatalog.remove(name)
+    register_coco_instances("tiny_val", {}, json_file, str(img_dir))
+    DatasetCatalog.get("tiny_val")
+    DatasetCatalog.register("tiny_val_sem", lambda: load_sem_seg(str(gt_dir), str(img_dir)))
+    MetadataCatalog.get("tiny_val_sem").set(stuff_classes=[str(c) for c in range(28)], ignore_label=255)
+    monkeypatch.chdir(tmp_path)  # the mapping files go to ./hungarian_matching like in the reference
+    inputs, outputs = [], []
+    for im, p in zip(fx["images"], fx["predictions"]):
+        inst = Instances((im["height"], im["width"]))
+        inst.pred_boxes = Boxes(torch.tensor(p["boxes"], dtype=torch.float32))
+        inst.scores = torch.tensor(p["scores"], dtype=torch.float32)
+        inst.pred_classes = torch.tensor(p["classes"], dtype=torch.int64)
+        outputs.append({"instances": inst, "sem_seg": torch.from_numpy(arrays["logits_" + im["file_name"][:-4]])})
+        inputs.append({"image_id": im["id"], "file_name": str(img_dir / im["file_name"]), "height": im["height"],
+                       "width": im["width"]})
+    return fx, inputs, outputs
+
+
+def test_instance_cluster_mapping_matches_reference(tiny_val):
+    fx, inputs, outputs = tiny_val
+    ev = COCOEvaluator("tiny_val", mode="hungarian_matching")
+    ev.process(inputs, outputs)
+    results = [r for p in ev._predictions for r in p["instances"]]
+    assert results == fx["coco_results"]  # xyxy -> xywh in the json, fp32 values as python floats
+    out = ev.evaluate()
+    assert {str(k): v for k, v in out["instance_mapping"].items()} == fx["instance_mapping"]
+    assert json.load(open("./hungarian_matching/instance_mapping.json")) == fx["instance_mapping_file"]
+    assert len(out["instance_mapping"]) == 300 and sum(v != -1 for v in out["instance_mapping"].values()) == 11
+    # eval mode: clusters without a mapping disappear, the others carry the dataset id of their category
+    ev2 = COCOEvaluator("tiny_val", output_dir="out", mode="eval")
+    ev2.process(inputs, outputs)
+    res = ev2.evaluate()["bbox"]
+    mapping = hungarian.load_mapping("./hungarian_matching/instance_mapping.json")
+    to_dataset = {v: k for k, v in MetadataCatalog.get("tiny_val").thing_dataset_id_to_contiguous_id.items()}
+    want = [dict(r, category_id=to_dataset[mapping[r["category_id"]]]) for r in fx["coco_results"]
+            if mapping[r["category_id"]] != -1]
+    assert json.load(open("out/coco_instances_results.json")) == want
+    assert res["num_results"] == len(want) and res["num_dropped"] == len(fx["coco_results"]) - len(want)
+
+
+def test_semantic_mapping_and_metrics_match_reference(tiny_val):
+    fx, inputs, outputs = tiny_val
+    assert to_supercategories(np.concatenate([np.arange(54), [255]]).astype(int)).tolist() == fx["transfer_table"]
+    ev = SemSegEvaluator("tiny_val_sem", mode="hungarian_matching")
+    ev.process(inputs, outputs)
+    assert sorted(zip(ev.pred_det_cate, ev.pseudo_gt_cate)) == [tuple(v) for v in fx["semantic_votes"]]
+    out = ev.evaluate()
+    assert out["sem_seg"] is None
+    on_disk = json.load(open("./hungarian_matching/semantic_mapping.json"))
+    assert on_disk == fx["semantic_mapping_file"] and list(on_disk) == list(fx["semantic_mapping_file"])  # same key order
+    ev2 = SemSegEvaluator("tiny_val_sem", mode="eval")
+    ev2.process(inputs, outputs)
+    assert ev2._conf_matrix.tolist() == fx["conf_matrix"]  # incl. the reference's chained in-place remapping
+    res = ev2.evaluate()["sem_seg"]
+    assert list(res) == list(fx["sem_seg_results"])
+    for k, v in fx["sem_seg_results"].items():
+        if v is None:
+            assert res[k] != res[k], k  # NaN for classes that do not occur
+        else:
+            assert res[k] == pytest.approx(v, rel=1e-12), k
+
+
+def test_vote_mapping_and_loop():
+    # coco_evaluation.py:273-297: majority per cluster, -1 without votes, ties to the smaller category
+    m = hungarian.majority_vote_mapping([0, 0, 0, 2, 2, 5], [3, 3, 1, 4, 7, 0], range(4), 8)
+    assert m == {0: 3, 1: -1, 2: 4, 3: -1}
+    assert hungarian.majority_vote_mapping([], [], range(2), 3) == {0: -1, 1: -1}
+    iou = hungarian.box_iou_xywh([0, 0, 10, 10], [[0, 0, 10, 10], [5, 5, 10, 10], [20, 20, 5, 5]])
+    assert np.allclose(iou, [1.0, 25 / 175, 0.0])
+    inst = Instances((4, 6))
+    inst.pred_boxes = Boxes(torch.tensor([[1.0, 1.0, 4.0, 3.0]]))
+    inst.scores = torch.tensor([0.5])
+    inst.pred_classes = torch.tensor([7])
+    inst.pred_masks = torch.zeros((1, 4, 6), dtype=torch.bool)
+    inst.pred_masks[0, 1:3, 1:4] = True
+    (r,) = instances_to_coco_json(inst, 9)
+    assert r["bbox"] == [1.0, 1.0, 3.0, 2.0] and r["category_id"] == 7 and r["image_id"] == 9
+    from u2seg_amd.data import rle
+
+    assert rle.decode(r["segmentation"]).sum() == 6 and r["segmentation"]["size"] == [4, 6]
+
+    class Model(torch.nn.Module):
+        def forward(self, batch):
+            return [{"v": x["v"] * 2} for x in batch]
+
+    class Sum(DatasetEvaluators.__mro__[1]):
+        def reset(self):
+            self.total = 0
+
+        def process(self, inputs, outputs):
+            self.total += sum(o["v"] for o in outputs)
+
+        def evaluate(self):
+            return {"sum": self.total}
+
+    model = Model().train()
+    assert inference_on_dataset(model, [[{"v": 1}, {"v": 2}], [{"v": 3}]], Sum()) == {"sum": 12}
+    assert model.training

@@ -46,6 +46,25 @@ def real_batches(cfg, device):
     return iter(DevicePrefetcher(loader, device) if str(device).startswith("cuda") else loader)
 
 
+def evaluate_on_disk_datasets(cfg, model, eval_mode, device):
+    """The reference's Trainer.test (engine/defaults.py:591-640) for the DATASETS.TEST entries that are on disk: first run
+    with --eval-mode hungarian_matching (writes ./hungarian_matching/*.json), then with --eval-mode eval.  None when no
+    test dataset is available."""
+    from u2seg_amd.data import build_detection_test_loader
+    from u2seg_amd.evaluation import build_evaluator, inference_on_dataset
+
+    register_all_coco()
+    results = {}
+    for name in cfg.DATASETS.TEST:
+        meta = MetadataCatalog.get(name)
+        if name not in DatasetCatalog or not os.path.isfile(meta.get("json_file", "")):
+            continue
+        loader = build_detection_test_loader(cfg, name)
+        stream = DevicePrefetcher(loader, device) if str(device).startswith("cuda") else loader
+        results[name] = inference_on_dataset(model, stream, build_evaluator(cfg, name, eval_mode=eval_mode))
+    return results or None
+
+
 def main(args):
     rank, local_rank, world = launch_info()
     cfg = setup(args)
@@ -64,6 +83,11 @@ def main(args):
         # tools/train_net.py:135-141 of the reference: weights from MODEL.WEIGHTS (or the last checkpoint with --resume)
         if cfg.MODEL.WEIGHTS and os.path.isfile(cfg.MODEL.WEIGHTS):
             DetectionCheckpointer(model, cfg.OUTPUT_DIR).resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume)
+        results = evaluate_on_disk_datasets(cfg, model, args.eval_mode, c.MODEL.DEVICE)
+        if results is not None:
+            if rank == 0:
+                print(results)
+            return results
         model.eval()
         with torch.no_grad():
             out = model(make_synthetic_batch(per_gpu, start_index=rank * per_gpu, device=c.MODEL.DEVICE))
