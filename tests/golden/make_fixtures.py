@@ -1123,6 +1123,87 @@ def gen_eval_fixture():
           sum(1 for v in sem_map.values() if v != -1), "mIoU", res["mIoU"])
 
 
+def gen_label_prep_fixture():
+    """The three remaining scripts of datasets/prepare_ours on small inputs: prepare_stuff_panoptic_fpn.py's function run on
+    the pseudo-panoptic golden output, generate_classaware_instanceseg_annotations.py and get_panoptic_anns_supercategory.py
+    run as scripts (runpy; the first has absolute paths, so its `open` is redirected to the temp files by base name)."""
+    import runpy
+    import tempfile
+
+    from PIL import Image
+
+    from u2seg_amd.data.pseudo_panoptic import id2rgb, rgb2id
+
+    sys.meta_path.insert(0, _Finder())
+    _Finder.ROOTS = _Finder.ROOTS + ("skimage", "pandas_stub")
+    import panopticapi.utils as PU
+
+    PU.id2rgb, PU.rgb2id = id2rgb, rgb2id
+    out = {}
+    # 1) panoptic -> semantic label maps
+    fx = json.load(open(os.path.join(HERE, "pseudo_panoptic_golden.json")))
+    arrays = np.load(os.path.join(HERE, "pseudo_panoptic_golden.npz"))
+    work = tempfile.mkdtemp()
+    pan_root, sem_root = os.path.join(work, "pan"), os.path.join(work, "sem")
+    os.makedirs(pan_root)
+    json.dump(fx["expected"], open(os.path.join(work, "pan.json"), "w"))
+    for a in fx["expected"]["annotations"]:
+        Image.fromarray(id2rgb(arrays["ids_" + a["file_name"]])).save(os.path.join(pan_root, a["file_name"]))
+    spec = importlib.util.spec_from_file_location("ref_prepare_stuff", os.path.join(REF, "datasets/prepare_ours/prepare_stuff_panoptic_fpn.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_prepare_stuff"] = mod  # its worker pool pickles the per-file function by module name
+    spec.loader.exec_module(mod)
+    mod.separate_coco_semantic_from_panoptic(os.path.join(work, "pan.json"), pan_root, sem_root, fx["expected"]["categories"])
+    sem_arrays = {"sem_" + a["file_name"]: np.asarray(Image.open(os.path.join(sem_root, a["file_name"])))
+                  for a in fx["expected"]["annotations"]}
+    # 2) class-aware instance annotations
+    template = {"licenses": [{"id": 1}], "info": {"year": 2017},
+                "images": [{"id": 7, "file_name": "7.jpg"}, {"id": 8, "file_name": "8.jpg"}, {"id": 9, "file_name": "9.jpg"}]}
+    masks = [{"ins_id": 0, "image_id": 7, "bbox": [1, 2, 3, 4], "segmentation": {"size": [4, 4], "counts": "04"}, "area": 4},
+             {"ins_id": 1, "image_id": 9, "bbox": [0, 0, 2, 2], "segmentation": {"size": [4, 4], "counts": "04"}, "area": 4},
+             {"ins_id": 2, "image_id": 7, "bbox": [2, 2, 1, 1], "segmentation": {"size": [4, 4], "counts": "04"}, "area": 1}]
+    clusters = {"0.jpg": 17, "1.jpg": 299, "2.jpg": 4}
+    files = {"instances_val2017.json": template, "coco_val_usl_dino_800_decode.json": clusters,
+             "cutler_cocoval_instances_idx.json": masks}
+    d2 = tempfile.mkdtemp()
+    for k, v in files.items():
+        json.dump(v, open(os.path.join(d2, k), "w"))
+    real_open = open
+
+    def redirected(path, *a, **k):
+        base = os.path.basename(str(path))
+        return real_open(os.path.join(d2, base) if base in files else path, *a, **k)
+
+    cwd = os.getcwd()
+    os.chdir(d2)
+    try:
+        runpy.run_path(os.path.join(REF, "datasets/prepare_ours/generate_classaware_instanceseg_annotations.py"),
+                       init_globals={"open": redirected}, run_name="__main__")
+        out["classaware"] = {"template": template, "masks": masks, "clusters": clusters,
+                             "expected": json.load(open(os.path.join(d2, "uni-training-ann/ins_annotations/cocoval_300.json")))}
+        # 3) supercategory version of the ground-truth panoptic json
+        d3 = tempfile.mkdtemp()
+        os.makedirs(os.path.join(d3, "datasets", "panoptic_anns"))
+        os.makedirs(os.path.join(d3, "run"))
+        standard = {"images": [{"id": 1}], "categories": [{"id": 1, "name": "person", "isthing": 1},
+                                                          {"id": 92, "name": "banner", "isthing": 0},
+                                                          {"id": 187, "name": "sky-other-merged", "isthing": 0},
+                                                          {"id": 200, "name": "rug-merged", "isthing": 0}],
+                    "annotations": [{"image_id": 1, "file_name": "1.png", "segments_info": [
+                        {"id": 5, "category_id": 1}, {"id": 6, "category_id": 187}, {"id": 7, "category_id": 92},
+                        {"id": 8, "category_id": 200}, {"id": 9, "category_id": 149}]}]}
+        json.dump(standard, open(os.path.join(d3, "datasets/panoptic_anns/panoptic_val2017.json"), "w"))
+        os.chdir(os.path.join(d3, "run"))
+        runpy.run_path(os.path.join(REF, "datasets/prepare_ours/get_panoptic_anns_supercategory.py"), run_name="__main__")
+        out["supercategory"] = {"standard": standard, "expected": {
+            str(n): json.load(open(os.path.join(d3, "datasets/panoptic_anns/panoptic_val2017_%dsuper.json" % n))) for n in (300, 800)}}
+    finally:
+        os.chdir(cwd)
+    json.dump(out, open(os.path.join(HERE, "label_prep_golden.json"), "w"))
+    np.savez_compressed(os.path.join(HERE, "label_prep_golden.npz"), **sem_arrays)
+    print("wrote label_prep_golden", {k: np.unique(v).tolist() for k, v in sem_arrays.items()})
+
+
 def _import_nn_utils():
     for m in ["pykeops", "pykeops.torch", "torchvision", "torchvision.transforms", "torchvision.datasets", "torchvision.models",
               "yacs", "yacs.config", "termcolor", "clip"]:
@@ -1211,6 +1292,9 @@ if __name__ == "__main__":
         gen_kmeans_fixture()
     if a.only in ("", "knn"):
         gen_knn_fixture()
+    if a.only == "label_prep":
+        gen_label_prep_fixture()
+        sys.exit(0)
     if a.only == "eval":
         gen_eval_fixture()
         sys.exit(0)

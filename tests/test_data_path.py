@@ -358,3 +358,37 @@ def test_pseudo_panoptic_merge_matches_reference_script(tmp_path):
     assert len(out["categories"]) == 827 and out["categories"][799]["isthing"] == 1 and out["categories"][800]["isthing"] == 0
     big = np.array([[0, 255, 256, 70000]], dtype=np.uint32)
     assert np.array_equal(PP.rgb2id(PP.id2rgb(big)), big)
+
+
+def test_label_preparation_steps_match_reference_scripts(tmp_path):
+    """The remaining datasets/prepare_ours steps against the reference's own code (fixture: make_fixtures.py --only
+    label_prep): panoptic png -> semantic label maps (chained onto the pseudo-panoptic golden), cluster ids into the
+    class-agnostic instance annotations, supercategory ids into the ground-truth panoptic json."""
+    import copy as _copy
+
+    from PIL import Image
+
+    from u2seg_amd.data import pseudo_panoptic as PP
+
+    fx = json.load(open(os.path.join(GOLD, "label_prep_golden.json")))
+    sem = np.load(os.path.join(GOLD, "label_prep_golden.npz"))
+    pan = json.load(open(os.path.join(GOLD, "pseudo_panoptic_golden.json")))["expected"]
+    ids = np.load(os.path.join(GOLD, "pseudo_panoptic_golden.npz"))
+    pan_root, sem_root = tmp_path / "pan", tmp_path / "sem"
+    os.makedirs(pan_root)
+    json.dump(pan, open(tmp_path / "pan.json", "w"))
+    for a in pan["annotations"]:
+        Image.fromarray(PP.id2rgb(ids["ids_" + a["file_name"]])).save(pan_root / a["file_name"])
+    assert PP.separate_semantic_from_panoptic(str(tmp_path / "pan.json"), str(pan_root), str(sem_root), pan["categories"]) == 2
+    for a in pan["annotations"]:
+        got = np.asarray(Image.open(sem_root / a["file_name"]))
+        assert got.dtype == np.uint8 and np.array_equal(got, sem["sem_" + a["file_name"]])
+    c = fx["classaware"]
+    assert PP.classaware_instance_annotations(_copy.deepcopy(c["template"]), c["clusters"], _copy.deepcopy(c["masks"])) == c["expected"]
+    assert [im["id"] for im in c["expected"]["images"]] == [7, 9] and len(c["expected"]["categories"]) == 300
+    s = fx["supercategory"]
+    for n in (300, 800):
+        assert PP.panoptic_supercategory_annotations(_copy.deepcopy(s["standard"]), n) == s["expected"][str(n)]
+    from u2seg_amd.evaluation.sem_seg_evaluation import STUFF_TO_SUPERCATEGORY
+
+    assert tuple(PP.STUFF_ID_TO_SUPERCATEGORY.values()) == STUFF_TO_SUPERCATEGORY  # one table, two orderings

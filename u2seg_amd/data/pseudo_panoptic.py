@@ -105,3 +105,66 @@ def generate(root, class_num=800, split="train"):
     with open(os.path.join(ann_root, "panoptic_annotations", "coco%s_%d.json" % (split, class_num)), "w", encoding="utf-8") as f:
         json.dump(out, f, ensure_ascii=False)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# the other label-preparation steps of datasets/prepare_ours/
+# ------------------------------------------------------------------------------------------------
+def classaware_instance_annotations(template, cluster_results, mask_annotations, num_categories=300):
+    """generate_classaware_instanceseg_annotations.py:36-70: class-agnostic instance masks (CutLER / MaskCut records with
+    an "ins_id") receive the cluster id of their crop ("<ins_id>.jpg" in the clustering result) as category and their
+    ins_id as annotation id; images without any instance are dropped.  Returns the COCO-format dict."""
+    out = {"licenses": template["licenses"],
+           "categories": [{"id": i + 1, "name": str(i + 1), "supercategory": str(i + 1)} for i in range(num_categories)],
+           "images": template["images"], "info": template["info"], "annotations": []}
+    seen = set()
+    for ann in mask_annotations:
+        ann["category_id"] = cluster_results[str(ann["ins_id"]) + ".jpg"]
+        ann["id"] = ann["ins_id"]
+        out["annotations"].append(ann)
+        seen.add(ann["image_id"])
+    out["images"] = [img for img in out["images"] if img["id"] in seen]
+    return out
+
+
+# COCO panoptic stuff category id -> 1-based index of its supercategory (get_panoptic_anns_supercategory.py:9-13); the
+# contiguous-order form of the same table is evaluation/sem_seg_evaluation.py:STUFF_TO_SUPERCATEGORY
+STUFF_ID_TO_SUPERCATEGORY = dict(zip(
+    (92, 93, 95, 100, 107, 109, 112, 118, 119, 122, 125, 128, 130, 133, 138, 141, 144, 145, 147, 148, 149, 151, 154, 155, 156,
+     159, 161, 166, 168, 171, 175, 176, 177, 178, 180, 181, 184, 185, 186, 187, 188, 189, 190, 191, 192, 193, 194, 195, 196,
+     197, 198, 199, 200),
+    (1, 1, 2, 3, 4, 1, 4, 5, 6, 7, 8, 2, 4, 4, 9, 1, 8, 8, 8, 10, 8, 2, 8, 10, 4, 8, 4, 2, 1, 11, 11, 11, 11, 10, 12, 12, 6, 9,
+     13, 14, 4, 4, 5, 8, 15, 6, 8, 3, 7, 2, 15, 11, 1)))
+
+
+def panoptic_supercategory_annotations(standard, cluster_num):
+    """get_panoptic_anns_supercategory.py:15-27: in the ground-truth panoptic json every stuff category id becomes
+    cluster_num + its supercategory index, in the segments and in the category table (in place; returns `standard`)."""
+    for ann in standard["annotations"]:
+        for seg in ann["segments_info"]:
+            if seg["category_id"] in STUFF_ID_TO_SUPERCATEGORY:
+                seg["category_id"] = STUFF_ID_TO_SUPERCATEGORY[seg["category_id"]] + cluster_num
+    for cate in standard["categories"]:
+        if cate["id"] in STUFF_ID_TO_SUPERCATEGORY:
+            cate["id"] = STUFF_ID_TO_SUPERCATEGORY[cate["id"]] + cluster_num
+    return standard
+
+
+def separate_semantic_from_panoptic(panoptic_json, panoptic_root, sem_seg_root, categories):
+    """prepare_stuff_panoptic_fpn.py:21-75: one uint8 label map per panoptic png - things 0, the stuff categories 1.. in the
+    order of `categories`, everything unlabelled 255 - the `sem_seg_file_name` inputs of the training data path."""
+    os.makedirs(sem_seg_root, exist_ok=True)
+    stuff_ids = [k["id"] for k in categories if k["isthing"] == 0]
+    assert len(stuff_ids) <= 254
+    id_map = {sid: i + 1 for i, sid in enumerate(stuff_ids)}
+    id_map.update({k["id"]: 0 for k in categories if k["isthing"] == 1})
+    id_map[0] = 255
+    with open(panoptic_json) as f:
+        obj = json.load(f)
+    for anno in obj["annotations"]:
+        panoptic = rgb2id(np.asarray(Image.open(os.path.join(panoptic_root, anno["file_name"])), dtype=np.uint32))
+        output = np.full(panoptic.shape, 255, dtype=np.uint8)
+        for seg in anno["segments_info"]:
+            output[panoptic == seg["id"]] = id_map[seg["category_id"]]
+        Image.fromarray(output).save(os.path.join(sem_seg_root, anno["file_name"]))
+    return len(obj["annotations"])
