@@ -18,7 +18,7 @@ from ..data import rle
 from ..data.catalog import MetadataCatalog
 from ..data.detection_utils import BoxMode
 from . import hungarian
-from .evaluator import DatasetEvaluator
+from .evaluator import DatasetEvaluator, gather_to_rank0
 
 SCORE_THRESH = 0.6
 IOU_THRESH = 0.7
@@ -88,7 +88,11 @@ class COCOEvaluator(DatasetEvaluator):
         return hungarian.majority_vote_mapping(preds, targets, range(num_clusters), NUM_GT_CLASSES)
 
     def evaluate(self):
-        coco_results = list(itertools.chain(*[p["instances"] for p in self._predictions]))
+        parts = gather_to_rank0(self._predictions)
+        if parts is None:
+            return {}  # only the main process evaluates (:189-197)
+        predictions = list(itertools.chain(*parts))
+        coco_results = list(itertools.chain(*[p["instances"] for p in predictions]))
         if self.mode == "hungarian_matching":
             mapping = self.cluster_mapping(coco_results)
             hungarian.save_mapping(mapping, self.hungarain_matching_save_path)

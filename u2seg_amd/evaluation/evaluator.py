@@ -1,5 +1,17 @@
 """Evaluator protocol and the inference loop (detectron2/evaluation/evaluator.py:17-224)."""
 import torch
+import torch.distributed as dist
+
+
+def gather_to_rank0(obj):
+    """[obj of rank 0, obj of rank 1, ...] on rank 0 and None elsewhere (utils/comm.py:167-218, comm.gather); a plain
+    one-element list without a process group.  The test loader shards the images over the ranks (InferenceSampler), the
+    evaluators meet again here."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
+    dist.gather_object(obj, out, dst=0)
+    return out
 
 
 class DatasetEvaluator:

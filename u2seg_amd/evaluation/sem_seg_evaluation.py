@@ -15,7 +15,7 @@ from PIL import Image
 
 from ..data.catalog import DatasetCatalog, MetadataCatalog
 from . import hungarian
-from .evaluator import DatasetEvaluator
+from .evaluator import DatasetEvaluator, gather_to_rank0
 
 SUPERCATEGORIES = ("textile", "building", "raw-material", "furniture-stuff", "floor", "plant", "food-stuff", "ground",
                    "structural", "water", "wall", "window", "ceiling", "sky", "solid")
@@ -98,10 +98,18 @@ class SemSegEvaluator(DatasetEvaluator):
 
     def evaluate(self):
         if self.mode == "hungarian_matching":
+            votes = gather_to_rank0((self.pred_det_cate, self.pseudo_gt_cate))
+            if votes is None:
+                return None
+            self.pred_det_cate = [p for part in votes for p in part[0]]
+            self.pseudo_gt_cate = [g for part in votes for g in part[1]]
             mapping = self.cluster_mapping()
             hungarian.save_mapping(mapping, self.hungarain_matching_save_path)
             return OrderedDict({"sem_seg": None, "semantic_mapping": mapping})
-        cm = self._conf_matrix
+        mats = gather_to_rank0(self._conf_matrix)
+        if mats is None:
+            return None
+        cm = self._conf_matrix = sum(mats[1:], mats[0].copy())
         acc = np.full(self._num_classes, np.nan, dtype=float)
         iou = np.full(self._num_classes, np.nan, dtype=float)
         tp = cm.diagonal()[:-1].astype(float)
