@@ -4,6 +4,10 @@ container (the reference does not travel to the GPU box); the resulting .npz / .
 
     python tests/golden/make_fixtures.py [--only NAME]
 
+Without --only: kmeans, knn, ops, model_small, trajectory, inference.  The host-side fixtures need their stand-ins in place
+before detectron2.data is imported and therefore run one per process:
+    --only data | eval | pseudo_panoptic | label_prep | config
+
 Stand-ins (none of them carries hot-path arithmetic except the two torchvision ops):
   * fvcore / iopath / yacs / omegaconf / termcolor / cv2 ... : registry, config node, weight init, smooth_l1 etc.
   * torchvision.ops.roi_align -> the reference's own vendored C++ op ROIAlignRotated (layers/csrc/ROIAlignRotated/
@@ -1204,6 +1208,31 @@ def gen_label_prep_fixture():
     print("wrote label_prep_golden", {k: np.unique(v).tolist() for k, v in sem_arrays.items()})
 
 
+def gen_config_fixture():
+    """The reference's fully resolved config (its defaults.py + the yaml _BASE_ chain) for the five U2Seg config files."""
+    install_standins()
+    sys.path.insert(0, REF)
+    import types as _types
+
+    sys.modules["detectron2._C"] = _types.ModuleType("detectron2._C")
+    from detectron2.config import get_cfg
+
+    def plain(x):
+        if isinstance(x, dict):
+            return {k: plain(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [plain(v) for v in x]
+        return x
+
+    out = {}
+    for name in ["u2seg_R50_800", "u2seg_R50_300", "u2seg_eval_800", "u2seg_eval_300"]:
+        cfg = get_cfg()
+        cfg.merge_from_file(os.path.join(REF, "configs/COCO-PanopticSegmentation/%s.yaml" % name))
+        out[name] = plain(cfg)
+    json.dump(out, open(os.path.join(HERE, "config_golden.json"), "w"))
+    print("wrote config_golden", {k: len(v) for k, v in out.items()})
+
+
 def _import_nn_utils():
     for m in ["pykeops", "pykeops.torch", "torchvision", "torchvision.transforms", "torchvision.datasets", "torchvision.models",
               "yacs", "yacs.config", "termcolor", "clip"]:
@@ -1292,6 +1321,9 @@ if __name__ == "__main__":
         gen_kmeans_fixture()
     if a.only in ("", "knn"):
         gen_knn_fixture()
+    if a.only == "config":
+        gen_config_fixture()
+        sys.exit(0)
     if a.only == "label_prep":
         gen_label_prep_fixture()
         sys.exit(0)

@@ -269,3 +269,48 @@ def test_detection_checkpointer_formats(tmp_path):
     rest = DetectionCheckpointer(model, str(tmp_path)).resume_or_load("", resume=True)
     assert rest["iteration"] == 9 and os.path.basename(path) == "model_0000009.pth"
     assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), sd.values()))
+
+
+def test_resolved_configs_equal_reference():
+    """Every key this package's config tree holds has the value the reference resolves for the same yaml (its defaults.py +
+    _BASE_ chain; fixture: tests/golden/make_fixtures.py --only config), for the four U2Seg train / eval configs - both
+    through this repo's flat copies and the values the model, solver and data path read."""
+    import json
+
+    from u2seg_amd.config import get_cfg
+
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "config_golden.json")))
+
+    def norm(x):
+        if isinstance(x, dict):
+            return {k: norm(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [norm(v) for v in x]
+        return x
+
+    def compare(mine, ref, path, skipped):
+        for k, v in mine.items():
+            here = path + [k]
+            if k not in ref:
+                skipped.append(".".join(here))
+                continue
+            if isinstance(v, dict):
+                assert isinstance(ref[k], dict), here
+                compare(v, ref[k], here, skipped)
+            elif ".".join(here) == "MODEL.WEIGHTS" and str(ref[k]).startswith("/home/"):
+                assert v == ""  # the training yamls point into the author's home directory; here: empty = random init
+            else:
+                assert norm(v) == ref[k], (".".join(here), v, ref[k])
+
+    for name, ref in gold.items():
+        cfg = get_cfg()
+        cfg.merge_from_file(os.path.join(ROOT, "configs", "COCO-PanopticSegmentation", name + ".yaml"))
+        skipped = []
+        compare(norm(cfg), ref, [], skipped)
+        assert skipped == [], skipped  # nothing in this tree is unknown to the reference
+        for key in ("MODEL", "SOLVER", "INPUT", "DATASETS", "DATALOADER", "TEST"):
+            assert key in cfg
+    # spot values the hot path depends on
+    r = gold["u2seg_R50_800"]
+    assert r["MODEL"]["ROI_HEADS"]["NUM_CLASSES"] == 800 and r["SOLVER"]["GAMMA"] == 0.02
+    assert r["DATALOADER"]["FILTER_EMPTY_ANNOTATIONS"] is False and r["INPUT"]["MASK_FORMAT"] == "bitmask"
