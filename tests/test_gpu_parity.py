@@ -1128,15 +1128,17 @@ def test_sgd_trajectory_vs_reference(F):
     finally:
         set_permutation_source(None)
     print(json.dumps(report, indent=1))
-    # Steps 0-1 see (almost) the reference's parameters: the single-step band of test_whole_model_vs_oracle.  From step 2
-    # on the bf16 and fp32 trajectories have taken a full-lr step apart and sampling decisions differ (the oracle itself
-    # moves by 1-2 % there under a 3e-7 perturbation, tests/test_oracle_golden.py), and split-K gradient accumulation
-    # order varies from run to run: 10 % per loss, 5 % on the total (measured: <= 3 % and <= 0.2 %).
+    # Step 0 sees the reference's parameters: the single-step band of test_whole_model_vs_oracle.  Afterwards the bf16 and
+    # fp32 runs drift apart and sampling decisions differ; the bf16-emulating oracle run against the same fixture (with
+    # 0 / 1e-6 / 3e-6 relative parameter noise per step, standing in for the run-to-run order of split-K accumulation)
+    # deviates by up to 2.1 % at step 1 and 5.7 % at steps 2-3 (loss_rpn_cls, 256 sampled anchors per image, is the noisy
+    # one; the others stay within 3 %), totals within 0.6 %.  Bands: 4 % / 6 % / 12 % per loss, 2 % / 3 % / 5 % on the total.
     for it, row in enumerate(report):
+        band, total_band = ((4e-2, 2e-2), (6e-2, 3e-2), (0.12, 5e-2))[min(it, 2)]
         for k in ("loss_sem_seg", "loss_rpn_cls", "loss_cls_stage0", "loss_cls_stage1", "loss_cls_stage2", "loss_mask"):
-            assert row[k][0] == pytest.approx(row[k][1], rel=4e-2 if it < 2 else 0.1), (it, k, row)
+            assert row[k][0] == pytest.approx(row[k][1], rel=band), (it, k, row)
         total = sum(v[0] for v in row.values())
-        assert total == pytest.approx(sum(v[1] for v in row.values()), rel=2e-2 if it < 2 else 5e-2), (it, row)
+        assert total == pytest.approx(sum(v[1] for v in row.values()), rel=total_band), (it, row)
     params = dict(model.named_parameters())
     disp = {}
     for k in fx["param_norm"]:
