@@ -222,7 +222,7 @@ class BatchIndexStream:
 
 
 def build_batch_data_loader(dataset, sampler, total_batch_size, *, aspect_ratio_grouping=False, num_workers=0,
-                            collate_fn=None, slot_megabytes=128, **kwargs):
+                            collate_fn=None, slot_megabytes=None, **kwargs):
     """Iterable of lists of mapped dicts, total_batch_size / world_size per list (build.py:294-359).
 
     num_workers == 0: the reference's sample-level structure.  With workers, and when every dataset dict carries its width
@@ -238,6 +238,10 @@ def build_batch_data_loader(dataset, sampler, total_batch_size, *, aspect_ratio_
 
         landscape = [d["width"] > d["height"] for d in base] if aspect_ratio_grouping else None
         prefetch = kwargs.pop("prefetch_factor", 2)
+        if slot_megabytes is None:
+            # ~10 MB per image covers a 1024 x 1333 sample (4.1 MB pixels, 1.4 MB label bytes, masks at 0.17 MB each);
+            # a batch that still does not fit travels the ordinary way (BatchPacker returns the list)
+            slot_megabytes = min(512, max(16, 10 * batch_size))
         ring = SlotRing(num_workers, slot_megabytes << 20, prefetch + 2)
         loader = torchdata.DataLoader(dataset, batch_sampler=BatchIndexStream(sampler, batch_size, landscape),
                                       num_workers=num_workers, collate_fn=BatchPacker(ring), prefetch_factor=prefetch,
