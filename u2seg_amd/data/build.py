@@ -375,8 +375,7 @@ class DevicePrefetcher:
             if self.on_gpu:
                 done = torch.cuda.Event()
                 done.record(self.stream)
-                arena.done = done
-                block.record_stream(torch.cuda.current_stream(self.device))
+                arena.done = done  # (the consumer-stream bookkeeping of the device tensors happens in __iter__)
         return moved, done
 
     def _stage(self, batch):
