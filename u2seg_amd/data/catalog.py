@@ -1,66 +1,90 @@
-"""Dataset and metadata registries (detectron2/data/catalog.py:18-236): names -> loader functions, names -> attribute bags."""
-import types
+"""Dataset and metadata registries with the surface of detectron2/data/catalog.py:18-236: `DatasetCatalog` maps a name to a
+loader function, `MetadataCatalog` maps a name to a bag of attributes that may be set once and never changed."""
 
 
-class _DatasetCatalog(dict):
-    def register(self, name, func):
-        assert callable(func), "You must register a function with `DatasetCatalog.register`!"
-        assert name not in self, "Dataset '{}' is already registered!".format(name)
-        self[name] = func
+class _Catalog:
+    """Name -> entry table shared by the two registries (membership test, listing, removal)."""
 
-    def get(self, name):
-        try:
-            f = self[name]
-        except KeyError as e:
-            raise KeyError("Dataset '{}' is not registered! Available datasets are: {}".format(
-                name, ", ".join(list(self.keys())))) from e
-        return f()
+    def __init__(self, kind):
+        self._kind, self._entries = kind, {}
+
+    def __contains__(self, name):
+        return name in self._entries
+
+    def keys(self):
+        return self._entries.keys()
 
     def list(self):
-        return list(self.keys())
+        return list(self._entries)
 
     def remove(self, name):
-        self.pop(name)
+        del self._entries[name]
+
+    pop = remove
+
+    def clear(self):
+        self._entries.clear()
 
 
-class Metadata(types.SimpleNamespace):
-    name = "N/A"
+class _DatasetCatalog(_Catalog):
+    def __init__(self):
+        super().__init__("dataset")
 
-    def __setattr__(self, key, val):
-        # the reference refuses to change a value once set (catalog.py:139-151): silent drift between loaders is a bug
-        if key in self.__dict__ and self.__dict__[key] != val:
-            raise AssertionError("Attribute '{}' in the metadata of '{}' cannot be set to a different value!\n{} != {}".format(
-                key, self.name, self.__dict__[key], val))
-        super().__setattr__(key, val)
+    def register(self, name, func):
+        if not callable(func):
+            raise AssertionError("DatasetCatalog.register needs a function returning the dataset dicts, got %r" % (func,))
+        if name in self._entries:
+            raise AssertionError("dataset '%s' is registered already" % name)
+        self._entries[name] = func
+
+    def get(self, name):
+        if name not in self._entries:
+            raise KeyError("dataset '%s' is not registered; known: %s" % (name, ", ".join(self._entries) or "none"))
+        return self._entries[name]()
+
+
+class Metadata:
+    """Attribute bag.  An attribute can be assigned the same value any number of times; a different value is an error
+    (catalog.py:139-151: two loaders disagreeing about, say, the class list is a bug, not something to paper over)."""
+
+    def __init__(self, name):
+        object.__setattr__(self, "_values", {"name": name})
 
     def __getattr__(self, key):
-        raise AttributeError("Attribute '{}' does not exist in the metadata of dataset '{}'. Available keys are {}.".format(
-            key, self.name, str(list(self.__dict__.keys()))))
+        values = object.__getattribute__(self, "_values")
+        if key in values:
+            return values[key]
+        raise AttributeError("metadata of '%s' has no '%s' (it has: %s)" % (values["name"], key, ", ".join(values)))
 
-    def as_dict(self):
-        return dict(self.__dict__)
+    def __setattr__(self, key, value):
+        values = object.__getattribute__(self, "_values")
+        if key in values and values[key] != value:
+            raise AssertionError("metadata '%s' of '%s' is already %r; refusing to replace it by %r"
+                                 % (key, values["name"], values[key], value))
+        values[key] = value
 
     def set(self, **kwargs):
-        for k, v in kwargs.items():
-            setattr(self, k, v)
+        for key, value in kwargs.items():
+            setattr(self, key, value)
         return self
 
     def get(self, key, default=None):
-        return self.__dict__.get(key, default)
+        return object.__getattribute__(self, "_values").get(key, default)
+
+    def as_dict(self):
+        return dict(object.__getattribute__(self, "_values"))
 
 
-class _MetadataCatalog(dict):
+class _MetadataCatalog(_Catalog):
+    def __init__(self):
+        super().__init__("metadata")
+
     def get(self, name):
-        assert len(name)
-        if name not in self:
-            self[name] = Metadata(name=name)
-        return self[name]
-
-    def list(self):
-        return list(self.keys())
-
-    def remove(self, name):
-        self.pop(name)
+        if not name:
+            raise AssertionError("metadata needs a dataset name")
+        if name not in self._entries:
+            self._entries[name] = Metadata(name)
+        return self._entries[name]
 
 
 DatasetCatalog = _DatasetCatalog()
