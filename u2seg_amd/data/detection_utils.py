@@ -60,14 +60,12 @@ def _apply_exif_orientation(image):
 
 
 def convert_PIL_to_numpy(image, format):
-    if format is not None:
-        image = image.convert("RGB" if format == "BGR" else format)
-    image = np.asarray(image)
+    """PIL image -> HWC (or HW1 for "L") uint8 array in `format`; "BGR" is RGB with the channel axis reversed."""
+    mode = "RGB" if format == "BGR" else format
+    pixels = np.asarray(image.convert(mode) if mode is not None else image)
     if format == "L":
-        image = np.expand_dims(image, -1)
-    elif format == "BGR":
-        image = image[:, :, ::-1]
-    return image
+        return pixels[..., None]
+    return pixels[..., ::-1] if format == "BGR" else pixels
 
 
 def read_image(file_name, format=None):
@@ -80,17 +78,16 @@ def read_image(file_name, format=None):
 
 
 def check_image_size(dataset_dict, image):
+    """The annotation's idea of the image size must match the file; a dict without a size receives the file's."""
+    h, w = image.shape[:2]
     if "width" in dataset_dict or "height" in dataset_dict:
-        image_wh = (image.shape[1], image.shape[0])
-        expected_wh = (dataset_dict["width"], dataset_dict["height"])
-        if not image_wh == expected_wh:
-            raise SizeMismatchError("Mismatched image shape{}, got {}, expect {}.".format(
-                " for image " + dataset_dict["file_name"] if "file_name" in dataset_dict else "", image_wh, expected_wh)
-                + " Please check the width/height in your annotation.")
-    if "width" not in dataset_dict:
-        dataset_dict["width"] = image.shape[1]
-    if "height" not in dataset_dict:
-        dataset_dict["height"] = image.shape[0]
+        stated = (dataset_dict["width"], dataset_dict["height"])
+        if stated != (w, h):
+            where = " for image " + dataset_dict["file_name"] if "file_name" in dataset_dict else ""
+            raise SizeMismatchError("the annotation%s states width x height = %s, the file has %s; check the json"
+                                    % (where, stated, (w, h)))
+    dataset_dict.setdefault("width", w)
+    dataset_dict.setdefault("height", h)
 
 
 def transform_instance_annotations(annotation, transforms, image_size):
@@ -98,10 +95,10 @@ def transform_instance_annotations(annotation, transforms, image_size):
     apply_polygons (detection_utils.py:270-331); bbox_mode becomes XYXY_ABS.  Modifies and returns `annotation`."""
     if isinstance(transforms, (tuple, list)):
         transforms = T.TransformList(transforms)
-    bbox = BoxMode.convert(annotation["bbox"], annotation["bbox_mode"], BoxMode.XYXY_ABS)
-    bbox = transforms.apply_box(np.array([bbox]))[0].clip(min=0)
-    annotation["bbox"] = np.minimum(bbox, list(image_size + image_size)[::-1])
-    annotation["bbox_mode"] = BoxMode.XYXY_ABS
+    corners = BoxMode.convert(annotation["bbox"], annotation["bbox_mode"], BoxMode.XYXY_ABS)
+    moved = transforms.apply_box(np.array([corners]))[0]
+    h, w = image_size
+    annotation["bbox"], annotation["bbox_mode"] = np.clip(moved, 0, [w, h, w, h]), BoxMode.XYXY_ABS
     if "segmentation" in annotation:
         segm = annotation["segmentation"]
         if isinstance(segm, list):
@@ -144,29 +141,24 @@ def annotations_to_instances(annos, image_size, mask_format="polygon"):
 
 
 def filter_empty_instances(instances, by_box=True, by_mask=True, box_threshold=1e-5):
+    """Drops instances whose box is thinner than box_threshold or whose mask has no pixel (detection_utils.py:486-520)."""
     assert by_box or by_mask
-    keep = []
+    keep = torch.ones(len(instances), dtype=torch.bool)
     if by_box:
-        keep.append(instances.gt_boxes.nonempty(threshold=box_threshold))
-    if instances.has("gt_masks") and by_mask:
-        keep.append(instances.gt_masks.nonempty())
-    if not keep:
-        return instances
-    m = keep[0]
-    for x in keep[1:]:
-        m = m & x
-    return instances[m]
+        keep &= instances.gt_boxes.nonempty(threshold=box_threshold)
+    if by_mask and instances.has("gt_masks"):
+        keep &= instances.gt_masks.nonempty()
+    return instances[keep]
 
 
 def build_augmentation(cfg, is_train):
-    """detection_utils.py:629-655: ResizeShortestEdge (+ RandomFlip in training)."""
+    """detection_utils.py:629-655: ResizeShortestEdge, followed in training by RandomFlip unless INPUT.RANDOM_FLIP is "none"."""
+    inp = cfg.INPUT
     if is_train:
-        min_size, max_size = cfg.INPUT.MIN_SIZE_TRAIN, cfg.INPUT.MAX_SIZE_TRAIN
-        sample_style = cfg.INPUT.MIN_SIZE_TRAIN_SAMPLING
+        resize = T.ResizeShortestEdge(inp.MIN_SIZE_TRAIN, inp.MAX_SIZE_TRAIN, inp.MIN_SIZE_TRAIN_SAMPLING)
     else:
-        min_size, max_size, sample_style = cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST, "choice"
-    augmentation = [T.ResizeShortestEdge(min_size, max_size, sample_style)]
-    if is_train and cfg.INPUT.RANDOM_FLIP != "none":
-        augmentation.append(T.RandomFlip(horizontal=cfg.INPUT.RANDOM_FLIP == "horizontal",
-                                         vertical=cfg.INPUT.RANDOM_FLIP == "vertical"))
-    return augmentation
+        resize = T.ResizeShortestEdge(inp.MIN_SIZE_TEST, inp.MAX_SIZE_TEST, "choice")
+    policy = [resize]
+    if is_train and inp.RANDOM_FLIP != "none":
+        policy.append(T.RandomFlip(horizontal=inp.RANDOM_FLIP == "horizontal", vertical=inp.RANDOM_FLIP == "vertical"))
+    return policy
