@@ -241,6 +241,9 @@ def install_standins():
         def ls(self, p):
             return os.listdir(p)
 
+        def mkdirs(self, p):
+            os.makedirs(p, exist_ok=True)
+
     class PathHandler:
         pass
 
@@ -1050,9 +1053,9 @@ def gen_eval_fixture():
             anns.append({"id": aid, "image_id": i + 1, "category_id": cat_ids[(i * 3 + k) % len(cat_ids)], "iscrowd": 0,
                          "bbox": [float(x0), float(y0), float(bw), float(bh)], "area": float(bw * bh)})
             aid += 1
-    cats = [{"id": c, "name": str(c), "supercategory": "x"} for c in range(1, 91)]
+    cats_json = [{"id": c, "name": str(c), "supercategory": "x"} for c in range(1, 91)]
     json_file = os.path.join(work, "val.json")
-    json.dump({"images": images, "annotations": anns, "categories": cats}, open(json_file, "w"))
+    json.dump({"images": images, "annotations": anns, "categories": cats_json}, open(json_file, "w"))
     register_coco_instances("tiny_val", {}, json_file, img_dir)
     DatasetCatalog.get("tiny_val")  # fills thing_dataset_id_to_contiguous_id
     DatasetCatalog.register("tiny_val_sem", lambda: load_sem_seg(gt_dir, img_dir))
@@ -1111,7 +1114,54 @@ def gen_eval_fixture():
     sem2.reset()
     sem2.process(inputs, outputs)
     res = sem2.evaluate()["sem_seg"]
-    out = {"images": images, "annotations": anns, "categories": cats, "predictions": preds_in,
+    # panoptic predictions: things carry cluster ids (0..299), stuff the unsupervised classes (1..27); both evaluator modes
+    import io
+
+    import panopticapi.utils as PU
+    from detectron2.evaluation import COCOPanopticEvaluator
+    from u2seg_amd.data.pseudo_panoptic import id2rgb, rgb2id
+
+    PU.id2rgb, PU.rgb2id = id2rgb, rgb2id
+    MetadataCatalog.get("tiny_val_pan").set(
+        thing_dataset_id_to_contiguous_id=dict(MetadataCatalog.get("tiny_val").thing_dataset_id_to_contiguous_id),
+        panoptic_json="unused.json", panoptic_root="unused")
+    pan_inputs, pan_outputs, pan_in = [], [], []
+    mapped_clusters = [int(k) for k, v in inst_map.items() if v != -1]
+    for im in images:
+        h, w = im["height"], im["width"]
+        ids = np.zeros((h, w), dtype=np.int32)
+        segs = []
+        blocks = [(0, h // 2, 0, w // 2), (0, h // 2, w // 2, w), (h // 2, h, 0, w // 3), (h // 2, h, w // 3, w)]
+        cats = [(True, mapped_clusters[im["id"] % len(mapped_clusters)]), (True, 298), (False, 3 + im["id"]), (False, 27)]
+        for sid, ((y0, y1, x0, x1), (thing, cat)) in enumerate(zip(blocks, cats), start=1):
+            ids[y0:y1, x0:x1] = sid
+            seg = {"id": sid, "isthing": thing, "category_id": cat}
+            if thing:
+                seg.update(score=0.9, instance_id=sid)
+            else:
+                seg.update(area=int((y1 - y0) * (x1 - x0)))
+            segs.append(seg)
+        pan_in.append({"ids": ids.tolist(), "segments_info": copy.deepcopy(segs)})
+        pan_inputs.append({"image_id": im["id"], "file_name": os.path.join(img_dir, im["file_name"])})
+        pan_outputs.append({"panoptic_seg": (torch.from_numpy(ids), segs)})
+
+    def decoded(ev):
+        return [{"image_id": p["image_id"], "file_name": p["file_name"], "segments_info": p["segments_info"],
+                 "ids": rgb2id(np.asarray(Image.open(io.BytesIO(p["png_string"])))).tolist()} for p in ev._predictions]
+
+    pan_e = COCOPanopticEvaluator("tiny_val_pan", None)  # the mapping files exist in ./hungarian_matching -> eval mode
+    assert pan_e.mode == "eval"
+    pan_e.reset()
+    pan_e.process(pan_inputs, copy.deepcopy(pan_outputs))
+    empty = tempfile.mkdtemp()
+    os.chdir(empty)
+    pan_h = COCOPanopticEvaluator("tiny_val_pan", None)
+    assert pan_h.mode == "hungarian_matching"
+    pan_h.reset()
+    pan_h.process(pan_inputs, copy.deepcopy(pan_outputs))
+    os.chdir(work)
+    out = {"images": images, "annotations": anns, "categories": cats_json, "predictions": preds_in,
+           "panoptic_inputs": pan_in, "panoptic_eval": decoded(pan_e), "panoptic_matching": decoded(pan_h),
            "coco_results": coco_results, "instance_mapping": {str(k): v for k, v in inst_map.items()},
            "instance_mapping_file": json.load(open("./hungarian_matching/instance_mapping.json")),
            "semantic_mapping_file": sem_map, "semantic_votes": [[int(a), int(b)] for a, b in votes],

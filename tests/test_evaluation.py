@@ -134,3 +134,44 @@ def test_vote_mapping_and_loop():
     model = Model().train()
     assert inference_on_dataset(model, [[{"v": 1}, {"v": 2}], [{"v": 3}]], Sum()) == {"sum": 12}
     assert model.training
+
+
+def test_panoptic_conversion_matches_reference(tiny_val, tmp_path, monkeypatch):
+    """COCOPanopticEvaluator.process in both modes == the reference's (fixture "panoptic_eval" / "panoptic_matching"): with
+    the mapping files present, thing clusters become dataset category ids, stuff classes 300 + supercategory, segments of
+    unmapped clusters are erased from the id map; without them the predictions pass through."""
+    import io
+
+    from u2seg_amd.data.pseudo_panoptic import rgb2id
+    from u2seg_amd.evaluation import COCOPanopticEvaluator
+
+    fx, inputs, _ = tiny_val
+    os.makedirs("hungarian_matching")
+    json.dump(fx["instance_mapping_file"], open("hungarian_matching/instance_mapping.json", "w"))
+    json.dump(fx["semantic_mapping_file"], open("hungarian_matching/semantic_mapping.json", "w"))
+    MetadataCatalog.get("tiny_val_pan").set(
+        thing_dataset_id_to_contiguous_id=dict(MetadataCatalog.get("tiny_val").thing_dataset_id_to_contiguous_id))
+
+    def outputs():
+        return [{"panoptic_seg": (torch.tensor(p["ids"], dtype=torch.int32), [dict(s) for s in p["segments_info"]])}
+                for p in fx["panoptic_inputs"]]
+
+    def decoded(ev):
+        return [{"image_id": p["image_id"], "file_name": p["file_name"], "segments_info": p["segments_info"],
+                 "ids": rgb2id(np.asarray(Image.open(io.BytesIO(p["png_string"])))).tolist()} for p in ev._predictions]
+
+    ev = COCOPanopticEvaluator("tiny_val_pan")
+    assert ev.mode == "eval"
+    ev.process(inputs, outputs())
+    assert decoded(ev) == fx["panoptic_eval"]
+    erased = [p for p, q in zip(fx["panoptic_eval"], fx["panoptic_inputs"]) if len(p["segments_info"]) < len(q["segments_info"])]
+    assert erased and all(0 in np.unique(p["ids"]) for p in erased)  # cluster 298 has no mapping: its pixels are void
+    res = ev.evaluate()["panoptic_seg"]
+    saved = json.load(open(res["predictions_json"]))
+    assert [a["file_name"] for a in saved["annotations"]] == [p["file_name"] for p in fx["panoptic_eval"]]
+    assert res["num_images"] == len(fx["images"])
+    monkeypatch.chdir(tmp_path / "images")  # a directory without mapping files
+    ev2 = COCOPanopticEvaluator("tiny_val_pan")
+    assert ev2.mode == "hungarian_matching"
+    ev2.process(inputs, outputs())
+    assert decoded(ev2) == fx["panoptic_matching"]
