@@ -1342,8 +1342,18 @@ def gen_knn_fixture():
         d_knns, ind_knns = mod.partitioned_kNN(x, K=K, recompute=True, partitions_size=300)
         ind_one, d_one = mod.kNN(x, x, K=K)
     assert torch.equal(d_knns, d_one)
+    # the representative of every cluster (nn_utils.py:408-439) from the density d_knns.mean(1), on labels with an empty
+    # cluster and tied densities (the planted twin rows)
+    gl = torch.Generator().manual_seed(12)
+    labels = torch.randint(0, 14, (N,), generator=gl)
+    labels[labels == 6] = 5  # cluster 6 stays empty
+    neighbors_dist = d_knns.mean(dim=1)
+    with mock.patch.object(torch.Tensor, "cuda", lambda self, *a, **k: self):
+        sel_all = mod.get_selection_without_reg(labels, neighbors_dist, 14, final_sample_num=13)
+        sel_cut = mod.get_selection_without_reg(labels, neighbors_dist, [9, 2, 6, 0, 13], final_sample_num=3)
     np.savez_compressed(os.path.join(HERE, "knn_golden.npz"), x=x.numpy(), d_knns=d_knns.numpy(), ind_knns=ind_knns.numpy(),
-                        K=np.array(K), partitions_size=np.array(300))
+                        K=np.array(K), partitions_size=np.array(300), sel_labels=labels.numpy(), sel_all=np.asarray(sel_all),
+                        sel_cut=np.asarray(sel_cut))
     print("wrote knn_golden.npz", d_knns.shape, float(d_knns.mean()))
 
 

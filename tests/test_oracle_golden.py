@@ -230,3 +230,18 @@ def test_whole_model_inference(golden_dir):
         ref_info = json.loads(str(g["panoptic_info_%d" % i]))
         assert [(d["isthing"], d["category_id"]) for d in info] == [(d["isthing"], d["category_id"]) for d in ref_info]
         assert (pan.numpy() != g["panoptic_%d" % i]).mean() < 1e-3
+
+
+def test_cluster_representatives(golden_dir):
+    """cluster/select.py (host logic, any device) == the reference's get_selection_without_reg on 14 clusters with an
+    empty one, tied densities and a truncated custom ordering (fixture generated next to the kNN lists)."""
+    from u2seg_amd.cluster.select import cluster_label_table, get_selection_without_reg
+
+    g = np.load(os.path.join(golden_dir, "knn_golden.npz"))
+    labels = torch.from_numpy(g["sel_labels"])
+    density = torch.from_numpy(g["d_knns"]).mean(dim=1)
+    assert np.array_equal(get_selection_without_reg(labels, density, 14, final_sample_num=13), g["sel_all"])
+    assert np.array_equal(get_selection_without_reg(labels, density, [9, 2, 6, 0, 13], final_sample_num=3), g["sel_cut"])
+    with pytest.raises(AssertionError):
+        get_selection_without_reg(labels, density, 14, final_sample_num=14)  # cluster 6 is empty: only 13 candidates
+    assert cluster_label_table(["0.jpg", "1.jpg"], torch.tensor([7, 3])) == {"0.jpg": 7, "1.jpg": 3}

@@ -1,3 +1,3 @@
-from . import kmeans, knn
+from . import kmeans, knn, select
 
-__all__ = ["kmeans", "knn"]
+__all__ = ["kmeans", "knn", "select"]
