@@ -13,7 +13,6 @@ import json
 import os
 import tempfile
 
-import numpy as np
 from PIL import Image
 
 from ..data.catalog import MetadataCatalog

@@ -6,7 +6,6 @@ IoU > 0.15 is a vote; evaluate() writes the majority mapping to ./hungarian_matc
 mode "eval": predictions are mapped (unmapped classes become the extra "ignore" label 16), a 17 x 17 confusion matrix is
 accumulated with one bincount per image, and mIoU / fwIoU / mACC / pACC plus the per-class numbers come out of it.
 Boundary IoU needs OpenCV, which this image does not have; the reference switches it off in that case too (:103-109)."""
-import json
 from collections import OrderedDict
 
 import numpy as np
