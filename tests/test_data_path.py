@@ -392,3 +392,46 @@ def test_label_preparation_steps_match_reference_scripts(tmp_path):
     from u2seg_amd.evaluation.sem_seg_evaluation import STUFF_TO_SUPERCATEGORY
 
     assert tuple(PP.STUFF_ID_TO_SUPERCATEGORY.values()) == STUFF_TO_SUPERCATEGORY  # one table, two orderings
+
+
+def test_rle_and_transform_properties():
+    """Size-independent properties (hypothesis): decode(encode(m)) == m and compress(uncompressed(m)) == encode(m) for random
+    masks incl. empty / full / single-column ones; area and tight box agree with the mask; flipping twice is the identity on
+    images, boxes and masks; a resize maps the image corners onto the new corners."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+    from hypothesis.extra import numpy as hnp
+
+    @settings(max_examples=60, deadline=None)
+    @given(hnp.arrays(np.uint8, st.tuples(st.integers(1, 17), st.integers(1, 23)), elements=st.integers(0, 1)))
+    def codec(mask):
+        enc = rle.encode(mask)
+        assert np.array_equal(rle.decode(enc), mask) and enc["size"] == list(mask.shape)
+        assert rle.compress(uncompressed_rle(mask)) == enc
+        assert rle.area(enc) == int(mask.sum())
+        x, y, w, h = rle.to_bbox(enc)
+        if mask.any():
+            ys, xs = np.nonzero(mask)
+            assert (x, y, w, h) == (xs.min(), ys.min(), xs.max() - xs.min() + 1, ys.max() - ys.min() + 1)
+        else:
+            assert (x, y, w, h) == (0, 0, 0, 0)
+
+    codec()
+
+    @settings(max_examples=30, deadline=None)
+    @given(st.integers(2, 40), st.integers(2, 40), st.integers(0, 2 ** 31 - 1))
+    def geometry(h, w, seed):
+        rs = np.random.RandomState(seed)
+        img = rs.randint(0, 255, (h, w, 3)).astype(np.uint8)
+        box = np.array([[rs.uniform(0, w / 2), rs.uniform(0, h / 2), rs.uniform(w / 2, w), rs.uniform(h / 2, h)]])
+        twice = T.TransformList([T.HFlipTransform(w), T.HFlipTransform(w)])
+        assert np.array_equal(twice.apply_image(img), img) and np.allclose(twice.apply_box(box.copy()), box)
+        one = T.HFlipTransform(w).apply_box(box.copy())
+        assert np.allclose(one[:, [0, 2]], w - box[:, [2, 0]]) and np.allclose(one[:, [1, 3]], box[:, [1, 3]])
+        nh, nw = T.ResizeShortestEdge.get_output_shape(h, w, 32, 50)
+        assert max(nh, nw) <= 50 and (min(nh, nw) == 32 or max(nh, nw) == 50)
+        rt = T.ResizeTransform(h, w, nh, nw)
+        assert rt.apply_image(img).shape == (nh, nw, 3)
+        assert np.allclose(rt.apply_box(np.array([[0.0, 0.0, w, h]])), [[0, 0, nw, nh]])
+
+    geometry()
