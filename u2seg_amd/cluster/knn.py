@@ -31,8 +31,9 @@ def kNN(x_train, x_test, K=20):
     nq, nt, d = x_test.shape[0], x_train.shape[0], x_train.shape[1]
     if nt < K:
         raise ValueError("kNN: %d train rows < K = %d (the reference assumes at least K rows, nn_utils.py:236)" % (nt, K))
-    d_knn = torch.empty((nq, K), dtype=torch.float32, device=x_test.device)
-    ind_knn = torch.empty((nq, K), dtype=torch.int64, device=x_test.device)
+    # a query row with non-finite features has no ranked neighbour: it keeps NaN distances and index -1
+    d_knn = torch.full((nq, K), float("nan"), dtype=torch.float32, device=x_test.device)
+    ind_knn = torch.full((nq, K), -1, dtype=torch.int64, device=x_test.device)
     ws = _workspace(nq, nt, d, K, x_test.device)
     _hip.call("u2_knn", x_test, x_train, ws, d_knn, ind_knn, nq, nt, d, K)
     return ind_knn, d_knn
