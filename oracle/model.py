@@ -321,7 +321,12 @@ class OracleModel:
         gtb = torch.cat([p.get("gt_boxes", p["proposal_boxes"]) for p in proposals])
         fg = torch.nonzero((gt_classes >= 0) & (gt_classes < K), as_tuple=True)[0]
         tgt = ops.get_deltas(boxes[fg], gtb[fg], weights)
-        loss_box = torch.abs(deltas.float()[fg] - tgt).sum() / max(gt_classes.numel(), 1.0)
+        pred = deltas.float()
+        if pred.shape[1] != 4:  # class-specific regression (fast_rcnn.py:434-437): the 4 outputs of the gt class
+            pred = pred.view(-1, K, 4)[fg, gt_classes[fg]]
+        else:
+            pred = pred[fg]
+        loss_box = torch.abs(pred - tgt).sum() / max(gt_classes.numel(), 1.0)
         return loss_cls, loss_box
 
     def forward_box(self, feats, proposals, gt_instances):
@@ -359,8 +364,10 @@ class OracleModel:
         return outs
 
     def mask_head_features(self, x):
-        for i in range(1, 5):
+        i = 1
+        while "roi_heads.mask_head.mask_fcn%d.weight" % i in self.p:  # ROI_MASK_HEAD.NUM_CONV layers (4 in the U2Seg configs)
             x = self.conv(x, "roi_heads.mask_head.mask_fcn%d" % i, 1, 1, relu=True)
+            i += 1
         w, b = self.q(self.p["roi_heads.mask_head.deconv.weight"]), self.p["roi_heads.mask_head.deconv.bias"]
         return self.q(F.relu(F.conv_transpose2d(self.q(x), w, b, stride=2)))
 
@@ -376,6 +383,11 @@ class OracleModel:
                                                 self.cfg.MODEL.ROI_MASK_HEAD.POOLER_RESOLUTION, scales))
         x = self.mask_head_features(pooled)
         logits = self.conv(x, "roi_heads.mask_head.predictor")
+        return self.mask_loss_from_logits(logits, fgs)
+
+    def mask_loss_from_logits(self, logits, fgs):
+        """mask_rcnn_loss (mask_head.py:33-112): BCE between the gt-class channel of every foreground ROI and its gt mask
+        cropped to the ROI at the logits' resolution."""
         side = logits.shape[-1]
         gt_classes, gt_masks = [], []
         for p in fgs:

@@ -1283,6 +1283,131 @@ def gen_config_fixture():
     print("wrote config_golden", {k: len(v) for k, v in out.items()})
 
 
+def gen_refunit_fixture():
+    """The seeded scenarios of the reference's own unit tests with published expected values - tests/modeling/test_rpn.py:35-67,
+    test_fast_rcnn.py:17-45, test_roi_heads.py:39-92 - run through the reference here.  The reference's results are first
+    checked against the constants in those tests (so the stand-ins are validated by numbers they did not produce).  The
+    seeded module weights are hundreds of MB (fc1 alone is 1024 x 50176), so the fixture keeps the outputs of the heavy
+    layers instead - RPN head maps, box predictor outputs, mask logits - together with the reference's sampled proposals;
+    the oracle is then held to the same published constants for everything downstream of those layers."""
+    import_reference()
+    from detectron2.config import get_cfg
+    from detectron2.layers import ShapeSpec
+    from detectron2.modeling.backbone import build_backbone
+    from detectron2.modeling.box_regression import Box2BoxTransform
+    from detectron2.modeling.proposal_generator import RPN, build_proposal_generator
+    from detectron2.modeling.roi_heads import StandardROIHeads
+    from detectron2.modeling.roi_heads.fast_rcnn import FastRCNNOutputLayers
+    from detectron2.structures import BitMasks, Boxes, ImageList, Instances
+    from detectron2.utils.events import EventStorage
+
+    arrays = {}
+
+    def capture_rpn_head(rpn, prefix):
+        def hook(_m, _inp, out):
+            arrays[prefix + "objectness"] = out[0][0].detach().numpy().copy()   # single level: [N, A, H, W]
+            arrays[prefix + "deltas"] = out[1][0].detach().numpy().copy()       # [N, 4A, H, W]
+        rpn.rpn_head.register_forward_hook(hook)
+
+    # ---- test_rpn.py:35-67 ----
+    torch.manual_seed(121)
+    cfg = get_cfg()
+    backbone = build_backbone(cfg)
+    rpn = RPN(cfg, backbone.output_shape())
+    capture_rpn_head(rpn, "rpn_")
+    images = ImageList(torch.rand(2, 20, 30), [(10, 10), (20, 30)])
+    features = {"res4": torch.rand(2, 1024, 1, 2)}
+    gt = Instances((15, 15))
+    gt.gt_boxes = Boxes(torch.tensor([[1, 1, 3, 3], [2, 2, 6, 6]], dtype=torch.float32))
+    with EventStorage():
+        proposals, losses = rpn(images, features, [gt[0], gt[1]])
+    assert torch.allclose(losses["loss_rpn_cls"], torch.tensor(0.08011703193)), losses
+    assert torch.allclose(losses["loss_rpn_loc"], torch.tensor(0.101470276)), losses
+    assert torch.allclose(proposals[0].proposal_boxes.tensor, torch.tensor([[0, 0, 10, 10], [7.2702, 0, 10, 10]]), atol=1e-4)
+    assert torch.allclose(proposals[0].objectness_logits, torch.tensor([0.1596, -0.0007]), atol=1e-4)
+    arrays["rpn_proposals1_boxes"] = proposals[1].proposal_boxes.tensor.numpy()
+    arrays["rpn_proposals1_logits"] = proposals[1].objectness_logits.numpy()
+
+    # ---- test_fast_rcnn.py:17-45 ----
+    torch.manual_seed(132)
+    pred = FastRCNNOutputLayers(ShapeSpec(channels=8), box2box_transform=Box2BoxTransform(weights=(10, 10, 5, 5)), num_classes=5)
+    pooled = torch.rand(2, 8)
+    scores, deltas = pred(pooled)
+    prop = Instances((10, 10))
+    prop.proposal_boxes = Boxes(torch.tensor([[0.8, 1.1, 3.2, 2.8], [2.3, 2.5, 7, 8]], dtype=torch.float32))
+    prop.gt_boxes = Boxes(torch.tensor([[1, 1, 3, 3], [2, 2, 6, 6]], dtype=torch.float32))
+    prop.gt_classes = torch.tensor([1, 2])
+    with EventStorage():
+        fl = pred.losses((scores, deltas), [prop])
+    assert torch.allclose(fl["loss_cls"], torch.tensor(1.7951188087)) and torch.allclose(fl["loss_box_reg"], torch.tensor(4.0357131958)), fl
+    arrays["fast_scores"], arrays["fast_deltas"] = scores.detach().numpy(), deltas.detach().numpy()
+
+    # ---- test_roi_heads.py:39-92 ----
+    torch.manual_seed(121)
+    cfg = get_cfg()
+    cfg.MODEL.ROI_BOX_HEAD.NAME = "FastRCNNConvFCHead"
+    cfg.MODEL.ROI_BOX_HEAD.NUM_FC = 2
+    cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE = "ROIAlignV2"
+    cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS = (10, 10, 5, 5)
+    cfg.MODEL.MASK_ON = True
+    images = ImageList(torch.rand(2, 20, 30), [(10, 10), (20, 30)])
+    features = {"res4": torch.rand(2, 1024, 1, 2)}
+    shape = {"res4": ShapeSpec(channels=1024, stride=16)}
+    g0 = Instances((15, 15))
+    g0.gt_boxes = Boxes(torch.tensor([[1, 1, 3, 3], [2, 2, 6, 6]], dtype=torch.float32))
+    g0.gt_classes = torch.tensor([2, 1])
+    g0.gt_masks = BitMasks(torch.rand((2, 15, 15)) > 0.5)
+    g1 = Instances((15, 15))
+    g1.gt_boxes = Boxes(torch.tensor([[1, 5, 2, 8], [7, 3, 10, 5]], dtype=torch.float32))
+    g1.gt_classes = torch.tensor([1, 2])
+    g1.gt_masks = BitMasks(torch.rand((2, 15, 15)) > 0.5)
+    pg = build_proposal_generator(cfg, shape)
+    heads = StandardROIHeads(cfg, shape)
+    capture_rpn_head(pg, "heads_rpn_")
+    box_losses = heads.box_predictor.losses
+
+    def capture_box(predictions, props):
+        arrays["heads_scores"], arrays["heads_deltas"] = predictions[0].detach().numpy().copy(), predictions[1].detach().numpy().copy()
+        for i, p in enumerate(props):
+            arrays["heads_sampled%d_boxes" % i] = p.proposal_boxes.tensor.numpy().copy()
+            arrays["heads_sampled%d_classes" % i] = p.gt_classes.numpy().copy()
+            arrays["heads_sampled%d_gt_boxes" % i] = p.gt_boxes.tensor.numpy().copy()
+        return box_losses(predictions, props)
+
+    heads.box_predictor.losses = capture_box
+    mask_layers = heads.mask_head.layers
+
+    def capture_mask(x):
+        out = mask_layers(x)
+        arrays["heads_mask_logits"] = out.detach().numpy().copy()
+        return out
+
+    heads.mask_head.layers = capture_mask
+
+    def mask_pre(_m, args):
+        for i, p in enumerate(args[1]):
+            arrays["heads_fg%d_boxes" % i] = p.proposal_boxes.tensor.numpy().copy()
+            arrays["heads_fg%d_classes" % i] = p.gt_classes.numpy().copy()
+            arrays["heads_fg%d_masks" % i] = p.gt_masks.tensor.numpy().copy()
+
+    heads.mask_head.register_forward_pre_hook(mask_pre)
+    with EventStorage():
+        proposals, pl = pg(images, features, [g0, g1])
+        _, dl = heads(images, features, proposals, [g0, g1])
+    dl.update(pl)
+    expected = {"loss_cls": 4.5253729820251465, "loss_box_reg": 0.009785720147192478, "loss_mask": 0.693184494972229,
+                "loss_rpn_cls": 0.08186662942171097, "loss_rpn_loc": 0.1104838103055954}
+    for k, v in expected.items():
+        assert torch.allclose(dl[k], torch.tensor(v)), (k, float(dl[k]), v)
+    for i, p in enumerate(proposals):
+        arrays["heads_proposals%d_boxes" % i] = p.proposal_boxes.tensor.numpy().copy()
+        arrays["heads_proposals%d_logits" % i] = p.objectness_logits.numpy().copy()
+    arrays["heads_masks0"], arrays["heads_masks1"] = g0.gt_masks.tensor.numpy(), g1.gt_masks.tensor.numpy()
+    np.savez_compressed(os.path.join(HERE, "refunit_golden.npz"), **arrays)
+    print("wrote refunit_golden: the reference reproduces the constants of its tests;", len(arrays), "arrays,",
+          sum(v.size * v.itemsize for v in arrays.values()) // 1024, "KiB raw", {k: v.shape for k, v in arrays.items() if "mask_logits" in k or "sampled0" in k})
+
+
 def _import_nn_utils():
     for m in ["pykeops", "pykeops.torch", "torchvision", "torchvision.transforms", "torchvision.datasets", "torchvision.models",
               "yacs", "yacs.config", "termcolor", "clip"]:
@@ -1381,6 +1506,9 @@ if __name__ == "__main__":
         gen_kmeans_fixture()
     if a.only in ("", "knn"):
         gen_knn_fixture()
+    if a.only == "refunit":
+        gen_refunit_fixture()
+        sys.exit(0)
     if a.only == "config":
         gen_config_fixture()
         sys.exit(0)

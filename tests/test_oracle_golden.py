@@ -245,3 +245,93 @@ def test_cluster_representatives(golden_dir):
     with pytest.raises(AssertionError):
         get_selection_without_reg(labels, density, 14, final_sample_num=14)  # cluster 6 is empty: only 13 candidates
     assert cluster_label_table(["0.jpg", "1.jpg"], torch.tensor([7, 3])) == {"0.jpg": 7, "1.jpg": 3}
+
+
+def _default_oracle(opts=()):
+    """Oracle over the package's default config (no yaml) = the reference's get_cfg() defaults the unit tests below use:
+    single-level RPN on res4 (stride 16), 5 anchor sizes x 3 ratios, StandardROIHeads with 80 classes."""
+    from u2seg_amd.config import get_cfg
+
+    cfg = get_cfg()
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu"] + list(opts))
+    om = OracleModel(cfg, {})
+    om.strides["res4"] = 16
+    return om
+
+
+def _rpn_outputs(om, objectness, deltas, gt_boxes_per_image, image_sizes):
+    from u2seg_amd.structures import Boxes, Instances
+
+    o, d = torch.from_numpy(objectness), torch.from_numpy(deltas)
+    n, _, h, w = o.shape
+    objs = [o.permute(0, 2, 3, 1).flatten(1)]
+    dlts = [d.view(n, -1, 4, h, w).permute(0, 3, 4, 1, 2).flatten(1, -2)]
+    anchors = ops.grid_anchors([(h, w)], [16], om.cell_anchors, om.cfg.MODEL.ANCHOR_GENERATOR.OFFSET)
+    gts = []
+    for b in gt_boxes_per_image:
+        inst = Instances((15, 15))
+        inst.gt_boxes = Boxes(torch.tensor(b, dtype=torch.float32))
+        gts.append(inst)
+    labels, matched = om.rpn_label_and_sample(torch.cat(anchors), gts)
+    losses = om.rpn_losses(anchors, objs, dlts, labels, matched)
+    return losses, om.rpn_proposals(anchors, objs, dlts, image_sizes), gts
+
+
+def test_reference_unit_test_constants(golden_dir):
+    """The constants the reference's own unit tests assert - tests/modeling/test_rpn.py:44-66 (RPN losses, proposals of
+    image 0), test_fast_rcnn.py:39-44 (class-specific box losses), test_roi_heads.py:76-82 (five losses of RPN +
+    StandardROIHeads with a mask head) - reached by the oracle from the outputs of the seeded layers (refunit_golden.npz:
+    RPN head maps, box predictor outputs, mask logits; the weights themselves are 100s of MB).  The fixture generator
+    asserts that the reference run here hits the same constants, so they pin both sides independently."""
+    g = np.load(os.path.join(golden_dir, "refunit_golden.npz"))
+    # --- test_rpn ---
+    om = _default_oracle()
+    losses, props, _ = _rpn_outputs(om, g["rpn_objectness"], g["rpn_deltas"], [[[1, 1, 3, 3]], [[2, 2, 6, 6]]], [(10, 10), (20, 30)])
+    assert torch.allclose(losses["loss_rpn_cls"], torch.tensor(0.08011703193))
+    assert torch.allclose(losses["loss_rpn_loc"], torch.tensor(0.101470276))
+    assert torch.allclose(props[0]["proposal_boxes"], torch.tensor([[0, 0, 10, 10], [7.2702, 0, 10, 10]]), atol=1e-4)
+    assert torch.allclose(props[0]["objectness_logits"], torch.tensor([0.1596, -0.0007]), atol=1e-4)
+    assert torch.allclose(props[1]["proposal_boxes"], torch.from_numpy(g["rpn_proposals1_boxes"]), atol=1e-5)
+    assert torch.allclose(props[1]["objectness_logits"], torch.from_numpy(g["rpn_proposals1_logits"]), atol=1e-6)
+    # --- test_fast_rcnn ---
+    om = _default_oracle()
+    om.num_classes = 5
+    prop = {"proposal_boxes": torch.tensor([[0.8, 1.1, 3.2, 2.8], [2.3, 2.5, 7, 8]]), "gt_classes": torch.tensor([1, 2]),
+            "gt_boxes": torch.tensor([[1.0, 1, 3, 3], [2, 2, 6, 6]])}
+    lc, lb = om.box_losses(torch.from_numpy(g["fast_scores"]), torch.from_numpy(g["fast_deltas"]), [prop], (10, 10, 5, 5))
+    assert torch.allclose(lc, torch.tensor(1.7951188087)) and torch.allclose(lb, torch.tensor(4.0357131958))
+    # --- test_roi_heads ---
+    om = _default_oracle(["MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS", (10, 10, 5, 5), "MODEL.MASK_ON", True])
+    gt_boxes = [[[1, 1, 3, 3], [2, 2, 6, 6]], [[1, 5, 2, 8], [7, 3, 10, 5]]]
+    losses, props, gts = _rpn_outputs(om, g["heads_rpn_objectness"], g["heads_rpn_deltas"], gt_boxes, [(10, 10), (20, 30)])
+    assert torch.allclose(losses["loss_rpn_cls"], torch.tensor(0.08186662942171097))
+    assert torch.allclose(losses["loss_rpn_loc"], torch.tensor(0.1104838103055954))
+    from u2seg_amd.structures import BitMasks
+
+    for i, (p, inst, cls) in enumerate(zip(props, gts, ([2, 1], [1, 2]))):
+        assert torch.allclose(p["proposal_boxes"], torch.from_numpy(g["heads_proposals%d_boxes" % i]), atol=1e-5)
+        inst.gt_classes = torch.tensor(cls)
+        inst.gt_masks = BitMasks(torch.from_numpy(g["heads_masks%d" % i]))
+    sampled = om.label_and_sample_proposals(props, gts)
+    for i, s in enumerate(sampled):  # the same proposals with the same labels; their order is the sampler's permutation
+        mine = sorted(zip(s["proposal_boxes"].tolist(), s["gt_classes"].tolist(), s["gt_boxes"].tolist()))
+        ref = sorted(zip(g["heads_sampled%d_boxes" % i].tolist(), g["heads_sampled%d_classes" % i].tolist(),
+                         g["heads_sampled%d_gt_boxes" % i].tolist()))
+        assert len(mine) == len(ref)
+        for a, b in zip(mine, ref):
+            assert np.allclose(a[0], b[0], atol=1e-5) and a[1] == b[1] and np.allclose(a[2], b[2])
+    ref_sampled = [{"proposal_boxes": torch.from_numpy(g["heads_sampled%d_boxes" % i]),
+                    "gt_classes": torch.from_numpy(g["heads_sampled%d_classes" % i]),
+                    "gt_boxes": torch.from_numpy(g["heads_sampled%d_gt_boxes" % i])} for i in range(2)]
+    lc, lb = om.box_losses(torch.from_numpy(g["heads_scores"]), torch.from_numpy(g["heads_deltas"]), ref_sampled, (10, 10, 5, 5))
+    assert torch.allclose(lc, torch.tensor(4.5253729820251465)) and torch.allclose(lb, torch.tensor(0.009785720147192478))
+    fgs = [{"proposal_boxes": torch.from_numpy(g["heads_fg%d_boxes" % i]), "gt_classes": torch.from_numpy(g["heads_fg%d_classes" % i]),
+            "gt_masks": torch.from_numpy(g["heads_fg%d_masks" % i])} for i in range(2)]
+    lm = om.mask_loss_from_logits(torch.from_numpy(g["heads_mask_logits"]), fgs)
+    assert torch.allclose(lm, torch.tensor(0.693184494972229))
+    # test_boxes.py:147-186: pairwise IoU of a unit box against six shifted / scaled ones
+    b1 = torch.tensor([[0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 1.0, 1.0]])
+    b2 = torch.tensor([[0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 0.5, 1.0], [0.0, 0.0, 1.0, 0.5], [0.0, 0.0, 0.5, 0.5],
+                       [0.5, 0.5, 1.0, 1.0], [0.5, 0.5, 1.5, 1.5]])
+    want = torch.tensor([[1.0, 0.5, 0.5, 0.25, 0.25, 0.25 / (2 - 0.25)]] * 2)
+    assert torch.allclose(ops.pairwise_iou(b1, b2), want)
