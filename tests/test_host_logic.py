@@ -120,6 +120,22 @@ def test_anchor_generator_and_sampling():
                              [-28.0, -8.0, 36.0, 8.0], [-12.0, -16.0, 20.0, 16.0], [-4.0, -32.0, 12.0, 32.0],
                              [-60.0, -16.0, 68.0, 16.0], [-28.0, -32.0, 36.0, 32.0], [-12.0, -64.0, 20.0, 64.0]])
     assert torch.allclose(anc, expected)
+    # tests/modeling/test_anchor_generator.py:45-72: the same cell anchors on a grid shifted by offset 0.5 (half a stride)
+    shifted = DefaultAnchorGenerator(sizes=[[32, 64]], aspect_ratios=[[0.25, 1, 4]], strides=[4], offset=0.5).grid_anchors([(1, 2)])[0]
+    assert torch.allclose(shifted, expected + 2.0)
+    from oracle import ops as O
+
+    cell = [O.generate_cell_anchors([32, 64], [0.25, 1, 4]).float()]
+    assert torch.allclose(O.grid_anchors([(1, 2)], [4], cell, 0.5)[0], expected + 2.0)
+    assert torch.allclose(O.grid_anchors([(1, 2)], [4], cell, 0.0)[0], expected)
+    # tests/structures/test_imagelist.py:20-44: padding to a multiple of the divisibility, sizes remembered
+    from u2seg_amd.structures import ImageList
+
+    il = ImageList.from_tensors([torch.ones(3, 15, 20)], 4)
+    assert tuple(il.tensor.shape) == (1, 3, 16, 20) and list(il.image_sizes[0]) == [15, 20]
+    il = ImageList.from_tensors([torch.ones(3, 25, 20), torch.ones(3, 10, 10)], 4)
+    assert tuple(il.tensor.shape) == (2, 3, 28, 20) and [list(x) for x in il.image_sizes] == [[25, 20], [10, 10]]
+    assert float(il.tensor[1, :, 10:, :].abs().sum()) == 0 and float(il.tensor[1, :, :10, :10].sum()) == 300
     import numpy as np
 
     g = np.load(os.path.join(ROOT, "tests", "golden", "ops_golden.npz"))
