@@ -335,3 +335,17 @@ def test_reference_unit_test_constants(golden_dir):
                        [0.5, 0.5, 1.0, 1.0], [0.5, 0.5, 1.5, 1.5]])
     want = torch.tensor([[1.0, 0.5, 0.5, 0.25, 0.25, 0.25 / (2 - 0.25)]] * 2)
     assert torch.allclose(ops.pairwise_iou(b1, b2), want)
+
+
+def test_mask_crop_and_paste_are_inverse():
+    """tests/layers/test_mask_ops.py:69-101 (crop with ROIAlign, paste back, IoU with the original mask; the reference
+    needs the COCO json for its masks and demands > 0.95 on large objects): here on ellipses of several sizes."""
+    yy, xx = torch.meshgrid(torch.arange(120.0), torch.arange(160.0), indexing="ij")
+    for cx, cy, rx, ry in ((80.0, 60.0, 50.0, 40.0), (40.0, 70.0, 25.0, 30.0), (110.0, 30.0, 30.0, 18.0)):
+        mask = (((xx + 0.5 - cx) / rx) ** 2 + ((yy + 0.5 - cy) / ry) ** 2) <= 1.0
+        box = torch.tensor([[cx - rx, cy - ry, cx + rx, cy + ry]])
+        crop = ops.crop_and_resize_masks(mask[None], box, 28)
+        assert crop.shape == (1, 28, 28) and crop.dtype == torch.bool
+        pasted = OracleModel.paste_masks(crop.float(), box, (120, 160))[0]
+        inter, union = (pasted & mask).sum().item(), (pasted | mask).sum().item()
+        assert inter / union > 0.95, (cx, cy, inter / union)
