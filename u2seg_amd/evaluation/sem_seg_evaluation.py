@@ -4,7 +4,8 @@
 mode "hungarian_matching": every (predicted class, ground-truth supercategory) pair of an image whose masks overlap with
 IoU > 0.15 is a vote; evaluate() writes the majority mapping to ./hungarian_matching/semantic_mapping.json.
 mode "eval": predictions are mapped (unmapped classes become the extra "ignore" label 16), a 17 x 17 confusion matrix is
-accumulated with one bincount per image, and mIoU / fwIoU / mACC / pACC plus the per-class numbers come out of it.
+accumulated with one bincount per image on the device the predictions live on, and mIoU / fwIoU / mACC / pACC plus the
+per-class numbers come out of it.
 Boundary IoU needs OpenCV, which this image does not have; the reference switches it off in that case too (:103-109)."""
 from collections import OrderedDict
 
@@ -51,44 +52,51 @@ class SemSegEvaluator(DatasetEvaluator):
         self.mode = mode
         self.hungarain_matching_save_path = mapping_path
         self.pseudo_gt_cate, self.pred_det_cate = [], []
+        self._lut = None
         self.reset()
 
     def reset(self):
-        self._conf_matrix = np.zeros((self._num_classes + 1, self._num_classes + 1), dtype=np.int64)
+        self._conf_matrix = torch.zeros((self._num_classes + 1, self._num_classes + 1), dtype=torch.int64)
 
     def _collect_votes(self, pred, gt):
-        for p in np.unique(pred):
-            if p == 0:
-                continue
-            mask_pred = pred == p
-            for g in np.unique(gt):
-                if g == 0 or g == 16:
-                    continue
-                mask_gt = gt == g
-                iou = np.sum(mask_pred & mask_gt) / np.sum(mask_pred | mask_gt)
-                if iou > IOU_THRESH:
-                    self.pseudo_gt_cate.append(int(g))
-                    self.pred_det_cate.append(int(p))
+        """One joint histogram of (predicted class, ground-truth supercategory) gives every pairwise intersection; with the
+        marginals that is every pairwise IoU at once - the reference masks the image once per pair (:208-221).  Runs on the
+        device the prediction lives on; only the handful of votes comes back."""
+        n = self._num_classes + 1
+        classes = max(int(pred.max()) + 1, NUM_CLUSTERS + 1)
+        joint = torch.bincount(pred.reshape(-1) * n + gt.reshape(-1), minlength=classes * n).view(classes, n)
+        area_p, area_g = joint.sum(dim=1, keepdim=True), joint.sum(dim=0, keepdim=True)
+        union = (area_p + area_g - joint).double()
+        iou = torch.where(union > 0, joint.double() / union.clamp(min=1), torch.zeros_like(union))
+        vote = (iou > IOU_THRESH) & (area_p > 0) & (area_g > 0)
+        vote[0, :] = False                     # predicted class 0 stands for "things"
+        vote[:, 0] = vote[:, n - 1] = False    # so does ground truth 0; 16 is the ignore label
+        for p, g in torch.nonzero(vote).tolist():
+            self.pred_det_cate.append(p)
+            self.pseudo_gt_cate.append(g)
 
     def process(self, inputs, outputs):
+        n = self._num_classes + 1
         for inp, out in zip(inputs, outputs):
-            pred = out["sem_seg"].argmax(dim=0).to(torch.device("cpu")).numpy().astype(int)
-            gt = to_supercategories(self.sem_seg_loading_fn(self.input_file_to_gt_file[inp["file_name"]], dtype=int))
-            gt[gt == self._ignore_label] = self._num_classes
+            pred = out["sem_seg"].argmax(dim=0)  # stays on the model's device
+            gt_np = to_supercategories(self.sem_seg_loading_fn(self.input_file_to_gt_file[inp["file_name"]], dtype=int))
+            gt_np[gt_np == self._ignore_label] = self._num_classes
+            gt = torch.from_numpy(gt_np).to(pred.device)
             if self.mode == "hungarian_matching":
                 self._collect_votes(pred, gt)
-            else:
-                mapping = hungarian.load_mapping(self.hungarain_matching_save_path)
+                continue
+            if self._lut is None:
                 # The reference rewrites the prediction in place, one cluster after the other in the order of the json
                 # file (:247-252), so a pixel moved to label t is moved again when cluster t's turn comes.  The same
                 # composition on a lookup table: lut[v] is where original label v currently stands.
-                lut = np.arange(max(int(pred.max()) + 1, 256))
-                for cls, tgt in mapping.items():
+                lut = np.arange(256)
+                for cls, tgt in hungarian.load_mapping(self.hungarain_matching_save_path).items():
                     lut[lut == cls] = self._num_classes if tgt == -1 else tgt
-                pred = lut[pred]
-                n = self._num_classes + 1
-                self._conf_matrix += np.bincount(n * pred.reshape(-1) + gt.reshape(-1),
-                                                 minlength=self._conf_matrix.size).reshape(self._conf_matrix.shape)
+                self._lut = torch.from_numpy(lut)
+            lut = self._lut.to(pred.device)
+            if self._conf_matrix.device != pred.device:
+                self._conf_matrix = self._conf_matrix.to(pred.device)
+            self._conf_matrix += torch.bincount(n * lut[pred].reshape(-1) + gt.reshape(-1), minlength=n * n).view(n, n)
 
     def cluster_mapping(self):
         mapping = hungarian.majority_vote_mapping(self.pred_det_cate, self.pseudo_gt_cate, range(1, NUM_CLUSTERS + 1), 15)
@@ -105,7 +113,7 @@ class SemSegEvaluator(DatasetEvaluator):
             mapping = self.cluster_mapping()
             hungarian.save_mapping(mapping, self.hungarain_matching_save_path)
             return OrderedDict({"sem_seg": None, "semantic_mapping": mapping})
-        mats = gather_to_rank0(self._conf_matrix)
+        mats = gather_to_rank0(self._conf_matrix.cpu().numpy())
         if mats is None:
             return None
         cm = self._conf_matrix = sum(mats[1:], mats[0].copy())
