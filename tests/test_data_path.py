@@ -435,3 +435,43 @@ def test_rle_and_transform_properties():
         assert np.allclose(rt.apply_box(np.array([[0.0, 0.0, w, h]])), [[0, 0, nw, nh]])
 
     geometry()
+
+
+def test_slot_packing_of_arbitrary_batches():
+    """BatchPacker / unpack on batches that do not come from the mapper: zero instances with an empty bool mask tensor,
+    odd widths (bit packing pads every row to whole bytes), label maps that do not fit a byte (stay int64), tiny label maps,
+    float images, extra python values - everything comes back with its dtype, shape and values."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    from u2seg_amd.data.slots import BatchPacker, PackedBatch, SlotRing, unpack
+    from u2seg_amd.structures import BitMasks, Boxes, Instances
+
+    ring = SlotRing(1, 8 << 20, 2)
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 40), st.integers(1, 40), st.integers(0, 5), st.integers(0, 2 ** 31 - 1), st.booleans())
+    def round_trip(h, w, n, seed, wide_labels):
+        g = torch.Generator().manual_seed(seed)
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(torch.rand((n, 4), generator=g) * 30)
+        inst.gt_classes = torch.randint(0, 800, (n,), generator=g)
+        inst.gt_masks = BitMasks(torch.rand((n, h, w), generator=g) > 0.5)
+        sem = torch.randint(0, 70000 if wide_labels else 256, (h * 3, w * 37), generator=g)  # >= 4096 elements in most draws
+        sample = {"file_name": "a/b.jpg", "height": h, "width": w, "image_id": seed,
+                  "image": torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8),
+                  "aux": torch.rand((2, 3), generator=g), "sem_seg": sem, "instances": inst, "extra": {"k": [1, 2]}}
+        packer = BatchPacker(ring)
+        packed = packer([sample, sample])
+        assert isinstance(packed, PackedBatch)
+        for d in unpack(torch.from_numpy(ring.view(packed.slot)[: packed.nbytes].copy()), packed.samples):
+            assert list(d.keys()) == list(sample.keys()) and d["extra"] == {"k": [1, 2]} and d["file_name"] == "a/b.jpg"
+            for key in ("image", "aux", "sem_seg"):
+                assert d[key].dtype == sample[key].dtype and torch.equal(d[key], sample[key]), key
+            di = d["instances"]
+            assert di.image_size == (h, w) and len(di) == n
+            assert torch.equal(di.gt_boxes.tensor, inst.gt_boxes.tensor) and torch.equal(di.gt_classes, inst.gt_classes)
+            assert di.gt_masks.tensor.dtype == torch.bool and di.gt_masks.tensor.shape == (n, h, w)
+            assert torch.equal(di.gt_masks.tensor, inst.gt_masks.tensor)
+
+    round_trip()
