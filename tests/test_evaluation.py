@@ -175,3 +175,73 @@ def test_panoptic_conversion_matches_reference(tiny_val, tmp_path, monkeypatch):
     assert ev2.mode == "hungarian_matching"
     ev2.process(inputs, outputs())
     assert decoded(ev2) == fx["panoptic_matching"]
+
+
+def test_two_pass_evaluation_through_train_net(tmp_path, monkeypatch):
+    """tools/train_net.py's evaluation entry over the builtin validation registration: the tiny validation set laid out at
+    the paths `coco_2017_val_panoptic_separated` expects under $DETECTRON2_DATASETS, a stub model replaying the fixture's
+    predictions, first `hungarian_matching` then `eval` - the mapping files and the semantic metrics equal the
+    reference-generated ones, and the three evaluators (semantic, instances, panoptic) are all assembled."""
+    import importlib.util
+
+    from u2seg_amd.config import get_cfg
+
+    fx = json.load(open(os.path.join(GOLD, "eval_golden.json")))
+    arrays = np.load(os.path.join(GOLD, "eval_golden.npz"))
+    root = tmp_path / "data"
+    img_dir = root / "coco" / "val2017"
+    sem_dir = root / "datasets" / "panoptic_anns" / "panoptic_stuff_val2017"
+    os.makedirs(img_dir)
+    os.makedirs(sem_dir)
+    os.makedirs(root / "coco" / "annotations")
+    images = []
+    for im in fx["images"]:
+        stem = im["file_name"][:-4]
+        Image.fromarray(np.zeros((im["height"], im["width"], 3), dtype=np.uint8)).save(img_dir / im["file_name"])
+        Image.fromarray(arrays["gt_" + stem], mode="L").save(sem_dir / (stem + ".png"))
+        images.append(im)
+    # the builtin registration announces the 800 cluster categories "1".."800"; the json has to agree with it (metadata may
+    # not change once set - the reference asserts the same), and ids 1..90 keep their contiguous ids 0..89
+    cats = [{"id": c, "name": str(c), "supercategory": str(c)} for c in range(1, 801)]
+    json.dump({"images": images, "annotations": fx["annotations"], "categories": cats},
+              open(root / "coco" / "annotations" / "instances_val2017.json", "w"))
+    monkeypatch.setenv("DETECTRON2_DATASETS", str(root))
+    monkeypatch.setenv("CLUSTER_NUM", "800")
+    monkeypatch.chdir(tmp_path)
+    for cat in (DatasetCatalog, MetadataCatalog):
+        for name in list(cat.keys()):
+            cat.remove(name)
+    spec = importlib.util.spec_from_file_location("u2seg_train_net", os.path.join(os.path.dirname(GOLD), "..", "tools", "train_net.py"))
+    train_net = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(train_net)
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(os.path.dirname(GOLD), "..", "configs", "COCO-PanopticSegmentation", "u2seg_eval_800.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "DATALOADER.NUM_WORKERS", 0, "OUTPUT_DIR", str(tmp_path / "out")])
+    by_id = {im["id"]: k for k, im in enumerate(fx["images"])}
+
+    class Replay(torch.nn.Module):
+        def forward(self, batch):
+            outs = []
+            for x in batch:
+                k = by_id[x["image_id"]]
+                im, p, pan = fx["images"][k], fx["predictions"][k], fx["panoptic_inputs"][k]
+                inst = Instances((im["height"], im["width"]))
+                inst.pred_boxes = Boxes(torch.tensor(p["boxes"], dtype=torch.float32))
+                inst.scores = torch.tensor(p["scores"], dtype=torch.float32)
+                inst.pred_classes = torch.tensor(p["classes"], dtype=torch.int64)
+                outs.append({"instances": inst, "sem_seg": torch.from_numpy(arrays["logits_" + im["file_name"][:-4]]),
+                             "panoptic_seg": (torch.tensor(pan["ids"], dtype=torch.int32), [dict(s) for s in pan["segments_info"]])})
+            return outs
+
+    model = Replay()
+    name = cfg.DATASETS.TEST[0]
+    first = train_net.evaluate_on_disk_datasets(cfg, model, "hungarian_matching", "cpu")[name]
+    assert {str(k): v for k, v in first["instance_mapping"].items()} == fx["instance_mapping"]
+    assert json.load(open("hungarian_matching/semantic_mapping.json")) == fx["semantic_mapping_file"]
+    second = train_net.evaluate_on_disk_datasets(cfg, model, "eval", "cpu")[name]
+    assert set(second) == {"sem_seg", "bbox", "panoptic_seg"}
+    for k, v in fx["sem_seg_results"].items():
+        if v is not None:
+            assert second["sem_seg"][k] == pytest.approx(v, rel=1e-12), k
+    assert second["panoptic_seg"]["num_images"] == len(images) and os.path.isfile(second["panoptic_seg"]["predictions_json"])
+    assert second["bbox"]["num_results"] > 0
