@@ -618,10 +618,18 @@ def gen_inference_fixture(name, hw, nimg):
         for k, v in model.state_dict().items():
             v.copy_(det_fill(k, v))
     model.eval()
-    batch = to_ref_batch(make_synthetic_batch(nimg, height=hw[0], width=hw[1]))
+    if isinstance(hw[0], int):
+        batch = to_ref_batch(make_synthetic_batch(nimg, height=hw[0], width=hw[1]))
+    else:  # ragged batch: one size per image, results requested at 1.5x the input resolution (postprocessing.py:9-100)
+        batch = []
+        for i, (h, w) in enumerate(hw):
+            x = to_ref_batch(make_synthetic_batch(1, start_index=i, height=h, width=w))[0]
+            x["height"], x["width"] = int(1.5 * h), int(1.5 * w)
+            batch.append(x)
     with torch.no_grad():
         out = model([{k: v for k, v in x.items() if k != "instances"} for x in batch])
-    arrays = {"score_thresh": np.array(0.0015)}
+    arrays = {"score_thresh": np.array(0.0015), "sizes": np.array([x["image"].shape[1:] for x in batch]),
+              "out_sizes": np.array([[x["height"], x["width"]] for x in batch])}
     for i, o in enumerate(out):
         inst = o["instances"]
         arrays["boxes_%d" % i] = inst.pred_boxes.tensor.numpy()
@@ -1534,3 +1542,4 @@ if __name__ == "__main__":
             gen_trajectory_fixture("trajectory_small", (192, 256), 2, 7)
         if a.only in ("", "inference"):
             gen_inference_fixture("inference_small", (192, 256), 2)
+            gen_inference_fixture("inference_ragged", [(160, 224), (128, 192)], 2)

@@ -232,6 +232,37 @@ def test_whole_model_inference(golden_dir):
         assert (pan.numpy() != g["panoptic_%d" % i]).mean() < 1e-3
 
 
+def test_whole_model_inference_ragged_and_rescaled(golden_dir):
+    """The same comparison on a ragged batch (160x224 and 128x192, padded to a common size inside the model) whose results
+    are requested at 1.5x the input resolution: detector_postprocess / sem_seg_postprocess (modeling/postprocessing.py:9-100)
+    rescale boxes, paste the masks and resize the semantic logits at the output size, the panoptic merge runs there too."""
+    g = np.load(os.path.join(golden_dir, "inference_ragged.npz"))
+    om = OracleModel.from_config_file(CFG, opts=["MODEL.ROI_HEADS.SCORE_THRESH_TEST", float(g["score_thresh"])])
+    with torch.no_grad():
+        for k, v in om.p.items():
+            v.copy_(det_fill(k, v))
+    batch = []
+    for i, ((h, w), (oh, ow)) in enumerate(zip(g["sizes"].tolist(), g["out_sizes"].tolist())):
+        x = make_synthetic_batch(1, start_index=i, height=h, width=w)[0]
+        x = {k: v for k, v in x.items() if k != "instances"}
+        x["height"], x["width"] = oh, ow
+        batch.append(x)
+    out = om.inference(batch)
+    for i, o in enumerate(out):
+        oh, ow = g["out_sizes"][i].tolist()
+        assert tuple(o["sem_seg"].shape[1:]) == (oh, ow) and tuple(o["masks"].shape[1:]) == (oh, ow)
+        assert np.array_equal(o["classes"].numpy(), g["classes_%d" % i])
+        np.testing.assert_allclose(o["scores"].numpy(), g["scores_%d" % i], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(o["boxes"].numpy(), g["boxes_%d" % i], rtol=1e-4, atol=1e-2)
+        areas = o["masks"].flatten(1).sum(1).numpy()
+        assert np.abs(areas - g["mask_areas_%d" % i]).max() <= 3
+        assert (o["sem_seg"].argmax(0).numpy() != g["sem_argmax_%d" % i]).mean() < 1e-3
+        pan, info = o["panoptic_seg"]
+        ref_info = json.loads(str(g["panoptic_info_%d" % i]))
+        assert [(d["isthing"], d["category_id"]) for d in info] == [(d["isthing"], d["category_id"]) for d in ref_info]
+        assert (pan.numpy() != g["panoptic_%d" % i]).mean() < 1e-3
+
+
 def test_cluster_representatives(golden_dir):
     """cluster/select.py (host logic, any device) == the reference's get_selection_without_reg on 14 clusters with an
     empty one, tied densities and a truncated custom ordering (fixture generated next to the kNN lists)."""
