@@ -159,6 +159,14 @@ def _data_eval_worker(rank, world, port, out, gold):
                        and abs(r2["sem_seg"]["mIoU"] - ev_fx["sem_seg_results"]["mIoU"]) < 1e-9)
     else:
         res["eval"] = r == {} and rs is None and r2 is None
+    # ragged row shards of the clustering features meet through one all-gather (cluster/knn.py:gather_rows)
+    from u2seg_amd.cluster.knn import gather_rows
+
+    rows = 3 if rank == 0 else 5
+    shard = torch.arange(rows * 4, dtype=torch.float32).view(rows, 4) + 100 * rank
+    full = gather_rows(shard)
+    res["gather_rows"] = (full.shape == (8, 4) and torch.equal(full[:3], torch.arange(12.0).view(3, 4))
+                          and torch.equal(full[3:], torch.arange(20.0).view(5, 4) + 100))
     out[rank] = res
     dist.destroy_process_group()
 
