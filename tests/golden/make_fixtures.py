@@ -1416,6 +1416,72 @@ def gen_refunit_fixture():
           sum(v.size * v.itemsize for v in arrays.values()) // 1024, "KiB raw", {k: v.shape for k, v in arrays.items() if "mask_logits" in k or "sampled0" in k})
 
 
+def gen_cocoeval_fixture():
+    """The reference's C++ COCO evaluation core (layers/csrc/cocoeval/cocoeval.cpp, compiled into the _C extension built by
+    import_reference) on a synthetic detection problem: 12 images, 5 categories, crowd regions, boxes of all three area
+    classes, 130 detections in one (image, category) cell (budget truncation), tied scores.  Inputs are prepared the way
+    fast_eval_api.py:55-88 does (instances + IoU tables per image and category); outputs: the precision / recall / score
+    tables of COCOevalEvaluateImages + COCOevalAccumulate."""
+    import_reference()
+    C = sys.modules["detectron2._C"]
+    from u2seg_amd.evaluation import cocoeval as CE
+
+    rs = np.random.RandomState(21)
+    images = [{"id": 3 * i + 1, "height": 200, "width": 300} for i in range(12)]
+    cats = [{"id": c} for c in (1, 2, 5, 7, 9)]
+    anns, results, aid = [], [], 1
+    for im in images:
+        for _ in range(rs.randint(0, 7)):
+            side = rs.choice([12.0, 50.0, 140.0]) * rs.uniform(0.7, 1.3)
+            w, h = side, side * rs.uniform(0.6, 1.4)
+            x, y = rs.uniform(0, 300 - w), rs.uniform(0, 200 - h)
+            cat = int(rs.choice([1, 2, 5, 7, 9]))
+            anns.append({"id": aid, "image_id": im["id"], "category_id": cat, "bbox": [float(x), float(y), float(w), float(h)],
+                         "area": float(w * h * rs.uniform(0.5, 0.9)), "iscrowd": int(rs.rand() < 0.15)})
+            aid += 1
+            for _ in range(rs.randint(0, 4)):  # detections around the instance, some in the wrong class
+                j = rs.uniform(-1, 1, 4) * side * rs.choice([0.03, 0.15, 0.5])
+                results.append({"image_id": im["id"], "category_id": cat if rs.rand() < 0.8 else int(rs.choice([1, 2, 5, 7, 9])),
+                                "bbox": [float(x + j[0]), float(y + j[1]), float(max(w + j[2], 1)), float(max(h + j[3], 1))],
+                                "score": float(np.round(rs.uniform(0.05, 1.0), 2))})  # two decimals: ties happen
+        for _ in range(rs.randint(0, 5)):  # strays
+            results.append({"image_id": im["id"], "category_id": int(rs.choice([1, 2, 5, 7, 9])),
+                            "bbox": [float(rs.uniform(0, 250)), float(rs.uniform(0, 150)), float(rs.uniform(5, 50)), float(rs.uniform(5, 50))],
+                            "score": float(np.round(rs.uniform(0.05, 0.6), 2))})
+    for k in range(130):  # one crowded cell beyond the 100-detection budget
+        results.append({"image_id": 1, "category_id": 2, "bbox": [float(2 * k % 250), float(k % 150), 30.0, 30.0],
+                        "score": float(np.round(rs.uniform(0.01, 0.99), 3))})
+    dataset = {"images": images, "annotations": anns, "categories": cats}
+    params = CE.Params(sorted(im["id"] for im in images), sorted(c["id"] for c in cats))
+    gts, dts = CE.prepare(anns, results, params)
+    ious = CE.compute_ious(gts, dts, params)
+
+    def cpp(instances):
+        return [C.InstanceAnnotation(int(o["id"]), float(o.get("score", 0.0)), float(o["area"]), bool(o["iscrowd"]),
+                                     bool(o["ignore"])) for o in instances]
+
+    gt_cpp = [[cpp(gts.get((i, c), [])) for c in params.catIds] for i in params.imgIds]
+    dt_cpp = [[cpp(dts.get((i, c), [])) for c in params.catIds] for i in params.imgIds]
+    iou_cpp = [[(ious[i, c].tolist() if len(ious[i, c]) else []) for c in params.catIds] for i in params.imgIds]
+    evals = C.COCOevalEvaluateImages(params.areaRng, params.maxDets[-1], params.iouThrs.tolist(), iou_cpp, gt_cpp, dt_cpp)
+
+    class P:
+        pass
+
+    pobj = P()
+    pobj.recThrs, pobj.maxDets, pobj.iouThrs = params.recThrs.tolist(), params.maxDets, params.iouThrs.tolist()
+    pobj.catIds, pobj.areaRng, pobj.imgIds, pobj.useCats = params.catIds, params.areaRng, params.imgIds, 1
+    acc = C.COCOevalAccumulate(pobj, evals)
+    counts = list(acc["counts"])
+    precision = np.array(acc["precision"]).reshape(counts)
+    scores = np.array(acc["scores"]).reshape(counts)
+    recall = np.array(acc["recall"]).reshape(counts[:1] + counts[2:])
+    json.dump({"dataset": dataset, "results": results}, open(os.path.join(HERE, "cocoeval_golden.json"), "w"))
+    np.savez_compressed(os.path.join(HERE, "cocoeval_golden.npz"), precision=precision, recall=recall, scores=scores)
+    print("wrote cocoeval_golden:", len(anns), "gt,", len(results), "detections; mean precision over valid entries",
+          float(precision[precision > -1].mean()))
+
+
 def _import_nn_utils():
     for m in ["pykeops", "pykeops.torch", "torchvision", "torchvision.transforms", "torchvision.datasets", "torchvision.models",
               "yacs", "yacs.config", "termcolor", "clip"]:
@@ -1514,6 +1580,9 @@ if __name__ == "__main__":
         gen_kmeans_fixture()
     if a.only in ("", "knn"):
         gen_knn_fixture()
+    if a.only == "cocoeval":
+        gen_cocoeval_fixture()
+        sys.exit(0)
     if a.only == "refunit":
         gen_refunit_fixture()
         sys.exit(0)

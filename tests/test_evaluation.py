@@ -245,3 +245,37 @@ def test_two_pass_evaluation_through_train_net(tmp_path, monkeypatch):
             assert second["sem_seg"][k] == pytest.approx(v, rel=1e-12), k
     assert second["panoptic_seg"]["num_images"] == len(images) and os.path.isfile(second["panoptic_seg"]["predictions_json"])
     assert second["bbox"]["num_results"] > 0
+    assert all(k in second["bbox"] for k in ("AP", "AP50", "AP75", "APs", "APm", "APl")) and 0 <= second["bbox"]["AP50"] <= 100
+
+
+def test_cocoeval_core_matches_reference_cpp():
+    """evaluation/cocoeval.py's matching + accumulation == the reference's C++ COCOevalEvaluateImages / COCOevalAccumulate
+    (fixture: make_fixtures.py --only cocoeval): every entry of the precision [10, 101, 5, 4, 3], recall [10, 5, 4, 3] and
+    score tables, on a problem with crowd regions, all area classes, tied scores and a cell beyond the 100-detection budget.
+    Plus hand-checkable cases for the IoU rule and the summary."""
+    from u2seg_amd.evaluation import cocoeval as CE
+
+    fx = json.load(open(os.path.join(GOLD, "cocoeval_golden.json")))
+    ref = np.load(os.path.join(GOLD, "cocoeval_golden.npz"))
+    out = CE.evaluate_bbox(fx["dataset"], fx["results"])
+    assert out["precision"].shape == ref["precision"].shape == (10, 101, 5, 4, 3)
+    np.testing.assert_allclose(out["precision"], ref["precision"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out["recall"], ref["recall"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out["scores"], ref["scores"], rtol=0, atol=1e-12)
+    p = ref["precision"][:, :, :, 0, 2]
+    assert out["stats"]["AP"] == pytest.approx(float(p[p > -1].mean()), rel=1e-12)
+    # crowd ground truth: the union is the detection's own area (a detection inside a crowd region has IoU 1)
+    iou = CE.box_ious([[10, 10, 10, 10]], [[0, 0, 100, 100], [0, 0, 100, 100]], [1, 0])
+    assert np.allclose(iou, [[1.0, 100 / 10000]])
+    # one image, two instances, detections: exact hit (0.9), shifted hit (0.8, IoU 0.905), stray (0.7)
+    gt = {"images": [{"id": 1}], "categories": [{"id": 1}],
+          "annotations": [{"id": 1, "image_id": 1, "category_id": 1, "bbox": [10, 10, 20, 20], "area": 400, "iscrowd": 0},
+                          {"id": 2, "image_id": 1, "category_id": 1, "bbox": [50, 50, 40, 40], "area": 1600, "iscrowd": 0}]}
+    res = [{"image_id": 1, "category_id": 1, "bbox": [10, 10, 20, 20], "score": 0.9},
+           {"image_id": 1, "category_id": 1, "bbox": [52, 50, 40, 40], "score": 0.8},
+           {"image_id": 1, "category_id": 1, "bbox": [200, 200, 10, 10], "score": 0.7}]
+    st = CE.evaluate_bbox(gt, res)["stats"]
+    assert st["AP50"] == pytest.approx(1.0) and st["AP75"] == pytest.approx(1.0)  # both found before the stray
+    assert st["AR1"] == pytest.approx(0.5) and st["AR100"] == pytest.approx(0.95)  # the shifted box fails only IoU 0.95
+    assert st["APl"] == -1.0  # no large instance
+    assert CE.evaluate_bbox(gt, [])["stats"]["AP"] == pytest.approx(0.0)

@@ -4,9 +4,9 @@
 mode "hungarian_matching": confident detections (score >= 0.6) vote for the category of every ground-truth box they
 overlap with IoU > 0.7; the majority mapping of the 300 evaluated clusters is written to
 ./hungarian_matching/instance_mapping.json (the reference then exits).  mode "eval": the mapping is applied, detections of
-unmapped clusters are dropped, category ids go back to dataset ids and the results are written in COCO format.  The AP
-numbers themselves come from pycocotools' COCOeval, which this image does not have; when it is importable the summary
-is returned, otherwise the remapped results are the output."""
+unmapped clusters are dropped, category ids go back to dataset ids, the results are written in COCO format and scored by
+evaluation/cocoeval.py (box AP / AR without pycocotools; its matching and accumulation are pinned to the reference's C++
+evaluation core)."""
 import itertools
 import json
 import os
@@ -112,16 +112,24 @@ class COCOEvaluator(DatasetEvaluator):
             with open(os.path.join(self._output_dir, "coco_instances_results.json"), "w") as f:
                 json.dump(remapped, f)
         results = {"num_results": len(remapped), "num_dropped": len(coco_results) - len(remapped)}
-        try:
-            from pycocotools.coco import COCO
-            from pycocotools.cocoeval import COCOeval
-        except ImportError:
-            return {"bbox": results}
-        gt = COCO(self._metadata.json_file)
-        ev = COCOeval(gt, gt.loadRes(remapped), "bbox")
-        ev.evaluate()
-        ev.accumulate()
-        ev.summarize()
-        names = ["AP", "AP50", "AP75", "APs", "APm", "APl"]
-        results.update({n: float(ev.stats[i] * 100) for i, n in enumerate(names)})
+        results.update(self._box_metrics(remapped))
         return {"bbox": results}
+
+    def _box_metrics(self, coco_results):
+        """AP, AP50, AP75, APs, APm, APl (x 100, NaN where undefined) and the per-category APs, as _derive_coco_results
+        reports them (:473-540; the reference skips the "segm" task, :346-347), from evaluation/cocoeval.py."""
+        from . import cocoeval
+
+        names = ("AP", "AP50", "AP75", "APs", "APm", "APl")
+        if not coco_results:
+            return {n: float("nan") for n in names}  # "No predictions from the model!"
+        dataset = json.load(open(self._metadata.json_file))
+        out = cocoeval.evaluate_bbox(dataset, coco_results)
+        res = {n: (out["stats"][n] * 100 if out["stats"][n] >= 0 else float("nan")) for n in names}
+        cats = sorted(dataset["categories"], key=lambda c: c["id"])
+        if len(cats) > 1:
+            for k, cat in enumerate(cats):
+                p = out["precision"][:, :, k, 0, -1]
+                p = p[p > -1]
+                res["AP-" + str(cat.get("name", cat["id"]))] = float(p.mean() * 100) if p.size else float("nan")
+        return res
