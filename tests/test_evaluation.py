@@ -279,3 +279,44 @@ def test_cocoeval_core_matches_reference_cpp():
     assert st["AR1"] == pytest.approx(0.5) and st["AR100"] == pytest.approx(0.95)  # the shifted box fails only IoU 0.95
     assert st["APl"] == -1.0  # no large instance
     assert CE.evaluate_bbox(gt, [])["stats"]["AP"] == pytest.approx(0.0)
+
+
+def test_panoptic_quality_hand_cases():
+    """evaluation/pq.py (restated from the PQ paper / panopticapi; parity unpinned - the reference has neither the package nor
+    a golden for it) on cases small enough to do by hand."""
+    from u2seg_amd.evaluation.pq import pq_compute_arrays
+
+    cats = {1: {"isthing": 1}, 2: {"isthing": 1}, 7: {"isthing": 0}}
+    gt = np.zeros((10, 10), dtype=np.int64)
+    gt[:5, :5] = 1     # thing, category 1, 25 px
+    gt[5:, :] = 2      # stuff, category 7, 50 px
+    gt[:5, 5:8] = 3    # thing, category 2, 15 px; the 10 px of columns 8-9 stay void
+    gt_segs = [{"id": 1, "category_id": 1, "iscrowd": 0}, {"id": 2, "category_id": 7, "iscrowd": 0},
+               {"id": 3, "category_id": 2, "iscrowd": 0}]
+    # perfect prediction (different ids): PQ = SQ = RQ = 1 everywhere
+    pred = gt * 10
+    segs = [{"id": 10, "category_id": 1}, {"id": 20, "category_id": 7}, {"id": 30, "category_id": 2}]
+    res = pq_compute_arrays([(gt, gt_segs, pred, segs)], cats)
+    assert res["All"] == {"pq": 1.0, "sq": 1.0, "rq": 1.0, "n": 3} and res["Things"]["n"] == 2 and res["Stuff"]["n"] == 1
+    # segment 10 shrinks to 20 of its 25 px (IoU 0.8); segment 30 gets the wrong category (one FP + one FN, categories 1 / 2);
+    # a stray segment lies entirely on void pixels (excused); the stuff segment spills 4 px onto void (they do not count)
+    pred = np.zeros_like(gt)
+    pred[:4, :5] = 10
+    pred[5:, :] = 20
+    pred[:5, 5:8] = 30
+    pred[:2, 8:] = 40
+    pred[2:4, 8:] = 20
+    segs = [{"id": 10, "category_id": 1}, {"id": 20, "category_id": 7}, {"id": 30, "category_id": 1}, {"id": 40, "category_id": 2}]
+    res = pq_compute_arrays([(gt, gt_segs, pred, segs)], cats)
+    pc = res["per_class"]
+    assert pc[1]["sq"] == pytest.approx(0.8) and pc[1]["rq"] == pytest.approx(1 / 1.5) and pc[1]["pq"] == pytest.approx(0.8 / 1.5)
+    assert pc[2] == {"pq": 0.0, "sq": 0.0, "rq": 0.0}   # its only instance was missed, the stray on void is not an FP
+    assert pc[7]["pq"] == pytest.approx(1.0)              # 50 / (54 + 50 - 50 - 4)
+    assert res["All"]["pq"] == pytest.approx((0.8 / 1.5 + 0 + 1.0) / 3) and res["Stuff"]["pq"] == pytest.approx(1.0)
+    # crowd ground truth: never a TP or FN, and a prediction of its category lying on it is not an FP
+    gt_segs[2]["iscrowd"] = 1
+    segs = [{"id": 10, "category_id": 1}, {"id": 20, "category_id": 7}, {"id": 30, "category_id": 2}, {"id": 40, "category_id": 2}]
+    res = pq_compute_arrays([(gt, gt_segs, pred, segs)], cats)
+    assert res["per_class"][2] == {"pq": 0.0, "sq": 0.0, "rq": 0.0} and res["Things"]["n"] == 1
+    with pytest.raises(KeyError):
+        pq_compute_arrays([(gt, gt_segs, pred, segs[:2])], cats)  # an id in the png without segments_info

@@ -5,8 +5,8 @@ The evaluator looks for ./hungarian_matching/{semantic,instance}_mapping.json wh
 "hungarian_matching" mode and stores the predictions as they are; with them ("eval") every segment's category goes through
 the mapping - a thing cluster to the dataset id of its category, an unsupervised stuff class to cluster_num(300) + its
 supercategory - and segments whose cluster has no mapping are erased from the id map.  evaluate() gathers the ranks,
-writes the pngs and predictions.json; panoptic quality itself is panopticapi's pq_compute, used when importable (it is not
-in this image)."""
+writes the pngs and predictions.json and computes PQ / SQ / RQ with panopticapi's pq_compute when that package is
+importable, with the restatement in evaluation/pq.py otherwise."""
 import io
 import itertools
 import json
@@ -95,11 +95,16 @@ class COCOPanopticEvaluator(DatasetEvaluator):
         with open(predictions_json, "w") as f:
             f.write(json.dumps(json_data))
         result = {"predictions_json": predictions_json, "num_images": len(predictions)}
+        gt_folder = self._metadata.get("panoptic_root")
+        if not (gt_json and os.path.isfile(gt_json) and gt_folder and os.path.isdir(gt_folder)):
+            return {"panoptic_seg": result}  # no panoptic ground truth on disk: the converted predictions are the output
         try:
             from panopticapi.evaluation import pq_compute
         except ImportError:
-            return {"panoptic_seg": result}
-        pq = pq_compute(gt_json, predictions_json, gt_folder=self._metadata.panoptic_root, pred_folder=pred_dir)
+            from .pq import pq_compute  # the same procedure restated (parity unpinned, see evaluation/pq.py)
+
+            result["pq_implementation"] = "u2seg_amd.evaluation.pq"
+        pq = pq_compute(gt_json, predictions_json, gt_folder=gt_folder, pred_folder=pred_dir)
         for group, suffix in (("All", ""), ("Things", "_th"), ("Stuff", "_st")):
             for key in ("pq", "sq", "rq"):
                 result[key.upper() + suffix] = 100 * pq[group][key]
