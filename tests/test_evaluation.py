@@ -320,3 +320,31 @@ def test_panoptic_quality_hand_cases():
     assert res["per_class"][2] == {"pq": 0.0, "sq": 0.0, "rq": 0.0} and res["Things"]["n"] == 1
     with pytest.raises(KeyError):
         pq_compute_arrays([(gt, gt_segs, pred, segs[:2])], cats)  # an id in the png without segments_info
+
+
+def test_panoptic_quality_file_form(tmp_path):
+    """pq.pq_compute on json + png files (panopticapi's calling convention) == the array form."""
+    from u2seg_amd.data.pseudo_panoptic import id2rgb
+    from u2seg_amd.evaluation.pq import pq_compute, pq_compute_arrays
+
+    cats = [{"id": 1, "isthing": 1}, {"id": 7, "isthing": 0}]
+    rs = np.random.RandomState(3)
+    samples, gt_json, pred_json = [], {"categories": cats, "annotations": []}, {"annotations": []}
+    os.makedirs(tmp_path / "gt")
+    os.makedirs(tmp_path / "pred")
+    for i in range(3):
+        gt = rs.randint(0, 4, (6, 8)).repeat(4, 0).repeat(4, 1)
+        pred = np.roll(gt, 2, axis=1) * 1000  # ids above 255: exercises the 3-byte id encoding
+        gsegs = [{"id": int(k), "category_id": 1 if k < 3 else 7, "iscrowd": 0} for k in np.unique(gt) if k]
+        psegs = [{"id": int(k), "category_id": 1 if k < 3000 else 7} for k in np.unique(pred) if k]
+        name = "%d.png" % i
+        Image.fromarray(id2rgb(gt)).save(tmp_path / "gt" / name)
+        Image.fromarray(id2rgb(pred)).save(tmp_path / "pred" / name)
+        gt_json["annotations"].append({"image_id": i, "file_name": name, "segments_info": gsegs})
+        pred_json["annotations"].append({"image_id": i, "file_name": name, "segments_info": psegs})
+        samples.append((gt, gsegs, pred, psegs))
+    json.dump(gt_json, open(tmp_path / "gt.json", "w"))
+    json.dump(pred_json, open(tmp_path / "pred.json", "w"))
+    a = pq_compute(str(tmp_path / "gt.json"), str(tmp_path / "pred.json"), str(tmp_path / "gt"), str(tmp_path / "pred"))
+    b = pq_compute_arrays(samples, {c["id"]: c for c in cats})
+    assert a == b and 0 < a["All"]["pq"] < 1
