@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 #include "u2seg_hip.h"
 
@@ -177,8 +178,85 @@ static void bench_conv(const char* name, int B, int H, int W, int C, int N, int 
   }
 }
 
+
+// ---- bench2: every conv shape of the u2seg_R50_800 training step x a list of kernel variants (one allocation, tiled random fill) ----
+struct LayerShape { const char* name; int B, H, W, C, N, K, pad, stride, relu, bias, stats; };
+
+static void bench2(int argc, char** argv) {
+  const LayerShape layers[] = {
+      {"p2 3x3 256->256 200x336", 16, 200, 336, 256, 256, 3, 1, 1, 0, 0, 1},
+      {"p3 3x3 256->256 100x168", 16, 100, 168, 256, 256, 3, 1, 1, 0, 0, 1},
+      {"p4 3x3 256->256 50x84", 16, 50, 84, 256, 256, 3, 1, 1, 0, 0, 1},
+      {"p5 3x3 256->256 25x42", 16, 25, 42, 256, 256, 3, 1, 1, 0, 0, 1},
+      {"rpn 3x3 256->256 200x336 b+r", 16, 200, 336, 256, 256, 3, 1, 1, 1, 1, 0},
+      {"sem 3x3 256->128 200x336", 16, 200, 336, 256, 128, 3, 1, 1, 0, 0, 0},
+      {"sem 3x3 128->256 200x336", 16, 200, 336, 128, 256, 3, 1, 1, 0, 0, 0},
+      {"res3 3x3 128->128 100x168", 16, 100, 168, 128, 128, 3, 1, 1, 0, 0, 1},
+      {"res5 3x3 512->512 25x42", 16, 25, 42, 512, 512, 3, 1, 1, 0, 0, 1},
+      {"res2 3x3 64->64 200x336", 16, 200, 336, 64, 64, 3, 1, 1, 0, 0, 1},
+      {"mask 3x3 256->256 261x14x14", 261, 14, 14, 256, 256, 3, 1, 1, 1, 1, 0},
+      {"res4 1x1 256->1024 50x84", 16, 50, 84, 256, 1024, 1, 0, 1, 0, 0, 1},
+      {"res4 1x1 1024->256 50x84", 16, 50, 84, 1024, 256, 1, 0, 1, 0, 0, 1},
+      {"res3 1x1 128->512 100x168", 16, 100, 168, 128, 512, 1, 0, 1, 0, 0, 1},
+      {"res3 1x1 512->128 100x168", 16, 100, 168, 512, 128, 1, 0, 1, 0, 0, 1},
+      {"res2 1x1 256->64 200x336", 16, 200, 336, 256, 64, 1, 0, 1, 0, 0, 1},
+      {"res2 1x1 64->256 200x336", 16, 200, 336, 64, 256, 1, 0, 1, 0, 0, 1},
+      {"lat2 1x1 256->256 200x336", 16, 200, 336, 256, 256, 1, 0, 1, 0, 0, 1},
+      {"lat3 1x1 512->256 100x168", 16, 100, 168, 512, 256, 1, 0, 1, 0, 0, 1},
+      {"res3 1x1 256->512 100x168", 16, 100, 168, 256, 512, 1, 0, 1, 0, 0, 0},
+      {"res5 1x1 512->2048 25x42", 16, 25, 42, 512, 2048, 1, 0, 1, 0, 0, 1},
+      {"res5 1x1 2048->512 25x42", 16, 25, 42, 2048, 512, 1, 0, 1, 0, 0, 1},
+      {"res4 1x1 s2 512->1024 100x168", 16, 100, 168, 512, 1024, 1, 0, 2, 0, 0, 1},
+      {"fc1 fwd 7x7 256->1024 M8192", 8192, 7, 7, 256, 1024, 7, 0, 1, 1, 1, 0},
+      {"fc1 dgrad gemm 1024->12544", 1, 8192, 1, 1024, 12544, 1, 0, 1, 0, 0, 0},
+      {"fc2 gemm 1024->1024 M8192", 1, 8192, 1, 1024, 1024, 1, 0, 1, 1, 1, 0},
+      {"gemm 8192^3", 1, 8192, 1, 8192, 8192, 1, 0, 1, 0, 0, 0},
+  };
+  std::vector<int> variants;
+  for (int i = 2; i < argc; ++i) variants.push_back((int)strtol(argv[i], nullptr, 0));
+  if (variants.empty()) variants = {15 << 12, 1 << 12, 2 << 12, 3 << 12, 4 << 12, 6 << 12, 7 << 12};
+  const size_t in_elems = (size_t)16 * 200 * 336 * 256, w_elems = (size_t)8192 * 8192, out_elems = (size_t)16 * 200 * 336 * 256;
+  DBuf<uint16_t> din(in_elems), dw(w_elems), dout(out_elems);
+  DBuf<float> db(16384), dst(2 * 16384);
+  {
+    std::vector<uint16_t> pat((size_t)1 << 22);
+    for (auto& v : pat) v = f2bf(frand());
+    for (size_t o = 0; o < in_elems; o += pat.size())
+      HIPCHK(hipMemcpy(din.d + o, pat.data(), std::min(pat.size(), in_elems - o) * 2, hipMemcpyHostToDevice));
+    for (auto& v : pat) v = f2bf(frand() * 0.05f);
+    for (size_t o = 0; o < w_elems; o += pat.size())
+      HIPCHK(hipMemcpy(dw.d + o, pat.data(), std::min(pat.size(), w_elems - o) * 2, hipMemcpyHostToDevice));
+  }
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  for (const auto& L : layers) {
+    const int Hout = (L.H + 2 * L.pad - L.K) / L.stride + 1, Wout = (L.W + 2 * L.pad - L.K) / L.stride + 1;
+    const double M = (double)L.B * Hout * Wout;
+    const double flop = 2.0 * M * L.N * L.K * L.K * L.C;
+    const double bytes = 2.0 * ((double)L.B * L.H * L.W * L.C + M * L.N + (double)L.N * L.K * L.K * L.C);
+    printf("LAYER %-32s GFLOP %8.1f  MB %7.1f |", L.name, flop * 1e-9, bytes * 1e-6);
+    for (int v : variants) {
+      auto run = [&]() {
+        return u2_conv_igemm(din.d, dw.d, dout.d, L.bias ? db.d : nullptr, L.stats ? dst.d : nullptr, L.B, L.H, L.W, L.C, L.C, Hout, Wout,
+                             L.N, L.N, L.K, L.K, L.pad, L.pad, L.stride, 1, L.relu, 0, v, nullptr);
+      };
+      int rc = 0;
+      for (int i = 0; i < 2; ++i) rc |= run();
+      HIPCHK(hipEventRecord(e0));
+      const int iters = 6;
+      for (int i = 0; i < iters; ++i) rc |= run();
+      HIPCHK(hipEventRecord(e1)); HIPCHK(hipEventSynchronize(e1));
+      float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+      if (rc) printf("  v%x rc=%d", v, rc);
+      else printf("  v%x %6.3fms %6.0fTF %4.1fTB/s", v, ms, flop / ms * 1e-9, bytes / ms * 1e-9);
+    }
+    printf("\n");
+    fflush(stdout);
+  }
+}
+
 int main(int argc, char** argv) {
   int fails = 0;
+  if (argc > 1 && !strcmp(argv[1], "bench2")) { bench2(argc, argv); return 0; }
   if (argc > 1 && !strcmp(argv[1], "one")) {  // a single shape, for PMC profiling
     const int v = argc > 2 ? atoi(argv[2]) : 0;
     bench_conv("fpn_out2 3x3 256->256 B16", 16, 200, 336, 256, 256, 3, 1, 1, v);
@@ -199,6 +277,20 @@ int main(int argc, char** argv) {
   const int cvs[] = {0, 1, 32, 48, 4, 4 | 32, 8, 8 | 4 | 32, 256, 256 | 1024};
   for (int v : cvs)
     for (const auto& c : convs) fails += test_conv(c, v);
+  // persistent tile kernels (conv_tile.hip): variant bits 12-15 pick the configuration, bit 16 caps the grid at 8
+  // work-groups so that every work-group walks several tiles (cross-tile prefetch, accumulator reset, tail waits)
+  const ConvCase tconvs[] = {
+      {2, 36, 32, 64, 256, 3, 3, 1, 1, 1, 0, 0, 0, 1, "tile 3x3 c64 n256 stats"},
+      {2, 36, 32, 96, 320, 3, 3, 1, 1, 1, 1, 0, 1, 0, "tile 3x3 c96 n320 bias relu"},
+      {1, 700, 3, 256, 512, 1, 1, 0, 1, 1, 0, 0, 0, 1, "tile 1x1 c256 n512 stats"},
+      {2, 37, 41, 160, 128, 1, 1, 0, 2, 1, 0, 0, 0, 1, "tile 1x1 s2 c160 n128 stats"},
+      {2, 18, 20, 128, 128, 3, 3, 1, 1, 2, 0, 0, 0, 0, "tile dgrad(3x3 s2) c128 n128"},
+      {1, 45, 23, 64, 72, 3, 3, 1, 1, 1, 0, 0, 1, 1, "tile 3x3 c64 n72 bias stats"},
+      {3, 7, 7, 32, 136, 7, 7, 0, 1, 1, 1, 0, 1, 0, "tile fc 7x7 c32 n136 bias relu"},
+  };
+  for (int cfg = 1; cfg <= 7; ++cfg)
+    for (int tiny = 0; tiny < 2; ++tiny)
+      for (const auto& c : tconvs) fails += test_conv(c, (cfg << 12) | (tiny << 16));
   const WgCase wgs[] = {
       {2, 9, 11, 64, 64, 1, 1, 0, 1, "wgrad 1x1 c64 n64"},
       {1, 13, 17, 128, 136, 3, 3, 1, 1, "wgrad 3x3 c128 n136"},

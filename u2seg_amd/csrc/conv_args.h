@@ -1,0 +1,46 @@
+// Argument block and staging helpers shared by the implicit-GEMM convolution kernels (conv_igemm.hip, conv_tile.hip).
+#pragma once
+#include "common.h"
+
+namespace u2conv {
+
+struct ConvArgs {
+  const bf16_t* in;
+  const bf16_t* wt;
+  bf16_t* out;
+  const float* bias;
+  float* stats;
+  const bf16_t* zero;
+  int B, Hin, Win, C, in_ld;
+  int Hout, Wout, N, out_ld;
+  int mul;                 // source pixel = output pixel * mul + tap offset
+  int relu, accumulate;
+  int M, tiles_m, tiles_n;
+  // tap table: tap t reads the source at (qy*mul + tap_dy[t], qx*mul + tap_dx[t]) and uses filter tap tap_w[t]
+  int ntaps, wt_taps;      // taps of this launch / taps in the weight layout ([N][wt_taps][C])
+  int KW, pad_h, pad_w;    // regular launches (remap_out == 0) derive tap t = (kh, kw) arithmetically, no table reads
+  short tap_dy[64], tap_dx[64], tap_w[64];
+  int tap_pk[64];          // the same table as one dword per tap (scalar loads): (dy & 0xff) | (dx & 0xff) << 8 | w << 16
+  // output placement: pixel (img, qy, qx) of the Hout x Wout grid is written at
+  // (img, qy*out_sy + out_y0, qx*out_sx + out_x0) of the Hfull x Wfull map (identity for ordinary launches)
+  int remap_out, Hfull, Wfull, out_sy, out_sx, out_y0, out_x0;
+  int stagger_by_parity;   // conv_igemm256<true>: wave groups = even / odd waves instead of waves 0-3 / 4-7
+};
+
+// Tile shapes: (TM pixels x TN output channels) = 128x128 (default) or 256x64 (layers with <= 64 output channels,
+// so no half of the MFMA work is spent on zero-padded channels).  4 waves, each a 64(n) x 64(m) sub-tile.
+
+template <int BK> __device__ __forceinline__ int swz(int row);
+template <> __device__ __forceinline__ int swz<64>(int row) { return row & 7; }
+template <> __device__ __forceinline__ int swz<32>(int row) { return (-(row >> 2)) & 3; }
+
+__device__ __forceinline__ void glds16(const bf16_t* src, void* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds(U2_GLB_PTR(src), U2_LDS_PTR(lds_dst_wave_base), 16, 0, 0);
+}
+
+
+// conv_tile.hip: persistent 64(ch) x 128(px)-per-wave tile kernels; returns 1 when it took the launch, 0 when the shape is
+// not served (caller falls back to conv_igemm_kernel), -1000 - hipError_t on a launch failure.
+int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s);
+
+}  // namespace u2conv

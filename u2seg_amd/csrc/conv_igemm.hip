@@ -17,42 +17,11 @@
 // lane ends up with 4 consecutive channels of one pixel; the tile is then transposed through LDS
 // and written with 16-byte coalesced stores (bias / accumulate / ReLU / BN column statistics fused).
 #include "common.h"
+#include "conv_args.h"
 #include "u2seg_hip.h"
 
+using namespace u2conv;
 namespace {
-
-struct ConvArgs {
-  const bf16_t* in;
-  const bf16_t* wt;
-  bf16_t* out;
-  const float* bias;
-  float* stats;
-  const bf16_t* zero;
-  int B, Hin, Win, C, in_ld;
-  int Hout, Wout, N, out_ld;
-  int mul;                 // source pixel = output pixel * mul + tap offset
-  int relu, accumulate;
-  int M, tiles_m, tiles_n;
-  // tap table: tap t reads the source at (qy*mul + tap_dy[t], qx*mul + tap_dx[t]) and uses filter tap tap_w[t]
-  int ntaps, wt_taps;      // taps of this launch / taps in the weight layout ([N][wt_taps][C])
-  int KW, pad_h, pad_w;    // regular launches (remap_out == 0) derive tap t = (kh, kw) arithmetically, no table reads
-  short tap_dy[64], tap_dx[64], tap_w[64];
-  // output placement: pixel (img, qy, qx) of the Hout x Wout grid is written at
-  // (img, qy*out_sy + out_y0, qx*out_sx + out_x0) of the Hfull x Wfull map (identity for ordinary launches)
-  int remap_out, Hfull, Wfull, out_sy, out_sx, out_y0, out_x0;
-  int stagger_by_parity;   // conv_igemm256<true>: wave groups = even / odd waves instead of waves 0-3 / 4-7
-};
-
-// Tile shapes: (TM pixels x TN output channels) = 128x128 (default) or 256x64 (layers with <= 64 output channels,
-// so no half of the MFMA work is spent on zero-padded channels).  4 waves, each a 64(n) x 64(m) sub-tile.
-
-template <int BK> __device__ __forceinline__ int swz(int row);
-template <> __device__ __forceinline__ int swz<64>(int row) { return row & 7; }
-template <> __device__ __forceinline__ int swz<32>(int row) { return (-(row >> 2)) & 3; }
-
-__device__ __forceinline__ void glds16(const bf16_t* src, void* lds_dst_wave_base) {
-  __builtin_amdgcn_global_load_lds(U2_GLB_PTR(src), U2_LDS_PTR(lds_dst_wave_base), 16, 0, 0);
-}
 
 template <int BK, bool GLDS, int TM, int TN, int NST>
 __global__ __launch_bounds__((TM / 64) * (TN / 64) * 64, 2) void conv_igemm_kernel(const ConvArgs a) {
@@ -1114,6 +1083,11 @@ const bf16_t* zero_page_ptr() {
 namespace {
 
 int launch_conv(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
+  {  // persistent tile kernels (conv_tile.hip) first; 0 = shape / variant not served there
+    const int rc = launch_conv_tile(a, N, C, variant, s);
+    if (rc == 1) return 0;
+    if (rc < 0) return rc;
+  }
   // wide layers: 256 x 256 tile, 8 waves, four-deep half-K-tile ring (variant bit 8 forces it, bit 9 forbids it)
   const bool wide_ok = !a.remap_out && C % 64 == 0 && a.ntaps * (C / 32) >= 4;
   // measured win: deep reductions (K >= 1024) with at least two full waves of 256 x 256 tiles; short-K 1x1 layers lose
@@ -1212,6 +1186,7 @@ extern "C" int u2_conv_igemm(const void* in, const void* wt, void* out, const fl
       for (int kw = 0; kw < KW; ++kw) {
         const int t = kh * KW + kw;
         a.tap_dy[t] = (short)(kh - pad_h); a.tap_dx[t] = (short)(kw - pad_w); a.tap_w[t] = (short)t;
+        a.tap_pk[t] = ((kh - pad_h) & 0xff) | (((kw - pad_w) & 0xff) << 8) | (t << 16);
       }
     a.remap_out = 0; a.out_sy = a.out_sx = 1; a.out_y0 = a.out_x0 = 0;
     return launch_conv(a, N, C, variant, s);
@@ -1232,6 +1207,7 @@ extern "C" int u2_conv_igemm(const void* in, const void* wt, void* out, const fl
           if (((vx % div) + div) % div) continue;
           a.tap_dy[nt] = (short)floor_div(vy, div); a.tap_dx[nt] = (short)floor_div(vx, div);
           a.tap_w[nt] = (short)(kh * KW + kw);
+          a.tap_pk[nt] = (a.tap_dy[nt] & 0xff) | ((a.tap_dx[nt] & 0xff) << 8) | ((kh * KW + kw) << 16);
           ++nt;
         }
       }

@@ -1,0 +1,523 @@
+// Persistent tile kernels of the implicit-GEMM convolution on CDNA4 MFMA (gfx950), bf16 in / fp32 accumulate.
+//
+// Same operation and argument block as conv_igemm.hip (F.conv2d / F.linear forward and data gradient behind
+// detectron2/layers/wrappers.py:127-134, roi_heads/box_head.py:94-97, roi_heads/mask_head.py:287-290), restructured
+// around three facts measured on the round-1 kernels:
+//   * a work-group that stops at the end of its tile leaves the matrix pipe idle for the tile's prologue (first operands
+//     come from HBM) and epilogue; for the 1x1 layers (4-16 K steps) that is most of the tile's life.  Here a work-group
+//     is persistent: it walks a strided list of tiles and its LDS-DMA ring never drains - the operands of the next
+//     tile are already in flight while the last K steps of the current one are multiplied and while it is stored;
+//   * the LDS-staged output transpose cost two barriers, 32-48 KB of LDS and made the ring alias the output tile.  Here
+//     the weight rows of a wave's 64-channel slice are staged in a permuted order, so that MFMA leaves every lane with
+//     two runs of 8 consecutive channels of one pixel: the accumulators go to HBM as 16-byte stores straight from
+//     registers (4 lanes = one 64-byte segment), bias / ReLU / accumulate / BN column statistics applied on the way;
+//   * with the whole LDS free for operands the ring is up to five half-K tiles deep (160 KB): global_load_lds runs
+//     three to four half tiles ahead of the MFMAs under counted vmcnt, one raw barrier per half tile.
+//
+// Wave tile 64 channels x 128 pixels (4 x 8 v_mfma_f32_16x16x32_bf16 accumulators, 12 ds_read_b128 per 32 MFMA);
+// work-group = WCH x WPX waves: 4x2 (256 ch x 256 px, one group per CU), 2x2 and 4x1 (two groups per CU).
+#include "common.h"
+#include "conv_args.h"
+
+namespace u2conv {
+namespace {
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// Transposing reduction over the 16 lanes of a DPP row (lanes sharing lane >> 4): every lane enters with 16 partial sums
+// v[0..15]; lane fr leaves with the row total of v[fr].  Four exchange steps, each halving the values a lane carries
+// (the lane keeps the half selected by one bit of fr and adds its partner's copy of that half): 15 adds instead of the 64
+// of an all-reduce, and the totals end up one per lane, which is what a full-wave atomic wants.
+__device__ __forceinline__ float row16_transpose_sum(float (&v)[16], int fr) {
+  {
+    const bool up = fr & 8;  // partner fr ^ 8 (row_ror:8)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float keep = up ? v[k + 8] : v[k], send = up ? v[k] : v[k + 8];
+      v[k] = keep + dpp_mov<0x128>(send);
+    }
+  }
+  {
+    const bool up = fr & 4;  // partner fr ^ 7 (row_half_mirror): same bit 3, opposite bit 2
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float keep = up ? v[k + 4] : v[k], send = up ? v[k] : v[k + 4];
+      v[k] = keep + dpp_mov<0x141>(send);
+    }
+  }
+  {
+    const bool up = fr & 2;  // partner fr ^ 2 (quad_perm [2,3,0,1])
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float keep = up ? v[k + 2] : v[k], send = up ? v[k] : v[k + 2];
+      v[k] = keep + dpp_mov<0x4E>(send);
+    }
+  }
+  const bool up = fr & 1;    // partner fr ^ 1 (quad_perm [1,0,3,2])
+  const float keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+  return keep + dpp_mov<0xB1>(send);
+}
+
+// m / d and m % d for 0 <= m < 2^24 through one float multiply (inv = 1.0f / d) and a +-1 correction
+__device__ __forceinline__ void divmod_f(int m, int d, float inv, int& q, int& r) {
+  q = (int)((float)m * inv);
+  r = m - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) { ++q; r -= d; }
+}
+
+// one 16-byte MFMA fragment from LDS byte address addr + OFF; NOT counted by the compiler: the caller waits (lgkmcnt) itself
+template <int OFF> __device__ __forceinline__ s16x8 lds_frag(unsigned addr) {
+  s16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// two floats -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+  return *reinterpret_cast<const uint32_t*>(&r);
+}
+
+template <int WCH, int WPX, int RING, bool JSPLIT>
+__global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const ConvArgs a) {
+  constexpr int NW = WCH * WPX, NT = NW * 64;
+  constexpr int TN = WCH * 64, TM = WPX * 128;
+  constexpr int LP = TM * 4 / NT;   // 16-byte chunks a thread moves per half K tile, pixel operand
+  constexpr int LW = TN * 4 / NT;   //                                                weight operand
+  constexpr int LPT = LP + LW;
+  constexpr int PBYTES = TM * 64, WBYTES = TN * 64, BUF = PBYTES + WBYTES;  // one half K tile: rows of 32 bf16
+  constexpr int AHEAD = RING - 1;
+  static_assert(LP >= 1 && LW >= 1 && RING >= 3 && RING <= 5, "unsupported configuration");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- the tiles of this work-group: XCD x owns a contiguous range of the (tile_m, tile_n) list (tile_n fastest), its
+  // work-groups walk that range with stride gridDim/8, so at any time an XCD's L2 serves one window of neighbouring tiles
+  const int T = a.tiles_m * a.tiles_n;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, stride = gridDim.x >> 3;
+  const int q8 = T >> 3, r8 = T & 7;
+  const int xbase = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int xcnt = q8 + (xcd < r8 ? 1 : 0);
+  if (idx >= xcnt) return;
+  const int my_tiles = (xcnt - idx + stride - 1) / stride;
+  const int first_tile = xbase + idx;
+  const int kh_per_tap = a.C >> 5;           // half K tiles (32 channels) per filter tap
+  const int nkh = a.ntaps * kh_per_tap;      // >= RING (host)
+  const int H = my_tiles * nkh;              // half K tiles this work-group multiplies, across all its tiles
+
+  // ---- staging cursors.  The pixel cursor runs AHEAD + 1 half tiles in front of the MFMAs, the weight cursor AHEAD; both
+  // cross tile boundaries on their own.  Per row a thread keeps the address of the tap-(0,0) source pixel and its (y, x):
+  // a tap only adds a wave-uniform offset and a bounds test (rows that fall into the padding read the zero page).
+  const int row_in = lane >> 2;
+  const int cc = (lane & 3) ^ swz<32>(row_in);
+  const int hw = a.Hout * a.Wout;
+  const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)a.Wout;
+  const bool linear = a.ntaps == 1 && a.mul == 1 && a.Hin == a.Hout && a.Win == a.Wout &&
+                      (a.remap_out ? ((a.tap_pk[0] & 0xffff) == 0) : (a.pad_h == 0 && a.pad_w == 0));
+
+  unsigned p_center[LP];  // byte offset of the tap-(0,0) source chunk from a.in (host: the input is < 4 GB)
+  int p_yx[LP];
+  const bf16_t* p_src[LP];
+  unsigned p_okmask = 0;  // bit i: row i of this thread reads real data in the current tap (advance by 32 channels)
+  int pt = -1, p_tap = a.ntaps, p_kc = 0, p_kh = 0, p_kw = 0;
+  auto setup_pixels = [&](int tile) {
+    const int m0 = (tile / a.tiles_n) * TM;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) {
+      const int m = m0 + (i * NW + w) * 16 + row_in;
+      if (m < a.M) {
+        if (linear) {
+          p_center[i] = (unsigned)(((size_t)m * a.in_ld + cc * 8) * 2);
+          p_yx[i] = 0;
+        } else {
+          int img, rem, oy, ox;
+          divmod_f(m, hw, inv_hw, img, rem);
+          divmod_f(rem, a.Wout, inv_w, oy, ox);
+          const int y = oy * a.mul, x = ox * a.mul;
+          p_center[i] = (unsigned)((((size_t)(img * a.Hin + y) * a.Win + x) * a.in_ld + cc * 8) * 2);
+          p_yx[i] = (y & 0xffff) | (x << 16);
+        }
+      } else {
+        p_center[i] = 0;
+        p_yx[i] = 0x8000;  // y = -32768: every tap is out of range
+      }
+    }
+  };
+  auto stage_pixels = [&](int buf) {
+    if (p_kc == 0) {
+      if (p_tap == a.ntaps) {
+        p_tap = 0; p_kh = 0; p_kw = 0;
+        ++pt;
+        setup_pixels(first_tile + pt * stride);
+      }
+      int dy, dx;
+      if (a.remap_out) {
+        const int pk = a.tap_pk[__builtin_amdgcn_readfirstlane(p_tap)];
+        dy = (int)(signed char)(pk & 0xff); dx = (int)(signed char)((pk >> 8) & 0xff);
+      } else {
+        dy = p_kh - a.pad_h; dx = p_kw - a.pad_w;
+        if (++p_kw == a.KW) { p_kw = 0; ++p_kh; }
+      }
+      const unsigned char* tap_base = reinterpret_cast<const unsigned char*>(a.in) + ((long long)dy * a.Win + dx) * a.in_ld * 2;
+      p_okmask = 0;
+#pragma unroll
+      for (int i = 0; i < LP; ++i) {
+        const int sy = (int)(short)(p_yx[i] & 0xffff) + dy, sx = (p_yx[i] >> 16) + dx;
+        const bool ok = (unsigned)sy < (unsigned)a.Hin && (unsigned)sx < (unsigned)a.Win;
+        p_src[i] = ok ? reinterpret_cast<const bf16_t*>(tap_base + p_center[i]) : a.zero;
+        p_okmask |= ok ? (1u << i) : 0u;
+      }
+      ++p_tap;
+      p_kc = kh_per_tap;
+    }
+    --p_kc;
+    unsigned char* base = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) {
+      glds16(p_src[i], base + (i * NW + w) * 1024);
+      p_src[i] += (p_okmask >> i & 1u) * 32;
+    }
+  };
+
+  // Weight rows: LDS row rho = blk * 16 + q of a wave's 64-channel slice holds channel
+  //   (blk >> 1) * 32 + (q >> 2) * 8 + (blk & 1) * 4 + (q & 3),
+  // so that the MFMA output rows a lane owns (q = fg * 4 + r in each of the 4 blocks) are channels fg*8 .. fg*8+7 and
+  // 32 + fg*8 .. 32 + fg*8+7 of the slice: two 16-byte runs per pixel.
+  unsigned w_base[LW];  // byte offset of the row's first chunk from a.wt; 0xffffffff = row beyond N (reads the zero page)
+  const bf16_t* w_src[LW];
+  int wt_i = -1, w_tap = a.ntaps, w_kc = 0;
+  auto setup_weights = [&](int tile) {
+    const int n0 = (tile % a.tiles_n) * TN;
+#pragma unroll
+    for (int i = 0; i < LW; ++i) {
+      const int R = (i * NW + w) * 16 + row_in;
+      const int blk = (R >> 4) & 3, q = R & 15;
+      const int n = n0 + (R & ~63) + (blk >> 1) * 32 + (q >> 2) * 8 + (blk & 1) * 4 + (q & 3);
+      w_base[i] = n < a.N ? (unsigned)(((size_t)n * ((size_t)a.wt_taps * a.C) + cc * 8) * 2) : 0xffffffffu;
+    }
+  };
+  auto stage_weights = [&](int buf) {
+    if (w_kc == 0) {
+      if (w_tap == a.ntaps) {
+        w_tap = 0;
+        ++wt_i;
+        setup_weights(first_tile + wt_i * stride);
+      }
+      const int wtap = a.remap_out ? (a.tap_pk[__builtin_amdgcn_readfirstlane(w_tap)] >> 16) : w_tap;
+      const unsigned char* tap_base = reinterpret_cast<const unsigned char*>(a.wt) + (size_t)wtap * a.C * 2;
+#pragma unroll
+      for (int i = 0; i < LW; ++i)
+        w_src[i] = w_base[i] != 0xffffffffu ? reinterpret_cast<const bf16_t*>(tap_base + w_base[i]) : a.zero;
+      ++w_tap;
+      w_kc = kh_per_tap;
+    }
+    --w_kc;
+    unsigned char* base = smem + buf * BUF + PBYTES;
+#pragma unroll
+    for (int i = 0; i < LW; ++i) {
+      glds16(w_src[i], base + (i * NW + w) * 1024);
+      w_src[i] += w_base[i] != 0xffffffffu ? 32 : 0;
+    }
+  };
+
+  const int wr = w / WPX;  // 64-channel slice of the tile
+  const int wc = w % WPX;  // 128-pixel slice of the tile
+  const int fr = lane & 15;
+  const int fg = lane >> 4;
+  // the swizzle has a period of 16 rows: fragment t of a wave is fragment 0 + t * 1024 bytes (an immediate offset)
+  const int wfrag0 = PBYTES + (wr * 64 + fr) * 64 + ((fg ^ swz<32>(fr)) << 4);
+  const int pfrag0 = (wc * 128 + fr) * 64 + ((fg ^ swz<32>(fr)) << 4);
+  auto ldw = [&](int hb, int t) { return *reinterpret_cast<const s16x8*>(smem + hb * BUF + wfrag0 + t * 1024); };
+  auto ldp = [&](int hb, int t) { return *reinterpret_cast<const s16x8*>(smem + hb * BUF + pfrag0 + t * 1024); };
+
+  f32x4 acc[4][8];
+  s16x8 wfA[2], wfB[2], pf[8];
+  s16x8 wf2[1][4];  // JSPLIT: the four weight fragments of the half tile
+
+  // BN column statistics: a lane accumulates the sums of ONE channel (st_n) over all tiles the work-group walks with the
+  // same tile_n and sends them with two full-wave atomics when the channel changes or the work-group is done.
+  float st_s = 0.f, st_ss = 0.f;
+  int st_n = -1;
+  auto stats_flush = [&]() {
+    if (st_n >= 0 && st_n < a.N) {
+      asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(a.stats + st_n), "v"(st_s) : "memory");
+      asm volatile("global_atomic_add_f32 %0, %1, off\n\ts_nop 1" ::"v"(a.stats + a.N + st_n), "v"(st_ss) : "memory");
+    }
+    st_s = 0.f; st_ss = 0.f;
+  };
+
+  // ---- epilogue: registers -> HBM.  acc[i][j][r] = channel (i >> 1) * 32 + fg * 8 + (i & 1) * 4 + r of the wave's slice,
+  // pixel j * 16 + fr of the wave's 128 pixels.  Every memory operation in here is inline asm on purpose: a global load,
+  // store or atomic the compiler can see inside the tile loop makes its wait-count pass put `s_waitcnt vmcnt(0)` in front
+  // of the first fragment read of every half tile (it cannot tell the LDS-DMA in flight from these), which turns the ring
+  // into a synchronous load.  Stores carry their own `s_nop 1` (the data registers may be reused right after the
+  // statement), the bias loads wait inside their statement.
+  auto epilogue = [&](int tile) {
+    const int tile_m = tile / a.tiles_n, tile_n = tile - tile_m * a.tiles_n;
+    const int m0 = tile_m * TM + wc * 128;
+    const int nb = tile_n * TN + wr * 64 + fg * 8;
+    const bool okA = nb < a.N, okB = nb + 32 < a.N;  // N % 8 == 0: an 8-channel run is valid or absent as a whole
+    f32x4 bia[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (a.bias) {  // drains the LDS-DMA ring once per tile (the layers with a bias have long reductions)
+      if (okA)
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(bia[0]), "=&v"(bia[1]) : "v"(a.bias + nb) : "memory");
+      if (okB)
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(bia[2]), "=&v"(bia[3]) : "v"(a.bias + nb + 32) : "memory");
+    }
+    float s[16], ss[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+    const bool nt_out = (size_t)a.M * a.out_ld * 2 > ((size_t)160 << 20);
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = m0 + j * 16 + fr;
+      if (m < a.M) {
+        size_t orow = (size_t)m;
+        if (a.remap_out) {
+          int img, rem, qy, qx;
+          divmod_f(m, hw, inv_hw, img, rem);
+          divmod_f(rem, a.Wout, inv_w, qy, qx);
+          orow = ((size_t)img * a.Hfull + qy * a.out_sy + a.out_y0) * a.Wfull + qx * a.out_sx + a.out_x0;
+        }
+        bf16_t* dst = a.out + orow * a.out_ld + nb;
+        uint32_t pk[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // block i holds channels e0 .. e0 + 3 of this lane's 16, e0 = (i >> 1) * 8 + (i & 1) * 4
+          float v0 = acc[i][j][0] + bia[i][0], v1 = acc[i][j][1] + bia[i][1];
+          float v2 = acc[i][j][2] + bia[i][2], v3 = acc[i][j][3] + bia[i][3];
+          if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+          pk[2 * i] = pack_bf16(v0, v1);
+          pk[2 * i + 1] = pack_bf16(v2, v3);
+        }
+        if (a.stats) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float lo = __uint_as_float(pk[e] << 16), hi = __uint_as_float(pk[e] & 0xffff0000u);
+            s[2 * e] += lo; ss[2 * e] += lo * lo;
+            s[2 * e + 1] += hi; ss[2 * e + 1] += hi * hi;
+          }
+        }
+        const u32x4_t va = {pk[0], pk[1], pk[2], pk[3]}, vb = {pk[4], pk[5], pk[6], pk[7]};
+        if (nt_out) {  // outputs far beyond the MALL size: do not let them evict what the next layer can still reuse
+          if (okA) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(va) : "memory");
+          if (okB) asm volatile("global_store_dwordx4 %0, %1, off offset:64 nt\n\ts_nop 1" ::"v"(dst), "v"(vb) : "memory");
+        } else {
+          if (okA) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(va) : "memory");
+          if (okB) asm volatile("global_store_dwordx4 %0, %1, off offset:64\n\ts_nop 1" ::"v"(dst), "v"(vb) : "memory");
+        }
+      }
+    }
+    if (a.stats) {
+      // after the transposing reduction lane (fg, fr) holds the tile's column sums of the channel below
+      const int n_here = tile_n * TN + wr * 64 + fg * 8 + (fr >> 3) * 32 + (fr & 7);
+      if (n_here != st_n) { stats_flush(); st_n = n_here; }
+      st_s += row16_transpose_sum(s, fr);
+      st_ss += row16_transpose_sum(ss, fr);
+    }
+  };
+
+#define U2_T_MFMA(I, WF, J) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF, pf[J], acc[I][J], 0, 0, 0)
+
+  // ---- prologue: P0 W0 ... P(AHEAD-1) W(AHEAD-1) P(AHEAD) in flight, publish half tile 0 ----
+#pragma unroll
+  for (int i = 0; i < AHEAD; ++i) { stage_pixels(i); stage_weights(i); }
+  stage_pixels(AHEAD);
+  wait_vm<LPT * (AHEAD - 1) + LP>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  const unsigned lds0 = (unsigned)(size_t)U2_LDS_PTR(smem);
+  if constexpr (JSPLIT) {  // same issue order as a steady-state B': pf0-3, wf0 .. wf3
+    const unsigned p0 = lds0 + pfrag0, w0 = lds0 + wfrag0;
+    pf[0] = lds_frag<0>(p0); pf[1] = lds_frag<1024>(p0); pf[2] = lds_frag<2048>(p0); pf[3] = lds_frag<3072>(p0);
+    wf2[0][0] = lds_frag<0>(w0); wf2[0][1] = lds_frag<1024>(w0); wf2[0][2] = lds_frag<2048>(w0); wf2[0][3] = lds_frag<3072>(w0);
+  } else {
+    wfA[0] = ldw(0, 0); wfA[1] = ldw(0, 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pf[j] = ldp(0, j);
+  }
+
+  // One half K tile gh (buffer hb = gh % RING), two phases:
+  //   A: 4 MFMA | read pixel fragments 4-7 and the second weight pair of gh, stage weights(gh + AHEAD) | 12 MFMA
+  //   B: vmcnt (half tile gh + 1 landed), barrier [publishes gh + 1, frees buffer hb] | stage pixels(gh + AHEAD + 1) into hb |
+  //      8 MFMA | read the first weight pair and pixel fragments 0-3 of gh + 1 | 8 MFMA
+  // so no MFMA waits on an LDS read issued less than ~8 MFMAs earlier, and the LDS-DMA of a half tile has AHEAD - 1 full
+  // half tiles of MFMAs to land.  The sequence runs straight through tile boundaries; only the accumulators are stored
+  // and cleared there.
+  int gh = 0, hb = 0;
+  for (int ti = 0; ti < my_tiles; ++ti) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < nkh; ++h) {
+      const int nb = (hb + 1 == RING) ? 0 : hb + 1;
+      const int sb = (hb == 0) ? RING - 1 : hb - 1;  // buffer of half tile gh + AHEAD (= gh - 1 mod RING)
+      if constexpr (JSPLIT) {
+        // j-split schedule: phase A' = all four channel blocks x pixel fragments 0-3, phase B' = x pixel fragments 4-7, channel
+        // block by channel block.  Pixel fragments 4-7 of gh are read at the head of A' and first used in B'; pixel fragments
+        // 0-3 of gh + 1 are read at the head of B' and first used in the next A'; weight fragment i of gh + 1 replaces
+        // fragment i right after its last four MFMAs in B' and is first used 4 * (i + 1) + 12 - 4 * i MFMAs later.  The
+        // fragment reads are inline asm with counted lgkmcnt (LDS returns in order): across the loop back-edge the compiler
+        // only ever emits lgkmcnt(0), which would expose the latency of the reads just issued at the head of A'.
+        const unsigned pa = lds0 + hb * BUF + pfrag0, pn = lds0 + nb * BUF + pfrag0, wn = lds0 + nb * BUF + wfrag0;
+        pf[4] = lds_frag<4096>(pa); pf[5] = lds_frag<5120>(pa); pf[6] = lds_frag<6144>(pa); pf[7] = lds_frag<7168>(pa);
+        if (gh + AHEAD < H) stage_weights(sb);
+        // outstanding LDS reads, oldest first: pf0-3, wf0, wf1, wf2, wf3 (of this half tile), pf4-7
+#define U2_T_JA(I, CNT)                                                                                            \
+  do {                                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT) : "memory");                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) U2_T_MFMA(I, wf2[0][I], j);                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+  } while (0)
+        __builtin_amdgcn_s_setprio(1);
+        U2_T_JA(0, 7); U2_T_JA(1, 6); U2_T_JA(2, 5); U2_T_JA(3, 4);
+        __builtin_amdgcn_s_setprio(0);
+#undef U2_T_JA
+        {
+          const int rem = H - 2 - gh;
+          if (rem >= AHEAD - 1) wait_vm<LPT * (AHEAD - 1)>();
+          else if (AHEAD > 3 && rem == 2) wait_vm<LPT * 2>();
+          else if (rem == 1) wait_vm<LPT>();
+          else wait_vm<0>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (gh + AHEAD + 1 < H) stage_pixels(hb);
+        const bool next = gh + 1 < H;
+        if (next) { pf[0] = lds_frag<0>(pn); pf[1] = lds_frag<1024>(pn); pf[2] = lds_frag<2048>(pn); pf[3] = lds_frag<3072>(pn); }
+        __builtin_amdgcn_sched_barrier(0);
+#define U2_T_JB(I)                                                                                                 \
+  do {                                                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                                 \
+    _Pragma("unroll") for (int j = 4; j < 8; ++j) U2_T_MFMA(I, wf2[0][I], j);                                      \
+    __builtin_amdgcn_s_setprio(0);                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    if (next) wf2[0][I] = lds_frag<I * 1024>(wn);                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+  } while (0)
+        U2_T_JB(0); U2_T_JB(1); U2_T_JB(2); U2_T_JB(3);
+#undef U2_T_JB
+      } else {
+      // phase A
+      __builtin_amdgcn_s_setprio(1);
+      U2_T_MFMA(0, wfA[0], 0); U2_T_MFMA(1, wfA[1], 0); U2_T_MFMA(0, wfA[0], 1); U2_T_MFMA(1, wfA[1], 1);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      pf[4] = ldp(hb, 4); pf[5] = ldp(hb, 5); pf[6] = ldp(hb, 6); pf[7] = ldp(hb, 7);
+      wfB[0] = ldw(hb, 2); wfB[1] = ldw(hb, 3);
+      if (gh + AHEAD < H) stage_weights(sb);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      U2_T_MFMA(0, wfA[0], 2); U2_T_MFMA(1, wfA[1], 2); U2_T_MFMA(0, wfA[0], 3); U2_T_MFMA(1, wfA[1], 3);
+#pragma unroll
+      for (int j = 4; j < 8; ++j) { U2_T_MFMA(0, wfA[0], j); U2_T_MFMA(1, wfA[1], j); }
+      __builtin_amdgcn_s_setprio(0);
+      // phase B
+      {
+        const int rem = H - 2 - gh;  // half tiles staged behind gh + 1
+        if (rem >= AHEAD - 1) wait_vm<LPT * (AHEAD - 1)>();
+        else if (AHEAD > 3 && rem == 2) wait_vm<LPT * 2>();
+        else if (rem == 1) wait_vm<LPT>();
+        else wait_vm<0>();
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (gh + AHEAD + 1 < H) stage_pixels(hb);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { U2_T_MFMA(2, wfB[0], j); U2_T_MFMA(3, wfB[1], j); }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gh + 1 < H) {
+        wfA[0] = ldw(nb, 0); wfA[1] = ldw(nb, 1);
+        pf[0] = ldp(nb, 0); pf[1] = ldp(nb, 1); pf[2] = ldp(nb, 2); pf[3] = ldp(nb, 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 4; j < 8; ++j) { U2_T_MFMA(2, wfB[0], j); U2_T_MFMA(3, wfB[1], j); }
+      __builtin_amdgcn_s_setprio(0);
+      }
+      ++gh;
+      hb = nb;
+    }
+    epilogue(first_tile + ti * stride);
+  }
+  if (a.stats) stats_flush();
+#undef U2_T_MFMA
+}
+
+template <int WCH, int WPX, int RING, bool JSPLIT>
+int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s) {
+  constexpr int TN = WCH * 64, TM = WPX * 128;
+  constexpr int LDS = RING * (TM + TN) * 64;
+  a.tiles_m = (a.M + TM - 1) / TM;
+  a.tiles_n = (N + TN - 1) / TN;
+  const long long T = (long long)a.tiles_m * a.tiles_n;
+  if (T >= (1 << 30)) return 0;
+  long long cap = tiny_grid ? 8 : 256LL * per_cu;
+  long long G = T < cap ? T : cap;
+  G = (G + 7) & ~7LL;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, JSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, JSPLIT>), dim3((unsigned)G), dim3(WCH * WPX * 64), LDS, s, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return -1000 - (int)e;
+  return 1;
+}
+
+}  // namespace
+
+// variant bits 12-15 select the tile configuration: 0 = automatic, 1 = 256ch x 256px ring 4, 2 = 256 x 256 ring 5,
+// 3 = 128ch x 256px (ring 3, two groups per CU), 4 = 256ch x 128px (ring 3, two groups per CU), 5 = 128ch x 256px ring 4,
+// 6 / 7 = configurations 1 / 2 with the j-split schedule, 15 = never (conv_igemm.hip kernels only);
+// bit 16: 8 work-groups only (tests: forces several tiles per work-group).
+int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
+  int sel = (variant >> 12) & 15;
+  const int tiny = (variant >> 16) & 1;
+  if (sel == 15) return 0;
+  if ((C & 31) || (N & 7) || (a.out_ld & 7) || a.ntaps < 1 || a.M >= (1 << 24) || a.M < 1 || a.accumulate) return 0;
+  // 32-bit byte offsets inside the kernel
+  if ((unsigned long long)a.B * a.Hin * a.Win * a.in_ld * 2ull >= 0xffffffffull || (unsigned long long)N * a.wt_taps * C * 2ull >= 0xfffffff0ull) return 0;
+  const int nkh = a.ntaps * (C >> 5);
+  if (sel == 0) {
+    // automatic choice: filled in from the per-layer measurements (tests/native/selftest bench2)
+    return 0;
+  }
+  const int ring = (sel == 2 || sel == 7) ? 5 : (sel == 1 || sel == 5 || sel == 6) ? 4 : 3;
+  if (nkh < ring) return 0;
+  switch (sel) {
+    case 1: return launch_cfg<4, 2, 4, false>(a, N, 1, tiny, s);
+    case 2: return launch_cfg<4, 2, 5, false>(a, N, 1, tiny, s);
+    case 3: return launch_cfg<2, 2, 3, false>(a, N, 2, tiny, s);
+    case 4: return launch_cfg<4, 1, 3, false>(a, N, 2, tiny, s);
+    case 5: return launch_cfg<2, 2, 4, false>(a, N, 1, tiny, s);
+    case 6: return launch_cfg<4, 2, 4, true>(a, N, 1, tiny, s);
+    case 7: return launch_cfg<4, 2, 5, true>(a, N, 1, tiny, s);
+    default: return 0;
+  }
+}
+
+}  // namespace u2conv
