@@ -16,6 +16,8 @@
 //
 // Wave tile 64 channels x 128 pixels (4 x 8 v_mfma_f32_16x16x32_bf16 accumulators, 12 ds_read_b128 per 32 MFMA);
 // work-group = WCH x WPX waves: 4x2 (256 ch x 256 px, one group per CU), 2x2 and 4x1 (two groups per CU).
+#include <stdlib.h>
+
 #include "common.h"
 #include "conv_args.h"
 
@@ -85,7 +87,7 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
   return *reinterpret_cast<const uint32_t*>(&r);
 }
 
-template <int WCH, int WPX, int RING, bool JSPLIT>
+template <int WCH, int WPX, int RING, bool JSPLIT, int ABL = 0>
 __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const ConvArgs a) {
   constexpr int NW = WCH * WPX, NT = NW * 64;
   constexpr int TN = WCH * 64, TM = WPX * 128;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #pragma unroll
     for (int i = 0; i < LP; ++i) {
       glds16(p_src[i], base + (i * NW + w) * 1024);
-      p_src[i] += (p_okmask >> i & 1u) * 32;
+      p_src[i] += (p_okmask >> i & 1u) * ((ABL & 8) ? 64 : 32);
     }
   };
 
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
       glds16(w_src[i], base + (i * NW + w) * 1024);
-      w_src[i] += w_base[i] != 0xffffffffu ? 32 : 0;
+      w_src[i] += w_base[i] != 0xffffffffu ? ((ABL & 8) ? 64 : 32) : 0;
     }
   };
 
@@ -330,7 +332,11 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     }
   };
 
-#define U2_T_MFMA(I, WF, J) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF, pf[J], acc[I][J], 0, 0, 0)
+#define U2_T_MFMA(I, WF, J)                                                                                        \
+  do {                                                                                                             \
+    if constexpr ((ABL & 4) == 0) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF, pf[J], acc[I][J], 0, 0, 0); \
+    else asm volatile("" ::"v"(WF), "v"(pf[J]));                                                                  \
+  } while (0)
 
   // ---- prologue: P0 W0 ... P(AHEAD-1) W(AHEAD-1) P(AHEAD) in flight, publish half tile 0 ----
 #pragma unroll
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       __builtin_amdgcn_sched_barrier(0);
       pf[4] = ldp(hb, 4); pf[5] = ldp(hb, 5); pf[6] = ldp(hb, 6); pf[7] = ldp(hb, 7);
       wfB[0] = ldw(hb, 2); wfB[1] = ldw(hb, 3);
-      if (gh + AHEAD < H) stage_weights(sb);
+      if ((ABL & 1) == 0 && gh + AHEAD < H) stage_weights(sb);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
       U2_T_MFMA(0, wfA[0], 2); U2_T_MFMA(1, wfA[1], 2); U2_T_MFMA(0, wfA[0], 3); U2_T_MFMA(1, wfA[1], 3);
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       for (int j = 4; j < 8; ++j) { U2_T_MFMA(0, wfA[0], j); U2_T_MFMA(1, wfA[1], j); }
       __builtin_amdgcn_s_setprio(0);
       // phase B
-      {
+      if constexpr ((ABL & 1) == 0) {
         const int rem = H - 2 - gh;  // half tiles staged behind gh + 1
         if (rem >= AHEAD - 1) wait_vm<LPT * (AHEAD - 1)>();
         else if (AHEAD > 3 && rem == 2) wait_vm<LPT * 2>();
@@ -438,9 +444,9 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
         else wait_vm<0>();
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if constexpr ((ABL & 2) == 0) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (gh + AHEAD + 1 < H) stage_pixels(hb);
+      if ((ABL & 1) == 0 && gh + AHEAD + 1 < H) stage_pixels(hb);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -466,7 +472,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #undef U2_T_MFMA
 }
 
-template <int WCH, int WPX, int RING, bool JSPLIT>
+template <int WCH, int WPX, int RING, bool JSPLIT, int ABL = 0>
 int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s) {
   constexpr int TN = WCH * 64, TM = WPX * 128;
   constexpr int LDS = RING * (TM + TN) * 64;
@@ -479,10 +485,10 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s) {
   G = (G + 7) & ~7LL;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, JSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, JSPLIT, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, JSPLIT>), dim3((unsigned)G), dim3(WCH * WPX * 64), LDS, s, a);
+  hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, JSPLIT, ABL>), dim3((unsigned)G), dim3(WCH * WPX * 64), LDS, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return -1000 - (int)e;
   return 1;
@@ -503,11 +509,36 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   if ((unsigned long long)a.B * a.Hin * a.Win * a.in_ld * 2ull >= 0xffffffffull || (unsigned long long)N * a.wt_taps * C * 2ull >= 0xfffffff0ull) return 0;
   const int nkh = a.ntaps * (C >> 5);
   if (sel == 0) {
-    // automatic choice: filled in from the per-layer measurements (tests/native/selftest bench2)
-    return 0;
+    // Automatic choice, from the per-layer A/B of tests/native/selftest bench2 on the shapes of the u2seg_R50_800 step
+    // (profiles/r02_conv_variants.txt): tile shape by output width and by how many whole rounds of tiles the chip gets.
+    const char* env = getenv("U2_CONV_TILE");  // debugging / A-B aid: force one configuration (or 15 = never)
+    if (env) sel = atoi(env) & 15;
+    if (sel == 15) return 0;
   }
-  const int ring = (sel == 2 || sel == 7) ? 5 : (sel == 1 || sel == 5 || sel == 6) ? 4 : 3;
-  if (nkh < ring) return 0;
+  if (sel == 0) {
+    const long long K = (long long)a.ntaps * C;
+    const long long t256 = (long long)((a.M + 255) / 256) * ((N + 255) / 256);
+    if (N <= 128) {
+      // 128-wide tiles (two groups per CU); the deep 3x3 layers with 128 outputs stay on the 128 x 128 BK-64 kernel
+      if (a.M >= 100000 && !(a.ntaps > 1 && K >= 2048)) sel = 3;
+    } else if (a.ntaps > 1) {
+      if (t256 >= 2048) sel = 2;                                   // stride-4 maps: >= 8 rounds of 256 x 256 tiles
+      else if (t256 >= 768) sel = 1;                               // stride-8 maps
+      else if (t256 >= 180 && t256 <= 256 && K >= 2048) sel = 1;   // one nearly full round (mask head 3x3)
+      else if (N >= 512 && t256 >= 128 && K >= 4096 && a.M >= 16000) sel = 1;  // res5 3x3 (not the 7x7 fc1: M = 8192)
+    } else {
+      if (N >= 4096) sel = 1;                                      // fc1 data gradient (N = 12544)
+      else if (a.M < 10000 && N <= 1024) sel = 0;                  // small fully connected layers
+      else if (K >= 2048) sel = 2;
+      else sel = 4;                                                // 1x1 layers: 256 ch x 128 px, two groups per CU
+    }
+    if (sel == 0) return 0;
+  }
+  const int ring = (sel == 2 || sel >= 7) ? 5 : (sel == 1 || sel == 5 || sel == 6) ? 4 : 3;
+  if (nkh < ring) {
+    if (nkh >= 3 && (variant >> 12 & 15) == 0) { sel = (N <= 128) ? 3 : 4; }  // automatic mode: the ring-3 configurations serve K >= 96
+    else return 0;
+  }
   switch (sel) {
     case 1: return launch_cfg<4, 2, 4, false>(a, N, 1, tiny, s);
     case 2: return launch_cfg<4, 2, 5, false>(a, N, 1, tiny, s);
@@ -516,6 +547,12 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
     case 5: return launch_cfg<2, 2, 4, false>(a, N, 1, tiny, s);
     case 6: return launch_cfg<4, 2, 4, true>(a, N, 1, tiny, s);
     case 7: return launch_cfg<4, 2, 5, true>(a, N, 1, tiny, s);
+    case 8: return launch_cfg<4, 2, 5, false, 1>(a, N, 1, tiny, s);   // ablations (wrong results): no LDS-DMA after the prologue
+    case 9: return launch_cfg<4, 2, 5, false, 3>(a, N, 1, tiny, s);   // ... and no barrier
+    case 10: return launch_cfg<4, 2, 5, false, 4>(a, N, 1, tiny, s);  // everything but the MFMAs
+    case 11: return launch_cfg<4, 2, 5, false, 2>(a, N, 1, tiny, s);  // no barrier (racy)
+    case 12: return launch_cfg<4, 2, 5, false, 12>(a, N, 1, tiny, s); // no MFMAs, and every 128-byte line visited once (64-channel stride)
+    case 13: return launch_cfg<4, 2, 5, false, 8>(a, N, 1, tiny, s);  // 64-channel stride with MFMAs
     default: return 0;
   }
 }
