@@ -156,6 +156,19 @@ long long u2_nms_workspace_bytes(int B, int n);
 int u2_batched_nms(const float* boxes, const int* group, const int* cnt, void* workspace, int* keep, int* nkeep, int B,
                    int n, float thr, int max_keep, void* stream);
 
+/* ---- selection with a total order (select.hip) -----------------------------------------------
+ * proposal_generator/proposal_utils.py:79-96 (per-level pre-NMS topk on the objectness logits, the score sort in front of
+ * batched_nms) and modeling/sampling.py:38-54 in its "k smallest random keys" form.  Every row is ranked by
+ * (value descending if largest else ascending, index ascending) - torch.topk leaves the order of ties open.
+ *   vals: fp32 (dtype 0) or bf16 (dtype 1); element i of row r is vals[r * row_stride + (i / group) * pitch + i % group]
+ *         (group = pitch = 1: contiguous rows; group = A, pitch = 32: the A valid columns of a 32-wide NHWC logit map);
+ *   mask (optional, int8 [rows][n]): only elements with mask == mask_value take part;
+ *   out_vals (optional) / out_idx [rows][k]: the k best in rank order; entries beyond out_cnt[r] = min(k, participants)
+ *   are (-/+inf, 0).  n < 2^24, k <= 16384. */
+int u2_topk_rows(const void* vals, int dtype, int rows, int n, long long row_stride, int group, int pitch,
+                 const signed char* mask, int mask_value, int k, int largest, float* out_vals, int* out_idx,
+                 int* out_cnt, void* stream);
+
 /* ---- inference tails (postprocess.hip) -------------------------------------------------------
  * layers/mask_ops.py:17-147 (paste_masks_in_image, GPU branch), meta_arch/panoptic_fpn.py:184-269. */
 /* out[k][y][x] (uint8 0/1) = bilinear sample of probs[k] (P x P fp32) on F.grid_sample(align_corners=False)'s grid over

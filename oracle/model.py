@@ -35,10 +35,13 @@ class _ScaleGradient(torch.autograd.Function):
 
 
 class OracleModel:
-    def __init__(self, cfg, state_dict, emulate_bf16=False, perm_fn=None):
+    def __init__(self, cfg, state_dict, emulate_bf16=False, perm_fn=None, key_fn=None):
         self.cfg = cfg
         self.emulate = emulate_bf16
         self.perm_fn = perm_fn
+        # key_fn(stage, image_index, n) -> n float keys: the sampling draws become argsort permutations of these keys
+        # (ops.subsample_labels_keyed); stage is "rpn" or "roi"
+        self.key_fn = key_fn
         self.p = {}
         for k, v in state_dict.items():
             t = v.detach().clone().float() if v.is_floating_point() else v.detach().clone()
@@ -198,11 +201,15 @@ class OracleModel:
     def rpn_label_and_sample(self, anchors_cat, gt_instances):
         r = self.cfg.MODEL.RPN
         labels, matched = [], []
-        for inst in gt_instances:
+        for i, inst in enumerate(gt_instances):
             gtb = inst.gt_boxes.tensor
             mq = ops.pairwise_iou(gtb, anchors_cat)
             midx, lab = ops.matcher(mq, r.IOU_THRESHOLDS, r.IOU_LABELS, True)
-            pos, neg = ops.subsample_labels(lab, r.BATCH_SIZE_PER_IMAGE, r.POSITIVE_FRACTION, 0, self.perm_fn)
+            if self.key_fn is not None:
+                pos, neg = ops.subsample_labels_keyed(lab, r.BATCH_SIZE_PER_IMAGE, r.POSITIVE_FRACTION, 0,
+                                                      self.key_fn("rpn", i, lab.numel()))
+            else:
+                pos, neg = ops.subsample_labels(lab, r.BATCH_SIZE_PER_IMAGE, r.POSITIVE_FRACTION, 0, self.perm_fn)
             lab.fill_(-1)
             lab.scatter_(0, pos, 1)
             lab.scatter_(0, neg, 0)
@@ -241,7 +248,10 @@ class OracleModel:
         bi = torch.arange(n)
         for li, (p, lg) in enumerate(zip(props, objs)):
             k = min(lg.shape[1], pre)
-            ts, ti = lg.topk(k, dim=1)
+            # proposal_utils.py:79-80 calls topk, whose order among equal logits is unspecified; the oracle fixes it the way a
+            # stable sort does (logit descending, anchor index ascending) - the rule the HIP selection kernel implements
+            srt = torch.sort(lg, dim=1, descending=True, stable=True)
+            ts, ti = srt[0][:, :k], srt[1][:, :k]
             tops.append(ts)
             topp.append(p[bi[:, None], ti])
             lvl.append(torch.full((k,), li, dtype=torch.int64))
@@ -273,7 +283,7 @@ class OracleModel:
         K = self.num_classes
         out = []
         gt_logit = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
-        for prop, inst in zip(proposals, gt_instances):
+        for i, (prop, inst) in enumerate(zip(proposals, gt_instances)):
             gtb, gtc = inst.gt_boxes.tensor, inst.gt_classes
             boxes = torch.cat([prop["proposal_boxes"], gtb])
             logits = torch.cat([prop["objectness_logits"], gt_logit * torch.ones(len(gtb))])
@@ -284,7 +294,11 @@ class OracleModel:
                 cls[mlab == -1] = -1
             else:
                 cls = torch.zeros_like(midx) + K
-            fg, bg = ops.subsample_labels(cls, h.BATCH_SIZE_PER_IMAGE, h.POSITIVE_FRACTION, K, self.perm_fn)
+            if self.key_fn is not None:
+                fg, bg = ops.subsample_labels_keyed(cls, h.BATCH_SIZE_PER_IMAGE, h.POSITIVE_FRACTION, K,
+                                                    self.key_fn("roi", i, cls.numel()))
+            else:
+                fg, bg = ops.subsample_labels(cls, h.BATCH_SIZE_PER_IMAGE, h.POSITIVE_FRACTION, K, self.perm_fn)
             sel = torch.cat([fg, bg])
             res = {"proposal_boxes": boxes[sel], "objectness_logits": logits[sel], "gt_classes": cls[sel],
                    "image_size": prop["image_size"]}
@@ -329,6 +343,31 @@ class OracleModel:
         loss_box = torch.abs(pred - tgt).sum() / max(gt_classes.numel(), 1.0)
         return loss_cls, loss_box
 
+    @torch.no_grad()
+    def cascade_next_stage(self, prev_boxes, image_sizes, gt_instances, k):
+        """cascade_rcnn.py:226-299: the boxes stage k-1 predicted become stage k's proposals - detached, clipped, empty ones
+        dropped in training (_create_proposals_from_boxes), then matched at IOUS[k] and labelled (_match_and_label_boxes)."""
+        ious = self.cfg.MODEL.ROI_BOX_CASCADE_HEAD.IOUS
+        K = self.num_classes
+        out = []
+        for b, size in zip(prev_boxes, image_sizes):
+            bx = ops.clip_boxes(b.detach(), size)
+            if self.training:
+                bx = bx[ops.nonempty(bx)]
+            out.append({"proposal_boxes": bx, "image_size": size})
+        if self.training:
+            for p, inst in zip(out, gt_instances):
+                gtb = inst.gt_boxes.tensor
+                midx, lab = self._match(p["proposal_boxes"], gtb, ious[k])
+                if len(gtb) > 0:
+                    cls = inst.gt_classes[midx]
+                    cls[lab == 0] = K
+                    p["gt_classes"], p["gt_boxes"] = cls, gtb[midx]
+                else:
+                    p["gt_classes"] = torch.zeros_like(midx) + K
+                    p["gt_boxes"] = torch.zeros((len(p["proposal_boxes"]), 4))
+        return out
+
     def forward_box(self, feats, proposals, gt_instances):
         m = self.cfg.MODEL
         feat_list = [feats[f] for f in m.ROI_HEADS.IN_FEATURES]
@@ -338,24 +377,7 @@ class OracleModel:
         prev = None
         for k in range(3):
             if k > 0:
-                new = []
-                for b, p0 in zip(prev, proposals):
-                    bx = ops.clip_boxes(b.detach(), p0["image_size"])
-                    if self.training:
-                        bx = bx[ops.nonempty(bx)]
-                    new.append({"proposal_boxes": bx, "image_size": p0["image_size"]})
-                proposals = new
-                if self.training:
-                    for p, inst in zip(proposals, gt_instances):
-                        gtb = inst.gt_boxes.tensor
-                        midx, lab = self._match(p["proposal_boxes"], gtb, ious[k])
-                        if len(gtb) > 0:
-                            cls = inst.gt_classes[midx]
-                            cls[lab == 0] = K
-                            p["gt_classes"], p["gt_boxes"] = cls, gtb[midx]
-                        else:
-                            p["gt_classes"] = torch.zeros_like(midx) + K
-                            p["gt_boxes"] = torch.zeros((len(p["proposal_boxes"]), 4))
+                proposals = self.cascade_next_stage(prev, [p["image_size"] for p in proposals], gt_instances, k)
             scores, deltas = self.run_stage(feat_list, proposals, k)
             boxes = torch.cat([p["proposal_boxes"] for p in proposals])
             pred = ops.apply_deltas(deltas, boxes, weights[k])

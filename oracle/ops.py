@@ -135,6 +135,22 @@ def subsample_labels(labels, num_samples, positive_fraction, bg_label, perm_fn=N
     return positive[perm1], negative[perm2]
 
 
+def subsample_labels_keyed(labels, num_samples, positive_fraction, bg_label, keys):
+    """detectron2/modeling/sampling.py:9-54 with the two ``torch.randperm`` draws replaced by the permutations a vector of
+    per-candidate keys induces: ``randperm(P) := argsort(keys[positive])`` and ``randperm(N) := argsort(keys[negative])``
+    (stable, so equal keys keep index order).  Everything else is subsample_labels above, line for line."""
+    positive = torch.nonzero((labels != -1) & (labels != bg_label), as_tuple=True)[0]
+    negative = torch.nonzero(labels == bg_label, as_tuple=True)[0]
+    queue = [torch.argsort(keys[positive], stable=True), torch.argsort(keys[negative], stable=True)]
+    sizes = [positive.numel(), negative.numel()]
+
+    def perm_fn(n):
+        assert n == sizes.pop(0)
+        return queue.pop(0)
+
+    return subsample_labels(labels, num_samples, positive_fraction, bg_label, perm_fn)
+
+
 def generate_cell_anchors(sizes, aspect_ratios):
     """detectron2/modeling/anchor_generator.py:181-216."""
     anchors = []

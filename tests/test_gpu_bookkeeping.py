@@ -1,0 +1,308 @@
+"""GPU parity of the ROI index bookkeeping on the branch the training step actually runs (-m gpu).
+
+bench.py / tools/train_net.py never install a permutation source, so every step goes through the batched code:
+RPN._subsample_batched (modeling/rpn.py), ROIHeads._label_and_sample_padded and CascadeROIHeads._next_stage_stacked
+(modeling/roi_heads.py) and the native selection kernel u2_topk_rows.  These tests inject the random KEYS that branch
+draws (modeling/sampling.py:set_key_source), hand the CPU oracle the permutations those keys induce
+(oracle/ops.py:subsample_labels_keyed = the reference's sampling.py:38-54 with randperm := argsort(keys[subset]); pinned to
+the reference-generated golden in tests/test_oracle_golden.py::test_levels_and_sampling) and demand BIT-EXACT agreement of
+every index list, label, matched gt and sampled order with the oracle's restatement of
+  detectron2/modeling/proposal_generator/rpn.py:307-363, proposal_utils.py:22-135,
+  roi_heads/roi_heads.py:220-302, roi_heads/cascade_rcnn.py:226-299, modeling/sampling.py:38-54.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "configs", "COCO-PanopticSegmentation", "u2seg_R50_800.yaml")
+DEV = "cuda:0"
+
+
+class KeyRecorder:
+    """Key source for modeling.sampling: tie-free keys (a scaled random permutation per row) drawn from a seeded CPU
+    generator; keeps every tensor it handed out so that the oracle can be given the same keys."""
+
+    def __init__(self, seed):
+        self.g = torch.Generator().manual_seed(seed)
+        self.calls = []
+
+    def __call__(self, shape, device):
+        rows, n = shape
+        k = torch.stack([(torch.randperm(n, generator=self.g).float() + 0.5) / n for _ in range(rows)])
+        self.calls.append(k)
+        return k.to(device)
+
+
+@pytest.fixture(scope="module")
+def F():
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from u2seg_amd import _hip
+    from u2seg_amd.layers import functional
+
+    _hip.load()
+    return functional
+
+
+@pytest.fixture(scope="module")
+def model_and_oracle():
+    from oracle.model import OracleModel
+    from u2seg_amd.config import get_cfg
+    from u2seg_amd.modeling import build_model
+
+    torch.manual_seed(7)
+    cfg = get_cfg()
+    cfg.merge_from_file(CFG)
+    cfg.merge_from_list(["MODEL.DEVICE", DEV])
+    model = build_model(cfg)
+    model.train()
+    om = OracleModel(cfg, {k: v.cpu() for k, v in model.state_dict().items()})
+    return cfg, model, om
+
+
+def _stable_rank(vals, k, largest, mask=None):
+    """CPU statement of the total order: (value descending / ascending, index ascending) among the participating elements."""
+    idx_all, val_all, cnt = [], [], []
+    for r in range(vals.shape[0]):
+        v = vals[r].float()
+        part = torch.arange(v.numel()) if mask is None else torch.nonzero(mask[r], as_tuple=True)[0]
+        order = torch.sort(v[part], descending=largest, stable=True)[1][:k]
+        sel = part[order]
+        c = sel.numel()
+        pad = k - c
+        idx_all.append(torch.cat([sel, torch.zeros(pad, dtype=torch.int64)]))
+        fill = -float("inf") if largest else float("inf")
+        val_all.append(torch.cat([v[sel], torch.full((pad,), fill)]))
+        cnt.append(c)
+    return torch.stack(val_all), torch.stack(idx_all), torch.tensor(cnt)
+
+
+def test_topk_rows_total_order(F):
+    """u2_topk_rows vs a stable CPU sort: values, index lists and counts bit-exact - on heavily tied bf16 logits read through
+    the (group, pitch) view of a 32-wide NHWC map at the full p2 size, on fp32 keys with a label mask at the full anchor
+    count, as a full masked sort (k = n), and on the degenerate rows (fewer participants than k, none at all)."""
+    g = torch.Generator().manual_seed(3)
+    # (1) RPN per-level top-k: [B, H*W, 32] bf16 map, A = 3 valid columns, many ties (logits quantised to 1/8)
+    b, hw, a = 3, 200 * 336, 3
+    m = (torch.randn((b, hw, 32), generator=g) * 2).mul(8).round().div(8).bfloat16()
+    m[1, :1000, :3] = 0.0
+    m[1, 5, 1] = -0.0  # -0.0 ranks equal to +0.0
+    logits = m[..., :a].reshape(b, hw * a)
+    for k in (2000, 1000, 7):
+        v, i, c = F.topk_rows(m.to(DEV), k, largest=True, group=a, pitch=32, n=hw * a)
+        rv, ri, rc = _stable_rank(logits, k, True)
+        assert torch.equal(i.cpu().long(), ri) and torch.equal(c.cpu().long(), rc)
+        assert torch.equal(v.cpu(), rv)
+    # (2) anchor subsampling: the 256 / 128 smallest fp32 keys among the anchors with a given label, n = 268 569
+    n = 268569
+    keys = torch.rand((2, n), generator=g)
+    keys[0, 1000:1100] = keys[0, 999]  # a run of ties
+    labels = torch.randint(-1, 2, (2, n), generator=g).to(torch.int8)  # {-1, 0, 1}
+    labels[1, :] = 0
+    labels[1, :50] = 1  # fewer positives than k
+    for val, k in ((1, 128), (0, 256)):
+        v, i, c = F.topk_rows(keys.to(DEV), k, largest=False, mask=labels.to(DEV), mask_value=val)
+        rv, ri, rc = _stable_rank(keys, k, False, labels == val)
+        assert torch.equal(c.cpu().long(), rc) and torch.equal(i.cpu().long(), ri) and torch.equal(v.cpu(), rv)
+    # (3) the score sort in front of NMS: k = n = 8819 with a keep mask, ties included
+    n = 8819
+    s = (torch.randn((4, n), generator=g) * 3).bfloat16().float()
+    keep = torch.rand((4, n), generator=g) > 0.1
+    keep[3] = False  # nothing kept
+    v, i, c = F.topk_rows(s.to(DEV), n, largest=True, mask=keep.to(torch.int8).to(DEV), mask_value=1)
+    rv, ri, rc = _stable_rank(s, n, True, keep)
+    assert torch.equal(c.cpu().long(), rc) and torch.equal(i.cpu().long(), ri) and torch.equal(v.cpu(), rv)
+    # (4) tiny rows, k larger than the row
+    t = torch.tensor([[1.0, -2.0, 1.0, float("inf"), 0.5]])
+    v, i, c = F.topk_rows(t.to(DEV), 5, largest=True)
+    assert i.cpu().tolist() == [[3, 0, 2, 4, 1]] and int(c) == 5
+
+
+def _gt(batch):
+    return [x["instances"] for x in batch]
+
+
+def test_rpn_anchor_sampler_production_branch(F, model_and_oracle):
+    """RPN.label_and_sample_anchors without a permutation source (= _subsample_batched, the branch bench.py runs) vs the
+    oracle's rpn.py:307-363 + sampling.py:38-54 with the permutations induced by the same keys: the [B, 268k-style] label
+    tensor and the matched gt boxes must be identical."""
+    from u2seg_amd.data import make_synthetic_batch
+    from u2seg_amd.modeling import sampling
+    from u2seg_amd.modeling.batched import PaddedTargets
+
+    cfg, model, om = model_and_oracle
+    rpn = model.proposal_generator
+    assert sampling.permutation_source() is None
+    h, w = 320, 448
+    batch_cpu = make_synthetic_batch(3, height=h, width=w, start_index=40)
+    batch = make_synthetic_batch(3, height=h, width=w, start_index=40, device=DEV)
+    grid = [((h + s - 1) // s, (w + s - 1) // s) for s in (4, 8, 16, 32, 64)]
+    anchors = rpn.anchor_generator.grid_anchors(grid)
+    anchors_cat = torch.cat(anchors, dim=0)
+    pt = PaddedTargets.of(_gt(batch), DEV)
+    rec = KeyRecorder(11)
+    sampling.set_key_source(rec)
+    try:
+        labels, match = rpn.label_and_sample_anchors(anchors_cat, pt.boxes, pt.counts)
+    finally:
+        sampling.set_key_source(None)
+    assert len(rec.calls) == 1 and rec.calls[0].shape == labels.shape
+    om.key_fn = lambda stage, i, n: rec.calls[0][i, :n]
+    try:
+        ref_labels, ref_matched = om.rpn_label_and_sample(anchors_cat.cpu(), _gt(batch_cpu))
+    finally:
+        om.key_fn = None
+    labels, match = labels.cpu(), match.cpu().long()
+    for i in range(3):
+        assert torch.equal(labels[i].long(), ref_labels[i].long()), "sampled anchor labels differ in image %d" % i
+        assert int((labels[i] == 1).sum()) <= 128 and int((labels[i] >= 0).sum()) == 256
+        gtb = batch_cpu[i]["instances"].gt_boxes.tensor
+        assert torch.equal(gtb[match[i]], ref_matched[i]), "matched gt boxes differ in image %d" % i
+
+
+def _random_proposals(batch_cpu, counts, pmax, seed):
+    """Ragged proposal sets around the gt boxes (so that a useful share is foreground), zero padded to pmax rows."""
+    g = torch.Generator().manual_seed(seed)
+    b = len(batch_cpu)
+    boxes = torch.zeros((b, pmax, 4))
+    logits = torch.zeros((b, pmax))
+    for i, (x, c) in enumerate(zip(batch_cpu, counts)):
+        h, w = x["height"], x["width"]
+        gtb = x["instances"].gt_boxes.tensor
+        if len(gtb):
+            base = gtb[torch.randint(0, len(gtb), (c,), generator=g)]
+            jit = (torch.rand((c, 4), generator=g) - 0.5) * torch.tensor([w, h, w, h]) * 0.25
+            bx = base + jit * (torch.rand((c, 1), generator=g) < 0.7)
+        else:
+            bx = torch.rand((c, 4), generator=g) * torch.tensor([w, h, w, h])
+        x0 = torch.minimum(bx[:, 0], bx[:, 2]).clamp(0, w - 2)
+        y0 = torch.minimum(bx[:, 1], bx[:, 3]).clamp(0, h - 2)
+        x1 = torch.maximum(bx[:, 0], bx[:, 2]).clamp(0, w)
+        y1 = torch.maximum(bx[:, 1], bx[:, 3]).clamp(0, h)
+        boxes[i, :c] = torch.stack([x0, y0, torch.maximum(x1, x0 + 1), torch.maximum(y1, y0 + 1)], dim=1)
+        logits[i, :c] = torch.sort(torch.randn(c, generator=g), descending=True)[0]
+    return boxes, logits
+
+
+def test_roi_label_and_sample_production_branch(F, model_and_oracle):
+    """ROIHeads.label_and_sample_proposals without a permutation source (= _label_and_sample_padded) on ragged proposal
+    sets vs the oracle's roi_heads.py:220-302 (+ add_ground_truth_to_proposals) with the key-induced permutations: the
+    sampled boxes IN ORDER, objectness logits, gt_classes, gt_boxes and gt mask rows of every image must be identical."""
+    from u2seg_amd.data import make_synthetic_batch
+    from u2seg_amd.modeling import sampling
+    from u2seg_amd.modeling.batched import LazyProposals, device_constant
+
+    cfg, model, om = model_and_oracle
+    heads = model.roi_heads
+    h, w = 320, 448
+    batch_cpu = make_synthetic_batch(3, height=h, width=w, start_index=60)
+    batch = make_synthetic_batch(3, height=h, width=w, start_index=60, device=DEV)
+    counts = [1000, 731, 64]  # the last image has fewer candidates than the 512 samples
+    pmax = 1000
+    boxes, logits = _random_proposals(batch_cpu, counts, pmax, seed=5)
+    lp = LazyProposals([(h, w)] * 3, boxes.to(DEV), logits.to(DEV), device_constant(counts, torch.int32, DEV), None, True)
+    rec = KeyRecorder(13)
+    sampling.set_key_source(rec)
+    try:
+        out = heads.label_and_sample_proposals(lp, _gt(batch))
+    finally:
+        sampling.set_key_source(None)
+    assert len(rec.calls) == 1
+    keys = rec.calls[0]
+    ngt = [len(x["instances"]) for x in batch_cpu]
+
+    def key_fn(stage, i, n):
+        assert stage == "roi" and n == counts[i] + ngt[i]
+        return torch.cat([keys[i, : counts[i]], keys[i, pmax : pmax + ngt[i]]])
+
+    om.key_fn = key_fn
+    try:
+        props = [{"proposal_boxes": boxes[i, : counts[i]], "objectness_logits": logits[i, : counts[i]], "image_size": (h, w)}
+                 for i in range(3)]
+        ref = om.label_and_sample_proposals(props, _gt(batch_cpu))
+    finally:
+        om.key_fn = None
+    for i in range(3):
+        got, exp = out[i], ref[i]
+        assert torch.equal(got.proposal_boxes.tensor.cpu(), exp["proposal_boxes"]), "sampled boxes / order differ, image %d" % i
+        assert torch.equal(got.objectness_logits.cpu(), exp["objectness_logits"])
+        assert torch.equal(got.gt_classes.cpu(), exp["gt_classes"])
+        assert torch.equal(got.gt_boxes.tensor.cpu(), exp["gt_boxes"])
+        assert torch.equal(got.gt_masks.tensor.cpu(), exp["gt_masks"])
+        nfg = int((exp["gt_classes"] < 800).sum())
+        assert nfg <= 128 and len(exp["gt_classes"]) <= 512 and nfg > 0
+    assert len(out[2]) == counts[2] + ngt[2]  # every candidate of the short image is taken
+
+
+def test_cascade_next_stage_stacked(F, model_and_oracle):
+    """CascadeROIHeads._next_stage_stacked (stages 2 and 3 of every training step) vs the oracle's cascade_rcnn.py:226-299:
+    clipped boxes, labels at IoU 0.6 / 0.7 and matched gt boxes identical; a batch containing a box that clips to empty takes
+    the ragged path and must still agree."""
+    from u2seg_amd.data import make_synthetic_batch
+
+    cfg, model, om = model_and_oracle
+    heads = model.roi_heads
+    h, w = 320, 448
+    batch_cpu = make_synthetic_batch(2, height=h, width=w, start_index=80)
+    batch = make_synthetic_batch(2, height=h, width=w, start_index=80, device=DEV)
+    boxes, _ = _random_proposals(batch_cpu, [512, 512], 512, seed=9)
+    boxes = boxes + torch.randn(boxes.shape, generator=torch.Generator().manual_seed(2)) * 6  # some leave the image
+    boxes[..., 2:] = torch.maximum(boxes[..., 2:], boxes[..., :2] + 0.5)
+    om.training = True
+    for stage in (1, 2):
+        for with_empty in (False, True):
+            bx = boxes.clone()
+            if with_empty:
+                bx[1, 17] = torch.tensor([w + 5.0, 10.0, w + 30.0, 50.0])  # clips to zero width
+            out = heads._next_stage_stacked(bx.to(DEV), [(h, w)] * 2, stage, _gt(batch))
+            ref = om.cascade_next_stage([bx[0], bx[1]], [(h, w)] * 2, _gt(batch_cpu), stage)
+            for i in range(2):
+                assert torch.equal(out[i].proposal_boxes.tensor.cpu(), ref[i]["proposal_boxes"]), (stage, with_empty, i)
+                assert torch.equal(out[i].gt_classes.cpu(), ref[i]["gt_classes"]), (stage, with_empty, i)
+                assert torch.equal(out[i].gt_boxes.tensor.cpu(), ref[i]["gt_boxes"]), (stage, with_empty, i)
+            assert len(out[1]) == (511 if with_empty else 512)
+
+
+def test_rpn_proposals_on_identical_maps(F, model_and_oracle):
+    """RPN.predict_proposals end to end (per-level top-k -> decode -> clip -> drop empty -> score sort -> per-level NMS ->
+    post-NMS top-k; rpn.py:482-533 + proposal_utils.py:22-135) vs the oracle on THE SAME objectness / delta maps, with the
+    logits quantised so that ties are everywhere: the proposal count, the order, the logits (exact) and the boxes (1e-4 px:
+    fp32 exp / fma differences of the decode) of every image must agree."""
+    cfg, model, om = model_and_oracle
+    rpn = model.proposal_generator
+    b, h, w = 2, 256, 320
+    g = torch.Generator().manual_seed(21)
+    grid = [((h + s - 1) // s, (w + s - 1) // s) for s in (4, 8, 16, 32, 64)]
+    anchors = rpn.anchor_generator.grid_anchors(grid)
+    objs, dlts, objs_cpu, dlts_cpu = [], [], [], []
+    for gh, gw in grid:
+        o = torch.zeros((b, gh, gw, 32))
+        o[..., :3] = (torch.randn((b, gh, gw, 3), generator=g) * 2).mul(4).round().div(4)
+        d = torch.zeros((b, gh, gw, 32))
+        d[..., :12] = torch.randn((b, gh, gw, 12), generator=g) * 0.3
+        o, d = o.bfloat16(), d.bfloat16()
+        objs.append(o.to(DEV))
+        dlts.append(d.to(DEV))
+        objs_cpu.append(o[..., :3].float().reshape(b, -1))
+        dlts_cpu.append(d[..., :12].float().reshape(b, -1, 4))
+    sizes = [(h, w), (h - 13, w - 27)]
+    for training in (True, False):
+        rpn.training = training
+        om.training = training
+        try:
+            lp = rpn.predict_proposals(anchors, objs, dlts, sizes)
+        finally:
+            rpn.training = True
+        ref = om.rpn_proposals([x.cpu() for x in anchors], objs_cpu, dlts_cpu, sizes)
+        om.training = True
+        counts = lp.counts.cpu().tolist()
+        for i in range(b):
+            exp = ref[i]
+            assert counts[i] == len(exp["proposal_boxes"]), (training, i, counts[i], len(exp["proposal_boxes"]))
+            got_l = lp.logits[i, : counts[i]].cpu()
+            assert torch.equal(got_l, exp["objectness_logits"]), (training, i)
+            np.testing.assert_allclose(lp.boxes[i, : counts[i]].cpu().numpy(), exp["proposal_boxes"].numpy(), atol=1e-4, rtol=0)

@@ -99,6 +99,18 @@ def test_levels_and_sampling(G):
     torch.manual_seed(11)
     pos, neg = ops.subsample_labels(T(G["sub_labels"]), 64, 0.25, 2)
     assert np.array_equal(pos.numpy(), G["sub_pos"]) and np.array_equal(neg.numpy(), G["sub_neg"])
+    # the keyed form (what the batched GPU samplers are checked against): keys that induce the reference's own two
+    # permutations reproduce the reference-generated golden picks, order included
+    labels = T(G["sub_labels"])
+    positive = torch.nonzero((labels != -1) & (labels != 2), as_tuple=True)[0]
+    negative = torch.nonzero(labels == 2, as_tuple=True)[0]
+    torch.manual_seed(11)
+    perm1, perm2 = torch.randperm(positive.numel()), torch.randperm(negative.numel())
+    keys = torch.zeros(labels.numel())
+    keys[positive[perm1]] = torch.arange(positive.numel(), dtype=torch.float32) / labels.numel()
+    keys[negative[perm2]] = torch.arange(negative.numel(), dtype=torch.float32) / labels.numel()
+    kpos, kneg = ops.subsample_labels_keyed(labels, 64, 0.25, 2, keys)
+    assert np.array_equal(kpos.numpy(), G["sub_pos"]) and np.array_equal(kneg.numpy(), G["sub_neg"])
 
 
 def test_nms(G):

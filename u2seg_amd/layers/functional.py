@@ -809,6 +809,29 @@ def iou_match(boxes, gt, ngt, lo, hi, allow_low_quality):
     return match, labels, mval
 
 
+def topk_rows(vals, k, largest=True, mask=None, mask_value=1, group=1, pitch=1, n=None, want_vals=True):
+    """Row-wise selection with a total order (u2_topk_rows): the k best of every row ranked by (value descending if
+    `largest` else ascending, index ascending).  vals: [rows, n] fp32 / bf16 contiguous, or - with group / pitch / n - the
+    `group` valid columns of a [rows, n // group, pitch]-shaped map (element i at (i // group) * pitch + i % group).
+    mask (int8 [rows, n]): only elements equal to mask_value take part.
+    Returns (values fp32 [rows, k] or None, indices int32 [rows, k], counts int32 [rows])."""
+    assert vals.is_cuda and vals.dtype in (torch.float32, BF16) and vals.is_contiguous()
+    rows = vals.shape[0]
+    if n is None:
+        assert vals.dim() == 2
+        n = vals.shape[1]
+    row_stride = vals[0].numel()
+    dev = vals.device
+    idx = torch.empty((rows, k), dtype=torch.int32, device=dev)
+    out = torch.empty((rows, k), dtype=torch.float32, device=dev) if want_vals else None
+    cnt = torch.empty((rows,), dtype=torch.int32, device=dev)
+    if mask is not None:
+        assert mask.dtype == torch.int8 and mask.is_contiguous() and tuple(mask.shape) == (rows, n)
+    _hip.call("u2_topk_rows", vals, 1 if vals.dtype == BF16 else 0, rows, n, row_stride, group, pitch, mask, int(mask_value),
+              k, int(largest), out, idx, cnt)
+    return out, idx, cnt
+
+
 def apply_deltas(src, deltas, weights, img_idx=None, sizes=None, clamp=math.log(1000.0 / 16)):
     n = src.shape[0]
     out = torch.empty((n, 4), dtype=torch.float32, device=src.device)

@@ -5,5 +5,5 @@ from .roi_heads import (ROI_BOX_HEAD_REGISTRY, ROI_HEADS_REGISTRY, ROI_MASK_HEAD
                         build_box_head, build_mask_head, build_roi_heads)
 from .rpn import (ANCHOR_GENERATOR_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, RPN, RPN_HEAD_REGISTRY, DefaultAnchorGenerator,
                   StandardRPNHead, build_anchor_generator, build_proposal_generator)
-from .sampling import set_permutation_source, subsample_labels
+from .sampling import set_key_source, set_permutation_source, subsample_labels
 from .semantic_seg import SEM_SEG_HEADS_REGISTRY, SemSegFPNHead, build_sem_seg_head

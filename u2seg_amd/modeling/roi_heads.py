@@ -400,17 +400,20 @@ class ROIHeads(nn.Module):
         # sampling.py:38-54 as random keys + top-k: <= 128 random foreground rows, background fills up to 512
         total = self.batch_size_per_image
         max_fg = int(total * self.positive_fraction)
-        key = torch.rand((nb, n), device=dev)
-        big = torch.full_like(key, 2.0)
+        from . import sampling
+
+        key = sampling.random_keys((nb, n), dev)
         is_bg = gt_classes == self.num_classes
         is_fg = (gt_classes >= 0) & ~is_bg
+        kind = (is_fg.to(torch.int8) + is_bg.to(torch.int8) * 2).contiguous()  # 1 foreground, 2 background, 0 not sampled
         kf, kb = min(max_fg, n), min(total, n)
-        fg_key, fg_idx = torch.where(is_fg, key, big).topk(kf, dim=1, largest=False)
-        bg_key, bg_idx = torch.where(is_bg, key, big).topk(kb, dim=1, largest=False)
-        fg_valid = fg_key < 1.5
-        num_bg = total - fg_valid.sum(dim=1, keepdim=True)
-        bg_valid = (bg_key < 1.5) & (torch.arange(kb, device=dev)[None] < num_bg)
-        cand, cvalid = torch.cat([fg_idx, bg_idx], dim=1), torch.cat([fg_valid, bg_valid], dim=1)
+        # the smallest keys first, ties by row index: positive[argsort(key[positive])] of sampling.py:38-54
+        _, fg_idx, fg_cnt = F.topk_rows(key, kf, largest=False, mask=kind, mask_value=1, want_vals=False)
+        _, bg_idx, bg_cnt = F.topk_rows(key, kb, largest=False, mask=kind, mask_value=2, want_vals=False)
+        num_bg = torch.minimum(bg_cnt, total - fg_cnt)
+        fg_valid = torch.arange(kf, device=dev)[None] < fg_cnt[:, None]
+        bg_valid = torch.arange(kb, device=dev)[None] < num_bg[:, None]
+        cand, cvalid = torch.cat([fg_idx, bg_idx], dim=1).long(), torch.cat([fg_valid, bg_valid], dim=1)
         order = torch.argsort((~cvalid).to(torch.int8), dim=1, stable=True)[:, :total]
         sampled = torch.gather(cand, 1, order)  # [B, S]; rows >= count are padding
         s = sampled.shape[1]

@@ -4,7 +4,7 @@ proposal_generator/proposal_utils.py:22-205).
 
 Device work goes through the HIP kernels: shared 3x3 conv + 1x1 heads (conv_igemm), anchor<->gt IoU matching
 (u2_iou_match), the fused per-level loss (u2_rpn_loss_level), box decoding (u2_apply_deltas) and per-level NMS
-(u2_batched_nms).  torch is used for top-k / sort / index plumbing."""
+(u2_batched_nms), per-level top-k, score sort and anchor subsampling (u2_topk_rows).  torch is left with gathers / concatenation."""
 import math
 
 import torch
@@ -217,21 +217,25 @@ class RPN(nn.Module):
         return out, match
 
     def _subsample_batched(self, labels):
-        """Same distribution as sampling.py:38-54 (a uniformly random subset of <= 128 positives, the rest of the 256
-        filled with uniformly random negatives) for the whole batch without host synchronisation: random keys + top-k."""
+        """sampling.py:38-54 for the whole batch without host synchronisation: one random key per anchor, the <= 128
+        positives with the smallest keys are kept, the rest of the 256 is filled with the negatives with the smallest keys
+        (= the reference's positive[randperm(P)[:num_pos]] with randperm := argsort of the keys).  Two u2_topk_rows
+        launches; the counts stay on the device."""
+        from . import sampling
+
         b, a = labels.shape
         n = self.batch_size_per_image
         max_pos = int(n * self.positive_fraction)
-        key = torch.rand((b, a), device=labels.device)
-        big = torch.full_like(key, 2.0)
-        pos_key, pos_idx = torch.where(labels == 1, key, big).topk(max_pos, dim=1, largest=False)
-        neg_key, neg_idx = torch.where(labels == 0, key, big).topk(n, dim=1, largest=False)
-        pos_valid = pos_key < 1.5
-        num_neg = n - pos_valid.sum(dim=1, keepdim=True)
-        neg_valid = (neg_key < 1.5) & (torch.arange(n, device=labels.device)[None] < num_neg)
+        key = sampling.random_keys((b, a), labels.device)
+        _, pos_idx, pos_cnt = F.topk_rows(key, min(max_pos, a), largest=False, mask=labels, mask_value=1, want_vals=False)
+        _, neg_idx, neg_cnt = F.topk_rows(key, min(n, a), largest=False, mask=labels, mask_value=0, want_vals=False)
+        num_neg = torch.minimum(neg_cnt, n - pos_cnt)
+        pos_valid = torch.arange(pos_idx.shape[1], device=labels.device)[None] < pos_cnt[:, None]
+        neg_valid = torch.arange(neg_idx.shape[1], device=labels.device)[None] < num_neg[:, None]
         out = torch.full_like(labels, -1)
-        out.scatter_(1, neg_idx, torch.where(neg_valid, 0, -1).to(out.dtype))
-        out.scatter_(1, pos_idx, torch.where(pos_valid, 1, -1).to(out.dtype))
+        # padding entries point at index 0 and carry -1; real entries are written afterwards (an index is never both)
+        out.scatter_(1, neg_idx.long(), torch.where(neg_valid, 0, -1).to(out.dtype))
+        out.scatter_(1, pos_idx.long(), torch.where(pos_valid, 1, -1).to(out.dtype))
         return out
 
     def losses(self, anchors_per_level, objs, dlts, labels, match, gt_boxes_pad):
@@ -254,29 +258,32 @@ class RPN(nn.Module):
         scores_l, boxes_l, lvl_l = [], [], []
         for lvl, (anc, o, d) in enumerate(zip(anchors_per_level, objs, dlts)):
             hwa = o.shape[1] * o.shape[2] * a
-            logits = o[..., :a].reshape(b, hwa)
             k = min(hwa, pre)
-            top_scores, top_idx = logits.topk(k, dim=1)
+            # the k best logits of every image, ranked (logit descending, anchor index ascending), read straight from the A
+            # valid columns of the 32-wide NHWC map
+            top_scores, top_idx, _ = F.topk_rows(o.contiguous(), k, largest=True, group=a, pitch=o.shape[-1], n=hwa)
+            top_idx = top_idx.long()
             deltas = d[..., : 4 * a].reshape(b, hwa, 4)
             sel = torch.gather(deltas, 1, top_idx[..., None].expand(b, k, 4)).float().reshape(b * k, 4)
             src = anc[top_idx.reshape(-1)]
             img = torch.arange(b, device=dev, dtype=torch.int32).repeat_interleave(k)
             boxes = F.apply_deltas(src, sel, self.bbox_reg_weights, img, sizes, _SCALE_CLAMP)
-            scores_l.append(top_scores.float())
+            scores_l.append(top_scores)
             boxes_l.append(boxes.view(b, k, 4))
             lvl_l.append(torch.full((k,), lvl, dtype=torch.int32, device=dev))
-        scores = torch.cat(scores_l, dim=1)
+        scores = torch.cat(scores_l, dim=1).contiguous()
         boxes = torch.cat(boxes_l, dim=1)
         lvls = torch.cat(lvl_l)[None].expand(b, -1)
         finite = torch.isfinite(boxes).all(dim=2) & torch.isfinite(scores)
         all_finite = finite.all()  # raised as FloatingPointError when the counts are first read on the host
         keep = finite & ((boxes[..., 2] - boxes[..., 0]) > self.min_box_size) & ((boxes[..., 3] - boxes[..., 1]) > self.min_box_size)
-        order_key = torch.where(keep, scores, torch.full_like(scores, -float("inf")))
-        order = torch.sort(order_key, dim=1, descending=True, stable=True)[1]
+        # stable descending sort of the kept candidates by score (layers/nms.py:9-20 hands batched_nms score order)
+        _, order, counts = F.topk_rows(scores, scores.shape[1], largest=True, mask=keep.to(torch.int8).contiguous(),
+                                       mask_value=1, want_vals=False)
+        order = order.long()
         s_boxes = torch.gather(boxes, 1, order[..., None].expand(-1, -1, 4)).contiguous()
         s_scores = torch.gather(scores, 1, order)
         s_lvls = torch.gather(lvls, 1, order).contiguous()
-        counts = keep.sum(dim=1).to(torch.int32)
         kept, nkeep = F.batched_nms(s_boxes, s_lvls, counts, self.nms_thresh, post)
         idx = kept.long()  # rows >= nkeep[i] are zero: padding that points at a valid row
         p_boxes = torch.gather(s_boxes, 1, idx[..., None].expand(-1, -1, 4))

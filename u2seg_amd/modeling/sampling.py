@@ -5,6 +5,26 @@ tests install a deterministic ``perm_fn`` (shared with the CPU oracle) through `
 import torch
 
 _perm_fn = None
+_key_fn = None
+
+
+def set_key_source(fn):
+    """fn(shape, device) -> float32 tensor of sampling keys in [0, 1); None restores torch.rand on the device.
+
+    The batched samplers (RPN._subsample_batched, ROIHeads._label_and_sample_padded - the branch every training step
+    runs) draw ONE key per candidate and keep the candidates with the smallest keys.  That is the reference's
+    ``positive[randperm(P)[:num_pos]]`` (sampling.py:38-54) with the permutation ``argsort(key[positive])``; parity tests
+    inject the keys here and hand the oracle that permutation, so the two can be compared bit for bit."""
+    global _key_fn
+    _key_fn = fn
+
+
+def random_keys(shape, device):
+    if _key_fn is not None:
+        k = _key_fn(tuple(shape), device)
+        assert tuple(k.shape) == tuple(shape) and k.dtype == torch.float32
+        return k.to(device)
+    return torch.rand(shape, device=device)
 
 
 def set_permutation_source(fn):
