@@ -27,13 +27,16 @@ class KeyRecorder:
     """Key source for modeling.sampling: tie-free keys (a scaled random permutation per row) drawn from a seeded CPU
     generator; keeps every tensor it handed out so that the oracle can be given the same keys."""
 
-    def __init__(self, seed):
+    def __init__(self, seed, first_wins=False):
         self.g = torch.Generator().manual_seed(seed)
         self.calls = []
+        self.first_wins = first_wins
 
     def __call__(self, shape, device):
         rows, n = shape
         k = torch.stack([(torch.randperm(n, generator=self.g).float() + 0.5) / n for _ in range(rows)])
+        if self.first_wins:  # candidate 0 carries the smallest key of its row: it is sampled whenever it takes part
+            k[:, 0] = 0.0
         self.calls.append(k)
         return k.to(device)
 
@@ -144,7 +147,9 @@ def test_rpn_anchor_sampler_production_branch(F, model_and_oracle):
     anchors = rpn.anchor_generator.grid_anchors(grid)
     anchors_cat = torch.cat(anchors, dim=0)
     pt = PaddedTargets.of(_gt(batch), DEV)
-    rec = KeyRecorder(11)
+    # anchor 0 (a background anchor in the image corner) gets the smallest key: the padding entries of the selection
+    # lists point at index 0 too and must not disturb it
+    rec = KeyRecorder(11, first_wins=True)
     sampling.set_key_source(rec)
     try:
         labels, match = rpn.label_and_sample_anchors(anchors_cat, pt.boxes, pt.counts)
@@ -159,7 +164,7 @@ def test_rpn_anchor_sampler_production_branch(F, model_and_oracle):
     labels, match = labels.cpu(), match.cpu().long()
     for i in range(3):
         assert torch.equal(labels[i].long(), ref_labels[i].long()), "sampled anchor labels differ in image %d" % i
-        assert int((labels[i] == 1).sum()) <= 128 and int((labels[i] >= 0).sum()) == 256
+        assert int((labels[i] == 1).sum()) <= 128 and int((labels[i] >= 0).sum()) == 256 and int(labels[i][0]) == 0
         gtb = batch_cpu[i]["instances"].gt_boxes.tensor
         assert torch.equal(gtb[match[i]], ref_matched[i]), "matched gt boxes differ in image %d" % i
 
@@ -306,3 +311,129 @@ def test_rpn_proposals_on_identical_maps(F, model_and_oracle):
             got_l = lp.logits[i, : counts[i]].cpu()
             assert torch.equal(got_l, exp["objectness_logits"]), (training, i)
             np.testing.assert_allclose(lp.boxes[i, : counts[i]].cpu().numpy(), exp["proposal_boxes"].numpy(), atol=1e-4, rtol=0)
+
+
+def _nhwc(x_nchw):
+    b, c, h, w = x_nchw.shape
+    cp = (c + 31) // 32 * 32
+    out = torch.zeros((b, h, w, cp), dtype=torch.bfloat16, device=DEV)
+    out[..., :c] = x_nchw.permute(0, 2, 3, 1).to(DEV)
+    return out
+
+
+def test_heads_teacher_forced_losses(F):
+    """All ten training losses at the tolerance north_star names (1e-3 relative), with every discrete decision shared.
+
+    A random-weight train-mode-BN network amplifies bf16 rounding noise until near-tie proposals, matches and samples flip,
+    so a free-running end-to-end comparison can only use wide bands.  Here the HIP heads are teacher-forced instead: they
+    get the bf16 oracle's FPN maps and the oracle's RPN proposals, the samplers get injected keys (the production, batched
+    branch), and the oracle is handed the boxes the HIP cascade actually used at stages 2 and 3.  Every discrete quantity
+    (sampled anchors, sampled ROIs and their order, the labels of the three stages) must then be IDENTICAL, and every loss
+    must agree to 1e-3: loss_sem_seg, loss_rpn_cls, loss_rpn_loc, loss_cls / loss_box_reg of the three stages, loss_mask."""
+    from oracle.model import OracleModel
+    from tests.golden.make_fixtures import det_fill
+    from u2seg_amd.config import get_cfg
+    from u2seg_amd.data import make_synthetic_batch
+    from u2seg_amd.modeling import build_model, sampling
+    from u2seg_amd.structures import Boxes, Instances
+
+    cfg = get_cfg()
+    cfg.merge_from_file(CFG)
+    cfg.merge_from_list(["MODEL.DEVICE", DEV])
+    model = build_model(cfg)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            v.copy_(det_fill(k, v.cpu()).to(DEV))
+    model.train()
+    om = OracleModel(cfg, {k: v.cpu() for k, v in model.state_dict().items()}, emulate_bf16=True)
+    h, w = 192, 256
+    batch_cpu = make_synthetic_batch(2, height=h, width=w)
+    batch = make_synthetic_batch(2, height=h, width=w, device=DEV)
+    gt_cpu, gt_dev = [x["instances"] for x in batch_cpu], [x["instances"] for x in batch]
+
+    with torch.no_grad():
+        images, sizes, (mh, mw) = om.preprocess(batch_cpu)
+        rf = om.backbone(images)                       # the teacher: bf16-emulated FPN maps p2..p6 (NCHW fp32)
+        rfd = {k: _nhwc(v) for k, v in rf.items()}
+        report = {}
+
+        # ---- semantic head ----
+        tgt = torch.full((2, mh, mw), cfg.MODEL.SEM_SEG_HEAD.IGNORE_VALUE, dtype=torch.int64)
+        for i, x in enumerate(batch_cpu):
+            tgt[i, :h, :w] = x["sem_seg"]
+        ref_sem = om.sem_seg_loss(om.sem_seg_logits(rf), tgt)
+        _, sl = model.sem_seg_head(rfd, model._sem_seg_targets(batch, (mh, mw)))
+        report["loss_sem_seg"] = (float(sl["loss_sem_seg"]), float(ref_sem))
+
+        # ---- RPN: labels bit-exact, losses 1e-3 ----
+        rec = KeyRecorder(31)
+        sampling.set_key_source(rec)
+        try:
+            _, rl = model.proposal_generator(sizes, rfd, gt_dev)
+        finally:
+            sampling.set_key_source(None)
+        anchors = om.anchors(rf)
+        objs, dlts = om.rpn_head(rf)
+        om.key_fn = lambda stage, i, n: rec.calls[0][i, :n]
+        labels, matched = om.rpn_label_and_sample(torch.cat(anchors), gt_cpu)
+        om.key_fn = None
+        ref_rpn = om.rpn_losses(anchors, objs, dlts, labels, matched)
+        for k in ("loss_rpn_cls", "loss_rpn_loc"):
+            report[k] = (float(rl[k]), float(ref_rpn[k]))
+
+        # ---- ROI heads on the ORACLE's proposals ----
+        om.training = True
+        props = om.rpn_proposals(anchors, objs, dlts, sizes)
+        plist = []
+        for p in props:
+            inst = Instances(p["image_size"])
+            inst.proposal_boxes = Boxes(p["proposal_boxes"].to(DEV))
+            inst.objectness_logits = p["objectness_logits"].to(DEV)
+            plist.append(inst)
+        heads = model.roi_heads
+        seen = []  # (stage, proposals) as the HIP cascade hands them to its loss functions
+        for k, pred in enumerate(heads.box_predictor):
+            orig = pred.losses
+
+            def wrapped(predictions, proposals, _orig=orig, _k=k):
+                seen.append((_k, proposals))
+                return _orig(predictions, proposals)
+
+            pred.losses = wrapped
+        rec2 = KeyRecorder(37)
+        sampling.set_key_source(rec2)
+        try:
+            _, dl = heads(None, rfd, plist, gt_dev)
+        finally:
+            sampling.set_key_source(None)
+            for pred in heads.box_predictor:
+                del pred.losses
+        assert [s[0] for s in seen] == [0, 1, 2]
+        keys = rec2.calls[0]
+        npad = keys.shape[1] - max(len(g) for g in gt_cpu)
+        cnt = [len(p["proposal_boxes"]) for p in props]
+        om.key_fn = lambda stage, i, n: torch.cat([keys[i, : cnt[i]], keys[i, npad : npad + len(gt_cpu[i])]])
+        sampled = om.label_and_sample_proposals(props, gt_cpu)
+        om.key_fn = None
+        feat_list = [rf[f] for f in cfg.MODEL.ROI_HEADS.IN_FEATURES]
+        wts = cfg.MODEL.ROI_BOX_CASCADE_HEAD.BBOX_REG_WEIGHTS
+        stage_props = sampled
+        for k, (_, used) in enumerate(seen):
+            if k > 0:  # the oracle relabels the boxes the HIP stage k-1 actually produced (clipping is idempotent)
+                stage_props = om.cascade_next_stage([used[i].proposal_boxes.tensor.cpu() for i in range(2)], sizes, gt_cpu, k)
+            for i in range(2):
+                assert torch.equal(used[i].proposal_boxes.tensor.cpu(), stage_props[i]["proposal_boxes"]), (k, i)
+                assert torch.equal(used[i].gt_classes.cpu(), stage_props[i]["gt_classes"]), "stage %d labels differ" % k
+                assert torch.equal(used[i].gt_boxes.tensor.cpu(), stage_props[i]["gt_boxes"]), (k, i)
+            scores, deltas = om.run_stage(feat_list, stage_props, k)
+            lc, lb = om.box_losses(scores, deltas, stage_props, wts[k])
+            report["loss_cls_stage%d" % k] = (float(dl["loss_cls_stage%d" % k]), float(lc))
+            report["loss_box_reg_stage%d" % k] = (float(dl["loss_box_reg_stage%d" % k]),
+                                                  float(lb) * cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT)
+        report["loss_mask"] = (float(dl["loss_mask"]), float(om.mask_loss(rf, sampled)))
+    import json
+
+    print(json.dumps(report, indent=1))
+    assert len(report) == 10
+    for k, (got, exp) in report.items():
+        assert got == pytest.approx(exp, rel=1e-3), (k, report)

@@ -232,11 +232,12 @@ class RPN(nn.Module):
         num_neg = torch.minimum(neg_cnt, n - pos_cnt)
         pos_valid = torch.arange(pos_idx.shape[1], device=labels.device)[None] < pos_cnt[:, None]
         neg_valid = torch.arange(neg_idx.shape[1], device=labels.device)[None] < num_neg[:, None]
-        out = torch.full_like(labels, -1)
-        # padding entries point at index 0 and carry -1; real entries are written afterwards (an index is never both)
-        out.scatter_(1, neg_idx.long(), torch.where(neg_valid, 0, -1).to(out.dtype))
-        out.scatter_(1, pos_idx.long(), torch.where(pos_valid, 1, -1).to(out.dtype))
-        return out
+        # entries beyond the counts are padding (index 0): they are redirected to a scratch column so that they can never
+        # collide with a real pick of anchor 0 inside one scatter
+        out = labels.new_full((b, a + 1), -1)
+        out.scatter_(1, torch.where(neg_valid, neg_idx.long(), a), torch.zeros_like(neg_idx, dtype=out.dtype))
+        out.scatter_(1, torch.where(pos_valid, pos_idx.long(), a), torch.ones_like(pos_idx, dtype=out.dtype))
+        return out[:, :a].contiguous()
 
     def losses(self, anchors_per_level, objs, dlts, labels, match, gt_boxes_pad):
         b = labels.shape[0]
