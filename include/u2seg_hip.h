@@ -24,7 +24,9 @@ extern "C" {
  *   out[m][n] = sum_{kh,kw,c} in[src(m,kh,kw)][c] * wt[n][kh][kw][c]   (+bias)(+=old)(relu)
  *   src: sy = oy*mul - pad_h + kh; if div > 1 the tap contributes only when sy % div == 0 and then sy /= div.
  *   stats (optional, [2][N] fp32, pre-zeroed): column sum and sum of squares of the stored bf16 outputs.
- * variant bit0: 1 = register-staged operands instead of global_load_lds. */
+ * variant bit0: 1 = register-staged operands instead of global_load_lds; bit2 BK 32; bit3 256x128 tile; bits 4-5 LDS ring depth;
+ * bit8 / bit9 force / forbid conv_igemm256; bits 12-15: persistent tile configuration of conv_tile.hip (0 automatic,
+ * 1-7 see there, 15 never); bit16: 8 work-groups only (tests). */
 int u2_conv_igemm(const void* in, const void* wt, void* out, const float* bias, float* stats,
                   int B, int Hin, int Win, int C, int in_ld, int Hout, int Wout, int N, int out_ld,
                   int KH, int KW, int pad_h, int pad_w, int mul, int div, int relu, int accumulate,
@@ -44,6 +46,11 @@ int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int B, int Hin,
                        int Hout, int Wout, int N, int dy_ld, int KH, int KW, int pad_h, int pad_w,
                        int stride, int n_valid, int c_valid, long long dw_stride_n, int dw_stride_tap,
                        int dw_stride_c, int variant, void* stream);
+
+/* Test / debugging aid: a code for the kernel (family, tile configuration) the most recent u2_conv_igemm or u2_conv_wgrad
+ * call on this thread selected (encoding in csrc/conv_args.h).  With variant 0 the selection can be steered through the
+ * environment variables U2_CONV_VARIANT / U2_WGRAD_VARIANT (same bits as the variant argument). */
+int u2_conv_last_kernel(void);
 
 /* fp32 master weights [N][Cin][T] -> bf16 kernel layouts: mode 0 [N][T][Cp] (forward / wgrad), mode 1 [Cp][T][Npad] with the
  * taps reversed (data gradient), mode 2 [T][Cp][Npad] (data gradient of a fully connected conv). Zero padded. */

@@ -122,14 +122,17 @@ class OracleModel:
             for bi in range(nblocks):
                 n = "%sres%d.%d." % (pre, si, bi)
                 stride = 2 if (bi == 0 and si > 2) else 1
-                out = self.bn(self.conv(x, n + "conv1"), n + "conv1.norm", relu=True)
-                out = self.bn(self.conv(out, n + "conv2", stride, 1), n + "conv2.norm", relu=True)
-                out = self.conv(out, n + "conv3")
+                c1 = self.bn(self.conv(x, n + "conv1"), n + "conv1.norm", relu=True)
+                c2 = self.bn(self.conv(c1, n + "conv2", stride, 1), n + "conv2.norm", relu=True)
+                out = self.conv(c2, n + "conv3")
                 if (n + "shortcut.weight") in self.p:
                     sc = self.bn(self.conv(x, n + "shortcut", stride), n + "shortcut.norm")
                 else:
                     sc = x
                 x = self.bn(out, n + "conv3.norm", residual=sc, relu=True)
+                if capture is not None:  # the units inside the block, for per-layer teacher forcing
+                    capture["res%d.%d.conv1" % (si, bi)], capture["res%d.%d.conv2" % (si, bi)] = c1, c2
+                    capture["res%d.%d.shortcut" % (si, bi)] = sc
                 if capture is not None:
                     capture["res%d.%d" % (si, bi)] = x
             res["res%d" % si] = x
@@ -159,7 +162,7 @@ class OracleModel:
         return out, sizes, (mh, mw)
 
     # ---- semantic head ------------------------------------------------------------------------
-    def sem_seg_logits(self, feats):
+    def sem_seg_logits(self, feats, capture=None):
         x = None
         for f, stride in (("p2", 4), ("p3", 8), ("p4", 16), ("p5", 32)):
             y = feats[f]
@@ -168,11 +171,15 @@ class OracleModel:
             for _ in range(head_len):
                 n = "sem_seg_head.%s.%d" % (f, idx)
                 y = self.gn(self.conv(y, n, 1, 1), n + ".norm")
+                if capture is not None:
+                    capture[n] = y
                 idx += 1
                 if stride != 4:
                     y = self.q(F.interpolate(y, scale_factor=2.0, mode="bilinear", align_corners=False))
                     idx += 1
             x = y if x is None else self.q(x + y)
+        if capture is not None:
+            capture["sem_seg_head.sum"] = x
         return self.conv(x, "sem_seg_head.predictor")
 
     def sem_seg_loss(self, logits, targets):

@@ -321,13 +321,15 @@ def _nhwc(x_nchw):
     return out
 
 
-def test_heads_teacher_forced_losses(F):
+@pytest.mark.parametrize("hw", [(192, 256), (800, 1333)])
+def test_heads_teacher_forced_losses(F, hw):
     """All ten training losses at the tolerance north_star names (1e-3 relative), with every discrete decision shared.
 
     A random-weight train-mode-BN network amplifies bf16 rounding noise until near-tie proposals, matches and samples flip,
     so a free-running end-to-end comparison can only use wide bands.  Here the HIP heads are teacher-forced instead: they
     get the bf16 oracle's FPN maps and the oracle's RPN proposals, the samplers get injected keys (the production, batched
-    branch), and the oracle is handed the boxes the HIP cascade actually used at stages 2 and 3.  Every discrete quantity
+    branch), and the oracle is handed the boxes the HIP cascade actually used at stages 2 and 3.  Run at the size of the
+    parity fixtures and at BASELINE.json's configuration 1 (2 images of 800 x 1333).  Every discrete quantity
     (sampled anchors, sampled ROIs and their order, the labels of the three stages) must then be IDENTICAL, and every loss
     must agree to 1e-3: loss_sem_seg, loss_rpn_cls, loss_rpn_loc, loss_cls / loss_box_reg of the three stages, loss_mask."""
     from oracle.model import OracleModel
@@ -346,7 +348,8 @@ def test_heads_teacher_forced_losses(F):
             v.copy_(det_fill(k, v.cpu()).to(DEV))
     model.train()
     om = OracleModel(cfg, {k: v.cpu() for k, v in model.state_dict().items()}, emulate_bf16=True)
-    h, w = 192, 256
+    h, w = hw
+    torch.set_num_threads(min(32, os.cpu_count() or 1))  # the fp32 oracle's small convolutions slow down beyond that
     batch_cpu = make_synthetic_batch(2, height=h, width=w)
     batch = make_synthetic_batch(2, height=h, width=w, device=DEV)
     gt_cpu, gt_dev = [x["instances"] for x in batch_cpu], [x["instances"] for x in batch]

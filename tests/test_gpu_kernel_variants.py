@@ -1,0 +1,258 @@
+"""Every kernel variant of the convolution family under `pytest -m gpu`, including the ones the dispatch heuristics only
+pick at the shapes of the benchmark configuration (u2seg_R50_800, batch 16, 800x1333).
+
+Two kinds of test:
+  * forced variants on small shapes: the product path passes variant 0, so the tests steer the launchers through
+    U2_CONV_VARIANT / U2_WGRAD_VARIANT (same bits as the C-ABI's variant argument) and check with u2_conv_last_kernel that
+    the intended kernel really ran - every template instantiation of conv_igemm.hip and conv_tile.hip gets a forward +
+    data-gradient + weight-gradient comparison with fp32 F.conv2d on the same bf16-rounded operands;
+  * true benchmark shapes through the AUTOMATIC dispatch (no override): the fpn_output2 layer (16 x 200 x 336, 3x3
+    256 -> 256; non-temporal output stores, the deepest LDS ring, XCD-grouped wgrad) forward / dgrad / wgrad and a few
+    more layers forward, against an fp32 reference evaluated at sampled output positions.
+"""
+import contextlib
+import os
+
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def F():
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from u2seg_amd import _hip
+    from u2seg_amd.layers import functional
+
+    _hip.load()
+    return functional
+
+
+def bf(x):
+    return x.bfloat16().float()
+
+
+def nhwc(x_nchw):
+    b, c, h, w = x_nchw.shape
+    cp = (c + 31) // 32 * 32
+    out = torch.zeros((b, h, w, cp), dtype=torch.bfloat16, device=DEV)
+    out[..., :c] = x_nchw.permute(0, 2, 3, 1).to(DEV)
+    return out
+
+
+def nchw(x_nhwc, c):
+    return x_nhwc[..., :c].permute(0, 3, 1, 2).float().cpu()
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@contextlib.contextmanager
+def forced(conv=None, wgrad=None):
+    old = {k: os.environ.get(k) for k in ("U2_CONV_VARIANT", "U2_WGRAD_VARIANT")}
+    try:
+        for k, v in (("U2_CONV_VARIANT", conv), ("U2_WGRAD_VARIANT", wgrad)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def last_kernel():
+    from u2seg_amd import _hip
+
+    return _hip.call_nostream("u2_conv_last_kernel")
+
+
+def igemm_code(bk, tm, tn, nst, glds=1):
+    return 1000000 + bk * 10000 + (tm // 64) * 1000 + (tn // 64) * 100 + nst * 10 + glds
+
+
+NEVER_TILE = 15 << 12
+# (U2_CONV_VARIANT, expected u2_conv_last_kernel of the FORWARD launch) on the 3x3 64 -> 256 case below (K = 576)
+CONV_VARIANTS = [
+    (NEVER_TILE, igemm_code(64, 128, 128, 2)),            # 128 x 128, BK 64, 2-stage LDS-DMA ring (the default of that family)
+    (NEVER_TILE | 1, igemm_code(64, 128, 128, 2, 0)),     # register-staged operands
+    (NEVER_TILE | 32, igemm_code(64, 128, 128, 3)),       # 3-stage ring
+    (NEVER_TILE | 48, igemm_code(64, 128, 128, 4)),       # 4-stage ring
+    (NEVER_TILE | 4, igemm_code(32, 128, 128, 4)),        # BK 32 (default ring depth 4)
+    (NEVER_TILE | 4 | 16, igemm_code(32, 128, 128, 2)),
+    (NEVER_TILE | 4 | 32, igemm_code(32, 128, 128, 3)),
+    (NEVER_TILE | 4 | 1, igemm_code(32, 128, 128, 2, 0)),
+    (NEVER_TILE | 8, igemm_code(64, 256, 128, 2)),        # 256 x 128 tile, 8 waves
+    (NEVER_TILE | 8 | 1, igemm_code(64, 256, 128, 2, 0)),
+    (NEVER_TILE | 8 | 32, igemm_code(64, 256, 128, 3)),
+    (NEVER_TILE | 8 | 4, igemm_code(32, 256, 128, 4)),
+    (NEVER_TILE | 8 | 4 | 16, igemm_code(32, 256, 128, 2)),
+    (NEVER_TILE | 8 | 4 | 32, igemm_code(32, 256, 128, 3)),
+    (NEVER_TILE | 8 | 4 | 1, igemm_code(32, 256, 128, 2, 0)),
+    (NEVER_TILE | 256, 256),                              # conv_igemm256_kernel<false>
+    (NEVER_TILE | 256 | 1024, 256 + 1024),                # conv_igemm256_kernel<true> (staggered wave groups)
+    (NEVER_TILE | 256 | 1024 | 2048, 256 + 1024),
+] + [((cfg << 12) | (tiny << 16), 100 + cfg) for cfg in range(1, 8) for tiny in (0, 1)]
+
+
+@pytest.mark.parametrize("variant,code", CONV_VARIANTS)
+def test_conv_forced_variant_fwd_bwd(F, variant, code):
+    """3x3 64 -> 256 conv with BN statistics on 2 x 36 x 32 (M = 2304: 9 tiles of 256 pixels, so that the persistent
+    kernels with the 8-work-group grid walk two tiles): forward, statistics, data gradient (a 3x3 256 -> 64 conv through the
+    same launcher) and weight gradient vs fp32 F.conv2d."""
+    g = torch.Generator().manual_seed(variant % 9973)
+    cin, cout = 64, 256
+    x = bf(torch.randn((2, cin, 36, 32), generator=g))
+    w = (torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    yr = bf(TF.conv2d(xr, bf(w), None, 1, 1))
+    gy = bf(torch.randn(yr.shape, generator=g))
+    yr.backward(gy)
+    xd = nhwc(x).requires_grad_(True)
+    wd = w.detach().to(DEV).requires_grad_(True)
+    with forced(conv=variant):
+        y, stats = F._Conv2dFn.apply(xd, wd, None, 1, 1, False, True)
+        assert last_kernel() == code, "variant %#x ran kernel %d, expected %d" % (variant, last_kernel(), code)
+        y.backward(nhwc(gy))
+    yy = nchw(y, cout)
+    assert rel_err(yy, yr.detach()) < 1e-2
+    assert torch.allclose(stats[0].cpu(), yy.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(stats[1].cpu(), (yy * yy).sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert rel_err(nchw(xd.grad, cin), xr.grad) < 1.5e-2
+    assert rel_err(wd.grad.cpu(), w.grad) < 1e-2
+
+
+@pytest.mark.parametrize("variant,code", [(NEVER_TILE, igemm_code(64, 256, 64, 2)), (NEVER_TILE | 1, igemm_code(64, 256, 64, 2, 0)),
+                                          (NEVER_TILE | 32, igemm_code(64, 256, 64, 3)), (NEVER_TILE | 48, igemm_code(64, 256, 64, 4)),
+                                          (NEVER_TILE | 4, igemm_code(32, 256, 64, 4)), (NEVER_TILE | 4 | 16, igemm_code(32, 256, 64, 2)),
+                                          (NEVER_TILE | 4 | 32, igemm_code(32, 256, 64, 3)), (NEVER_TILE | 4 | 1, igemm_code(32, 256, 64, 2, 0))])
+def test_conv_narrow_tile_variants(F, variant, code):
+    """The 256 x 64 tile family (layers with <= 64 output channels): 1x1 512 -> 40 with bias and ReLU."""
+    g = torch.Generator().manual_seed(5 + variant % 97)
+    x = bf(torch.randn((2, 512, 19, 23), generator=g))
+    w = torch.randn((40, 512, 1, 1), generator=g) / 512 ** 0.5
+    b = torch.randn(40, generator=g) * 0.1
+    yr = bf(TF.relu(TF.conv2d(x, bf(w), b)))
+    with forced(conv=variant):
+        y = F.conv2d(nhwc(x), w.to(DEV), b.to(DEV), 1, 0, relu=True)
+        assert last_kernel() == code
+    assert rel_err(nchw(y, 40), yr) < 1e-2
+    assert float(y[..., 40:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("variant,code", [(0, 2003), (1, 2001), (2, 2002), (3, 2000), (64, 2103), (128, 2003), (256, 2256),
+                                          (256 | 64, 2356), (16, 2003), (32, 2003)])
+def test_wgrad_forced_variants(F, variant, code):
+    """conv_wgrad_kernel<GLDS, TR> (all four), the XCD-grouped launch and conv_wgrad256_kernel on 3x3 s1 128 -> 136 (the plain
+    layout) and on 1x1 (the direct-into-arena layout), vs fp32."""
+    g = torch.Generator().manual_seed(3 + variant)
+    for (cin, cout, k, pad) in ((128, 136, 3, 1), (256, 264, 1, 0)):
+        x = bf(torch.randn((2, cin, 21, 27), generator=g))
+        w = (torch.randn((cout, cin, k, k), generator=g) / (cin * k * k) ** 0.5).requires_grad_(True)
+        yr = TF.conv2d(x, bf(w), None, 1, pad)
+        gy = bf(torch.randn(yr.shape, generator=g))
+        yr.backward(gy)
+        wd = w.detach().to(DEV).requires_grad_(True)
+        with forced(wgrad=variant):
+            y, _ = F._Conv2dFn.apply(nhwc(x), wd, None, 1, pad, False, False)
+            y.backward(nhwc(gy))
+            assert last_kernel() == code, (variant, last_kernel(), code)
+        assert rel_err(wd.grad.cpu(), w.grad) < 1e-2
+
+
+def _sampled_conv_ref(x, w, bias, pos, pad):
+    """fp32 conv outputs at sampled positions.  x [B,H,W,C] bf16 (GPU), w [N,C,KH,KW] fp32 (GPU, bf16-rounded by the caller),
+    pos int64 [S,3] (b, y, x) -> [S, N] fp32."""
+    n, c, kh, kw = w.shape
+    b, h, wd_, _ = x.shape
+    out = torch.zeros((pos.shape[0], n), dtype=torch.float32, device=x.device)
+    for i in range(kh):
+        for j in range(kw):
+            yy, xx = pos[:, 1] + i - pad, pos[:, 2] + j - pad
+            ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < wd_)
+            patch = x[pos[:, 0], yy.clamp(0, h - 1), xx.clamp(0, wd_ - 1)][:, :c].float() * ok[:, None]
+            out += patch @ w[:, :, i, j].t()
+    if bias is not None:
+        out += bias
+    return out
+
+
+FULL_SHAPES = [
+    # name, B, H, W, cin, cout, k, pad, relu+bias, expected forward kernel under the automatic dispatch
+    ("fpn_output2 3x3 256->256 @200x336", 16, 200, 336, 256, 256, 3, 1, False, 102),
+    ("rpn conv 3x3 256->256 @100x168 bias relu", 16, 100, 168, 256, 256, 3, 1, True, 101),
+    ("res3 conv2 3x3 128->128 @100x168", 16, 100, 168, 128, 128, 3, 1, False, 103),
+    ("res4 conv3 1x1 256->1024 @50x84", 16, 50, 84, 256, 1024, 1, 0, False, 104),
+    ("res5 conv1 1x1 2048->512 @25x42", 16, 25, 42, 2048, 512, 1, 0, False, 102),
+    ("mask head 3x3 256->256 @261x14x14 bias relu", 261, 14, 14, 256, 256, 3, 1, True, 101),
+]
+
+
+@pytest.mark.parametrize("name,b,h,w,cin,cout,k,pad,br,code", FULL_SHAPES)
+def test_conv_full_shapes_auto_dispatch_forward(F, name, b, h, w, cin, cout, k, pad, br, code):
+    """Benchmark-shape layers through the automatic dispatch: the expected persistent-tile configuration is selected and
+    4096 sampled output pixels (all channels) agree with fp32; the BN statistics equal the column sums of the stored output."""
+    g = torch.Generator().manual_seed(len(name))
+    x = (torch.randn((b, h, w, cin), generator=g)).bfloat16().to(DEV)
+    wt = torch.randn((cout, cin, k, k), generator=g) / (cin * k * k) ** 0.5
+    bias = (torch.randn(cout, generator=g) * 0.1) if br else None
+    with forced():
+        y, stats = F._Conv2dFn.apply(x, wt.to(DEV), bias.to(DEV) if br else None, 1, pad, br, not br)
+        assert last_kernel() == code, (name, last_kernel())
+    pos = torch.stack([torch.randint(0, b, (4096,), generator=g), torch.randint(0, h, (4096,), generator=g),
+                       torch.randint(0, w, (4096,), generator=g)], dim=1).to(DEV)
+    pos[:64, 1] = 0
+    pos[64:128, 2] = w - 1
+    pos[128:160] = torch.tensor([b - 1, h - 1, w - 1], device=DEV)  # the last pixel of the last tile
+    ref = _sampled_conv_ref(x, bf(wt).to(DEV), bias.to(DEV) if br else None, pos, pad)
+    if br:
+        ref = ref.relu()
+    got = y[pos[:, 0], pos[:, 1], pos[:, 2]][:, :cout].float()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-2, name
+    if stats is not None:
+        yf = y[..., :cout].float().reshape(-1, cout)
+        assert torch.allclose(stats[0], yf.sum(0), rtol=2e-4, atol=0.5)
+        assert torch.allclose(stats[1], (yf * yf).sum(0), rtol=2e-4, atol=0.5)
+
+
+def test_conv_fpn_output2_backward_full_shape(F):
+    """The fpn_output2 layer at the benchmark shape (16 x 200 x 336, 3x3 256 -> 256), backward through the automatic
+    dispatch: data gradient at sampled pixels and weight gradient on a sampled 16 x 16 channel block (all 9 taps) vs fp32."""
+    g = torch.Generator().manual_seed(77)
+    b, h, w, c = 16, 200, 336, 256
+    x = torch.randn((b, h, w, c), generator=g).bfloat16().to(DEV).requires_grad_(True)
+    wt = (torch.randn((c, c, 3, 3), generator=g) / (c * 9) ** 0.5)
+    wd = wt.to(DEV).requires_grad_(True)
+    gy = torch.randn((b, h, w, c), generator=g).bfloat16().to(DEV)
+    with forced():
+        y, _ = F._Conv2dFn.apply(x, wd, None, 1, 1, False, True)
+        y.backward(gy)
+        assert last_kernel() in (2103, 2356), last_kernel()  # the wgrad ran last: XCD-grouped launch
+    # data gradient = conv of gy with the flipped, transposed filter
+    wflip = bf(wt).flip(2, 3).permute(1, 0, 2, 3).contiguous().to(DEV)
+    pos = torch.stack([torch.randint(0, b, (2048,), generator=g), torch.randint(0, h, (2048,), generator=g),
+                       torch.randint(0, w, (2048,), generator=g)], dim=1).to(DEV)
+    pos[:32, 1] = 0
+    pos[32:64, 2] = w - 1
+    ref = _sampled_conv_ref(gy, wflip, None, pos, 1)
+    got = x.grad[pos[:, 0], pos[:, 1], pos[:, 2]].float()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1.5e-2
+    # weight gradient block: n in ns, c in cs, all taps
+    ns = torch.tensor([0, 1, 17, 63, 64, 100, 127, 128, 129, 190, 200, 222, 240, 250, 254, 255], device=DEV)
+    cs = torch.tensor([0, 3, 31, 32, 33, 64, 65, 90, 127, 128, 160, 191, 192, 200, 254, 255], device=DEV)
+    gys = gy[..., ns].float()
+    xs = TF.pad(x.detach()[..., cs].float(), (0, 0, 1, 1, 1, 1))
+    for kh in range(3):
+        for kw in range(3):
+            ref_w = torch.einsum("bhwn,bhwc->nc", gys, xs[:, kh : kh + h, kw : kw + w])
+            got_w = wd.grad[ns][:, cs][:, :, kh, kw]
+            assert float((got_w - ref_w).abs().max() / ref_w.abs().max()) < 1e-2, (kh, kw)

@@ -719,10 +719,12 @@ def test_whole_model_vs_oracle(F):
 
 
 def test_backbone_and_heads_blockwise_vs_oracle(F):
-    """Teacher-forced block-level parity: every ResNet block, the FPN, the semantic head and the RPN head of the HIP path
-    get the bf16 oracle's activations as input and must reproduce the oracle's output of that block to 2e-3 relative L2 (6e-3 for the 11-layer semantic head)
-    (a random-weight train-mode BN network amplifies rounding noise ~1.2x per layer, so end-to-end feature comparison
-    is meaningless: the oracle's own bf16-vs-fp32 feature distance is 40-70%)."""
+    """Teacher-forced per-layer parity at the tolerance north_star names: every conv + norm (+ residual)(+ ReLU) unit of the
+    ResNet, the FPN, every conv + GroupNorm unit and the predictor of the semantic head and the RPN head of the HIP path get
+    the bf16 oracle's activations as input and must reproduce the oracle's output of that unit to 1e-3 relative L2.  Whole
+    bottleneck blocks (three units + shortcut chained on the HIP side) are held to 2e-3 and the 11-layer semantic head end to
+    end to 5e-3: a random-weight train-mode-BN network amplifies rounding noise ~1.2x per layer, so longer free-running
+    chains only measure that amplification (the oracle's own bf16-vs-fp32 feature distance is 40-70%)."""
     from oracle.model import OracleModel
     from tests.golden.make_fixtures import det_fill
     from u2seg_amd.config import get_cfg
@@ -739,13 +741,13 @@ def test_backbone_and_heads_blockwise_vs_oracle(F):
     model.train()
     sd = {k: v.cpu() for k, v in model.state_dict().items()}
     om = OracleModel(cfg, sd, emulate_bf16=True)
-    cap = {}
+    cap, scap = {}, {}
     with torch.no_grad():
         images, sizes, padded = om.preprocess(make_synthetic_batch(2, height=192, width=256))
         rf = om.backbone(images, cap)
-        rsem = om.sem_seg_logits(rf)
+        rsem = om.sem_seg_logits(rf, scap)
         robj, rdl = om.rpn_head(rf)
-    errs = {}
+    unit, chain = {}, {}
 
     def err(a, b):
         return float((a - b).norm() / b.norm())
@@ -755,28 +757,48 @@ def test_backbone_and_heads_blockwise_vs_oracle(F):
     with torch.no_grad():
         imgs = [x["image"] for x in batch]
         mean, std = model.pixel_mean.view(-1).float().contiguous(), model.pixel_std.view(-1).float().contiguous()
-        errs["stem"] = err(nchw(bu.stem(imgs, mean, std, padded)), cap["stem"])
+        unit["stem"] = err(nchw(bu.stem(imgs, mean, std, padded)), cap["stem"])
         prev = cap["stem"]
         res = {}
         for si, nb in zip(range(2, 6), [3, 4, 6, 3]):
             stage = getattr(bu, "res%d" % si)
             for bi in range(nb):
-                out = stage[bi](nhwc(prev))
-                errs["res%d.%d" % (si, bi)] = err(nchw(out), cap["res%d.%d" % (si, bi)])
-                prev = cap["res%d.%d" % (si, bi)]
+                blk, key = stage[bi], "res%d.%d" % (si, bi)
+                xin = nhwc(prev)
+                unit[key + ".conv1"] = err(nchw(blk.conv1(xin)), cap[key + ".conv1"])
+                unit[key + ".conv2"] = err(nchw(blk.conv2(nhwc(cap[key + ".conv1"]))), cap[key + ".conv2"])
+                if blk.shortcut is not None:
+                    unit[key + ".shortcut"] = err(nchw(blk.shortcut(xin)), cap[key + ".shortcut"])
+                out3 = blk.conv3(nhwc(cap[key + ".conv2"]), residual=nhwc(cap[key + ".shortcut"]), relu=True)
+                unit[key + ".conv3"] = err(nchw(out3), cap[key])
+                chain[key] = err(nchw(blk(xin)), cap[key])
+                prev = cap[key]
             res["res%d" % si] = nhwc(prev)
         feats = model.backbone.forward_features(res)
-        for k in ("p2", "p3", "p4", "p5", "p6"):
-            errs[k] = err(nchw(feats[k]), rf[k])
+        for k in ("p2", "p3", "p4", "p5", "p6"):  # lateral 1x1 + BN (+ upsample-add) + output 3x3 + BN: two units
+            chain[k] = err(nchw(feats[k]), rf[k])
         rfd = {k: nhwc(v) for k, v in rf.items()}
-        errs["sem_logits"] = err(nchw(model.sem_seg_head.layers(rfd), 28), rsem)
+        head = model.sem_seg_head
+        for f, sh in zip(head.in_features, head.scale_heads):  # every conv + GN + ReLU unit on the oracle's input of that unit
+            y_ref = rf[f]
+            for i, op in enumerate(sh):
+                name = "sem_seg_head.%s.%d" % (f, i)
+                if name in scap:
+                    unit[name] = err(nchw(op(nhwc(y_ref))), scap[name])
+                    y_ref = scap[name]
+                else:  # the bilinear x2 between two units: the oracle's next input
+                    y_ref = bf(TF.interpolate(y_ref, scale_factor=2.0, mode="bilinear", align_corners=False))
+        unit["sem_seg_head.predictor"] = err(nchw(head.predictor(nhwc(scap["sem_seg_head.sum"])), 28), rsem)
+        chain["sem_logits"] = err(nchw(head.layers(rfd), 28), rsem)
         objs, dlts = model.proposal_generator.rpn_head([rfd[f] for f in model.proposal_generator.in_features])
-        for i in range(5):
-            errs["rpn_obj_l%d" % i] = err(objs[i][..., :3].reshape(2, -1).float().cpu(), robj[i])
-            errs["rpn_dlt_l%d" % i] = err(dlts[i][..., :12].reshape(2, -1, 4).float().cpu(), rdl[i])
-    print(json.dumps(errs, indent=1))
-    for k, v in errs.items():
-        assert v < (6e-3 if k == "sem_logits" else 2e-3), (k, errs)
+        for i in range(5):  # 3x3 + ReLU and the two 1x1 predictors: two units
+            chain["rpn_obj_l%d" % i] = err(objs[i][..., :3].reshape(2, -1).float().cpu(), robj[i])
+            chain["rpn_dlt_l%d" % i] = err(dlts[i][..., :12].reshape(2, -1, 4).float().cpu(), rdl[i])
+    print(json.dumps({"unit": unit, "chain": chain}, indent=1))
+    for k, v in unit.items():
+        assert v < 1e-3, (k, v)
+    for k, v in chain.items():
+        assert v < (5e-3 if k == "sem_logits" else 2e-3), (k, v)
 
 
 def test_inference_tails_vs_oracle_and_reference(F, G):
@@ -851,7 +873,9 @@ def test_inference_tails_vs_oracle_and_reference(F, G):
     full = combine_semantic_and_instance_outputs_batch([pi, inst], [sem, torch.from_numpy(G["pan_sem"]).to(DEV)], 0.5, 64, 0.3, 0)
     bounded = combine_semantic_and_instance_outputs_batch([pi], [sem], 0.5, 64, 0.3, 28)
     assert torch.equal(full[0][0], bounded[0][0]) and full[0][1] == bounded[0][1] and len(full[0][1]) > 2
-    assert np.array_equal(full[1][0].cpu().numpy(), G["pan_out"]) or True  # (different thresholds: shape check only)
+    # the golden's second image with the golden's own thresholds, merged in one launch with an unrelated first image
+    gold2 = combine_semantic_and_instance_outputs_batch([pi, inst], [sem, torch.from_numpy(G["pan_sem"]).to(DEV)], 0.5, 4096 // 8, 0.5, 0)
+    assert np.array_equal(gold2[1][0].cpu().numpy(), G["pan_out"])
     assert full[1][0].shape == (96, 128)
 
     # 4. full eval forward: semantic argmax vs the bf16 oracle, detection count and field contract
@@ -876,7 +900,56 @@ def test_inference_tails_vs_oracle_and_reference(F, G):
         assert agree > 0.97 and agree_ref > 0.95, (float(agree), float(agree_ref))
         inst = o["instances"]
         assert len(inst) == len(r["scores"]) == 100 and inst.pred_masks.shape == (100, 192, 256) and inst.pred_masks.dtype == torch.bool
-        assert float(inst.scores.max()) == pytest.approx(float(r["scores"].max()), rel=5e-2)
+
+    # 5. detections, teacher-forced: the cascade box heads of the HIP path run on the oracle's FPN maps and the oracle's RPN
+    # proposals; the class probabilities [R, 801] and decoded boxes [R, 4] that enter fast_rcnn_inference must agree with the
+    # oracle's (random-weight scores sit within 1e-6 of each other, so the free-running top-100 is rounding noise - the inputs
+    # of the selection are the meaningful quantity), and the selection itself, run by the oracle on exactly those inputs, must
+    # return the detections the HIP path returned.
+    import u2seg_amd.modeling.inference as inf_mod
+    from u2seg_amd.structures import Boxes
+
+    om.training = False
+    cpu_batch = [{k: v for k, v in x.items() if k != "instances"} for x in make_synthetic_batch(2, height=192, width=256)]
+    with torch.no_grad():
+        images, sizes, _ = om.preprocess(cpu_batch)
+        rf = om.backbone(images)
+        objs, dlts = om.rpn_head(rf)
+        props = om.rpn_proposals(om.anchors(rf), objs, dlts, sizes)
+        outs = om.forward_box(rf, props, None)
+        ref_probs = sum(torch.softmax(o[0].float(), dim=-1) for o in outs) * (1.0 / 3)
+        ref_boxes = O.apply_deltas(outs[-1][1], torch.cat([p["proposal_boxes"] for p in outs[-1][2]]),
+                                   cfg.MODEL.ROI_BOX_CASCADE_HEAD.BBOX_REG_WEIGHTS[2])
+        plist = []
+        for p in props:
+            pi = Instances(p["image_size"])
+            pi.proposal_boxes, pi.objectness_logits = Boxes(p["proposal_boxes"].to(DEV)), p["objectness_logits"].to(DEV)
+            plist.append(pi)
+        seen = {}
+        orig = inf_mod.fast_rcnn_inference
+
+        def spy(boxes, scores, image_shapes, *a, **kw):
+            seen["boxes"], seen["scores"] = [b.clone() for b in boxes], [s_.clone() for s_ in scores]
+            seen["out"] = orig(boxes, scores, image_shapes, *a, **kw)
+            return seen["out"]
+
+        inf_mod.fast_rcnn_inference = spy
+        try:
+            model.roi_heads._forward_box({k: nhwc(v) for k, v in rf.items()}, plist)
+        finally:
+            inf_mod.fast_rcnn_inference = orig
+        got_probs, got_boxes = torch.cat(seen["scores"]).cpu(), torch.cat(seen["boxes"]).cpu()
+        assert got_probs.shape == ref_probs.shape and got_boxes.shape == ref_boxes.shape
+        # three cascaded stages run free on each side (stage k pools at the boxes stage k-1 predicted): 1e-2 relative L2
+        assert float((got_probs - ref_probs).norm() / ref_probs.norm()) < 1e-2
+        # pixels, after three cascaded decodes of bf16 deltas (2^-8 relative) on boxes up to 256 px wide
+        assert float((got_boxes - ref_boxes).abs().max()) < 2.5 and float((got_boxes - ref_boxes).abs().mean()) < 0.1
+        counts = [len(p["proposal_boxes"]) for p in props]
+        for i, (b_, s_) in enumerate(zip(got_boxes.split(counts), got_probs.split(counts))):
+            rb, rs, rc = om.box_inference_single(b_, s_, sizes[i])
+            det = seen["out"][0][i]
+            assert torch.equal(det.pred_classes.cpu(), rc) and torch.equal(det.scores.cpu(), rs)
+            assert torch.equal(det.pred_boxes.tensor.cpu(), rb)
 
 
 def _two_rank_worker(rank, world, port, out):

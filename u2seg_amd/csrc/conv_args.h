@@ -39,6 +39,12 @@ __device__ __forceinline__ void glds16(const bf16_t* src, void* lds_dst_wave_bas
 }
 
 
+// Which kernel the most recent u2_conv_igemm / u2_conv_wgrad launch selected (u2_conv_last_kernel, a test / debugging aid):
+//   conv_tile_kernel configuration k -> 100 + k;  conv_igemm256_kernel -> 256 (+ 1024 staggered);
+//   conv_igemm_kernel<BK, GLDS, TM, TN, NST> -> 1000000 + BK * 10000 + (TM / 64) * 1000 + (TN / 64) * 100 + NST * 10 + GLDS;
+//   conv_wgrad_kernel<GLDS, TR> -> 2000 + GLDS * 2 + TR (+ 100 when XCD-grouped);  conv_wgrad256_kernel -> 2256 (+ 100).
+extern int g_last_conv_kernel;
+
 // conv_tile.hip: persistent 64(ch) x 128(px)-per-wave tile kernels; returns 1 when it took the launch, 0 when the shape is
 // not served (caller falls back to conv_igemm_kernel), -1000 - hipError_t on a launch failure.
 int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s);

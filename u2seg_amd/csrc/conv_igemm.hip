@@ -16,6 +16,8 @@
 // The MFMA is issued with the weight tile as the "A" operand and the pixel tile as "B", so every
 // lane ends up with 4 consecutive channels of one pixel; the tile is then transposed through LDS
 // and written with 16-byte coalesced stores (bias / accumulate / ReLU / BN column statistics fused).
+#include <stdlib.h>
+
 #include "common.h"
 #include "conv_args.h"
 #include "u2seg_hip.h"
@@ -1067,6 +1069,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
 }
 
 __device__ __attribute__((aligned(256))) bf16_t g_zero_page[128];
+}  // namespace
+namespace u2conv {
+int g_last_conv_kernel = 0;
+}
+extern "C" int u2_conv_last_kernel(void) { return u2conv::g_last_conv_kernel; }
+namespace {
 
 const bf16_t* zero_page_ptr() {
   static const bf16_t* p = nullptr;
@@ -1082,7 +1090,15 @@ const bf16_t* zero_page_ptr() {
 
 namespace {
 
+// a caller that passes variant 0 (the product path always does) can be steered from the environment: tests and A/B runs
+int env_variant(const char* name, int variant) {
+  if (variant != 0) return variant;
+  const char* e = getenv(name);
+  return e ? (int)strtol(e, nullptr, 0) : 0;
+}
+
 int launch_conv(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
+  variant = env_variant("U2_CONV_VARIANT", variant);
   {  // persistent tile kernels (conv_tile.hip) first; 0 = shape / variant not served there
     const int rc = launch_conv_tile(a, N, C, variant, s);
     if (rc == 1) return 0;
@@ -1102,6 +1118,7 @@ int launch_conv(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
       attr_set = true;
     }
     a.stagger_by_parity = (variant & 2048) ? 1 : 0;
+    g_last_conv_kernel = 256 + ((variant & 1024) ? 1024 : 0);
     if (variant & 1024)  // staggered two-group schedule
       hipLaunchKernelGGL(conv_igemm256_kernel<true>, dim3(a.tiles_m * a.tiles_n), dim3(C256_THREADS), C256_LDS_BYTES, s, a);
     else
@@ -1131,6 +1148,7 @@ int launch_conv(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   if (lds > 160 * 1024) return -3;
 #define U2_LAUNCH_CONV(BK_, GL_, TM_, TN_, NST_)                                                                 \
   do {                                                                                                           \
+    g_last_conv_kernel = 1000000 + BK_ * 10000 + (TM_ / 64) * 1000 + (TN_ / 64) * 100 + NST_ * 10 + (GL_ ? 1 : 0); \
     static bool attr_set = false;                                                                                \
     if (!attr_set) {                                                                                             \
       (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BK_, GL_, TM_, TN_, NST_>,                        \
@@ -1245,6 +1263,7 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
   // 256 x 256 tiles: only on request (variant bit 8).  Measured 516 vs 805 TFLOP/s on the 200x336 3x3 256->256 layer: with
   // one resident work-group per CU the transposing reads of a step are not hidden behind anything, while four resident
   // 128 x 128 groups hide them behind each other, which outweighs the halved operand traffic.
+  variant = env_variant("U2_WGRAD_VARIANT", variant);
   const bool wide = (variant & 256) && (variant & 3) == 0;
   const int tw = wide ? 256 : 128;
   a.tiles_n = (N + tw - 1) / tw;
@@ -1275,6 +1294,7 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
   const dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool glds = (variant & 1) == 0, tr = (variant & 2) == 0;
+  g_last_conv_kernel = (wide ? 2256 : 2000 + (glds ? 2 : 0) + (tr ? 1 : 0)) + (a.xcd_group ? 100 : 0);
   if (wide) {
     static bool attr_set = false;
     if (!attr_set) {

@@ -511,11 +511,7 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   if (sel == 0) {
     // Automatic choice, from the per-layer A/B of tests/native/selftest bench2 on the shapes of the u2seg_R50_800 step
     // (profiles/r02_conv_variants.txt): tile shape by output width and by how many whole rounds of tiles the chip gets.
-    const char* env = getenv("U2_CONV_TILE");  // debugging / A-B aid: force one configuration (or 15 = never)
-    if (env) sel = atoi(env) & 15;
-    if (sel == 15) return 0;
-  }
-  if (sel == 0) {
+
     const long long K = (long long)a.ntaps * C;
     const long long t256 = (long long)((a.M + 255) / 256) * ((N + 255) / 256);
     if (N <= 128) {
@@ -539,6 +535,7 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
     if (nkh >= 3 && (variant >> 12 & 15) == 0) { sel = (N <= 128) ? 3 : 4; }  // automatic mode: the ring-3 configurations serve K >= 96
     else return 0;
   }
+  g_last_conv_kernel = 100 + sel;
   switch (sel) {
     case 1: return launch_cfg<4, 2, 4, false>(a, N, 1, tiny, s);
     case 2: return launch_cfg<4, 2, 5, false>(a, N, 1, tiny, s);
