@@ -670,10 +670,14 @@ def test_knn_row_sharded_two_ranks():
     knn_lists_agree(g["x"], np.concatenate([d0, d1]), np.concatenate([i0, i1]), g["d_knns"], g["ind_knns"])
 
 
-def test_whole_model_vs_oracle(F):
-    """u2seg_R50_800 on 2 synthetic 192x256 images, name-keyed weights, shared injected permutations:
-    the HIP path's 10 losses vs the oracle with bf16 emulation (2% relative: bf16 accumulation-order noise moves a few
-    proposals across NMS / matching thresholds) and vs the reference's fp32 losses (5%)."""
+@pytest.mark.parametrize("branch", ["per_image_permutations", "batched_keys"])
+def test_whole_model_vs_oracle(F, branch):
+    """u2seg_R50_800 on 2 synthetic 192x256 images, name-keyed weights, free running (the teacher-forced 1e-3 comparison is
+    tests/test_gpu_bookkeeping.py::test_heads_teacher_forced_losses): the HIP path's 10 losses vs the oracle with bf16
+    emulation (2% relative: bf16 accumulation-order noise moves a few proposals across NMS / matching thresholds).
+    "per_image_permutations" injects the reference's CPU randperm stream (the per-image sampling branch) and also compares
+    with the reference's own fp32 losses (tests/golden/model_small.json, 3%); "batched_keys" runs the branch every training
+    step takes (padded / stacked bookkeeping, u2_topk_rows) with injected keys that the oracle turns into permutations."""
     from oracle.model import OracleModel
     from tests.golden.make_fixtures import det_fill
     from u2seg_amd.config import get_cfg
@@ -690,17 +694,43 @@ def test_whole_model_vs_oracle(F):
     model.train()
     sd = {k: v.cpu() for k, v in model.state_dict().items()}
 
-    # the same CPU randperm stream the reference fixture was generated with (torch.manual_seed(5), CPU generator)
-    set_permutation_source(lambda n, device=None: torch.randperm(n))
     batch = make_synthetic_batch(2, height=192, width=256, device=DEV)
-    torch.manual_seed(5)
-    losses = model(batch)
-    sum(losses.values()).backward()
-    set_permutation_source(None)
-    torch.cuda.synchronize()
-    om = OracleModel(cfg, sd, emulate_bf16=True)
-    torch.manual_seed(5)
-    ref = om.train_forward(make_synthetic_batch(2, height=192, width=256))
+    if branch == "per_image_permutations":
+        # the same CPU randperm stream the reference fixture was generated with (torch.manual_seed(5), CPU generator)
+        set_permutation_source(lambda n, device=None: torch.randperm(n))
+        torch.manual_seed(5)
+        losses = model(batch)
+        sum(losses.values()).backward()
+        set_permutation_source(None)
+        torch.cuda.synchronize()
+        om = OracleModel(cfg, sd, emulate_bf16=True)
+        torch.manual_seed(5)
+        ref = om.train_forward(make_synthetic_batch(2, height=192, width=256))
+    else:
+        from tests.test_gpu_bookkeeping import KeyRecorder
+        from u2seg_amd.modeling import set_key_source
+
+        rec = KeyRecorder(5)
+        set_key_source(rec)
+        try:
+            losses = model(batch)
+            sum(losses.values()).backward()
+        finally:
+            set_key_source(None)
+        torch.cuda.synchronize()
+        assert len(rec.calls) == 2  # one draw for the anchors, one for the ROIs
+        cpu_batch = make_synthetic_batch(2, height=192, width=256)
+        ngt = [len(x["instances"]) for x in cpu_batch]
+
+        def key_fn(stage, i, n):
+            if stage == "rpn":
+                return rec.calls[0][i, :n]
+            k = rec.calls[1]
+            npad = k.shape[1] - max(ngt)  # the HIP path pads the proposals of every image to the post-NMS top-k
+            return torch.cat([k[i, : n - ngt[i]], k[i, npad : npad + ngt[i]]])
+
+        om = OracleModel(cfg, sd, emulate_bf16=True, key_fn=key_fn)
+        ref = om.train_forward(cpu_batch)
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "model_small.json")))["losses"]
     report = {k: (float(losses[k]), float(ref[k]), fx[k]) for k in sorted(ref)}
     print(json.dumps(report, indent=1))
@@ -710,10 +740,13 @@ def test_whole_model_vs_oracle(F):
     dense = ["loss_sem_seg", "loss_rpn_cls", "loss_cls_stage0", "loss_cls_stage1", "loss_cls_stage2", "loss_mask"]
     for k in dense:
         assert float(losses[k]) == pytest.approx(float(ref[k]), rel=2e-2), (k, report)
-        assert float(losses[k]) == pytest.approx(fx[k], rel=3e-2), (k, report)
+        if branch == "per_image_permutations":
+            assert float(losses[k]) == pytest.approx(fx[k], rel=3e-2), (k, report)
     assert float(losses["loss_rpn_loc"]) == pytest.approx(float(ref["loss_rpn_loc"]), rel=5e-2), report
     for k in ("loss_box_reg_stage0", "loss_box_reg_stage1", "loss_box_reg_stage2"):
-        assert 0.3 * fx[k] < float(losses[k]) < 3.0 * fx[k], (k, report)
+        # free running, the few foreground ROIs these average over differ between the two runs (the proposals come from each
+        # side's own RPN maps); with shared ROIs they agree to 1e-5 (teacher-forced test).  Same order of magnitude only.
+        assert 0.3 * float(ref[k]) < float(losses[k]) < 3.0 * float(ref[k]), (k, report)
     gn = float(model.backbone.bottom_up.stem.conv1.weight.grad.norm())
     assert gn == gn and gn > 0
 
@@ -1165,11 +1198,15 @@ def test_real_data_pipeline_to_model(F):
         assert len(losses) == 10 and bool(torch.isfinite(sum(v.detach() for v in losses.values())))
 
 
-def test_sgd_trajectory_vs_reference(F):
+@pytest.mark.parametrize("branch", ["per_image_permutations", "batched_keys"])
+def test_sgd_trajectory_vs_reference(F, branch):
     """Four training steps through the product path (HIP model, FlatSGD arena + u2_sgd_clip_step, WarmupMultiStepLR,
     SimpleTrainer) against the reference's own four steps (tests/golden/trajectory_small.json: its PanopticFPN, its
     clip-wrapped SGD, its LR schedule, fp32 CPU): the lr of every step exactly, the dense losses of every step within the
-    bf16 band of test_whole_model_vs_oracle, then where the parameters and BN running statistics ended up."""
+    bf16 band of test_whole_model_vs_oracle, then where the parameters and BN running statistics ended up.
+    "per_image_permutations" replays the reference's randperm stream through the per-image sampling branch;
+    "batched_keys" takes the batched branch of every real training step (its random draws are then not the fixture's: the
+    sampled anchors / ROIs are a different uniformly random subset, which the bands below already absorb)."""
     from tests.golden.make_fixtures import det_fill
     from u2seg_amd.config import get_cfg
     from u2seg_amd.data import make_synthetic_batch
@@ -1189,7 +1226,13 @@ def test_sgd_trajectory_vs_reference(F):
     init = {k: dict(model.named_parameters())[k].detach().clone() for k in fx["param_norm"]}
     opt = build_optimizer(cfg, model)
     trainer = SimpleTrainer(model, opt, build_lr_scheduler(cfg, opt))
-    set_permutation_source(lambda n, device=None: torch.randperm(n))
+    if branch == "per_image_permutations":
+        set_permutation_source(lambda n, device=None: torch.randperm(n))
+    else:
+        from tests.test_gpu_bookkeeping import KeyRecorder
+        from u2seg_amd.modeling import set_key_source
+
+        set_key_source(KeyRecorder(fx["seed"]))
     torch.manual_seed(fx["seed"])
     n, (h, w) = fx["num_images"], fx["image_hw"]
     report = []
@@ -1200,6 +1243,8 @@ def test_sgd_trajectory_vs_reference(F):
             report.append({k: (float(v.detach()), fx["losses"][it][k]) for k, v in losses.items()})
     finally:
         set_permutation_source(None)
+        if branch != "per_image_permutations":
+            set_key_source(None)
     print(json.dumps(report, indent=1))
     # Step 0 sees the reference's parameters: the single-step band of test_whole_model_vs_oracle.  Afterwards the bf16 and
     # fp32 runs drift apart and sampling decisions differ; the bf16-emulating oracle run against the same fixture (with
