@@ -70,7 +70,9 @@ int u2_weight_layout_batched(const float* base, const U2LayoutDesc* table, int n
 /* ---- normalisation / activation (norm.hip) ----------------------------------------------------
  * Replaces nn.SyncBatchNorm / nn.GroupNorm / relu_ chosen by detectron2/layers/batch_norm.py:169-197. */
 int u2_colstats(const void* x, float* out /*[slots][2][C]*/, int slots, int rows_per_slot, int C, int ld, void* stream);
-int u2_bn_finalize_fwd(const float* sums, float count, const float* gamma, const float* beta, float* running_mean,
+/* count: elements per channel behind `sums`; count_dev (optional, device, 1 float) overrides it - SyncBN all-reduces the
+ * per-rank counts together with the sums, because ranks pad their batches to different sizes (nn.SyncBatchNorm does). */
+int u2_bn_finalize_fwd(const float* sums, float count, const float* count_dev, const float* gamma, const float* beta, float* running_mean,
                        float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                        float* shift, int C, void* stream);
 int u2_affine_act(const void* x, const float* scale, const float* shift, const void* resid, void* out, int slots,
@@ -84,7 +86,7 @@ int u2_norm_bwd_reduce(const void* dout, const void* mask, const void* x, const 
  * u2_norm_bwd_apply can run on (dz, x) with relu = 0 and dz doubles as the residual branch's gradient; dout2 (optional,
  * needs dz_out) is a second incoming gradient summed on the fly (resnet.py:204-210: the block output feeds the next
  * block's conv1 and its identity shortcut). */
-int u2_bn_finalize_bwd(const float* sums, float count, const float* gamma, const float* mean, const float* invstd,
+int u2_bn_finalize_bwd(const float* sums, float count, const float* count_dev, const float* gamma, const float* mean, const float* invstd,
                        const float* local_sums, float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C,
                        int accumulate /* dgamma/dbeta += instead of = (parameter gradient arena) */, void* stream);
 int u2_norm_bwd_apply(const void* dout, const void* mask, const void* x, const float* k1, const float* k2,

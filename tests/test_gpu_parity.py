@@ -1057,6 +1057,76 @@ def test_kmeans_row_sharded_two_ranks():
     assert np.array_equal(c0, c1)  # identical on both ranks
 
 
+def _syncbn_ragged_worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from u2seg_amd.layers import functional as F
+
+    torch.cuda.set_device(0)
+    g = torch.Generator().manual_seed(50 + rank)
+    c = 64
+    shape = (2, c, 11, 13) if rank == 0 else (3, c, 17, 9)  # different element counts per rank (286 vs 459)
+    x = bf(torch.randn(shape, generator=g) * 2 + 0.3 * rank)
+    gy = bf(torch.randn(shape, generator=g))
+    gg = torch.Generator().manual_seed(7)  # the parameters are replicated
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=gg), 0.1 * torch.randn(c, generator=gg)
+    xd = nhwc(x).requires_grad_(True)
+    gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    stats = torch.stack([x.sum((0, 2, 3)), (x * x).sum((0, 2, 3))]).to(DEV)
+    y = F.batch_norm_act(xd, stats, gd, bd, rm, rv, None, True, 0.1, 1e-5, sync=True)
+    y.backward(nhwc(gy))
+    torch.cuda.synchronize()
+    out[rank] = {"x": x, "gy": gy, "y": nchw(y.detach()), "dx": nchw(xd.grad), "dgamma": gd.grad.cpu(), "dbeta": bd.grad.cpu(),
+                 "rm": rm.cpu(), "rv": rv.cpu()}
+    dist.destroy_process_group()
+
+
+def test_syncbn_unequal_counts_two_ranks():
+    """SyncBN with a different number of elements per rank (ranks pad their batches to their own image sizes): forward,
+    running statistics, input gradient and the local affine gradients of both ranks vs nn.functional.batch_norm on the
+    CONCATENATED batch (what nn.SyncBatchNorm, selected at layers/batch_norm.py:187, computes by gathering the per-rank
+    counts).  Dividing the all-reduced sums by m_local * world - the round-1 code - fails this test."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_syncbn_ragged_worker, args=(2, port, out), nprocs=2, join=True)
+        r = [out[0], out[1]]
+    c = 64
+    g = torch.Generator().manual_seed(7)
+    gamma, beta = (1 + 0.2 * torch.randn(c, generator=g)).requires_grad_(True), (0.1 * torch.randn(c, generator=g)).requires_grad_(True)
+    flat = [t["x"].permute(0, 2, 3, 1).reshape(-1, c) for t in r]
+    xc = torch.cat(flat).clone().requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    yc = TF.relu(TF.batch_norm(xc, rm, rv, gamma, beta, True, 0.1, 1e-5))
+    gyc = torch.cat([t["gy"].permute(0, 2, 3, 1).reshape(-1, c) for t in r])
+    yc.backward(gyc)
+    n0 = flat[0].shape[0]
+    for i, t in enumerate(r):
+        sl = slice(0, n0) if i == 0 else slice(n0, None)
+        got_y = t["y"].permute(0, 2, 3, 1).reshape(-1, c)
+        assert rel_err(got_y, bf(yc.detach()[sl])) < 1e-2
+        got_dx = t["dx"].permute(0, 2, 3, 1).reshape(-1, c)
+        assert rel_err(got_dx, xc.grad[sl]) < 1.5e-2
+        # running statistics: identical on both ranks, equal to the concatenated batch's
+        assert torch.allclose(t["rm"], rm, atol=1e-4) and torch.allclose(t["rv"], rv, atol=1e-3)
+        # affine gradients are local sums (DDP averages them afterwards): this rank's pixels only
+        mu, var = xc.detach().mean(0), xc.detach().var(0, unbiased=False)
+        xhat = (xc.detach()[sl] - mu) * torch.rsqrt(var + 1e-5)
+        dz = gyc[sl] * (yc.detach()[sl] > 0)
+        assert rel_err(t["dbeta"], dz.sum(0)) < 1e-2 and rel_err(t["dgamma"], (dz * xhat).sum(0)) < 1e-2
+    assert torch.equal(r[0]["rm"], r[1]["rm"]) and torch.equal(r[0]["rv"], r[1]["rv"])
+
+
 def test_two_rank_step_on_one_gpu():
     """The multi-process data-parallel path (SyncBN statistic all-reduce inside forward/backward, bucketed gradient
     all-reduce, grad_scale = 1/world in the optimizer kernel) with two ranks sharing cuda:0 over gloo (RCCL refuses two

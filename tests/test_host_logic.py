@@ -330,3 +330,32 @@ def test_resolved_configs_equal_reference():
     r = gold["u2seg_R50_800"]
     assert r["MODEL"]["ROI_HEADS"]["NUM_CLASSES"] == 800 and r["SOLVER"]["GAMMA"] == 0.02
     assert r["DATALOADER"]["FILTER_EMPTY_ANNOTATIONS"] is False and r["INPUT"]["MASK_FORMAT"] == "bitmask"
+
+
+def test_lr_schedule_resume_matches_uninterrupted_run():
+    """A run resumed at iteration k continues the reference's schedule (warm-up and STEPS milestones counted from iteration 0,
+    solver/build.py:283-323 + the checkpointer restoring the scheduler): lr(k), lr(k+1), ... equal an uninterrupted run's."""
+    from u2seg_amd.solver.build import WarmupMultiStepLR
+
+    class Opt:
+        lr = 0.0
+
+    def make():
+        o = Opt()
+        return o, WarmupMultiStepLR(o, 0.01, [30, 50], 0.02, 1e-3, 20)
+
+    full_opt, full = make()
+    lrs = []
+    for _ in range(70):
+        lrs.append(full_opt.lr)
+        full.step()
+    for k in (7, 20, 31, 55):  # inside the warm-up, at its end, after each milestone
+        o, s = make()
+        s.resume_at(k)
+        for it in range(k, 70):
+            assert o.lr == lrs[it], (k, it)
+            s.step()
+        o2, s2 = make()
+        s2.load_state_dict({"last_iter": k})
+        assert o2.lr == lrs[k]
+    assert lrs[0] == pytest.approx(1e-5) and lrs[20] == 0.01 and lrs[30] == pytest.approx(2e-4) and lrs[50] == pytest.approx(4e-6)

@@ -103,6 +103,7 @@ def main(args):
     if (cfg.MODEL.WEIGHTS and os.path.isfile(cfg.MODEL.WEIGHTS)) or args.resume:
         rest = checkpointer.resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume)
         start_iter = int(rest.get("iteration", -1)) + 1 if args.resume else 0
+        sched.resume_at(start_iter)  # lr of iteration start_iter, milestones counted from iteration 0
     elif cfg.MODEL.WEIGHTS and rank == 0:
         print("MODEL.WEIGHTS %s not found: random initialisation" % cfg.MODEL.WEIGHTS)
     stream = real_batches(cfg, c.MODEL.DEVICE)

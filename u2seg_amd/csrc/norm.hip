@@ -348,12 +348,14 @@ static dim3 fast_grid(int slots, int rows_per_slot, int C) {
 }
 
 // BatchNorm forward finalize: sums -> mean/invstd/scale/shift, running-stat update (momentum).
-__global__ void bn_finalize_fwd_kernel(const float* __restrict__ sums, float count, const float* __restrict__ gamma,
+__global__ void bn_finalize_fwd_kernel(const float* __restrict__ sums, float count, const float* __restrict__ count_dev,
+                                       const float* __restrict__ gamma,
                                        const float* __restrict__ beta, float* __restrict__ running_mean,
                                        float* __restrict__ running_var, float momentum, float eps, float* __restrict__ mean,
                                        float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (count_dev) count = *count_dev;  // SyncBN: the all-reduced element count of all ranks (they may differ per rank)
   const float mu = sums[c] / count;
   float var = sums[C + c] / count - mu * mu;
   var = fmaxf(var, 0.f);
@@ -371,13 +373,15 @@ __global__ void bn_finalize_fwd_kernel(const float* __restrict__ sums, float cou
 }
 
 // BatchNorm backward finalize: S1 = sum dz, S2 = sum dz*xhat -> dgamma, dbeta and the dx coefficients.
-__global__ void bn_finalize_bwd_kernel(const float* __restrict__ sums, float count, const float* __restrict__ gamma,
+__global__ void bn_finalize_bwd_kernel(const float* __restrict__ sums, float count, const float* __restrict__ count_dev,
+                                       const float* __restrict__ gamma,
                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                        const float* __restrict__ local_sums, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ k1, float* __restrict__ k2,
                                        float* __restrict__ k3, int C, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (count_dev) count = *count_dev;
   const float s1 = sums[c], s2 = sums[C + c];
   const float g = gamma[c], is = invstd[c], mu = mean[c];
   if (accumulate) {
@@ -605,20 +609,20 @@ extern "C" int u2_relu_bwd(const void* dout, const void* out, void* dz, long lon
   return 0;
 }
 
-extern "C" int u2_bn_finalize_fwd(const float* sums, float count, const float* gamma, const float* beta,
+extern "C" int u2_bn_finalize_fwd(const float* sums, float count, const float* count_dev, const float* gamma, const float* beta,
                                   float* running_mean, float* running_var, float momentum, float eps, float* mean,
                                   float* invstd, float* scale, float* shift, int C, void* stream) {
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, gamma,
-                     beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C);
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, count_dev,
+                     gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C);
   U2_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int u2_bn_finalize_bwd(const float* sums, float count, const float* gamma, const float* mean,
+extern "C" int u2_bn_finalize_bwd(const float* sums, float count, const float* count_dev, const float* gamma, const float* mean,
                                   const float* invstd, const float* local_sums, float* dgamma, float* dbeta, float* k1,
                                   float* k2, float* k3, int C, int accumulate, void* stream) {
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, gamma,
-                     mean, invstd, local_sums, dgamma, dbeta, k1, k2, k3, C, accumulate);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, count_dev,
+                     gamma, mean, invstd, local_sums, dgamma, dbeta, k1, k2, k3, C, accumulate);
   U2_CHECK_LAUNCH();
   return 0;
 }

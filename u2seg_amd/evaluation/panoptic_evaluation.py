@@ -60,7 +60,8 @@ class COCOPanopticEvaluator(DatasetEvaluator):
     def process(self, inputs, outputs):
         for inp, out in zip(inputs, outputs):
             ids, segments = out["panoptic_seg"]
-            ids = ids.cpu().numpy()
+            ids = ids.cpu().numpy().copy()  # edited below: never the model's own output (shared with other evaluators)
+            segments = [dict(seg) for seg in segments] if segments is not None else None
             assert segments is not None, "the PanopticFPN path always returns segments_info"
             if self.mode != "hungarian_matching":
                 kept = []

@@ -71,7 +71,8 @@ def accumulate_image(stat, gt_ids, gt_segments, pred_ids, pred_segments, categor
             continue
         if gt_seg[g].get("iscrowd", 0) == 1 or gt_seg[g]["category_id"] != pred_seg[p]["category_id"]:
             continue
-        union = pred_seg[p]["area"] + gt_area[g] - area - overlap.get((VOID, p), 0)
+        # the published procedure takes the ground-truth area from the annotation json when it carries one
+        union = pred_seg[p]["area"] + gt_seg[g].get("area", gt_area[g]) - area - overlap.get((VOID, p), 0)
         iou = area / union
         if iou > 0.5:
             cat = gt_seg[g]["category_id"]

@@ -272,17 +272,23 @@ class _BatchNormActFn(Function):
 
     @staticmethod
     def forward(ctx, y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, grad_dst=None,
-                twin=False):
+                twin=False, sync=True):
         _check_act(y)
         b, h, w, c = y.shape
         m = b * h * w
-        world = _world()
+        world = _world() if sync else 1
+        count, count_dev = float(m), None
         if world > 1:
-            dist.all_reduce(stats)
-        count = float(m * world)
+            # nn.SyncBatchNorm (layers/batch_norm.py:187) gathers (mean, invstd, count) of every rank: the ranks pad their
+            # batches to their own maximum image size, so the element counts differ.  One all-reduce of [sum | sumsq | count].
+            from ..modeling.batched import device_constant
+
+            packed = torch.cat([stats.reshape(-1), device_constant([float(m)], torch.float32, y.device)])
+            dist.all_reduce(packed)
+            stats, count_dev = packed[: 2 * c].view(2, c), packed[2 * c :]
         mean = torch.empty(c, dtype=torch.float32, device=y.device)
         invstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
-        _hip.call("u2_bn_finalize_fwd", stats, count, gamma, beta, running_mean, running_var, momentum, eps, mean,
+        _hip.call("u2_bn_finalize_fwd", stats, count, count_dev, gamma, beta, running_mean, running_var, momentum, eps, mean,
                   invstd, scale, shift, c)
         out = torch.empty_like(y)
         _hip.call("u2_affine_act", y, scale, shift, residual, out, 1, m, c, c, int(relu))
@@ -291,6 +297,7 @@ class _BatchNormActFn(Function):
         ctx.save_for_backward(y, out if (relu and not remask) else None, gamma, mean, invstd,
                               scale if remask else None, shift if remask else None)
         ctx.cfg = (relu, count, world, residual is not None)
+        ctx.count_dev = count_dev
         ctx.grad_dst = grad_dst  # (dgamma, dbeta) arena slices or None
         ctx.twin = twin
         if twin:  # two handles on the same activation: their gradients arrive separately and are summed in the kernel
@@ -304,7 +311,7 @@ class _BatchNormActFn(Function):
         relu, count, world, has_res = ctx.cfg
         b, h, w, c = y.shape
         m = b * h * w
-        nret = 12
+        nret = 13
         if dout is None:
             dout, dout2 = dout2, None
         if dout is None:
@@ -325,7 +332,7 @@ class _BatchNormActFn(Function):
         coef = torch.empty((5, c), dtype=torch.float32, device=y.device)
         direct = ctx.grad_dst is not None
         dgamma, dbeta = ctx.grad_dst if direct else (coef[0], coef[1])
-        _hip.call("u2_bn_finalize_bwd", sums, count, gamma, mean, invstd, local, dgamma, dbeta, coef[2], coef[3],
+        _hip.call("u2_bn_finalize_bwd", sums, count, ctx.count_dev, gamma, mean, invstd, local, dgamma, dbeta, coef[2], coef[3],
                   coef[4], c, int(direct))
         dx = torch.empty_like(y)
         if fuse:
@@ -336,19 +343,19 @@ class _BatchNormActFn(Function):
             _hip.call("u2_norm_bwd_apply", dout, out, y, coef[2], coef[3], coef[4], dx, dres, 1, m, c, c, int(relu), msc, msh)
         if direct:
             dgamma = dbeta = None
-        return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None
+        return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
 
 
 def batch_norm_act(y, stats, gamma, beta, running_mean, running_var, residual=None, relu=False, momentum=0.1,
-                   eps=1e-5, twin=False):
+                   eps=1e-5, twin=False, sync=True):
     """twin=True: returns the activation with a second autograd handle on the same memory in `._u2_twin` (for a consumer
     pair such as the next residual block's conv1 and identity shortcut); the two gradients are summed inside the
-    backward kernel instead of by autograd."""
+    backward kernel instead of by autograd.  sync=False: per-process statistics (NORM "BN"), no all-reduce."""
     gd, bd = grad_slot(gamma), grad_slot(beta)
     grad_dst = (gd, bd) if gd is not None and bd is not None else None
     twin = bool(twin) and torch.is_grad_enabled()
     out = _BatchNormActFn.apply(y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, grad_dst,
-                                twin)
+                                twin, sync)
     if twin:
         out, other = out
         out._u2_twin = other

@@ -46,9 +46,10 @@ class BatchNorm2d(nn.Module):
     """Training-mode batch norm with cross-rank statistics when torch.distributed is initialised
     (the role of nn.SyncBatchNorm / nn.BatchNorm2d picked by get_norm, layers/batch_norm.py:182-189)."""
 
-    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, sync=True):
         super().__init__()
         self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.sync = sync  # False: NORM "BN" - statistics of this process only
         self.weight = nn.Parameter(torch.ones(num_features))
         self.bias = nn.Parameter(torch.zeros(num_features))
         self.register_buffer("running_mean", torch.zeros(num_features))
@@ -109,8 +110,8 @@ def get_norm(norm, out_channels):
         if len(norm) == 0:
             return None
         norm = {
-            "BN": BatchNorm2d,
-            "SyncBN": BatchNorm2d,
+            "BN": lambda channels: BatchNorm2d(channels, sync=False),   # per-GPU statistics (layers/batch_norm.py:181)
+            "SyncBN": BatchNorm2d,                                       # statistics over all ranks (:187)
             "FrozenBN": FrozenBatchNorm2d,
             "GN": lambda channels: GroupNorm(32, channels),
         }[norm]
@@ -145,7 +146,7 @@ class Conv2d(nn.Module):
             y, stats = F.conv2d(x, self.weight, None, self.stride, self.padding, relu=False, want_stats=True)
             norm.count_batch()
             return F.batch_norm_act(y, stats, norm.weight, norm.bias, norm.running_mean, norm.running_var, residual,
-                                    relu, norm.momentum, norm.eps, twin=twin)
+                                    relu, norm.momentum, norm.eps, twin=twin, sync=norm.sync)
         y = F.conv2d(x, self.weight, None, self.stride, self.padding, relu=False)
         if isinstance(norm, GroupNorm):
             assert residual is None

@@ -50,7 +50,7 @@ class BasicStem(nn.Module):
         if self.training and hasattr(norm, "momentum"):
             norm.count_batch()
             x = F.batch_norm_act(y, stats, norm.weight, norm.bias, norm.running_mean, norm.running_var, None, True,
-                                 norm.momentum, norm.eps)
+                                 norm.momentum, norm.eps, sync=norm.sync)
         else:
             scale, shift = norm.eval_scale_shift()
             x = F.affine_act(y, scale.float(), shift.float(), None, True)

@@ -77,12 +77,6 @@ class FlatSGD:
 
     def zero_grad(self):
         self.flat_grad.zero_()
-        for p in self.params:  # autograd may have replaced .grad with a fresh tensor
-            if p.grad is None or p.grad.data_ptr() != self._grad_view_ptr(p):
-                pass
-
-    def _grad_view_ptr(self, p):
-        return p.grad.data_ptr() if p.grad is not None else 0
 
     def _distributed(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -193,6 +187,19 @@ class WarmupMultiStepLR:
     def step(self):
         self.last_iter += 1
         self.optimizer.lr = self.get_lr(self.last_iter)
+
+    def resume_at(self, iteration):
+        """Continue the schedule at `iteration` (the next step to run): the reference restores its scheduler through the
+        checkpointer (engine/defaults.py:410-421 resume_or_load -> start_iter); without this a resumed run would restart the
+        warm-up and count the STEPS milestones from the resume point."""
+        self.last_iter = int(iteration)
+        self.optimizer.lr = self.get_lr(self.last_iter)
+
+    def state_dict(self):
+        return {"last_iter": self.last_iter}
+
+    def load_state_dict(self, state):
+        self.resume_at(state["last_iter"])
 
 
 def build_lr_scheduler(cfg, optimizer):
