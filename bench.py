@@ -7,7 +7,12 @@ COCO-shaped 3x800x1333 batches, bf16 activations / fp32 master weights, one proc
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  `roofline` is measured live with HIP events
 around every launch of the dominant kernel family (the MFMA implicit-GEMM conv) inside the timed region;
-`cpu_baseline` times the CPU oracle (oracle/) on a bounded sample (rank 0, N = 1 only)."""
+`cpu_baseline` times the CPU oracle (oracle/) on a bounded sample (rank 0, N = 1 only).
+
+The default workload is BASELINE.json's metric (configs[1]: training images/s).  Two more workloads make the other
+single-GPU configurations driver-measurable with the same JSON contract:
+    python bench.py --workload kmeans   # configs[3]: Lloyd iterations over 1M x 768 synthetic DINO embeddings, K = 300 (s/iter)
+    python bench.py --workload infer    # configs[4]: u2seg_eval_800 panoptic inference, batch 32 (img/s)"""
 import argparse
 import json
 import os
@@ -49,9 +54,6 @@ class KernelTimer:
                                   timer.alg_bytes(name, args)))
 
         _hip.call = timed_call
-        import u2seg_amd.layers.functional as F
-
-        F._hip.call = timed_call
 
     @staticmethod
     def alg_bytes(name, a):
@@ -59,9 +61,11 @@ class KernelTimer:
         if name == "u2_conv_igemm":
             b, hin, win, c, ho, wo, n, kh, kw, accum = a[5], a[6], a[7], a[8], a[10], a[11], a[12], a[14], a[15], a[21]
             return 2.0 * (b * hin * win * c + n * kh * kw * c + b * ho * wo * n * (2 if accum else 1))
-        if name == "u2_conv_wgrad":
+        if name in ("u2_conv_wgrad", "u2_conv_wgrad_into"):
             b, hin, win, c, ho, wo, n, kh, kw = a[3], a[4], a[5], a[6], a[8], a[9], a[10], a[12], a[13]
             return 2.0 * (b * hin * win * c + b * ho * wo * n) + 4.0 * n * kh * kw * c
+        if name in ("u2_kmeans_assign", "u2_kmeans_update"):
+            return 4.0 * a[4] * a[5]  # x read once (the fused ideal reads it once per iteration)
         return 0.0
 
     @staticmethod
@@ -70,10 +74,13 @@ class KernelTimer:
             # (in, wt, out, bias, stats, B, Hin, Win, C, in_ld, Hout, Wout, N, out_ld, KH, KW, ph, pw, mul, div, ...)
             b, c, ho, wo, n, kh, kw, div = a[5], a[8], a[10], a[11], a[12], a[14], a[15], a[19]
             return 2.0 * b * ho * wo * n * kh * kw * c / (div * div)
-        if name == "u2_conv_wgrad":
+        if name in ("u2_conv_wgrad", "u2_conv_wgrad_into"):
             # (x, dy, dw, B, Hin, Win, C, x_ld, Hout, Wout, N, dy_ld, KH, KW, ...)
             b, c, ho, wo, n, kh, kw = a[3], a[6], a[8], a[9], a[10], a[12], a[13]
             return 2.0 * b * ho * wo * n * kh * kw * c
+        if name == "u2_kmeans_assign":
+            # (x, c, cnorm_ws, labels, N, D, K): |c|^2 - 2 x.c for every (point, centroid) pair
+            return 2.0 * a[4] * a[5] * a[6]
         return 0.0
 
     def summary(self):
@@ -88,45 +95,160 @@ class KernelTimer:
 
 
 CPU_BASELINE_THREADS = 32     # more threads than this slow the oracle's small fp32 convolutions down (256 threads: 15x slower)
-CPU_BASELINE_TIMEOUT_S = 150  # the default bench.py run must stay within a few minutes
+CPU_BASELINE_TIMEOUT_S = 200  # the default bench.py run must stay within a few minutes
+CFG_DIR = os.path.join(ROOT, "configs", "COCO-PanopticSegmentation")
+KMEANS_D, KMEANS_K = 768, 300
 
 
-def cpu_baseline_worker(sample_hw=(800, 1333)):
-    """Times the CPU oracle's train iteration (fwd + bwd, fp32) on 1 synthetic image; returns the JSON object."""
-    from oracle.model import OracleModel
-    import u2seg_amd.data as data
+def _timed_iterations(fn, warmup=1, timed=3):
+    """1 warm-up + 3 timed iterations; returns the mean seconds of the timed ones."""
+    for _ in range(warmup):
+        fn()
+    t0 = time.time()
+    for _ in range(timed):
+        fn()
+    return (time.time() - t0) / timed
 
+
+def cpu_baseline_worker(workload):
+    """Times the CPU oracle on a bounded sample of the workload (1 warm-up + 3 timed iterations); returns the JSON object."""
     cores = min(os.cpu_count() or 1, CPU_BASELINE_THREADS)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
-    om = OracleModel.from_config_file(os.path.join(ROOT, "configs", "COCO-PanopticSegmentation", "u2seg_R50_800.yaml"))
+    host = "%d of the host's %d hardware threads" % (cores, os.cpu_count() or 1)
+    if workload == "kmeans":
+        from oracle import ops
+
+        n = 20000
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn((n, KMEANS_D), generator=g)
+        c = x[torch.randperm(n, generator=g)[:KMEANS_K]].clone()
+
+        def it():
+            cl = ops.kmeans_assign(x, c)
+            ops.kmeans_update(x, cl, KMEANS_K)
+
+        dt = _timed_iterations(it)
+        return {"value": dt * (1000000 / n), "unit": "s/iter", "cores": cores, "kind": "port",
+                "sample": "Lloyd iterations (oracle/ops.py, chunked plain-torch form of nn_utils.py:325-364) over %d x %d points, "
+                          "K = %d, 1 warm-up + 3 timed on %s: %.2f s/iter, scaled linearly to N = 1M" % (n, KMEANS_D, KMEANS_K, host, dt)}
+    from oracle.model import OracleModel
+    import u2seg_amd.data as data
+
+    if workload == "infer":
+        om = OracleModel.from_config_file(os.path.join(CFG_DIR, "u2seg_eval_800.yaml"))
+        batch = [{k: v for k, v in x.items() if k != "instances"} for x in data.make_synthetic_batch(1)]
+        with torch.no_grad():
+            dt = _timed_iterations(lambda: om.inference(batch))
+        return {"value": 1 / dt, "unit": "img/s", "cores": cores, "kind": "port",
+                "sample": "1 synthetic 800x1333 image, full panoptic inference of the fp32 CPU oracle, 1 warm-up + 3 timed on %s "
+                          "(%.1f s per image)" % (host, dt)}
+    om = OracleModel.from_config_file(os.path.join(CFG_DIR, "u2seg_R50_800.yaml"))
     nimg = 2  # BASELINE.json configs[0]: the reference's own CPU case is 2 images, 1 train iteration
-    batch = data.make_synthetic_batch(nimg, height=sample_hw[0], width=sample_hw[1])
-    t0 = time.time()
-    losses = om.train_forward(batch)
-    sum(losses.values()).backward()
-    dt = time.time() - t0
+    batch = data.make_synthetic_batch(nimg)
+
+    def it():
+        for p in om.parameters().values():
+            p.grad = None
+        losses = om.train_forward(batch)
+        sum(losses.values()).backward()
+
+    dt = _timed_iterations(it)
     return {"value": nimg / dt, "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": "%d synthetic %dx%d images, 1 fwd+bwd iteration of the fp32 CPU oracle on %d of the host's %d hardware "
-                      "threads (%.1f s, includes first-call overheads)" % (nimg, sample_hw[0], sample_hw[1], cores,
-                                                                           os.cpu_count() or 1, dt)}
+            "sample": "%d synthetic 800x1333 images, fwd+bwd iteration of the fp32 CPU oracle, 1 warm-up + 3 timed on %s "
+                      "(%.1f s per iteration)" % (nimg, host, dt)}
 
 
-def cpu_baseline():
+def cpu_baseline(workload):
     """Runs the oracle in a child process with a hard time limit, so that a slow host cannot stall the benchmark."""
     import subprocess
 
+    unit = "s/iter" if workload == "kmeans" else "img/s"
     try:
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True, text=True,
-                             timeout=CPU_BASELINE_TIMEOUT_S, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", workload],
+                             capture_output=True, text=True, timeout=CPU_BASELINE_TIMEOUT_S,
+                             env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
         for line in reversed(out.stdout.strip().splitlines()):
             if line.startswith("{"):
                 return json.loads(line)
-        return {"value": None, "unit": "img/s", "cores": CPU_BASELINE_THREADS, "kind": "port",
+        return {"value": None, "unit": unit, "cores": CPU_BASELINE_THREADS, "kind": "port",
                 "sample": "oracle child process failed: " + out.stderr.strip()[-300:]}
     except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "img/s", "cores": CPU_BASELINE_THREADS, "kind": "port",
-                "sample": "1 synthetic 800x1333 image did not finish one fp32 oracle iteration within %d s" % CPU_BASELINE_TIMEOUT_S}
+        return {"value": None, "unit": unit, "cores": CPU_BASELINE_THREADS, "kind": "port",
+                "sample": "the oracle sample did not finish 1 + 3 iterations within %d s" % CPU_BASELINE_TIMEOUT_S}
+
+
+def _pmc_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (profiles/r02_pmc_traffic.json, else r01)."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            pj = json.load(open(path))
+            if kernel_key in pj:
+                return pj[kernel_key]["hbm_bytes_per_launch"], "HBM bytes per launch from profiles/%s (%s)" % (name, pj["note"])
+    return None, "no PMC profile committed for this kernel"
+
+
+def conv_roofline(timer, sampled, steps, imgs_per_s_per_gpu=None):
+    ks = timer.summary()
+    conv = {k: v for k, v in ks.items() if k in ("u2_conv_igemm", "u2_conv_wgrad", "u2_conv_wgrad_into")}
+    if not conv:
+        return None
+    name, d = max(conv.items(), key=lambda kv: kv[1]["ms"])
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    traffic, note = _pmc_traffic({"u2_conv_igemm": "conv_igemm"}.get(name, "conv_wgrad"))
+    # launches whose whole reduction is <= 256 deep (1x1 convs on <= 256 channels) are HBM-bound by construction: report the two
+    # groups next to the all-launch average the `frac` is computed from
+    deep = [r for r in timer.records if r[0] == name and TimerShape.k_depth(r) > 256]
+    shallow = [r for r in timer.records if r[0] == name and TimerShape.k_depth(r) <= 256]
+
+    def tf(rs):
+        ms = sum(r[2].elapsed_time(r[3]) for r in rs)
+        return (sum(r[1] for r in rs) / (ms * 1e-3) / 1e12, ms / sampled) if rs and ms > 0 else (None, 0.0)
+
+    def tbs(rs):
+        ms = sum(r[2].elapsed_time(r[3]) for r in rs)
+        return sum(r[5] for r in rs) / (ms * 1e-3) / 1e12 if rs and ms > 0 else None
+
+    out = {"kernel": {"u2_conv_igemm": "implicit-GEMM conv, forward + data-gradient launches (conv_tile_kernel / conv_igemm_kernel "
+                                       "/ conv_igemm256_kernel: all tile configurations)",
+                      "u2_conv_wgrad": "conv_wgrad_kernel", "u2_conv_wgrad_into": "conv_wgrad_kernel"}[name],
+           "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+           "traffic": traffic, "traffic_note": note,
+           "algorithmic_bytes_per_launch_avg": d["bytes"] / d["launches"],
+           "launches_per_step": d["launches"] / sampled, "avg_launch_ms": d["ms"] / d["launches"],
+           "sampled_steps": "the last %d of the %d timed steps carry the HIP events" % (sampled, steps),
+           "flop_per_launch_avg": d["flops"] / d["launches"],
+           "kernel_ms_per_step": {k: v["ms"] / sampled for k, v in ks.items()},
+           "kernel_tflops": {k: v["flops"] / (v["ms"] * 1e-3) / 1e12 for k, v in ks.items() if v["ms"] > 0},
+           "by_reduction_depth": {"K>256 (MFMA-bound)": {"tflops": tf(deep)[0], "ms_per_step": tf(deep)[1]},
+                                  "K<=256 (HBM-bound 1x1 layers)": {"tflops": tf(shallow)[0], "ms_per_step": tf(shallow)[1],
+                                                                   "algorithmic_TB_per_s": tbs(shallow)}}}
+    if imgs_per_s_per_gpu is not None:
+        out["conv_stack_frac_of_peak_e2e"] = imgs_per_s_per_gpu * CONV_STACK_TRAIN_GFLOP_PER_IMAGE * 1e9 / (PEAK_BF16_TFLOPS * 1e12)
+    return out
+
+
+class TimerShape:
+    @staticmethod
+    def k_depth(rec):
+        """Reduction depth KH * KW * C of a recorded conv launch (record[4] = the integer arguments of the call)."""
+        name, ints = rec[0], rec[4]
+        if name == "u2_conv_igemm":   # (B, Hin, Win, C, in_ld, Hout, Wout, N, out_ld, KH, KW, ...)
+            return ints[3] * ints[9] * ints[10]
+        return 1 << 30
+
+
+def per_layer_report(timer, sampled):
+    agg = {}
+    for name, fl, s, e, shape, _ in timer.records:
+        d = agg.setdefault((name, shape), [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += s.elapsed_time(e)
+        d[2] += fl
+    for (name, shape), d in sorted(agg.items(), key=lambda kv: -kv[1][1])[:48]:
+        print("LAYER %-14s %-70s n=%3d  %7.3f ms/step  %7.1f TF/s" % (name, shape, d[0] / sampled, d[1] / sampled,
+                                                                     d[2] / (d[1] * 1e-3) / 1e12), file=sys.stderr)
 
 
 def main():
@@ -134,15 +256,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--workload", choices=["train", "kmeans", "infer"], default="train")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (train: 16, infer: 32)")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--kmeans-n", type=int, default=1000000, help="points in total (sharded over the GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: time the CPU oracle and print its JSON object")
     ap.add_argument("--per-layer", action="store_true", help="debug: print the conv launches grouped by shape")
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline_worker()))
+        print(json.dumps(cpu_baseline_worker(args.workload)))
         return
 
     rank = int(os.environ.get("RANK", 0))
@@ -155,105 +279,143 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
     from u2seg_amd import _hip
-    from u2seg_amd.config import get_cfg
-    from u2seg_amd.data import make_synthetic_batch
-    from u2seg_amd.engine import SimpleTrainer
-    from u2seg_amd.modeling import build_model
-    from u2seg_amd.solver import build_lr_scheduler, build_optimizer
 
     _hip.load()
-    timer = KernelTimer(["u2_conv_igemm", "u2_conv_wgrad"])
+    timer = KernelTimer(["u2_conv_igemm", "u2_conv_wgrad", "u2_conv_wgrad_into", "u2_kmeans_assign", "u2_kmeans_update"])
     timer.install()
-
-    torch.manual_seed(1234)  # identical initial weights on every rank
-    cfg = get_cfg()
-    cfg.merge_from_file(os.path.join(ROOT, "configs", "COCO-PanopticSegmentation", "u2seg_R50_800.yaml"))
-    cfg.merge_from_list(["MODEL.DEVICE", dev, "SOLVER.IMS_PER_BATCH", args.batch * world])
-    model = build_model(cfg)
-    model.train()
-    opt = build_optimizer(cfg, model)
-    sched = build_lr_scheduler(cfg, opt)
-    trainer = SimpleTrainer(model, opt, sched)
-    # a few cached synthetic batches resident in HBM (tools/benchmark.py:108-115 caches 100 batches the same way)
-    nb = 2
-    batches = [make_synthetic_batch(args.batch, start_index=(rank * nb + i) * args.batch, height=args.height,
-                                    width=args.width, device=dev) for i in range(nb)]
-    torch.manual_seed(1000 + rank)  # per-rank sampling randomness
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        trainer.run_step(batches[i % nb])
-    barrier()
-    # HIP-event pairs around every conv launch cost ~5% of a step on the host side, so only the last step(s) of the
-    # timed region carry them: the roofline numbers are a sample of the timed region, `value` stays (almost) undisturbed.
-    sampled = max(1, args.steps // 8)
-    t0 = time.time()
-    for i in range(args.steps):
-        timer.enabled = i >= args.steps - sampled
-        trainer.run_step(batches[i % nb])
-    barrier()
-    dt = time.time() - t0
-    timer.enabled = False
-    total = trainer.check_finite()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
+    def timed(step_fn):
+        """W untimed steps, then exactly K timed ones between barriers; MAX over ranks.  Only the last step(s) carry the
+        per-launch HIP events (they cost host time): the roofline numbers are a sample of the timed region."""
+        for i in range(args.warmup):
+            step_fn(i)
+        barrier()
+        sampled = max(1, args.steps // 8)
+        t0 = time.time()
+        for i in range(args.steps):
+            timer.enabled = i >= args.steps - sampled
+            step_fn(args.warmup + i)
+        barrier()
+        dt = time.time() - t0
+        timer.enabled = False
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        return dt, sampled
 
+    out = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "vs_baseline": None, "data": "synthetic"}
+    if args.workload == "train":
+        from u2seg_amd.config import get_cfg
+        from u2seg_amd.data import make_synthetic_batch
+        from u2seg_amd.engine import SimpleTrainer
+        from u2seg_amd.modeling import build_model
+        from u2seg_amd.solver import build_lr_scheduler, build_optimizer
+
+        batch = args.batch or 16
+        torch.manual_seed(1234)  # identical initial weights on every rank
+        cfg = get_cfg()
+        cfg.merge_from_file(os.path.join(CFG_DIR, "u2seg_R50_800.yaml"))
+        cfg.merge_from_list(["MODEL.DEVICE", dev, "SOLVER.IMS_PER_BATCH", batch * world])
+        model = build_model(cfg)
+        model.train()
+        opt = build_optimizer(cfg, model)
+        trainer = SimpleTrainer(model, opt, build_lr_scheduler(cfg, opt))
+        # a few cached synthetic batches resident in HBM (tools/benchmark.py:108-115 caches 100 batches the same way)
+        nb = 2
+        batches = [make_synthetic_batch(batch, start_index=(rank * nb + i) * batch, height=args.height, width=args.width,
+                                        device=dev) for i in range(nb)]
+        torch.manual_seed(1000 + rank)  # per-rank sampling randomness
+        dt, sampled = timed(lambda i: trainer.run_step(batches[i % nb]))
+        total = trainer.check_finite()
+        imgs_per_s = batch * world * args.steps / dt
+        out.update({"metric": "training images/sec (whole node) u2seg_R50_800 @ 800x1333", "value": imgs_per_s, "unit": "img/s",
+                    "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "dtype": "bf16",
+                    "config": {"workload": "u2seg_R50_800.yaml bf16, batch %d per GPU, %dx%d synthetic COCO-panoptic batches, "
+                                           "random init, SGD+per-param clip" % (batch, args.height, args.width),
+                               "global_batch": batch * world, "parallelism": "dp%d" % world},
+                    "final_total_loss": total})
+        if rank == 0:
+            out["roofline"] = conv_roofline(timer, sampled, args.steps, imgs_per_s / world)
+    elif args.workload == "infer":
+        from u2seg_amd.config import get_cfg
+        from u2seg_amd.data import make_synthetic_batch
+        from u2seg_amd.modeling import build_model
+
+        batch = args.batch or 32
+        torch.manual_seed(1234)
+        cfg = get_cfg()
+        cfg.merge_from_file(os.path.join(CFG_DIR, "u2seg_eval_800.yaml"))
+        cfg.merge_from_list(["MODEL.DEVICE", dev])
+        model = build_model(cfg)
+        model.eval()
+        data = [{k: v for k, v in x.items() if k != "instances"}
+                for x in make_synthetic_batch(batch, start_index=rank * batch, height=args.height, width=args.width, device=dev)]
+        res = {}
+
+        def step(i):
+            with torch.no_grad():
+                res["out"] = model(data)
+
+        dt, sampled = timed(step)
+        imgs_per_s = batch * world * args.steps / dt
+        out.update({"metric": "panoptic inference images/sec (whole node) u2seg_eval_800 @ 800x1333", "value": imgs_per_s,
+                    "unit": "img/s", "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                    "dtype": "bf16",
+                    "config": {"workload": "u2seg_eval_800.yaml bf16, batch %d per GPU, %dx%d synthetic images, random init, full "
+                                           "post-processing (box NMS, pasted masks, semantic argmax, panoptic merge)"
+                                           % (batch, args.height, args.width),
+                               "global_batch": batch * world, "parallelism": "replicas%d" % world},
+                    "instances_image0": len(res["out"][0]["instances"]), "segments_image0": len(res["out"][0]["panoptic_seg"][1])})
+        if rank == 0:
+            out["roofline"] = conv_roofline(timer, sampled, args.steps)
+    else:
+        from u2seg_amd.cluster import kmeans as KM
+
+        n_local = args.kmeans_n // world
+        g = torch.Generator(device=dev).manual_seed(rank)
+        gc = torch.Generator(device=dev).manual_seed(12345)  # the mixture centres are the same on every rank
+        centers = torch.randn((KMEANS_K, KMEANS_D), generator=gc, device=dev) * 2
+        x = centers[torch.randint(0, KMEANS_K, (n_local,), generator=g, device=dev)] + \
+            0.5 * torch.randn((n_local, KMEANS_D), generator=g, device=dev)
+        state = {"c": centers + 0.3 * torch.randn((KMEANS_K, KMEANS_D), generator=gc, device=dev)}
+
+        def step(i):
+            lab = KM.assign(x, state["c"])
+            state["c"], _ = KM.update_sharded(x, lab, KMEANS_K) if world > 1 else KM.update(x, lab, KMEANS_K)
+
+        dt, sampled = timed(step)
+        s_per_iter = dt / args.steps
+        out.update({"metric": "k-means seconds per Lloyd iteration (u2seg_R50_300 Instance_Clustering: N = 1M x 768 DINO-sized "
+                              "embeddings, K = 300)", "value": s_per_iter, "unit": "s/iter", "ms_per_step": s_per_iter * 1e3,
+                    "higher_is_better": False, "scaling": "strong", "dtype": "f32",
+                    "config": {"workload": "Lloyd iterations (assign + update) over %d x %d synthetic embeddings (mixture of %d "
+                                           "Gaussians, sigma 0.5), K = %d, rows sharded over the GPUs" %
+                                           (n_local * world, KMEANS_D, KMEANS_K, KMEANS_K), "parallelism": "rows%d" % world},
+                    "finite_centroids": bool(torch.isfinite(state["c"]).all())})
+        if rank == 0:
+            ks = timer.summary()
+            a = ks.get("u2_kmeans_assign")
+            if a:
+                ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+                out["roofline"] = {"kernel": "kmeans_assign_kernel (|c|^2 - 2 x.c on the exact-fp32 v_mfma_f32_32x32x2_f32)",
+                                   "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
+                                   "traffic": None, "avg_launch_ms": a["ms"] / a["launches"],
+                                   "flop_per_launch": a["flops"] / a["launches"],
+                                   "algorithmic_bytes_per_launch": a["bytes"] / a["launches"],
+                                   "kernel_ms_per_iter": {k: v["ms"] / sampled for k, v in ks.items()},
+                                   "update_GB_per_s": (ks["u2_kmeans_update"]["bytes"] / (ks["u2_kmeans_update"]["ms"] * 1e-3) / 1e9
+                                                       if "u2_kmeans_update" in ks else None)}
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        imgs_per_s = args.batch * world * args.steps / dt
-        ks = timer.summary()
-        dom = max(ks.items(), key=lambda kv: kv[1]["ms"]) if ks else None
-        roofline = None
-        if dom is not None:
-            name, d = dom
-            achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            traffic, traffic_note = None, "no PMC profile committed"
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(pmc):
-                pj = json.load(open(pmc))
-                key = {"u2_conv_igemm": "conv_igemm", "u2_conv_wgrad": "conv_wgrad"}[name]
-                traffic = pj[key]["hbm_bytes_per_launch"]
-                traffic_note = "HBM bytes per launch from profiles/r01_pmc_traffic.json (" + pj["note"] + ")"
-            roofline = {"kernel": {"u2_conv_igemm": "conv_igemm_kernel (fwd + dgrad launches)",
-                                   "u2_conv_wgrad": "conv_wgrad_kernel"}[name],
-                        "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
-                        "algorithmic_bytes_per_launch_avg": d["bytes"] / d["launches"],
-                        "launches_per_step": d["launches"] / sampled, "avg_launch_ms": d["ms"] / d["launches"],
-                        "sampled_steps": "the last %d of the %d timed steps carry the HIP events" % (sampled, args.steps),
-                        "flop_per_launch_avg": d["flops"] / d["launches"],
-                        "kernel_ms_per_step": {k: v["ms"] / sampled for k, v in ks.items()},
-                        "kernel_tflops": {k: v["flops"] / (v["ms"] * 1e-3) / 1e12 for k, v in ks.items()},
-                        "conv_stack_frac_of_peak_e2e": imgs_per_s / world * CONV_STACK_TRAIN_GFLOP_PER_IMAGE * 1e9 / (PEAK_BF16_TFLOPS * 1e12)}
-        out = {
-            "metric": "training images/sec (whole node) u2seg_R50_800 @ 800x1333",
-            "value": imgs_per_s, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "u2seg_R50_800.yaml bf16, batch %d per GPU, %dx%d synthetic COCO-panoptic batches, "
-                                   "random init, SGD+per-param clip" % (args.batch, args.height, args.width),
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world},
-            "final_total_loss": total,
-            "roofline": roofline,
-        }
         if args.per_layer:
-            agg = {}
-            for name, fl, s, e, shape, _ in timer.records:
-                d = agg.setdefault((name, shape), [0, 0.0, 0.0])
-                d[0] += 1
-                d[1] += s.elapsed_time(e)
-                d[2] += fl
-            for (name, shape), d in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
-                print("LAYER %-14s %-70s n=%3d  %7.3f ms/step  %7.1f TF/s" % (name, shape, d[0] / sampled, d[1] / sampled,
-                                                                             d[2] / (d[1] * 1e-3) / 1e12), file=sys.stderr)
+            per_layer_report(timer, max(1, args.steps // 8))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -212,8 +212,13 @@ int u2_sgd_clip_step(float* params, const float* grads, float* momentum_buf, con
 /* ---- k-means over DINO embeddings (kmeans.hip): u2seg/Instance_Clustering/shared/utils/nn_utils.py:304-379 ---- */
 int u2_kmeans_assign(const float* x, const float* c, float* cnorm_ws /*[K]*/, long long* labels, int N, int D, int K,
                      void* stream);
+/* csum [K][D] += sum of the rows of x by label, counts [K] += label histogram (both pre-zeroed by the caller, or holding
+ * another shard's partial sums).  workspace (optional, u2_kmeans_update_workspace_floats(N, D, K) floats): the points are
+ * bucketed by label there and the sums become a segmented reduction that reads every row of x once, whole (0.75 -> ~4 TB/s);
+ * without it a privatised-LDS kernel is used. */
+long long u2_kmeans_update_workspace_floats(int N, int D, int K);
 int u2_kmeans_update(const float* x, const long long* labels, float* csum, float* counts, int N, int D, int K,
-                     void* stream);
+                     float* workspace, void* stream);
 int u2_kmeans_finalize(const float* csum, const float* counts, float* c, int D, int K, void* stream);
 
 /* ---- k nearest neighbours over the same embeddings (knn.hip): nn_utils.py:204-299 (kNN, partitioned_kNN) ----

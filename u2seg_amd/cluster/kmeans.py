@@ -9,6 +9,19 @@ import torch.distributed as dist
 from .. import _hip
 
 
+_ws_cache = {}
+
+
+def _update_workspace(n, d, k, device):
+    """Slab workspace of u2_kmeans_update, kept between iterations (the kernel overwrites every slab it reads)."""
+    need = _hip.call_nostream("u2_kmeans_update_workspace_floats", n, d, k)
+    key = str(device)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _ws_cache[key] = torch.empty(need, dtype=torch.float32, device=device)
+    return ws
+
+
 def assign(x, c):
     """argmin_j sum_d (x_id - c_jd)^2 -> int64 [N] (u2_kmeans_assign: exact-fp32 MFMA dot products)."""
     n, d = x.shape
@@ -24,7 +37,7 @@ def update(x, labels, k):
     n, d = x.shape
     csum = torch.zeros((k, d), dtype=torch.float32, device=x.device)
     counts = torch.zeros(k, dtype=torch.float32, device=x.device)
-    _hip.call("u2_kmeans_update", x.contiguous(), labels, csum, counts, n, d, k)
+    _hip.call("u2_kmeans_update", x.contiguous(), labels, csum, counts, n, d, k, _update_workspace(n, d, k, x.device))
     c = torch.empty_like(csum)
     _hip.call("u2_kmeans_finalize", csum, counts, c, d, k)
     return c, counts
@@ -47,7 +60,8 @@ def update_sharded(x_local, labels_local, k, group=None):
     buf = torch.zeros(k * d + k, dtype=torch.float32, device=x_local.device)
     csum, counts = buf[: k * d].view(k, d), buf[k * d :]
     if n:
-        _hip.call("u2_kmeans_update", x_local.contiguous(), labels_local, csum, counts, n, d, k)
+        _hip.call("u2_kmeans_update", x_local.contiguous(), labels_local, csum, counts, n, d, k,
+                  _update_workspace(n, d, k, x_local.device))
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(buf, group=group)
     c = torch.empty((k, d), dtype=torch.float32, device=x_local.device)
