@@ -34,7 +34,8 @@ int u2_conv_igemm(const void* in, const void* wt, void* out, const float* bias, 
 
 /* Weight gradient: dw[n][kh][kw][c] += sum_m dy[m][n] * x[src(m,kh,kw)][c]; fp32 atomics, dw pre-zeroed.
  * variant bit0: register staging; bit1: scalar LDS gathers instead of ds_read_b64_tr_b16; bits 4-5: fewer pixel splits;
- * bit6 / bit7: force / forbid the XCD-grouped launch (default: on for multi-tap filters over >= 200k pixels). */
+ * bit6 / bit7: force / forbid the XCD-grouped launch (default: on for multi-tap filters over >= 200k pixels); bit8 / bit11:
+ * force / forbid the 256 x 256 tile kernel (default: 1x1 layers over >= 200k pixels and the 7x7 fc1); bits 9-10: LDS ring depth. */
 int u2_conv_wgrad(const void* x, const void* dy, float* dw, int B, int Hin, int Win, int C, int x_ld,
                   int Hout, int Wout, int N, int dy_ld, int KH, int KW, int pad_h, int pad_w,
                   int stride, int variant, void* stream);

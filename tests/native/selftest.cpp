@@ -182,7 +182,7 @@ static void bench_conv(const char* name, int B, int H, int W, int C, int N, int 
 // ---- bench2: every conv shape of the u2seg_R50_800 training step x a list of kernel variants (one allocation, tiled random fill) ----
 struct LayerShape { const char* name; int B, H, W, C, N, K, pad, stride, relu, bias, stats; };
 
-static void bench2(int argc, char** argv) {
+static void bench2(int argc, char** argv, bool wgrad) {
   const LayerShape layers[] = {
       {"p2 3x3 256->256 200x336", 16, 200, 336, 256, 256, 3, 1, 1, 0, 0, 1},
       {"p3 3x3 256->256 100x168", 16, 100, 168, 256, 256, 3, 1, 1, 0, 0, 1},
@@ -214,17 +214,26 @@ static void bench2(int argc, char** argv) {
   };
   std::vector<int> variants;
   for (int i = 2; i < argc; ++i) variants.push_back((int)strtol(argv[i], nullptr, 0));
-  if (variants.empty()) variants = {15 << 12, 1 << 12, 2 << 12, 3 << 12, 4 << 12, 6 << 12, 7 << 12};
+  if (variants.empty()) {
+    if (wgrad) variants = {2048, 0, 256};
+    else variants = {15 << 12, 0, 1 << 12, 2 << 12, 3 << 12, 4 << 12, 5 << 12};
+  }
   const size_t in_elems = (size_t)16 * 200 * 336 * 256, w_elems = (size_t)8192 * 8192, out_elems = (size_t)16 * 200 * 336 * 256;
-  DBuf<uint16_t> din(in_elems), dw(w_elems), dout(out_elems);
-  DBuf<float> db(16384), dst(2 * 16384);
+  DBuf<uint16_t> din(in_elems), dw(wgrad ? 16 : w_elems), dout(out_elems);
+  DBuf<float> db(16384), dst(2 * 16384), dgw(wgrad ? w_elems : 16);
+  if (wgrad) {  // the output gradient operand
+    std::vector<uint16_t> pat((size_t)1 << 22);
+    for (auto& v : pat) v = f2bf(frand());
+    for (size_t o = 0; o < out_elems; o += pat.size())
+      HIPCHK(hipMemcpy(dout.d + o, pat.data(), std::min(pat.size(), out_elems - o) * 2, hipMemcpyHostToDevice));
+  }
   {
     std::vector<uint16_t> pat((size_t)1 << 22);
     for (auto& v : pat) v = f2bf(frand());
     for (size_t o = 0; o < in_elems; o += pat.size())
       HIPCHK(hipMemcpy(din.d + o, pat.data(), std::min(pat.size(), in_elems - o) * 2, hipMemcpyHostToDevice));
     for (auto& v : pat) v = f2bf(frand() * 0.05f);
-    for (size_t o = 0; o < w_elems; o += pat.size())
+    for (size_t o = 0; !wgrad && o < w_elems; o += pat.size())
       HIPCHK(hipMemcpy(dw.d + o, pat.data(), std::min(pat.size(), w_elems - o) * 2, hipMemcpyHostToDevice));
   }
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -236,6 +245,9 @@ static void bench2(int argc, char** argv) {
     printf("LAYER %-32s GFLOP %8.1f  MB %7.1f |", L.name, flop * 1e-9, bytes * 1e-6);
     for (int v : variants) {
       auto run = [&]() {
+        if (wgrad)
+          return u2_conv_wgrad(din.d, dout.d, dgw.d, L.B, L.H, L.W, L.C, L.C, Hout, Wout, L.N, L.N, L.K, L.K, L.pad, L.pad, L.stride,
+                               v, nullptr);
         return u2_conv_igemm(din.d, dw.d, dout.d, L.bias ? db.d : nullptr, L.stats ? dst.d : nullptr, L.B, L.H, L.W, L.C, L.C, Hout, Wout,
                              L.N, L.N, L.K, L.K, L.pad, L.pad, L.stride, 1, L.relu, 0, v, nullptr);
       };
@@ -256,7 +268,8 @@ static void bench2(int argc, char** argv) {
 
 int main(int argc, char** argv) {
   int fails = 0;
-  if (argc > 1 && !strcmp(argv[1], "bench2")) { bench2(argc, argv); return 0; }
+  if (argc > 1 && !strcmp(argv[1], "bench2")) { bench2(argc, argv, false); return 0; }
+  if (argc > 1 && !strcmp(argv[1], "bench2w")) { bench2(argc, argv, true); return 0; }
   if (argc > 1 && !strcmp(argv[1], "one")) {  // a single shape, for PMC profiling
     const int v = argc > 2 ? atoi(argv[2]) : 0;
     bench_conv("fpn_out2 3x3 256->256 B16", 16, 200, 336, 256, 256, 3, 1, 1, v);
@@ -288,7 +301,7 @@ int main(int argc, char** argv) {
       {1, 45, 23, 64, 72, 3, 3, 1, 1, 1, 0, 0, 1, 1, "tile 3x3 c64 n72 bias stats"},
       {3, 7, 7, 32, 136, 7, 7, 0, 1, 1, 1, 0, 1, 0, "tile fc 7x7 c32 n136 bias relu"},
   };
-  for (int cfg = 1; cfg <= 7; ++cfg)
+  for (int cfg = 1; cfg <= 5; ++cfg)
     for (int tiny = 0; tiny < 2; ++tiny)
       for (const auto& c : tconvs) fails += test_conv(c, (cfg << 12) | (tiny << 16));
   const WgCase wgs[] = {
@@ -300,6 +313,8 @@ int main(int argc, char** argv) {
   for (int v = 0; v < 4; ++v)
     for (const auto& c : wgs) fails += test_wgrad(c, v);
   for (const auto& c : wgs) fails += test_wgrad(c, 64);
+  for (const auto& c : wgs) fails += test_wgrad(c, 1 << 9);
+  for (const auto& c : wgs) fails += test_wgrad(c, 2 << 9);
   for (const auto& c : wgs) fails += test_wgrad(c, 256);
   for (const auto& c : wgs) fails += test_wgrad(c, 256, true);
   for (const auto& c : wgs) fails += test_wgrad(c, 0, true);

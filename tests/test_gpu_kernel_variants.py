@@ -101,7 +101,7 @@ CONV_VARIANTS = [
     (NEVER_TILE | 256, 256),                              # conv_igemm256_kernel<false>
     (NEVER_TILE | 256 | 1024, 256 + 1024),                # conv_igemm256_kernel<true> (staggered wave groups)
     (NEVER_TILE | 256 | 1024 | 2048, 256 + 1024),
-] + [((cfg << 12) | (tiny << 16), 100 + cfg) for cfg in range(1, 8) for tiny in (0, 1)]
+] + [((cfg << 12) | (tiny << 16), 100 + cfg) for cfg in range(1, 6) for tiny in (0, 1)]
 
 
 @pytest.mark.parametrize("variant,code", CONV_VARIANTS)

@@ -694,11 +694,12 @@ constexpr int WP = 32;  // pixels per reduction step
 // different chunk pairs (bits 1-3) makes the 8 x 32 B of a half-wave cover one 256-byte bank row exactly.
 __device__ __forceinline__ int wg_swz(int pix) { return ((pix & 3) << 1) | (pix & 8); }
 
-template <bool GLDS, bool TR>
+template <bool GLDS, bool TR, int RING = 2>
 __global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int TILE_BYTES = WP * 128 * 2;  // 8 KB per operand per stage
   constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+  static_assert(RING == 2 || (GLDS && TR), "the deeper rings exist for the LDS-DMA + transposing-read form only");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING * STAGE_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -850,7 +851,11 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradArgs a) {
     return r;
   };
 
+  // a wave whose 64 x 64 sub-tile lies outside the valid N x C block (64-channel layers fill a quarter of the tile) only
+  // helps with the staging: its MFMAs would multiply the zero page
+  const bool wave_active = (n0 + wr * 64 < a.n_valid) && (c0 + wc * 64 < a.c_valid);
   auto compute = [&](int buf) {
+    if (!wave_active) return;
     const unsigned char* ybase = smem + buf * STAGE_BYTES;
     const unsigned char* xbase = ybase + TILE_BYTES;
     s16x8 yf[4], xf[4];
@@ -870,7 +875,31 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradArgs a) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
   };
 
-  if constexpr (GLDS) {
+  if constexpr (GLDS && RING > 2) {
+    // RING-deep LDS ring: the loads of steps st+1 .. st+RING-1 are in flight while step st is multiplied (a step is only 16
+    // MFMAs per wave, ~0.1 us: with the two-buffer form every step waited out most of a memory round trip).  4 LDS-DMA
+    // loads per thread per step, retired in order: counted vmcnt, raw barrier (__syncthreads would drain them).
+#pragma unroll
+    for (int s0 = 0; s0 < RING - 1; ++s0)
+      if (s0 < nsteps) issue(s0, s0);
+    int buf = 0;
+    for (int st = 0; st < nsteps; ++st) {
+      const int ahead = min(nsteps, st + RING - 1) - (st + 1);  // steps issued behind step st
+      if (ahead >= 2) {
+        if (RING > 3 && ahead >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else if (ahead == 1) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (st + RING - 1 < nsteps) issue(st + RING - 1, buf == 0 ? RING - 1 : buf - 1);
+      compute(buf);
+      buf = (buf + 1 == RING) ? 0 : buf + 1;
+    }
+  } else if constexpr (GLDS) {
     issue(0, 0);
     for (int st = 0; st < nsteps; ++st) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1264,7 +1293,12 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
   // one resident work-group per CU the transposing reads of a step are not hidden behind anything, while four resident
   // 128 x 128 groups hide them behind each other, which outweighs the halved operand traffic.
   variant = env_variant("U2_WGRAD_VARIANT", variant);
-  const bool wide = (variant & 256) && (variant & 3) == 0;
+  // 256 x 256 tiles (half the operand traffic per flop) win where nothing else hides the memory stream: 1x1 layers over the
+  // stride-4 / stride-8 maps and the 7x7 "fully connected" fc1 (tests/native/selftest bench2w, profiles/r02_wgrad_variants.txt);
+  // variant bit 8 forces them, bit 11 forbids them
+  const bool wide_auto = !(variant & 2048) && (N % 256 == 0) && (C % 256 == 0) &&
+                         ((KH * KW == 1 && a.M >= 200000) || (KH * KW > 1 && a.M <= 16384 && Hout == 1 && Wout == 1));
+  const bool wide = ((variant & 256) || wide_auto) && (variant & 3) == 0;
   const int tw = wide ? 256 : 128;
   a.tiles_n = (N + tw - 1) / tw;
   a.tiles_c = (C + tw - 1) / tw;
@@ -1305,7 +1339,10 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
     U2_CHECK_LAUNCH();
     return 0;
   }
-  if (glds && tr)       hipLaunchKernelGGL((conv_wgrad_kernel<true, true>), grid, block, 0, s, a);
+  const int ring = (variant >> 9) & 3;  // bits 9-10: LDS ring depth of the LDS-DMA form (0 = two buffers, 1 = 3, 2 = 4)
+  if (glds && tr && ring == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<true, true, 3>), grid, block, 0, s, a);
+  else if (glds && tr && ring == 2) hipLaunchKernelGGL((conv_wgrad_kernel<true, true, 4>), grid, block, 0, s, a);
+  else if (glds && tr)  hipLaunchKernelGGL((conv_wgrad_kernel<true, true>), grid, block, 0, s, a);
   else if (glds && !tr) hipLaunchKernelGGL((conv_wgrad_kernel<true, false>), grid, block, 0, s, a);
   else if (!glds && tr) hipLaunchKernelGGL((conv_wgrad_kernel<false, true>), grid, block, 0, s, a);
   else                  hipLaunchKernelGGL((conv_wgrad_kernel<false, false>), grid, block, 0, s, a);

@@ -71,13 +71,6 @@ __device__ __forceinline__ void divmod_f(int m, int d, float inv, int& q, int& r
   if (r >= d) { ++q; r -= d; }
 }
 
-// one 16-byte MFMA fragment from LDS byte address addr + OFF; NOT counted by the compiler: the caller waits (lgkmcnt) itself
-template <int OFF> __device__ __forceinline__ s16x8 lds_frag(unsigned addr) {
-  s16x8 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-  return v;
-}
-
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 // two floats -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32)
@@ -87,7 +80,7 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
   return *reinterpret_cast<const uint32_t*>(&r);
 }
 
-template <int WCH, int WPX, int RING, bool JSPLIT, int ABL = 0>
+template <int WCH, int WPX, int RING>
 __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const ConvArgs a) {
   constexpr int NW = WCH * WPX, NT = NW * 64;
   constexpr int TN = WCH * 64, TM = WPX * 128;
@@ -187,7 +180,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #pragma unroll
     for (int i = 0; i < LP; ++i) {
       glds16(p_src[i], base + (i * NW + w) * 1024);
-      p_src[i] += (p_okmask >> i & 1u) * ((ABL & 8) ? 64 : 32);
+      p_src[i] += (p_okmask >> i & 1u) * 32;
     }
   };
 
@@ -228,7 +221,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
       glds16(w_src[i], base + (i * NW + w) * 1024);
-      w_src[i] += w_base[i] != 0xffffffffu ? ((ABL & 8) ? 64 : 32) : 0;
+      w_src[i] += w_base[i] != 0xffffffffu ? 32 : 0;
     }
   };
 
@@ -244,7 +237,6 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 
   f32x4 acc[4][8];
   s16x8 wfA[2], wfB[2], pf[8];
-  s16x8 wf2[1][4];  // JSPLIT: the four weight fragments of the half tile
 
   // BN column statistics: a lane accumulates the sums of ONE channel (st_n) over all tiles the work-group walks with the
   // same tile_n and sends them with two full-wave atomics when the channel changes or the work-group is done.
@@ -332,11 +324,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     }
   };
 
-#define U2_T_MFMA(I, WF, J)                                                                                        \
-  do {                                                                                                             \
-    if constexpr ((ABL & 4) == 0) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF, pf[J], acc[I][J], 0, 0, 0); \
-    else asm volatile("" ::"v"(WF), "v"(pf[J]));                                                                  \
-  } while (0)
+#define U2_T_MFMA(I, WF, J) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF, pf[J], acc[I][J], 0, 0, 0)
 
   // ---- prologue: P0 W0 ... P(AHEAD-1) W(AHEAD-1) P(AHEAD) in flight, publish half tile 0 ----
 #pragma unroll
@@ -345,16 +333,9 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   wait_vm<LPT * (AHEAD - 1) + LP>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  const unsigned lds0 = (unsigned)(size_t)U2_LDS_PTR(smem);
-  if constexpr (JSPLIT) {  // same issue order as a steady-state B': pf0-3, wf0 .. wf3
-    const unsigned p0 = lds0 + pfrag0, w0 = lds0 + wfrag0;
-    pf[0] = lds_frag<0>(p0); pf[1] = lds_frag<1024>(p0); pf[2] = lds_frag<2048>(p0); pf[3] = lds_frag<3072>(p0);
-    wf2[0][0] = lds_frag<0>(w0); wf2[0][1] = lds_frag<1024>(w0); wf2[0][2] = lds_frag<2048>(w0); wf2[0][3] = lds_frag<3072>(w0);
-  } else {
-    wfA[0] = ldw(0, 0); wfA[1] = ldw(0, 1);
+  wfA[0] = ldw(0, 0); wfA[1] = ldw(0, 1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) pf[j] = ldp(0, j);
-  }
+  for (int j = 0; j < 4; ++j) pf[j] = ldp(0, j);
 
   // One half K tile gh (buffer hb = gh % RING), two phases:
   //   A: 4 MFMA | read pixel fragments 4-7 and the second weight pair of gh, stage weights(gh + AHEAD) | 12 MFMA
@@ -372,55 +353,6 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     for (int h = 0; h < nkh; ++h) {
       const int nb = (hb + 1 == RING) ? 0 : hb + 1;
       const int sb = (hb == 0) ? RING - 1 : hb - 1;  // buffer of half tile gh + AHEAD (= gh - 1 mod RING)
-      if constexpr (JSPLIT) {
-        // j-split schedule: phase A' = all four channel blocks x pixel fragments 0-3, phase B' = x pixel fragments 4-7, channel
-        // block by channel block.  Pixel fragments 4-7 of gh are read at the head of A' and first used in B'; pixel fragments
-        // 0-3 of gh + 1 are read at the head of B' and first used in the next A'; weight fragment i of gh + 1 replaces
-        // fragment i right after its last four MFMAs in B' and is first used 4 * (i + 1) + 12 - 4 * i MFMAs later.  The
-        // fragment reads are inline asm with counted lgkmcnt (LDS returns in order): across the loop back-edge the compiler
-        // only ever emits lgkmcnt(0), which would expose the latency of the reads just issued at the head of A'.
-        const unsigned pa = lds0 + hb * BUF + pfrag0, pn = lds0 + nb * BUF + pfrag0, wn = lds0 + nb * BUF + wfrag0;
-        pf[4] = lds_frag<4096>(pa); pf[5] = lds_frag<5120>(pa); pf[6] = lds_frag<6144>(pa); pf[7] = lds_frag<7168>(pa);
-        if (gh + AHEAD < H) stage_weights(sb);
-        // outstanding LDS reads, oldest first: pf0-3, wf0, wf1, wf2, wf3 (of this half tile), pf4-7
-#define U2_T_JA(I, CNT)                                                                                            \
-  do {                                                                                                             \
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT) : "memory");                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                             \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) U2_T_MFMA(I, wf2[0][I], j);                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                             \
-  } while (0)
-        __builtin_amdgcn_s_setprio(1);
-        U2_T_JA(0, 7); U2_T_JA(1, 6); U2_T_JA(2, 5); U2_T_JA(3, 4);
-        __builtin_amdgcn_s_setprio(0);
-#undef U2_T_JA
-        {
-          const int rem = H - 2 - gh;
-          if (rem >= AHEAD - 1) wait_vm<LPT * (AHEAD - 1)>();
-          else if (AHEAD > 3 && rem == 2) wait_vm<LPT * 2>();
-          else if (rem == 1) wait_vm<LPT>();
-          else wait_vm<0>();
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (gh + AHEAD + 1 < H) stage_pixels(hb);
-        const bool next = gh + 1 < H;
-        if (next) { pf[0] = lds_frag<0>(pn); pf[1] = lds_frag<1024>(pn); pf[2] = lds_frag<2048>(pn); pf[3] = lds_frag<3072>(pn); }
-        __builtin_amdgcn_sched_barrier(0);
-#define U2_T_JB(I)                                                                                                 \
-  do {                                                                                                             \
-    __builtin_amdgcn_s_setprio(1);                                                                                 \
-    _Pragma("unroll") for (int j = 4; j < 8; ++j) U2_T_MFMA(I, wf2[0][I], j);                                      \
-    __builtin_amdgcn_s_setprio(0);                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                                             \
-    if (next) wf2[0][I] = lds_frag<I * 1024>(wn);                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                             \
-  } while (0)
-        U2_T_JB(0); U2_T_JB(1); U2_T_JB(2); U2_T_JB(3);
-#undef U2_T_JB
-      } else {
       // phase A
       __builtin_amdgcn_s_setprio(1);
       U2_T_MFMA(0, wfA[0], 0); U2_T_MFMA(1, wfA[1], 0); U2_T_MFMA(0, wfA[0], 1); U2_T_MFMA(1, wfA[1], 1);
@@ -428,7 +360,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       __builtin_amdgcn_sched_barrier(0);
       pf[4] = ldp(hb, 4); pf[5] = ldp(hb, 5); pf[6] = ldp(hb, 6); pf[7] = ldp(hb, 7);
       wfB[0] = ldw(hb, 2); wfB[1] = ldw(hb, 3);
-      if ((ABL & 1) == 0 && gh + AHEAD < H) stage_weights(sb);
+      if (gh + AHEAD < H) stage_weights(sb);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
       U2_T_MFMA(0, wfA[0], 2); U2_T_MFMA(1, wfA[1], 2); U2_T_MFMA(0, wfA[0], 3); U2_T_MFMA(1, wfA[1], 3);
@@ -436,7 +368,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       for (int j = 4; j < 8; ++j) { U2_T_MFMA(0, wfA[0], j); U2_T_MFMA(1, wfA[1], j); }
       __builtin_amdgcn_s_setprio(0);
       // phase B
-      if constexpr ((ABL & 1) == 0) {
+      {
         const int rem = H - 2 - gh;  // half tiles staged behind gh + 1
         if (rem >= AHEAD - 1) wait_vm<LPT * (AHEAD - 1)>();
         else if (AHEAD > 3 && rem == 2) wait_vm<LPT * 2>();
@@ -444,9 +376,9 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
         else wait_vm<0>();
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if constexpr ((ABL & 2) == 0) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if ((ABL & 1) == 0 && gh + AHEAD + 1 < H) stage_pixels(hb);
+      if (gh + AHEAD + 1 < H) stage_pixels(hb);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -462,7 +394,6 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #pragma unroll
       for (int j = 4; j < 8; ++j) { U2_T_MFMA(2, wfB[0], j); U2_T_MFMA(3, wfB[1], j); }
       __builtin_amdgcn_s_setprio(0);
-      }
       ++gh;
       hb = nb;
     }
@@ -472,7 +403,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #undef U2_T_MFMA
 }
 
-template <int WCH, int WPX, int RING, bool JSPLIT, int ABL = 0>
+template <int WCH, int WPX, int RING>
 int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s) {
   constexpr int TN = WCH * 64, TM = WPX * 128;
   constexpr int LDS = RING * (TM + TN) * 64;
@@ -485,10 +416,10 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s) {
   G = (G + 7) & ~7LL;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, JSPLIT, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, JSPLIT, ABL>), dim3((unsigned)G), dim3(WCH * WPX * 64), LDS, s, a);
+  hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING>), dim3((unsigned)G), dim3(WCH * WPX * 64), LDS, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return -1000 - (int)e;
   return 1;
@@ -498,8 +429,10 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s) {
 
 // variant bits 12-15 select the tile configuration: 0 = automatic, 1 = 256ch x 256px ring 4, 2 = 256 x 256 ring 5,
 // 3 = 128ch x 256px (ring 3, two groups per CU), 4 = 256ch x 128px (ring 3, two groups per CU), 5 = 128ch x 256px ring 4,
-// 6 / 7 = configurations 1 / 2 with the j-split schedule, 15 = never (conv_igemm.hip kernels only);
-// bit 16: 8 work-groups only (tests: forces several tiles per work-group).
+// 15 = never (conv_igemm.hip kernels only); bit 16: 8 work-groups only (tests: forces several tiles per work-group).
+// Tried and removed (numbers in profiles/r02_conv_ablation.txt, r02_conv_pingpong.txt): a j-split schedule
+// with every LDS read 12+ MFMAs ahead of its use (+0 %), and a ping-pong schedule with the two wave groups half a sequence
+// apart (-8 %).
 int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   int sel = (variant >> 12) & 15;
   const int tiny = (variant >> 16) & 1;
@@ -530,26 +463,26 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
     }
     if (sel == 0) return 0;
   }
-  const int ring = (sel == 2 || sel >= 7) ? 5 : (sel == 1 || sel == 5 || sel == 6) ? 4 : 3;
+  if (sel > 5) return 0;
+  int ring = (sel == 2) ? 5 : (sel == 1 || sel == 5) ? 4 : 3;
   if (nkh < ring) {
-    if (nkh >= 3 && (variant >> 12 & 15) == 0) { sel = (N <= 128) ? 3 : 4; }  // automatic mode: the ring-3 configurations serve K >= 96
-    else return 0;
+    // a work-group only needs RING half tiles over ALL the tiles it walks; in automatic mode fall back to the ring-3
+    // configurations (K >= 64 with two or more tiles per work-group, K >= 96 otherwise)
+    if ((variant >> 12 & 15) != 0) return 0;
+    sel = (N <= 128) ? 3 : 4;
+    ring = 3;
+    const int TN = sel == 3 ? 128 : 256, TM = sel == 3 ? 256 : 128;
+    const long long T = (long long)((a.M + TM - 1) / TM) * ((N + TN - 1) / TN);
+    const long long min_tiles = (T >> 3) / 64;  // 512 work-groups: 64 per XCD
+    if (nkh * min_tiles < ring) return 0;
   }
   g_last_conv_kernel = 100 + sel;
   switch (sel) {
-    case 1: return launch_cfg<4, 2, 4, false>(a, N, 1, tiny, s);
-    case 2: return launch_cfg<4, 2, 5, false>(a, N, 1, tiny, s);
-    case 3: return launch_cfg<2, 2, 3, false>(a, N, 2, tiny, s);
-    case 4: return launch_cfg<4, 1, 3, false>(a, N, 2, tiny, s);
-    case 5: return launch_cfg<2, 2, 4, false>(a, N, 1, tiny, s);
-    case 6: return launch_cfg<4, 2, 4, true>(a, N, 1, tiny, s);
-    case 7: return launch_cfg<4, 2, 5, true>(a, N, 1, tiny, s);
-    case 8: return launch_cfg<4, 2, 5, false, 1>(a, N, 1, tiny, s);   // ablations (wrong results): no LDS-DMA after the prologue
-    case 9: return launch_cfg<4, 2, 5, false, 3>(a, N, 1, tiny, s);   // ... and no barrier
-    case 10: return launch_cfg<4, 2, 5, false, 4>(a, N, 1, tiny, s);  // everything but the MFMAs
-    case 11: return launch_cfg<4, 2, 5, false, 2>(a, N, 1, tiny, s);  // no barrier (racy)
-    case 12: return launch_cfg<4, 2, 5, false, 12>(a, N, 1, tiny, s); // no MFMAs, and every 128-byte line visited once (64-channel stride)
-    case 13: return launch_cfg<4, 2, 5, false, 8>(a, N, 1, tiny, s);  // 64-channel stride with MFMAs
+    case 1: return launch_cfg<4, 2, 4>(a, N, 1, tiny, s);
+    case 2: return launch_cfg<4, 2, 5>(a, N, 1, tiny, s);
+    case 3: return launch_cfg<2, 2, 3>(a, N, 2, tiny, s);
+    case 4: return launch_cfg<4, 1, 3>(a, N, 2, tiny, s);
+    case 5: return launch_cfg<2, 2, 4>(a, N, 1, tiny, s);
     default: return 0;
   }
 }
