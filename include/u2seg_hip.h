@@ -78,6 +78,10 @@ int u2_bn_finalize_fwd(const float* sums, float count, const float* count_dev, c
                        float* shift, int C, void* stream);
 int u2_affine_act(const void* x, const float* scale, const float* shift, const void* resid, void* out, int slots,
                   int rows_per_slot, int C, int ld, int relu, void* stream);
+/* backbone/fpn.py:141-158 in one pass: out = bf16(x * scale + shift) + nearest_x2(top), top [B][H/2][W/2][C]: the lateral conv's
+ * BatchNorm apply fused with the top-down upsample-add (bit-identical to u2_affine_act followed by u2_fpn_upsample_add_fwd). */
+int u2_affine_upadd(const void* x, const float* scale, const float* shift, const void* top, void* out, int B, int H, int W,
+                    int C, int relu, void* stream);
 int u2_norm_bwd_reduce(const void* dout, const void* mask, const void* x, const float* mean, const float* invstd,
                        float* out /*[slots][2][C]*/, int slots, int rows_per_slot, int C, int ld, int relu,
                        const float* mask_scale, const float* mask_shift, const void* dout2, void* dz_out, void* stream);

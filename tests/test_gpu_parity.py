@@ -1341,3 +1341,67 @@ def test_sgd_trajectory_vs_reference(F, branch):
     for k, v in fx["running_mean_norm"].items():
         assert float(sd[k].double().norm()) == pytest.approx(v, rel=5e-2), k
     assert int(sd["backbone.bottom_up.stem.conv1.norm.num_batches_tracked"]) == fx["num_batches_tracked"] == fx["steps"]
+
+
+def test_fpn_lateral_upsample_fusion_is_bit_identical(F):
+    """backbone/fpn.py:141-158 fused (u2_affine_upadd inside the lateral's BatchNorm apply) vs the two separate passes
+    (BatchNorm apply, then nearest x2 + add): the same bits forward, the same gradients for the lateral's input, the coarser
+    level and the affine parameters."""
+    from u2seg_amd.layers.modules import BatchNorm2d, Conv2d
+
+    g = torch.Generator().manual_seed(4)
+    conv = Conv2d(64, 96, kernel_size=1, bias=False, norm=BatchNorm2d(96)).to(DEV).train()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.2)
+        conv.norm.weight.copy_(1 + 0.3 * torch.randn(96, generator=g))
+        conv.norm.bias.copy_(0.2 * torch.randn(96, generator=g))
+    x = nhwc(torch.randn((2, 64, 12, 20), generator=g))
+    top = nhwc(torch.randn((2, 96, 6, 10), generator=g))
+    gy = nhwc(torch.randn((2, 96, 12, 20), generator=g))
+    outs = []
+    for fused in (True, False):
+        xi, ti = x.clone().requires_grad_(True), top.clone().requires_grad_(True)
+        conv.zero_grad()
+        y = conv(xi, residual_up=ti) if fused else F.fpn_upsample_add(conv(xi), ti)
+        y.backward(gy)
+        outs.append((y.detach().clone(), xi.grad.clone(), ti.grad.clone(), conv.norm.weight.grad.clone(), conv.norm.bias.grad.clone(),
+                     conv.weight.grad.clone()))
+    for i, (a, b) in enumerate(zip(*outs)):
+        if i in (0, 2):  # the fused output and the coarser level's gradient (2x2 sums of the incoming gradient): the same bits
+            assert torch.equal(a, b), i
+        elif i == 1:     # behind the BatchNorm backward, whose column sums are fp32 atomics (order-dependent last bits)
+            assert rel_err(a.float().cpu(), b.float().cpu()) < 1e-2, i
+        else:            # parameter gradients: fp32 atomics as well
+            assert rel_err(a.float().cpu(), b.float().cpu()) < 1e-2, i
+    ref = bf(bf(TF.batch_norm(bf(TF.conv2d(nchw(x, 64), bf(conv.weight.detach().cpu()))), None, None, conv.norm.weight.detach().cpu(),
+                               conv.norm.bias.detach().cpu(), True, 0.1, 1e-5)) + TF.interpolate(nchw(top, 96), scale_factor=2.0, mode="nearest"))
+    assert rel_err(nchw(outs[0][0], 96), ref) < 1e-2
+
+
+def test_r50_300_config_builds_and_steps(F):
+    """BASELINE.json configuration 4's model file (u2seg_R50_300.yaml: 300 pseudo classes) through the HIP path: build, one
+    training step with finite losses and the 300-way heads, one inference call."""
+    from u2seg_amd.config import get_cfg
+    from u2seg_amd.data import make_synthetic_batch
+    from u2seg_amd.engine import SimpleTrainer
+    from u2seg_amd.modeling import build_model
+    from u2seg_amd.solver import build_optimizer
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "COCO-PanopticSegmentation", "u2seg_R50_300.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", DEV])
+    assert cfg.MODEL.ROI_HEADS.NUM_CLASSES == 300
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model.train()
+    assert model.roi_heads.box_predictor[0].cls_score.weight.shape[0] == 301
+    assert model.roi_heads.mask_head.predictor.weight.shape[0] == 300
+    trainer = SimpleTrainer(model, build_optimizer(cfg, model))
+    losses = trainer.run_step(make_synthetic_batch(2, height=256, width=320, num_thing_classes=300, device=DEV))
+    assert len(losses) == 10 and trainer.check_finite() > 0
+    model.eval()
+    with torch.no_grad():
+        out = model([{k: v for k, v in x.items() if k != "instances"} for x in make_synthetic_batch(1, height=256, width=320, device=DEV)])
+    assert out[0]["sem_seg"].shape[1:] == (256, 320)
+    cls = out[0]["instances"].pred_classes
+    assert cls.numel() == 0 or int(cls.max()) < 300

@@ -31,5 +31,5 @@ for e in ev:
     k = (e.name, site); agg[k][0] += e.self_device_time_total; agg[k][1] += 1
 tot = sum(v[0] for v in agg.values())
 print("ATen self device time total %.2f ms" % (tot / 1e3))
-for (n, s), (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
+for (n, s), (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:130]:
     print("%8.3f ms %5d  %-28s %s" % (t / 1e3, c, n, s))

@@ -278,6 +278,37 @@ __global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __re
   }
 }
 
+// FPN top-down step fused with the lateral's normalisation (backbone/fpn.py:141-158): out = (x * scale + shift) + nearest_x2(top).
+// The normalised lateral is rounded to bf16 before the sum, exactly as the two separate passes (and the reference's bf16
+// autocast tensors) round it, so the fusion does not change a single bit of the result.
+__global__ __launch_bounds__(256) void affine_upadd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const bf16_t* __restrict__ top,
+                                                           bf16_t* __restrict__ out, int B, int H, int W, int C, int relu) {
+  const int cpr = C >> 3;
+  const int Wt = W >> 1, Ht = H >> 1;
+  const size_t total = (size_t)B * H * W * cpr;
+  const bool nt = (size_t)B * H * W * C * 2 > NT_BYTES;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / cpr;
+    const int c = (int)(i - row * cpr) * 8;
+    const int xw = (int)(row % W);
+    const size_t t = row / W;
+    const int y = (int)(t % H), b = (int)(t / H);
+    const uint4 xq = ld_stream(x + row * C + c, nt);
+    const uint4 tq = *reinterpret_cast<const uint4*>(top + (((size_t)b * Ht + (y >> 1)) * Wt + (xw >> 1)) * C + c);
+    const bf16_t* xv = reinterpret_cast<const bf16_t*>(&xq);
+    const bf16_t* tv = reinterpret_cast<const bf16_t*>(&tq);
+    bf16_t ov[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = bf2f(f2bf(bf2f(xv[e]) * scale[c + e] + shift[c + e])) + bf2f(tv[e]);
+      if (relu) f = fmaxf(f, 0.f);
+      ov[e] = f2bf(f);
+    }
+    st_stream(out + row * C + c, *reinterpret_cast<const uint4*>(ov), nt);
+  }
+}
+
 // MASK: 0 no ReLU, 1 read the activation, 2 recompute x*ms + mh > 0
 template <int MASK, bool DRES>
 __global__ __launch_bounds__(256) void norm_bwd_apply_fast_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ mask,
@@ -569,6 +600,17 @@ extern "C" int u2_affine_act(const void* x, const float* scale, const float* shi
   }
   hipLaunchKernelGGL(affine_act_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      scale, shift, (const bf16_t*)resid, (bf16_t*)out, rows_per_slot, M, C, ld, relu);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_affine_upadd(const void* x, const float* scale, const float* shift, const void* top, void* out, int B, int H,
+                               int W, int C, int relu, void* stream) {
+  if ((C & 7) || (H & 1) || (W & 1)) return -1;
+  const size_t total = (size_t)B * H * W * (C >> 3);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(affine_upadd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, scale, shift,
+                     (const bf16_t*)top, (bf16_t*)out, B, H, W, C, relu);
   U2_CHECK_LAUNCH();
   return 0;
 }

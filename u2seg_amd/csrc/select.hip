@@ -83,6 +83,26 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_rows_kernel(const SelectArgs
     return order_bits(u, a.largest, a.dtype);
   };
 
+  // one sweep over the participating elements of the row, eight independent loads per thread in flight (a row is streamed by a
+  // single work-group: the sweep is latency-bound, not bandwidth-bound)
+  auto for_each_key = [&](auto&& fn) {
+    constexpr int UNR = 8;
+    for (int base = 0; base < n; base += UNR * SEL_THREADS) {
+      uint32_t vk[UNR];
+      bool ok[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int i = base + u * SEL_THREADS + tid;
+        ok[u] = false;
+        vk[u] = 0;
+        if (i < n) vk[u] = load_key(i, ok[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+        if (ok[u]) fn(base + u * SEL_THREADS + tid, vk[u]);
+    }
+  };
+
   // ---- most-significant-digit radix selection of the k-th largest 64-bit key (value key : ~index).  `prefix` holds the
   // `fixed` high bits decided so far, `want` how many elements of the bucket that shares them are still to be taken.
   // Key bits 63..32 = value (bf16: bits 47..32 are zero for every element), 31..24 = 0xff (index < 2^24), 23..0 = ~index.
@@ -96,14 +116,10 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_rows_kernel(const SelectArgs
     for (int b = tid; b < 256; b += SEL_THREADS) hist[b] = 0;
     __syncthreads();
     const unsigned long long hi_mask = fixed == 0 ? 0ull : (~0ull << (64 - fixed));
-    for (int i = tid; i < n; i += SEL_THREADS) {
-      bool ok;
-      const uint32_t vk = load_key(i, ok);
-      if (!ok) continue;
+    for_each_key([&](int i, uint32_t vk) {
       const unsigned long long key = ((unsigned long long)vk << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
-      if ((key & hi_mask) != prefix) continue;
-      atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
-    }
+      if ((key & hi_mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+    });
     __syncthreads();
     if (tid == 0) {
       unsigned total = 0;
@@ -144,10 +160,7 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_rows_kernel(const SelectArgs
   for (int i = tid; i < a.cap; i += SEL_THREADS) sel[i] = 0ull;
   if (tid == 0) hist[261] = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += SEL_THREADS) {
-    bool ok;
-    const uint32_t vk = load_key(i, ok);
-    if (!ok) continue;
+  for_each_key([&](int i, uint32_t vk) {
     const unsigned long long key = ((unsigned long long)vk << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
     // with `fixed` high bits decided, an element is taken iff its high bits are >= the prefix (== prefix: it lies in the
     // bucket that is taken whole; > prefix: ranked above)
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_rows_kernel(const SelectArgs
       const unsigned pos = atomicAdd(&hist[261], 1u);
       if (pos < (unsigned)a.cap) sel[pos] = key;
     }
-  }
+  });
   __syncthreads();
   const int got = min((int)hist[261], a.k);
 

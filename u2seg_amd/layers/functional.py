@@ -272,7 +272,7 @@ class _BatchNormActFn(Function):
 
     @staticmethod
     def forward(ctx, y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, grad_dst=None,
-                twin=False, sync=True):
+                twin=False, sync=True, res_up=False):
         _check_act(y)
         b, h, w, c = y.shape
         m = b * h * w
@@ -291,13 +291,19 @@ class _BatchNormActFn(Function):
         _hip.call("u2_bn_finalize_fwd", stats, count, count_dev, gamma, beta, running_mean, running_var, momentum, eps, mean,
                   invstd, scale, shift, c)
         out = torch.empty_like(y)
-        _hip.call("u2_affine_act", y, scale, shift, residual, out, 1, m, c, c, int(relu))
+        if res_up:
+            # FPN top-down step (backbone/fpn.py:153-155): the residual is the coarser level, nearest-upsampled on the fly
+            assert residual is not None and not relu and tuple(residual.shape) == (b, h // 2, w // 2, c)
+            _hip.call("u2_affine_upadd", y, scale, shift, residual.contiguous(), out, b, h, w, c, 0)
+        else:
+            _hip.call("u2_affine_act", y, scale, shift, residual, out, 1, m, c, c, int(relu))
         # ReLU mask in backward: without a residual it is recomputed from y (one activation read less per pass)
         remask = relu and residual is None
         ctx.save_for_backward(y, out if (relu and not remask) else None, gamma, mean, invstd,
                               scale if remask else None, shift if remask else None)
         ctx.cfg = (relu, count, world, residual is not None)
         ctx.count_dev = count_dev
+        ctx.res_up = res_up
         ctx.grad_dst = grad_dst  # (dgamma, dbeta) arena slices or None
         ctx.twin = twin
         if twin:  # two handles on the same activation: their gradients arrive separately and are summed in the kernel
@@ -311,7 +317,7 @@ class _BatchNormActFn(Function):
         relu, count, world, has_res = ctx.cfg
         b, h, w, c = y.shape
         m = b * h * w
-        nret = 13
+        nret = 14
         if dout is None:
             dout, dout2 = dout2, None
         if dout is None:
@@ -339,23 +345,27 @@ class _BatchNormActFn(Function):
             _hip.call("u2_norm_bwd_apply", dz, None, y, coef[2], coef[3], coef[4], dx, None, 1, m, c, c, 0, None, None)
             dres = dz
         else:
-            dres = torch.empty_like(y) if has_res else None
+            dres = torch.empty_like(y) if (has_res and not ctx.res_up) else None
             _hip.call("u2_norm_bwd_apply", dout, out, y, coef[2], coef[3], coef[4], dx, dres, 1, m, c, c, int(relu), msc, msh)
+            if ctx.res_up:  # gradient of the coarser level: the 2x2 sums of dout
+                dres = torch.empty((b, h // 2, w // 2, c), dtype=BF16, device=y.device)
+                _hip.call("u2_fpn_upsample_add_bwd", dout, dres, b, h, w, c)
         if direct:
             dgamma = dbeta = None
-        return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
+        return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
 
 
 def batch_norm_act(y, stats, gamma, beta, running_mean, running_var, residual=None, relu=False, momentum=0.1,
-                   eps=1e-5, twin=False, sync=True):
+                   eps=1e-5, twin=False, sync=True, res_up=False):
     """twin=True: returns the activation with a second autograd handle on the same memory in `._u2_twin` (for a consumer
     pair such as the next residual block's conv1 and identity shortcut); the two gradients are summed inside the
-    backward kernel instead of by autograd.  sync=False: per-process statistics (NORM "BN"), no all-reduce."""
+    backward kernel instead of by autograd.  sync=False: per-process statistics (NORM "BN"), no all-reduce.
+    res_up=True: `residual` is the next coarser FPN level [B, H/2, W/2, C], nearest-upsampled inside the same pass."""
     gd, bd = grad_slot(gamma), grad_slot(beta)
     grad_dst = (gd, bd) if gd is not None and bd is not None else None
     twin = bool(twin) and torch.is_grad_enabled()
     out = _BatchNormActFn.apply(y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, grad_dst,
-                                twin, sync)
+                                twin, sync, res_up)
     if twin:
         out, other = out
         out._u2_twin = other

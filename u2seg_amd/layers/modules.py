@@ -135,7 +135,11 @@ class Conv2d(nn.Module):
         assert activation in (None, "relu"), "only ReLU is fused (the U2Seg graph uses nothing else)"
         self.activation = activation
 
-    def forward(self, x, residual=None, relu=None, twin=False):
+    def forward(self, x, residual=None, relu=None, twin=False, residual_up=None):
+        """residual_up: the coarser FPN level to add nearest-upsampled (fused into the BatchNorm apply in training)."""
+        if residual_up is not None and not (isinstance(self.norm, BatchNorm2d) and self.training):
+            assert residual is None
+            return F.fpn_upsample_add(self.forward(x, None, relu, twin), residual_up)
         relu = (self.activation == "relu") if relu is None else relu
         norm = self.norm
         if norm is None:
@@ -145,6 +149,10 @@ class Conv2d(nn.Module):
         if isinstance(norm, BatchNorm2d) and self.training:
             y, stats = F.conv2d(x, self.weight, None, self.stride, self.padding, relu=False, want_stats=True)
             norm.count_batch()
+            if residual_up is not None:
+                assert residual is None
+                return F.batch_norm_act(y, stats, norm.weight, norm.bias, norm.running_mean, norm.running_var, residual_up,
+                                        relu, norm.momentum, norm.eps, twin=twin, sync=norm.sync, res_up=True)
             return F.batch_norm_act(y, stats, norm.weight, norm.bias, norm.running_mean, norm.running_var, residual,
                                     relu, norm.momentum, norm.eps, twin=twin, sync=norm.sync)
         y = F.conv2d(x, self.weight, None, self.stride, self.padding, relu=False)

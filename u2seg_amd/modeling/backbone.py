@@ -218,8 +218,8 @@ class FPN(Backbone):
         results.append(self.output_convs[0](prev))
         for idx, (lateral_conv, output_conv) in enumerate(zip(self.lateral_convs, self.output_convs)):
             if idx > 0:
-                lateral = lateral_conv(bottom_up_features[self.in_features[-idx - 1]])
-                prev = F.fpn_upsample_add(lateral, prev)
+                # lateral 1x1 + its norm + nearest x2 of the coarser level + add: one pass over the map (fpn.py:141-158)
+                prev = lateral_conv(bottom_up_features[self.in_features[-idx - 1]], residual_up=prev)
                 results.insert(0, output_conv(prev))
         if self.top_block is not None:
             top_in = results[self._out_features.index(self.top_block.in_feature)]
