@@ -185,6 +185,11 @@ int u2_topk_rows(const void* vals, int dtype, int rows, int n, long long row_str
 
 /* ---- inference tails (postprocess.hip) -------------------------------------------------------
  * layers/mask_ops.py:17-147 (paste_masks_in_image, GPU branch), meta_arch/panoptic_fpn.py:184-269. */
+/* meta_arch/semantic_seg.py:240-244 + panoptic_fpn.py:173 at inference: logits [B][H][W][Cp] NHWC bf16 (K valid channels) ->
+ * out (optional) fp32 NCHW [B][K][H*S][W*S] = F.interpolate(logits.float(), scale_factor=S, mode="bilinear",
+ * align_corners=False) and argmax (optional) int64 [B][H*S][W*S] = out.argmax(1) (first maximum), one pass. */
+int u2_semseg_upsample(const void* logits, float* out, long long* argmax, int B, int H, int W, int Cp, int K, int S,
+                       void* stream);
 /* out[k][y][x] (uint8 0/1) = bilinear sample of probs[k] (P x P fp32) on F.grid_sample(align_corners=False)'s grid over
  * boxes[k] = (x0, y0, x1, y1), zero outside the map, >= threshold. */
 int u2_paste_masks(const float* probs, const float* boxes, void* out, int n, int P, int H, int W, float threshold,

@@ -1405,3 +1405,22 @@ def test_r50_300_config_builds_and_steps(F):
     assert out[0]["sem_seg"].shape[1:] == (256, 320)
     cls = out[0]["instances"].pred_classes
     assert cls.numel() == 0 or int(cls.max()) < 300
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 64, 64, 54), (1, 200, 336, 64, 54), (3, 7, 5, 32, 3)])
+def test_sem_seg_inference_upsample_and_argmax(F, shape):
+    """meta_arch/semantic_seg.py:240-244 (F.interpolate x4, bilinear, align_corners=False) and panoptic_fpn.py:173
+    (argmax over classes) in one kernel: logits to 1e-5 of ATen's fp32 resampling of the same bf16 map; argmax equal
+    wherever ATen's top-2 margin is above the resampling round-off."""
+    b, h, w, cp, k = shape
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.randn(b, h, w, cp, device="cuda", generator=g) * 3).to(torch.bfloat16)
+    ref = TF.interpolate(x[..., :k].permute(0, 3, 1, 2).float(), scale_factor=4, mode="bilinear", align_corners=False)
+    out, amax = F.sem_seg_upsample(x, k, 4)
+    assert out.shape == ref.shape and amax.shape == (b, h * 4, w * 4) and amax.dtype == torch.int64
+    assert (out - ref).abs().max().item() < 1e-5
+    assert torch.equal(amax, out.argmax(dim=1))  # the kernel's argmax is the argmax of the logits it wrote
+    top2 = ref.topk(min(2, k), dim=1).values
+    decided = (top2[:, 0] - top2[:, -1]) > 1e-4 if k > 1 else torch.ones_like(amax, dtype=torch.bool)
+    assert torch.equal(amax[decided], ref.argmax(dim=1)[decided])
+    assert decided.float().mean().item() > 0.99

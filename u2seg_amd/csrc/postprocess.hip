@@ -198,6 +198,75 @@ extern "C" int u2_panoptic_merge(const U2PanopticImage* images, int n_images, fl
   return 0;
 }
 
+
+namespace {
+// ------------------------------------------------------------------------------------------------
+// Semantic head at inference: F.interpolate(logits.float(), scale_factor = S, mode = "bilinear", align_corners = False)
+// (meta_arch/semantic_seg.py:240-244) and the per-pixel argmax PanopticFPN.inference takes of it (panoptic_fpn.py:173), in one
+// pass over the low-resolution NHWC bf16 logits: the S-times upsampled fp32 NCHW logits are written once (the caller's
+// "sem_seg" result) and the argmax map with them, so the 3.9 GB of a batch-32 result are never read back.
+// Arithmetic = ATen's upsample_bilinear2d: src = max((dst + 0.5) / S - 0.5, 0); i0 = floor(src); i1 = i0 + (i0 < n - 1);
+// value = l0y * (l0x * v00 + l1x * v01) + l1y * (l0x * v10 + l1x * v11), fp32, contraction off.
+// ------------------------------------------------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(256) void semseg_upsample_kernel(const bf16_t* __restrict__ x, float* __restrict__ out,
+                                                              long long* __restrict__ amax, int B, int H, int W, int Cp, int K,
+                                                              int S) {
+  const int Ho = H * S, Wo = W * S;
+  const float inv = 1.0f / (float)S;
+  const size_t total = (size_t)B * Ho * Wo;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ox = (int)(i % Wo);
+    const size_t t = i / Wo;
+    const int oy = (int)(t % Ho), b = (int)(t / Ho);
+    const float sy = fmaxf(inv * ((float)oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(inv * ((float)ox + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const bf16_t* base = x + (size_t)b * H * W * Cp;
+    const bf16_t* p00 = base + ((size_t)y0 * W + x0) * Cp;
+    const bf16_t* p01 = base + ((size_t)y0 * W + x1) * Cp;
+    const bf16_t* p10 = base + ((size_t)y1 * W + x0) * Cp;
+    const bf16_t* p11 = base + ((size_t)y1 * W + x1) * Cp;
+    float best = 0.f;
+    int besti = 0;
+#pragma unroll
+    for (int c8 = 0; c8 < KMAX; c8 += 8) {
+      if (c8 >= K) break;
+      bf16_t v00[8], v01[8], v10[8], v11[8];
+      *reinterpret_cast<uint4*>(v00) = *reinterpret_cast<const uint4*>(p00 + c8);
+      *reinterpret_cast<uint4*>(v01) = *reinterpret_cast<const uint4*>(p01 + c8);
+      *reinterpret_cast<uint4*>(v10) = *reinterpret_cast<const uint4*>(p10 + c8);
+      *reinterpret_cast<uint4*>(v11) = *reinterpret_cast<const uint4*>(p11 + c8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = c8 + e;
+        if (c >= K) break;
+        const float f = hy * (hx * bf2f(v00[e]) + lx * bf2f(v01[e])) + ly * (hx * bf2f(v10[e]) + lx * bf2f(v11[e]));
+        if (out) out[(((size_t)b * K + c) * Ho + oy) * Wo + ox] = f;
+        if (c == 0 || f > best) { best = f; besti = c; }  // first maximum wins, like torch.argmax
+      }
+    }
+    if (amax) amax[i] = besti;
+  }
+}
+
+}  // namespace
+
+extern "C" int u2_semseg_upsample(const void* logits, float* out, long long* argmax, int B, int H, int W, int Cp, int K, int S,
+                                  void* stream) {
+  if ((Cp & 7) || K < 1 || K > Cp || K > 64 || S < 1) return -1;
+  const size_t total = (size_t)B * H * S * W * S;
+  if (!total) return 0;
+  size_t g = (total + 255) / 256;
+  if (g > 256 * 32) g = 256 * 32;
+  hipLaunchKernelGGL(semseg_upsample_kernel<64>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, out,
+                     argmax, B, H, W, Cp, K, S);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int u2_paste_masks(const float* probs, const float* boxes, void* out, int n, int P, int H, int W, float threshold,
                               void* stream) {
   if (n <= 0 || H <= 0 || W <= 0) return 0;

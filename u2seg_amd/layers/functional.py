@@ -826,6 +826,17 @@ def iou_match(boxes, gt, ngt, lo, hi, allow_low_quality):
     return match, labels, mval
 
 
+def sem_seg_upsample(x, num_classes, scale):
+    """x [B, H, W, Cp] bf16 -> (fp32 [B, num_classes, H*scale, W*scale] bilinear-upsampled logits, int64 [B, H*scale, W*scale]
+    argmax) (u2_semseg_upsample; inference only)."""
+    _check_act(x)
+    b, h, w, cp = x.shape
+    out = torch.empty((b, num_classes, h * scale, w * scale), dtype=torch.float32, device=x.device)
+    amax = torch.empty((b, h * scale, w * scale), dtype=torch.int64, device=x.device)
+    _hip.call("u2_semseg_upsample", x, out, amax, b, h, w, cp, num_classes, int(scale))
+    return out, amax
+
+
 def topk_rows(vals, k, largest=True, mask=None, mask_value=1, group=1, pitch=1, n=None, want_vals=True):
     """Row-wise selection with a total order (u2_topk_rows): the k best of every row ranked by (value descending if
     `largest` else ascending, index ascending).  vals: [rows, n] fp32 / bf16 contiguous, or - with group / pitch / n - the

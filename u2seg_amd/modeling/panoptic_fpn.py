@@ -162,14 +162,20 @@ class PanopticFPN(GeneralizedRCNN):
             return detector_results, sem_seg_results
         out_sizes = [(inp.get("height", size[0]), inp.get("width", size[1])) for inp, size in zip(batched_inputs, image_sizes)]
         detector_rs = detector_postprocess_batch(detector_results, out_sizes)
-        processed = []
-        for sem_seg_result, detector_r, image_size, (height, width) in zip(sem_seg_results, detector_rs, image_sizes, out_sizes):
+        processed, sem_argmax = [], []
+        fused_argmax = getattr(sem_seg_results, "u2_argmax", None)
+        for i, (sem_seg_result, detector_r, image_size, (height, width)) in enumerate(zip(sem_seg_results, detector_rs, image_sizes,
+                                                                                         out_sizes)):
             sem_seg_r = sem_seg_postprocess(sem_seg_result, image_size, height, width)
             processed.append({"sem_seg": sem_seg_r, "instances": detector_r})
+            if fused_argmax is not None and (height, width) == tuple(image_size):
+                sem_argmax.append(fused_argmax[i, : image_size[0], : image_size[1]])  # no second resampling: the kernel's argmax
+            else:
+                sem_argmax.append(sem_seg_r.argmax(dim=0))
         # the merge of all images: one launch, one host synchronisation (the reference loops and syncs per instance)
         mask_res = 2 * self.roi_heads.mask_pooler.output_size if getattr(self.roi_heads, "mask_on", False) else 0
         merged = combine_semantic_and_instance_outputs_batch(
-            [p["instances"] for p in processed], [p["sem_seg"].argmax(dim=0) for p in processed], self.combine_overlap_thresh,
+            [p["instances"] for p in processed], sem_argmax, self.combine_overlap_thresh,
             self.combine_stuff_area_thresh, self.combine_instances_score_thresh, mask_res)
         for p, panoptic_r in zip(processed, merged):
             p["panoptic_seg"] = panoptic_r

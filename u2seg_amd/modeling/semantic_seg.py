@@ -88,8 +88,10 @@ class SemSegFPNHead(nn.Module):
         if self.training:
             loss = F.sem_seg_loss(x, targets_u8, self.num_classes, self.ignore_value)
             return None, {"loss_sem_seg": loss * self.loss_weight}
-        logits = x[..., : self.num_classes].permute(0, 3, 1, 2).float()
-        logits = torch.nn.functional.interpolate(logits, scale_factor=self.common_stride, mode="bilinear", align_corners=False)
+        # x4 bilinear (align_corners=False) of the fp32 logits and their argmax in one kernel; the argmax rides along on the
+        # result tensor for PanopticFPN.inference (panoptic_fpn.py:173), which would otherwise read the logits back
+        logits, argmax = F.sem_seg_upsample(x, self.num_classes, self.common_stride)
+        logits.u2_argmax = argmax
         return logits, {}
 
 
