@@ -71,6 +71,13 @@ int u2_weight_layout_batched(const float* base, const U2LayoutDesc* table, int n
 /* ---- normalisation / activation (norm.hip) ----------------------------------------------------
  * Replaces nn.SyncBatchNorm / nn.GroupNorm / relu_ chosen by detectron2/layers/batch_norm.py:169-197. */
 int u2_colstats(const void* x, float* out /*[slots][2][C]*/, int slots, int rows_per_slot, int C, int ld, void* stream);
+/* nn.GroupNorm finalize (layers/batch_norm.py:189 "GN", semantic_seg.py:196-205). fwd: stats [B][2][C] (u2_colstats per image)
+ * -> mean / invstd / scale / shift [B][C], n = H*W*(C/groups) elements per group. bwd: sums [B][2][C] (u2_norm_bwd_reduce)
+ * -> k1/k2/k3 [B][C] for u2_norm_bwd_apply and dgamma / dbeta [C] summed over the images in order. */
+int u2_gn_finalize_fwd(const float* stats, const float* gamma, const float* beta, float n, float eps, int B, int C, int groups,
+                       float* mean, float* invstd, float* scale, float* shift, void* stream);
+int u2_gn_finalize_bwd(const float* sums, const float* gamma, const float* mean, const float* invstd, float n, int B, int C,
+                       int groups, float* k1, float* k2, float* k3, float* dgamma, float* dbeta, void* stream);
 /* count: elements per channel behind `sums`; count_dev (optional, device, 1 float) overrides it - SyncBN all-reduces the
  * per-rank counts together with the sums, because ranks pad their batches to different sizes (nn.SyncBatchNorm does). */
 int u2_bn_finalize_fwd(const float* sums, float count, const float* count_dev, const float* gamma, const float* beta, float* running_mean,

@@ -215,7 +215,7 @@ static void bench2(int argc, char** argv, bool wgrad) {
   std::vector<int> variants;
   for (int i = 2; i < argc; ++i) variants.push_back((int)strtol(argv[i], nullptr, 0));
   if (variants.empty()) {
-    if (wgrad) variants = {2048, 0, 256};
+    if (wgrad) variants = {2048, 0, 256, 4096, 4096 | (1 << 14)};
     else variants = {15 << 12, 0, 1 << 12, 2 << 12, 3 << 12, 4 << 12, 5 << 12};
   }
   const size_t in_elems = (size_t)16 * 200 * 336 * 256, w_elems = (size_t)8192 * 8192, out_elems = (size_t)16 * 200 * 336 * 256;
@@ -275,6 +275,32 @@ int main(int argc, char** argv) {
     bench_conv("fpn_out2 3x3 256->256 B16", 16, 200, 336, 256, 256, 3, 1, 1, v);
     return 0;
   }
+  const WgCase halo_cases[] = {  // 3x3 / stride 1 / pad 1 only: wgrad_halo.hip (variant bit 12), bits 14-15 = rounds - 1
+      {2, 14, 14, 64, 64, 3, 3, 1, 1, "halo 14x14 c64 n64"},
+      {1, 13, 17, 128, 136, 3, 3, 1, 1, "halo 13x17 c128 n136"},
+      {3, 25, 42, 96, 200, 3, 3, 1, 1, "halo 25x42 c96 n200"},
+      {2, 40, 70, 64, 256, 3, 3, 1, 1, "halo 40x70 c64 n256"},
+      {2, 3, 11, 32, 8, 3, 3, 1, 1, "halo 3x11 c32 n8 (1 step)"},
+      {1, 5, 101, 32, 72, 3, 3, 1, 1, "halo 5x101 c32 n72 (2 steps)"},
+      {1, 8, 95, 64, 40, 3, 3, 1, 1, "halo 8x95 c64 n40 (3 steps)"},
+      {1, 12, 84, 32, 16, 3, 3, 1, 1, "halo 12x84 c32 n16 (4 steps)"},
+      {1, 5, 300, 32, 72, 3, 3, 1, 1, "halo 5x300 c32 n72"},
+  };
+  auto run_halo = [&]() {
+    int f = 0;
+    for (const auto& c : halo_cases) {
+      f += test_wgrad(c, 4096);
+      if (u2_conv_last_kernel() != 2900) { printf("FAIL %-28s did not take the halo kernel (%d)\n", c.name, u2_conv_last_kernel()); ++f; }
+      f += test_wgrad(c, 4096 | (1 << 14));
+      f += test_wgrad(c, 4096, true);
+    }
+    return f;
+  };
+  if (argc > 1 && !strcmp(argv[1], "halo")) {
+    fails = run_halo();
+    printf("SELFTEST halo %s (%d failures)\n", fails ? "FAILED" : "OK", fails);
+    return fails ? 1 : 0;
+  }
   hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs %d  abi %d\n", prop.gcnArchName, prop.multiProcessorCount, u2_abi_version());
   const ConvCase convs[] = {
@@ -318,6 +344,7 @@ int main(int argc, char** argv) {
   for (const auto& c : wgs) fails += test_wgrad(c, 256);
   for (const auto& c : wgs) fails += test_wgrad(c, 256, true);
   for (const auto& c : wgs) fails += test_wgrad(c, 0, true);
+  fails += run_halo();
   printf("SELFTEST %s (%d failures)\n", fails ? "FAILED" : "OK", fails);
   if (argc > 1 && !strcmp(argv[1], "bench")) {
     for (int v = 0; v < 1; ++v) {

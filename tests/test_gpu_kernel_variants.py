@@ -169,6 +169,28 @@ def test_wgrad_forced_variants(F, variant, code):
         assert rel_err(wd.grad.cpu(), w.grad) < 1e-2
 
 
+@pytest.mark.parametrize("variant", [4096, 4096 | (1 << 14)])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 14, 14), (1, 128, 136, 13, 17), (3, 96, 200, 25, 42), (2, 64, 256, 40, 70),
+                                   (2, 32, 8, 3, 11), (1, 32, 72, 5, 101)])
+def test_wgrad_halo_kernel(F, variant, shape):
+    """conv_wgrad_halo_kernel (3x3 / stride 1 / pad 1, all nine taps per work-group over padded pixel coordinates) forced on
+    small maps - every row wrap count (W + 1 < 16, < 32, >= 32), partial channel tiles, one to many steps per work-group -
+    vs fp32; the automatic dispatch only takes it from ~4000 positions per work-group (the full-shape test below)."""
+    b, cin, cout, h, w_ = shape
+    g = torch.Generator().manual_seed(h * 100 + w_ + variant)
+    x = bf(torch.randn((b, cin, h, w_), generator=g))
+    w = (torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5).requires_grad_(True)
+    yr = TF.conv2d(x, bf(w), None, 1, 1)
+    gy = bf(torch.randn(yr.shape, generator=g))
+    yr.backward(gy)
+    wd = w.detach().to(DEV).requires_grad_(True)
+    with forced(wgrad=variant):
+        y, _ = F._Conv2dFn.apply(nhwc(x), wd, None, 1, 1, False, False)
+        y.backward(nhwc(gy))
+        assert last_kernel() == 2900, last_kernel()
+    assert rel_err(wd.grad.cpu(), w.grad) < 1e-2
+
+
 def _sampled_conv_ref(x, w, bias, pos, pad):
     """fp32 conv outputs at sampled positions.  x [B,H,W,C] bf16 (GPU), w [N,C,KH,KW] fp32 (GPU, bf16-rounded by the caller),
     pos int64 [S,3] (b, y, x) -> [S, N] fp32."""
@@ -236,7 +258,7 @@ def test_conv_fpn_output2_backward_full_shape(F):
     with forced():
         y, _ = F._Conv2dFn.apply(x, wd, None, 1, 1, False, True)
         y.backward(gy)
-        assert last_kernel() in (2103, 2356), last_kernel()  # the wgrad ran last: XCD-grouped launch
+        assert last_kernel() == 2900, last_kernel()  # the wgrad ran last: nine-tap halo kernel (wgrad_halo.hip)
     # data gradient = conv of gy with the flipped, transposed filter
     wflip = bf(wt).flip(2, 3).permute(1, 0, 2, 3).contiguous().to(DEV)
     pos = torch.stack([torch.randint(0, b, (2048,), generator=g), torch.randint(0, h, (2048,), generator=g),

@@ -49,4 +49,10 @@ extern int g_last_conv_kernel;
 // not served (caller falls back to conv_igemm_kernel), -1000 - hipError_t on a launch failure.
 int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s);
 
+// wgrad_halo.hip: 3x3 / stride 1 / pad 1 weight gradient, all nine taps per work-group with the input halo in LDS; same
+// return convention as launch_conv_tile.  g_last_conv_kernel code: 2900.
+int launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* dw, long long dw_sn, int dw_st, int dw_sc, int n_valid,
+                      int c_valid, const bf16_t* zero, int B, int H, int W, int C, int x_ld, int N, int dy_ld, int rounds,
+                      int force, hipStream_t s);
+
 }  // namespace u2conv

@@ -1293,6 +1293,16 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
   // one resident work-group per CU the transposing reads of a step are not hidden behind anything, while four resident
   // 128 x 128 groups hide them behind each other, which outweighs the halved operand traffic.
   variant = env_variant("U2_WGRAD_VARIANT", variant);
+  // 3x3 / stride 1 / pad 1: all nine taps per work-group, input halo in LDS (wgrad_halo.hip); variant bit 12 forces it,
+  // bit 13 forbids it (as does any of the per-tap kernel's own variant bits 0-10), bits 14-15: rounds of work-groups (0 = one per CU);
+  // automatic when a work-group gets >= 4000 positions to reduce
+  const bool halo_ok = KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Hin == Hout && Win == Wout;
+  if (halo_ok && !(variant & 8192) && (variant & 0x7ff) == 0) {
+    const int rc = launch_wgrad_halo(a.x, a.dy, dw, dw_stride_n, dw_stride_tap, dw_stride_c, n_valid, c_valid, a.zero, B, Hin, Win,
+                                     C, x_ld, N, dy_ld, ((variant >> 14) & 3) + 1, (variant & 4096) ? 1 : 0, (hipStream_t)stream);
+    if (rc == 1) { g_last_conv_kernel = 2900; return 0; }
+    if (rc < 0) return rc;
+  }
   // 256 x 256 tiles (half the operand traffic per flop) win where nothing else hides the memory stream: 1x1 layers over the
   // stride-4 / stride-8 maps and the 7x7 "fully connected" fc1 (tests/native/selftest bench2w, profiles/r02_wgrad_variants.txt);
   // variant bit 8 forces them, bit 11 forbids them

@@ -378,6 +378,69 @@ static dim3 fast_grid(int slots, int rows_per_slot, int C) {
   return dim3(gx, slots);
 }
 
+// GroupNorm finalize, one work-group per image (plus one for the parameter gradients in the backward form): the group
+// sums of the per-channel column statistics and everything derived from them, instead of a chain of ~15 small tensor ops.
+// forward: stats [B][2][C] (sum, sum of squares over the H*W pixels) -> mean / invstd / scale / shift [B][C]
+__global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float n, float eps, int C, int cg,
+                                                              float* __restrict__ mean, float* __restrict__ invstd,
+                                                              float* __restrict__ scale, float* __restrict__ shift) {
+  extern __shared__ float gs[];  // [2][G]
+  const int b = blockIdx.x, G = C / cg;
+  const float* st = stats + (size_t)b * 2 * C;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float s = 0.f, ss = 0.f;
+    for (int i = 0; i < cg; ++i) { s += st[g * cg + i]; ss += st[C + g * cg + i]; }
+    const float mu = s / n;
+    gs[g] = mu;
+    gs[G + g] = rsqrtf(fmaxf(ss / n - mu * mu, 0.f) + eps);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float mu = gs[c / cg], is = gs[G + c / cg];
+    const float sc = gamma[c] * is;
+    mean[(size_t)b * C + c] = mu;
+    invstd[(size_t)b * C + c] = is;
+    scale[(size_t)b * C + c] = sc;
+    shift[(size_t)b * C + c] = beta[c] - mu * sc;
+  }
+}
+
+// backward: sums [B][2][C] (S1 = sum dz, S2 = sum dz * xhat per channel) -> the dx coefficients k1 / k2 / k3 [B][C] of
+// u2_norm_bwd_apply and, in work-group B, dgamma[c] = sum_b S2, dbeta[c] = sum_b S1 (in image order)
+__global__ __launch_bounds__(256) void gn_finalize_bwd_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              float n, int B, int C, int cg, float* __restrict__ k1,
+                                                              float* __restrict__ k2, float* __restrict__ k3,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  extern __shared__ float gs[];  // [2][G]
+  const int b = blockIdx.x, G = C / cg;
+  if (b == B) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int i = 0; i < B; ++i) { s1 += sums[(size_t)i * 2 * C + c]; s2 += sums[(size_t)i * 2 * C + C + c]; }
+      dbeta[c] = s1;
+      dgamma[c] = s2;
+    }
+    return;
+  }
+  const float* sm = sums + (size_t)b * 2 * C;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a = 0.f, bq = 0.f;
+    for (int i = 0; i < cg; ++i) { a += gamma[g * cg + i] * sm[g * cg + i]; bq += gamma[g * cg + i] * sm[C + g * cg + i]; }
+    gs[g] = a / n;
+    gs[G + g] = bq / n;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float a = gs[c / cg], bq = gs[G + c / cg];
+    const float is = invstd[(size_t)b * C + c], mu = mean[(size_t)b * C + c];
+    k1[(size_t)b * C + c] = is * gamma[c];
+    k2[(size_t)b * C + c] = -is * is * bq;
+    k3[(size_t)b * C + c] = -is * a + is * is * bq * mu;
+  }
+}
+
 // BatchNorm forward finalize: sums -> mean/invstd/scale/shift, running-stat update (momentum).
 __global__ void bn_finalize_fwd_kernel(const float* __restrict__ sums, float count, const float* __restrict__ count_dev,
                                        const float* __restrict__ gamma,
@@ -665,6 +728,27 @@ extern "C" int u2_bn_finalize_bwd(const float* sums, float count, const float* c
                                   float* k2, float* k3, int C, int accumulate, void* stream) {
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, count_dev,
                      gamma, mean, invstd, local_sums, dgamma, dbeta, k1, k2, k3, C, accumulate);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_gn_finalize_fwd(const float* stats, const float* gamma, const float* beta, float n, float eps, int B, int C,
+                                  int groups, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  if (B <= 0) return 0;
+  if (groups < 1 || C % groups) return -1;
+  hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(B), dim3(256), 2 * groups * sizeof(float), (hipStream_t)stream, stats, gamma,
+                     beta, n, eps, C, C / groups, mean, invstd, scale, shift);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_gn_finalize_bwd(const float* sums, const float* gamma, const float* mean, const float* invstd, float n, int B,
+                                  int C, int groups, float* k1, float* k2, float* k3, float* dgamma, float* dbeta,
+                                  void* stream) {
+  if (B <= 0) return 0;
+  if (groups < 1 || C % groups) return -1;
+  hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(B + 1), dim3(256), 2 * groups * sizeof(float), (hipStream_t)stream, sums, gamma,
+                     mean, invstd, n, B, C, C / groups, k1, k2, k3, dgamma, dbeta);
   U2_CHECK_LAUNCH();
   return 0;
 }

@@ -391,15 +391,10 @@ class _GroupNormActFn(Function):
         cg = c // groups
         stats = zeros_f32((b, 2, c), y.device)
         _hip.call("u2_colstats", y, stats, b, hw, c, c)
-        n = float(hw * cg)
-        s = stats.view(b, 2, groups, cg).sum(-1)
-        mean_g = s[:, 0] / n
-        var_g = (s[:, 1] / n - mean_g * mean_g).clamp_(min=0)
-        invstd_g = torch.rsqrt(var_g + eps)
-        mean = mean_g.repeat_interleave(cg, dim=1).contiguous()
-        invstd = invstd_g.repeat_interleave(cg, dim=1).contiguous()
-        scale = (gamma.detach()[None] * invstd).contiguous()
-        shift = (beta.detach()[None] - mean * scale).contiguous()
+        coef = torch.empty((4, b, c), dtype=torch.float32, device=y.device)
+        mean, invstd, scale, shift = coef[0], coef[1], coef[2], coef[3]
+        _hip.call("u2_gn_finalize_fwd", stats, gamma.detach(), beta.detach(), float(hw * cg), float(eps), b, c, groups, mean,
+                  invstd, scale, shift)
         out = torch.empty_like(y)
         _hip.call("u2_affine_act", y, scale, shift, None, out, b, hw, c, c, int(relu))
         ctx.save_for_backward(y, gamma, mean, invstd, scale if relu else None, shift if relu else None)
@@ -416,16 +411,13 @@ class _GroupNormActFn(Function):
         dout = dout.contiguous()
         sums = zeros_f32((b, 2, c), y.device)
         _hip.call("u2_norm_bwd_reduce", dout, None, y, mean, invstd, sums, b, hw, c, c, int(relu), msc, msh, None, None)
-        s1, s2 = sums[:, 0], sums[:, 1]
-        g = gamma.detach()[None]
-        a = ((g * s1).view(b, groups, cg).sum(-1) / n).repeat_interleave(cg, dim=1)
-        bq = ((g * s2).view(b, groups, cg).sum(-1) / n).repeat_interleave(cg, dim=1)
-        k1 = (invstd * g).contiguous()
-        k2 = (-invstd * invstd * bq).contiguous()
-        k3 = (-invstd * a + invstd * invstd * bq * mean).contiguous()
+        coef = torch.empty((3, b, c), dtype=torch.float32, device=y.device)
+        k1, k2, k3 = coef[0], coef[1], coef[2]
+        dparam = torch.empty((2, c), dtype=torch.float32, device=y.device)
+        _hip.call("u2_gn_finalize_bwd", sums, gamma.detach(), mean, invstd, n, b, c, groups, k1, k2, k3, dparam[0], dparam[1])
         dx = torch.empty_like(y)
         _hip.call("u2_norm_bwd_apply", dout, None, y, k1, k2, k3, dx, None, b, hw, c, c, int(relu), msc, msh)
-        return dx, s2.sum(0), s1.sum(0), None, None, None
+        return dx, dparam[0], dparam[1], None, None, None
 
 
 def group_norm_act(y, gamma, beta, groups, relu=False, eps=1e-5):
