@@ -91,13 +91,15 @@ int u2_affine_upadd(const void* x, const float* scale, const float* shift, const
                     int C, int relu, void* stream);
 int u2_norm_bwd_reduce(const void* dout, const void* mask, const void* x, const float* mean, const float* invstd,
                        float* out /*[slots][2][C]*/, int slots, int rows_per_slot, int C, int ld, int relu,
-                       const float* mask_scale, const float* mask_shift, const void* dout2, void* dz_out, void* stream);
+                       const float* mask_scale, const float* mask_shift, const void* dout2, void* dz_out, const void* dout3,
+                       void* stream);
 /* mask_scale/mask_shift [slots][C] (optional, both or neither): recompute the ReLU mask as x*scale+shift > 0 - the
  * expression u2_affine_act evaluated in the forward pass - instead of reading the activation `mask` (which may be NULL).
  * u2_norm_bwd_reduce only: dz_out (optional) receives the masked gradient dz = (dout [+ dout2]) * mask, so that
  * u2_norm_bwd_apply can run on (dz, x) with relu = 0 and dz doubles as the residual branch's gradient; dout2 (optional,
  * needs dz_out) is a second incoming gradient summed on the fly (resnet.py:204-210: the block output feeds the next
- * block's conv1 and its identity shortcut). */
+ * block's conv1 and its identity shortcut); dout3 (optional, needs dout2) a third one (the last block of a stage also feeds
+ * the FPN lateral conv, backbone/fpn.py:141-146). */
 int u2_bn_finalize_bwd(const float* sums, float count, const float* count_dev, const float* gamma, const float* mean, const float* invstd,
                        const float* local_sums, float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C,
                        int accumulate /* dgamma/dbeta += instead of = (parameter gradient arena) */, void* stream);
@@ -105,6 +107,10 @@ int u2_norm_bwd_apply(const void* dout, const void* mask, const void* x, const f
                       const float* k3, void* dx, void* dres, int slots, int rows_per_slot, int C, int ld, int relu,
                       const float* mask_scale, const float* mask_shift, void* stream);
 int u2_relu_bwd(const void* dout, const void* out, void* dz, long long numel, void* stream);
+/* out = a + b (+ c (+ d)) on bf16 tensors of numel elements (numel % 8 == 0), summed in fp32 and rounded once; out may alias an
+ * input. The gradient sum autograd would otherwise make with k - 1 separate adds where a tensor has k consumers (the FPN
+ * outputs feed the RPN head, the ROI poolers and the semantic head: meta_arch/panoptic_fpn.py:105-131). */
+int u2_add_n(const void* a, const void* b, const void* c, const void* d, void* out, long long numel, void* stream);
 
 /* ---- pooling / resampling (pool_resize.hip) ----------------------------------------------------
  * backbone/resnet.py:358 (max_pool2d 3x3 s2 p1), backbone/fpn.py:153-155 (nearest x2 + add),

@@ -1424,3 +1424,40 @@ def test_sem_seg_inference_upsample_and_argmax(F, shape):
     decided = (top2[:, 0] - top2[:, -1]) > 1e-4 if k > 1 else torch.ones_like(amax, dtype=torch.bool)
     assert torch.equal(amax[decided], ref.argmax(dim=1)[decided])
     assert decided.float().mean().item() > 0.99
+
+
+@pytest.mark.parametrize("handles", [2, 3])
+def test_gradient_handles_sum_in_kernel(F, handles):
+    """A tensor with several consumers: the BatchNorm block tail hands out 2 / 3 autograd handles whose gradients meet
+    inside its backward kernel (resnet.py:204-210 + fpn.py:141-146 read a stage output three times), and F.fan_out sums k
+    gradients in one kernel; both against plain autograd accumulation on one handle."""
+    g = torch.Generator(device="cuda").manual_seed(11 + handles)
+    y = (torch.randn((2, 9, 11, 64), device=DEV, generator=g) * 2).bfloat16()
+    res = torch.randn((2, 9, 11, 64), device=DEV, generator=g).bfloat16()
+    gamma = (1 + 0.2 * torch.randn(64, device=DEV, generator=g))
+    beta = 0.1 * torch.randn(64, device=DEV, generator=g)
+    ws = [torch.randn((2, 9, 11, 64), device=DEV, generator=g).bfloat16() for _ in range(handles)]
+    yf = y.float().reshape(-1, 64)
+    stats = torch.stack([yf.sum(0), (yf * yf).sum(0)])
+
+    def run(twin):
+        yd, rd = y.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        gd, bd = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        out = F.batch_norm_act(yd, stats.clone(), gd, bd, torch.zeros(64, device=DEV), torch.ones(64, device=DEV), rd, True,
+                               0.1, 1e-5, twin=twin)
+        hs = [out] * handles if not twin else ([out, out._u2_twin] + ([out._u2_third] if handles == 3 else []))
+        sum((h * w).float().sum() for h, w in zip(hs, ws)).backward()
+        return yd.grad, rd.grad, gd.grad, bd.grad
+
+    ref = run(False)
+    got = run(3 if handles == 3 else True)
+    for a, b in zip(got, ref):
+        assert rel_err(a.float(), b.float()) < 1e-2
+
+    def run_fan(use):
+        x = y.clone().requires_grad_(True)
+        hs = F.fan_out(x, handles) if use else (x,) * handles
+        sum((h * w).float().sum() for h, w in zip(hs, ws)).backward()
+        return x.grad
+
+    assert rel_err(run_fan(True).float(), run_fan(False).float()) < 1e-2

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
                                                         const float* __restrict__ invstd, float* __restrict__ out,
                                                         int rows_per_slot, int C, int ld, int rows_per_block,
                                                         const float* __restrict__ msc, const float* __restrict__ msh,
-                                                        const bf16_t* __restrict__ dout2, bf16_t* __restrict__ dz_out) {
+                                                        const bf16_t* __restrict__ dout2, bf16_t* __restrict__ dz_out,
+                                                        const bf16_t* __restrict__ dout3) {
   __shared__ float part[2][2048];
   constexpr int U = 2;  // rows in flight per thread
   const int cpr = C >> 3;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
         }
       }
       for (int r0 = r_begin + rl; r0 < r_end; r0 += U * rows_par) {
-        uint4 xq[U], dq[U], mq[U], eq[U];
+        uint4 xq[U], dq[U], mq[U], eq[U], fq[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int r = r0 + u * rows_par;
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
               dq[u] = ld_stream(dout + off, nt);
               if (MASK == 1) mq[u] = ld_stream(mask + off, nt);
               if (DZ && dout2) eq[u] = ld_stream(dout2 + off, nt);
+              if (DZ && dout3) fq[u] = ld_stream(dout3 + off, nt);
             }
           }
         }
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
             const bf16_t* dv = reinterpret_cast<const bf16_t*>(&dq[u]);
             const bf16_t* mv = reinterpret_cast<const bf16_t*>(&mq[u]);
             const bf16_t* ev = reinterpret_cast<const bf16_t*>(&eq[u]);
+            const bf16_t* fv = reinterpret_cast<const bf16_t*>(&fq[u]);
             bf16_t zv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -112,6 +115,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
               } else {
                 float dz = bf2f(dv[e]);
                 if (DZ && dout2) dz = bf2f(f2bf(dz + bf2f(ev[e])));  // rounded like the bf16 sum autograd would form
+                if (DZ && dout3) dz = bf2f(f2bf(dz + bf2f(fv[e])));
                 if (MASK == 1 && !(bf2f(mv[e]) > 0.f)) dz = 0.f;
                 if (MASK == 2 && !(xf * ms[e] + mh[e] > 0.f)) dz = 0.f;
                 if (DZ) zv[e] = f2bf(dz);
@@ -227,6 +231,27 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const bf16_t* __restrict_
   }
 }
 
+
+// out = a + b (+ c) (+ d), summed in fp32 and rounded once: the gradients that reach a tensor with several consumers
+__global__ __launch_bounds__(256) void add_n_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                    const bf16_t* __restrict__ c, const bf16_t* __restrict__ d,
+                                                    bf16_t* __restrict__ out, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    bf16_t av[8], bv[8], cv[8], dv[8];
+    *reinterpret_cast<uint4*>(av) = reinterpret_cast<const uint4*>(a)[i];
+    *reinterpret_cast<uint4*>(bv) = reinterpret_cast<const uint4*>(b)[i];
+    if (c) *reinterpret_cast<uint4*>(cv) = reinterpret_cast<const uint4*>(c)[i];
+    if (d) *reinterpret_cast<uint4*>(dv) = reinterpret_cast<const uint4*>(d)[i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = bf2f(av[e]) + bf2f(bv[e]);
+      if (c) v += bf2f(cv[e]);
+      if (d) v += bf2f(dv[e]);
+      av[e] = f2bf(v);
+    }
+    reinterpret_cast<uint4*>(out)[i] = *reinterpret_cast<const uint4*>(av);
+  }
+}
 
 // ---- fast paths: C/8 divides 256, so a thread keeps one 8-channel column chunk for its whole life and the
 //      per-channel coefficients live in registers; grid.y = slot, rows of a slot are strided over grid.x.
@@ -619,7 +644,7 @@ extern "C" int u2_colstats(const void* x, float* out, int slots, int rows_per_sl
   if (rpb < 64) rpb = 64;
   const dim3 grid((rows_per_slot + rpb - 1) / rpb, slots);
   hipLaunchKernelGGL((colreduce_kernel<0, 0, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, nullptr,
-                     nullptr, nullptr, nullptr, out, rows_per_slot, C, ld, rpb, nullptr, nullptr, nullptr, nullptr);
+                     nullptr, nullptr, nullptr, out, rows_per_slot, C, ld, rpb, nullptr, nullptr, nullptr, nullptr, nullptr);
   U2_CHECK_LAUNCH();
   return 0;
 }
@@ -627,9 +652,9 @@ extern "C" int u2_colstats(const void* x, float* out, int slots, int rows_per_sl
 extern "C" int u2_norm_bwd_reduce(const void* dout, const void* mask, const void* x, const float* mean, const float* invstd,
                                   float* out, int slots, int rows_per_slot, int C, int ld, int relu,
                                   const float* mask_scale, const float* mask_shift, const void* dout2, void* dz_out,
-                                  void* stream) {
+                                  const void* dout3, void* stream) {
   if ((C & 7) || (ld & 7)) return -1;
-  if (dout2 && !dz_out) return -1;
+  if ((dout2 && !dz_out) || (dout3 && !dout2)) return -1;
   if (slots <= 0 || rows_per_slot <= 0) return 0;
   int rpb = (rows_per_slot + 511) / 512;
   if (rpb < 64) rpb = 64;
@@ -638,7 +663,7 @@ extern "C" int u2_norm_bwd_reduce(const void* dout, const void* mask, const void
 #define U2_REDUCE(MM_, DZ_)                                                                                          \
   hipLaunchKernelGGL((colreduce_kernel<1, MM_, DZ_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,      \
                      (const bf16_t*)dout, (const bf16_t*)mask, mean, invstd, out, rows_per_slot, C, ld, rpb, mask_scale, \
-                     mask_shift, (const bf16_t*)dout2, (bf16_t*)dz_out)
+                     mask_shift, (const bf16_t*)dout2, (bf16_t*)dz_out, (const bf16_t*)dout3)
   if (dz_out) { if (!relu) U2_REDUCE(0, true); else if (mask_scale) U2_REDUCE(2, true); else U2_REDUCE(1, true); }
   else { if (!relu) U2_REDUCE(0, false); else if (mask_scale) U2_REDUCE(2, false); else U2_REDUCE(1, false); }
 #undef U2_REDUCE
@@ -710,6 +735,16 @@ extern "C" int u2_relu_bwd(const void* dout, const void* out, void* dz, long lon
   const size_t n8 = (size_t)numel >> 3;
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
                      (const bf16_t*)out, (bf16_t*)dz, n8);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_add_n(const void* a, const void* b, const void* c, const void* d, void* out, long long numel, void* stream) {
+  if ((numel & 7) || !a || !b || (d && !c)) return -1;
+  if (numel == 0) return 0;
+  const size_t n8 = (size_t)numel >> 3;
+  hipLaunchKernelGGL(add_n_kernel, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b,
+                     (const bf16_t*)c, (const bf16_t*)d, (bf16_t*)out, n8);
   U2_CHECK_LAUNCH();
   return 0;
 }

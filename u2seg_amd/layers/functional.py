@@ -120,8 +120,10 @@ class _Conv2dFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, relu, want_stats, param_ref=None):
         _check_act(x)
-        param = param_ref[0] if param_ref is not None else None  # boxed so that autograd does not treat it as an input
-        wgrad_dst = grad_slot(param) if param is not None else None
+        # boxed so that autograd does not treat them as inputs: the owning Parameter and its arena gradient slice (looked up by
+        # conv2d() - Function.forward runs with autograd disabled, where grad_slot() answers None)
+        param = param_ref[0] if param_ref is not None else None
+        wgrad_dst = param_ref[1] if param_ref is not None and len(param_ref) > 1 else None
         n, cin, kh, kw = weight.shape
         b, h, w_, cp = x.shape
         assert cin <= cp
@@ -140,12 +142,15 @@ class _Conv2dFn(Function):
         # 1x1 / linear weights: the gradient is accumulated straight into the optimizer's arena slice
         ctx.wgrad_dst = wgrad_dst if (kh * kw == 1 and wgrad_dst is not None) else None
         ctx.param = param
+        ctx.set_materialize_grads(False)  # no zero tensor for the (non-differentiable) statistics output
         if want_stats:
             ctx.mark_non_differentiable(stats)
         return out, stats
 
     @staticmethod
     def backward(ctx, dout, _dstats):
+        if dout is None:
+            return (None,) * 8
         x, weight, out = ctx.saved_tensors
         stride, pad, relu, has_bias = ctx.cfg
         n, cin, kh, kw = weight.shape
@@ -198,7 +203,8 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, want_stats=False, 
     itself when that is a Parameter); it carries the optimizer's gradient slot and the cached kernel layouts."""
     if param is None and isinstance(weight, torch.nn.Parameter):
         param = weight
-    out, stats = _Conv2dFn.apply(x, weight, bias, stride, pad, relu, want_stats, (param,) if param is not None else None)
+    out, stats = _Conv2dFn.apply(x, weight, bias, stride, pad, relu, want_stats,
+                                 (param, grad_slot(param)) if param is not None else None)
     return (out, stats) if want_stats else out
 
 
@@ -306,31 +312,31 @@ class _BatchNormActFn(Function):
         ctx.res_up = res_up
         ctx.grad_dst = grad_dst  # (dgamma, dbeta) arena slices or None
         ctx.twin = twin
-        if twin:  # two handles on the same activation: their gradients arrive separately and are summed in the kernel
+        if twin:  # two or three handles on the same activation: their gradients arrive separately and are summed in the kernel
             ctx.set_materialize_grads(False)
-            return out, out.detach()
+            return (out, out.detach(), out.detach()) if int(twin) == 3 else (out, out.detach())
         return out
 
     @staticmethod
-    def backward(ctx, dout, dout2=None):
+    def backward(ctx, dout, dout2=None, dout3=None):
         y, out, gamma, mean, invstd, msc, msh = ctx.saved_tensors
         relu, count, world, has_res = ctx.cfg
         b, h, w, c = y.shape
         m = b * h * w
         nret = 14
-        if dout is None:
-            dout, dout2 = dout2, None
-        if dout is None:
+        arrived = [g.contiguous() for g in (dout, dout2, dout3) if g is not None]
+        if not arrived:
             return (None,) * nret
-        dout = dout.contiguous()
         fuse = has_res and relu  # residual block tail: dz is materialised by the reduce pass and is the residual gradient
-        if dout2 is not None:
-            dout2 = dout2.contiguous()
-            if not fuse:
-                dout, dout2 = dout + dout2, None
+        if not fuse and len(arrived) > 1:
+            total = arrived[0]
+            for g in arrived[1:]:
+                total = total + g
+            arrived = [total]
+        dout, dout2, dout3 = (arrived + [None, None])[:3]
         dz = torch.empty_like(y) if fuse else None
         sums = zeros_f32((2, c), y.device)
-        _hip.call("u2_norm_bwd_reduce", dout, out, y, mean, invstd, sums, 1, m, c, c, int(relu), msc, msh, dout2, dz)
+        _hip.call("u2_norm_bwd_reduce", dout, out, y, mean, invstd, sums, 1, m, c, c, int(relu), msc, msh, dout2, dz, dout3)
         local = sums
         if world > 1:
             local = sums.clone()
@@ -359,14 +365,17 @@ def batch_norm_act(y, stats, gamma, beta, running_mean, running_var, residual=No
                    eps=1e-5, twin=False, sync=True, res_up=False):
     """twin=True: returns the activation with a second autograd handle on the same memory in `._u2_twin` (for a consumer
     pair such as the next residual block's conv1 and identity shortcut); the two gradients are summed inside the
-    backward kernel instead of by autograd.  sync=False: per-process statistics (NORM "BN"), no all-reduce.
+    backward kernel instead of by autograd.  twin=3: a third handle in `._u2_third` as well.  sync=False: per-process statistics (NORM "BN"), no all-reduce.
     res_up=True: `residual` is the next coarser FPN level [B, H/2, W/2, C], nearest-upsampled inside the same pass."""
     gd, bd = grad_slot(gamma), grad_slot(beta)
     grad_dst = (gd, bd) if gd is not None and bd is not None else None
-    twin = bool(twin) and torch.is_grad_enabled()
+    twin = (3 if twin == 3 else int(bool(twin))) if torch.is_grad_enabled() else 0
     out = _BatchNormActFn.apply(y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, grad_dst,
                                 twin, sync, res_up)
-    if twin:
+    if twin == 3:  # a third handle (`._u2_third`) for a third consumer, e.g. the FPN lateral conv on a stage output
+        out, other, third = out
+        out._u2_twin, out._u2_third = other, third
+    elif twin:
         out, other = out
         out._u2_twin = other
     return out
@@ -410,7 +419,7 @@ class _GroupNormActFn(Function):
         n = float(hw * cg)
         dout = dout.contiguous()
         sums = zeros_f32((b, 2, c), y.device)
-        _hip.call("u2_norm_bwd_reduce", dout, None, y, mean, invstd, sums, b, hw, c, c, int(relu), msc, msh, None, None)
+        _hip.call("u2_norm_bwd_reduce", dout, None, y, mean, invstd, sums, b, hw, c, c, int(relu), msc, msh, None, None, None)
         coef = torch.empty((3, b, c), dtype=torch.float32, device=y.device)
         k1, k2, k3 = coef[0], coef[1], coef[2]
         dparam = torch.empty((2, c), dtype=torch.float32, device=y.device)
@@ -684,6 +693,41 @@ def _roi_gather(shapes, scales, sets, device):
     _hip.call("u2_roi_align_bwd_gather_multi", ptrs, hs, ws, sc, nl, ns, arr(0), arr(1), arr(2), arr(3), ps, gs,
               shapes[0][0], shapes[0][3])
     return gbuf
+
+
+class _FanOutFn(Function):
+    """k autograd handles on one tensor: their gradients arrive separately and are summed by one kernel (u2_add_n) instead of
+    autograd's k - 1 accumulation adds."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.set_materialize_grads(False)
+        return tuple(x.detach() for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g.contiguous() for g in grads if g is not None]
+        if not gs:
+            return None, None
+        while len(gs) > 1:
+            part, gs = gs[:4], gs[4:]
+            if part[0].dtype != BF16 or part[0].numel() % 8:
+                total = part[0]
+                for g in part[1:]:
+                    total = total + g
+            else:
+                total = torch.empty_like(part[0])
+                part = part + [None] * (4 - len(part))
+                _hip.call("u2_add_n", part[0], part[1], part[2], part[3], total, total.numel())
+            gs.insert(0, total)
+        return gs[0], None
+
+
+def fan_out(x, k):
+    """`k` handles on `x` for `k` consumers (training only; without autograd the tensor itself k times)."""
+    if k <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * max(k, 1)
+    return _FanOutFn.apply(x, k)
 
 
 class RoiGradTap:

@@ -65,6 +65,7 @@ class BottleneckBlock(nn.Module):
         super().__init__()
         assert num_groups == 1 and dilation == 1, "grouped / dilated bottlenecks are not used by the U2Seg configs"
         self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+        self.third_handle = False  # set by ResNet on the last block of a stage that is also a backbone output
         if in_channels != out_channels:
             self.shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=stride, bias=False,
                                    norm=get_norm(norm, out_channels))
@@ -88,7 +89,8 @@ class BottleneckBlock(nn.Module):
         out = self.conv1(x)
         out = self.conv2(out)
         shortcut = self.shortcut(x_sc) if self.shortcut is not None else x_sc
-        return self.conv3(out, residual=shortcut, relu=True, twin=True)  # out += shortcut; relu_
+        # out += shortcut; relu_.  The last block of a stage that is also a backbone output hands out a third handle
+        return self.conv3(out, residual=shortcut, relu=True, twin=3 if self.third_handle else True)
 
 
 class ResNet(Backbone):
@@ -110,6 +112,9 @@ class ResNet(Backbone):
             self._out_feature_channels[name] = blocks[-1].out_channels
         self.stage_names = tuple(self.stage_names)
         self._out_features = out_features if out_features is not None else [name]
+        for sname, stage in zip(self.stage_names[:-1], self.stages[:-1]):
+            if sname in self._out_features and hasattr(stage[-1], "third_handle"):
+                stage[-1].third_handle = True
         assert freeze_at == 0, "BACKBONE.FREEZE_AT > 0 is not used by the U2Seg configs"
 
     def forward(self, images, pixel_mean, pixel_std, padded_hw):
@@ -118,7 +123,9 @@ class ResNet(Backbone):
         for name, stage in zip(self.stage_names, self.stages):
             x = stage(x)
             if name in self._out_features:
-                outputs[name] = x
+                # a stage output read by the next stage (conv1 + shortcut: the two twin handles) AND by the caller: the caller
+                # gets the third handle, so that all three gradients meet inside one BatchNorm backward kernel
+                outputs[name] = getattr(x, "_u2_third", x)
         return outputs
 
     @staticmethod

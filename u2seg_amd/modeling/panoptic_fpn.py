@@ -4,6 +4,7 @@ import torch
 from torch import nn
 
 from ..config import configurable
+from ..layers import functional as F
 from ..structures import ImageList
 from ..utils.registry import Registry
 from .backbone import build_backbone
@@ -45,6 +46,18 @@ class GeneralizedRCNN(nn.Module):
     def device(self):
         return self.pixel_mean.device
 
+    @staticmethod
+    def _fan_out_features(features, consumers):
+        """One feature dict per consumer (`consumers`: their in_features lists).  A map read by several of them gets one autograd
+        handle per reader, so that its gradient is summed by one kernel (layers/functional.py:fan_out)."""
+        readers = {name: [i for i, names in enumerate(consumers) if name in names] for name in features}
+        out = [dict(features) for _ in consumers]
+        for name, who in readers.items():
+            if len(who) > 1:
+                for i, handle in zip(who, F.fan_out(features[name], len(who))):
+                    out[i][name] = handle
+        return out
+
     def _watch_feature_grads(self, features):
         """Fire on_heads_backward_done once the gradient of every FPN output has been computed in backward."""
         cb = self.on_heads_backward_done
@@ -76,8 +89,9 @@ class GeneralizedRCNN(nn.Module):
         features, image_sizes, _ = self._backbone_features(batched_inputs)
         self._watch_feature_grads(features)
         gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
-        proposals, proposal_losses = self.proposal_generator(image_sizes, features, gt_instances)
-        _, detector_losses = self.roi_heads(None, features, proposals, gt_instances)
+        rpn_f, roi_f = self._fan_out_features(features, [self.proposal_generator.in_features, self.roi_heads.box_in_features])
+        proposals, proposal_losses = self.proposal_generator(image_sizes, rpn_f, gt_instances)
+        _, detector_losses = self.roi_heads(None, roi_f, proposals, gt_instances)
         losses = {}
         losses.update(detector_losses)
         losses.update(proposal_losses)
@@ -144,10 +158,12 @@ class PanopticFPN(GeneralizedRCNN):
         self._watch_feature_grads(features)
         assert "sem_seg" in batched_inputs[0]
         gt_sem_seg = self._sem_seg_targets(batched_inputs, padded_hw)
-        _, sem_seg_losses = self.sem_seg_head(features, gt_sem_seg)
+        sem_f, rpn_f, roi_f = self._fan_out_features(
+            features, [self.sem_seg_head.in_features, self.proposal_generator.in_features, self.roi_heads.box_in_features])
+        _, sem_seg_losses = self.sem_seg_head(sem_f, gt_sem_seg)
         gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
-        proposals, proposal_losses = self.proposal_generator(image_sizes, features, gt_instances)
-        _, detector_losses = self.roi_heads(None, features, proposals, gt_instances)
+        proposals, proposal_losses = self.proposal_generator(image_sizes, rpn_f, gt_instances)
+        _, detector_losses = self.roi_heads(None, roi_f, proposals, gt_instances)
         losses = sem_seg_losses
         losses.update(proposal_losses)
         losses.update(detector_losses)
