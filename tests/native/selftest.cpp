@@ -216,7 +216,7 @@ static void bench2(int argc, char** argv, bool wgrad) {
   for (int i = 2; i < argc; ++i) variants.push_back((int)strtol(argv[i], nullptr, 0));
   if (variants.empty()) {
     if (wgrad) variants = {2048, 0, 256, 4096, 4096 | (1 << 14)};
-    else variants = {15 << 12, 0, 1 << 12, 2 << 12, 3 << 12, 4 << 12, 5 << 12};
+    else variants = {15 << 12, 0, 1 << 12, 2 << 12, 3 << 12, 4 << 12, 5 << 12, 6 << 12};
   }
   const size_t in_elems = (size_t)16 * 200 * 336 * 256, w_elems = (size_t)8192 * 8192, out_elems = (size_t)16 * 200 * 336 * 256;
   DBuf<uint16_t> din(in_elems), dw(wgrad ? 16 : w_elems), dout(out_elems);
@@ -275,6 +275,22 @@ int main(int argc, char** argv) {
     bench_conv("fpn_out2 3x3 256->256 B16", 16, 200, 336, 256, 256, 3, 1, 1, v);
     return 0;
   }
+  const ConvCase tconvs[] = {
+      {2, 36, 32, 64, 256, 3, 3, 1, 1, 1, 0, 0, 0, 1, "tile 3x3 c64 n256 stats"},
+      {2, 36, 32, 96, 320, 3, 3, 1, 1, 1, 1, 0, 1, 0, "tile 3x3 c96 n320 bias relu"},
+      {1, 700, 3, 256, 512, 1, 1, 0, 1, 1, 0, 0, 0, 1, "tile 1x1 c256 n512 stats"},
+      {2, 37, 41, 160, 128, 1, 1, 0, 2, 1, 0, 0, 0, 1, "tile 1x1 s2 c160 n128 stats"},
+      {2, 18, 20, 128, 128, 3, 3, 1, 1, 2, 0, 0, 0, 0, "tile dgrad(3x3 s2) c128 n128"},
+      {1, 45, 23, 64, 72, 3, 3, 1, 1, 1, 0, 0, 1, 1, "tile 3x3 c64 n72 bias stats"},
+      {3, 7, 7, 32, 136, 7, 7, 0, 1, 1, 1, 0, 1, 0, "tile fc 7x7 c32 n136 bias relu"},
+  };
+  if (argc > 2 && !strcmp(argv[1], "tile")) {  // one persistent-tile configuration only
+    const int cfg = atoi(argv[2]);
+    for (int tiny = 0; tiny < 2; ++tiny)
+      for (const auto& c : tconvs) fails += test_conv(c, (cfg << 12) | (tiny << 16));
+    printf("SELFTEST tile %d %s (%d failures)\n", cfg, fails ? "FAILED" : "OK", fails);
+    return fails ? 1 : 0;
+  }
   const WgCase halo_cases[] = {  // 3x3 / stride 1 / pad 1 only: wgrad_halo.hip (variant bit 12), bits 14-15 = rounds - 1
       {2, 14, 14, 64, 64, 3, 3, 1, 1, "halo 14x14 c64 n64"},
       {1, 13, 17, 128, 136, 3, 3, 1, 1, "halo 13x17 c128 n136"},
@@ -318,16 +334,7 @@ int main(int argc, char** argv) {
     for (const auto& c : convs) fails += test_conv(c, v);
   // persistent tile kernels (conv_tile.hip): variant bits 12-15 pick the configuration, bit 16 caps the grid at 8
   // work-groups so that every work-group walks several tiles (cross-tile prefetch, accumulator reset, tail waits)
-  const ConvCase tconvs[] = {
-      {2, 36, 32, 64, 256, 3, 3, 1, 1, 1, 0, 0, 0, 1, "tile 3x3 c64 n256 stats"},
-      {2, 36, 32, 96, 320, 3, 3, 1, 1, 1, 1, 0, 1, 0, "tile 3x3 c96 n320 bias relu"},
-      {1, 700, 3, 256, 512, 1, 1, 0, 1, 1, 0, 0, 0, 1, "tile 1x1 c256 n512 stats"},
-      {2, 37, 41, 160, 128, 1, 1, 0, 2, 1, 0, 0, 0, 1, "tile 1x1 s2 c160 n128 stats"},
-      {2, 18, 20, 128, 128, 3, 3, 1, 1, 2, 0, 0, 0, 0, "tile dgrad(3x3 s2) c128 n128"},
-      {1, 45, 23, 64, 72, 3, 3, 1, 1, 1, 0, 0, 1, 1, "tile 3x3 c64 n72 bias stats"},
-      {3, 7, 7, 32, 136, 7, 7, 0, 1, 1, 1, 0, 1, 0, "tile fc 7x7 c32 n136 bias relu"},
-  };
-  for (int cfg = 1; cfg <= 5; ++cfg)
+  for (int cfg = 1; cfg <= 6; ++cfg)
     for (int tiny = 0; tiny < 2; ++tiny)
       for (const auto& c : tconvs) fails += test_conv(c, (cfg << 12) | (tiny << 16));
   const WgCase wgs[] = {

@@ -429,6 +429,7 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s) {
 
 // variant bits 12-15 select the tile configuration: 0 = automatic, 1 = 256ch x 256px ring 4, 2 = 256 x 256 ring 5,
 // 3 = 128ch x 256px (ring 3, two groups per CU), 4 = 256ch x 128px (ring 3, two groups per CU), 5 = 128ch x 256px ring 4,
+// 6 = 64ch x 512px ring 4 (layers with <= 64 output channels: no MFMA spent on absent channels),
 // 15 = never (conv_igemm.hip kernels only); bit 16: 8 work-groups only (tests: forces several tiles per work-group).
 // Tried and removed (numbers in profiles/r02_conv_ablation.txt, r02_conv_pingpong.txt): a j-split schedule
 // with every LDS read 12+ MFMAs ahead of its use (+0 %), and a ping-pong schedule with the two wave groups half a sequence
@@ -449,6 +450,7 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
     const long long t256 = (long long)((a.M + 255) / 256) * ((N + 255) / 256);
     if (N <= 128) {
       // 128-wide tiles (two groups per CU); the deep 3x3 layers with 128 outputs stay on the 128 x 128 BK-64 kernel
+      // (configuration 6, 64ch x 512px with one group per CU, measured slower on the 64-channel layers: 364 vs 451 TFLOP/s)
       if (a.M >= 100000 && !(a.ntaps > 1 && K >= 2048)) sel = 3;
     } else if (a.ntaps > 1) {
       if (t256 >= 2048) sel = 2;                                   // stride-4 maps: >= 8 rounds of 256 x 256 tiles
@@ -463,8 +465,8 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
     }
     if (sel == 0) return 0;
   }
-  if (sel > 5) return 0;
-  int ring = (sel == 2) ? 5 : (sel == 1 || sel == 5) ? 4 : 3;
+  if (sel > 6) return 0;
+  int ring = (sel == 2) ? 5 : (sel == 1 || sel == 5 || sel == 6) ? 4 : 3;
   if (nkh < ring) {
     // a work-group only needs RING half tiles over ALL the tiles it walks; in automatic mode fall back to the ring-3
     // configurations (K >= 64 with two or more tiles per work-group, K >= 96 otherwise)
@@ -483,6 +485,7 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
     case 3: return launch_cfg<2, 2, 3>(a, N, 2, tiny, s);
     case 4: return launch_cfg<4, 1, 3>(a, N, 2, tiny, s);
     case 5: return launch_cfg<2, 2, 4>(a, N, 1, tiny, s);
+    case 6: return launch_cfg<1, 4, 4>(a, N, 1, tiny, s);
     default: return 0;
   }
 }
