@@ -191,10 +191,13 @@ int u2_batched_nms(const float* boxes, const int* group, const int* cnt, void* w
  *         (group = pitch = 1: contiguous rows; group = A, pitch = 32: the A valid columns of a 32-wide NHWC logit map);
  *   mask (optional, int8 [rows][n]): only elements with mask == mask_value take part;
  *   out_vals (optional) / out_idx [rows][k]: the k best in rank order; entries beyond out_cnt[r] = min(k, participants)
- *   are (-/+inf, 0).  n < 2^24, k <= 16384. */
+ *   are (-/+inf, 0).  n < 2^24, k <= 16384;
+ *   idx_in (optional, int32 [rows][n], values in [0, 2^24)): the index element i stands for - ties are broken on it and it
+ *   is what out_idx reports - so that the survivors of a first selection over segments of a long row can be merged by a
+ *   second call with the same total order. */
 int u2_topk_rows(const void* vals, int dtype, int rows, int n, long long row_stride, int group, int pitch,
                  const signed char* mask, int mask_value, int k, int largest, float* out_vals, int* out_idx,
-                 int* out_cnt, void* stream);
+                 int* out_cnt, const int* idx_in, void* stream);
 
 /* ---- inference tails (postprocess.hip) -------------------------------------------------------
  * layers/mask_ops.py:17-147 (paste_masks_in_image, GPU branch), meta_arch/panoptic_fpn.py:184-269. */

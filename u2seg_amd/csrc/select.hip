@@ -29,6 +29,7 @@ struct SelectArgs {
   int k, largest;
   float* out_vals;        // [rows][k]
   int* out_idx;           // [rows][k]
+  const int* idx_in;      // optional [rows][n]: the index an element stands for (tie-break and output) instead of its position
   int* out_cnt;           // [rows] (optional): number of real entries (min(k, participating elements))
   int cap;                // LDS slots for the survivors (power of two >= k)
 };
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_rows_kernel(const SelectArgs
   const int n = a.n;
   const float inv_group = 1.0f / (float)a.group;
   const signed char* mrow = a.mask ? a.mask + (size_t)row * n : nullptr;
+  const int* irow = a.idx_in ? a.idx_in + (size_t)row * n : nullptr;
 
   auto load_key = [&](int i, bool& ok) -> uint32_t {
     ok = !mrow || mrow[i] == (signed char)a.mask_value;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_rows_kernel(const SelectArgs
     __syncthreads();
     const unsigned long long hi_mask = fixed == 0 ? 0ull : (~0ull << (64 - fixed));
     for_each_key([&](int i, uint32_t vk) {
-      const unsigned long long key = ((unsigned long long)vk << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
+      const unsigned long long key = ((unsigned long long)vk << 32) | (uint32_t)(0xffffffffu - (uint32_t)(irow ? irow[i] : i));
       if ((key & hi_mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
     });
     __syncthreads();
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_rows_kernel(const SelectArgs
   if (tid == 0) hist[261] = 0;
   __syncthreads();
   for_each_key([&](int i, uint32_t vk) {
-    const unsigned long long key = ((unsigned long long)vk << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
+    const unsigned long long key = ((unsigned long long)vk << 32) | (uint32_t)(0xffffffffu - (uint32_t)(irow ? irow[i] : i));
     // with `fixed` high bits decided, an element is taken iff its high bits are >= the prefix (== prefix: it lies in the
     // bucket that is taken whole; > prefix: ranked above)
     if (take_all || (key & hi_mask) >= prefix) {
@@ -200,13 +202,13 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_rows_kernel(const SelectArgs
 
 extern "C" int u2_topk_rows(const void* vals, int dtype, int rows, int n, long long row_stride, int group, int pitch,
                             const signed char* mask, int mask_value, int k, int largest, float* out_vals, int* out_idx,
-                            int* out_cnt, void* stream) {
+                            int* out_cnt, const int* idx_in, void* stream) {
   if (rows <= 0 || k <= 0) return 0;
   if (n <= 0 || n >= (1 << 24) || k > 16384 || group < 1 || pitch < group || (dtype != 0 && dtype != 1)) return -1;
   SelectArgs a;
   a.vals = vals; a.dtype = dtype; a.rows = rows; a.n = n; a.row_stride = row_stride; a.group = group; a.pitch = pitch;
   a.mask = mask; a.mask_value = mask_value; a.k = k; a.largest = largest;
-  a.out_vals = out_vals; a.out_idx = out_idx; a.out_cnt = out_cnt;
+  a.out_vals = out_vals; a.out_idx = out_idx; a.out_cnt = out_cnt; a.idx_in = idx_in;
   int cap = 2;
   while (cap < k) cap <<= 1;
   a.cap = cap;

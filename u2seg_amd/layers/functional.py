@@ -885,14 +885,43 @@ def topk_rows(vals, k, largest=True, mask=None, mask_value=1, group=1, pitch=1, 
         assert vals.dim() == 2
         n = vals.shape[1]
     row_stride = vals[0].numel()
+    if mask is not None:
+        assert mask.dtype == torch.int8 and mask.is_contiguous() and tuple(mask.shape) == (rows, n)
+    segs = _topk_segments(rows, n, group, pitch, row_stride, k)
+    if segs > 1:
+        # A row is streamed by ONE work-group (five to seven dependent sweeps): long rows are cut into `segs` equal segments that
+        # are ranked as rows of their own, and the survivors (k per segment, with their original indices) are ranked again.
+        seg_n = n // segs
+        k1 = min(k, seg_n)
+        v1, i1, c1 = _topk_launch(vals, rows * segs, seg_n, row_stride // segs, group, pitch,
+                                  mask.view(rows * segs, seg_n) if mask is not None else None, mask_value, k1, largest, True, None)
+        i1 += (torch.arange(rows * segs, device=vals.device, dtype=torch.int32) % segs * seg_n)[:, None]
+        live = (torch.arange(k1, device=vals.device, dtype=torch.int32)[None, :] < c1[:, None]).to(torch.int8)
+        return _topk_launch(v1.view(rows, segs * k1), rows, segs * k1, segs * k1, 1, 1, live.view(rows, segs * k1), 1, k, largest,
+                            want_vals, i1.view(rows, segs * k1))
+    return _topk_launch(vals, rows, n, row_stride, group, pitch, mask, mask_value, k, largest, want_vals, None)
+
+
+def _topk_segments(rows, n, group, pitch, row_stride, k):
+    """How many equal segments to cut the rows of a selection into (1 = none): only long rows that few work-groups would
+    stream, a divisor of the group count (segments must tile the row exactly), segments still several times longer than k."""
+    if n < 32768 or rows >= 128 or n % group or row_stride != (n // group) * pitch:
+        return 1
+    groups = n // group
+    best = 1
+    for s in range(2, 33):
+        if groups % s == 0 and n // s >= max(4096, 2 * k) and rows * s <= 256:
+            best = s
+    return best
+
+
+def _topk_launch(vals, rows, n, row_stride, group, pitch, mask, mask_value, k, largest, want_vals, idx_in):
     dev = vals.device
     idx = torch.empty((rows, k), dtype=torch.int32, device=dev)
     out = torch.empty((rows, k), dtype=torch.float32, device=dev) if want_vals else None
     cnt = torch.empty((rows,), dtype=torch.int32, device=dev)
-    if mask is not None:
-        assert mask.dtype == torch.int8 and mask.is_contiguous() and tuple(mask.shape) == (rows, n)
     _hip.call("u2_topk_rows", vals, 1 if vals.dtype == BF16 else 0, rows, n, row_stride, group, pitch, mask, int(mask_value),
-              k, int(largest), out, idx, cnt)
+              k, int(largest), out, idx, cnt, idx_in)
     return out, idx, cnt
 
 
