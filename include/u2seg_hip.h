@@ -236,7 +236,13 @@ int u2_sgd_clip_step(float* params, const float* grads, float* momentum_buf, con
                      float clip, float grad_scale, void* stream);
 
 /* ---- k-means over DINO embeddings (kmeans.hip): u2seg/Instance_Clustering/shared/utils/nn_utils.py:304-379 ---- */
-int u2_kmeans_assign(const float* x, const float* c, float* cnorm_ws /*[K]*/, long long* labels, int N, int D, int K,
+/* labels[i] = argmin_j |x_i - c_j|^2 (first minimum).  workspace: u2_kmeans_assign_workspace_floats(N, D, K) floats.  The
+ * distances are screened with split-bf16 MFMA products and every point whose two best candidates are closer than the
+ * screening error bound is labelled again with exact fp32 products, so the result is that of the exact kernel
+ * (exact_only = 1 runs only that one; it is also what D % 32 != 0 or K > 320 fall back to).  After the call
+ * ((int*)workspace)[((K + 3) & ~3) + 1] holds the number of re-checked points. */
+long long u2_kmeans_assign_workspace_floats(int N, int D, int K);
+int u2_kmeans_assign(const float* x, const float* c, float* workspace, long long* labels, int N, int D, int K, int exact_only,
                      void* stream);
 /* csum [K][D] += sum of the rows of x by label, counts [K] += label histogram (both pre-zeroed by the caller, or holding
  * another shard's partial sums).  workspace (optional, u2_kmeans_update_workspace_floats(N, D, K) floats): the points are

@@ -559,6 +559,37 @@ def test_kmeans(golden_dir=None):
         assert bad.numel() <= 5 and torch.allclose(d_lab, d_ref, rtol=1e-5), (k, bad.numel())
 
 
+def test_kmeans_screened_assign_equals_exact():
+    """The split-bf16 screening pass + exact re-check of the undecided points must return the labels of the exact-fp32 kernel
+    for every point: on well separated data, on unit-norm clustered data with many near-ties (centroids drawn next to each
+    other), with duplicated centroids (exact ties: first index wins), and with K not a multiple of 16."""
+    from u2seg_amd.cluster import kmeans as KM
+
+    g = torch.Generator().manual_seed(21)
+    cases = []
+    x = torch.randn((20000, 768), generator=g)
+    cases.append((x, x[torch.randperm(20000, generator=g)[:300]] + 0.01 * torch.randn((300, 768), generator=g)))
+    xu = _clustered_unit_rows(30011, 384, 5, nclusters=12)
+    cu = xu[torch.randperm(30011, generator=g)[:299]].clone()
+    cu[7] = cu[3]                       # an exact duplicate
+    cu[100:140] = cu[50:90] + 1e-6      # forty near-duplicates: far below the screening resolution
+    cases.append((xu, cu))
+    cases.append((torch.randn((1000, 64), generator=g) * 5, torch.randn((17, 64), generator=g) * 5))
+    for x, c in cases:
+        xd, cd = x.to(DEV), c.to(DEV)
+        fast = KM.assign(xd, cd)
+        n_checked = KM.last_recheck_count(xd.device)
+        exact = KM.assign(xd, cd, exact=True)
+        assert torch.equal(fast, exact), int((fast != exact).sum())
+        ref = O.kmeans_assign(x[:2000], c)
+        bad = torch.nonzero(exact[:2000].cpu() != ref)[:, 0]
+        d_lab = ((x[bad] - c[exact[:2000].cpu()[bad]]) ** 2).sum(1)
+        d_ref = ((x[bad] - c[ref[bad]]) ** 2).sum(1)
+        assert torch.allclose(d_lab, d_ref, rtol=1e-5)  # the exact kernel vs the oracle: only at fp32-level ties
+        assert 0 <= n_checked <= x.shape[0]
+    assert n_checked < 1000  # the last (well separated, K = 17) case re-checks almost nothing
+
+
 def _clustered_unit_rows(n, d, seed, nclusters=40):
     g = torch.Generator().manual_seed(seed)
     centers = torch.randn((nclusters, d), generator=g)

@@ -22,14 +22,32 @@ def _update_workspace(n, d, k, device):
     return ws
 
 
-def assign(x, c):
-    """argmin_j sum_d (x_id - c_jd)^2 -> int64 [N] (u2_kmeans_assign: exact-fp32 MFMA dot products)."""
+def assign(x, c, exact=False):
+    """argmin_j sum_d (x_id - c_jd)^2 -> int64 [N] (u2_kmeans_assign: split-bf16 MFMA screening, exact-fp32 MFMA products for
+    the points it cannot decide; exact=True: the exact kernel for every point)."""
     n, d = x.shape
     k = c.shape[0]
     labels = torch.empty(n, dtype=torch.int64, device=x.device)
-    ws = torch.empty(k, dtype=torch.float32, device=x.device)
-    _hip.call("u2_kmeans_assign", x.contiguous(), c.contiguous(), ws, labels, n, d, k)
+    need = _hip.call_nostream("u2_kmeans_assign_workspace_floats", n, d, k)
+    key = "assign:" + str(x.device)
+    ent = _ws_cache.get(key)
+    ws = ent[0] if ent is not None else None
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=x.device)
+    _ws_cache[key] = (ws, k)
+    _hip.call("u2_kmeans_assign", x.contiguous(), c.contiguous(), ws, labels, n, d, k, int(exact))
     return labels
+
+
+def last_recheck_count(device):
+    """How many points the last assign() on `device` sent to the exact kernel (reads the workspace: one host sync)."""
+    ent = _ws_cache.get("assign:" + str(device))
+    if ent is None:
+        return None
+    ws, k = ent if isinstance(ent, tuple) else (ent, None)
+    if k is None:
+        return None
+    return int(ws.view(torch.int32)[((k + 3) & ~3) + 1])
 
 
 def update(x, labels, k):

@@ -39,12 +39,19 @@ __device__ __forceinline__ bool km_less(float v, int j, float bv, int bj) {
   return v < bv || (v == bv && j < bj);
 }
 
+// rows / nrows (optional): the kernel labels the points rows[0 .. *nrows) instead of 0 .. N - 1 (the re-check list of the
+// screening kernel below; the grid is sized for the worst case and work-groups past the list leave at once)
 __global__ __launch_bounds__(256, 1) void kmeans_assign_kernel(const float* __restrict__ x, const float* __restrict__ c,
                                                                const float* __restrict__ cn, long long* __restrict__ labels,
-                                                               int N, int D, int K) {
+                                                               int N, int D, int K, const int* __restrict__ rows,
+                                                               const int* __restrict__ nrows) {
   __shared__ float stage[2 * KM_STAGE];  // [2][xs: KM_PTS x KM_PITCH | cs: 320 x KM_PITCH]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int p0 = blockIdx.x * KM_PTS;
+  if (rows) {
+    N = min(N, *nrows);
+    if (p0 >= N) return;
+  }
   const int li = lane & 31, lk = lane >> 5;
 
   float best_v[16];
@@ -68,7 +75,10 @@ __global__ __launch_bounds__(256, 1) void kmeans_assign_kernel(const float* __re
     const float* xrow[2];
     const float* crow[5];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) xrow[q] = x + (size_t)min(p0 + ((q * 256 + tid) >> 2), N - 1) * D + c4 * 4;
+    for (int q = 0; q < 2; ++q) {
+      const int pi = min(p0 + ((q * 256 + tid) >> 2), N - 1);
+      xrow[q] = x + (size_t)(rows ? rows[pi] : pi) * D + c4 * 4;
+    }
 #pragma unroll
     for (int q = 0; q < 5; ++q) crow[q] = c + (size_t)min(k0 + ((q * 256 + tid) >> 2), K - 1) * D + c4 * 4;
     auto gload = [&](int d0) {
@@ -168,9 +178,190 @@ __global__ __launch_bounds__(256, 1) void kmeans_assign_kernel(const float* __re
     }
     if (li == 0) {
       const int p = p0 + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      if (p < N) labels[p] = (long long)j;
+      if (p < N) labels[rows ? rows[p] : p] = (long long)j;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// E step, fast form: screen with split-bf16 MFMA, re-check the few undecided points exactly.
+//
+// x and c are split into two bf16 pieces each (v = hi + lo + r, |r| <= 2^-17 |v|) and the dot product is taken as
+// hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 (fp32 accumulation): three MFMAs at the bf16 rate instead of one at
+// the fp32 rate (16x the throughput), with |error| <= 3 * 2^-18 * sum_d |x_d c_d| <= 1.2e-5 |x| |c|.  A point whose two
+// best distances differ by less than 1e-4 |x| max_j |c_j| (4x the worst case of both errors) is appended to a list and
+// labelled again by the exact-fp32 kernel above - so the labels are those of the exact kernel for every point, while
+// more than 99 % of the points never see it.
+//
+// Work-group = 256 points x 320 centroids (8 waves of 32 points; 160 accumulator registers): x goes from HBM straight
+// into the MFMA A-operand registers (each element is needed by exactly one wave) and is split there; the split
+// centroids (L2-resident, 2 x 320 x D bf16) stream through a three-stage LDS ring by LDS-DMA, 40 KB per 32-dimension step.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int KS_PTS = 256;
+constexpr int KS_NB = 20;                    // 16-centroid blocks: 320 centroids
+constexpr int KS_KMAX = KS_NB * 16;
+constexpr int KS_STAGE = 2 * KS_KMAX * 64;   // [hi | lo][320 rows][32 bf16]
+constexpr int KS_RING = 3;
+constexpr int KS_DMA = KS_STAGE / 1024 / 8;  // LDS-DMA instructions per wave per step (5)
+
+// chl [2][320][D] bf16 (hi plane, lo plane; rows >= K zero), cn[j] = |c_j|^2 in fp32, *cmax2 = max_j cn[j]
+__global__ __launch_bounds__(256) void csplit_kernel(const float* __restrict__ c, bf16_t* __restrict__ chl, float* __restrict__ cn,
+                                                     unsigned* __restrict__ cmax2, int D, int K) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= KS_KMAX) return;
+  float s = 0.f;
+  for (int d = threadIdx.x & 63; d < D; d += 64) {
+    const float v = j < K ? c[(size_t)j * D + d] : 0.f;
+    const bf16_t h = f2bf(v);
+    chl[(size_t)j * D + d] = h;
+    chl[((size_t)KS_KMAX + j) * D + d] = f2bf(v - bf2f(h));
+    s += v * v;
+  }
+  if (j >= K) return;
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) {
+    cn[j] = s;
+    atomicMax(cmax2, __float_as_uint(s));  // s >= 0: the unsigned order of the bits is the order of the floats
+  }
+}
+
+typedef __attribute__((ext_vector_type(2))) __bf16 ks_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float ks_f32x2;
+__device__ __forceinline__ uint32_t ks_pack(float lo, float hi) {  // v_cvt_pk_bf16_f32, round to nearest even
+  const ks_f32x2 v = {lo, hi};
+  const ks_bf16x2 r = __builtin_convertvector(v, ks_bf16x2);
+  return *reinterpret_cast<const uint32_t*>(&r);
+}
+__device__ __forceinline__ int ks_swz(int row) { return (-(row >> 2)) & 3; }  // 64-byte rows: conflict-free ds_read_b128
+
+__global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restrict__ x, const bf16_t* __restrict__ chl,
+                                                            const float* __restrict__ cn, const unsigned* __restrict__ cmax2,
+                                                            long long* __restrict__ labels, int* __restrict__ list,
+                                                            int* __restrict__ nlist, int N, int D, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int p0 = blockIdx.x * KS_PTS + w * 32;
+  const int nsteps = D >> 5;
+
+  // x: lane (fr, fg) owns row m * 16 + fr, dimensions d0 + fg * 8 .. + 7 of both 16-point blocks (the MFMA A layout)
+  const float* xp[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) xp[m] = x + (size_t)min(p0 + m * 16 + fr, N - 1) * D + fg * 8;
+  f32x4 raw[2][2];
+  auto load_x = [&]() {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                   : "=&v"(raw[m][0]), "=&v"(raw[m][1]) : "v"(xp[m]) : "memory");
+      xp[m] += 32;
+    }
+  };
+  // centroids: instruction i of wave w fills LDS rows (w * 5 + i) * 16 .. + 15 (row = plane * 320 + centroid)
+  const bf16_t* cp[KS_DMA];
+#pragma unroll
+  for (int i = 0; i < KS_DMA; ++i) {
+    const int row = (w * KS_DMA + i) * 16 + (lane >> 2);
+    cp[i] = chl + (size_t)row * D + (((lane & 3) ^ ks_swz(lane >> 2)) << 3);
+  }
+  auto stage_c = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < KS_DMA; ++i) {
+      __builtin_amdgcn_global_load_lds(U2_GLB_PTR(cp[i]), U2_LDS_PTR(ks_smem + buf * KS_STAGE + (w * KS_DMA + i) * 1024), 16, 0, 0);
+      cp[i] += 32;
+    }
+  };
+  const int boff = fr * 64 + ((fg ^ ks_swz(fr)) << 4);  // B fragment of block nb, plane pl: + (pl * 320 + nb * 16) * 64
+
+  f32x4 acc[2][KS_NB];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int nb = 0; nb < KS_NB; ++nb) acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float n2[2] = {0.f, 0.f};
+
+  // in flight at the top of step s, oldest first: centroids(s), x(s), centroids(s + 1)
+  stage_c(0);
+  load_x();
+  if (nsteps > 1) stage_c(1);
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS_DMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
+    __builtin_amdgcn_s_barrier();  // stage s is complete for every wave, and every wave is done with stage s - 1
+    asm volatile("" ::: "memory");
+    // split this step's x into its two bf16 pieces (MFMA A operands)
+    s16x8 ah[2], al[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      uint32_t h[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v0 = raw[m][e >> 1][(e & 1) * 2], v1 = raw[m][e >> 1][(e & 1) * 2 + 1];
+        n2[m] += v0 * v0 + v1 * v1;
+        h[e] = ks_pack(v0, v1);
+        l[e] = ks_pack(v0 - __uint_as_float(h[e] << 16), v1 - __uint_as_float(h[e] & 0xffff0000u));
+      }
+      ah[m] = *reinterpret_cast<const s16x8*>(h);
+      al[m] = *reinterpret_cast<const s16x8*>(l);
+    }
+    if (s + 1 < nsteps) load_x();
+    if (s + 2 < nsteps) stage_c((s + 2) % KS_RING);
+    const unsigned char* sb = ks_smem + (s % KS_RING) * KS_STAGE + boff;
+#pragma unroll
+    for (int nb = 0; nb < KS_NB; ++nb) {
+      const s16x8 bh = *reinterpret_cast<const s16x8*>(sb + nb * 1024);
+      const s16x8 bl = *reinterpret_cast<const s16x8*>(sb + KS_KMAX * 64 + nb * 1024);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh, acc[m][nb], 0, 0, 0);
+        acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl, acc[m][nb], 0, 0, 0);
+        acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh, acc[m][nb], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+  // |x| per point: the four k-chunk lanes of a row, then through LDS into the D layout (lane (fg, fr): points fg * 4 + r)
+  float* norms = reinterpret_cast<float*>(ks_smem);
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    float v = n2[m];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (fg == 0) norms[w * 32 + m * 16 + fr] = sqrtf(v);
+  }
+  __syncthreads();
+  const float margin_unit = 1e-4f * sqrtf(__uint_as_float(*cmax2));
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float b = INFINITY, s2 = INFINITY;
+      int bj = 0x7fffffff;
+#pragma unroll
+      for (int nb = 0; nb < KS_NB; ++nb) {
+        const int j = nb * 16 + fr;
+        if (j < K) {
+          const float v = cn[j] - 2.f * acc[m][nb][r];
+          if (km_less(v, j, b, bj)) { s2 = b; b = v; bj = j; }
+          else if (v < s2) s2 = v;
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const float ob = __shfl_xor(b, o, 64), os2 = __shfl_xor(s2, o, 64);
+        const int obj = __shfl_xor(bj, o, 64);
+        if (km_less(ob, obj, b, bj)) { s2 = fminf(b, os2); b = ob; bj = obj; }
+        else s2 = fminf(s2, ob);
+      }
+      const int pl = m * 16 + fg * 4 + r;
+      const int p = p0 + pl;
+      if (fr == 0 && p < N) {
+        labels[p] = (long long)bj;
+        if (!(s2 - b >= margin_unit * norms[w * 32 + pl])) list[atomicAdd(nlist, 1)] = p;  // also: NaN anywhere, K == 1
+      }
+    }
 }
 
 // csum[K][D] += x rows by label; counts[K] += 1.  grid = (point chunks, D / DS); LDS holds [K][DS] partial sums.
@@ -330,14 +521,44 @@ __global__ void kmeans_finalize_kernel(const float* __restrict__ csum, const flo
 
 }  // namespace
 
-extern "C" int u2_kmeans_assign(const float* x, const float* c, float* cnorm_ws, long long* labels, int N, int D, int K,
-                                void* stream) {
-  if (D % KM_BD != 0 || K < 1 || !cnorm_ws) return -1;
+extern "C" long long u2_kmeans_assign_workspace_floats(int N, int D, int K) {
+  // |c|^2 [K] | max |c|^2, list length [2] | split centroids [2][320][D] bf16 | re-check list [N]
+  return (long long)K + 16 + (long long)KS_KMAX * D + N + 16;
+}
+
+extern "C" int u2_kmeans_assign(const float* x, const float* c, float* workspace, long long* labels, int N, int D, int K,
+                                int exact_only, void* stream) {
+  if (D % KM_BD != 0 || K < 1 || !workspace) return -1;
   if (N <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(cnorm_kernel, dim3((K + 3) / 4), dim3(256), 0, s, c, cnorm_ws, D, K);
+  float* cn = workspace;
+  const bool screen = !exact_only && D % 32 == 0 && K <= KS_KMAX && K >= 2 && N >= KS_PTS;
+  if (!screen) {
+    hipLaunchKernelGGL(cnorm_kernel, dim3((K + 3) / 4), dim3(256), 0, s, c, cn, D, K);
+    U2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(kmeans_assign_kernel, dim3((N + KM_PTS - 1) / KM_PTS), dim3(256), 0, s, x, c, cn, labels, N, D, K,
+                       (const int*)nullptr, (const int*)nullptr);
+    U2_CHECK_LAUNCH();
+    return 0;
+  }
+  unsigned* scal = reinterpret_cast<unsigned*>(workspace + ((K + 3) & ~3));  // [0] max |c|^2 bits, [1] list length
+  bf16_t* chl = reinterpret_cast<bf16_t*>(workspace + ((K + 3) & ~3) + 4);
+  int* list = reinterpret_cast<int*>(workspace + ((K + 3) & ~3) + 4 + (size_t)KS_KMAX * D);
+  hipError_t e = hipMemsetAsync(scal, 0, 8, s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(csplit_kernel, dim3(KS_KMAX / 4), dim3(256), 0, s, c, chl, cn, scal, D, K);
   U2_CHECK_LAUNCH();
-  hipLaunchKernelGGL(kmeans_assign_kernel, dim3((N + KM_PTS - 1) / KM_PTS), dim3(256), 0, s, x, c, cnorm_ws, labels, N, D, K);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kmeans_screen_kernel, dim3((N + KS_PTS - 1) / KS_PTS), dim3(512), KS_RING * KS_STAGE, s, x, chl, cn, scal,
+                     labels, list, reinterpret_cast<int*>(scal + 1), N, D, K);
+  U2_CHECK_LAUNCH();
+  // the undecided points, exactly; the grid covers the worst case, work-groups beyond the list return immediately
+  hipLaunchKernelGGL(kmeans_assign_kernel, dim3((N + KM_PTS - 1) / KM_PTS), dim3(256), 0, s, x, c, cn, labels, N, D, K,
+                     (const int*)list, (const int*)(scal + 1));
   U2_CHECK_LAUNCH();
   return 0;
 }
