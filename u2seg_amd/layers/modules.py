@@ -155,12 +155,39 @@ class Conv2d(nn.Module):
                                         relu, norm.momentum, norm.eps, twin=twin, sync=norm.sync, res_up=True)
             return F.batch_norm_act(y, stats, norm.weight, norm.bias, norm.running_mean, norm.running_var, residual,
                                     relu, norm.momentum, norm.eps, twin=twin, sync=norm.sync)
-        y = F.conv2d(x, self.weight, None, self.stride, self.padding, relu=False)
         if isinstance(norm, GroupNorm):
             assert residual is None
+            y = F.conv2d(x, self.weight, None, self.stride, self.padding, relu=False)
             return F.group_norm_act(y, norm.weight, norm.bias, norm.num_groups, relu, norm.eps)
+        # fixed statistics (eval-mode BN / FrozenBN): y * scale + shift is an affine map per output channel
+        if not torch.is_grad_enabled():
+            folded = self._folded_eval()
+            if residual is None:
+                # folded into the conv: weights scaled per output channel, shift as the bias, ReLU in the epilogue - no
+                # elementwise pass at all (the conv kernels add a bias and clamp before the one bf16 rounding)
+                return F.conv2d(x, folded[0], folded[1], self.stride, self.padding, relu=relu, param=folded[0])
+            y = F.conv2d(x, self.weight, None, self.stride, self.padding, relu=False)
+            return F.affine_act(y, folded[2], folded[3], residual, relu)
+        y = F.conv2d(x, self.weight, None, self.stride, self.padding, relu=False)
         scale, shift = norm.eval_scale_shift()
         return F.affine_act(y, scale.float(), shift.float(), residual, relu)
+
+    def _folded_eval(self):
+        """(scaled weight, shift, scale, shift) of conv + fixed-statistics norm, cached until any of the tensors involved
+        changes through torch (version counters) or is re-allocated."""
+        norm = self.norm
+        parts = (self.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var)
+        key = tuple((t._version, t.data_ptr()) for t in parts)
+        hit = self.__dict__.get("_u2_fold")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        with torch.no_grad():
+            scale, shift = norm.eval_scale_shift()
+            scale, shift = scale.float().contiguous(), shift.float().contiguous()
+            wf = (self.weight.detach().float() * scale.view(-1, 1, 1, 1)).contiguous()
+        val = (wf, shift, scale, shift)
+        self.__dict__["_u2_fold"] = (key, val)
+        return val
 
 
 class Linear(nn.Module):
