@@ -10,6 +10,8 @@ Every function here launches HIP kernels; none has a CPU or ATen compute fallbac
 """
 import math
 
+import os
+
 import torch
 import torch.distributed as dist
 from torch.autograd import Function
@@ -123,6 +125,57 @@ def weight_fc_dgrad_layout(w, cp, npad, owner=None):
 
 
 # --------------------------------------------------------------------------------------------
+# weight gradients on a second stream
+# --------------------------------------------------------------------------------------------
+# Nothing in the backward pass reads a weight gradient, so the wgrad kernels of all convolutions run on a side stream:
+# they overlap with the data-gradient convs and - more usefully, MFMA work beside HBM-bound work - with the norm /
+# ROI backward passes of the main stream, and one fills the other's partially occupied tail rounds.  The side stream
+# waits for the main stream at every launch (its operands are produced there); the main stream waits for the side stream
+# once, in a callback that autograd runs when the backward pass ends (so `.grad` is complete when backward() returns),
+# and wherever gradients are consumed earlier (solver.FlatSGD: the all-reduce of the arena's tail starts inside backward).
+_WGRAD_SIDE = os.environ.get("U2_WGRAD_SIDE_STREAM", "1") != "0"
+_side_streams = {}
+_side_dirty = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def join_wgrad_stream(device=None):
+    """Make the current stream wait for every weight-gradient launch issued so far."""
+    for dev, s in _side_streams.items():
+        if device is None or dev == torch.device(device):
+            _side_dirty[dev] = False
+            torch.cuda.current_stream(dev).wait_stream(s)
+
+
+def _run_wgrad(device, operands, launch):
+    """launch() (kernel launches + torch ops) on the side stream; `operands` were produced on the current stream."""
+    if not _WGRAD_SIDE:
+        launch()
+        return
+    main = torch.cuda.current_stream(device)
+    side = _side_stream(device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        launch()
+    for t in operands:
+        t.record_stream(side)  # their memory may be released on the main stream while the side stream still reads it
+    _side_dirty[device] = True
+
+    def _join():  # runs when the backward pass has finished (queued once per launch: the first one to run does the work)
+        if _side_dirty.get(device):
+            _side_dirty[device] = False
+            main.wait_stream(side)
+
+    torch.autograd.Variable._execution_engine.queue_callback(_join)
+
+
+# --------------------------------------------------------------------------------------------
 # convolution / linear
 # --------------------------------------------------------------------------------------------
 class _Conv2dFn(Function):
@@ -153,6 +206,8 @@ class _Conv2dFn(Function):
         ctx.cfg = (stride, pad, relu, bias is not None)
         # 1x1 / linear weights: the gradient is accumulated straight into the optimizer's arena slice
         ctx.wgrad_dst = wgrad_dst if (kh * kw == 1 and wgrad_dst is not None) else None
+        # the arena slice in the parameter's own [N, Cin, KH, KW] shape (multi-tap filters accumulate into it with a torch add)
+        ctx.arena = wgrad_dst if (wgrad_dst is not None and tuple(wgrad_dst.shape) == tuple(weight.shape)) else None
         ctx.param = param
         ctx.set_materialize_grads(False)  # no zero tensor for the (non-differentiable) statistics output
         if want_stats:
@@ -189,10 +244,23 @@ class _Conv2dFn(Function):
                           kh - 1 - pad, kw - 1 - pad, 1, stride, 0, 0, 0)
         if ctx.needs_input_grad[1]:
             dst = ctx.wgrad_dst
+            arena = ctx.arena
             if dst is not None:
                 assert dst.is_contiguous() and dst.dtype == torch.float32 and dst.numel() == n * cin
-                _hip.call("u2_conv_wgrad_into", x, dz, dst, b, h, w_, cp, cp, ho, wo, npad, npad, kh, kw, pad, pad, stride,
-                          n, cin, cin, 1, 1, 0)
+
+                def launch():
+                    _hip.call("u2_conv_wgrad_into", x, dz, dst, b, h, w_, cp, cp, ho, wo, npad, npad, kh, kw, pad, pad, stride,
+                              n, cin, cin, 1, 1, 0)
+
+                _run_wgrad(x.device, (x, dz), launch)
+            elif arena is not None and _WGRAD_SIDE:
+                # multi-tap filters: kernel-layout scratch, then permuted into the arena slice - all of it on the side stream
+                def launch():
+                    dwk = torch.zeros((npad, kh * kw, cp), dtype=torch.float32, device=x.device)
+                    _hip.call("u2_conv_wgrad", x, dz, dwk, b, h, w_, cp, cp, ho, wo, npad, npad, kh, kw, pad, pad, stride, 0)
+                    arena.add_(dwk[:n, :, :cin].view(n, kh, kw, cin).permute(0, 3, 1, 2))
+
+                _run_wgrad(x.device, (x, dz), launch)
             else:
                 dwk = zeros_f32((npad, kh * kw, cp), x.device)
                 _hip.call("u2_conv_wgrad", x, dz, dwk, b, h, w_, cp, cp, ho, wo, npad, npad, kh, kw, pad, pad, stride, 0)
