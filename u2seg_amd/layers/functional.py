@@ -36,7 +36,7 @@ class _ZeroPool:
     CHUNK = 1 << 22
 
     def __init__(self):
-        self.chunk, self.off = None, 0
+        self.chunks = {}  # (device, stream) -> [chunk, offset]: a chunk is filled on, and only handed out to, one stream
 
     def take(self, shape, device):
         numel = 1
@@ -45,10 +45,12 @@ class _ZeroPool:
         if numel * 2 > self.CHUNK or numel == 0:
             return torch.zeros(shape, dtype=torch.float32, device=device)
         n = (numel + 63) // 64 * 64
-        if self.chunk is None or self.chunk.device != device or self.off + n > self.CHUNK:
-            self.chunk, self.off = torch.zeros(self.CHUNK, dtype=torch.float32, device=device), 0
-        v = self.chunk[self.off : self.off + numel].view(shape)
-        self.off += n
+        key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+        ent = self.chunks.get(key)
+        if ent is None or ent[1] + n > self.CHUNK:
+            ent = self.chunks[key] = [torch.zeros(self.CHUNK, dtype=torch.float32, device=device), 0]
+        v = ent[0][ent[1] : ent[1] + numel].view(shape)
+        ent[1] += n
         return v
 
 
@@ -145,6 +147,20 @@ def _side_stream(device):
     return s
 
 
+_aux_streams = {}
+
+
+def aux_stream(device):
+    """A second compute stream for an independent branch of the model (None when switched off: U2_AUX_STREAM=0)."""
+    if os.environ.get("U2_AUX_STREAM", "1") == "0":
+        return None
+    device = torch.device(device)
+    s = _aux_streams.get(device)
+    if s is None:
+        s = _aux_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 def join_wgrad_stream(device=None):
     """Make the current stream wait for every weight-gradient launch issued so far."""
     for dev, s in _side_streams.items():
@@ -170,7 +186,7 @@ def _run_wgrad(device, operands, launch):
     def _join():  # runs when the backward pass has finished (queued once per launch: the first one to run does the work)
         if _side_dirty.get(device):
             _side_dirty[device] = False
-            main.wait_stream(side)
+            torch.cuda.current_stream(device).wait_stream(side)  # the stream backward() was called on
 
     torch.autograd.Variable._execution_engine.queue_callback(_join)
 

@@ -160,10 +160,24 @@ class PanopticFPN(GeneralizedRCNN):
         gt_sem_seg = self._sem_seg_targets(batched_inputs, padded_hw)
         sem_f, rpn_f, roi_f = self._fan_out_features(
             features, [self.sem_seg_head.in_features, self.proposal_generator.in_features, self.roi_heads.box_in_features])
-        _, sem_seg_losses = self.sem_seg_head(sem_f, gt_sem_seg)
+        # The semantic head only shares the FPN maps with the detector branch: it runs on a second stream, so that its large
+        # kernels fill the chip while the proposal / sampling bookkeeping of the other branch occupies a few CUs at a time
+        # (autograd replays every node on the stream of its forward pass, so the backward passes overlap the same way).
+        aux = F.aux_stream(self.device) if sem_f[self.sem_seg_head.in_features[0]].is_cuda else None
+        if aux is not None:
+            main = torch.cuda.current_stream(self.device)
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                _, sem_seg_losses = self.sem_seg_head(sem_f, gt_sem_seg)
+            for t in list(sem_f.values()) + [gt_sem_seg]:
+                t.record_stream(aux)
+        else:
+            _, sem_seg_losses = self.sem_seg_head(sem_f, gt_sem_seg)
         gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         proposals, proposal_losses = self.proposal_generator(image_sizes, rpn_f, gt_instances)
         _, detector_losses = self.roi_heads(None, roi_f, proposals, gt_instances)
+        if aux is not None:
+            main.wait_stream(aux)
         losses = sem_seg_losses
         losses.update(proposal_losses)
         losses.update(detector_losses)
