@@ -185,9 +185,24 @@ class PanopticFPN(GeneralizedRCNN):
 
     def inference(self, batched_inputs, do_postprocess=True):
         features, image_sizes, _ = self._backbone_features(batched_inputs)
-        sem_seg_results, _ = self.sem_seg_head(features, None)
+        # as in training: the semantic head beside the detector branch, whose NMS / selection steps use a few CUs at a time
+        aux = F.aux_stream(self.device) if next(iter(features.values())).is_cuda else None
+        if aux is not None:
+            main = torch.cuda.current_stream(self.device)
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                sem_seg_results, _ = self.sem_seg_head(features, None)
+            for t in features.values():
+                t.record_stream(aux)
+        else:
+            sem_seg_results, _ = self.sem_seg_head(features, None)
         proposals, _ = self.proposal_generator(image_sizes, features, None)
         detector_results, _ = self.roi_heads(None, features, proposals, None)
+        if aux is not None:
+            main.wait_stream(aux)
+            sem_seg_results.record_stream(main)
+            if getattr(sem_seg_results, "u2_argmax", None) is not None:
+                sem_seg_results.u2_argmax.record_stream(main)
         if not do_postprocess:
             return detector_results, sem_seg_results
         out_sizes = [(inp.get("height", size[0]), inp.get("width", size[1])) for inp, size in zip(batched_inputs, image_sizes)]
