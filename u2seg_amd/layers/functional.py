@@ -150,15 +150,29 @@ def _side_stream(device):
 _aux_streams = {}
 
 
+def _cuda_device(device):
+    device = torch.device(device)
+    return torch.device("cuda", torch.cuda.current_device()) if device.index is None else device
+
+
 def aux_stream(device):
     """A second compute stream for an independent branch of the model (None when switched off: U2_AUX_STREAM=0)."""
     if os.environ.get("U2_AUX_STREAM", "1") == "0":
         return None
-    device = torch.device(device)
+    device = _cuda_device(device)
     s = _aux_streams.get(device)
     if s is None:
         s = _aux_streams[device] = torch.cuda.Stream(device=device)
     return s
+
+
+def join_aux_stream(device):
+    """The current stream waits for everything queued on the second compute stream."""
+    if not torch.cuda.is_available() or torch.device(device).type != "cuda":
+        return
+    s = _aux_streams.get(_cuda_device(device))
+    if s is not None:
+        torch.cuda.current_stream(s.device).wait_stream(s)
 
 
 def join_wgrad_stream(device=None):

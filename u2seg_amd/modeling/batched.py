@@ -27,7 +27,12 @@ def device_constant(values, dtype, device):
         return hit
     host = torch.tensor(values, dtype=dtype)
     dev = torch.device(device)
-    out = host.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else host.to(dev)
+    if dev.type == "cuda":
+        out = host.pin_memory().to(dev, non_blocking=True)
+        # a cached constant is handed to whichever stream asks next: finish the copy once, here (first use of a value only)
+        torch.cuda.current_stream(dev).synchronize()
+    else:
+        out = host.to(dev)
     _const_cache[key] = out
     if len(_const_cache) > 512:
         _const_cache.popitem(last=False)

@@ -92,6 +92,7 @@ class GeneralizedRCNN(nn.Module):
         rpn_f, roi_f = self._fan_out_features(features, [self.proposal_generator.in_features, self.roi_heads.box_in_features])
         proposals, proposal_losses = self.proposal_generator(image_sizes, rpn_f, gt_instances)
         _, detector_losses = self.roi_heads(None, roi_f, proposals, gt_instances)
+        F.join_aux_stream(self.device)  # the RPN losses were computed on the second stream
         losses = {}
         losses.update(detector_losses)
         losses.update(proposal_losses)
@@ -176,8 +177,7 @@ class PanopticFPN(GeneralizedRCNN):
         gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         proposals, proposal_losses = self.proposal_generator(image_sizes, rpn_f, gt_instances)
         _, detector_losses = self.roi_heads(None, roi_f, proposals, gt_instances)
-        if aux is not None:
-            main.wait_stream(aux)
+        F.join_aux_stream(self.device)  # semantic head and RPN losses
         losses = sem_seg_losses
         losses.update(proposal_losses)
         losses.update(detector_losses)
