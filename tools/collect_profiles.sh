@@ -7,10 +7,12 @@ TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_train -o bench -- \
   python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${TAG}_train.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_train_serial -o bench -- \
+  python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --serial > $R/gpurun_out/${TAG}_train_serial.log 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch -o bench -- \
-  python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_pmc_fetch.log 2>&1
+  python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --serial > $R/gpurun_out/${TAG}_pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_pmc_write -o bench -- \
-  python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_pmc_write.log 2>&1
+  python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --serial > $R/gpurun_out/${TAG}_pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_kmeans -o bench -- \
   python $R/bench.py --workload kmeans --no-cpu-baseline > $R/gpurun_out/${TAG}_kmeans.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_infer -o bench -- \
@@ -18,4 +20,4 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 # keep the merge small: the per-dispatch traces are not needed, only the statistics and the counter rows
 find $R/gpurun_out -name "*kernel_trace.csv" -path "*${TAG}_*" ! -path "*pmc*" -delete
 ls -la $R/gpurun_out/${TAG}_*/ | head -40
-for f in train pmc_fetch pmc_write kmeans infer; do tail -1 $R/gpurun_out/${TAG}_$f.log | cut -c1-200; done
+for f in train train_serial pmc_fetch pmc_write kmeans infer; do tail -1 $R/gpurun_out/${TAG}_$f.log | cut -c1-200; done

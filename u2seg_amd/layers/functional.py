@@ -136,6 +136,15 @@ def weight_fc_dgrad_layout(w, cp, npad, owner=None):
 # once, in a callback that autograd runs when the backward pass ends (so `.grad` is complete when backward() returns),
 # and wherever gradients are consumed earlier (solver.FlatSGD: the all-reduce of the arena's tail starts inside backward).
 _WGRAD_SIDE = os.environ.get("U2_WGRAD_SIDE_STREAM", "1") != "0"
+_AUX_ENABLED = True
+
+
+def set_stream_overlap(on):
+    """Switch the side stream (weight gradients) and the second compute stream (semantic head) on / off at run time; off =
+    every kernel of the step in one stream, one after the other (bench.py times its kernels that way)."""
+    global _WGRAD_SIDE, _AUX_ENABLED
+    _WGRAD_SIDE = bool(on) and os.environ.get("U2_WGRAD_SIDE_STREAM", "1") != "0"
+    _AUX_ENABLED = bool(on)
 _side_streams = {}
 _side_dirty = {}
 
@@ -157,7 +166,7 @@ def _cuda_device(device):
 
 def aux_stream(device):
     """A second compute stream for an independent branch of the model (None when switched off: U2_AUX_STREAM=0)."""
-    if os.environ.get("U2_AUX_STREAM", "1") == "0":
+    if not _AUX_ENABLED or os.environ.get("U2_AUX_STREAM", "1") == "0":
         return None
     device = _cuda_device(device)
     s = _aux_streams.get(device)
