@@ -164,22 +164,23 @@ def _cuda_device(device):
     return torch.device("cuda", torch.cuda.current_device()) if device.index is None else device
 
 
-def aux_stream(device):
-    """A second compute stream for an independent branch of the model (None when switched off: U2_AUX_STREAM=0)."""
+def aux_stream(device, index=0):
+    """A further compute stream for an independent branch of the model (None when switched off: U2_AUX_STREAM=0).
+    index 0: the semantic head; index 1: the mask head beside the box cascade."""
     if not _AUX_ENABLED or os.environ.get("U2_AUX_STREAM", "1") == "0":
         return None
-    device = _cuda_device(device)
-    s = _aux_streams.get(device)
+    key = (_cuda_device(device), index)
+    s = _aux_streams.get(key)
     if s is None:
-        s = _aux_streams[device] = torch.cuda.Stream(device=device)
+        s = _aux_streams[key] = torch.cuda.Stream(device=key[0])
     return s
 
 
-def join_aux_stream(device):
-    """The current stream waits for everything queued on the second compute stream."""
+def join_aux_stream(device, index=0):
+    """The current stream waits for everything queued on that further compute stream."""
     if not torch.cuda.is_available() or torch.device(device).type != "cuda":
         return
-    s = _aux_streams.get(_cuda_device(device))
+    s = _aux_streams.get((_cuda_device(device), index))
     if s is not None:
         torch.cuda.current_stream(s.device).wait_stream(s)
 
@@ -872,6 +873,13 @@ class _RoiGradTapFn(Function):
         st = ctx.state
         grads = list(gfeats)
         pend, st.pending = st.pending, []
+        here = torch.cuda.current_stream(pend[0][3].device) if pend and pend[0][3].is_cuda else None
+        for entry in pend:  # a set left by a ROIAlign that ran on another stream (the mask head's): wait for it, keep it alive
+            ev = entry[6] if len(entry) > 6 else None
+            if ev is not None and here is not None:
+                here.wait_event(ev)
+                for t in entry[:4]:
+                    t.record_stream(here)
         for i in range(0, len(pend), 4):
             gbuf = _roi_gather(st.shapes, st.scales, pend[i : i + 4], pend[i][3].device)
             grads = [g if old is None else old + g for old, g in zip(grads, gbuf)]
@@ -936,6 +944,10 @@ class _ROIAlignFn(Function):
         tap = ctx.tap
         if tap is not None:  # deferred: the tap's backward gathers all pending sets at once
             tap.scales = scales
+            if dout.is_cuda:  # the tap may run on another stream than this node: mark the point its inputs are complete at
+                ev = torch.cuda.Event()
+                ev.record()
+                entry = entry + (ev,)
             tap.pending.append(entry)
             return (*none, *([None] * nl))
         return (*none, *_roi_gather(shapes, scales, [entry], dout.device))

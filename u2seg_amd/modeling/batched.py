@@ -156,6 +156,8 @@ def image_index(sizes, device):
         idx = torch.repeat_interleave(torch.arange(len(sizes), dtype=torch.float32), torch.tensor(sizes, dtype=torch.int64))
         dev = torch.device(device)
         hit = _const_cache[key] = idx.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else idx.to(dev)
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()  # cached for any stream: finish the upload once
         if len(_const_cache) > 512:
             _const_cache.popitem(last=False)
     return hit

@@ -5,6 +5,8 @@ roi_heads/cascade_rcnn.py:20-299).  Per-image Python loops remain only for the i
 reference also does per image; all arithmetic on features runs in the HIP kernels."""
 import math
 
+import os
+
 import torch
 from torch import nn
 
@@ -588,8 +590,21 @@ class CascadeROIHeads(StandardROIHeads):
         if self.training:
             proposals = self.label_and_sample_proposals(proposals, targets)
             features = self._tap_pooled_features(features)
-            losses = self._forward_box(features, proposals, targets)
-            losses.update(self._forward_mask(features, proposals))
+            # the mask head only needs the sampled proposals: it runs on its own stream beside the three cascade stages, whose
+            # decode / match / relabel steps between the stages leave most of the chip idle
+            stacked = self.mask_on and isinstance(proposals, BatchList) and proposals.stacked and proposals.boxes.is_cuda
+            aux = F.aux_stream(proposals.boxes.device, 1) if stacked and os.environ.get("U2_MASK_STREAM", "1") != "0" else None
+            if aux is not None:
+                main = torch.cuda.current_stream(proposals.boxes.device)
+                aux.wait_stream(main)
+                with torch.cuda.stream(aux):
+                    mask_losses = self._forward_mask(features, proposals)
+                losses = self._forward_box(features, proposals, targets)
+                main.wait_stream(aux)
+                losses.update(mask_losses)
+            else:
+                losses = self._forward_box(features, proposals, targets)
+                losses.update(self._forward_mask(features, proposals))
             return proposals, losses
         pred_instances = self._forward_box(features, proposals)
         pred_instances = self.forward_with_given_boxes(features, pred_instances)
