@@ -185,6 +185,15 @@ def join_aux_stream(device, index=0):
         torch.cuda.current_stream(s.device).wait_stream(s)
 
 
+def join_all_streams():
+    """The current stream waits for the side stream and every further compute stream: used where gradients are consumed
+    (optimizer step, gradient all-reduce - also the one of the arena's tail that starts inside the backward pass, when
+    the heads' parameter gradients may still be in flight on the streams their branches ran on)."""
+    join_wgrad_stream()
+    for (dev, _index), s in _aux_streams.items():
+        torch.cuda.current_stream(dev).wait_stream(s)
+
+
 def join_wgrad_stream(device=None):
     """Make the current stream wait for every weight-gradient launch issued so far."""
     for dev, s in _side_streams.items():

@@ -91,9 +91,9 @@ class FlatSGD:
         exist; RCCL works on them over xGMI while the backbone backward (~40 % of the step) keeps the CUs busy."""
         if not self._distributed() or self._tail_from is not None:
             return
-        from ..layers.functional import join_wgrad_stream
+        from ..layers.functional import join_all_streams
 
-        join_wgrad_stream()  # the head weight gradients were launched on the side stream
+        join_all_streams()  # the heads' gradients were produced on the side stream and on their branches' streams
         self._tail_from = int(first_elem)
         self._launch_all_reduce(self._tail_from, self.total)
 
@@ -101,9 +101,9 @@ class FlatSGD:
         """Sum gradients over ranks in a few large buckets (mean is folded into the step's grad_scale)."""
         if not self._distributed():
             return 1.0
-        from ..layers.functional import join_wgrad_stream
+        from ..layers.functional import join_all_streams
 
-        join_wgrad_stream()
+        join_all_streams()
         self._launch_all_reduce(0, self.total if self._tail_from is None else self._tail_from)
         for h in self._pending:
             h.wait()
@@ -111,9 +111,9 @@ class FlatSGD:
         return 1.0 / dist.get_world_size()
 
     def step(self, grad_scale=1.0):
-        from ..layers.functional import join_wgrad_stream
+        from ..layers.functional import join_all_streams
 
-        join_wgrad_stream()
+        join_all_streams()
         _hip.call("u2_sgd_clip_step", self.flat_param, self.flat_grad, self.flat_mom, self.chunk_tensor, self.chunk_begin,
                   self.chunk_len, self.chunk_tensor.numel(), self.partial, self.first_chunk, self.wd, float(self.lr),
                   float(self.momentum), float(self.clip_value), float(grad_scale))
