@@ -279,6 +279,8 @@ int main(int argc, char** argv) {
       {2, 36, 32, 64, 256, 3, 3, 1, 1, 1, 0, 0, 0, 1, "tile 3x3 c64 n256 stats"},
       {2, 36, 32, 96, 320, 3, 3, 1, 1, 1, 1, 0, 1, 0, "tile 3x3 c96 n320 bias relu"},
       {1, 700, 3, 256, 512, 1, 1, 0, 1, 1, 0, 0, 0, 1, "tile 1x1 c256 n512 stats"},
+      {1, 700, 3, 256, 512, 1, 1, 0, 1, 1, 1, 1, 1, 0, "tile 1x1 c256 n512 accumulate bias relu"},
+      {2, 33, 21, 64, 264, 1, 1, 0, 1, 1, 1, 1, 0, 0, "tile 1x1 c64 n264 accumulate relu"},
       {2, 37, 41, 160, 128, 1, 1, 0, 2, 1, 0, 0, 0, 1, "tile 1x1 s2 c160 n128 stats"},
       {2, 18, 20, 128, 128, 3, 3, 1, 1, 2, 0, 0, 0, 0, "tile dgrad(3x3 s2) c128 n128"},
       {1, 45, 23, 64, 72, 3, 3, 1, 1, 1, 0, 0, 1, 1, "tile 3x3 c64 n72 bias stats"},

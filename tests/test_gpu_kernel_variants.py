@@ -279,3 +279,24 @@ def test_conv_fpn_output2_backward_full_shape(F):
             ref_w = torch.einsum("bhwn,bhwc->nc", gys, xs[:, kh : kh + h, kw : kw + w])
             got_w = wd.grad[ns][:, cs][:, :, kh, kw]
             assert float((got_w - ref_w).abs().max() / ref_w.abs().max()) < 1e-2, (kh, kw)
+
+
+@pytest.mark.parametrize("shape", [(4, 200, 169, 64, 256, 104), (2, 37, 41, 64, 256, None), (1, 90, 70, 512, 2048, 104),
+                                   (3, 20, 24, 256, 1024, 104)])
+def test_conv_accumulating_epilogue(F, shape):
+    """conv_tile_kernel<4, 1, 3, ACC>: out = relu(bf16(conv1x1(x) + bias) + out) in place - the residual tail of a bottleneck at
+    inference (backbone/resnet.py:204-210 with the fixed-statistics norm folded into the conv) - vs fp32, with partial tiles;
+    a map too small for the persistent kernel at K = 64 goes to conv_igemm_kernel's accumulate path (same rounding rule)."""
+    b, h, w, cin, cout, code = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    x = bf(torch.randn((b, cin, h, w), generator=g))
+    wt = torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    res = bf(torch.randn((b, cout, h, w), generator=g))
+    ref = TF.relu(bf(TF.conv2d(x, bf(wt), bias)) + res)
+    out = nhwc(res)
+    with torch.no_grad(), forced():
+        got = F.conv2d_add_(nhwc(x), wt.to(DEV), bias.to(DEV), out, 1, 0, relu=True)
+        assert code is None or last_kernel() == code, last_kernel()
+    assert got.data_ptr() == out.data_ptr()
+    assert rel_err(got.permute(0, 3, 1, 2)[:, :cout].float().cpu(), ref) < 1e-2

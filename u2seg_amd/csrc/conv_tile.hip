@@ -80,7 +80,8 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
   return *reinterpret_cast<const uint32_t*>(&r);
 }
 
-template <int WCH, int WPX, int RING>
+// ACC: out = act(bf16(conv + bias) + out) - the epilogue reads what it overwrites (a residual block's tail at inference)
+template <int WCH, int WPX, int RING, bool ACC = false>
 __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const ConvArgs a) {
   constexpr int NW = WCH * WPX, NT = NW * 64;
   constexpr int TN = WCH * 64, TM = WPX * 128;
@@ -275,8 +276,29 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     for (int e = 0; e < 16; ++e) { s[e] = 0.f; ss[e] = 0.f; }
     const bool nt_out = (size_t)a.M * a.out_ld * 2 > ((size_t)160 << 20);
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    u32x4_t olda[4], oldb[4];  // ACC: the values under rows j & 3 of the current batch of four rows
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+      if constexpr (ACC) {
+        if ((j & 3) == 0) {
+          // four rows' worth of loads, then ONE wait for everything in flight (a counted wait would have to know which of
+          // the masked loads / stores below were issued at all): two exposed round trips per tile instead of eight
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int mm = m0 + (j + jj) * 16 + fr;
+            olda[jj] = u32x4_t{0u, 0u, 0u, 0u};
+            oldb[jj] = u32x4_t{0u, 0u, 0u, 0u};
+            if (mm < a.M) {
+              const bf16_t* src = a.out + (size_t)mm * a.out_ld + nb;
+              if (okA) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(olda[jj]) : "v"(src) : "memory");
+              if (okB) asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=&v"(oldb[jj]) : "v"(src) : "memory");
+            }
+          }
+          asm volatile("s_waitcnt vmcnt(0)"
+                       : "+v"(olda[0]), "+v"(olda[1]), "+v"(olda[2]), "+v"(olda[3]), "+v"(oldb[0]), "+v"(oldb[1]), "+v"(oldb[2]),
+                         "+v"(oldb[3])::"memory");
+        }
+      }
       const int m = m0 + j * 16 + fr;
       if (m < a.M) {
         size_t orow = (size_t)m;
@@ -293,11 +315,21 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
           // block i holds channels e0 .. e0 + 3 of this lane's 16, e0 = (i >> 1) * 8 + (i & 1) * 4
           float v0 = acc[i][j][0] + bia[i][0], v1 = acc[i][j][1] + bia[i][1];
           float v2 = acc[i][j][2] + bia[i][2], v3 = acc[i][j][3] + bia[i][3];
+          if constexpr (ACC) {
+            // the conv result is rounded to bf16 first, then the stored value is added (conv_igemm_kernel's accumulate rule)
+            const uint32_t c01 = pack_bf16(v0, v1), c23 = pack_bf16(v2, v3);
+            const u32x4_t o = (i < 2) ? olda[j & 3] : oldb[j & 3];
+            const uint32_t o01 = o[(i & 1) * 2], o23 = o[(i & 1) * 2 + 1];
+            v0 = __uint_as_float(c01 << 16) + __uint_as_float(o01 << 16);
+            v1 = __uint_as_float(c01 & 0xffff0000u) + __uint_as_float(o01 & 0xffff0000u);
+            v2 = __uint_as_float(c23 << 16) + __uint_as_float(o23 << 16);
+            v3 = __uint_as_float(c23 & 0xffff0000u) + __uint_as_float(o23 & 0xffff0000u);
+          }
           if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
           pk[2 * i] = pack_bf16(v0, v1);
           pk[2 * i + 1] = pack_bf16(v2, v3);
         }
-        if (a.stats) {
+        if (!ACC && a.stats) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float lo = __uint_as_float(pk[e] << 16), hi = __uint_as_float(pk[e] & 0xffff0000u);
@@ -315,7 +347,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
         }
       }
     }
-    if (a.stats) {
+    if (!ACC && a.stats) {
       // after the transposing reduction lane (fg, fr) holds the tile's column sums of the channel below
       const int n_here = tile_n * TN + wr * 64 + fg * 8 + (fr >> 3) * 32 + (fr & 7);
       if (n_here != st_n) { stats_flush(); st_n = n_here; }
@@ -399,11 +431,11 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     }
     epilogue(first_tile + ti * stride);
   }
-  if (a.stats) stats_flush();
+  if (!ACC && a.stats) stats_flush();
 #undef U2_T_MFMA
 }
 
-template <int WCH, int WPX, int RING>
+template <int WCH, int WPX, int RING, bool ACC = false>
 int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s) {
   constexpr int TN = WCH * 64, TM = WPX * 128;
   constexpr int LDS = RING * (TM + TN) * 64;
@@ -416,10 +448,10 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s) {
   G = (G + 7) & ~7LL;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING>), dim3((unsigned)G), dim3(WCH * WPX * 64), LDS, s, a);
+  hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, ACC>), dim3((unsigned)G), dim3(WCH * WPX * 64), LDS, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return -1000 - (int)e;
   return 1;
@@ -438,7 +470,9 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   int sel = (variant >> 12) & 15;
   const int tiny = (variant >> 16) & 1;
   if (sel == 15) return 0;
-  if ((C & 31) || (N & 7) || (a.out_ld & 7) || a.ntaps < 1 || a.M >= (1 << 24) || a.M < 1 || a.accumulate) return 0;
+  if ((C & 31) || (N & 7) || (a.out_ld & 7) || a.ntaps < 1 || a.M >= (1 << 24) || a.M < 1) return 0;
+  // the accumulating epilogue exists for configuration 4 (256ch x 128px: the 1x1 conv3 of a residual block), no statistics
+  if (a.accumulate && (a.stats || a.remap_out || (sel != 0 && sel != 4) || N < 128)) return 0;
   // 32-bit byte offsets inside the kernel
   if ((unsigned long long)a.B * a.Hin * a.Win * a.in_ld * 2ull >= 0xffffffffull || (unsigned long long)N * a.wt_taps * C * 2ull >= 0xfffffff0ull) return 0;
   const int nkh = a.ntaps * (C >> 5);
@@ -447,8 +481,11 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
     // (profiles/r02_conv_variants.txt): tile shape by output width and by how many whole rounds of tiles the chip gets.
 
     const long long K = (long long)a.ntaps * C;
+    if (a.accumulate) sel = 4;
     const long long t256 = (long long)((a.M + 255) / 256) * ((N + 255) / 256);
-    if (N <= 128) {
+    if (sel == 4) {
+      // accumulate: fixed above
+    } else if (N <= 128) {
       // 128-wide tiles (two groups per CU); the deep 3x3 layers with 128 outputs stay on the 128 x 128 BK-64 kernel
       // (configuration 6, 64ch x 512px with one group per CU, measured slower on the 64-channel layers: 364 vs 451 TFLOP/s)
       if (a.M >= 100000 && !(a.ntaps > 1 && K >= 2048)) sel = 3;
@@ -483,7 +520,7 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
     case 1: return launch_cfg<4, 2, 4>(a, N, 1, tiny, s);
     case 2: return launch_cfg<4, 2, 5>(a, N, 1, tiny, s);
     case 3: return launch_cfg<2, 2, 3>(a, N, 2, tiny, s);
-    case 4: return launch_cfg<4, 1, 3>(a, N, 2, tiny, s);
+    case 4: return a.accumulate ? launch_cfg<4, 1, 3, true>(a, N, 2, tiny, s) : launch_cfg<4, 1, 3>(a, N, 2, tiny, s);
     case 5: return launch_cfg<2, 2, 4>(a, N, 1, tiny, s);
     case 6: return launch_cfg<1, 4, 4>(a, N, 1, tiny, s);
     default: return 0;

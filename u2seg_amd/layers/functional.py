@@ -337,6 +337,26 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, want_stats=False, 
     return (out, stats) if want_stats else out
 
 
+def conv2d_add_(x, weight, bias, out, stride=1, pad=0, relu=False, param=None):
+    """Inference only, in place: out = act(bf16(conv(x, weight) + bias) + out) - a residual block's tail (conv3 with its
+    fixed-statistics norm folded in, + shortcut, + ReLU: backbone/resnet.py:204-210) as ONE launch that reads the shortcut
+    where it writes the result.  `out` is overwritten: the caller must own it."""
+    assert not torch.is_grad_enabled()
+    _check_act(x)
+    _check_act(out)
+    n, cin, kh, kw = weight.shape
+    b, h, w_, cp = x.shape
+    ho = (h + 2 * pad - kh) // stride + 1
+    wo = (w_ + 2 * pad - kw) // stride + 1
+    npad = ceil32(n)
+    assert tuple(out.shape) == (b, ho, wo, npad) and npad == n, "the accumulating epilogue has no padded output channels"
+    wk = weight_fwd_layout(weight, cp, param)
+    bias_f = bias.detach().float().contiguous() if bias is not None else None
+    _hip.call("u2_conv_igemm", x, wk, out, bias_f, None, b, h, w_, cp, cp, ho, wo, n, npad, kh, kw, pad, pad, stride, 1, int(relu),
+              1, 0)
+    return out
+
+
 def linear(x2d, weight, bias=None, relu=False):
     """nn.Linear on a [R, K] bf16 matrix (K % 32 == 0); returns [R, ceil32(N)]."""
     r, k = x2d.shape

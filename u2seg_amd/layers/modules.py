@@ -6,6 +6,8 @@ Mirrors detectron2/layers/wrappers.py:87-139 (Conv2d = conv -> norm -> activatio
 """
 from collections import namedtuple
 
+import os
+
 import torch
 from torch import nn
 
@@ -135,8 +137,9 @@ class Conv2d(nn.Module):
         assert activation in (None, "relu"), "only ReLU is fused (the U2Seg graph uses nothing else)"
         self.activation = activation
 
-    def forward(self, x, residual=None, relu=None, twin=False, residual_up=None):
-        """residual_up: the coarser FPN level to add nearest-upsampled (fused into the BatchNorm apply in training)."""
+    def forward(self, x, residual=None, relu=None, twin=False, residual_up=None, residual_owned=False):
+        """residual_up: the coarser FPN level to add nearest-upsampled (fused into the BatchNorm apply in training).
+        residual_owned: at inference the caller gives `residual` up - the result is written over it (one launch)."""
         if residual_up is not None and not (isinstance(self.norm, BatchNorm2d) and self.training):
             assert residual is None
             return F.fpn_upsample_add(self.forward(x, None, relu, twin), residual_up)
@@ -166,6 +169,8 @@ class Conv2d(nn.Module):
                 # folded into the conv: weights scaled per output channel, shift as the bias, ReLU in the epilogue - no
                 # elementwise pass at all (the conv kernels add a bias and clamp before the one bf16 rounding)
                 return F.conv2d(x, folded[0], folded[1], self.stride, self.padding, relu=relu, param=folded[0])
+            if residual_owned and self.out_channels % 32 == 0 and os.environ.get("U2_EVAL_RESIDUAL_FUSE", "1") != "0":
+                return F.conv2d_add_(x, folded[0], folded[1], residual, self.stride, self.padding, relu=relu, param=folded[0])
             y = F.conv2d(x, self.weight, None, self.stride, self.padding, relu=False)
             return F.affine_act(y, folded[2], folded[3], residual, relu)
         y = F.conv2d(x, self.weight, None, self.stride, self.padding, relu=False)

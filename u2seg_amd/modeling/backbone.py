@@ -66,6 +66,7 @@ class BottleneckBlock(nn.Module):
         assert num_groups == 1 and dilation == 1, "grouped / dilated bottlenecks are not used by the U2Seg configs"
         self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
         self.third_handle = False  # set by ResNet on the last block of a stage that is also a backbone output
+        self.first_in_stage = True  # ResNet clears it on every block but the first of its stage
         if in_channels != out_channels:
             self.shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=stride, bias=False,
                                    norm=get_norm(norm, out_channels))
@@ -90,7 +91,10 @@ class BottleneckBlock(nn.Module):
         out = self.conv2(out)
         shortcut = self.shortcut(x_sc) if self.shortcut is not None else x_sc
         # out += shortcut; relu_.  The last block of a stage that is also a backbone output hands out a third handle
-        return self.conv3(out, residual=shortcut, relu=True, twin=3 if self.third_handle else True)
+        # at inference the shortcut buffer is given up: a projection shortcut is this block's own tensor, an identity shortcut
+        # is the previous block's output, which inside a stage has no reader but this block
+        owned = not torch.is_grad_enabled() and not self.training and (self.shortcut is not None or not self.first_in_stage)
+        return self.conv3(out, residual=shortcut, relu=True, twin=3 if self.third_handle else True, residual_owned=owned)
 
 
 class ResNet(Backbone):
@@ -112,6 +116,10 @@ class ResNet(Backbone):
             self._out_feature_channels[name] = blocks[-1].out_channels
         self.stage_names = tuple(self.stage_names)
         self._out_features = out_features if out_features is not None else [name]
+        for stage in self.stages:
+            for blk in list(stage)[1:]:
+                if hasattr(blk, "first_in_stage"):
+                    blk.first_in_stage = False
         for sname, stage in zip(self.stage_names[:-1], self.stages[:-1]):
             if sname in self._out_features and hasattr(stage[-1], "third_handle"):
                 stage[-1].third_handle = True
