@@ -25,6 +25,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_HBM_TBPS = 8.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 CONV_STACK_TRAIN_GFLOP_PER_IMAGE = 885.83  # BASELINE.md section 2 (ResNet-50 + FPN fwd + dgrad + wgrad)
 
@@ -229,6 +230,17 @@ def conv_roofline(timer, sampled, steps, imgs_per_s_per_gpu=None):
            "by_reduction_depth": {"K>256 (MFMA-bound)": {"tflops": tf(deep)[0], "ms_per_step": tf(deep)[1]},
                                   "K<=256 (HBM-bound 1x1 layers)": {"tflops": tf(shallow)[0], "ms_per_step": tf(shallow)[1],
                                                                    "algorithmic_TB_per_s": tbs(shallow)}}}
+    # Speed of light of THIS launch mix: every launch at max(flop / MFMA peak, algorithmic bytes / HBM peak).  A 1x1 conv moves
+    # 2 (K + N) bytes per pixel for 2 K N flop - 51 flop/B on the res2 layers, 205 on res4 - far left of the 312 flop/B ridge of
+    # 2.5 PFLOP/s over 8 TB/s, so a third of the launches is bandwidth-bound by construction and the mix cannot reach the MFMA peak.
+    recs = [r for r in timer.records if r[0] == name]
+    sol_s = sum(max(r[1] / (PEAK_BF16_TFLOPS * 1e12), r[5] / (PEAK_HBM_TBPS * 1e12)) for r in recs)
+    if sol_s > 0:
+        att = sum(r[1] for r in recs) / sol_s / 1e12
+        out["launch_mix_roofline"] = {"hbm_peak_TB_per_s": PEAK_HBM_TBPS, "attainable_tflops": att,
+                                      "frac_of_attainable": achieved / att,
+                                      "launches_hbm_bound": sum(1 for r in recs if r[5] / (PEAK_HBM_TBPS * 1e12) >
+                                                                r[1] / (PEAK_BF16_TFLOPS * 1e12)) / sampled}
     if timer.overlapped:
         ov = {}
         for rname, _fl, s_, e_, _i, _b in timer.overlapped:
