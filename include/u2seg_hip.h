@@ -83,8 +83,10 @@ int u2_gn_finalize_bwd(const float* sums, const float* gamma, const float* mean,
 int u2_bn_finalize_fwd(const float* sums, float count, const float* count_dev, const float* gamma, const float* beta, float* running_mean,
                        float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                        float* shift, int C, void* stream);
+/* relu_bits (optional, uint8 [slots * rows_per_slot][C / 8], needs ld == C and C / 8 dividing 256): bit e of byte c is
+ * out[row][8 c + e] > 0 - what the backward pass of a residual block's tail needs of the activation, in 1/16 of its bytes. */
 int u2_affine_act(const void* x, const float* scale, const float* shift, const void* resid, void* out, int slots,
-                  int rows_per_slot, int C, int ld, int relu, void* stream);
+                  int rows_per_slot, int C, int ld, int relu, void* relu_bits, void* stream);
 /* backbone/fpn.py:141-158 in one pass: out = bf16(x * scale + shift) + nearest_x2(top), top [B][H/2][W/2][C]: the lateral conv's
  * BatchNorm apply fused with the top-down upsample-add (bit-identical to u2_affine_act followed by u2_fpn_upsample_add_fwd). */
 int u2_affine_upadd(const void* x, const float* scale, const float* shift, const void* top, void* out, int B, int H, int W,
@@ -92,14 +94,14 @@ int u2_affine_upadd(const void* x, const float* scale, const float* shift, const
 int u2_norm_bwd_reduce(const void* dout, const void* mask, const void* x, const float* mean, const float* invstd,
                        float* out /*[slots][2][C]*/, int slots, int rows_per_slot, int C, int ld, int relu,
                        const float* mask_scale, const float* mask_shift, const void* dout2, void* dz_out, const void* dout3,
-                       void* stream);
+                       int mask_is_bits, void* stream);
 /* mask_scale/mask_shift [slots][C] (optional, both or neither): recompute the ReLU mask as x*scale+shift > 0 - the
  * expression u2_affine_act evaluated in the forward pass - instead of reading the activation `mask` (which may be NULL).
  * u2_norm_bwd_reduce only: dz_out (optional) receives the masked gradient dz = (dout [+ dout2]) * mask, so that
  * u2_norm_bwd_apply can run on (dz, x) with relu = 0 and dz doubles as the residual branch's gradient; dout2 (optional,
  * needs dz_out) is a second incoming gradient summed on the fly (resnet.py:204-210: the block output feeds the next
  * block's conv1 and its identity shortcut); dout3 (optional, needs dout2) a third one (the last block of a stage also feeds
- * the FPN lateral conv, backbone/fpn.py:141-146). */
+ * the FPN lateral conv, backbone/fpn.py:141-146); mask_is_bits: `mask` is the relu_bits array of u2_affine_act (needs dz_out). */
 int u2_bn_finalize_bwd(const float* sums, float count, const float* count_dev, const float* gamma, const float* mean, const float* invstd,
                        const float* local_sums, float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C,
                        int accumulate /* dgamma/dbeta += instead of = (parameter gradient arena) */, void* stream);

@@ -39,7 +39,8 @@ constexpr size_t NT_BYTES = 160u << 20;
 //         When msc/msh are given the ReLU mask is recomputed as (x*msc + msh > 0) - the very expression the forward
 //         affine_act evaluated (fp contraction is off, so it is bit-identical) - and the activation is not read at all.
 // ---------------------------------------------------------------------------------------------
-// MASK (MODE 1): 0 no ReLU, 1 read the activation, 2 recompute x*msc + msh > 0
+// MASK (MODE 1): 0 no ReLU, 1 read the activation, 2 recompute x*msc + msh > 0, 3 read one bit per element ([row][C/8] bytes
+//         written by the forward apply pass: a sixteenth of the activation's bytes)
 // DZ (MODE 1): the incoming gradient is dout (+ dout2 when given: the two consumers of a residual block's output, summed
 //         here instead of by a separate pass) and the masked gradient dz is also written out - it is the gradient of
 //         the residual input as it stands, and the apply pass then reads dz and x only.
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
             if (MODE == 1) {
               dq[u] = ld_stream(dout + off, nt);
               if (MASK == 1) mq[u] = ld_stream(mask + off, nt);
+              if (MASK == 3) mq[u].x = reinterpret_cast<const unsigned char*>(mask)[(row0 + r) * (size_t)cpr + cbase + chunk];
               if (DZ && dout2) eq[u] = ld_stream(dout2 + off, nt);
               if (DZ && dout3) fq[u] = ld_stream(dout3 + off, nt);
             }
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
                 if (DZ && dout2) dz = bf2f(f2bf(dz + bf2f(ev[e])));  // rounded like the bf16 sum autograd would form
                 if (DZ && dout3) dz = bf2f(f2bf(dz + bf2f(fv[e])));
                 if (MASK == 1 && !(bf2f(mv[e]) > 0.f)) dz = 0.f;
+                if (MASK == 3 && !((mq[u].x >> e) & 1u)) dz = 0.f;
                 if (MASK == 2 && !(xf * ms[e] + mh[e] > 0.f)) dz = 0.f;
                 if (DZ) zv[e] = f2bf(dz);
                 s0[e] += dz;
@@ -261,7 +264,8 @@ constexpr int EW_UNROLL = 2;
 template <bool RESID, bool RELU>
 __global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const bf16_t* __restrict__ resid,
-                                                              bf16_t* __restrict__ out, int rows_per_slot, int C, int ld) {
+                                                              bf16_t* __restrict__ out, int rows_per_slot, int C, int ld,
+                                                              unsigned char* __restrict__ relu_bits) {
   const int cpr = C >> 3;
   const int rows_par = 256 / cpr;
   const int cc = threadIdx.x % cpr, rl = threadIdx.x / cpr;
@@ -290,14 +294,17 @@ __global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __re
         const bf16_t* xv = reinterpret_cast<const bf16_t*>(&xq[u]);
         const bf16_t* rv = reinterpret_cast<const bf16_t*>(&rq[u]);
         bf16_t ov[8];
+        unsigned bits = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float f = bf2f(xv[e]) * sc[e] + sh[e];
           if (RESID) f += bf2f(rv[e]);
           if (RELU) f = fmaxf(f, 0.f);
           ov[e] = f2bf(f);
+          bits |= (bf2f(ov[e]) > 0.f ? 1u : 0u) << e;  // the test the backward pass would make on the stored activation
         }
         st_stream(out + (base + r) * ld + cc * 8, *reinterpret_cast<const uint4*>(ov), nt);
+        if (relu_bits) relu_bits[(base + r) * cpr + cc] = (unsigned char)bits;  // [row][C / 8]: 1/16 of the activation's bytes
       }
     }
   }
@@ -652,8 +659,9 @@ extern "C" int u2_colstats(const void* x, float* out, int slots, int rows_per_sl
 extern "C" int u2_norm_bwd_reduce(const void* dout, const void* mask, const void* x, const float* mean, const float* invstd,
                                   float* out, int slots, int rows_per_slot, int C, int ld, int relu,
                                   const float* mask_scale, const float* mask_shift, const void* dout2, void* dz_out,
-                                  const void* dout3, void* stream) {
+                                  const void* dout3, int mask_is_bits, void* stream) {
   if ((C & 7) || (ld & 7)) return -1;
+  if (mask_is_bits && (!mask || !relu || !dz_out || ld != C)) return -1;
   if ((dout2 && !dz_out) || (dout3 && !dout2)) return -1;
   if (slots <= 0 || rows_per_slot <= 0) return 0;
   int rpb = (rows_per_slot + 511) / 512;
@@ -664,7 +672,7 @@ extern "C" int u2_norm_bwd_reduce(const void* dout, const void* mask, const void
   hipLaunchKernelGGL((colreduce_kernel<1, MM_, DZ_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,      \
                      (const bf16_t*)dout, (const bf16_t*)mask, mean, invstd, out, rows_per_slot, C, ld, rpb, mask_scale, \
                      mask_shift, (const bf16_t*)dout2, (bf16_t*)dz_out, (const bf16_t*)dout3)
-  if (dz_out) { if (!relu) U2_REDUCE(0, true); else if (mask_scale) U2_REDUCE(2, true); else U2_REDUCE(1, true); }
+  if (dz_out) { if (!relu) U2_REDUCE(0, true); else if (mask_is_bits) U2_REDUCE(3, true); else if (mask_scale) U2_REDUCE(2, true); else U2_REDUCE(1, true); }
   else { if (!relu) U2_REDUCE(0, false); else if (mask_scale) U2_REDUCE(2, false); else U2_REDUCE(1, false); }
 #undef U2_REDUCE
   U2_CHECK_LAUNCH();
@@ -672,14 +680,16 @@ extern "C" int u2_norm_bwd_reduce(const void* dout, const void* mask, const void
 }
 
 extern "C" int u2_affine_act(const void* x, const float* scale, const float* shift, const void* resid, void* out,
-                             int slots, int rows_per_slot, int C, int ld, int relu, void* stream) {
+                             int slots, int rows_per_slot, int C, int ld, int relu, void* relu_bits, void* stream) {
   if ((C & 7) || (ld & 7)) return -1;
+  if (relu_bits && !(fast_ok(C) && ld == C)) return -1;
   const size_t M = (size_t)slots * rows_per_slot;
   if (M == 0) return 0;
   if (fast_ok(C)) {
 #define U2_AFFINE(RS_, RL_)                                                                                          \
   hipLaunchKernelGGL((affine_act_fast_kernel<RS_, RL_>), fast_grid(slots, rows_per_slot, C), dim3(256), 0, (hipStream_t)stream, \
-                     (const bf16_t*)x, scale, shift, (const bf16_t*)resid, (bf16_t*)out, rows_per_slot, C, ld)
+                     (const bf16_t*)x, scale, shift, (const bf16_t*)resid, (bf16_t*)out, rows_per_slot, C, ld,                 \
+                     (unsigned char*)relu_bits)
     if (resid) { if (relu) U2_AFFINE(true, true); else U2_AFFINE(true, false); }
     else { if (relu) U2_AFFINE(false, true); else U2_AFFINE(false, false); }
 #undef U2_AFFINE

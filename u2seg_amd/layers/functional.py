@@ -446,15 +446,23 @@ class _BatchNormActFn(Function):
         _hip.call("u2_bn_finalize_fwd", stats, count, count_dev, gamma, beta, running_mean, running_var, momentum, eps, mean,
                   invstd, scale, shift, c)
         out = torch.empty_like(y)
+        bits = None
         if res_up:
             # FPN top-down step (backbone/fpn.py:153-155): the residual is the coarser level, nearest-upsampled on the fly
             assert residual is not None and not relu and tuple(residual.shape) == (b, h // 2, w // 2, c)
             _hip.call("u2_affine_upadd", y, scale, shift, residual.contiguous(), out, b, h, w, c, 0)
         else:
-            _hip.call("u2_affine_act", y, scale, shift, residual, out, 1, m, c, c, int(relu))
+            # a residual block's tail: backward needs only the sign of the activation - kept as one bit per element, so that
+            # the reduce pass reads a sixteenth of the activation's bytes for it
+            cpr = c // 8
+            if relu and residual is not None and c % 8 == 0 and cpr <= 256 and 256 % cpr == 0:
+                bits = torch.empty((m, cpr), dtype=torch.uint8, device=y.device)
+            _hip.call("u2_affine_act", y, scale, shift, residual, out, 1, m, c, c, int(relu), bits)
         # ReLU mask in backward: without a residual it is recomputed from y (one activation read less per pass)
         remask = relu and residual is None
-        ctx.save_for_backward(y, out if (relu and not remask) else None, gamma, mean, invstd,
+        keep_out = relu and not remask
+        ctx.mask_bits = bool(keep_out and bits is not None)
+        ctx.save_for_backward(y, (bits if ctx.mask_bits else out) if keep_out else None, gamma, mean, invstd,
                               scale if remask else None, shift if remask else None)
         ctx.cfg = (relu, count, world, residual is not None)
         ctx.count_dev = count_dev
@@ -485,7 +493,8 @@ class _BatchNormActFn(Function):
         dout, dout2, dout3 = (arrived + [None, None])[:3]
         dz = torch.empty_like(y) if fuse else None
         sums = zeros_f32((2, c), y.device)
-        _hip.call("u2_norm_bwd_reduce", dout, out, y, mean, invstd, sums, 1, m, c, c, int(relu), msc, msh, dout2, dz, dout3)
+        _hip.call("u2_norm_bwd_reduce", dout, out, y, mean, invstd, sums, 1, m, c, c, int(relu), msc, msh, dout2, dz, dout3,
+                  int(bool(ctx.mask_bits and fuse)))
         local = sums
         if world > 1:
             local = sums.clone()
@@ -534,7 +543,7 @@ def affine_act(y, scale, shift, residual=None, relu=False):
     """Inference-mode normalisation: y*scale + shift (+res)(relu); no autograd."""
     b, h, w, c = y.shape
     out = torch.empty_like(y)
-    _hip.call("u2_affine_act", y, scale.contiguous(), shift.contiguous(), residual, out, 1, b * h * w, c, c, int(relu))
+    _hip.call("u2_affine_act", y, scale.contiguous(), shift.contiguous(), residual, out, 1, b * h * w, c, c, int(relu), None)
     return out
 
 
@@ -554,7 +563,7 @@ class _GroupNormActFn(Function):
         _hip.call("u2_gn_finalize_fwd", stats, gamma.detach(), beta.detach(), float(hw * cg), float(eps), b, c, groups, mean,
                   invstd, scale, shift)
         out = torch.empty_like(y)
-        _hip.call("u2_affine_act", y, scale, shift, None, out, b, hw, c, c, int(relu))
+        _hip.call("u2_affine_act", y, scale, shift, None, out, b, hw, c, c, int(relu), None)
         ctx.save_for_backward(y, gamma, mean, invstd, scale if relu else None, shift if relu else None)
         ctx.cfg = (groups, relu)
         return out
@@ -568,7 +577,7 @@ class _GroupNormActFn(Function):
         n = float(hw * cg)
         dout = dout.contiguous()
         sums = zeros_f32((b, 2, c), y.device)
-        _hip.call("u2_norm_bwd_reduce", dout, None, y, mean, invstd, sums, b, hw, c, c, int(relu), msc, msh, None, None, None)
+        _hip.call("u2_norm_bwd_reduce", dout, None, y, mean, invstd, sums, b, hw, c, c, int(relu), msc, msh, None, None, None, 0)
         coef = torch.empty((3, b, c), dtype=torch.float32, device=y.device)
         k1, k2, k3 = coef[0], coef[1], coef[2]
         dparam = torch.empty((2, c), dtype=torch.float32, device=y.device)
