@@ -341,6 +341,54 @@ __global__ __launch_bounds__(256) void affine_upadd_kernel(const bf16_t* __restr
   }
 }
 
+// The same pass in the form of the other streaming kernels (C / 8 divides 256): a thread keeps one 8-channel column chunk and
+// its scale / shift in registers and has four rows in flight; the generic form above measured 1.3 TB/s (one row per thread in
+// flight, per-element coefficient loads, 64-bit index arithmetic per chunk), a third of what the BN apply passes reach.
+__global__ __launch_bounds__(256) void affine_upadd_fast_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const bf16_t* __restrict__ top,
+                                                                bf16_t* __restrict__ out, int B, int H, int W, int C, int relu) {
+  constexpr int U = 4;
+  const int cpr = C >> 3;
+  const int rows_par = 256 / cpr;
+  const int cc = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  const int Wt = W >> 1, Ht = H >> 1;
+  const int rows = B * H * W;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = scale[cc * 8 + e]; sh[e] = shift[cc * 8 + e]; }
+  const int stride = gridDim.x * rows_par;
+  const bool nt = (size_t)rows * C * 2 > NT_BYTES;
+  for (int r0 = blockIdx.x * rows_par + rl; r0 < rows; r0 += U * stride) {
+    uint4 xq[U], tq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + u * stride;
+      if (r < rows) {
+        const int xw = r % W, t = r / W;
+        const int y = t % H, b = t / H;
+        xq[u] = ld_stream(x + (size_t)r * C + cc * 8, nt);
+        tq[u] = *reinterpret_cast<const uint4*>(top + (((size_t)b * Ht + (y >> 1)) * Wt + (xw >> 1)) * C + cc * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + u * stride;
+      if (r < rows) {
+        const bf16_t* xv = reinterpret_cast<const bf16_t*>(&xq[u]);
+        const bf16_t* tv = reinterpret_cast<const bf16_t*>(&tq[u]);
+        bf16_t ov[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = bf2f(f2bf(bf2f(xv[e]) * sc[e] + sh[e])) + bf2f(tv[e]);
+          if (relu) f = fmaxf(f, 0.f);
+          ov[e] = f2bf(f);
+        }
+        st_stream(out + (size_t)r * C + cc * 8, *reinterpret_cast<const uint4*>(ov), nt);
+      }
+    }
+  }
+}
+
 // MASK: 0 no ReLU, 1 read the activation, 2 recompute x*ms + mh > 0
 template <int MASK, bool DRES>
 __global__ __launch_bounds__(256) void norm_bwd_apply_fast_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ mask,
@@ -707,6 +755,15 @@ extern "C" int u2_affine_upadd(const void* x, const float* scale, const float* s
   if ((C & 7) || (H & 1) || (W & 1)) return -1;
   const size_t total = (size_t)B * H * W * (C >> 3);
   if (total == 0) return 0;
+  if (fast_ok(C) && (long long)B * H * W < (1LL << 31)) {
+    const int rows_par = 256 / (C >> 3);
+    long long gx = ((long long)B * H * W + rows_par * 4 - 1) / (rows_par * 4);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(affine_upadd_fast_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, scale,
+                       shift, (const bf16_t*)top, (bf16_t*)out, B, H, W, C, relu);
+    U2_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(affine_upadd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, scale, shift,
                      (const bf16_t*)top, (bf16_t*)out, B, H, W, C, relu);
   U2_CHECK_LAUNCH();
