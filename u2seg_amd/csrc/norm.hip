@@ -611,6 +611,7 @@ __global__ __launch_bounds__(256) void weight_layout_kernel(const float* __restr
 // One launch for every cached layout of every parameter, as LDS-tiled transposes (both sides move whole 128-byte
 // segments).  Entries own the block range [block_begin, next entry's block_begin):
 //   mode 0:    N * ceil(Cp / 64) blocks - block (n, 64 input channels): reads 64*T contiguous floats, writes T rows of 64 c
+//              (T == 1 and Cp == Cin: ceil(N * Cp / 4096) blocks of a plain conversion)
 //   mode 1, 2: ceil(Npad / 64) * ceil(Cin*T / 64) blocks - block (64 n, 64 contiguous (c,t) columns): reads 64 rows of
 //              256 B, writes 64 output rows of 64 n (requires Cp == Cin: no all-zero output rows)
 __global__ __launch_bounds__(256) void weight_layout_batched_kernel(const float* __restrict__ base,
@@ -628,7 +629,23 @@ __global__ __launch_bounds__(256) void weight_layout_batched_kernel(const float*
   const int N = d.N, Cin = d.Cin, T = d.T, Cp = d.Cp, Npad = d.Npad, mode = d.mode;
   const int lb = b - d.block_begin;
   const int tid = threadIdx.x;
-  if (mode == 0) {
+  if (mode == 0 && T == 1 && Cp == Cin) {
+    // 1x1 filters / linear layers without channel padding: the layout IS the source order - a plain conversion in blocks of
+    // 4096 elements (the tiled path below would give every block 64 floats; these entries were most of the kernel's time)
+    const size_t total = (size_t)N * Cp, i0 = (size_t)lb * 4096;
+    for (int i = tid * 4; i < 4096; i += 1024) {
+      const size_t idx = i0 + i;
+      if (idx + 3 < total) {
+        const float4 v = *reinterpret_cast<const float4*>(w + idx);
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+        pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+        *reinterpret_cast<uint2*>(out + idx) = pk;
+      } else {
+        for (size_t k = idx; k < total && k < idx + 4; ++k) out[k] = f2bf(w[k]);
+      }
+    }
+  } else if (mode == 0) {
     const int cchunks = (Cp + 63) >> 6;
     const int n = lb / cchunks, c0 = (lb - n * cchunks) * 64;
     const int cn = min(64, Cin - c0);  // valid input channels of this chunk (<= 0: pure padding)

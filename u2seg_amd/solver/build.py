@@ -142,7 +142,12 @@ class FlatSGD:
                 assert 0 <= off < self.total * 4 and off % 4 == 0
                 desc[i] = (off // 4, ent[0].data_ptr()) + tuple(key) + (blocks, 0)
                 n_, cin_, t_, cp_, npad_, mode_ = key
-                blocks += n_ * ((cp_ + 63) // 64) if mode_ == 0 else ((npad_ + 63) // 64) * ((cin_ * t_ + 63) // 64)
+                if mode_ == 0 and t_ == 1 and cp_ == cin_:
+                    blocks += (n_ * cp_ + 4095) // 4096  # plain conversion (u2_weight_layout_batched: the same rule)
+                elif mode_ == 0:
+                    blocks += n_ * ((cp_ + 63) // 64)
+                else:
+                    blocks += ((npad_ + 63) // 64) * ((cin_ * t_ + 63) // 64)
             self._layout_table = torch.from_numpy(desc.view(np.uint8).copy()).to(self.flat_param.device)
             self._layout_table_len = len(ents)
             self._layout_blocks = blocks
