@@ -232,6 +232,58 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const bf16_t* __restric
                                                          bf16_t* __restrict__ dlogits, float* __restrict__ loss_sum, int R,
                                                          int NC, int LP, float gscale) {
   const int lane = threadIdx.x & 63;
+  if (LP <= 1024 && (LP & 7) == 0) {
+    // a wave walks rows with the grid's stride and sends ONE atomic at the end: 8192 same-address atomics (one per row) were
+    // the whole 0.11 ms of this kernel
+    float loss_acc = 0.f;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < R; row += gridDim.x * 4) {
+    const bf16_t* zr = logits + (size_t)row * LP;
+    // the whole row in registers (<= 2 x 16 bytes per lane): one read of the logits instead of three passes of 2-byte loads
+    const int chunks = LP >> 3;
+    float v[2][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int ch = it * 64 + lane;
+      bf16_t raw[8];
+      if (ch < chunks) *reinterpret_cast<uint4*>(raw) = *reinterpret_cast<const uint4*>(zr + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[it][e] = (ch < chunks && ch * 8 + e < NC) ? bf2f(raw[e]) : -INFINITY;
+        mx = fmaxf(mx, v[it][e]);
+      }
+    }
+    mx = wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[it][e] = __expf(v[it][e] - mx);  // exp(-inf) = 0 for the pad columns
+        se += v[it][e];
+      }
+    se = wave_sum(se);
+    const int t = (int)labels[row];
+    const float inv = 1.f / se;
+    bf16_t* dr = dlogits + (size_t)row * LP;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int ch = it * 64 + lane;
+      if (ch < chunks) {
+        bf16_t ov[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = ch * 8 + e;
+          ov[e] = f2bf(c < NC ? (v[it][e] * inv - (c == t ? 1.f : 0.f)) * gscale : 0.f);
+        }
+        *reinterpret_cast<uint4*>(dr + ch * 8) = *reinterpret_cast<const uint4*>(ov);
+      }
+    }
+    loss_acc += mx + __logf(se) - bf2f(zr[t]);
+    }
+    if (lane == 0 && loss_acc != 0.f) atomicAdd(loss_sum, loss_acc);
+    return;
+  }
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
   const bf16_t* zr = logits + (size_t)row * LP;
@@ -435,7 +487,9 @@ extern "C" int u2_scale_to_bf16(const float* acc, const float* num, const float*
 extern "C" int u2_softmax_ce(const void* logits, const void* labels, void* dlogits, float* loss_sum, int R, int NC,
                              int LP, float gscale, void* stream) {
   if (R <= 0) return 0;
-  hipLaunchKernelGGL(softmax_ce_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits,
+  int grid = (R + 3) / 4;
+  if (LP <= 1024 && (LP & 7) == 0 && grid > 512) grid = 512;  // the register-resident form loops over rows
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits,
                      (const long long*)labels, (bf16_t*)dlogits, loss_sum, R, NC, LP, gscale);
   U2_CHECK_LAUNCH();
   return 0;
