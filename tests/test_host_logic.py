@@ -359,3 +359,74 @@ def test_lr_schedule_resume_matches_uninterrupted_run():
         s2.load_state_dict({"last_iter": k})
         assert o2.lr == lrs[k]
     assert lrs[0] == pytest.approx(1e-5) and lrs[20] == 0.01 and lrs[30] == pytest.approx(2e-4) and lrs[50] == pytest.approx(4e-6)
+
+
+def test_fan_out_handles_sum_gradients_on_cpu():
+    """functional.fan_out / PanopticFPN._fan_out_features: k autograd handles on one tensor, one handle per reader of a map that
+    several consumers share, the tensor itself for a single reader; the gradients of all handles add up (CPU: torch adds)."""
+    import torch
+
+    from u2seg_amd.layers import functional as F
+    from u2seg_amd.modeling.panoptic_fpn import GeneralizedRCNN
+
+    x = torch.randn(3, 4, requires_grad=True)
+    a, b, c = F.fan_out(x, 3)
+    assert a.data_ptr() == x.data_ptr() and b.data_ptr() == x.data_ptr()
+    (a * 1.0 + b * 2.0 + c * 3.0).sum().backward()
+    assert torch.allclose(x.grad, torch.full_like(x, 6.0))
+    with torch.no_grad():
+        assert all(h is x for h in F.fan_out(x, 3))  # no autograd: the tensor itself
+    feats = {"p2": torch.randn(2, 2, requires_grad=True), "p3": torch.randn(2, 2, requires_grad=True),
+             "p6": torch.randn(2, 2, requires_grad=True)}
+    sem, rpn, roi = GeneralizedRCNN._fan_out_features(feats, [["p2", "p3"], ["p2", "p3", "p6"], ["p2"]])
+    assert rpn["p6"] is feats["p6"] and sem["p6"] is feats["p6"]          # one reader: untouched
+    assert sem["p2"] is not feats["p2"] and rpn["p2"] is not sem["p2"]    # three readers: three handles
+    (sem["p2"].sum() + 2 * rpn["p2"].sum() + 4 * roi["p2"].sum() + sem["p3"].sum() + rpn["p3"].sum()).backward()
+    assert torch.allclose(feats["p2"].grad, torch.full((2, 2), 7.0)) and torch.allclose(feats["p3"].grad, torch.full((2, 2), 2.0))
+
+
+def test_topk_segment_chooser():
+    """layers/functional.py:_topk_segments - long rows are cut into equal segments only when they tile the row exactly, stay
+    several times longer than k and do not exceed the chip's work-group slots."""
+    from u2seg_amd.layers.functional import _topk_segments
+
+    assert _topk_segments(16, 1000, 1, 1, 1000, 100) == 1                         # short rows: one pass
+    s = _topk_segments(16, 201600, 3, 32, 67200 * 32, 2000)                       # stride-4 anchors through the (3, 32) view
+    assert s > 1 and 67200 % s == 0 and 16 * s <= 256 and 201600 // s >= 4096
+    s = _topk_segments(16, 268569, 1, 1, 268569, 256)                             # all anchors: 268 569 = 3^3 * 7^3 * 29
+    assert s in (3, 7, 9) and 268569 % s == 0
+    assert _topk_segments(16, 65537, 1, 1, 65537, 100) == 1                       # a prime length cannot be tiled
+    assert _topk_segments(200, 201600, 3, 32, 67200 * 32, 2000) == 1              # many rows already fill the chip
+    assert _topk_segments(16, 201600, 3, 32, 67200 * 32 + 8, 2000) == 1           # rows with a gap behind them: not a plain view
+
+
+def test_eval_fold_cache_and_block_flags():
+    """Conv2d._folded_eval (inference: fixed-statistics norm folded into the conv) is cached until one of its tensors changes
+    through torch; ResNet marks the first block of every stage (its shortcut buffer is not given up at inference) and the last
+    block of a stage that is also a backbone output (third gradient handle)."""
+    import torch
+
+    from u2seg_amd.config import get_cfg
+    from u2seg_amd.layers.modules import Conv2d, get_norm
+    from u2seg_amd.modeling import build_model
+
+    conv = Conv2d(8, 4, 1, bias=False, norm=get_norm("BN", 4)).eval()
+    with torch.no_grad():
+        conv.norm.running_var.fill_(3.0)
+        conv.norm.running_mean.fill_(0.5)
+        w1, b1, sc1, sh1 = conv._folded_eval()
+        assert conv._folded_eval()[0] is w1                                        # cached
+        scale = conv.norm.weight / torch.sqrt(conv.norm.running_var + conv.norm.eps)
+        assert torch.allclose(w1, conv.weight * scale.view(-1, 1, 1, 1)) and torch.allclose(b1, conv.norm.bias - 0.5 * scale)
+        conv.norm.running_mean.add_(1.0)                                           # in-place change: version counter moves
+        w2, b2, _, _ = conv._folded_eval()
+        assert w2 is not w1 and torch.allclose(b2, conv.norm.bias - 1.5 * scale)
+    cfg = get_cfg()
+    cfg.merge_from_file("configs/COCO-PanopticSegmentation/u2seg_R50_800.yaml")
+    cfg.MODEL.DEVICE = "cpu"
+    bottom_up = build_model(cfg).backbone.bottom_up
+    for name, stage in zip(bottom_up.stage_names, bottom_up.stages):
+        blocks = list(stage)
+        assert blocks[0].first_in_stage and not any(b.first_in_stage for b in blocks[1:])
+        assert not any(b.third_handle for b in blocks[:-1])
+        assert blocks[-1].third_handle == (name != bottom_up.stage_names[-1])      # res2-res4 feed the next stage AND the FPN
