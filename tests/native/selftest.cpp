@@ -288,8 +288,9 @@ int main(int argc, char** argv) {
   };
   if (argc > 2 && !strcmp(argv[1], "tile")) {  // one persistent-tile configuration only
     const int cfg = atoi(argv[2]);
+    const int extra = argc > 3 ? (int)strtol(argv[3], nullptr, 0) : 0;  // further variant bits (bit 17: slab-major order)
     for (int tiny = 0; tiny < 2; ++tiny)
-      for (const auto& c : tconvs) fails += test_conv(c, (cfg << 12) | (tiny << 16));
+      for (const auto& c : tconvs) fails += test_conv(c, (cfg << 12) | (tiny << 16) | extra);
     printf("SELFTEST tile %d %s (%d failures)\n", cfg, fails ? "FAILED" : "OK", fails);
     return fails ? 1 : 0;
   }

@@ -81,7 +81,11 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 }
 
 // ACC: out = act(bf16(conv + bias) + out) - the epilogue reads what it overwrites (a residual block's tail at inference)
-template <int WCH, int WPX, int RING, bool ACC = false>
+// SLAB: multi-tap filters walk the reduction slab-major - all taps of one 32-channel slab, then the next slab - instead of
+// tap-major.  The nine shifted reads of a slab then touch the same 64-byte pieces within nine half tiles (an XCD's 32
+// work-groups re-read ~0.6 MB in between) instead of every tap re-reading the tile's whole 131 KB input window eight half
+// tiles later (32 x 131 KB + the weights: beyond the 4 MB L2).  The per-tap bounds tests move to once per tile (a bit per tap).
+template <int WCH, int WPX, int RING, bool ACC = false, bool SLAB = false>
 __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const ConvArgs a) {
   constexpr int NW = WCH * WPX, NT = NW * 64;
   constexpr int TN = WCH * 64, TM = WPX * 128;
@@ -125,7 +129,9 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   int p_yx[LP];
   const bf16_t* p_src[LP];
   unsigned p_okmask = 0;  // bit i: row i of this thread reads real data in the current tap (advance by 32 channels)
+  unsigned p_okbits[LP];  // SLAB: bit t = tap t of row i reads real data
   int pt = -1, p_tap = a.ntaps, p_kc = 0, p_kh = 0, p_kw = 0;
+  int p_slab = kh_per_tap - 1;
   auto setup_pixels = [&](int tile) {
     const int m0 = (tile / a.tiles_n) * TM;
 #pragma unroll
@@ -148,8 +154,45 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
         p_yx[i] = 0x8000;  // y = -32768: every tap is out of range
       }
     }
+    if constexpr (SLAB) {
+#pragma unroll
+      for (int i = 0; i < LP; ++i) p_okbits[i] = 0;
+      int kh = 0, kw = 0;
+      for (int t = 0; t < a.ntaps; ++t) {
+        const int dy = kh - a.pad_h, dx = kw - a.pad_w;
+        if (++kw == a.KW) { kw = 0; ++kh; }
+#pragma unroll
+        for (int i = 0; i < LP; ++i) {
+          const int sy = (int)(short)(p_yx[i] & 0xffff) + dy, sx = (p_yx[i] >> 16) + dx;
+          const bool ok = (unsigned)sy < (unsigned)a.Hin && (unsigned)sx < (unsigned)a.Win;
+          p_okbits[i] |= ok ? (1u << t) : 0u;
+        }
+      }
+    }
   };
   auto stage_pixels = [&](int buf) {
+    if constexpr (SLAB) {
+      if (p_tap == a.ntaps) {  // next slab, or the first slab of the next tile
+        p_tap = 0; p_kh = 0; p_kw = 0;
+        if (++p_slab == kh_per_tap) {
+          p_slab = 0;
+          ++pt;
+          setup_pixels(first_tile + pt * stride);
+        }
+      }
+      const int dy = p_kh - a.pad_h, dx = p_kw - a.pad_w;
+      if (++p_kw == a.KW) { p_kw = 0; ++p_kh; }
+      const unsigned char* sbase = reinterpret_cast<const unsigned char*>(a.in) + ((long long)dy * a.Win + dx) * a.in_ld * 2 +
+                                   (long long)p_slab * 64;
+      unsigned char* base = smem + buf * BUF;
+#pragma unroll
+      for (int i = 0; i < LP; ++i) {
+        const bool ok = (p_okbits[i] >> p_tap) & 1u;
+        glds16(ok ? reinterpret_cast<const bf16_t*>(sbase + p_center[i]) : a.zero, base + (i * NW + w) * 1024);
+      }
+      ++p_tap;
+      return;
+    }
     if (p_kc == 0) {
       if (p_tap == a.ntaps) {
         p_tap = 0; p_kh = 0; p_kw = 0;
@@ -191,7 +234,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   // 32 + fg*8 .. 32 + fg*8+7 of the slice: two 16-byte runs per pixel.
   unsigned w_base[LW];  // byte offset of the row's first chunk from a.wt; 0xffffffff = row beyond N (reads the zero page)
   const bf16_t* w_src[LW];
-  int wt_i = -1, w_tap = a.ntaps, w_kc = 0;
+  int wt_i = -1, w_tap = a.ntaps, w_kc = 0, w_slab = kh_per_tap - 1;
   auto setup_weights = [&](int tile) {
     const int n0 = (tile % a.tiles_n) * TN;
 #pragma unroll
@@ -203,6 +246,23 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     }
   };
   auto stage_weights = [&](int buf) {
+    if constexpr (SLAB) {
+      if (w_tap == a.ntaps) {
+        w_tap = 0;
+        if (++w_slab == kh_per_tap) {
+          w_slab = 0;
+          ++wt_i;
+          setup_weights(first_tile + wt_i * stride);
+        }
+      }
+      const unsigned char* tb = reinterpret_cast<const unsigned char*>(a.wt) + ((size_t)w_tap * a.C + (size_t)w_slab * 32) * 2;
+      unsigned char* base = smem + buf * BUF + PBYTES;
+#pragma unroll
+      for (int i = 0; i < LW; ++i)
+        glds16(w_base[i] != 0xffffffffu ? reinterpret_cast<const bf16_t*>(tb + w_base[i]) : a.zero, base + (i * NW + w) * 1024);
+      ++w_tap;
+      return;
+    }
     if (w_kc == 0) {
       if (w_tap == a.ntaps) {
         w_tap = 0;
@@ -258,6 +318,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   // into a synchronous load.  Stores carry their own `s_nop 1` (the data registers may be reused right after the
   // statement), the bias loads wait inside their statement.
   auto epilogue = [&](int tile) {
+    if (a.abl & 4) return;
     const int tile_m = tile / a.tiles_n, tile_n = tile - tile_m * a.tiles_n;
     const int m0 = tile_m * TM + wc * 128;
     const int nb = tile_n * TN + wr * 64 + fg * 8;
@@ -329,7 +390,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
           pk[2 * i] = pack_bf16(v0, v1);
           pk[2 * i + 1] = pack_bf16(v2, v3);
         }
-        if (!ACC && a.stats) {
+        if (!ACC && a.stats && !(a.abl & 2)) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float lo = __uint_as_float(pk[e] << 16), hi = __uint_as_float(pk[e] & 0xffff0000u);
@@ -338,7 +399,8 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
           }
         }
         const u32x4_t va = {pk[0], pk[1], pk[2], pk[3]}, vb = {pk[4], pk[5], pk[6], pk[7]};
-        if (nt_out) {  // outputs far beyond the MALL size: do not let them evict what the next layer can still reuse
+        if (a.abl & 1) {
+        } else if (nt_out) {  // outputs far beyond the MALL size: do not let them evict what the next layer can still reuse
           if (okA) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(va) : "memory");
           if (okB) asm volatile("global_store_dwordx4 %0, %1, off offset:64 nt\n\ts_nop 1" ::"v"(dst), "v"(vb) : "memory");
         } else {
@@ -347,7 +409,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
         }
       }
     }
-    if (!ACC && a.stats) {
+    if (!ACC && a.stats && !(a.abl & 2)) {
       // after the transposing reduction lane (fg, fr) holds the tile's column sums of the channel below
       const int n_here = tile_n * TN + wr * 64 + fg * 8 + (fr >> 3) * 32 + (fr & 7);
       if (n_here != st_n) { stats_flush(); st_n = n_here; }
@@ -435,7 +497,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #undef U2_T_MFMA
 }
 
-template <int WCH, int WPX, int RING, bool ACC = false>
+template <int WCH, int WPX, int RING, bool ACC = false, bool SLAB = false>
 int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s) {
   constexpr int TN = WCH * 64, TM = WPX * 128;
   constexpr int LDS = RING * (TM + TN) * 64;
@@ -448,10 +510,10 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s) {
   G = (G + 7) & ~7LL;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, ACC, SLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, ACC>), dim3((unsigned)G), dim3(WCH * WPX * 64), LDS, s, a);
+  hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, ACC, SLAB>), dim3((unsigned)G), dim3(WCH * WPX * 64), LDS, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return -1000 - (int)e;
   return 1;
@@ -515,7 +577,20 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
     const long long min_tiles = (T >> 3) / 64;  // 512 work-groups: 64 per XCD
     if (nkh * min_tiles < ring) return 0;
   }
-  g_last_conv_kernel = 100 + sel;
+  a.abl = (variant >> 18) & 7;
+  // bit 17: slab-major reduction order for the multi-tap filters (not the parity-class launches of a strided data gradient)
+  const bool slab = ((variant >> 17) & 1) && !a.remap_out && a.ntaps > 1 && a.ntaps <= 32 && !a.accumulate;
+  g_last_conv_kernel = 100 + sel + (slab ? 50 : 0);
+  if (slab) {
+    switch (sel) {
+      case 1: return launch_cfg<4, 2, 4, false, true>(a, N, 1, tiny, s);
+      case 2: return launch_cfg<4, 2, 5, false, true>(a, N, 1, tiny, s);
+      case 3: return launch_cfg<2, 2, 3, false, true>(a, N, 2, tiny, s);
+      case 4: return launch_cfg<4, 1, 3, false, true>(a, N, 2, tiny, s);
+      default: break;
+    }
+    g_last_conv_kernel = 100 + sel;
+  }
   switch (sel) {
     case 1: return launch_cfg<4, 2, 4>(a, N, 1, tiny, s);
     case 2: return launch_cfg<4, 2, 5>(a, N, 1, tiny, s);
