@@ -273,6 +273,14 @@ def per_layer_report(timer, sampled):
                                                                      d[2] / (d[1] * 1e-3) / 1e12), file=sys.stderr)
 
 
+def cpu_baselines_parallel(workloads):
+    """The oracle samples of several workloads at once, one child process each (32 threads each, GPUs hidden)."""
+    import concurrent.futures as cf
+
+    with cf.ThreadPoolExecutor(max_workers=len(workloads)) as ex:
+        return dict(zip(workloads, ex.map(cpu_baseline, workloads)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,7 +291,12 @@ def main():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--kmeans-n", type=int, default=1000000, help="points in total (sharded over the GPUs)")
+    ap.add_argument("--kmeans-data", choices=["randn", "mixture"], default="mixture",
+                    help="SURVEY 8(d) config 4: x = randn(N, 768) (base case) or the mixture of 300 Gaussians, sigma 0.5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="train workload only: do not append the k-means (config 4) and inference (config 5) measurements as "
+                         "`extra_workloads` (they run after the timed training region, N = 1 only)")
     ap.add_argument("--serial", action="store_true",
                     help="every step in one stream (no side / second stream): the mode the roofline sample steps run in; used "
                          "for the rocprofv3 summary that the per-kernel durations of the roofline object are checked against")
@@ -314,28 +327,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(step_fn):
+    def timed(step_fn, steps, warmup):
         """W untimed steps, then exactly K timed ones between barriers; MAX over ranks.  Only the last step(s) carry the
         per-launch HIP events (they cost host time): the roofline numbers are a sample of the timed region."""
         from u2seg_amd.layers import functional as Fn
 
+        timer.records, timer.overlapped = [], []
         Fn.set_stream_overlap(not args.serial)
-        for i in range(args.warmup):
+        for i in range(warmup):
             step_fn(i)
         barrier()
-        sampled = max(1, args.steps // 8)
+        sampled = max(1, steps // 8)
 
         t0 = time.time()
-        for i in range(args.steps):
+        for i in range(steps):
             # The last `sampled` steps carry the per-launch HIP events of the roofline object and run all their kernels in ONE
             # stream: in the normal step the semantic head and the weight gradients run on further streams, and a kernel that
             # shares the CUs with another one is timed into it (the conv family measures 25-35 % longer per launch while the
             # step gets 5 % shorter).  The `sampled` steps before them are timed the same way WITH the overlap, for the record.
-            serial = i >= args.steps - sampled
-            timer.enabled = i >= args.steps - 2 * sampled
+            serial = i >= steps - sampled
+            timer.enabled = i >= steps - 2 * sampled
             timer.tag = "serial" if serial else "overlapped"
             Fn.set_stream_overlap(not serial and not args.serial)
-            step_fn(args.warmup + i)
+            step_fn(warmup + i)
         barrier()
         dt = time.time() - t0
         timer.enabled = False
@@ -346,14 +360,14 @@ def main():
             dt = float(t[0])
         return dt, sampled
 
-    out = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "vs_baseline": None, "data": "synthetic"}
-    if args.workload == "train":
+    def run_train(steps, warmup):
         from u2seg_amd.config import get_cfg
         from u2seg_amd.data import make_synthetic_batch
         from u2seg_amd.engine import SimpleTrainer
         from u2seg_amd.modeling import build_model
         from u2seg_amd.solver import build_lr_scheduler, build_optimizer
 
+        out = {}
         batch = args.batch or 16
         torch.manual_seed(1234)  # identical initial weights on every rank
         cfg = get_cfg()
@@ -368,22 +382,27 @@ def main():
         batches = [make_synthetic_batch(batch, start_index=(rank * nb + i) * batch, height=args.height, width=args.width,
                                         device=dev) for i in range(nb)]
         torch.manual_seed(1000 + rank)  # per-rank sampling randomness
-        dt, sampled = timed(lambda i: trainer.run_step(batches[i % nb]))
+        dt, sampled = timed(lambda i: trainer.run_step(batches[i % nb]), steps, warmup)
         total = trainer.check_finite()
-        imgs_per_s = batch * world * args.steps / dt
+        imgs_per_s = batch * world * steps / dt
         out.update({"metric": "training images/sec (whole node) u2seg_R50_800 @ 800x1333", "value": imgs_per_s, "unit": "img/s",
-                    "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "dtype": "bf16",
+                    "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "dtype": "bf16",
                     "config": {"workload": "u2seg_R50_800.yaml bf16, batch %d per GPU, %dx%d synthetic COCO-panoptic batches, "
                                            "random init, SGD+per-param clip" % (batch, args.height, args.width),
                                "global_batch": batch * world, "parallelism": "dp%d" % world},
                     "final_total_loss": total})
         if rank == 0:
-            out["roofline"] = conv_roofline(timer, sampled, args.steps, imgs_per_s / world)
-    elif args.workload == "infer":
+            out["roofline"] = conv_roofline(timer, sampled, steps, imgs_per_s / world)
+            if args.per_layer:
+                per_layer_report(timer, sampled)
+        return out
+
+    def run_infer(steps, warmup):
         from u2seg_amd.config import get_cfg
         from u2seg_amd.data import make_synthetic_batch
         from u2seg_amd.modeling import build_model
 
+        out = {}
         batch = args.batch or 32
         torch.manual_seed(1234)
         cfg = get_cfg()
@@ -399,64 +418,117 @@ def main():
             with torch.no_grad():
                 res["out"] = model(data)
 
-        dt, sampled = timed(step)
-        imgs_per_s = batch * world * args.steps / dt
+        dt, sampled = timed(step, steps, warmup)
+        imgs_per_s = batch * world * steps / dt
         out.update({"metric": "panoptic inference images/sec (whole node) u2seg_eval_800 @ 800x1333", "value": imgs_per_s,
-                    "unit": "img/s", "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                    "dtype": "bf16",
+                    "unit": "img/s", "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                    "dtype": "bf16", "steps": steps, "warmup": warmup,
                     "config": {"workload": "u2seg_eval_800.yaml bf16, batch %d per GPU, %dx%d synthetic images, random init, full "
                                            "post-processing (box NMS, pasted masks, semantic argmax, panoptic merge)"
                                            % (batch, args.height, args.width),
                                "global_batch": batch * world, "parallelism": "replicas%d" % world},
                     "instances_image0": len(res["out"][0]["instances"]), "segments_image0": len(res["out"][0]["panoptic_seg"][1])})
         if rank == 0:
-            out["roofline"] = conv_roofline(timer, sampled, args.steps)
-    else:
+            out["roofline"] = conv_roofline(timer, sampled, steps)
+            if args.per_layer:
+                per_layer_report(timer, sampled)
+        return out
+
+    def run_kmeans(steps, warmup, data_kind):
         from u2seg_amd.cluster import kmeans as KM
 
+        out = {}
         n_local = args.kmeans_n // world
         g = torch.Generator(device=dev).manual_seed(rank)
-        gc = torch.Generator(device=dev).manual_seed(12345)  # the mixture centres are the same on every rank
-        centers = torch.randn((KMEANS_K, KMEANS_D), generator=gc, device=dev) * 2
-        x = centers[torch.randint(0, KMEANS_K, (n_local,), generator=g, device=dev)] + \
-            0.5 * torch.randn((n_local, KMEANS_D), generator=g, device=dev)
-        state = {"c": centers + 0.3 * torch.randn((KMEANS_K, KMEANS_D), generator=gc, device=dev)}
+        gc = torch.Generator(device=dev).manual_seed(12345)  # the mixture centres / the initial centroids are the same on every rank
+        if data_kind == "mixture":
+            centers = torch.randn((KMEANS_K, KMEANS_D), generator=gc, device=dev) * 2
+            x = centers[torch.randint(0, KMEANS_K, (n_local,), generator=g, device=dev)] + \
+                0.5 * torch.randn((n_local, KMEANS_D), generator=g, device=dev)
+            state = {"c": centers + 0.3 * torch.randn((KMEANS_K, KMEANS_D), generator=gc, device=dev)}
+            what = "mixture of %d Gaussians, sigma 0.5" % KMEANS_K
+        else:  # SURVEY 8(d) base case: unstructured data, the reference's init (random rows of x)
+            x = torch.randn((n_local, KMEANS_D), generator=g, device=dev)
+            state = {"c": x[torch.randperm(n_local, generator=g, device=dev)[:KMEANS_K]].clone()}
+            what = "x = randn(N, %d), initial centroids = random rows" % KMEANS_D
+            if world > 1:
+                dist.broadcast(state["c"], 0)
+        rechecks = []
 
         def step(i):
             lab = KM.assign(x, state["c"])
             state["c"], _ = KM.update_sharded(x, lab, KMEANS_K) if world > 1 else KM.update(x, lab, KMEANS_K)
 
-        dt, sampled = timed(step)
-        s_per_iter = dt / args.steps
+        dt, sampled = timed(step, steps, warmup)
+        rechecks.append(KM.last_recheck_count(x.device))
+        s_per_iter = dt / steps
         out.update({"metric": "k-means seconds per Lloyd iteration (u2seg_R50_300 Instance_Clustering: N = 1M x 768 DINO-sized "
                               "embeddings, K = 300)", "value": s_per_iter, "unit": "s/iter", "ms_per_step": s_per_iter * 1e3,
-                    "higher_is_better": False, "scaling": "strong", "dtype": "f32 (distances screened in split bf16, undecided points in exact fp32)",
-                    "config": {"workload": "Lloyd iterations (assign + update) over %d x %d synthetic embeddings (mixture of %d "
-                                           "Gaussians, sigma 0.5), K = %d, rows sharded over the GPUs" %
-                                           (n_local * world, KMEANS_D, KMEANS_K, KMEANS_K), "parallelism": "rows%d" % world},
+                    "higher_is_better": False, "scaling": "strong", "steps": steps, "warmup": warmup,
+                    "dtype": "f32 (distances screened in split bf16, undecided points in exact fp32)",
+                    "config": {"workload": "Lloyd iterations (assign + update) over %d x %d synthetic embeddings (%s), K = %d, rows "
+                                           "sharded over the GPUs" % (n_local * world, KMEANS_D, what, KMEANS_K),
+                               "parallelism": "rows%d" % world},
                     "finite_centroids": bool(torch.isfinite(state["c"]).all())})
         if rank == 0:
             ks = timer.summary()
             a = ks.get("u2_kmeans_assign")
             if a:
-                ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
-                # the screening kernel multiplies three bf16 piece pairs per product: executed MFMA flop = 3 x algorithmic
-                out["roofline"] = {"kernel": "u2_kmeans_assign: kmeans_screen_kernel (|c|^2 - 2 x.c as hi.hi + hi.lo + lo.hi on "
-                                             "v_mfma_f32_16x16x32_bf16) + exact-fp32 kmeans_assign_kernel on the undecided points",
-                                   "bound": "mfma", "achieved": 3 * ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": 3 * ach / 2500.0,
-                                   "algorithmic_tflops": ach, "fp32_mfma_peak_tflops": 157.3,
-                                   "rechecked_points_last_call": KM.last_recheck_count(x.device),
-                                   "traffic": None, "avg_launch_ms": a["ms"] / a["launches"],
-                                   "flop_per_launch": a["flops"] / a["launches"],
-                                   "algorithmic_bytes_per_launch": a["bytes"] / a["launches"],
+                # one Lloyd iteration needs ONE pass over X (N*D*4 bytes) once the distances run on bf16-class
+                # MFMA, so the iteration is priced against HBM; the E step's algorithmic 2*N*K*D flop are reported beside it
+                # (algorithmic, not the 3 bf16 piece products the screening kernel executes per product)
+                alg_bytes = 4.0 * n_local * KMEANS_D
+                ach = alg_bytes / s_per_iter / 1e12
+                out["roofline"] = {"kernel": "Lloyd iteration = u2_kmeans_assign (kmeans_screen_kernel: |c|^2 - 2 x.c as hi.hi + hi.lo "
+                                             "+ lo.hi on v_mfma_f32_16x16x32_bf16, + exact-fp32 kmeans_assign_kernel on the undecided "
+                                             "points) + u2_kmeans_update (label-bucketed segmented sums)",
+                                   "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": ach / PEAK_HBM_TBPS,
+                                   "traffic": None, "algorithmic_bytes_per_iter": alg_bytes,
+                                   "e_step_algorithmic_tflops": a["flops"] / (a["ms"] * 1e-3) / 1e12,
+                                   "e_step_frac_of_bf16_mfma_peak": a["flops"] / (a["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                                   "rechecked_points_last_call": rechecks[-1],
+                                   "avg_launch_ms": a["ms"] / a["launches"],
                                    "kernel_ms_per_iter": {k: v["ms"] / sampled for k, v in ks.items()},
                                    "update_GB_per_s": (ks["u2_kmeans_update"]["bytes"] / (ks["u2_kmeans_update"]["ms"] * 1e-3) / 1e9
                                                        if "u2_kmeans_update" in ks else None)}
+        return out
+
+    def release():
+        import gc
+
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    out = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "vs_baseline": None, "data": "synthetic"}
+    if args.workload == "train":
+        out.update(run_train(args.steps, args.warmup))
+    elif args.workload == "infer":
+        out.update(run_infer(args.steps, args.warmup))
+    else:
+        out.update(run_kmeans(args.steps, args.warmup, args.kmeans_data))
+    extra = {}
+    if args.workload == "train" and world == 1 and not args.no_extra:
+        # BASELINE.json configs[3] and configs[4] in the same invocation, after the timed training region and
+        # with the training state released; each entry is a full bench object (own timed region, roofline, cpu_baseline)
+        release()
+        for name, fn in (("kmeans", lambda: run_kmeans(10, 2, "mixture")), ("kmeans_randn", lambda: run_kmeans(10, 2, "randn")),
+                         ("infer", lambda: run_infer(5, 2))):
+            try:
+                extra[name] = dict({"n_gpus": 1, "data": "synthetic"}, **fn())
+            except Exception as e:  # an auxiliary workload must never take the headline line down with it
+                extra[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            release()
     if rank == 0:
-        if args.per_layer:
-            per_layer_report(timer, max(1, args.steps // 8))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload)
+            kinds = [args.workload] + (["kmeans", "infer"] if extra else [])
+            cb = cpu_baselines_parallel(kinds)
+            out["cpu_baseline"] = cb[args.workload]
+            for name in extra:
+                if "error" not in extra[name]:
+                    extra[name]["cpu_baseline"] = cb["kmeans" if name.startswith("kmeans") else "infer"]
+        if extra:
+            out["extra_workloads"] = extra
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

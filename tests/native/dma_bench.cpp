@@ -65,10 +65,90 @@ static void run(const char* name, const char* src, size_t window, int rowb, floa
   }
 }
 
-int main() {
+
+// ---- store side (round 3): what an output tile costs.  One work-group of 8 waves per CU writes 128 KiB tiles (256 pixels x
+// 512 B = 256 bf16 channels) the way the conv epilogue does - 16 x 16-byte stores per lane and tile - in four wave-instruction
+// shapes, optionally followed by NM MFMAs per wave and tile (the next tile's K loop) and optionally by s_waitcnt vmcnt(0)
+// (what an in-order counted wait behind the stores amounts to).
+//   SMODE 0: 16 pixels x 64 B per instruction (the 16x16x32 MFMA D layout, two 8-channel runs per lane)
+//   SMODE 1: 8 pixels x 128 B (full cache lines)       SMODE 2: 32 pixels x 32 B (the 32x32x16 D layout)
+//   SMODE 3: 1 KiB contiguous
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+template <int SMODE, bool NT, bool DRAIN>
+__global__ __launch_bounds__(512) void push_kernel(char* __restrict__ dst, int tiles, int nm, int do_store, float* sink) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  f32x4_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  s16x8_t fa, fb;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { fa[i] = (short)(lane + i); fb[i] = (short)(lane * 3 + i); }
+  u32x4_t v = {(unsigned)lane, 1u, 2u, 3u};
+  for (int t = 0; t < tiles; ++t) {
+    char* tile = dst + ((size_t)t * gridDim.x + blockIdx.x) * (128 << 10);
+    if (do_store) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        size_t off;
+        if (SMODE == 0) off = (size_t)((w & 1) * 128 + (k >> 1) * 16 + (lane & 15)) * 512 + (w >> 1) * 128 + (k & 1) * 64 + (lane >> 4) * 16;
+        else if (SMODE == 1) off = (size_t)((w & 1) * 128 + k * 8 + (lane >> 3)) * 512 + (w >> 1) * 128 + (lane & 7) * 16;
+        else if (SMODE == 2) off = (size_t)((w & 1) * 128 + (k >> 2) * 32 + (lane & 31)) * 512 + (w >> 1) * 128 + (k & 3) * 32 + (lane >> 5) * 16;
+        else off = (size_t)(w * 16 + k) * 1024 + lane * 16;
+        char* p = tile + off;
+        if (NT) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+      }
+      if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    for (int m = 0; m < nm; ++m) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[i], 0, 0, 0);
+    }
+  }
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r += acc[i][0];
+  if (r == 123456.f) sink[0] = r;
+}
+
+template <int SMODE, bool NT, bool DRAIN>
+static void run_push(const char* name, char* dst, int nm, int do_store, float* sink) {
+  const int tiles = 32;  // 32 x 128 KiB = 4 MiB per CU, 1 GiB over the chip
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((push_kernel<SMODE, NT, DRAIN>), dim3(256), dim3(512), 0, 0, dst, tiles, nm, do_store, sink);
+  HIPCHK(hipEventRecord(e0));
+  hipLaunchKernelGGL((push_kernel<SMODE, NT, DRAIN>), dim3(256), dim3(512), 0, 0, dst, tiles, nm, do_store, sink);
+  HIPCHK(hipEventRecord(e1)); HIPCHK(hipEventSynchronize(e1));
+  float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  const double bytes = do_store ? 256.0 * tiles * (128 << 10) : 0.0;
+  printf("%-44s nt %d drain %d mfma/tile/wave %5d stores %d: %8.3f ms  %6.2f us per tile  %6.2f TB/s (%5.1f GB/s per CU)\n", name, (int)NT,
+         (int)DRAIN, nm * 8, do_store, ms, ms * 1e3 / tiles, bytes / ms * 1e-9, bytes / ms * 1e-6 / 256);
+}
+
+static void store_bench(char* dst, float* sink) {
+  for (int nm : {0, 64, 288}) {  // 0: stores only; 512 / 2304 MFMA per wave and tile = the K loop of a 1x1 (K = 512) / 3x3 (K = 2304) layer
+    if (nm) run_push<0, false, false>("(MFMA only)", dst, nm, 0, sink);
+    run_push<0, false, false>("store 16 px x 64 B", dst, nm, 1, sink);
+    run_push<0, true, false>("store 16 px x 64 B", dst, nm, 1, sink);
+    run_push<0, true, true>("store 16 px x 64 B", dst, nm, 1, sink);
+    run_push<1, false, false>("store 8 px x 128 B", dst, nm, 1, sink);
+    run_push<1, true, false>("store 8 px x 128 B", dst, nm, 1, sink);
+    run_push<1, true, true>("store 8 px x 128 B", dst, nm, 1, sink);
+    run_push<2, false, false>("store 32 px x 32 B", dst, nm, 1, sink);
+    run_push<2, true, false>("store 32 px x 32 B", dst, nm, 1, sink);
+    run_push<3, false, false>("store 1 KiB contiguous", dst, nm, 1, sink);
+    run_push<3, true, false>("store 1 KiB contiguous", dst, nm, 1, sink);
+    run_push<3, true, true>("store 1 KiB contiguous", dst, nm, 1, sink);
+  }
+}
+
+int main(int argc, char** argv) {
   const size_t total = (size_t)1 << 30;
   char* src; float* sink;
   HIPCHK(hipMalloc(&src, total + (1 << 20))); HIPCHK(hipMemset(src, 1, total)); HIPCHK(hipMalloc(&sink, 64));
+  if (argc > 1 && argv[1][0] == 's') { store_bench(src, sink); return 0; }
   for (size_t window : {(size_t)64 << 10, (size_t)1 << 20}) {   // 64 KiB per CU: L2-resident; 1 MiB per CU x 512: MALL / HBM
     run<0, 8>("glds 16 rows x 64 B (pitch 512)", src, window, 512, sink);
     run<1, 8>("glds 8 rows x 128 B (pitch 512)", src, window, 512, sink);

@@ -26,7 +26,8 @@ struct ConvArgs {
   int remap_out, Hfull, Wfull, out_sy, out_sx, out_y0, out_x0;
   int stagger_by_parity;   // conv_igemm256<true>: wave groups = even / odd waves instead of waves 0-3 / 4-7
   int abl;                 // conv_tile.hip measurement switches (tests/native/selftest bench2 only; 0 in production):
-                           // bit 0 no output stores, bit 1 no BN statistics, bit 2 no epilogue at all
+                           // bit 0 no output stores, bit 1 no BN statistics, bit 2 no epilogue at all, bit 3 never `nt` stores,
+                           // bit 4 full-line (8 pixels x 128 B) stores, bit 5 counted waits that skip the epilogue's stores
 };
 
 // Tile shapes: (TM pixels x TN output channels) = 128x128 (default) or 256x64 (layers with <= 64 output channels,
@@ -50,6 +51,10 @@ extern int g_last_conv_kernel;
 // conv_tile.hip: persistent 64(ch) x 128(px)-per-wave tile kernels; returns 1 when it took the launch, 0 when the shape is
 // not served (caller falls back to conv_igemm_kernel), -1000 - hipError_t on a launch failure.
 int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s);
+
+// conv_halo.hip: 3x3 / stride 1 / pad 1 with the input halo of a 16 x 32 pixel patch staged once per 32-channel slab; same
+// return convention as launch_conv_tile.  g_last_conv_kernel code: 300.
+int launch_conv_halo(ConvArgs& a, int N, int C, int variant, hipStream_t s);
 
 // wgrad_halo.hip: 3x3 / stride 1 / pad 1 weight gradient, all nine taps per work-group with the input halo in LDS; same
 // return convention as launch_conv_tile.  g_last_conv_kernel code: 2900.

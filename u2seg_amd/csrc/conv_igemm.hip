@@ -1128,6 +1128,11 @@ int env_variant(const char* name, int variant) {
 
 int launch_conv(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   variant = env_variant("U2_CONV_VARIANT", variant);
+  {  // 3x3 / stride 1 / pad 1 layers on large maps: halo-staged kernel (conv_halo.hip)
+    const int rc = launch_conv_halo(a, N, C, variant, s);
+    if (rc == 1) return 0;
+    if (rc < 0) return rc;
+  }
   {  // persistent tile kernels (conv_tile.hip) first; 0 = shape / variant not served there
     const int rc = launch_conv_tile(a, N, C, variant, s);
     if (rc == 1) return 0;
