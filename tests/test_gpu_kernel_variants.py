@@ -101,7 +101,9 @@ CONV_VARIANTS = [
     (NEVER_TILE | 256, 256),                              # conv_igemm256_kernel<false>
     (NEVER_TILE | 256 | 1024, 256 + 1024),                # conv_igemm256_kernel<true> (staggered wave groups)
     (NEVER_TILE | 256 | 1024 | 2048, 256 + 1024),
-] + [((cfg << 12) | (tiny << 16), 100 + cfg) for cfg in range(1, 7) for tiny in (0, 1)]
+] + [((cfg << 12) | (tiny << 16), 100 + cfg) for cfg in range(1, 7) for tiny in (0, 1)] + [
+    (1 << 24, 300), ((1 << 24) | (1 << 16), 300),         # conv_halo.hip (halo-staged 3x3), 12 tiles / 8 work-groups
+]
 
 
 @pytest.mark.parametrize("variant,code", CONV_VARIANTS)
@@ -210,10 +212,10 @@ def _sampled_conv_ref(x, w, bias, pos, pad):
 
 FULL_SHAPES = [
     # name, B, H, W, cin, cout, k, pad, relu+bias, expected forward kernel under the automatic dispatch
-    ("fpn_output2 3x3 256->256 @200x336", 16, 200, 336, 256, 256, 3, 1, False, 102),
+    ("fpn_output2 3x3 256->256 @200x336", 16, 200, 336, 256, 256, 3, 1, False, 300),   # conv_halo.hip
     ("rpn conv 3x3 256->256 @100x168 bias relu", 16, 100, 168, 256, 256, 3, 1, True, 101),
-    ("res3 conv2 3x3 128->128 @100x168", 16, 100, 168, 128, 128, 3, 1, False, 103),
-    ("res2 conv2 3x3 64->64 @200x336", 16, 200, 336, 64, 64, 3, 1, False, 103),
+    ("res3 conv2 3x3 128->128 @100x168", 16, 100, 168, 128, 128, 3, 1, False, 300),
+    ("res2 conv2 3x3 64->64 @200x336", 16, 200, 336, 64, 64, 3, 1, False, 300),
     ("res4 conv3 1x1 256->1024 @50x84", 16, 50, 84, 256, 1024, 1, 0, False, 104),
     ("res5 conv1 1x1 2048->512 @25x42", 16, 25, 42, 2048, 512, 1, 0, False, 102),
     ("mask head 3x3 256->256 @261x14x14 bias relu", 261, 14, 14, 256, 256, 3, 1, True, 101),

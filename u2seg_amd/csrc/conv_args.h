@@ -25,9 +25,8 @@ struct ConvArgs {
   // (img, qy*out_sy + out_y0, qx*out_sx + out_x0) of the Hfull x Wfull map (identity for ordinary launches)
   int remap_out, Hfull, Wfull, out_sy, out_sx, out_y0, out_x0;
   int stagger_by_parity;   // conv_igemm256<true>: wave groups = even / odd waves instead of waves 0-3 / 4-7
-  int abl;                 // conv_tile.hip measurement switches (tests/native/selftest bench2 only; 0 in production):
-                           // bit 0 no output stores, bit 1 no BN statistics, bit 2 no epilogue at all, bit 3 never `nt` stores,
-                           // bit 4 full-line (8 pixels x 128 B) stores, bit 5 counted waits that skip the epilogue's stores
+  int abl;                 // conv_halo.hip measurement switches (tests/native/selftest bench2 only; 0 in production):
+                           // bit 0 no output stores, bit 1 no BN statistics, bit 2 no epilogue at all, bit 3 never `nt` stores
 };
 
 // Tile shapes: (TM pixels x TN output channels) = 128x128 (default) or 256x64 (layers with <= 64 output channels,

@@ -409,10 +409,10 @@ double patch_fill(int H, int W, int ph, int pw) {
 }  // namespace
 
 // Serves 3x3 / stride 1 / pad 1 launches (C % 32 == 0, N % 8 == 0, not accumulating).  variant bit 24: always where it applies,
-// bit 25: never, bit 26: the 8 x 64 patch; otherwise automatic, from tests/native/selftest bench2 (profiles/r03_conv_halo.txt):
+// bit 25: never; otherwise automatic, from tests/native/selftest bench2 (profiles/r03_conv_halo.txt):
 // the halo kernel wins wherever its patches are reasonably full - the stride-4 maps (200 x 336: 92 % full, +7...31 %) and the
 // layers with <= 128 output channels on the stride-8 maps (78-84 % full, +11 %) - and loses on small maps (50 x 84 and below,
-// 14 x 14 ROI maps), which stay on the tile kernels.  g_last_conv_kernel code: 300 (16 x 32 patches), 301 (8 x 64).
+// 14 x 14 ROI maps), which stay on the tile kernels.  g_last_conv_kernel code: 300.
 int launch_conv_halo(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   if ((variant >> 25) & 1) return 0;
   if (((variant >> 12) & 15) != 0) return 0;  // a tile-kernel configuration was asked for explicitly
@@ -423,10 +423,9 @@ int launch_conv_halo(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   if ((C & 31) || (N & 7) || (a.out_ld & 7) || a.M < 1) return 0;
   if ((unsigned long long)a.B * a.Hin * a.Win * a.in_ld * 2ull >= 0xffffffffull || (unsigned long long)N * 9 * C * 2ull >= 0xfffffff0ull)
     return 0;
-  const double f16 = patch_fill(a.Hout, a.Wout, 16, 32), f8 = patch_fill(a.Hout, a.Wout, 8, 64);
-  bool wide = f8 > f16 + 0.03;
-  if ((variant >> 26) & 1) wide = true;
-  const double fill = wide ? f8 : f16;
+  // (an 8 x 64 patch instantiation exists as a template parameter set, but at 256 registers it spills six of them into the
+  //  tile loop, and a scratch access there makes the compiler drain the LDS-DMA queue in every slab: not dispatched)
+  const double fill = patch_fill(a.Hout, a.Wout, 16, 32);
   if (!forced) {
     const long long tiles = (long long)a.B * ((a.Hout + 15) / 16) * ((a.Wout + 31) / 32) * ((N + TN - 1) / TN);
     if (tiles < 512) return 0;                          // less than two rounds of tiles: the tile kernels' finer grain wins
@@ -434,8 +433,8 @@ int launch_conv_halo(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   }
   const int tiny = (variant >> 16) & 1;
   a.abl = (variant >> 18) & 63;
-  g_last_conv_kernel = wide ? 301 : 300;
-  return wide ? launch_halo_cfg<8, 64>(a, N, tiny, s) : launch_halo_cfg<16, 32>(a, N, tiny, s);
+  g_last_conv_kernel = 300;
+  return launch_halo_cfg<16, 32>(a, N, tiny, s);
 }
 
 }  // namespace u2conv

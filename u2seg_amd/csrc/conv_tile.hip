@@ -17,7 +17,6 @@
 // Wave tile 64 channels x 128 pixels (4 x 8 v_mfma_f32_16x16x32_bf16 accumulators, 12 ds_read_b128 per 32 MFMA);
 // work-group = WCH x WPX waves: 4x2 (256 ch x 256 px, one group per CU), 2x2 and 4x1 (two groups per CU).
 #include <stdlib.h>
-#include <type_traits>
 
 #include "common.h"
 #include "conv_args.h"
@@ -72,9 +71,6 @@ __device__ __forceinline__ void divmod_f(int m, int d, float inv, int& q, int& r
   if (r >= d) { ++q; r -= d; }
 }
 
-template <int CTRL> __device__ __forceinline__ uint32_t dpp_mov_u(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
-}
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 // two floats -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32)
@@ -85,11 +81,7 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 }
 
 // ACC: out = act(bf16(conv + bias) + out) - the epilogue reads what it overwrites (a residual block's tail at inference)
-// SLAB: multi-tap filters walk the reduction slab-major - all taps of one 32-channel slab, then the next slab - instead of
-// tap-major.  The nine shifted reads of a slab then touch the same 64-byte pieces within nine half tiles (an XCD's 32
-// work-groups re-read ~0.6 MB in between) instead of every tap re-reading the tile's whole 131 KB input window eight half
-// tiles later (32 x 131 KB + the weights: beyond the 4 MB L2).  The per-tap bounds tests move to once per tile (a bit per tap).
-template <int WCH, int WPX, int RING, bool ACC = false, bool SLAB = false>
+template <int WCH, int WPX, int RING, bool ACC = false>
 __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const ConvArgs a) {
   constexpr int NW = WCH * WPX, NT = NW * 64;
   constexpr int TN = WCH * 64, TM = WPX * 128;
@@ -133,9 +125,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   int p_yx[LP];
   const bf16_t* p_src[LP];
   unsigned p_okmask = 0;  // bit i: row i of this thread reads real data in the current tap (advance by 32 channels)
-  unsigned p_okbits[LP];  // SLAB: bit t = tap t of row i reads real data
   int pt = -1, p_tap = a.ntaps, p_kc = 0, p_kh = 0, p_kw = 0;
-  int p_slab = kh_per_tap - 1;
   auto setup_pixels = [&](int tile) {
     const int m0 = (tile / a.tiles_n) * TM;
 #pragma unroll
@@ -158,45 +148,8 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
         p_yx[i] = 0x8000;  // y = -32768: every tap is out of range
       }
     }
-    if constexpr (SLAB) {
-#pragma unroll
-      for (int i = 0; i < LP; ++i) p_okbits[i] = 0;
-      int kh = 0, kw = 0;
-      for (int t = 0; t < a.ntaps; ++t) {
-        const int dy = kh - a.pad_h, dx = kw - a.pad_w;
-        if (++kw == a.KW) { kw = 0; ++kh; }
-#pragma unroll
-        for (int i = 0; i < LP; ++i) {
-          const int sy = (int)(short)(p_yx[i] & 0xffff) + dy, sx = (p_yx[i] >> 16) + dx;
-          const bool ok = (unsigned)sy < (unsigned)a.Hin && (unsigned)sx < (unsigned)a.Win;
-          p_okbits[i] |= ok ? (1u << t) : 0u;
-        }
-      }
-    }
   };
   auto stage_pixels = [&](int buf) {
-    if constexpr (SLAB) {
-      if (p_tap == a.ntaps) {  // next slab, or the first slab of the next tile
-        p_tap = 0; p_kh = 0; p_kw = 0;
-        if (++p_slab == kh_per_tap) {
-          p_slab = 0;
-          ++pt;
-          setup_pixels(first_tile + pt * stride);
-        }
-      }
-      const int dy = p_kh - a.pad_h, dx = p_kw - a.pad_w;
-      if (++p_kw == a.KW) { p_kw = 0; ++p_kh; }
-      const unsigned char* sbase = reinterpret_cast<const unsigned char*>(a.in) + ((long long)dy * a.Win + dx) * a.in_ld * 2 +
-                                   (long long)p_slab * 64;
-      unsigned char* base = smem + buf * BUF;
-#pragma unroll
-      for (int i = 0; i < LP; ++i) {
-        const bool ok = (p_okbits[i] >> p_tap) & 1u;
-        glds16(ok ? reinterpret_cast<const bf16_t*>(sbase + p_center[i]) : a.zero, base + (i * NW + w) * 1024);
-      }
-      ++p_tap;
-      return;
-    }
     if (p_kc == 0) {
       if (p_tap == a.ntaps) {
         p_tap = 0; p_kh = 0; p_kw = 0;
@@ -238,7 +191,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   // 32 + fg*8 .. 32 + fg*8+7 of the slice: two 16-byte runs per pixel.
   unsigned w_base[LW];  // byte offset of the row's first chunk from a.wt; 0xffffffff = row beyond N (reads the zero page)
   const bf16_t* w_src[LW];
-  int wt_i = -1, w_tap = a.ntaps, w_kc = 0, w_slab = kh_per_tap - 1;
+  int wt_i = -1, w_tap = a.ntaps, w_kc = 0;
   auto setup_weights = [&](int tile) {
     const int n0 = (tile % a.tiles_n) * TN;
 #pragma unroll
@@ -250,23 +203,6 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     }
   };
   auto stage_weights = [&](int buf) {
-    if constexpr (SLAB) {
-      if (w_tap == a.ntaps) {
-        w_tap = 0;
-        if (++w_slab == kh_per_tap) {
-          w_slab = 0;
-          ++wt_i;
-          setup_weights(first_tile + wt_i * stride);
-        }
-      }
-      const unsigned char* tb = reinterpret_cast<const unsigned char*>(a.wt) + ((size_t)w_tap * a.C + (size_t)w_slab * 32) * 2;
-      unsigned char* base = smem + buf * BUF + PBYTES;
-#pragma unroll
-      for (int i = 0; i < LW; ++i)
-        glds16(w_base[i] != 0xffffffffu ? reinterpret_cast<const bf16_t*>(tb + w_base[i]) : a.zero, base + (i * NW + w) * 1024);
-      ++w_tap;
-      return;
-    }
     if (w_kc == 0) {
       if (w_tap == a.ntaps) {
         w_tap = 0;
@@ -307,12 +243,6 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   // same tile_n and sends them with two full-wave atomics when the channel changes or the work-group is done.
   float st_s = 0.f, st_ss = 0.f;
   int st_n = -1;
-  int st_base = -1;   // wave-uniform: first channel of the 64-channel slice st_n belongs to (-1: nothing accumulated yet)
-  // Counted waits behind an epilogue.  vmcnt retires in order, so a wait for an LDS-DMA group that was issued BEFORE the
-  // epilogue's stores may leave those stores (and the two statistics atomics) outstanding as well: for the AHEAD - 1 half
-  // tiles after an epilogue whose store count is known exactly (a full tile: every lane stores both runs of all eight rows)
-  // the wait is N + st_ops instead of N, and the stores drain behind the next tile's MFMAs instead of in front of them.
-  int st_relax = 0, st_ops = 0;
   auto stats_flush = [&]() {
     if (st_n >= 0 && st_n < a.N) {
       asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(a.stats + st_n), "v"(st_s) : "memory");
@@ -327,18 +257,13 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   // of the first fragment read of every half tile (it cannot tell the LDS-DMA in flight from these), which turns the ring
   // into a synchronous load.  Stores carry their own `s_nop 1` (the data registers may be reused right after the
   // statement), the bias loads wait inside their statement.
-  auto epilogue_body = [&](int tile, auto has_bias_c) {
-    constexpr bool HAS_BIAS = decltype(has_bias_c)::value;
+  auto epilogue = [&](int tile) {
     const int tile_m = tile / a.tiles_n, tile_n = tile - tile_m * a.tiles_n;
     const int m0 = tile_m * TM + wc * 128;
-    const int nslice = tile_n * TN + wr * 64;
-    const int nb = nslice + fg * 8;
+    const int nb = tile_n * TN + wr * 64 + fg * 8;
     const bool okA = nb < a.N, okB = nb + 32 < a.N;  // N % 8 == 0: an 8-channel run is valid or absent as a whole
-    // wave-uniform: every lane stores both runs of all eight rows (the store count of this epilogue is exactly 16)
-    bool full = !ACC && !HAS_BIAS && (m0 + 127 < a.M) && (nslice + 63 < a.N) && !(a.abl & 1) && !a.remap_out;
-    int ops = 16;
     f32x4 bia[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    if constexpr (HAS_BIAS) {  // drains the LDS-DMA ring once per tile (the layers with a bias have long reductions)
+    if (a.bias) {  // drains the LDS-DMA ring once per tile (the layers with a bias have long reductions)
       if (okA)
         asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(bia[0]), "=&v"(bia[1]) : "v"(a.bias + nb) : "memory");
@@ -346,12 +271,10 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
         asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(bia[2]), "=&v"(bia[3]) : "v"(a.bias + nb + 32) : "memory");
     }
-    f32x2_t s2[8], ss2[8];  // packed: element e = channels 2e, 2e + 1 of this lane's 16
+    float s[16], ss[16];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s2[e] = f32x2_t{0.f, 0.f}; ss2[e] = f32x2_t{0.f, 0.f}; }
-    const bool nt_out = (size_t)a.M * a.out_ld * 2 > ((size_t)160 << 20) && !(a.abl & 8);
-    const bool lines = (a.abl & 16) && !a.remap_out;  // full-line stores: see below
-    const bool do_stats = !ACC && a.stats && !(a.abl & 2);
+    for (int e = 0; e < 16; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+    const bool nt_out = (size_t)a.M * a.out_ld * 2 > ((size_t)160 << 20);
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
     u32x4_t olda[4], oldb[4];  // ACC: the values under rows j & 3 of the current batch of four rows
 #pragma unroll
@@ -377,58 +300,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
         }
       }
       const int m = m0 + j * 16 + fr;
-      const bool row_ok = m < a.M;
-      uint32_t pk[8];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        // block i holds channels e0 .. e0 + 3 of this lane's 16, e0 = (i >> 1) * 8 + (i & 1) * 4
-        float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-        if constexpr (HAS_BIAS) { v0 += bia[i][0]; v1 += bia[i][1]; v2 += bia[i][2]; v3 += bia[i][3]; }
-        if constexpr (ACC) {
-          // the conv result is rounded to bf16 first, then the stored value is added (conv_igemm_kernel's accumulate rule)
-          const uint32_t c01 = pack_bf16(v0, v1), c23 = pack_bf16(v2, v3);
-          const u32x4_t o = (i < 2) ? olda[j & 3] : oldb[j & 3];
-          const uint32_t o01 = o[(i & 1) * 2], o23 = o[(i & 1) * 2 + 1];
-          v0 = __uint_as_float(c01 << 16) + __uint_as_float(o01 << 16);
-          v1 = __uint_as_float(c01 & 0xffff0000u) + __uint_as_float(o01 & 0xffff0000u);
-          v2 = __uint_as_float(c23 << 16) + __uint_as_float(o23 << 16);
-          v3 = __uint_as_float(c23 & 0xffff0000u) + __uint_as_float(o23 & 0xffff0000u);
-        }
-        if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-        pk[2 * i] = pack_bf16(v0, v1);
-        pk[2 * i + 1] = pack_bf16(v2, v3);
-      }
-      if (do_stats && row_ok) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const f32x2_t v = {__uint_as_float(pk[e] << 16), __uint_as_float(pk[e] & 0xffff0000u)};
-          s2[e] += v;
-          ss2[e] = __builtin_elementwise_fma(v, v, ss2[e]);
-        }
-      }
-      if (a.abl & 1) {
-      } else if (lines) {
-        // Full cache lines per store instruction: lanes fr < 8 hand their second run to lane fr + 8 and receive that
-        // lane's first run (one row_ror:8 exchange), so that instruction 1 writes pixels 0-7 of the row block (lanes fr < 8:
-        // bytes 0-63 of the pixel's 128, lanes fr >= 8: bytes 64-127) and instruction 2 pixels 8-15 - 8 x 128 B instead of
-        // 16 x 64 B per instruction.
-        const bool lo8 = fr < 8;
-        uint32_t rx[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rx[e] = dpp_mov_u<0x128>(lo8 ? pk[4 + e] : pk[e]);
-        const u32x4_t v1 = {lo8 ? pk[0] : rx[0], lo8 ? pk[1] : rx[1], lo8 ? pk[2] : rx[2], lo8 ? pk[3] : rx[3]};
-        const u32x4_t v2 = {lo8 ? rx[0] : pk[4], lo8 ? rx[1] : pk[5], lo8 ? rx[2] : pk[6], lo8 ? rx[3] : pk[7]};
-        const int mq = m0 + j * 16 + (fr & 7);
-        bf16_t* d1 = a.out + (size_t)mq * a.out_ld + nb + (lo8 ? 0 : 32);
-        const bool ok = lo8 ? okA : okB;
-        if (nt_out) {
-          if (ok && mq < a.M) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(d1), "v"(v1) : "memory");
-          if (ok && mq + 8 < a.M) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(d1 + (size_t)8 * a.out_ld), "v"(v2) : "memory");
-        } else {
-          if (ok && mq < a.M) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(d1), "v"(v1) : "memory");
-          if (ok && mq + 8 < a.M) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(d1 + (size_t)8 * a.out_ld), "v"(v2) : "memory");
-        }
-      } else if (row_ok) {
+      if (m < a.M) {
         size_t orow = (size_t)m;
         if (a.remap_out) {
           int img, rem, qy, qx;
@@ -437,6 +309,34 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
           orow = ((size_t)img * a.Hfull + qy * a.out_sy + a.out_y0) * a.Wfull + qx * a.out_sx + a.out_x0;
         }
         bf16_t* dst = a.out + orow * a.out_ld + nb;
+        uint32_t pk[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // block i holds channels e0 .. e0 + 3 of this lane's 16, e0 = (i >> 1) * 8 + (i & 1) * 4
+          float v0 = acc[i][j][0] + bia[i][0], v1 = acc[i][j][1] + bia[i][1];
+          float v2 = acc[i][j][2] + bia[i][2], v3 = acc[i][j][3] + bia[i][3];
+          if constexpr (ACC) {
+            // the conv result is rounded to bf16 first, then the stored value is added (conv_igemm_kernel's accumulate rule)
+            const uint32_t c01 = pack_bf16(v0, v1), c23 = pack_bf16(v2, v3);
+            const u32x4_t o = (i < 2) ? olda[j & 3] : oldb[j & 3];
+            const uint32_t o01 = o[(i & 1) * 2], o23 = o[(i & 1) * 2 + 1];
+            v0 = __uint_as_float(c01 << 16) + __uint_as_float(o01 << 16);
+            v1 = __uint_as_float(c01 & 0xffff0000u) + __uint_as_float(o01 & 0xffff0000u);
+            v2 = __uint_as_float(c23 << 16) + __uint_as_float(o23 << 16);
+            v3 = __uint_as_float(c23 & 0xffff0000u) + __uint_as_float(o23 & 0xffff0000u);
+          }
+          if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+          pk[2 * i] = pack_bf16(v0, v1);
+          pk[2 * i + 1] = pack_bf16(v2, v3);
+        }
+        if (!ACC && a.stats) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float lo = __uint_as_float(pk[e] << 16), hi = __uint_as_float(pk[e] & 0xffff0000u);
+            s[2 * e] += lo; ss[2 * e] += lo * lo;
+            s[2 * e + 1] += hi; ss[2 * e + 1] += hi * hi;
+          }
+        }
         const u32x4_t va = {pk[0], pk[1], pk[2], pk[3]}, vb = {pk[4], pk[5], pk[6], pk[7]};
         if (nt_out) {  // outputs far beyond the MALL size: do not let them evict what the next layer can still reuse
           if (okA) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(va) : "memory");
@@ -447,29 +347,13 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
         }
       }
     }
-    if (do_stats) {
+    if (!ACC && a.stats) {
       // after the transposing reduction lane (fg, fr) holds the tile's column sums of the channel below
-      const int n_here = nslice + fg * 8 + (fr >> 3) * 32 + (fr & 7);
-      if (nslice != st_base) {
-        if (st_base >= 0) {  // two atomics go out; their count is exact only when the whole old slice lies below N
-          if (st_base + 63 < a.N) ops += 2; else full = false;
-        }
-        stats_flush();
-        st_n = n_here;
-        st_base = nslice;
-      }
-      float s[16], ss[16];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { s[2 * e] = s2[e][0]; s[2 * e + 1] = s2[e][1]; ss[2 * e] = ss2[e][0]; ss[2 * e + 1] = ss2[e][1]; }
+      const int n_here = tile_n * TN + wr * 64 + fg * 8 + (fr >> 3) * 32 + (fr & 7);
+      if (n_here != st_n) { stats_flush(); st_n = n_here; }
       st_s += row16_transpose_sum(s, fr);
       st_ss += row16_transpose_sum(ss, fr);
     }
-    if (full && (a.abl & 32)) { st_relax = AHEAD - 1; st_ops = ops; } else st_relax = 0;
-  };
-  auto epilogue = [&](int tile) {
-    if (a.abl & 4) return;
-    if (a.bias) epilogue_body(tile, std::true_type{});
-    else epilogue_body(tile, std::false_type{});
   };
 
 #define U2_T_MFMA(I, WF, J) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF, pf[J], acc[I][J], 0, 0, 0)
@@ -518,14 +402,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       // phase B
       {
         const int rem = H - 2 - gh;  // half tiles staged behind gh + 1
-        if (rem >= AHEAD - 1) {
-          if (st_relax > 0) {
-            --st_relax;
-            if (st_ops == 16) wait_vm<LPT * (AHEAD - 1) + 16>(); else wait_vm<LPT * (AHEAD - 1) + 18>();
-          } else {
-            wait_vm<LPT * (AHEAD - 1)>();
-          }
-        }
+        if (rem >= AHEAD - 1) wait_vm<LPT * (AHEAD - 1)>();
         else if (AHEAD > 3 && rem == 2) wait_vm<LPT * 2>();
         else if (rem == 1) wait_vm<LPT>();
         else wait_vm<0>();
@@ -558,7 +435,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #undef U2_T_MFMA
 }
 
-template <int WCH, int WPX, int RING, bool ACC = false, bool SLAB = false>
+template <int WCH, int WPX, int RING, bool ACC = false>
 int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s) {
   constexpr int TN = WCH * 64, TM = WPX * 128;
   constexpr int LDS = RING * (TM + TN) * 64;
@@ -571,10 +448,10 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s) {
   G = (G + 7) & ~7LL;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, ACC, SLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, ACC, SLAB>), dim3((unsigned)G), dim3(WCH * WPX * 64), LDS, s, a);
+  hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, ACC>), dim3((unsigned)G), dim3(WCH * WPX * 64), LDS, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return -1000 - (int)e;
   return 1;
@@ -631,6 +508,7 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
     // a work-group only needs RING half tiles over ALL the tiles it walks; in automatic mode fall back to the ring-3
     // configurations (K >= 64 with two or more tiles per work-group, K >= 96 otherwise)
     if ((variant >> 12 & 15) != 0) return 0;
+    if (a.accumulate && N <= 128) return 0;  // the accumulating epilogue exists for configuration 4 only
     sel = (N <= 128) ? 3 : 4;
     ring = 3;
     const int TN = sel == 3 ? 128 : 256, TM = sel == 3 ? 256 : 128;
@@ -638,20 +516,7 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
     const long long min_tiles = (T >> 3) / 64;  // 512 work-groups: 64 per XCD
     if (nkh * min_tiles < ring) return 0;
   }
-  a.abl = (variant >> 18) & 63;  // measurement / A-B switches, see ConvArgs::abl
-  // bit 17: slab-major reduction order for the multi-tap filters (not the parity-class launches of a strided data gradient)
-  const bool slab = ((variant >> 17) & 1) && !a.remap_out && a.ntaps > 1 && a.ntaps <= 32 && !a.accumulate;
-  g_last_conv_kernel = 100 + sel + (slab ? 50 : 0);
-  if (slab) {
-    switch (sel) {
-      case 1: return launch_cfg<4, 2, 4, false, true>(a, N, 1, tiny, s);
-      case 2: return launch_cfg<4, 2, 5, false, true>(a, N, 1, tiny, s);
-      case 3: return launch_cfg<2, 2, 3, false, true>(a, N, 2, tiny, s);
-      case 4: return launch_cfg<4, 1, 3, false, true>(a, N, 2, tiny, s);
-      default: break;
-    }
-    g_last_conv_kernel = 100 + sel;
-  }
+  g_last_conv_kernel = 100 + sel;
   switch (sel) {
     case 1: return launch_cfg<4, 2, 4>(a, N, 1, tiny, s);
     case 2: return launch_cfg<4, 2, 5>(a, N, 1, tiny, s);
