@@ -82,6 +82,8 @@ class OracleModel:
     def conv(self, x, name, stride=1, pad=0, relu=False):
         w = self.q(self.p[name + ".weight"])
         b = self.p.get(name + ".bias")
+        if b is not None:
+            b = self.q(b)  # autocast casts every floating-point argument of the convolution, the bias included
         y = F.conv2d(self.q(x), w, b, stride, pad)
         if relu:
             y = F.relu(y)
@@ -95,7 +97,8 @@ class OracleModel:
             y = F.batch_norm(x, self.p[name + ".running_mean"], self.p[name + ".running_var"], self.p[name + ".weight"],
                              self.p[name + ".bias"], False, 0.1, 1e-5)
         if residual is not None:
-            y = y + residual
+            # backbone/resnet.py:204-209 under autocast: the norm's output is a bf16 tensor, `out += shortcut` a bf16 add
+            y = self.q(y) + residual
         if relu:
             y = F.relu(y)
         return self.q(y)
@@ -105,36 +108,44 @@ class OracleModel:
         return self.q(F.relu(y) if relu else y)
 
     def linear(self, x, name, relu=False):
-        y = F.linear(self.q(x), self.q(self.p[name + ".weight"]), self.p[name + ".bias"])
+        y = F.linear(self.q(x), self.q(self.p[name + ".weight"]), self.q(self.p[name + ".bias"]))
         if relu:
             y = F.relu(y)
         return self.q(y)
 
     # ---- backbone -----------------------------------------------------------------------------
-    def backbone(self, images, capture=None):
+    def stem(self, images):
+        """backbone/resnet.py:355-359 (BasicStem: conv 7x7/2 + norm + relu_, max_pool2d 3x3/2)."""
         pre = "backbone.bottom_up."
         x = self.bn(self.conv(images, pre + "stem.conv1", 2, 3), pre + "stem.conv1.norm", relu=True)
-        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+
+    def bottleneck(self, x, si, bi, capture=None):
+        """backbone/resnet.py:194-210 (BottleneckBlock.forward, stride on the 3x3 conv: STRIDE_IN_1X1 False)."""
+        n = "backbone.bottom_up.res%d.%d." % (si, bi)
+        stride = 2 if (bi == 0 and si > 2) else 1
+        c1 = self.bn(self.conv(x, n + "conv1"), n + "conv1.norm", relu=True)
+        c2 = self.bn(self.conv(c1, n + "conv2", stride, 1), n + "conv2.norm", relu=True)
+        out = self.conv(c2, n + "conv3")
+        if (n + "shortcut.weight") in self.p:
+            sc = self.bn(self.conv(x, n + "shortcut", stride), n + "shortcut.norm")
+        else:
+            sc = x
+        y = self.bn(out, n + "conv3.norm", residual=sc, relu=True)
+        if capture is not None:  # the units inside the block, for per-layer teacher forcing
+            capture["res%d.%d.conv1" % (si, bi)], capture["res%d.%d.conv2" % (si, bi)] = c1, c2
+            capture["res%d.%d.shortcut" % (si, bi)] = sc
+            capture["res%d.%d" % (si, bi)] = y
+        return y
+
+    def backbone(self, images, capture=None):
+        x = self.stem(images)
         if capture is not None:
             capture["stem"] = x
         res = {}
         for si, nblocks in zip(range(2, 6), [3, 4, 6, 3]):
             for bi in range(nblocks):
-                n = "%sres%d.%d." % (pre, si, bi)
-                stride = 2 if (bi == 0 and si > 2) else 1
-                c1 = self.bn(self.conv(x, n + "conv1"), n + "conv1.norm", relu=True)
-                c2 = self.bn(self.conv(c1, n + "conv2", stride, 1), n + "conv2.norm", relu=True)
-                out = self.conv(c2, n + "conv3")
-                if (n + "shortcut.weight") in self.p:
-                    sc = self.bn(self.conv(x, n + "shortcut", stride), n + "shortcut.norm")
-                else:
-                    sc = x
-                x = self.bn(out, n + "conv3.norm", residual=sc, relu=True)
-                if capture is not None:  # the units inside the block, for per-layer teacher forcing
-                    capture["res%d.%d.conv1" % (si, bi)], capture["res%d.%d.conv2" % (si, bi)] = c1, c2
-                    capture["res%d.%d.shortcut" % (si, bi)] = sc
-                if capture is not None:
-                    capture["res%d.%d" % (si, bi)] = x
+                x = self.bottleneck(x, si, bi, capture)
             res["res%d" % si] = x
         return self.fpn(res)
 

@@ -446,6 +446,10 @@ def import_reference():
         # (b, x0, y0, x1, y1) -> (b, cx, cy, w, h, 0): the rotated op centres at (cx, cy)*scale - 0.5 like aligned ROIAlign
         r = torch.stack([rois[:, 0], (rois[:, 1] + rois[:, 3]) / 2, (rois[:, 2] + rois[:, 4]) / 2, rois[:, 3] - rois[:, 1],
                          rois[:, 4] - rois[:, 2], torch.zeros_like(rois[:, 0])], dim=1)
+        if input.dtype != torch.float32:
+            # torchvision registers roi_align for autocast with a wrapper that computes in fp32 and returns the input's dtype
+            # (torchvision/csrc/ops/autocast/roi_align_kernel.cpp); the vendored rotated op has no bf16 kernel either
+            return roi_align_rotated(input.float(), r.float(), output_size, spatial_scale, max(sampling_ratio, 0)).to(input.dtype)
         return roi_align_rotated(input, r, output_size, spatial_scale, max(sampling_ratio, 0))
 
     RA.roi_align = roi_align
@@ -1572,6 +1576,70 @@ def gen_kmeans_fixture():
     print("wrote kmeans_golden.npz", cl.shape, c.shape)
 
 
+def gen_bf16_units_fixture():
+    """Pins the oracle's bf16 mode (OracleModel(emulate_bf16=True)): the REFERENCE's PanopticFPN, name-keyed weights, one
+    synthetic 96 x 128 image, train mode, run under torch.autocast("cpu", dtype=torch.bfloat16) - the precision recipe of
+    engine/train_loop.py:451-521 with the dtype BASELINE.json asks for.  Forward hooks keep, for a handful of units that
+    together contain every layer type of the conv stack, the unit's bf16 INPUT and OUTPUT (teacher forcing: the oracle gets the
+    reference's own input, so only this unit's rounding points are compared, not 50 layers of amplified noise), plus the ten
+    losses of the run.  tests/test_oracle_golden.py::test_bf16_mode_vs_reference_autocast holds the oracle to them."""
+    import_reference()
+    os.environ.setdefault("CLUSTER_NUM", "800")
+    from detectron2.config import get_cfg
+    from detectron2.modeling import build_model
+    from detectron2.utils.events import EventStorage
+
+    from u2seg_amd.data import make_synthetic_batch
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(REF, "configs/COCO-PanopticSegmentation/u2seg_R50_800.yaml"))
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.MODEL.WEIGHTS = ""
+    model = build_model(cfg)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            v.copy_(det_fill(k, v))
+    model.train()
+    bu = model.backbone.bottom_up
+    units = {"stem": bu.stem, "res2.0": bu.res2[0], "res3.0": bu.res3[0], "res4.1": bu.res4[1], "res5.2": bu.res5[2],
+             "fpn_lateral4": model.backbone.fpn_lateral4, "fpn_output3": model.backbone.fpn_output3,
+             "sem.p3.0": model.sem_seg_head.scale_heads[1][0], "sem.predictor": model.sem_seg_head.predictor,
+             "rpn.conv": model.proposal_generator.rpn_head.conv,
+             "rpn.objectness": model.proposal_generator.rpn_head.objectness_logits,
+             "box.fc2": model.roi_heads.box_head[0].fc2, "mask.fcn1": model.roi_heads.mask_head.mask_fcn1}
+    got = {}
+
+    def hook(name):
+        def fn(_m, inp, out):
+            if name not in got:  # modules shared across FPN levels (rpn head) fire once per level: keep the first (p2)
+                i, o = inp[0].detach(), out.detach()
+                if name in ("box.fc2", "mask.fcn1"):  # per-ROI independent units (no normalisation): a few ROIs are enough
+                    keep = 64 if name == "box.fc2" else 4
+                    i, o = i[:keep], o[:keep]
+                got[name] = (i.clone(), o.clone())
+        return fn
+
+    for k, m in units.items():
+        m.register_forward_hook(hook(k))
+    batch = to_ref_batch(make_synthetic_batch(1, height=96, width=128))
+    torch.manual_seed(5)
+    with EventStorage(), torch.autocast("cpu", dtype=torch.bfloat16):
+        losses = model(batch)
+    arrays = {}
+    meta = {"image_hw": [96, 128], "num_images": 1, "seed": 5, "autocast": "cpu bfloat16",
+            "losses": {k: float(v) for k, v in losses.items()}, "dtypes": {}}
+    for k, (i, o) in got.items():
+        meta["dtypes"][k] = [str(i.dtype), str(o.dtype)]
+        for tag, t in (("in", i), ("out", o)):
+            if t.dtype == torch.bfloat16:
+                arrays["%s.%s" % (k, tag)] = t.contiguous().view(torch.int16).numpy().copy()
+            else:
+                arrays["%s.%s" % (k, tag)] = t.float().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "bf16_units_golden.npz"), **arrays)
+    json.dump(meta, open(os.path.join(HERE, "bf16_units_golden.json"), "w"), indent=1)
+    print("wrote bf16_units_golden", {k: list(v.shape) for k, v in arrays.items()}, meta["losses"], meta["dtypes"])
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -1585,6 +1653,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.only == "refunit":
         gen_refunit_fixture()
+        sys.exit(0)
+    if a.only == "bf16_units":
+        gen_bf16_units_fixture()
         sys.exit(0)
     if a.only == "config":
         gen_config_fixture()

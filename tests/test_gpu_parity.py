@@ -65,23 +65,23 @@ def rel_err(a, b):
 ])
 def test_conv_fwd_bwd(F, cin, cout, k, stride, pad, bias, relu):
     """conv (+bias)(+relu) forward, dgrad, wgrad, bias grad vs F.conv2d on the same bf16-rounded operands.
-    Tolerance: 1e-2 of the output range (one bf16 rounding of the result + fp32 accumulation-order noise)."""
+    Tolerance: 4e-3 of the output range against the UNROUNDED fp32 reference (the HIP result is the correctly rounded fp32 sum
+    up to accumulation-order noise: half a bf16 step, 2^-9 of the element); fp32 weight / bias gradients 2e-3."""
     g = torch.Generator().manual_seed(cin * 7 + cout)
     x = bf(torch.randn((2, cin, 19, 23), generator=g))
     w = (torch.randn((cout, cin, k, k), generator=g) / (cin * k * k) ** 0.5).requires_grad_(True)
     b = (torch.randn(cout, generator=g) * 0.1).requires_grad_(True) if bias else None
     xr = x.clone().requires_grad_(True)
-    yr = TF.conv2d(xr, bf(w), b, stride, pad)
+    yr = TF.conv2d(xr, bf(w), bf(b) if bias else None, stride, pad)  # autocast rounds the bias like the other operands
     if relu:
         yr = TF.relu(yr)
-    yr = bf(yr)
     gy = bf(torch.randn(yr.shape, generator=g))
     yr.backward(gy)
     xd = nhwc(x).requires_grad_(True)
     wd = w.detach().to(DEV).requires_grad_(True)
     bd = b.detach().to(DEV).requires_grad_(True) if bias else None
     y, stats = F._Conv2dFn.apply(xd, wd, bd, stride, pad, relu, not relu and not bias)
-    assert rel_err(nchw(y, cout), yr.detach()) < 1e-2
+    assert rel_err(nchw(y, cout), yr.detach()) < 4e-3
     if stats is not None:  # BN statistics of the stored bf16 output
         yy = nchw(y, cout)
         assert torch.allclose(stats[0].cpu(), yy.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
@@ -89,10 +89,10 @@ def test_conv_fwd_bwd(F, cin, cout, k, stride, pad, bias, relu):
     if y.shape[3] != cout:
         assert float(y[..., cout:].abs().max()) == 0.0  # pad columns stay zero
     y.backward(nhwc(gy, y.shape[3]))
-    assert rel_err(nchw(xd.grad, cin), xr.grad) < 1.5e-2
-    assert rel_err(wd.grad.cpu(), w.grad) < 1e-2
+    assert rel_err(nchw(xd.grad, cin), xr.grad) < 4e-3
+    assert rel_err(wd.grad.cpu(), w.grad) < 4e-3  # the reference gradient passes through bf(w)'s backward: rounded to bf16
     if bias:
-        assert rel_err(bd.grad.cpu(), b.grad) < 1e-2
+        assert rel_err(bd.grad.cpu(), b.grad) < 4e-3
 
 
 def test_stem_conv(F):
@@ -122,7 +122,8 @@ def test_batch_norm_residual_relu(F):
     beta = (0.1 * torch.randn(64, generator=g)).requires_grad_(True)
     rm, rv = torch.zeros(64), torch.ones(64)
     xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
-    yr = bf(TF.relu(TF.batch_norm(xr, rm, rv, gamma, beta, True, 0.1, 1e-5) + rr))
+    # backbone/resnet.py:204-209 under autocast: the norm output is a bf16 tensor, `out += shortcut` a bf16 add
+    yr = bf(TF.relu(bf(TF.batch_norm(xr, rm, rv, gamma, beta, True, 0.1, 1e-5)) + rr))
     gy = bf(torch.randn(yr.shape, generator=g))
     yr.backward(gy)
     xd, rd = nhwc(x).requires_grad_(True), nhwc(res).requires_grad_(True)
@@ -131,7 +132,7 @@ def test_batch_norm_residual_relu(F):
     xf = nchw(xd)
     stats = torch.stack([xf.sum((0, 2, 3)), (xf * xf).sum((0, 2, 3))]).to(DEV)
     y = F.batch_norm_act(xd, stats, gd, bd, rmd, rvd, rd, True, 0.1, 1e-5)
-    assert rel_err(nchw(y), yr.detach()) < 1e-2
+    assert rel_err(nchw(y), yr.detach()) < 4e-3
     assert torch.allclose(rmd.cpu(), rm, atol=1e-4) and torch.allclose(rvd.cpu(), rv, atol=1e-3)  # running stats
     y.backward(nhwc(gy))
     assert rel_err(nchw(xd.grad), xr.grad) < 2e-2
@@ -580,7 +581,11 @@ def test_kmeans_screened_assign_equals_exact():
         fast = KM.assign(xd, cd)
         n_checked = KM.last_recheck_count(xd.device)
         exact = KM.assign(xd, cd, exact=True)
-        assert torch.equal(fast, exact), int((fast != exact).sum())
+        if not torch.equal(fast, exact):  # say which of the two left the fp64 answer (diagnostic for a failure seen once in round 3)
+            d = (xd.double() ** 2).sum(1, keepdim=True) - 2 * xd.double() @ cd.double().t() + (cd.double() ** 2).sum(1)[None]
+            ref = d.argmin(1)
+            raise AssertionError("screened vs exact labels differ at %d points; vs fp64 argmin: screened %d, exact %d, re-checked %s"
+                                 % (int((fast != exact).sum()), int((fast != ref).sum()), int((exact != ref).sum()), n_checked))
         ref = O.kmeans_assign(x[:2000], c)
         bad = torch.nonzero(exact[:2000].cpu() != ref)[:, 0]
         d_lab = ((x[bad] - c[exact[:2000].cpu()[bad]]) ** 2).sum(1)
@@ -703,30 +708,22 @@ def test_knn_row_sharded_two_ranks():
 
 
 
-def free_running(attempts=2):
-    """For the two tests that let the HIP model run freely against a CPU run (no teacher forcing): the fp32 atomics of the BN
-    statistics land in a different order on every run, random-weight train-mode BN amplifies that last-bit noise, and once
-    in a few dozen runs a proposal crosses an NMS / matching threshold and moves a sampled loss out of its band.  The strict
-    comparisons are the teacher-forced ones (tests/test_gpu_bookkeeping.py); here a second attempt is allowed."""
-    import functools
-
-    def deco(fn):
-        @functools.wraps(fn)
-        def wrapper(*args, **kwargs):
-            for attempt in range(attempts):
-                try:
-                    return fn(*args, **kwargs)
-                except AssertionError:
-                    if attempt + 1 == attempts:
-                        raise
-                    print("free-running comparison out of band on attempt %d, running it again" % (attempt + 1))
-        return wrapper
-    return deco
+@pytest.fixture
+def fixed_order_statistics(F):
+    """The two tests that let the HIP model run freely against a CPU run (no teacher forcing) take the BN column statistics
+    from a fixed-order reduction of the stored conv output instead of the conv epilogue's fp32 atomics
+    (functional.set_deterministic_stats): the forward pass is then bit-reproducible from run to run, so a comparison that
+    holds once holds every time - no retries.  The strict comparisons are the teacher-forced ones
+    (tests/test_gpu_bookkeeping.py)."""
+    F.set_deterministic_stats(True)
+    try:
+        yield
+    finally:
+        F.set_deterministic_stats(False)
 
 
 @pytest.mark.parametrize("branch", ["per_image_permutations", "batched_keys"])
-@free_running()
-def test_whole_model_vs_oracle(F, branch):
+def test_whole_model_vs_oracle(F, fixed_order_statistics, branch):
     """u2seg_R50_800 on 2 synthetic 192x256 images, name-keyed weights, free running (the teacher-forced 1e-3 comparison is
     tests/test_gpu_bookkeeping.py::test_heads_teacher_forced_losses): the HIP path's 10 losses vs the oracle with bf16
     emulation (2% relative: bf16 accumulation-order noise moves a few proposals across NMS / matching thresholds).
@@ -810,8 +807,8 @@ def test_backbone_and_heads_blockwise_vs_oracle(F):
     """Teacher-forced per-layer parity at the tolerance north_star names: every conv + norm (+ residual)(+ ReLU) unit of the
     ResNet, the FPN, every conv + GroupNorm unit and the predictor of the semantic head and the RPN head of the HIP path get
     the bf16 oracle's activations as input and must reproduce the oracle's output of that unit to 1e-3 relative L2.  Whole
-    bottleneck blocks (three units + shortcut chained on the HIP side) are held to 2e-3 and the 11-layer semantic head end to
-    end to 5e-3: a random-weight train-mode-BN network amplifies rounding noise ~1.2x per layer, so longer free-running
+    bottleneck blocks (three units + shortcut chained on the HIP side) and the 11-layer semantic head end to end are held to
+    2e-3: a random-weight train-mode-BN network amplifies rounding noise ~1.2x per layer, so longer free-running
     chains only measure that amplification (the oracle's own bf16-vs-fp32 feature distance is 40-70%)."""
     from oracle.model import OracleModel
     from tests.golden.make_fixtures import det_fill
@@ -886,7 +883,7 @@ def test_backbone_and_heads_blockwise_vs_oracle(F):
     for k, v in unit.items():
         assert v < 1e-3, (k, v)
     for k, v in chain.items():
-        assert v < (5e-3 if k == "sem_logits" else 2e-3), (k, v)
+        assert v < 2e-3, (k, v)
 
 
 def test_inference_tails_vs_oracle_and_reference(F, G):
@@ -1324,8 +1321,7 @@ def test_real_data_pipeline_to_model(F):
 
 
 @pytest.mark.parametrize("branch", ["per_image_permutations", "batched_keys"])
-@free_running()
-def test_sgd_trajectory_vs_reference(F, branch):
+def test_sgd_trajectory_vs_reference(F, fixed_order_statistics, branch):
     """Four training steps through the product path (HIP model, FlatSGD arena + u2_sgd_clip_step, WarmupMultiStepLR,
     SimpleTrainer) against the reference's own four steps (tests/golden/trajectory_small.json: its PanopticFPN, its
     clip-wrapped SGD, its LR schedule, fp32 CPU): the lr of every step exactly, the dense losses of every step within the

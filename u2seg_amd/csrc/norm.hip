@@ -174,7 +174,9 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const bf16_t* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float f = bf2f(xv[e]) * sc[e] + sh[e];
-      if (resid) f += bf2f(rv[e]);
+      // backbone/resnet.py:204-209 under autocast: the norm's output is a bf16 tensor and `out += shortcut` a bf16 add - the
+      // normalised value is rounded before the sum (pinned by tests/golden/bf16_units_golden.npz, the reference under autocast)
+      if (resid) f = bf2f(f2bf(f)) + bf2f(rv[e]);
       if (relu) f = fmaxf(f, 0.f);
       ov[e] = f2bf(f);
     }
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __re
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float f = bf2f(xv[e]) * sc[e] + sh[e];
-          if (RESID) f += bf2f(rv[e]);
+          if (RESID) f = bf2f(f2bf(f)) + bf2f(rv[e]);  // the normalised value is a bf16 tensor in the reference: rounded before the sum
           if (RELU) f = fmaxf(f, 0.f);
           ov[e] = f2bf(f);
           bits |= (bf2f(ov[e]) > 0.f ? 1u : 0u) << e;  // the test the backward pass would make on the stored activation

@@ -191,7 +191,9 @@ __global__ __launch_bounds__(256) void bilinear2_fwd_kernel(const bf16_t* __rest
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float f = hy * (hx * bf2f(v00[e]) + lx * bf2f(v01[e])) + ly * (hx * bf2f(v10[e]) + lx * bf2f(v11[e]));
-      if (addend) f += bf2f(o[e]);
+      // meta_arch/semantic_seg.py:240-244 under autocast: nn.Upsample returns a bf16 tensor, the running sum is a bf16 add -
+      // the interpolated value is rounded before the sum, as the two separate passes would
+      if (addend) f = bf2f(f2bf(f)) + bf2f(o[e]);
       o[e] = f2bf(f);
     }
     *reinterpret_cast<uint4*>(out + i * 8) = *reinterpret_cast<const uint4*>(o);

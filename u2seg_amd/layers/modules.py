@@ -58,9 +58,11 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self._pending_batches = 0  # folded into the buffer when it is read (state_dict): no per-step device op
+        self._updates = 0  # training-mode forwards so far: the running statistics change through a raw-pointer kernel
 
     def count_batch(self):
         self._pending_batches += 1
+        self._updates += 1
 
     def _flush_batches(self):
         if self._pending_batches:
@@ -168,7 +170,7 @@ class Conv2d(nn.Module):
             if residual is None:
                 # folded into the conv: weights scaled per output channel, shift as the bias, ReLU in the epilogue - no
                 # elementwise pass at all (the conv kernels add a bias and clamp before the one bf16 rounding)
-                return F.conv2d(x, folded[0], folded[1], self.stride, self.padding, relu=relu, param=folded[0])
+                return F.conv2d(x, folded[0], folded[1], self.stride, self.padding, relu=relu, param=folded[0], round_bias=False)
             if residual_owned and self.out_channels % 32 == 0 and os.environ.get("U2_EVAL_RESIDUAL_FUSE", "1") != "0":
                 return F.conv2d_add_(x, folded[0], folded[1], residual, self.stride, self.padding, relu=relu, param=folded[0])
             y = F.conv2d(x, self.weight, None, self.stride, self.padding, relu=False)
@@ -182,7 +184,13 @@ class Conv2d(nn.Module):
         changes through torch (version counters) or is re-allocated."""
         norm = self.norm
         parts = (self.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var)
-        key = tuple((t._version, t.data_ptr()) for t in parts)
+        # the optimizer (u2_sgd_clip_step) and the BN finalize kernel write through raw pointers and never bump `_version`:
+        # the optimizer's step stamp and the norm's update counter are part of the key
+        def stamp(t):
+            st = getattr(t, "_u2_stamp", None)
+            return st[0] if st is not None else 0
+
+        key = tuple((t._version, t.data_ptr(), stamp(t)) for t in parts) + (getattr(norm, "_updates", 0),)
         hit = self.__dict__.get("_u2_fold")
         if hit is not None and hit[0] == key:
             return hit[1]
