@@ -208,6 +208,11 @@ int u2_topk_rows(const void* vals, int dtype, int rows, int n, long long row_str
  * align_corners=False) and argmax (optional) int64 [B][H*S][W*S] = out.argmax(1) (first maximum), one pass. */
 int u2_semseg_upsample(const void* logits, float* out, long long* argmax, int B, int H, int W, int Cp, int K, int S,
                        void* stream);
+/* modeling/postprocessing.py:77-100 (sem_seg_postprocess): the [C][Hin][Win] fp32 window of a larger map (channel stride in_cs,
+ * row stride in_rs, in elements) -> out fp32 [C][Hout][Wout] = F.interpolate(window, size=(Hout, Wout), mode="bilinear",
+ * align_corners=False): source index scale * (dst + 0.5) - 0.5 clamped at 0 with scale = in / out in fp32, like ATen. */
+int u2_bilinear_resize_f32(const float* in, float* out, int C, int Hin, int Win, long long in_cs, long long in_rs, int Hout,
+                           int Wout, void* stream);
 /* out[k][y][x] (uint8 0/1) = bilinear sample of probs[k] (P x P fp32) on F.grid_sample(align_corners=False)'s grid over
  * boxes[k] = (x0, y0, x1, y1), zero outside the map, >= threshold. */
 int u2_paste_masks(const float* probs, const float* boxes, void* out, int n, int P, int H, int W, float threshold,

@@ -1640,6 +1640,40 @@ def gen_bf16_units_fixture():
     print("wrote bf16_units_golden", {k: list(v.shape) for k, v in arrays.items()}, meta["losses"], meta["dtypes"])
 
 
+def gen_checkpoint_matching_fixture():
+    """detectron2/checkpoint/c2_model_loading.py:209-330 (align_and_update_state_dicts, the name-matching heuristic behind
+    DetectionCheckpointer._load_model for files with `matching_heuristics`, i.e. U2Seg's dino_RN50_pretrain_d2_format.pkl): the
+    REFERENCE function run on the reference model's own 431 state-dict keys against a backbone-only, prefix-free d2-format key
+    set (+ an unused classifier weight, + one tensor of the wrong shape).  Tensors are 1-element stand-ins tagged with their
+    index except where a shape matters.  fvcore's Checkpointer base class is absent here, so the file round trip itself
+    (pickle / torch.save) cannot be produced by the reference; what is pinned is its matching logic on the real key set."""
+    import_reference()
+    os.environ.setdefault("CLUSTER_NUM", "800")
+    from detectron2.checkpoint.c2_model_loading import align_and_update_state_dicts
+    from detectron2.config import get_cfg
+    from detectron2.modeling import build_model
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(REF, "configs/COCO-PanopticSegmentation/u2seg_R50_800.yaml"))
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.MODEL.WEIGHTS = ""
+    model_sd = build_model(cfg).state_dict()
+    prefix = "backbone.bottom_up."
+    ckpt = {}
+    for i, (k, v) in enumerate(model_sd.items()):
+        if k.startswith(prefix) and "num_batches_tracked" not in k:
+            ckpt[k[len(prefix):]] = torch.full(tuple(v.shape), float(i))
+    ckpt["stem.fc.weight"] = torch.zeros(1000, 2048)            # present in ImageNet-style files, unused by the detector
+    ckpt["res2.0.conv1.weight"] = torch.zeros(3, 3)              # wrong shape: skipped with a warning
+    shapes = {k: list(v.shape) for k, v in ckpt.items()}
+    out = align_and_update_state_dicts(model_sd, dict(ckpt), c2_conversion=False)
+    tag = {id(v): k for k, v in ckpt.items()}
+    mapping = {mk: tag[id(v)] for mk, v in out.items() if id(v) in tag}
+    json.dump({"model_keys": {k: list(v.shape) for k, v in model_sd.items()}, "ckpt_shapes": shapes, "result": mapping},
+              open(os.path.join(HERE, "checkpoint_matching_golden.json"), "w"), indent=0)
+    print("wrote checkpoint_matching_golden.json:", len(mapping), "entries,", sum(1 for a, b in mapping.items() if a != b), "renamed")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -1653,6 +1687,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.only == "refunit":
         gen_refunit_fixture()
+        sys.exit(0)
+    if a.only == "checkpoint":
+        gen_checkpoint_matching_fixture()
         sys.exit(0)
     if a.only == "bf16_units":
         gen_bf16_units_fixture()

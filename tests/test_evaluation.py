@@ -98,6 +98,32 @@ def test_semantic_mapping_and_metrics_match_reference(tiny_val):
             assert res[k] == pytest.approx(v, rel=1e-12), k
 
 
+@pytest.mark.gpu
+def test_semantic_evaluator_accumulates_on_the_device(tiny_val):
+    """evaluation/sem_seg_evaluation.py:205-300 with the predictions resident on the GPU (where inference leaves them): the
+    joint (prediction, ground-truth) histogram of the voting pass and the 17 x 17 confusion matrix are accumulated on the
+    device (torch.bincount there), only votes / the final matrix come back - same votes, mapping file, matrix and metrics as
+    the reference-generated fixture."""
+    fx, inputs, outputs = tiny_val
+    assert torch.cuda.is_available()
+    outputs = [dict(o, sem_seg=o["sem_seg"].to("cuda:0")) for o in outputs]
+    ev = SemSegEvaluator("tiny_val_sem", mode="hungarian_matching")
+    ev.process(inputs, outputs)
+    assert sorted(zip(ev.pred_det_cate, ev.pseudo_gt_cate)) == [tuple(v) for v in fx["semantic_votes"]]
+    assert ev.evaluate()["sem_seg"] is None
+    assert json.load(open("./hungarian_matching/semantic_mapping.json")) == fx["semantic_mapping_file"]
+    ev2 = SemSegEvaluator("tiny_val_sem", mode="eval")
+    ev2.process(inputs, outputs)
+    assert ev2._conf_matrix.is_cuda  # the accumulation stayed on the device
+    assert ev2._conf_matrix.tolist() == fx["conf_matrix"]
+    res = ev2.evaluate()["sem_seg"]
+    for k, v in fx["sem_seg_results"].items():
+        if v is None:
+            assert res[k] != res[k], k
+        else:
+            assert res[k] == pytest.approx(v, rel=1e-12), k
+
+
 def test_vote_mapping_and_loop():
     # coco_evaluation.py:273-297: majority per cluster, -1 without votes, ties to the smaller category
     m = hungarian.majority_vote_mapping([0, 0, 0, 2, 2, 5], [3, 3, 1, 4, 7, 0], range(4), 8)

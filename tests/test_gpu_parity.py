@@ -1395,6 +1395,19 @@ def test_sgd_trajectory_vs_reference(F, fixed_order_statistics, branch):
     assert int(sd["backbone.bottom_up.stem.conv1.norm.num_batches_tracked"]) == fx["num_batches_tracked"] == fx["steps"]
 
 
+def test_sem_seg_postprocess_resize(F):
+    """modeling/postprocessing.py:77-100: the crop to the image size + bilinear resize to the requested output size
+    (u2_bilinear_resize_f32 reads the cropped window in place) vs ATen's interpolate, up- and down-scaling."""
+    from u2seg_amd.modeling.inference import sem_seg_postprocess
+
+    g = torch.Generator().manual_seed(3)
+    full = torch.randn((28, 160, 224), generator=g).to(DEV)
+    for img, out in (((150, 200), (225, 300)), ((160, 224), (97, 133)), ((33, 47), (160, 224)), ((160, 224), (160, 224))):
+        got = sem_seg_postprocess(full, img, *out)
+        ref = torch.nn.functional.interpolate(full[:, : img[0], : img[1]][None], size=out, mode="bilinear", align_corners=False)[0]
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-5, (img, out)
+
+
 def test_fpn_lateral_upsample_fusion_is_bit_identical(F):
     """backbone/fpn.py:141-158 fused (u2_affine_upadd inside the lateral's BatchNorm apply) vs the two separate passes
     (BatchNorm apply, then nearest x2 + add): the same bits forward, the same gradients for the lateral's input, the coarser

@@ -287,6 +287,30 @@ def test_detection_checkpointer_formats(tmp_path):
     assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), sd.values()))
 
 
+def test_checkpoint_name_matching_equals_reference():
+    """checkpoint/c2_model_loading.py:209-330: the suffix-matching heuristic that maps a prefix-free backbone file (the format of
+    U2Seg's dino_RN50_pretrain_d2_format.pkl, u2seg_R50_800.yaml:6) onto the model's names.  The fixture is the output of the
+    reference's own align_and_update_state_dicts on the reference model's 431 keys (make_fixtures.py --only checkpoint);
+    u2seg_amd.checkpoint.align_by_suffix must route every checkpoint tensor to the same model key, and this package's model
+    must expose exactly those keys and shapes."""
+    import json
+
+    from u2seg_amd.checkpoint import align_by_suffix
+    from u2seg_amd.modeling import build_model
+
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "checkpoint_matching_golden.json")))
+    model_sd = build_model(_cfg()).state_dict()
+    assert {k: list(v.shape) for k, v in model_sd.items()} == fx["model_keys"]
+    ckpt = {k: torch.empty(shape, device="meta") for k, shape in fx["ckpt_shapes"].items()}
+    mine = align_by_suffix(list(model_sd.keys()), ckpt)
+    mine_map = {mk: next(ck for ck, t in ckpt.items() if t is v) for mk, v in mine.items()}
+    wrong_shape = "res2.0.conv1.weight"  # the reference drops a shape mismatch while matching, this package right after it
+    want = dict(fx["result"])
+    assert want.pop(wrong_shape) == wrong_shape and mine_map.pop("backbone.bottom_up." + wrong_shape) == wrong_shape
+    assert mine_map == want
+    assert sum(1 for a, b in want.items() if a != b) == 264 and want["stem.fc.weight"] == "stem.fc.weight"  # unused: passed through
+
+
 def test_resolved_configs_equal_reference():
     """Every key this package's config tree holds has the value the reference resolves for the same yaml (its defaults.py +
     _BASE_ chain; fixture: tests/golden/make_fixtures.py --only config), for the four U2Seg train / eval configs - both

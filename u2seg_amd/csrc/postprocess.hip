@@ -252,6 +252,28 @@ __global__ __launch_bounds__(256) void semseg_upsample_kernel(const bf16_t* __re
   }
 }
 
+// sem_seg_postprocess (modeling/postprocessing.py:77-100): bilinear resize of a cropped fp32 [C][Hin][Win] window to
+// [C][Hout][Wout], align_corners = False, ATen's source-index rule (fp32 scale = in / out; negative source clamped to 0)
+__global__ __launch_bounds__(256) void bilinear_resize_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int C,
+                                                                  int Hin, int Win, long long in_cs, long long in_rs, int Ho, int Wo,
+                                                                  float sch, float scw) {
+  const size_t total = (size_t)C * Ho * Wo;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ox = (int)(i % Wo);
+    const size_t t = i / Wo;
+    const int oy = (int)(t % Ho), c = (int)(t / Ho);
+    const float sy = fmaxf(sch * ((float)oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(scw * ((float)ox + 0.5f) - 0.5f, 0.f);
+    const int y0 = min((int)sy, Hin - 1), x0 = min((int)sx, Win - 1);
+    const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* base = in + (size_t)c * in_cs;
+    const float v00 = base[(size_t)y0 * in_rs + x0], v01 = base[(size_t)y0 * in_rs + x1];
+    const float v10 = base[(size_t)y1 * in_rs + x0], v11 = base[(size_t)y1 * in_rs + x1];
+    out[i] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+  }
+}
+
 }  // namespace
 
 extern "C" int u2_semseg_upsample(const void* logits, float* out, long long* argmax, int B, int H, int W, int Cp, int K, int S,
@@ -277,6 +299,18 @@ extern "C" int u2_paste_masks(const float* probs, const float* boxes, void* out,
   if (blocks > 0x7fffffffLL) return -1;
   hipLaunchKernelGGL(paste_masks_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, probs, boxes,
                      (uint8_t*)out, total, P, H, W, threshold);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_bilinear_resize_f32(const float* in, float* out, int C, int Hin, int Win, long long in_cs, long long in_rs,
+                                      int Hout, int Wout, void* stream) {
+  if (C < 1 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1) return -1;
+  const size_t total = (size_t)C * Hout * Wout;
+  size_t g = (total + 255) / 256;
+  if (g > 256 * 32) g = 256 * 32;
+  hipLaunchKernelGGL(bilinear_resize_f32_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, in, out, C, Hin, Win, in_cs,
+                     in_rs, Hout, Wout, (float)Hin / (float)Hout, (float)Win / (float)Wout);
   U2_CHECK_LAUNCH();
   return 0;
 }

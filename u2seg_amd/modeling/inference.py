@@ -132,6 +132,12 @@ def sem_seg_postprocess(result, img_size, output_height, output_width):
     result = result[:, : img_size[0], : img_size[1]]
     if (output_height, output_width) == tuple(img_size):
         return result  # bilinear resampling to the same size (align_corners=False) is the identity
+    if result.is_cuda and result.dtype == torch.float32 and result.stride(2) == 1:
+        # the cropped window is read in place (channel / row strides): no copy of the crop, one launch
+        out = torch.empty((result.shape[0], output_height, output_width), dtype=torch.float32, device=result.device)
+        _hip.call("u2_bilinear_resize_f32", result, out, result.shape[0], img_size[0], img_size[1], result.stride(0),
+                  result.stride(1), output_height, output_width)
+        return out
     result = result.expand(1, -1, -1, -1)
     return torch.nn.functional.interpolate(result, size=(output_height, output_width), mode="bilinear", align_corners=False)[0]
 

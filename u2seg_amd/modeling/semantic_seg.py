@@ -22,45 +22,48 @@ class _Upsample2(nn.Module):
 
 @SEM_SEG_HEADS_REGISTRY.register()
 class SemSegFPNHead(nn.Module):
+    """One stack per FPN level that brings the level to the common stride - (3x3 conv + norm + ReLU, x2 bilinear) once per
+    octave above it, a single conv at the common stride itself - their sum, and a 1x1 predictor
+    (meta_arch/semantic_seg.py:143-267).  Child modules carry the reference's names (`p2.0`, `p4.2`, `predictor`, ...): the
+    level stacks are registered under the feature names, upsampling steps keep their slot in the stack's numbering."""
+
     @configurable
     def __init__(self, input_shape, *, num_classes, conv_dims, common_stride, loss_weight=1.0, norm=None, ignore_value=-1):
         super().__init__()
-        input_shape = sorted(input_shape.items(), key=lambda x: x[1].stride)
-        if not len(input_shape):
-            raise ValueError("SemSegFPNHead(input_shape=) cannot be empty!")
-        self.in_features = [k for k, v in input_shape]
-        feature_strides = [v.stride for k, v in input_shape]
-        feature_channels = [v.channels for k, v in input_shape]
-        self.ignore_value, self.common_stride, self.loss_weight = ignore_value, common_stride, loss_weight
-        self.num_classes = num_classes
+        levels = sorted((spec.stride, name, spec.channels) for name, spec in input_shape.items())
+        if not levels:
+            raise ValueError("the semantic head needs at least one input feature map")
+        self.num_classes, self.common_stride = num_classes, common_stride
+        self.loss_weight, self.ignore_value = loss_weight, ignore_value
+        self.in_features = [name for _, name, _ in levels]
         self.scale_heads = []
-        for in_feature, stride, channels in zip(self.in_features, feature_strides, feature_channels):
-            head_ops = []
-            head_length = max(1, int(math.log2(stride) - math.log2(self.common_stride)))
-            for k in range(head_length):
-                norm_module = get_norm(norm, conv_dims)
-                conv = Conv2d(channels if k == 0 else conv_dims, conv_dims, kernel_size=3, stride=1, padding=1,
-                              bias=not norm, norm=norm_module, activation="relu")
-                c2_msra_fill(conv)
-                head_ops.append(conv)
-                if stride != self.common_stride:
-                    head_ops.append(_Upsample2())
-            self.scale_heads.append(nn.Sequential(*head_ops))
-            self.add_module(in_feature, self.scale_heads[-1])
-        self.predictor = Conv2d(conv_dims, num_classes, kernel_size=1, stride=1, padding=0)
+        for stride, name, channels in levels:
+            stack = self._level_stack(stride, channels, conv_dims, common_stride, norm)
+            self.add_module(name, stack)
+            self.scale_heads.append(stack)
+        self.predictor = Conv2d(conv_dims, num_classes, kernel_size=1)
         c2_msra_fill(self.predictor)
+
+    @staticmethod
+    def _level_stack(stride, channels, width, common_stride, norm):
+        octaves = int(math.log2(stride) - math.log2(common_stride))
+        ops, cin = [], channels
+        for _ in range(max(1, octaves)):
+            conv = Conv2d(cin, width, kernel_size=3, padding=1, bias=not norm, norm=get_norm(norm, width), activation="relu")
+            c2_msra_fill(conv)
+            ops.append(conv)
+            if stride != common_stride:
+                ops.append(_Upsample2())
+            cin = width
+        return nn.Sequential(*ops)
 
     @classmethod
     def from_config(cls, cfg, input_shape):
-        return {
-            "input_shape": {k: v for k, v in input_shape.items() if k in cfg.MODEL.SEM_SEG_HEAD.IN_FEATURES},
-            "ignore_value": cfg.MODEL.SEM_SEG_HEAD.IGNORE_VALUE,
-            "num_classes": cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES,
-            "conv_dims": cfg.MODEL.SEM_SEG_HEAD.CONVS_DIM,
-            "common_stride": cfg.MODEL.SEM_SEG_HEAD.COMMON_STRIDE,
-            "norm": cfg.MODEL.SEM_SEG_HEAD.NORM,
-            "loss_weight": cfg.MODEL.SEM_SEG_HEAD.LOSS_WEIGHT,
-        }
+        head = cfg.MODEL.SEM_SEG_HEAD
+        wanted = set(head.IN_FEATURES)
+        return dict(input_shape={name: spec for name, spec in input_shape.items() if name in wanted},
+                    num_classes=head.NUM_CLASSES, conv_dims=head.CONVS_DIM, common_stride=head.COMMON_STRIDE, norm=head.NORM,
+                    loss_weight=head.LOSS_WEIGHT, ignore_value=head.IGNORE_VALUE)
 
     def layers(self, features):
         """Sum of the per-level heads at the common stride, then the 1x1 predictor (semantic_seg.py:246-253).
@@ -90,6 +93,11 @@ class SemSegFPNHead(nn.Module):
             return None, {"loss_sem_seg": loss * self.loss_weight}
         # x4 bilinear (align_corners=False) of the fp32 logits and their argmax in one kernel; the argmax rides along on the
         # result tensor for PanopticFPN.inference (panoptic_fpn.py:173), which would otherwise read the logits back
+        if self.num_classes > 64:  # the fused kernel keeps a pixel's class scores in registers (U2Seg configs: 28 classes)
+            logits = torch.nn.functional.interpolate(x[..., : self.num_classes].permute(0, 3, 1, 2).float(),
+                                                     scale_factor=self.common_stride, mode="bilinear", align_corners=False)
+            logits.u2_argmax = logits.argmax(dim=1)
+            return logits, {}
         logits, argmax = F.sem_seg_upsample(x, self.num_classes, self.common_stride)
         logits.u2_argmax = argmax
         return logits, {}
