@@ -111,6 +111,8 @@ CONV_VARIANTS = [
     (NEVER_TILE | 256 | 1024, 256 + 1024),                # conv_igemm256_kernel<true> (staggered wave groups)
     (NEVER_TILE | 256 | 1024 | 2048, 256 + 1024),
 ] + [((cfg << 12) | (tiny << 16), 100 + cfg) for cfg in range(1, 7) for tiny in (0, 1)] + [
+    # stream-K form (variant bit 27), 24 work-groups: shares begin and end inside tiles, partial tiles are handed over
+    ((cfg << 12) | (1 << 16) | (1 << 27), 500 + cfg) for cfg in (1, 2, 3, 4)] + [
     (1 << 24, 300), ((1 << 24) | (1 << 16), 300),         # conv_halo.hip (halo-staged 3x3), 12 tiles / 8 work-groups
 ]
 
@@ -222,7 +224,7 @@ def _sampled_conv_ref(x, w, bias, pos, pad):
 FULL_SHAPES = [
     # name, B, H, W, cin, cout, k, pad, relu+bias, expected forward kernel under the automatic dispatch
     ("fpn_output2 3x3 256->256 @200x336", 16, 200, 336, 256, 256, 3, 1, False, 300),   # conv_halo.hip
-    ("rpn conv 3x3 256->256 @100x168 bias relu", 16, 100, 168, 256, 256, 3, 1, True, 101),
+    ("rpn conv 3x3 256->256 @100x168 bias relu", 16, 100, 168, 256, 256, 3, 1, True, 501),   # stream-K form of configuration 1
     ("res3 conv2 3x3 128->128 @100x168", 16, 100, 168, 128, 128, 3, 1, False, 300),
     ("res2 conv2 3x3 64->64 @200x336", 16, 200, 336, 64, 64, 3, 1, False, 300),
     ("res4 conv3 1x1 256->1024 @50x84", 16, 50, 84, 256, 1024, 1, 0, False, 104),

@@ -25,6 +25,10 @@ struct ConvArgs {
   // (img, qy*out_sy + out_y0, qx*out_sx + out_x0) of the Hfull x Wfull map (identity for ordinary launches)
   int remap_out, Hfull, Wfull, out_sy, out_sx, out_y0, out_x0;
   int stagger_by_parity;   // conv_igemm256<true>: wave groups = even / odd waves instead of waves 0-3 / 4-7
+  // stream-K launches of conv_tile.hip (work-groups own equal shares of the (tile, half K tile) sequence): one fp32 partial-tile
+  // slot and one flag per work-group, device memory owned by the library (per stream)
+  float* sk_ws;
+  int* sk_flags;
   int abl;                 // conv_halo.hip measurement switches (tests/native/selftest bench2 only; 0 in production):
                            // bit 0 no output stores, bit 1 no BN statistics, bit 2 no epilogue at all, bit 3 never `nt` stores
 };

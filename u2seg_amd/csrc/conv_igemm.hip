@@ -1225,7 +1225,7 @@ extern "C" int u2_conv_igemm(const void* in, const void* wt, void* out, const fl
   a.in = (const bf16_t*)in; a.wt = (const bf16_t*)wt; a.out = (bf16_t*)out; a.bias = bias; a.stats = stats;
   a.zero = zero_page_ptr();
   if (!a.zero) return -2;
-  a.abl = 0; a.stagger_by_parity = 0;
+  a.abl = 0; a.stagger_by_parity = 0; a.sk_ws = nullptr; a.sk_flags = nullptr;
   a.B = B; a.Hin = Hin; a.Win = Win; a.C = C; a.in_ld = in_ld;
   a.N = N; a.out_ld = out_ld; a.mul = mul; a.relu = relu; a.accumulate = accumulate;
   a.wt_taps = KH * KW;

@@ -81,7 +81,16 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 }
 
 // ACC: out = act(bf16(conv + bias) + out) - the epilogue reads what it overwrites (a residual block's tail at inference)
-template <int WCH, int WPX, int RING, bool ACC = false>
+// SK ("stream-K"): instead of whole tiles, the work-groups of an XCD take EQUAL shares of the XCD's (tile, half K tile)
+// sequence - for layers whose tile count fills the last round of tiles badly (263 or 525 tiles on 256 / 512 slots: half of
+// the chip idle for the second round).  A share that begins inside a tile (k0 > 0) holds a non-leading part of it: its
+// accumulators go, raw fp32, into the work-group's slot of a.sk_ws and its flag is raised - at the START of that work-group's
+// life.  The share that holds the tile's first half K tile is its owner: at the END of its life it waits for the flags of
+// the (consecutive) work-groups holding the rest, adds their slots and runs the ordinary epilogue.  Every work-group of the
+// launch is resident (grid <= CUs x work-groups per CU), and nobody waits before having published, so the hand-over cannot
+// deadlock; slot stores and loads are both `sc0 sc1` (coherent for any placement of the two work-groups, MI355X_MICROARCH.md
+// "Workgroup dispatch ..."), the flag is a relaxed agent-scope atomic behind s_waitcnt vmcnt(0) + barrier.
+template <int WCH, int WPX, int RING, bool ACC = false, bool SK = false>
 __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const ConvArgs a) {
   constexpr int NW = WCH * WPX, NT = NW * 64;
   constexpr int TN = WCH * 64, TM = WPX * 128;
@@ -104,12 +113,29 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   const int q8 = T >> 3, r8 = T & 7;
   const int xbase = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
   const int xcnt = q8 + (xcd < r8 ? 1 : 0);
-  if (idx >= xcnt) return;
-  const int my_tiles = (xcnt - idx + stride - 1) / stride;
-  const int first_tile = xbase + idx;
   const int kh_per_tap = a.C >> 5;           // half K tiles (32 channels) per filter tap
   const int nkh = a.ntaps * kh_per_tap;      // >= RING (host)
-  const int H = my_tiles * nkh;              // half K tiles this work-group multiplies, across all its tiles
+  int my_tiles, first_tile, H;
+  int sk_k0 = 0, sk_k1 = nkh;                // SK: first half K tile of the first tile / end of the last tile of this share
+  long long sk_s0 = 0;
+  const long long sk_S = (long long)xcnt * nkh;   // SK: half K tiles of this XCD's tile range
+  if constexpr (SK) {
+    sk_s0 = sk_S * idx / stride;
+    const long long s1 = sk_S * (idx + 1) / stride;
+    if (s1 <= sk_s0) return;
+    first_tile = xbase + (int)(sk_s0 / nkh);
+    sk_k0 = (int)(sk_s0 % nkh);
+    const int last = (int)((s1 - 1) / nkh);
+    my_tiles = last - (int)(sk_s0 / nkh) + 1;
+    sk_k1 = (int)(s1 - (long long)last * nkh);
+    H = (int)(s1 - sk_s0);
+  } else {
+    if (idx >= xcnt) return;
+    my_tiles = (xcnt - idx + stride - 1) / stride;
+    first_tile = xbase + idx;
+    H = my_tiles * nkh;                      // half K tiles this work-group multiplies, across all its tiles
+  }
+  const int tstep = SK ? 1 : stride;         // distance of consecutive tiles of this work-group in the tile list
 
   // ---- staging cursors.  The pixel cursor runs AHEAD + 1 half tiles in front of the MFMAs, the weight cursor AHEAD; both
   // cross tile boundaries on their own.  Per row a thread keeps the address of the tap-(0,0) source pixel and its (y, x):
@@ -149,13 +175,9 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       }
     }
   };
-  auto stage_pixels = [&](int buf) {
-    if (p_kc == 0) {
-      if (p_tap == a.ntaps) {
-        p_tap = 0; p_kh = 0; p_kw = 0;
-        ++pt;
-        setup_pixels(first_tile + pt * stride);
-      }
+  // enters filter tap p_tap (of the tile setup_pixels() prepared) at its 32-channel slab `skip` (0 except for a stream-K
+  // share that begins inside a tile)
+  auto pixel_tap = [&](int skip) {
       int dy, dx;
       if (a.remap_out) {
         const int pk = a.tap_pk[__builtin_amdgcn_readfirstlane(p_tap)];
@@ -170,11 +192,20 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       for (int i = 0; i < LP; ++i) {
         const int sy = (int)(short)(p_yx[i] & 0xffff) + dy, sx = (p_yx[i] >> 16) + dx;
         const bool ok = (unsigned)sy < (unsigned)a.Hin && (unsigned)sx < (unsigned)a.Win;
-        p_src[i] = ok ? reinterpret_cast<const bf16_t*>(tap_base + p_center[i]) : a.zero;
+        p_src[i] = ok ? reinterpret_cast<const bf16_t*>(tap_base + p_center[i]) + skip * 32 : a.zero;
         p_okmask |= ok ? (1u << i) : 0u;
       }
       ++p_tap;
-      p_kc = kh_per_tap;
+      p_kc = kh_per_tap - skip;
+  };
+  auto stage_pixels = [&](int buf) {
+    if (p_kc == 0) {
+      if (p_tap == a.ntaps) {
+        p_tap = 0; p_kh = 0; p_kw = 0;
+        ++pt;
+        setup_pixels(first_tile + pt * tstep);
+      }
+      pixel_tap(0);
     }
     --p_kc;
     unsigned char* base = smem + buf * BUF;
@@ -202,20 +233,23 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       w_base[i] = n < a.N ? (unsigned)(((size_t)n * ((size_t)a.wt_taps * a.C) + cc * 8) * 2) : 0xffffffffu;
     }
   };
+  auto weight_tap = [&](int skip) {
+      const int wtap = a.remap_out ? (a.tap_pk[__builtin_amdgcn_readfirstlane(w_tap)] >> 16) : w_tap;
+      const unsigned char* tap_base = reinterpret_cast<const unsigned char*>(a.wt) + ((size_t)wtap * a.C + (size_t)skip * 32) * 2;
+#pragma unroll
+      for (int i = 0; i < LW; ++i)
+        w_src[i] = w_base[i] != 0xffffffffu ? reinterpret_cast<const bf16_t*>(tap_base + w_base[i]) : a.zero;
+      ++w_tap;
+      w_kc = kh_per_tap - skip;
+  };
   auto stage_weights = [&](int buf) {
     if (w_kc == 0) {
       if (w_tap == a.ntaps) {
         w_tap = 0;
         ++wt_i;
-        setup_weights(first_tile + wt_i * stride);
+        setup_weights(first_tile + wt_i * tstep);
       }
-      const int wtap = a.remap_out ? (a.tap_pk[__builtin_amdgcn_readfirstlane(w_tap)] >> 16) : w_tap;
-      const unsigned char* tap_base = reinterpret_cast<const unsigned char*>(a.wt) + (size_t)wtap * a.C * 2;
-#pragma unroll
-      for (int i = 0; i < LW; ++i)
-        w_src[i] = w_base[i] != 0xffffffffu ? reinterpret_cast<const bf16_t*>(tap_base + w_base[i]) : a.zero;
-      ++w_tap;
-      w_kc = kh_per_tap;
+      weight_tap(0);
     }
     --w_kc;
     unsigned char* base = smem + buf * BUF + PBYTES;
@@ -358,6 +392,16 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 
 #define U2_T_MFMA(I, WF, J) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF, pf[J], acc[I][J], 0, 0, 0)
 
+  if constexpr (SK) {  // both cursors enter the first tile at half K tile sk_k0
+    const int tap0 = sk_k0 / kh_per_tap, skip0 = sk_k0 - tap0 * kh_per_tap;
+    pt = 0; wt_i = 0;
+    setup_pixels(first_tile);
+    setup_weights(first_tile);
+    p_tap = tap0; w_tap = tap0;
+    p_kh = tap0 / a.KW; p_kw = tap0 - p_kh * a.KW;
+    pixel_tap(skip0);
+    weight_tap(skip0);
+  }
   // ---- prologue: P0 W0 ... P(AHEAD-1) W(AHEAD-1) P(AHEAD) in flight, publish half tile 0 ----
 #pragma unroll
   for (int i = 0; i < AHEAD; ++i) { stage_pixels(i); stage_weights(i); }
@@ -376,13 +420,70 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   // so no MFMA waits on an LDS read issued less than ~8 MFMAs earlier, and the LDS-DMA of a half tile has AHEAD - 1 full
   // half tiles of MFMAs to land.  The sequence runs straight through tile boundaries; only the accumulators are stored
   // and cleared there.
+  // ---- SK hand-over of a partial tile (see the kernel's head comment).  Slot layout: 16 bytes per thread and accumulator
+  // block, [i * 8 + j][thread] - every wave instruction moves 1 KB contiguous.
+  typedef __attribute__((ext_vector_type(4))) unsigned int sk_u32x4;
+  auto sk_publish = [&]() {
+    // one running pointer, opaque to the optimiser: 32 precomputed 64-bit addresses would not fit beside the accumulators
+    unsigned char* slot = reinterpret_cast<unsigned char*>(a.sk_ws) + (size_t)blockIdx.x * (TM * TN * 4) + (size_t)tid * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(slot), "v"(acc[i][j]) : "memory");
+        slot += NT * 16;
+        asm volatile("" : "+v"(slot));
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's part of the slot has left (no LDS hazard: the ring is only read / DMA-written)
+    // (inline asm like every other memory operation inside the tile loop: a compiler-visible global access here would make
+    //  the wait-count pass drain the LDS-DMA queue in front of every half tile's first fragment read)
+    if (tid == 0) {
+      const int one = 1;
+      asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(a.sk_flags + blockIdx.x), "v"(one) : "memory");
+    }
+  };
+  auto sk_combine = [&](int tile) {
+    // the work-groups idx + 1, idx + 2, ... of this XCD hold the rest of the tile: all whose share begins before the tile ends
+    const long long tile_end = (long long)(tile - xbase + 1) * nkh;
+    for (int j = idx + 1; j < stride && sk_S * j / stride < tile_end; ++j) {
+      const int peer = j * 8 + xcd;  // blockIdx.x of that work-group
+      if (tid == 0) {
+        int f;
+        do {
+          asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(f) : "v"(a.sk_flags + peer) : "memory");
+          if (f == 0) __builtin_amdgcn_s_sleep(8);
+        } while (f == 0);
+        const int zero = 0;  // consumed: clean for the next launch
+        asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(a.sk_flags + peer), "v"(zero) : "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const unsigned char* slot = reinterpret_cast<const unsigned char*>(a.sk_ws) + (size_t)peer * (TM * TN * 4) + (size_t)tid * 16;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {  // four accumulator blocks per batch: 16 scratch registers
+        f32x4 t[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(t[jj]) : "v"(slot) : "memory");
+          slot += NT * 16;
+          asm volatile("" : "+v"(slot));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])::"memory");
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[q >> 1][(q & 1) * 4 + jj] += t[jj];
+      }
+    }
+  };
+
   int gh = 0, hb = 0;
   for (int ti = 0; ti < my_tiles; ++ti) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int h = 0; h < nkh; ++h) {
+    const int h_begin = (SK && ti == 0) ? sk_k0 : 0, h_end = (SK && ti == my_tiles - 1) ? sk_k1 : nkh;
+    for (int h = h_begin; h < h_end; ++h) {
       const int nb = (hb + 1 == RING) ? 0 : hb + 1;
       const int sb = (hb == 0) ? RING - 1 : hb - 1;  // buffer of half tile gh + AHEAD (= gh - 1 mod RING)
       // phase A
@@ -429,21 +530,80 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       ++gh;
       hb = nb;
     }
-    epilogue(first_tile + ti * stride);
+    if constexpr (SK) {
+      if (h_begin > 0) { sk_publish(); continue; }              // a non-leading part: handed to the tile's owner
+      if (h_end < nkh) break;                                   // the owner collects the parts behind its own: below
+    }
+    epilogue(first_tile + ti * tstep);
+  }
+  if constexpr (SK) {
+    // (outside the tile loop on purpose: no K loop follows, so the fragment registers and the staging state are dead here
+    //  and the additions need no spill - a scratch access inside the tile loop would drain the LDS-DMA queue every half tile)
+    if (sk_k1 < nkh && !(my_tiles == 1 && sk_k0 > 0)) {
+      sk_combine(first_tile + my_tiles - 1);
+      epilogue(first_tile + my_tiles - 1);
+    }
   }
   if (!ACC && a.stats) stats_flush();
 #undef U2_T_MFMA
 }
 
+// stream-K scratch: one fp32 partial-tile slot (256 KB at most) and one flag per work-group, per stream (convolutions of
+// independent branches run concurrently on several streams); allocated on first use, flags zeroed once - the kernel leaves
+// every flag it consumed at zero
+struct SkScratch { hipStream_t stream; float* ws; int* flags; };
+constexpr int SK_MAX_GROUPS = 512;
+bool sk_scratch(hipStream_t s, ConvArgs& a) {
+  static SkScratch table[16];
+  static int used = 0;
+  for (int i = 0; i < used; ++i)
+    if (table[i].stream == s) { a.sk_ws = table[i].ws; a.sk_flags = table[i].flags; return true; }
+  if (used == 16) return false;
+  SkScratch e{s, nullptr, nullptr};
+  if (hipMalloc(&e.ws, (size_t)SK_MAX_GROUPS * 256 * 256 * 4) != hipSuccess) return false;
+  if (hipMalloc(&e.flags, SK_MAX_GROUPS * sizeof(int)) != hipSuccess) { (void)hipFree(e.ws); return false; }
+  if (hipMemset(e.flags, 0, SK_MAX_GROUPS * sizeof(int)) != hipSuccess) return false;
+  table[used++] = e;
+  a.sk_ws = e.ws; a.sk_flags = e.flags;
+  return true;
+}
+
+// sk: 0 = never, 1 = where the tile count fills its last round badly, 2 = always (tests)
 template <int WCH, int WPX, int RING, bool ACC = false>
-int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s) {
+int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s, int sk = 0) {
   constexpr int TN = WCH * 64, TM = WPX * 128;
   constexpr int LDS = RING * (TM + TN) * 64;
   a.tiles_m = (a.M + TM - 1) / TM;
   a.tiles_n = (N + TN - 1) / TN;
   const long long T = (long long)a.tiles_m * a.tiles_n;
   if (T >= (1 << 30)) return 0;
-  long long cap = tiny_grid ? 8 : 256LL * per_cu;
+  long long cap = tiny_grid ? (sk == 2 ? 24 : 8) : 256LL * per_cu;
+  if constexpr (!ACC) {
+    const long long nkh = (long long)a.ntaps * (a.C >> 5);
+    const long long rounds = (T + cap - 1) / cap;
+    // Measured (tests/native/selftest bench2, profiles/r03_conv_streamk.txt): equal shares pay for the 256 x 256 configurations
+    // on deep reductions when whole tiles fill the chip badly - 263 tiles (3x3 256->256 at stride 16: 642 -> 866 TFLOP/s), 132
+    // tiles (res5 3x3, fc1: +14 % / +48 %) - or fill the last of several rounds badly (3x3 at stride 8: +7.5 %, fc1 data
+    // gradient +10 %).  They lose on the two-groups-per-CU configurations (1x1 layers, -5...-25 %: the hand-over costs more than
+    // the second, independent work-group hides) and where nearly every tile would be split for a small gain (mask head 3x3,
+    // 203 tiles: -13 %).  The stream-K instantiation also spills a dozen registers (reloaded once per filter tap).
+    const double util = (double)T / (double)(rounds * cap);
+    const bool want = sk == 2 || (sk == 1 && WCH == 4 && WPX == 2 && T >= 8 && nkh >= 32 && (util < 0.7 || (util < 0.9 && T >= 512) || (nkh >= 128 && T >= 512)));
+    long long Gs = cap;
+    while (Gs > 8 && (T / 8) * nkh / (Gs / 8) < RING + 1) Gs -= 8;
+    if (want && (T / 8) * nkh / (Gs / 8) >= RING + 1 && sk_scratch(s, a)) {
+      static bool attr_set_sk = false;
+      if (!attr_set_sk) {
+        (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set_sk = true;
+      }
+      g_last_conv_kernel += 400;  // 5xx: the stream-K form of configuration xx
+      hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, false, true>), dim3((unsigned)Gs), dim3(WCH * WPX * 64), LDS, s, a);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return -1000 - (int)e;
+      return 1;
+    }
+  }
   long long G = T < cap ? T : cap;
   G = (G + 7) & ~7LL;
   static bool attr_set = false;
@@ -493,6 +653,8 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
       if (t256 >= 2048) sel = 2;                                   // stride-4 maps: >= 8 rounds of 256 x 256 tiles
       else if (t256 >= 768) sel = 1;                               // stride-8 maps
       else if (t256 >= 180 && t256 <= 256 && K >= 2048) sel = 1;   // one nearly full round (mask head 3x3)
+      else if (t256 > 256 && t256 < 768 && K >= 2048) sel = 1;     // stride-16 maps: 263 tiles, as equal stream-K shares
+      else if (t256 >= 96 && K >= 8192) sel = 1;                   // fc1 (7x7 on 256 channels, 128 tiles): stream-K, 1024 -> 1160
       else if (N >= 512 && t256 >= 128 && K >= 4096 && a.M >= 16000) sel = 1;  // res5 3x3 (not the 7x7 fc1: M = 8192)
     } else {
       if (N >= 4096) sel = 1;                                      // fc1 data gradient (N = 12544)
@@ -517,11 +679,14 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
     if (nkh * min_tiles < ring) return 0;
   }
   g_last_conv_kernel = 100 + sel;
+  // stream-K form (equal shares of the (tile, half K tile) sequence): automatic where whole tiles fill the last round badly;
+  // variant bit 27 forces it, bit 28 forbids it.  g_last_conv_kernel: 500 + configuration.
+  const int sk = ((variant >> 28) & 1) ? 0 : ((variant >> 27) & 1) ? 2 : 1;
   switch (sel) {
-    case 1: return launch_cfg<4, 2, 4>(a, N, 1, tiny, s);
-    case 2: return launch_cfg<4, 2, 5>(a, N, 1, tiny, s);
-    case 3: return launch_cfg<2, 2, 3>(a, N, 2, tiny, s);
-    case 4: return a.accumulate ? launch_cfg<4, 1, 3, true>(a, N, 2, tiny, s) : launch_cfg<4, 1, 3>(a, N, 2, tiny, s);
+    case 1: return launch_cfg<4, 2, 4>(a, N, 1, tiny, s, sk);
+    case 2: return launch_cfg<4, 2, 5>(a, N, 1, tiny, s, sk);
+    case 3: return launch_cfg<2, 2, 3>(a, N, 2, tiny, s, sk);
+    case 4: return a.accumulate ? launch_cfg<4, 1, 3, true>(a, N, 2, tiny, s) : launch_cfg<4, 1, 3>(a, N, 2, tiny, s, sk);
     case 5: return launch_cfg<2, 2, 4>(a, N, 1, tiny, s);
     case 6: return launch_cfg<1, 4, 4>(a, N, 1, tiny, s);
     default: return 0;
