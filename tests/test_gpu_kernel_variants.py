@@ -228,7 +228,8 @@ FULL_SHAPES = [
     ("res3 conv2 3x3 128->128 @100x168", 16, 100, 168, 128, 128, 3, 1, False, 300),
     ("res2 conv2 3x3 64->64 @200x336", 16, 200, 336, 64, 64, 3, 1, False, 300),
     ("res4 conv3 1x1 256->1024 @50x84", 16, 50, 84, 256, 1024, 1, 0, False, 104),
-    ("res5 conv1 1x1 2048->512 @25x42", 16, 25, 42, 2048, 512, 1, 0, False, 102),
+    ("res5 conv1 1x1 2048->512 @25x42", 16, 25, 42, 2048, 512, 1, 0, False, 502),            # 132 tiles: stream-K
+    ("fpn_output4 3x3 256->256 @50x84", 16, 50, 84, 256, 256, 3, 1, False, 501),            # 263 tiles: stream-K
     ("mask head 3x3 256->256 @261x14x14 bias relu", 261, 14, 14, 256, 256, 3, 1, True, 101),
 ]
 
