@@ -240,7 +240,19 @@ def set_deterministic_stats(on):
 
 def _fixed_order_stats(out, n):
     o = out[..., :n].float().reshape(-1, n)
-    return torch.stack([o.sum(0), (o * o).sum(0)]).contiguous()
+    packed = torch.cat([o.sum(0), (o * o).sum(0), o.new_zeros(1)])
+    st = packed[: 2 * n].view(2, n)
+    st._u2_packed = packed
+    return st
+
+
+def _stats_buffer(n, device):
+    """[sum | sum of squares] of a conv output's channels as a view of a zeroed [2n + 1] buffer: under SyncBN the extra slot
+    takes this rank's element count and the whole buffer is all-reduced as it stands (no concatenation, no host round trip)."""
+    packed = zeros_f32((2 * n + 1,), device)
+    st = packed[: 2 * n].view(2, n)
+    st._u2_packed = packed
+    return st
 
 
 class _Conv2dFn(Function):
@@ -263,7 +275,7 @@ class _Conv2dFn(Function):
         wk = weight_fwd_layout(weight, cp, param)
         alloc = torch.zeros if npad != n else torch.empty
         out = alloc((b, ho, wo, npad), dtype=BF16, device=x.device)
-        stats = zeros_f32((2, n), x.device) if want_stats else None
+        stats = _stats_buffer(n, x.device) if want_stats else None
         # autocast casts every floating-point argument of a convolution, the bias included (pinned by the reference run under
         # bf16 autocast, tests/golden/bf16_units_golden.npz); a folded eval-mode norm shift is not a conv bias and stays fp32
         bias_f = None
@@ -415,7 +427,7 @@ class _StemConvFn(Function):
         wk = torch.zeros((n, 1, kp), dtype=BF16, device=weight.device)
         wk[:, 0, :147] = weight.detach().permute(0, 2, 3, 1).reshape(n, 147)
         out = torch.empty((b, ho, wo, n), dtype=BF16, device=weight.device)
-        stats = zeros_f32((2, n), weight.device)
+        stats = _stats_buffer(n, weight.device)
         m = b * ho * wo
         _hip.call("u2_conv_igemm", col, wk, out, None, None if _DET_STATS else stats, 1, m, 1, kp, kp, m, 1, n, n, 1, 1, 0, 0, 1,
                   1, 0, 0, 0)
@@ -461,9 +473,10 @@ class _BatchNormActFn(Function):
         if world > 1:
             # nn.SyncBatchNorm (layers/batch_norm.py:187) gathers (mean, invstd, count) of every rank: the ranks pad their
             # batches to their own maximum image size, so the element counts differ.  One all-reduce of [sum | sumsq | count].
-            from ..modeling.batched import device_constant
-
-            packed = torch.cat([stats.reshape(-1), device_constant([float(m)], torch.float32, y.device)])
+            packed = getattr(stats, "_u2_packed", None)
+            if packed is None or packed.numel() != 2 * c + 1:  # statistics that did not come from a conv epilogue (tests)
+                packed = torch.cat([stats.reshape(-1).float(), stats.new_zeros(1, dtype=torch.float32)])
+            packed[2 * c :].fill_(float(m))  # an asynchronous fill: no synchronising constant upload per batch shape
             dist.all_reduce(packed)
             stats, count_dev = packed[: 2 * c].view(2, c), packed[2 * c :]
         mean = torch.empty(c, dtype=torch.float32, device=y.device)
