@@ -83,7 +83,10 @@ constexpr int TN = 128, WSLOT = TN * 64; // output channels of a tile / one (sla
 constexpr int WBASE = 2 * HBUF;
 constexpr int LDS_BYTES = WBASE + WR * WSLOT;  // 155648
 
-template <int PH, int PWD>
+// OPT bit 0: no s_setprio around the MFMA runs, bit 1: no sched_barrier fences between the MFMA runs and the LDS reads / staging.
+// Measured (profiles/r03_conv_halo_sched.txt): without both the kernel is 4 % faster (fpn_output2 1208 -> 1260 TFLOP/s), either
+// one alone +2 % / -1 %: the default is 3; variant bits 29-30 select OPT ^ 3 (so 0 there = the default).
+template <int PH, int PWD, int OPT = 3>
 __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
   constexpr int HPITCH = PWD + 4;
   constexpr int FPR = PWD / 16;       // 16-pixel fragments per patch row
@@ -315,10 +318,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
   {                                                                                                                      \
     const int nslot = (slot + 1 == WR) ? 0 : slot + 1;                                                                   \
     const int sslot = (slot == 0) ? WR - 1 : slot - 1; /* slot of step g + WA = g - 1 (mod WR) */                        \
-    __builtin_amdgcn_s_setprio(1);                                                                                       \
+    if constexpr (!(OPT & 1)) __builtin_amdgcn_s_setprio(1);                                                                                       \
     U2_H_MFMA(0, wfA[0], 0); U2_H_MFMA(1, wfA[1], 0); U2_H_MFMA(0, wfA[0], 1); U2_H_MFMA(1, wfA[1], 1);                  \
-    __builtin_amdgcn_s_setprio(0);                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    if constexpr (!(OPT & 1)) __builtin_amdgcn_s_setprio(0);                                                                                       \
+    if constexpr (!(OPT & 2)) __builtin_amdgcn_sched_barrier(0);                                                                                   \
     pf[4] = U2_H_LDP(T, 4); pf[5] = U2_H_LDP(T, 5); pf[6] = U2_H_LDP(T, 6); pf[7] = U2_H_LDP(T, 7);                      \
     wfB[0] = ldw(slot, 2); wfB[1] = ldw(slot, 3);                                                                        \
     if ((T) < HPIECES && slab_g + 1 < total_slabs) {                                                                     \
@@ -326,19 +329,19 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
       stage_halo_piece((T) < HPIECES ? (T) : 0, (slab_g + 1) & 1);                                                       \
     }                                                                                                                    \
     if (g + WA < G) stage_weights(sslot);                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                                   \
-    __builtin_amdgcn_s_setprio(1);                                                                                       \
+    if constexpr (!(OPT & 2)) __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    if constexpr (!(OPT & 1)) __builtin_amdgcn_s_setprio(1);                                                                                       \
     U2_H_MFMA(0, wfA[0], 2); U2_H_MFMA(1, wfA[1], 2); U2_H_MFMA(0, wfA[0], 3); U2_H_MFMA(1, wfA[1], 3);                  \
     _Pragma("unroll") for (int j = 4; j < 8; ++j) { U2_H_MFMA(0, wfA[0], j); U2_H_MFMA(1, wfA[1], j); }                  \
-    __builtin_amdgcn_s_setprio(0);                                                                                       \
+    if constexpr (!(OPT & 1)) __builtin_amdgcn_s_setprio(0);                                                                                       \
     if (tail) wait_vm<0>(); else wait_vm<VMCNT>();                                                                       \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
     __builtin_amdgcn_s_barrier();                                                                                        \
     asm volatile("" ::: "memory");                                                                                       \
-    __builtin_amdgcn_s_setprio(1);                                                                                       \
+    if constexpr (!(OPT & 1)) __builtin_amdgcn_s_setprio(1);                                                                                       \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) { U2_H_MFMA(2, wfB[0], j); U2_H_MFMA(3, wfB[1], j); }                  \
-    __builtin_amdgcn_s_setprio(0);                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    if constexpr (!(OPT & 1)) __builtin_amdgcn_s_setprio(0);                                                                                       \
+    if constexpr (!(OPT & 2)) __builtin_amdgcn_sched_barrier(0);                                                                                   \
     if ((T) == 8) { /* the next step reads the other halo buffer */                                                      \
       const int hd = (slab_g & 1) ? -HBUF : HBUF;                                                                        \
       pbase[0] += hd; pbase[1] += hd; pbase[2] += hd;                                                                    \
@@ -348,10 +351,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
       pf[0] = U2_H_LDP(((T) + 1) % 9, 0); pf[1] = U2_H_LDP(((T) + 1) % 9, 1);                                            \
       pf[2] = U2_H_LDP(((T) + 1) % 9, 2); pf[3] = U2_H_LDP(((T) + 1) % 9, 3);                                            \
     }                                                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                                   \
-    __builtin_amdgcn_s_setprio(1);                                                                                       \
+    if constexpr (!(OPT & 2)) __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    if constexpr (!(OPT & 1)) __builtin_amdgcn_s_setprio(1);                                                                                       \
     _Pragma("unroll") for (int j = 4; j < 8; ++j) { U2_H_MFMA(2, wfB[0], j); U2_H_MFMA(3, wfB[1], j); }                  \
-    __builtin_amdgcn_s_setprio(0);                                                                                       \
+    if constexpr (!(OPT & 1)) __builtin_amdgcn_s_setprio(0);                                                                                       \
     ++g;                                                                                                                 \
     slot = nslot;                                                                                                        \
   }
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
 #undef U2_H_MFMA
 }
 
-template <int PH, int PWD>
+template <int PH, int PWD, int OPT = 3>
 int launch_halo_cfg(ConvArgs& a, int N, int tiny, hipStream_t s) {
   const long long patches = (long long)a.B * ((a.Hout + PH - 1) / PH) * ((a.Wout + PWD - 1) / PWD);
   a.tiles_m = (int)patches;
@@ -393,10 +396,10 @@ int launch_halo_cfg(ConvArgs& a, int N, int tiny, hipStream_t s) {
   G = (G + 7) & ~7LL;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_halo_kernel<PH, PWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_halo_kernel<PH, PWD, OPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_halo_kernel<PH, PWD>), dim3((unsigned)G), dim3(512), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((conv_halo_kernel<PH, PWD, OPT>), dim3((unsigned)G), dim3(512), LDS_BYTES, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return -1000 - (int)e;
   return 1;
@@ -434,7 +437,12 @@ int launch_conv_halo(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   const int tiny = (variant >> 16) & 1;
   a.abl = (variant >> 18) & 63;
   g_last_conv_kernel = 300;
-  return launch_halo_cfg<16, 32>(a, N, tiny, s);
+  switch ((variant >> 29) & 3) {
+    case 1: return launch_halo_cfg<16, 32, 2>(a, N, tiny, s);
+    case 2: return launch_halo_cfg<16, 32, 1>(a, N, tiny, s);
+    case 3: return launch_halo_cfg<16, 32, 0>(a, N, tiny, s);
+    default: return launch_halo_cfg<16, 32, 3>(a, N, tiny, s);
+  }
 }
 
 }  // namespace u2conv
