@@ -114,6 +114,12 @@ int u2_relu_bwd(const void* dout, const void* out, void* dz, long long numel, vo
  * outputs feed the RPN head, the ROI poolers and the semantic head: meta_arch/panoptic_fpn.py:105-131). */
 int u2_add_n(const void* a, const void* b, const void* c, const void* d, void* out, long long numel, void* stream);
 
+/* The kernel-layout weight gradient of a multi-tap convolution, scratch fp32 [Npad][T][Cp] (u2_conv_wgrad), accumulated into the
+ * parameter's own gradient storage fp32 [N][Cin][T] (= [Cout, Cin, kh, kw], the optimizer arena): grad[n][c][t] += scratch[n][t][c]
+ * for n < N, c < Cin.  Replaces the strided `grad.add_(scratch.view(...).permute(0, 3, 1, 2))` of autograd's AccumulateGrad
+ * (engine/train_loop.py:479-521 leaves that accumulation to torch). */
+int u2_wgrad_permute_add(const float* scratch, float* grad, int N, int Cin, int T, int Cp, void* stream);
+
 /* ---- pooling / resampling (pool_resize.hip) ----------------------------------------------------
  * backbone/resnet.py:358 (max_pool2d 3x3 s2 p1), backbone/fpn.py:153-155 (nearest x2 + add),
  * meta_arch/semantic_seg.py:206-211 (bilinear x2), meta_arch/rcnn.py:223-234 (normalise + pad) feeding the stem. */

@@ -873,3 +873,31 @@ extern "C" int u2_gn_finalize_bwd(const float* sums, const float* gamma, const f
   U2_CHECK_LAUNCH();
   return 0;
 }
+
+// grad[n][c][t] += scratch[n][t][c]: one work-group per output channel n; the [T][Cp] slab goes through LDS so that both the
+// read (c fastest) and the read-modify-write of the [Cin][T] row (t fastest) are contiguous
+namespace {
+__global__ __launch_bounds__(256) void wgrad_permute_add_kernel(const float* __restrict__ scratch, float* __restrict__ grad, int Cin,
+                                                                 int T, int Cp) {
+  extern __shared__ float slab[];  // [T][Cp + 1]
+  const int n = blockIdx.x;
+  const float* src = scratch + (size_t)n * T * Cp;
+  const int pitch = Cp + 1;
+  for (int i = threadIdx.x; i < T * Cp; i += 256) slab[(i / Cp) * pitch + (i % Cp)] = src[i];
+  __syncthreads();
+  float* dst = grad + (size_t)n * Cin * T;
+  for (int i = threadIdx.x; i < Cin * T; i += 256) {
+    const int c = i / T, t = i - c * T;
+    dst[i] += slab[t * pitch + c];
+  }
+}
+}  // namespace
+
+extern "C" int u2_wgrad_permute_add(const float* scratch, float* grad, int N, int Cin, int T, int Cp, void* stream) {
+  if (N <= 0 || Cin <= 0 || T <= 0 || Cin > Cp) return -1;
+  const size_t lds = (size_t)T * (Cp + 1) * sizeof(float);
+  if (lds > 64 * 1024) return -2;  // 49 taps x 256 channels and beyond: the caller keeps the torch path
+  hipLaunchKernelGGL(wgrad_permute_add_kernel, dim3(N), dim3(256), lds, (hipStream_t)stream, scratch, grad, Cin, T, Cp);
+  U2_CHECK_LAUNCH();
+  return 0;
+}

@@ -339,9 +339,14 @@ class _Conv2dFn(Function):
             elif arena is not None and _WGRAD_SIDE:
                 # multi-tap filters: kernel-layout scratch, then permuted into the arena slice - all of it on the side stream
                 def launch():
-                    dwk = torch.zeros((npad, kh * kw, cp), dtype=torch.float32, device=x.device)
+                    # scratch from the (per-stream) zero pool, accumulated into the arena by one transposing kernel: the
+                    # strided torch add took 70-170 us per 3x3 layer, 1.3 ms per step
+                    dwk = zeros_f32((npad, kh * kw, cp), x.device)
                     _hip.call("u2_conv_wgrad", x, dz, dwk, b, h, w_, cp, cp, ho, wo, npad, npad, kh, kw, pad, pad, stride, 0)
-                    arena.add_(dwk[:n, :, :cin].view(n, kh, kw, cin).permute(0, 3, 1, 2))
+                    if kh * kw * (cp + 1) * 4 <= 64 * 1024 and arena.is_contiguous():
+                        _hip.call("u2_wgrad_permute_add", dwk, arena, n, cin, kh * kw, cp)
+                    else:
+                        arena.add_(dwk[:n, :, :cin].view(n, kh, kw, cin).permute(0, 3, 1, 2))
 
                 _run_wgrad(x.device, (x, dz), launch)
             else:
