@@ -182,8 +182,8 @@ def cpu_baseline(workload):
 
 
 def _pmc_traffic(kernel_key):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (profiles/r02_pmc_traffic.json, else r01)."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/rNN_pmc_traffic.json)."""
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             pj = json.load(open(path))
@@ -213,8 +213,8 @@ def conv_roofline(timer, sampled, steps, imgs_per_s_per_gpu=None):
         ms = sum(r[2].elapsed_time(r[3]) for r in rs)
         return sum(r[5] for r in rs) / (ms * 1e-3) / 1e12 if rs and ms > 0 else None
 
-    out = {"kernel": {"u2_conv_igemm": "implicit-GEMM conv, forward + data-gradient launches (conv_tile_kernel / conv_igemm_kernel "
-                                       "/ conv_igemm256_kernel: all tile configurations)",
+    out = {"kernel": {"u2_conv_igemm": "implicit-GEMM conv, forward + data-gradient launches (conv_halo_kernel / conv_tile_kernel incl. "
+                                       "its stream-K form / conv_igemm_kernel: every kernel behind u2_conv_igemm)",
                       "u2_conv_wgrad": "conv_wgrad_kernel", "u2_conv_wgrad_into": "conv_wgrad_kernel"}[name],
            "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
            "traffic": traffic, "traffic_note": note,

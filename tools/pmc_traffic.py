@@ -28,7 +28,7 @@ def per_kernel(d, counter):
 def family(name):
     if "conv_wgrad" in name:
         return "conv_wgrad"
-    if "conv_tile_kernel" in name or "conv_igemm" in name:
+    if "conv_tile_kernel" in name or "conv_igemm" in name or "conv_halo_kernel" in name:
         return "conv_igemm"
     return None
 
