@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
     f32x2_t s2[8], ss2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s2[e] = f32x2_t{0.f, 0.f}; ss2[e] = f32x2_t{0.f, 0.f}; }
-    const bool nt_out = (size_t)a.M * a.out_ld * 2 > ((size_t)160 << 20) && !(a.abl & 8);
+    const bool nt_out = (size_t)a.M * a.out_ld * 2 > ((size_t)160 << 20) && (a.abl & 8);
     const bool do_stats = a.stats && !(a.abl & 2);
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 #pragma unroll

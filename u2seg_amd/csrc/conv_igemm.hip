@@ -248,7 +248,7 @@ __global__ __launch_bounds__((TM / 64) * (TN / 64) * 64, 2) void conv_igemm_kern
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
   const bool vec_ok = ((a.out_ld & 7) == 0) && (n0 + cchunk * 8 + 8 <= a.N);
-  const bool nt_out = !a.accumulate && (size_t)a.M * a.out_ld * 2 > ((size_t)160 << 20);
+  const bool nt_out = !a.accumulate && (size_t)a.M * a.out_ld * 2 > ((size_t)160 << 20) && (a.abl & 8);
 #pragma unroll
   for (int it = 0; it < TM / RPI; ++it) {
     const int row = it * RPI + rbase;
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(C256_THREADS, 2) void conv_igemm256_kernel(const Co
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
   const bool vec_ok = ((a.out_ld & 7) == 0) && (n0 + cchunk * 8 + 8 <= a.N);
-  const bool nt_out = !a.accumulate && (size_t)a.M * a.out_ld * 2 > ((size_t)160 << 20);
+  const bool nt_out = !a.accumulate && (size_t)a.M * a.out_ld * 2 > ((size_t)160 << 20) && (a.abl & 8);
   for (int it = 0; it < 16; ++it) {
     const int row = it * 16 + rbase;
     const int m = m0 + row;
@@ -1128,6 +1128,7 @@ int env_variant(const char* name, int variant) {
 
 int launch_conv(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   variant = env_variant("U2_CONV_VARIANT", variant);
+  a.abl = (variant >> 18) & 63;  // measurement switches (conv_args.h); bit 3 = `nt` output stores, applies to every kernel below
   {  // 3x3 / stride 1 / pad 1 layers on large maps: halo-staged kernel (conv_halo.hip)
     const int rc = launch_conv_halo(a, N, C, variant, s);
     if (rc == 1) return 0;

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     float s[16], ss[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { s[e] = 0.f; ss[e] = 0.f; }
-    const bool nt_out = (size_t)a.M * a.out_ld * 2 > ((size_t)160 << 20);
+    const bool nt_out = (size_t)a.M * a.out_ld * 2 > ((size_t)160 << 20) && (a.abl & 8);
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
     u32x4_t olda[4], oldb[4];  // ACC: the values under rows j & 3 of the current batch of four rows
 #pragma unroll
