@@ -207,6 +207,29 @@ int u2_topk_rows(const void* vals, int dtype, int rows, int n, long long row_str
                  const signed char* mask, int mask_value, int k, int largest, float* out_vals, int* out_idx,
                  int* out_cnt, const int* idx_in, void* stream);
 
+/* Several selections in one launch (up to 8 segments; a work-group per row of every segment): the per-level pre-NMS top-k of
+ * proposal_utils.py:79-96 over all feature levels at once, or the positive and the negative draw of sampling.py:38-54 over the
+ * same keys.  Fields as the arguments of u2_topk_rows, plus:
+ *   cnt_in / cnt_group: element i takes part iff i % cnt_group < cnt_in[row * (n / cnt_group) + i / cnt_group] - the rows of a
+ *     first selection (k entries each, cnt real ones) concatenated as the input of a merging second selection;
+ *   idx_mod / idx_mul: the reported index is the element's index + (row % idx_mod) * idx_mul - rows that are equal segments of a
+ *     longer row report positions in that row (idx_mod = 1, idx_mul = 0: none);
+ *   dtype 2: fp32 storage of bf16-representable values (the fp32 out_vals of a first selection over a bf16 map): ranked on the
+ *     upper 16 bits only. */
+typedef struct U2TopkSeg {
+  const void* vals;
+  const signed char* mask;
+  const int* idx_in;
+  const int* cnt_in;
+  float* out_vals;
+  int* out_idx;
+  int* out_cnt;
+  long long row_stride;
+  int dtype, rows, n, group, pitch, mask_value, k, largest;
+  int cnt_group, idx_mod, idx_mul, reserved;
+} U2TopkSeg;
+int u2_topk_rows_multi(const U2TopkSeg* segs, int nseg, void* stream);
+
 /* ---- inference tails (postprocess.hip) -------------------------------------------------------
  * layers/mask_ops.py:17-147 (paste_masks_in_image, GPU branch), meta_arch/panoptic_fpn.py:184-269. */
 /* meta_arch/semantic_seg.py:240-244 + panoptic_fpn.py:173 at inference: logits [B][H][W][Cp] NHWC bf16 (K valid channels) ->

@@ -123,6 +123,26 @@ def test_topk_rows_total_order(F):
     t = torch.tensor([[1.0, -2.0, 1.0, float("inf"), 0.5]])
     v, i, c = F.topk_rows(t.to(DEV), 5, largest=True)
     assert i.cpu().tolist() == [[3, 0, 2, 4, 1]] and int(c) == 5
+    # (5) several selections in one pair of launches (u2_topk_rows_multi): two levels long enough to be cut into segments and
+    # merged, a short one, and two masked draws over the same keys - every result as if it had been asked for alone
+    maps = []
+    for hw_l in (200 * 336, 100 * 168, 13 * 21):
+        mm = (torch.randn((b, hw_l, 32), generator=g) * 2).mul(4).round().div(4).bfloat16()
+        maps.append(mm)
+    specs = [dict(vals=mm.to(DEV), k=min(mm.shape[1] * a, 2000), largest=True, group=a, pitch=32, n=mm.shape[1] * a) for mm in maps]
+    n = 268569
+    keys = torch.rand((2, n), generator=g)
+    labels = torch.randint(-1, 2, (2, n), generator=g).to(torch.int8)
+    specs += [dict(vals=keys.to(DEV), k=128, largest=False, mask=labels.to(DEV), mask_value=1, want_vals=False),
+              dict(vals=keys.to(DEV), k=256, largest=False, mask=labels.to(DEV), mask_value=0)]
+    res = F.topk_rows_multi(specs)
+    for mm, (v, i, c) in zip(maps, res[:3]):
+        rv, ri, rc = _stable_rank(mm[..., :a].reshape(b, -1), min(mm.shape[1] * a, 2000), True)
+        assert torch.equal(i.cpu().long(), ri) and torch.equal(c.cpu().long(), rc) and torch.equal(v.cpu(), rv)
+    for (v, i, c), (val, k) in zip(res[3:], ((1, 128), (0, 256))):
+        rv, ri, rc = _stable_rank(keys, k, False, labels == val)
+        assert torch.equal(c.cpu().long(), rc) and torch.equal(i.cpu().long(), ri)
+        assert v is None or torch.equal(v.cpu(), rv)
 
 
 def _gt(batch):

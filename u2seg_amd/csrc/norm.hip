@@ -31,6 +31,18 @@ __device__ __forceinline__ void st_stream(bf16_t* p, uint4 v, bool nt) {
 }
 constexpr size_t NT_BYTES = 160u << 20;
 
+// Traversal order of the streaming passes (experiment knob, default off).  In isolation a pass that walks a 192-512 MiB tensor
+// in the direction its producer wrote it runs 10-45 % slower than one that walks it back to front (tests/native/mall_bench:
+// the producer's dirty lines are on their way out of the 256 MiB Infinity Cache).  In the training step the reversed passes
+// measured no gain (serial step 74.4-75.6 ms either way, overlapped step 71.2 -> 71.8 ms: profiles/r03_stream_order.txt) -
+// the large tensors are already streamed with the nt hint.  U2_STREAM_ORDER: bit 0 forward apply passes, bit 1 backward
+// reductions, bit 2 backward apply passes run back to front.
+static int stream_order() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("U2_STREAM_ORDER"); v = e ? atoi(e) & 7 : 0; }
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Column reductions over an [M][C] bf16 matrix, optionally split into `slots` equal row ranges
 // (slot = image for GroupNorm).  out[slot][q][C], q = quantity index.
@@ -51,12 +63,12 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
                                                         int rows_per_slot, int C, int ld, int rows_per_block,
                                                         const float* __restrict__ msc, const float* __restrict__ msh,
                                                         const bf16_t* __restrict__ dout2, bf16_t* __restrict__ dz_out,
-                                                        const bf16_t* __restrict__ dout3) {
+                                                        const bf16_t* __restrict__ dout3, int rev) {
   __shared__ float part[2][2048];
   constexpr int U = 2;  // rows in flight per thread
   const int cpr = C >> 3;
   const int slot = blockIdx.y;
-  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_begin = (rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rows_per_block;
   const int r_end = min(rows_per_slot, r_begin + rows_per_block);
   const size_t row0 = (size_t)slot * rows_per_slot;
   const int tid = threadIdx.x;
@@ -267,7 +279,7 @@ template <bool RESID, bool RELU>
 __global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const bf16_t* __restrict__ resid,
                                                               bf16_t* __restrict__ out, int rows_per_slot, int C, int ld,
-                                                              unsigned char* __restrict__ relu_bits) {
+                                                              unsigned char* __restrict__ relu_bits, int rev) {
   const int cpr = C >> 3;
   const int rows_par = 256 / cpr;
   const int cc = threadIdx.x % cpr, rl = threadIdx.x / cpr;
@@ -282,8 +294,9 @@ __global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __re
     uint4 xq[EW_UNROLL], rq[EW_UNROLL];
 #pragma unroll
     for (int u = 0; u < EW_UNROLL; ++u) {
-      const int r = r0 + u * stride;
+      int r = r0 + u * stride;
       if (r < rows_per_slot) {
+        if (rev) r = rows_per_slot - 1 - r;
         const size_t off = (base + r) * ld + cc * 8;
         xq[u] = ld_stream(x + off, nt);
         if (RESID) rq[u] = ld_stream(resid + off, nt);
@@ -291,8 +304,9 @@ __global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __re
     }
 #pragma unroll
     for (int u = 0; u < EW_UNROLL; ++u) {
-      const int r = r0 + u * stride;
+      int r = r0 + u * stride;
       if (r < rows_per_slot) {
+        if (rev) r = rows_per_slot - 1 - r;
         const bf16_t* xv = reinterpret_cast<const bf16_t*>(&xq[u]);
         const bf16_t* rv = reinterpret_cast<const bf16_t*>(&rq[u]);
         bf16_t ov[8];
@@ -398,7 +412,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_fast_kernel(const bf16_t* 
                                                                   const float* __restrict__ k2, const float* __restrict__ k3,
                                                                   bf16_t* __restrict__ dx, bf16_t* __restrict__ dres,
                                                                   int rows_per_slot, int C, int ld,
-                                                                  const float* __restrict__ msc, const float* __restrict__ msh) {
+                                                                  const float* __restrict__ msc, const float* __restrict__ msh, int rev) {
   const int cpr = C >> 3;
   const int rows_par = 256 / cpr;
   const int cc = threadIdx.x % cpr, rl = threadIdx.x / cpr;
@@ -418,8 +432,9 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_fast_kernel(const bf16_t* 
     uint4 dq[EW_UNROLL], xq[EW_UNROLL], mq[EW_UNROLL];
 #pragma unroll
     for (int u = 0; u < EW_UNROLL; ++u) {
-      const int r = r0 + u * stride;
+      int r = r0 + u * stride;
       if (r < rows_per_slot) {
+        if (rev) r = rows_per_slot - 1 - r;
         const size_t off = (base + r) * ld + cc * 8;
         dq[u] = ld_stream(dout + off, nt);
         xq[u] = ld_stream(x + off, nt);
@@ -428,8 +443,9 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_fast_kernel(const bf16_t* 
     }
 #pragma unroll
     for (int u = 0; u < EW_UNROLL; ++u) {
-      const int r = r0 + u * stride;
+      int r = r0 + u * stride;
       if (r < rows_per_slot) {
+        if (rev) r = rows_per_slot - 1 - r;
         const bf16_t* dv = reinterpret_cast<const bf16_t*>(&dq[u]);
         const bf16_t* xv = reinterpret_cast<const bf16_t*>(&xq[u]);
         const bf16_t* mv = reinterpret_cast<const bf16_t*>(&mq[u]);
@@ -718,7 +734,7 @@ extern "C" int u2_colstats(const void* x, float* out, int slots, int rows_per_sl
   if (rpb < 64) rpb = 64;
   const dim3 grid((rows_per_slot + rpb - 1) / rpb, slots);
   hipLaunchKernelGGL((colreduce_kernel<0, 0, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, nullptr,
-                     nullptr, nullptr, nullptr, out, rows_per_slot, C, ld, rpb, nullptr, nullptr, nullptr, nullptr, nullptr);
+                     nullptr, nullptr, nullptr, out, rows_per_slot, C, ld, rpb, nullptr, nullptr, nullptr, nullptr, nullptr, stream_order() & 1);
   U2_CHECK_LAUNCH();
   return 0;
 }
@@ -738,7 +754,7 @@ extern "C" int u2_norm_bwd_reduce(const void* dout, const void* mask, const void
 #define U2_REDUCE(MM_, DZ_)                                                                                          \
   hipLaunchKernelGGL((colreduce_kernel<1, MM_, DZ_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,      \
                      (const bf16_t*)dout, (const bf16_t*)mask, mean, invstd, out, rows_per_slot, C, ld, rpb, mask_scale, \
-                     mask_shift, (const bf16_t*)dout2, (bf16_t*)dz_out, (const bf16_t*)dout3)
+                     mask_shift, (const bf16_t*)dout2, (bf16_t*)dz_out, (const bf16_t*)dout3, (stream_order() >> 1) & 1)
   if (dz_out) { if (!relu) U2_REDUCE(0, true); else if (mask_is_bits) U2_REDUCE(3, true); else if (mask_scale) U2_REDUCE(2, true); else U2_REDUCE(1, true); }
   else { if (!relu) U2_REDUCE(0, false); else if (mask_scale) U2_REDUCE(2, false); else U2_REDUCE(1, false); }
 #undef U2_REDUCE
@@ -756,7 +772,7 @@ extern "C" int u2_affine_act(const void* x, const float* scale, const float* shi
 #define U2_AFFINE(RS_, RL_)                                                                                          \
   hipLaunchKernelGGL((affine_act_fast_kernel<RS_, RL_>), fast_grid(slots, rows_per_slot, C), dim3(256), 0, (hipStream_t)stream, \
                      (const bf16_t*)x, scale, shift, (const bf16_t*)resid, (bf16_t*)out, rows_per_slot, C, ld,                 \
-                     (unsigned char*)relu_bits)
+                     (unsigned char*)relu_bits, stream_order() & 1)
     if (resid) { if (relu) U2_AFFINE(true, true); else U2_AFFINE(true, false); }
     else { if (relu) U2_AFFINE(false, true); else U2_AFFINE(false, false); }
 #undef U2_AFFINE
@@ -801,7 +817,7 @@ extern "C" int u2_norm_bwd_apply(const void* dout, const void* mask, const void*
 #define U2_APPLY(MM_, DR_)                                                                                           \
   hipLaunchKernelGGL((norm_bwd_apply_fast_kernel<MM_, DR_>), fast_grid(slots, rows_per_slot, C), dim3(256), 0,            \
                      (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)mask, (const bf16_t*)x, k1, k2, k3, (bf16_t*)dx, \
-                     (bf16_t*)dres, rows_per_slot, C, ld, mask_scale, mask_shift)
+                     (bf16_t*)dres, rows_per_slot, C, ld, mask_scale, mask_shift, (stream_order() >> 2) & 1)
     if (dres) { if (mm == 0) U2_APPLY(0, true); else if (mm == 1) U2_APPLY(1, true); else U2_APPLY(2, true); }
     else { if (mm == 0) U2_APPLY(0, false); else if (mm == 1) U2_APPLY(1, false); else U2_APPLY(2, false); }
 #undef U2_APPLY

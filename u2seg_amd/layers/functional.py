@@ -8,6 +8,7 @@ layout (``[Cout][kh*kw][Cin]`` bf16) on the fly.
 
 Every function here launches HIP kernels; none has a CPU or ATen compute fallback.
 """
+import ctypes
 import math
 
 import os
@@ -1085,56 +1086,94 @@ def sem_seg_upsample(x, num_classes, scale):
     return out, amax
 
 
+class _TopkSeg(ctypes.Structure):
+    """U2TopkSeg of include/u2seg_hip.h."""
+    _fields_ = ([(f, ctypes.c_void_p) for f in ("vals", "mask", "idx_in", "cnt_in", "out_vals", "out_idx", "out_cnt")]
+                + [("row_stride", ctypes.c_longlong)]
+                + [(f, ctypes.c_int) for f in ("dtype", "rows", "n", "group", "pitch", "mask_value", "k", "largest", "cnt_group",
+                                               "idx_mod", "idx_mul", "reserved")])
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
 def topk_rows(vals, k, largest=True, mask=None, mask_value=1, group=1, pitch=1, n=None, want_vals=True):
     """Row-wise selection with a total order (u2_topk_rows): the k best of every row ranked by (value descending if
     `largest` else ascending, index ascending).  vals: [rows, n] fp32 / bf16 contiguous, or - with group / pitch / n - the
     `group` valid columns of a [rows, n // group, pitch]-shaped map (element i at (i // group) * pitch + i % group).
     mask (int8 [rows, n]): only elements equal to mask_value take part.
     Returns (values fp32 [rows, k] or None, indices int32 [rows, k], counts int32 [rows])."""
-    assert vals.is_cuda and vals.dtype in (torch.float32, BF16) and vals.is_contiguous()
-    rows = vals.shape[0]
-    if n is None:
-        assert vals.dim() == 2
-        n = vals.shape[1]
-    row_stride = vals[0].numel()
-    if mask is not None:
-        assert mask.dtype == torch.int8 and mask.is_contiguous() and tuple(mask.shape) == (rows, n)
-    segs = _topk_segments(rows, n, group, pitch, row_stride, k)
-    if segs > 1:
-        # A row is streamed by ONE work-group (five to seven dependent sweeps): long rows are cut into `segs` equal segments that
-        # are ranked as rows of their own, and the survivors (k per segment, with their original indices) are ranked again.
-        seg_n = n // segs
-        k1 = min(k, seg_n)
-        v1, i1, c1 = _topk_launch(vals, rows * segs, seg_n, row_stride // segs, group, pitch,
-                                  mask.view(rows * segs, seg_n) if mask is not None else None, mask_value, k1, largest, True, None)
-        i1 += (torch.arange(rows * segs, device=vals.device, dtype=torch.int32) % segs * seg_n)[:, None]
-        live = (torch.arange(k1, device=vals.device, dtype=torch.int32)[None, :] < c1[:, None]).to(torch.int8)
-        return _topk_launch(v1.view(rows, segs * k1), rows, segs * k1, segs * k1, 1, 1, live.view(rows, segs * k1), 1, k, largest,
-                            want_vals, i1.view(rows, segs * k1))
-    return _topk_launch(vals, rows, n, row_stride, group, pitch, mask, mask_value, k, largest, want_vals, None)
+    return topk_rows_multi([dict(vals=vals, k=k, largest=largest, mask=mask, mask_value=mask_value, group=group, pitch=pitch, n=n,
+                                 want_vals=want_vals)])[0]
+
+
+def topk_rows_multi(specs):
+    """Several independent selections (each a dict of topk_rows' arguments) in two launches of u2_topk_rows_multi instead of
+    one or two per selection: the per-level pre-NMS top-k of all feature levels, or the two draws of a sampler over the same keys.
+    A row is streamed by ONE work-group (five to seven dependent sweeps): long rows are cut into equal segments that are ranked
+    as rows of their own in the first launch (reporting positions in the full row), and the survivors (k per segment, the real
+    ones counted) are ranked again in the second.  Returns a list of (values or None, indices, counts)."""
+    first, second, results = [], [], [None] * len(specs)
+    keep = []  # the intermediate tensors are referenced by raw pointers only: they must outlive the launches below
+    for j, sp in enumerate(specs):
+        vals, k, largest = sp["vals"], int(sp["k"]), int(bool(sp.get("largest", True)))
+        mask, mask_value = sp.get("mask"), int(sp.get("mask_value", 1))
+        group, pitch, n, want_vals = int(sp.get("group", 1)), int(sp.get("pitch", 1)), sp.get("n"), sp.get("want_vals", True)
+        assert vals.is_cuda and vals.dtype in (torch.float32, BF16) and vals.is_contiguous()
+        dev, rows = vals.device, vals.shape[0]
+        if n is None:
+            assert vals.dim() == 2
+            n = vals.shape[1]
+        row_stride = vals[0].numel()
+        if mask is not None:
+            assert mask.dtype == torch.int8 and mask.is_contiguous() and tuple(mask.shape) == (rows, n)
+        idx = torch.empty((rows, k), dtype=torch.int32, device=dev)
+        out = torch.empty((rows, k), dtype=torch.float32, device=dev) if want_vals else None
+        cnt = torch.empty((rows,), dtype=torch.int32, device=dev)
+        results[j] = (out, idx, cnt)
+        dtype = 1 if vals.dtype == BF16 else 0
+        segs = _topk_segments(rows, n, group, pitch, row_stride, k)
+        if segs > 1:
+            seg_n = n // segs
+            k1 = min(k, seg_n)
+            v1 = torch.empty((rows * segs, k1), dtype=torch.float32, device=dev)
+            i1 = torch.empty((rows * segs, k1), dtype=torch.int32, device=dev)
+            c1 = torch.empty((rows * segs,), dtype=torch.int32, device=dev)
+            keep.append((v1, i1, c1))
+            first.append(_TopkSeg(_ptr(vals), _ptr(mask), None, None, _ptr(v1), _ptr(i1), _ptr(c1), row_stride // segs, dtype,
+                                  rows * segs, seg_n, group, pitch, mask_value, k1, largest, 1, segs, seg_n, 0))
+            # dtype 2: fp32 storage of bf16 values (the survivors of a bf16 map) - two digit sweeps instead of four
+            second.append(_TopkSeg(_ptr(v1), None, _ptr(i1), _ptr(c1), _ptr(out), _ptr(idx), _ptr(cnt), segs * k1, 2 * dtype, rows,
+                                   segs * k1, 1, 1, 0, k, largest, k1, 1, 0, 0))
+        else:
+            first.append(_TopkSeg(_ptr(vals), _ptr(mask), None, None, _ptr(out), _ptr(idx), _ptr(cnt), row_stride, dtype, rows, n,
+                                  group, pitch, mask_value, k, largest, 1, 1, 0, 0))
+    for batch in (first, second):
+        batch.sort(key=lambda g: -g.n)  # the longest rows start first
+        for at in range(0, len(batch), 8):
+            part = batch[at:at + 8]
+            _hip.call("u2_topk_rows_multi", (_TopkSeg * len(part))(*part), len(part))
+    del keep
+    return results
 
 
 def _topk_segments(rows, n, group, pitch, row_stride, k):
     """How many equal segments to cut the rows of a selection into (1 = none): only long rows that few work-groups would
-    stream, a divisor of the group count (segments must tile the row exactly), segments still several times longer than k."""
+    stream, a divisor of the group count (segments must tile the row exactly), segments still several times longer than k.
+    The first launch streams n / s elements per work-group, the merging second one s * k (at about twice the cost per element:
+    fp32 keys, carried indices): s is the admissible divisor nearest to sqrt(n / 2k)."""
     if n < 32768 or rows >= 128 or n % group or row_stride != (n // group) * pitch:
         return 1
     groups = n // group
-    best = 1
+    target = math.sqrt(n / (2.0 * k))
+    best, best_d = 1, None
     for s in range(2, 33):
         if groups % s == 0 and n // s >= max(4096, 2 * k) and rows * s <= 256:
-            best = s
+            d = abs(math.log(s / target))
+            if best_d is None or d < best_d:
+                best, best_d = s, d
     return best
-
-
-def _topk_launch(vals, rows, n, row_stride, group, pitch, mask, mask_value, k, largest, want_vals, idx_in):
-    dev = vals.device
-    idx = torch.empty((rows, k), dtype=torch.int32, device=dev)
-    out = torch.empty((rows, k), dtype=torch.float32, device=dev) if want_vals else None
-    cnt = torch.empty((rows,), dtype=torch.int32, device=dev)
-    _hip.call("u2_topk_rows", vals, 1 if vals.dtype == BF16 else 0, rows, n, row_stride, group, pitch, mask, int(mask_value),
-              k, int(largest), out, idx, cnt, idx_in)
-    return out, idx, cnt
 
 
 def apply_deltas(src, deltas, weights, img_idx=None, sizes=None, clamp=math.log(1000.0 / 16)):

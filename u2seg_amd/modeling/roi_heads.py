@@ -410,8 +410,9 @@ class ROIHeads(nn.Module):
         kind = (is_fg.to(torch.int8) + is_bg.to(torch.int8) * 2).contiguous()  # 1 foreground, 2 background, 0 not sampled
         kf, kb = min(max_fg, n), min(total, n)
         # the smallest keys first, ties by row index: positive[argsort(key[positive])] of sampling.py:38-54
-        _, fg_idx, fg_cnt = F.topk_rows(key, kf, largest=False, mask=kind, mask_value=1, want_vals=False)
-        _, bg_idx, bg_cnt = F.topk_rows(key, kb, largest=False, mask=kind, mask_value=2, want_vals=False)
+        (_, fg_idx, fg_cnt), (_, bg_idx, bg_cnt) = F.topk_rows_multi([
+            dict(vals=key, k=kf, largest=False, mask=kind, mask_value=1, want_vals=False),
+            dict(vals=key, k=kb, largest=False, mask=kind, mask_value=2, want_vals=False)])
         num_bg = torch.minimum(bg_cnt, total - fg_cnt)
         fg_valid = torch.arange(kf, device=dev)[None] < fg_cnt[:, None]
         bg_valid = torch.arange(kb, device=dev)[None] < num_bg[:, None]

@@ -219,16 +219,17 @@ class RPN(nn.Module):
     def _subsample_batched(self, labels):
         """sampling.py:38-54 for the whole batch without host synchronisation: one random key per anchor, the <= 128
         positives with the smallest keys are kept, the rest of the 256 is filled with the negatives with the smallest keys
-        (= the reference's positive[randperm(P)[:num_pos]] with randperm := argsort of the keys).  Two u2_topk_rows
-        launches; the counts stay on the device."""
+        (= the reference's positive[randperm(P)[:num_pos]] with randperm := argsort of the keys).  Both draws share
+        one u2_topk_rows_multi launch; the counts stay on the device."""
         from . import sampling
 
         b, a = labels.shape
         n = self.batch_size_per_image
         max_pos = int(n * self.positive_fraction)
         key = sampling.random_keys((b, a), labels.device)
-        _, pos_idx, pos_cnt = F.topk_rows(key, min(max_pos, a), largest=False, mask=labels, mask_value=1, want_vals=False)
-        _, neg_idx, neg_cnt = F.topk_rows(key, min(n, a), largest=False, mask=labels, mask_value=0, want_vals=False)
+        (_, pos_idx, pos_cnt), (_, neg_idx, neg_cnt) = F.topk_rows_multi([
+            dict(vals=key, k=min(max_pos, a), largest=False, mask=labels, mask_value=1, want_vals=False),
+            dict(vals=key, k=min(n, a), largest=False, mask=labels, mask_value=0, want_vals=False)])
         num_neg = torch.minimum(neg_cnt, n - pos_cnt)
         pos_valid = torch.arange(pos_idx.shape[1], device=labels.device)[None] < pos_cnt[:, None]
         neg_valid = torch.arange(neg_idx.shape[1], device=labels.device)[None] < num_neg[:, None]
@@ -257,12 +258,14 @@ class RPN(nn.Module):
         pre, post = self.pre_nms_topk[self.training], self.post_nms_topk[self.training]
         sizes = device_constant([list(x) for x in image_sizes], torch.float32, dev)
         scores_l, boxes_l, lvl_l = [], [], []
+        # the k best logits of every image and level, ranked (logit descending, anchor index ascending), read straight from the
+        # A valid columns of the 32-wide NHWC maps; all levels in one pair of launches
+        tops = F.topk_rows_multi([dict(vals=o.contiguous(), k=min(o.shape[1] * o.shape[2] * a, pre), largest=True, group=a,
+                                       pitch=o.shape[-1], n=o.shape[1] * o.shape[2] * a) for o in objs])
         for lvl, (anc, o, d) in enumerate(zip(anchors_per_level, objs, dlts)):
             hwa = o.shape[1] * o.shape[2] * a
             k = min(hwa, pre)
-            # the k best logits of every image, ranked (logit descending, anchor index ascending), read straight from the A
-            # valid columns of the 32-wide NHWC map
-            top_scores, top_idx, _ = F.topk_rows(o.contiguous(), k, largest=True, group=a, pitch=o.shape[-1], n=hwa)
+            top_scores, top_idx, _ = tops[lvl]
             top_idx = top_idx.long()
             deltas = d[..., : 4 * a].reshape(b, hwa, 4)
             sel = torch.gather(deltas, 1, top_idx[..., None].expand(b, k, 4)).float().reshape(b * k, 4)
