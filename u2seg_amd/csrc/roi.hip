@@ -267,8 +267,15 @@ struct RoiSetDev { const float* rois; const int* order; const int* seg; const bf
 struct RoiSetsDev { RoiSetDev s[4]; int n; };
 
 constexpr int GS_TS = 8, GS_MAXL = 256, GS_KB = 4, GS_MAXP = 14;
+constexpr int GS_STAGE_BYTES = 24576;  // 48 bins of 256 channels
+typedef float gs_f2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const RoiSetsDev sets, bf16_t* __restrict__ gfeat, int level,
+// The accumulation reads, per (pixel quad, ROI), the 2 x 2 ... 3 x 3 bins of dout that touch the quad: 16 quads of a tile
+// re-read the same 16-25 bin rows of a ROI, and with the reads coming from L2 that re-reading was the kernel's time (1.17 of
+// the 1.47 ms of the stride-4 level; 17 TB/s of 16-byte loads).  The bin rows a batch of ROIs has in common with the tile are
+// therefore staged in LDS once (coalesced 512-byte rows) and the quads read them from there; a ROI whose bins do not fit
+// the stage (a 14 x 14 mask ROI on a coarse level) keeps reading from L2.
+__global__ __launch_bounds__(256, 4) void roi_align_bwd_gather_kernel(const RoiSetsDev sets, bf16_t* __restrict__ gfeat, int level,
                                                                    int nlevels, int H, int W, int C, float scale) {
   constexpr int TS = GS_TS;
   constexpr int NQ = 2;    // items per thread: an item = (tile row, 4-pixel quad of that row, 8-channel chunk)
@@ -276,18 +283,22 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const RoiSets
   __shared__ int nlist;
   __shared__ float tabY[GS_KB][TS][GS_MAXP];                                  // [roi][tile row][bin row]
   __shared__ __attribute__((aligned(16))) float tabX[GS_KB][GS_MAXP][TS];     // [roi][bin column][tile column]
+  __shared__ int rmask[GS_KB], cmask[GS_KB];                                  // bins with a weight on some tile row / column
+  __shared__ __attribute__((aligned(16))) unsigned char stage[GS_STAGE_BYTES];
   const int b = blockIdx.z;
   const int ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
   const int tid = threadIdx.x;
   const int cpr = C >> 3;             // 16-byte chunks per pixel
   const int items = TS * 2 * cpr;     // C <= 256: at most 512
-  float acc[NQ][4][8];
+  const int stage_slots = GS_STAGE_BYTES / (C * 2);
+  gs_f2 acc[NQ][4][4];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[q][j][e] = 0.f;
+      for (int e = 0; e < 4; ++e) acc[q][j][e] = gs_f2{0.f, 0.f};
+  if (tid < GS_KB) { rmask[tid] = 0; cmask[tid] = 0; }
 
   for (int si = 0; si < sets.n; ++si) {
     const RoiSetDev st = sets.s[si];
@@ -333,13 +344,45 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const RoiSets
             const float inv_g = g.bh / (float)g.gh;
             for (int iy = 0; iy < g.gh; ++iy) sum += axis_weight(g.sh + bin * g.bh + (iy + 0.5f) * inv_g, H, ty0 + rc);
             tabY[kk][rc][bin] = sum;
+            if (sum != 0.f) atomicOr(&rmask[kk], 1 << bin);
           } else {
             const float inv_g = g.bw / (float)g.gw;
             for (int ix = 0; ix < g.gw; ++ix) sum += axis_weight(g.sw + bin * g.bw + (ix + 0.5f) * inv_g, W, tx0 + rc);
             tabX[kk][bin][rc] = sum;
+            if (sum != 0.f) atomicOr(&cmask[kk], 1 << bin);
           }
         }
         __syncthreads();
+        // the bin rectangle of every ROI of the batch that carries weight on the tile, and its place in the stage
+        int ph_lo[GS_KB], ph_n[GS_KB], pw_lo[GS_KB], pw_n[GS_KB], sbase[GS_KB];
+        int used = 0;
+#pragma unroll
+        for (int kk = 0; kk < GS_KB; ++kk) {
+          const int rm = kk < nb ? rmask[kk] : 0, cm = kk < nb ? cmask[kk] : 0;
+          ph_lo[kk] = rm ? __ffs(rm) - 1 : 0;
+          ph_n[kk] = rm ? 32 - __clz(rm) - ph_lo[kk] : 0;
+          pw_lo[kk] = cm ? __ffs(cm) - 1 : 0;
+          pw_n[kk] = cm ? 32 - __clz(cm) - pw_lo[kk] : 0;
+          if (!cm) ph_n[kk] = 0;
+          const int bins = ph_n[kk] * pw_n[kk];
+          sbase[kk] = -1;
+          if (bins > 0 && used + bins <= stage_slots) { sbase[kk] = used; used += bins; }
+        }
+#pragma unroll
+        for (int kk = 0; kk < GS_KB; ++kk) {
+          if (sbase[kk] < 0) continue;
+          const RoiGeom& g = list[k0 + kk];
+          const bf16_t* src = st.dout + (size_t)g.r * P * P * C;
+          const int chunks = ph_n[kk] * pw_n[kk] * cpr;
+          for (int t = tid; t < chunks; t += 256) {
+            const int ch = t % cpr, bin = t / cpr;
+            const int ph = ph_lo[kk] + bin / pw_n[kk], pw = pw_lo[kk] + bin % pw_n[kk];
+            *reinterpret_cast<uint4*>(stage + ((size_t)(sbase[kk] + bin) * cpr + ch) * 16) =
+                *reinterpret_cast<const uint4*>(src + (size_t)(ph * P + pw) * C + ch * 8);
+          }
+        }
+        __syncthreads();
+        if (tid < GS_KB) { rmask[tid] = 0; cmask[tid] = 0; }  // for the next batch (every thread holds its copy by now)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const int item = q * 256 + tid;
@@ -348,28 +391,36 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const RoiSets
           const int row = rq >> 1, quad = rq & 1;
           const int py = ty0 + row, px = tx0 + quad * 4;
           if (item >= items || py >= H || px >= W) continue;
-          for (int kk = 0; kk < nb; ++kk) {
+#pragma unroll
+          for (int kk = 0; kk < GS_KB; ++kk) {
+            if (kk >= nb || ph_n[kk] == 0) continue;
             const RoiGeom& g = list[k0 + kk];
             if (py < g.py0 || py > g.py1 || px + 3 < g.px0 || px > g.px1) continue;
             const float ic = g.inv_cnt;
+            const bool staged = sbase[kk] >= 0;
             const bf16_t* rbase = st.dout + (size_t)g.r * P * P * C + ch * 8;
-            for (int ph = 0; ph < P; ++ph) {
+            const unsigned char* sb = stage + ((size_t)sbase[kk] * cpr + ch) * 16;
+            for (int i = 0; i < ph_n[kk]; ++i) {
+              const int ph = ph_lo[kk] + i;
               const float ay = tabY[kk][row][ph];
               if (ay == 0.f) continue;
               const float ayc = ay * ic;
-              for (int pw = 0; pw < P; ++pw) {
+              for (int jx = 0; jx < pw_n[kk]; ++jx) {
+                const int pw = pw_lo[kk] + jx;
                 const float4 ax = *reinterpret_cast<const float4*>(&tabX[kk][pw][quad * 4]);
                 if (ax.x == 0.f && ax.y == 0.f && ax.z == 0.f && ax.w == 0.f) continue;
-                bf16_t dv[8];
-                *reinterpret_cast<uint4*>(dv) = *reinterpret_cast<const uint4*>(rbase + (size_t)(ph * P + pw) * C);
+                uint4 dq;
+                if (staged) dq = *reinterpret_cast<const uint4*>(sb + (size_t)(i * pw_n[kk] + jx) * cpr * 16);
+                else dq = *reinterpret_cast<const uint4*>(rbase + (size_t)(ph * P + pw) * C);
+                const uint32_t dw[4] = {dq.x, dq.y, dq.z, dq.w};
                 const float w0 = ayc * ax.x, w1 = ayc * ax.y, w2 = ayc * ax.z, w3 = ayc * ax.w;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                  const float d = bf2f(dv[e]);
-                  acc[q][0][e] += w0 * d;
-                  acc[q][1][e] += w1 * d;
-                  acc[q][2][e] += w2 * d;
-                  acc[q][3][e] += w3 * d;
+                for (int e = 0; e < 4; ++e) {
+                  const gs_f2 d = gs_f2{__uint_as_float(dw[e] << 16), __uint_as_float(dw[e] & 0xffff0000u)};
+                  acc[q][0][e] = __builtin_elementwise_fma(gs_f2{w0, w0}, d, acc[q][0][e]);
+                  acc[q][1][e] = __builtin_elementwise_fma(gs_f2{w1, w1}, d, acc[q][1][e]);
+                  acc[q][2][e] = __builtin_elementwise_fma(gs_f2{w2, w2}, d, acc[q][2][e]);
+                  acc[q][3][e] = __builtin_elementwise_fma(gs_f2{w3, w3}, d, acc[q][3][e]);
                 }
               }
             }
@@ -393,7 +444,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const RoiSets
       if (px >= W) continue;
       bf16_t o[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[q][j][e]);
+      for (int e = 0; e < 4; ++e) { o[2 * e] = f2bf(acc[q][j][e].x); o[2 * e + 1] = f2bf(acc[q][j][e].y); }
       *reinterpret_cast<uint4*>(gfeat + (((size_t)b * H + py) * W + px) * C + ch * 8) = *reinterpret_cast<const uint4*>(o);
     }
   }
@@ -840,7 +891,10 @@ extern "C" int u2_roi_align_bwd_gather_multi(void* const* gfeats, const int* Hs,
     sets.s[i].rois = (const float*)rois[i]; sets.s[i].order = (const int*)order[i]; sets.s[i].seg = (const int*)seg[i];
     sets.s[i].dout = (const bf16_t*)dout[i]; sets.s[i].P = P[i]; sets.s[i].gscale = gscale[i];
   }
+  const char* e_lv = getenv("U2_ROI_LEVEL");  // experiments: launch one level only
+  const int only = e_lv ? atoi(e_lv) : -1;
   for (int l = 0; l < nlevels; ++l) {
+    if (only >= 0 && l != only) continue;
     const dim3 grid((Ws[l] + 7) / 8, (Hs[l] + 7) / 8, B);
     hipLaunchKernelGGL(roi_align_bwd_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, sets, (bf16_t*)gfeats[l], l,
                        nlevels, Hs[l], Ws[l], C, scales[l]);
