@@ -150,6 +150,10 @@ int u2_softmax_ce(const void* logits, const void* labels, void* dlogits, float* 
 int u2_mask_predict_bce(const void* x, const float* Wp, const float* bp, const void* cls, const void* target, void* dx,
                         float* dWp, float* dbp, float* loss_sum, void* logit_out, int N, int P, int C, float gscale,
                         void* stream);
+/* proposal_generator/rpn.py:366-429, one feature level.  dlt == NULL (and ddlt == NULL, A == 3): `obj` is the output of the
+ * objectness and anchor-delta 1x1 convs run as ONE conv (columns 0-2 objectness, 3-14 deltas of an LPo-wide NHWC map) and dobj
+ * receives both gradients in the same columns - the map their common input's gradient is then formed from by one data-gradient
+ * conv instead of two and a sum. */
 int u2_rpn_loss_level(const void* obj, const void* dlt, const void* labels, const int* match, const float* gt,
                       const float* anchors, void* dobj, void* ddlt, float* loss, int B, int HW, int A, int LPo, int LPd,
                       int Atot, int lvl_off, int G, float gscale, void* stream);

@@ -51,3 +51,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 #define U2_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
+
+// Zero-fill of a few words as an ordinary kernel of the stream.  hipMemsetAsync is not used for scratch that the next kernels
+// of the same stream update with atomics: a k-means run of the test-suite was seen (1 run in 8) with the list counter of the
+// screening pass reset WHILE the pass was appending to it - the 8-byte memset queued in front of two kernels had not been
+// executed in front of them.
+__global__ static void u2_zero_words_kernel(unsigned* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline void u2_zero_words(void* p, size_t nwords, hipStream_t s) {
+  if (nwords == 0) return;
+  size_t g = (nwords + 255) / 256;
+  if (g > 256) g = 256;
+  hipLaunchKernelGGL(u2_zero_words_kernel, dim3((unsigned)g), dim3(256), 0, s, (unsigned*)p, nwords);
+}
+

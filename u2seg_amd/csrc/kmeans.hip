@@ -249,6 +249,12 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
   const float* xp[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) xp[m] = x + (size_t)min(p0 + m * 16 + fr, N - 1) * D + fg * 8;
+  // Inline-asm loads (the compiler would drain the LDS-DMA ring in front of the first use of a load it can see).  The
+  // registers are loaded in step s and split in step s + 1, i.e. loop-carried, and the compiler - which does not know the data is
+  // in flight - is free to move them (it did: v_mov at the back-edge, in front of a wait that used to sit at the top of the
+  // next step; the ~120 MFMAs in between usually covered the latency, and when they did not a wave split stale registers:
+  // 1 run in 6 of the GPU test-suite with thousands of wrong labels).  The wait for x(s + 1) therefore closes step s, so that
+  // nothing is in flight when the back-edge is taken.
   f32x4 raw[2][2];
   auto load_x = [&]() {
 #pragma unroll
@@ -281,14 +287,17 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     for (int nb = 0; nb < KS_NB; ++nb) acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   float n2[2] = {0.f, 0.f};
 
-  // in flight at the top of step s, oldest first: centroids(s), x(s), centroids(s + 1)
+  // in flight when step s begins: centroids(s + 1) only - centroids(s) and x(s) were waited for at the end of step s - 1
   stage_c(0);
   load_x();
-  if (nsteps > 1) stage_c(1);
+  if (nsteps > 1) {
+    stage_c(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS_DMA) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
   for (int s = 0; s < nsteps; ++s) {
-    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS_DMA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
     __builtin_amdgcn_s_barrier();  // stage s is complete for every wave, and every wave is done with stage s - 1
     asm volatile("" ::: "memory");
     // split this step's x into its two bf16 pieces (MFMA A operands)
@@ -332,6 +341,10 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
       acc[0][nb + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[0], bh1, acc[0][nb + 1], 0, 0, 0);
       acc[1][nb + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[1], bh1, acc[1][nb + 1], 0, 0, 0);
     }
+    // close the step: centroids(s + 1) and x(s + 1) have landed, only centroids(s + 2) stays in flight over the back-edge
+    if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS_DMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
   }
   __syncthreads();
   // |x| per point: the four k-chunk lanes of a row, then through LDS into the D layout (lane (fg, fr): points fg * 4 + r)
@@ -579,8 +592,8 @@ extern "C" int u2_kmeans_assign(const float* x, const float* c, float* workspace
   unsigned* scal = reinterpret_cast<unsigned*>(workspace + ((K + 3) & ~3));  // [0] max |c|^2 bits, [1] list length
   bf16_t* chl = reinterpret_cast<bf16_t*>(workspace + ((K + 3) & ~3) + 4);
   int* list = reinterpret_cast<int*>(workspace + ((K + 3) & ~3) + 4 + (size_t)KS_KMAX * D);
-  hipError_t e = hipMemsetAsync(scal, 0, 8, s);
-  if (e != hipSuccess) return (int)e;
+  u2_zero_words(scal, 2, s);
+  U2_CHECK_LAUNCH();
   hipLaunchKernelGGL(csplit_kernel, dim3(KS_KMAX / 4), dim3(256), 0, s, c, chl, cn, scal, D, K);
   U2_CHECK_LAUNCH();
   static bool attr_set = false;
@@ -612,8 +625,8 @@ extern "C" int u2_kmeans_update(const float* x, const long long* labels, float* 
     int* lab_sorted = order + N;
     int* icounts = lab_sorted + N;
     int* cursor = icounts + K;
-    hipError_t e = hipMemsetAsync(icounts, 0, (size_t)K * sizeof(int), s);
-    if (e != hipSuccess) return (int)e;
+    u2_zero_words(icounts, (size_t)K, s);
+    U2_CHECK_LAUNCH();
     hipLaunchKernelGGL(km_hist_kernel, dim3(1024), dim3(256), (size_t)K * sizeof(int), s, labels, icounts, N, K);
     hipLaunchKernelGGL(km_scan_kernel, dim3(1), dim3(256), 0, s, icounts, cursor, counts, K);
     hipLaunchKernelGGL(km_scatter_kernel, dim3((N + KM_SCAT - 1) / KM_SCAT), dim3(256), (size_t)K * sizeof(int), s, labels, cursor, order,

@@ -380,6 +380,8 @@ __device__ __forceinline__ void get_deltas(const float* s, const float* t, float
 // RPN losses for one FPN level.  obj: [B][HW][LPo] (A valid cols), dlt: [B][HW][LPd] (4A valid cols),
 // labels int8 [B][Atot] (-1 ignore / 0 / 1, already subsampled), match int32 [B][Atot], gt fp32 [B][G][4],
 // anchors fp32 [HW*A][4] of this level.  Writes dobj/ddlt (bf16, same layouts, pads zero) and adds to loss[0:2].
+// FUSED3: one 32-wide map holds both predictions of A = 3 anchors (columns 0-2 objectness, 3-14 deltas) and takes one gradient row
+template <bool FUSED3>
 __global__ __launch_bounds__(256) void rpn_loss_level_kernel(const bf16_t* __restrict__ obj, const bf16_t* __restrict__ dlt,
                                                              const int8_t* __restrict__ labels, const int* __restrict__ match,
                                                              const float* __restrict__ gt, const float* __restrict__ anchors,
@@ -421,8 +423,20 @@ __global__ __launch_bounds__(256) void rpn_loss_level_kernel(const bf16_t* __res
       }
     }
     uint4* go = reinterpret_cast<uint4*>(dobj + i * LPo);
-    uint4* gd = reinterpret_cast<uint4*>(ddlt + i * LPd);
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    if (FUSED3) {
+      bf16_t row[16];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) row[c] = go_l[c];
+#pragma unroll
+      for (int c = 0; c < 12; ++c) row[3 + c] = gd_l[c];
+      row[15] = 0;
+      go[0] = *reinterpret_cast<const uint4*>(row);
+      go[1] = *reinterpret_cast<const uint4*>(row + 8);
+      for (int c = 2; c < LPo / 8; ++c) go[c] = zero4;
+      continue;
+    }
+    uint4* gd = reinterpret_cast<uint4*>(ddlt + i * LPd);
     go[0] = *reinterpret_cast<const uint4*>(go_l);
     for (int c = 1; c < LPo / 8; ++c) go[c] = zero4;
     gd[0] = *reinterpret_cast<const uint4*>(gd_l);
@@ -510,13 +524,26 @@ extern "C" int u2_mask_predict_bce(const void* x, const float* Wp, const float* 
 extern "C" int u2_rpn_loss_level(const void* obj, const void* dlt, const void* labels, const int* match, const float* gt,
                                  const float* anchors, void* dobj, void* ddlt, float* loss, int B, int HW, int A, int LPo,
                                  int LPd, int Atot, int lvl_off, int G, float gscale, void* stream) {
-  if (A > 4 || (LPo & 7) || LPd < 16 || (LPd & 7)) return -1;
+  if (A > 4 || (LPo & 7)) return -1;
+  const bool fused = dlt == nullptr;  // fused map: the deltas are columns 3 .. 14 of `obj`, the gradients one row of `dobj`
+  if (fused) {
+    if (ddlt || A != 3 || LPo < 16) return -1;
+    dlt = (const bf16_t*)obj + A;
+    LPd = LPo;
+  } else if (!ddlt || LPd < 16 || (LPd & 7)) {
+    return -1;
+  }
   if (B <= 0 || HW <= 0) return 0;
   size_t g = ((size_t)B * HW + 255) / 256;
   if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(rpn_loss_level_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)obj,
-                     (const bf16_t*)dlt, (const int8_t*)labels, match, gt, anchors, (bf16_t*)dobj, (bf16_t*)ddlt, loss, B,
-                     HW, A, LPo, LPd, Atot, lvl_off, G, gscale);
+  if (fused)
+    hipLaunchKernelGGL(rpn_loss_level_kernel<true>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)obj,
+                       (const bf16_t*)dlt, (const int8_t*)labels, match, gt, anchors, (bf16_t*)dobj, (bf16_t*)ddlt, loss, B,
+                       HW, A, LPo, LPd, Atot, lvl_off, G, gscale);
+  else
+    hipLaunchKernelGGL(rpn_loss_level_kernel<false>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)obj,
+                       (const bf16_t*)dlt, (const int8_t*)labels, match, gt, anchors, (bf16_t*)dobj, (bf16_t*)ddlt, loss, B,
+                       HW, A, LPo, LPd, Atot, lvl_off, G, gscale);
   U2_CHECK_LAUNCH();
   return 0;
 }

@@ -837,8 +837,8 @@ extern "C" int u2_iou_match(const float* boxes, int per_image_boxes, const float
   const size_t lds = (size_t)G * 5 * sizeof(float);
   if (allow_low_quality) {
     if (!gt_max) return -1;
-    hipError_t e = hipMemsetAsync(gt_max, 0, (size_t)B * G * sizeof(unsigned int), s);
-    if (e != hipSuccess) return (int)e;
+    u2_zero_words(gt_max, (size_t)B * G, s);
+    U2_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(iou_match_kernel, dim3(gx, B), dim3(256), lds, s, boxes, per_image_boxes, gt, ngt, match, mval,
                      allow_low_quality ? gt_max : nullptr, n, G);

@@ -79,6 +79,16 @@ def _weight_layout(w, cp, npad, mode, owner=None):
     n, cin, kh, kw = w.shape
     t = kh * kw
     shape = (n, t, cp) if mode == 0 else ((cp, t, npad) if mode == 1 else (t * cp, 1, npad))
+    tcache = getattr(owner, "_u2_step_layouts", None) if owner is not None else None
+    if tcache is not None:
+        # a derived weight that lives for one pass (the RPN's concatenated predictor, used on five levels): layouts kept on the
+        # tensor itself; the caller never modifies it in place
+        key = (n, cin, t, cp, npad, mode)
+        out = tcache.get(key)
+        if out is None:
+            out = tcache[key] = torch.empty(shape, dtype=BF16, device=w.device)
+            _hip.call("u2_weight_layout", w.detach().float().contiguous(), out, n, cin, t, cp, npad, mode)
+        return out
     stamp_ref = getattr(owner, "_u2_stamp", None) if owner is not None else None
     if mode != 0 and cp != cin:
         stamp_ref = None  # the batched transposer has no all-zero output rows; such layouts are built on the fly
@@ -291,7 +301,10 @@ class _Conv2dFn(Function):
         # 1x1 / linear weights: the gradient is accumulated straight into the optimizer's arena slice
         ctx.wgrad_dst = wgrad_dst if (kh * kw == 1 and wgrad_dst is not None) else None
         # the arena slice in the parameter's own [N, Cin, KH, KW] shape (multi-tap filters accumulate into it with a torch add)
-        ctx.arena = wgrad_dst if (wgrad_dst is not None and tuple(wgrad_dst.shape) == tuple(weight.shape)) else None
+        # (a reshaped view of the parameter - the box head's fc1 as a 7x7 conv - gets the slice in the view's shape)
+        ctx.arena = None
+        if wgrad_dst is not None and wgrad_dst.numel() == weight.numel() and wgrad_dst.is_contiguous():
+            ctx.arena = wgrad_dst if tuple(wgrad_dst.shape) == tuple(weight.shape) else wgrad_dst.view(weight.shape)
         ctx.param = param
         ctx.set_materialize_grads(False)  # no zero tensor for the (non-differentiable) statistics output
         if want_stats:
@@ -822,10 +835,10 @@ def mask_predict_bce_loss(x, weight, bias, classes, target_u8):
 
 class _RPNLossFn(Function):
     """RPN objectness BCE(sum) + localisation L1(sum) over all levels, both / normalizer
-    (proposal_generator/rpn.py:366-429)."""
+    (proposal_generator/rpn.py:366-429).  `fused`: each level is ONE map holding objectness (columns 0-2) and deltas (3-14)."""
 
     @staticmethod
-    def forward(ctx, labels, match, gt_boxes, anchors_per_level, num_anchors, normalizer, *obj_and_deltas):
+    def forward(ctx, labels, match, gt_boxes, anchors_per_level, num_anchors, normalizer, fused, *obj_and_deltas):
         nl = len(anchors_per_level)
         objs, dlts = obj_and_deltas[:nl], obj_and_deltas[nl:]
         b, atot = labels.shape
@@ -834,26 +847,44 @@ class _RPNLossFn(Function):
         grads = []
         off = 0
         for lvl in range(nl):
-            o, d = objs[lvl], dlts[lvl]
+            o = objs[lvl]
             hw = o.shape[1] * o.shape[2]
-            go, gd = torch.empty_like(o), torch.empty_like(d)
+            if fused:
+                go, d, gd = torch.empty_like(o), None, None
+            else:
+                d = dlts[lvl]
+                go, gd = torch.empty_like(o), torch.empty_like(d)
             _hip.call("u2_rpn_loss_level", o, d, labels, match, gt_boxes, anchors_per_level[lvl], go, gd, loss, b, hw,
-                      num_anchors, o.shape[3], d.shape[3], atot, off, g, 1.0 / normalizer)
+                      num_anchors, o.shape[3], d.shape[3] if d is not None else 0, atot, off, g, 1.0 / normalizer)
             grads.append((go, gd))
             off += hw * num_anchors
         assert off == atot
         ctx.grads = grads
+        ctx.fused = fused
+        ctx.num_anchors = num_anchors
         return loss[0] / normalizer, loss[1] / normalizer
 
     @staticmethod
     def backward(ctx, g_cls, g_loc):
+        if ctx.fused:
+            a = ctx.num_anchors
+            go0 = ctx.grads[0][0]
+            scale = torch.zeros(go0.shape[-1], dtype=torch.float32, device=go0.device)
+            scale[:a] = g_cls
+            scale[a : 5 * a] = g_loc
+            scale = scale.to(go0.dtype)
+            return (None, None, None, None, None, None, None, *[go * scale for go, _ in ctx.grads])
         gos = [go * g_cls.to(go.dtype) for go, _ in ctx.grads]
         gds = [gd * g_loc.to(gd.dtype) for _, gd in ctx.grads]
-        return (None, None, None, None, None, None, *gos, *gds)
+        return (None, None, None, None, None, None, None, *gos, *gds)
 
 
 def rpn_losses(labels, match, gt_boxes, anchors_per_level, num_anchors, normalizer, objs, deltas):
-    return _RPNLossFn.apply(labels, match, gt_boxes, anchors_per_level, num_anchors, float(normalizer), *objs, *deltas)
+    """objs / deltas: per level [B, H, W, LP] maps - or, when the head ran both predictors as one conv (the maps carry
+    `_u2_rpn_fused`), the fused maps in `objs` (deltas are then views of them and are not used)."""
+    if all(getattr(o, "_u2_rpn_fused", False) for o in objs):
+        return _RPNLossFn.apply(labels, match, gt_boxes, anchors_per_level, num_anchors, float(normalizer), True, *objs)
+    return _RPNLossFn.apply(labels, match, gt_boxes, anchors_per_level, num_anchors, float(normalizer), False, *objs, *deltas)
 
 
 # --------------------------------------------------------------------------------------------

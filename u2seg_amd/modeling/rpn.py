@@ -133,13 +133,46 @@ class StandardRPNHead(nn.Module):
                 "conv_dims": cfg.MODEL.RPN.CONV_DIMS}
 
     def forward(self, features):
-        """features: list of NHWC maps -> (list [B,H,W,32] objectness (A valid), list [B,H,W,32] deltas (4A valid))."""
+        """features: list of NHWC maps -> (list [B,H,W,32] objectness (A valid), list [B,H,W,>=4A] deltas (4A valid)).
+
+        With A = 3 the two 1x1 predictors run as ONE conv of 15 output channels (rpn.py:170-176 reads `t` twice): the map holds
+        the objectness in columns 0-2 and the deltas in columns 3-14, the second list holds views of it.  One read of `t`
+        instead of two, and in training one data-gradient conv instead of two plus the sum autograd forms for a tensor with
+        two consumers (550 MB at the stride-4 level); the loss kernel writes both gradients into one map (F.rpn_losses)."""
         objs, dlts = [], []
+        a = self.num_anchors
+        fused = a == 3 and self.anchor_deltas.out_channels == 4 * a
+        if fused:
+            w, bias = self._fused_predictor()
         for x in features:
             t = self.conv(x)
-            objs.append(self.objectness_logits(t))
-            dlts.append(self.anchor_deltas(t))
+            if fused:
+                y = F.conv2d(t, w, bias, 1, 0, param=w)
+                y._u2_rpn_fused = True
+                objs.append(y)
+                dlts.append(y[..., a:])
+            else:
+                objs.append(self.objectness_logits(t))
+                dlts.append(self.anchor_deltas(t))
         return objs, dlts
+
+    def _fused_predictor(self):
+        """[A + 4A, C, 1, 1] weight and bias of the two predictors.  Training: a fresh concatenation per forward pass (autograd
+        splits its gradient), kernel layouts cached on the tensor for the five levels.  Inference: kept until a weight changes."""
+        wo, wd = self.objectness_logits.weight, self.anchor_deltas.weight
+        bo, bd = self.objectness_logits.bias, self.anchor_deltas.bias
+        if torch.is_grad_enabled() and (wo.requires_grad or wd.requires_grad):
+            w, b = torch.cat([wo, wd], 0), torch.cat([bo, bd], 0)
+            w._u2_step_layouts = {}
+            return w, b
+        stamp = getattr(wo, "_u2_stamp", None)
+        key = (wo._version, wd._version, bo._version, bd._version, wo.data_ptr(), wd.data_ptr(), stamp[0] if stamp else None)
+        cached = self.__dict__.get("_fused_eval")
+        if cached is None or cached[0] != key:
+            w, b = torch.cat([wo.detach(), wd.detach()], 0), torch.cat([bo.detach(), bd.detach()], 0)
+            w._u2_step_layouts = {}
+            cached = self.__dict__["_fused_eval"] = (key, w, b)
+        return cached[1], cached[2]
 
 
 def build_rpn_head(cfg, input_shape):
