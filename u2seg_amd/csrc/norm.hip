@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void add_n_kernel(const bf16_t* __restrict__ a
 //      Two rows are in flight per thread (all loads issued before the first use) to cover the HBM latency. ----
 constexpr int EW_UNROLL = 2;
 
-template <bool RESID, bool RELU>
+template <bool RESID, bool RELU, int UN>
 __global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const bf16_t* __restrict__ resid,
                                                               bf16_t* __restrict__ out, int rows_per_slot, int C, int ld,
@@ -290,10 +290,10 @@ __global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __re
   const size_t base = (size_t)slot * rows_per_slot;
   const int stride = gridDim.x * rows_par;
   const bool nt = (size_t)rows_per_slot * gridDim.y * ld * 2 > NT_BYTES;
-  for (int r0 = blockIdx.x * rows_par + rl; r0 < rows_per_slot; r0 += EW_UNROLL * stride) {
-    uint4 xq[EW_UNROLL], rq[EW_UNROLL];
+  for (int r0 = blockIdx.x * rows_par + rl; r0 < rows_per_slot; r0 += UN * stride) {
+    uint4 xq[UN], rq[UN];
 #pragma unroll
-    for (int u = 0; u < EW_UNROLL; ++u) {
+    for (int u = 0; u < UN; ++u) {
       int r = r0 + u * stride;
       if (r < rows_per_slot) {
         if (rev) r = rows_per_slot - 1 - r;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __re
       }
     }
 #pragma unroll
-    for (int u = 0; u < EW_UNROLL; ++u) {
+    for (int u = 0; u < UN; ++u) {
       int r = r0 + u * stride;
       if (r < rows_per_slot) {
         if (rev) r = rows_per_slot - 1 - r;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void affine_upadd_fast_kernel(const bf16_t* __
 }
 
 // MASK: 0 no ReLU, 1 read the activation, 2 recompute x*ms + mh > 0
-template <int MASK, bool DRES>
+template <int MASK, bool DRES, int UN>
 __global__ __launch_bounds__(256) void norm_bwd_apply_fast_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ mask,
                                                                   const bf16_t* __restrict__ x, const float* __restrict__ k1,
                                                                   const float* __restrict__ k2, const float* __restrict__ k3,
@@ -428,10 +428,10 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_fast_kernel(const bf16_t* 
   const size_t base = (size_t)slot * rows_per_slot;
   const int stride = gridDim.x * rows_par;
   const bool nt = (size_t)rows_per_slot * gridDim.y * ld * 2 > NT_BYTES;
-  for (int r0 = blockIdx.x * rows_par + rl; r0 < rows_per_slot; r0 += EW_UNROLL * stride) {
-    uint4 dq[EW_UNROLL], xq[EW_UNROLL], mq[EW_UNROLL];
+  for (int r0 = blockIdx.x * rows_par + rl; r0 < rows_per_slot; r0 += UN * stride) {
+    uint4 dq[UN], xq[UN], mq[UN];
 #pragma unroll
-    for (int u = 0; u < EW_UNROLL; ++u) {
+    for (int u = 0; u < UN; ++u) {
       int r = r0 + u * stride;
       if (r < rows_per_slot) {
         if (rev) r = rows_per_slot - 1 - r;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_fast_kernel(const bf16_t* 
       }
     }
 #pragma unroll
-    for (int u = 0; u < EW_UNROLL; ++u) {
+    for (int u = 0; u < UN; ++u) {
       int r = r0 + u * stride;
       if (r < rows_per_slot) {
         if (rev) r = rows_per_slot - 1 - r;
@@ -468,9 +468,14 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_fast_kernel(const bf16_t* 
 }
 
 static bool fast_ok(int C) { const int cpr = C >> 3; return cpr >= 1 && cpr <= 256 && (256 % cpr) == 0; }
-static dim3 fast_grid(int slots, int rows_per_slot, int C) {
+static int ew_unroll() {  // rows in flight per thread of the apply passes (U2_EW_UNROLL = 2 | 4: experiments)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("U2_EW_UNROLL"); v = (e && atoi(e) == 4) ? 4 : 2; }
+  return v;
+}
+static dim3 fast_grid(int slots, int rows_per_slot, int C, int un = EW_UNROLL) {
   const int rows_par = 256 / (C >> 3);
-  int gx = (rows_per_slot + rows_par * EW_UNROLL - 1) / (rows_par * EW_UNROLL);
+  int gx = (rows_per_slot + rows_par * un - 1) / (rows_par * un);
   const int cap = max(1, 4096 / slots);
   if (gx > cap) gx = cap;
   return dim3(gx, slots);
@@ -769,13 +774,15 @@ extern "C" int u2_affine_act(const void* x, const float* scale, const float* shi
   const size_t M = (size_t)slots * rows_per_slot;
   if (M == 0) return 0;
   if (fast_ok(C)) {
-#define U2_AFFINE(RS_, RL_)                                                                                          \
-  hipLaunchKernelGGL((affine_act_fast_kernel<RS_, RL_>), fast_grid(slots, rows_per_slot, C), dim3(256), 0, (hipStream_t)stream, \
-                     (const bf16_t*)x, scale, shift, (const bf16_t*)resid, (bf16_t*)out, rows_per_slot, C, ld,                 \
-                     (unsigned char*)relu_bits, stream_order() & 1)
+#define U2_AFFINE_U(RS_, RL_, UN_)                                                                                   \
+  hipLaunchKernelGGL((affine_act_fast_kernel<RS_, RL_, UN_>), fast_grid(slots, rows_per_slot, C, UN_), dim3(256), 0,           \
+                     (hipStream_t)stream, (const bf16_t*)x, scale, shift, (const bf16_t*)resid, (bf16_t*)out, rows_per_slot, C, \
+                     ld, (unsigned char*)relu_bits, stream_order() & 1)
+#define U2_AFFINE(RS_, RL_) do { if (ew_unroll() == 4) U2_AFFINE_U(RS_, RL_, 4); else U2_AFFINE_U(RS_, RL_, 2); } while (0)
     if (resid) { if (relu) U2_AFFINE(true, true); else U2_AFFINE(true, false); }
     else { if (relu) U2_AFFINE(false, true); else U2_AFFINE(false, false); }
 #undef U2_AFFINE
+#undef U2_AFFINE_U
     U2_CHECK_LAUNCH();
     return 0;
   }
@@ -814,13 +821,15 @@ extern "C" int u2_norm_bwd_apply(const void* dout, const void* mask, const void*
   if (M == 0) return 0;
   if (fast_ok(C)) {
     const int mm = !relu ? 0 : (mask_scale ? 2 : 1);
-#define U2_APPLY(MM_, DR_)                                                                                           \
-  hipLaunchKernelGGL((norm_bwd_apply_fast_kernel<MM_, DR_>), fast_grid(slots, rows_per_slot, C), dim3(256), 0,            \
+#define U2_APPLY_U(MM_, DR_, UN_)                                                                                    \
+  hipLaunchKernelGGL((norm_bwd_apply_fast_kernel<MM_, DR_, UN_>), fast_grid(slots, rows_per_slot, C, UN_), dim3(256), 0,  \
                      (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)mask, (const bf16_t*)x, k1, k2, k3, (bf16_t*)dx, \
                      (bf16_t*)dres, rows_per_slot, C, ld, mask_scale, mask_shift, (stream_order() >> 2) & 1)
+#define U2_APPLY(MM_, DR_) do { if (ew_unroll() == 4) U2_APPLY_U(MM_, DR_, 4); else U2_APPLY_U(MM_, DR_, 2); } while (0)
     if (dres) { if (mm == 0) U2_APPLY(0, true); else if (mm == 1) U2_APPLY(1, true); else U2_APPLY(2, true); }
     else { if (mm == 0) U2_APPLY(0, false); else if (mm == 1) U2_APPLY(1, false); else U2_APPLY(2, false); }
 #undef U2_APPLY
+#undef U2_APPLY_U
     U2_CHECK_LAUNCH();
     return 0;
   }
