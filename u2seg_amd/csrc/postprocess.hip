@@ -24,10 +24,30 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restric
   const long long i8 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
   if (i8 >= total) return;
   const long long hw = (long long)H * W;
-  int k = (int)(i8 / hw);
-  const long long rem = i8 - (long long)k * hw;
+  // (mask, row, column) of the block's first byte by scalar divisions (uniform), of the thread's first byte by at most a few
+  // subtractions: two 64-bit divisions per thread were a third of the kernel
+  const long long b8 = (long long)blockIdx.x * 2048;
+  int k = (int)(b8 / hw);
+  const long long rem = b8 - (long long)k * hw;
   int y = (int)(rem / W);
-  int x = (int)(rem - (long long)y * W);
+  int x = (int)(rem - (long long)y * W) + (int)threadIdx.x * 8;
+  while (x >= W) { x -= W; ++y; }
+  while (y >= H) { y -= H; ++k; }
+  // 8 bytes inside one row that the mask's box does not reach (most of an 800 x 1333 canvas): zeros, no arithmetic
+  if (x + 8 <= W && i8 + 8 <= total) {
+    const float by0 = boxes[(size_t)k * 4 + 1], by1 = boxes[(size_t)k * 4 + 3];
+    const float bx0 = boxes[(size_t)k * 4 + 0], bx1 = boxes[(size_t)k * 4 + 2];
+    const float iy_ = paste_axis_coord((float)y, by0, by1, P);
+    bool empty = !(iy_ > -1.f && iy_ < (float)P);
+    if (!empty) {
+      const float ixa = paste_axis_coord((float)x, bx0, bx1, P), ixb = paste_axis_coord((float)(x + 7), bx0, bx1, P);
+      empty = !(fmaxf(ixa, ixb) > -1.f && fminf(ixa, ixb) < (float)P);
+    }
+    if (empty) {
+      *reinterpret_cast<unsigned long long*>(out + i8) = 0ull;
+      return;
+    }
+  }
   unsigned long long bits = 0ull;
   int cur_k = -1, cur_y = -1;
   float x0 = 0.f, y0 = 0.f, x1 = 0.f, y1 = 0.f, iy = 0.f, wy_n = 0.f, wy_s = 0.f;
@@ -85,8 +105,8 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restric
 // label by an LDS histogram, ids handed out in ascending label order (torch.unique is sorted), one more pass to write.
 // Every decision is integer / exact, so the map is bit-identical to the reference's.
 // ---------------------------------------------------------------------------------------------
-constexpr int PM_THREADS = 1024, PM_MAXSEM = 256;
-struct PanopticBatch { U2PanopticImage im[24]; };
+constexpr int PM_THREADS = 1024, PM_MAXSEM = 256, PM_MAXIMG = 40, PM_STRIPES = 16;
+struct PanopticBatch { U2PanopticImage im[PM_MAXIMG]; };   // 40 x 80 bytes of kernel arguments: a 32-image batch in one launch
 
 __device__ __forceinline__ void block_sum2_1024(int& a, int& b, int* red /*[34]*/) {
   for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
@@ -103,19 +123,25 @@ __device__ __forceinline__ void block_sum2_1024(int& a, int& b, int* red /*[34]*
   a = red[32]; b = red[33];
 }
 
-__global__ __launch_bounds__(PM_THREADS) void panoptic_merge_kernel(const PanopticBatch batch, float overlap_thr,
-                                                                    int stuff_area_thr, float score_thr, int mask_res) {
+// The merge of one image is serial in the instances (each claims what the better ones left), so that part is one work-group per
+// image; the passes over the whole 800 x 1333 map around it - clearing it, the semantic histogram, writing the stuff ids - are
+// plain data-parallel and run as PM_STRIPES work-groups per image (one work-group streaming 1 M pixels three times was 2 of the
+// 2.8 ms the one-kernel form took per launch; and a 32-image batch was two launches of 24 + 8 images, one after the other).
+__global__ __launch_bounds__(PM_THREADS) void panoptic_clear_kernel(const PanopticBatch batch) {
+  const U2PanopticImage im = batch.im[blockIdx.y];
+  const long long hw = (long long)im.H * im.W;
+  for (long long p = (long long)blockIdx.x * PM_THREADS + threadIdx.x; p < hw; p += (long long)gridDim.x * PM_THREADS) im.panoptic[p] = 0;
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < im.num_sem; i += PM_THREADS) { im.stuff_area[i] = 0; im.stuff_segment[i] = 0; }
+}
+
+__global__ __launch_bounds__(PM_THREADS) void panoptic_merge_kernel(const PanopticBatch batch, float overlap_thr, float score_thr,
+                                                                    int mask_res) {
   __shared__ int red[34];
-  __shared__ int hist_all[PM_MAXSEM], hist_free[PM_MAXSEM], stuff_id[PM_MAXSEM];
-  __shared__ int s_seg;
   const U2PanopticImage im = batch.im[blockIdx.x];
   const int tid = threadIdx.x;
   const int H = im.H, W = im.W;
   const long long hw = (long long)H * W;
-  for (long long p = tid; p < hw; p += PM_THREADS) im.panoptic[p] = 0;
-  for (int i = tid; i < PM_MAXSEM; i += PM_THREADS) { hist_all[i] = 0; hist_free[i] = 0; stuff_id[i] = 0; }
-  if (tid == 0) s_seg = 0;
-  __syncthreads();
   int seg = 0;
   for (int rank = 0; rank < im.K; ++rank) {
     if (tid == 0) im.inst_segment[rank] = 0;
@@ -151,32 +177,58 @@ __global__ __launch_bounds__(PM_THREADS) void panoptic_merge_kernel(const Panopt
     if (tid == 0) im.inst_segment[rank] = seg;
     __syncthreads();
   }
+}
+
+// semantic histogram of a stripe: per label the free pixels (-> stuff_area) and whether the label occurs at all (-> a flag in
+// stuff_segment, replaced by the segment id in the last kernel)
+__global__ __launch_bounds__(PM_THREADS) void panoptic_stuff_hist_kernel(const PanopticBatch batch) {
+  __shared__ int hist_all[PM_MAXSEM], hist_free[PM_MAXSEM];
+  const U2PanopticImage im = batch.im[blockIdx.y];
+  const long long hw = (long long)im.H * im.W;
+  for (int i = threadIdx.x; i < PM_MAXSEM; i += PM_THREADS) { hist_all[i] = 0; hist_free[i] = 0; }
   __syncthreads();
-  // stuff
-  for (long long p = tid; p < hw; p += PM_THREADS) {
+  for (long long p = (long long)blockIdx.x * PM_THREADS + threadIdx.x; p < hw; p += (long long)gridDim.x * PM_THREADS) {
     const long long lab = im.semantic[p];
-    if (lab >= 0 && lab < PM_MAXSEM) {
+    if (lab >= 0 && lab < im.num_sem) {
       atomicAdd(&hist_all[(int)lab], 1);
       if (im.panoptic[p] == 0) atomicAdd(&hist_free[(int)lab], 1);
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    for (int lab = 1; lab < PM_MAXSEM; ++lab) {  // label 0 = "thing" pixels of the semantic head
+  for (int i = threadIdx.x; i < im.num_sem; i += PM_THREADS) {
+    if (hist_free[i]) atomicAdd(&im.stuff_area[i], hist_free[i]);
+    if (hist_all[i]) atomicOr(&im.stuff_segment[i], 1);
+  }
+}
+
+// ids in ascending label order (torch.unique is sorted) after the instance segments; FILL: write them into the stripe,
+// otherwise (one work-group per image, after the fill) into stuff_segment
+template <bool FILL>
+__global__ __launch_bounds__(PM_THREADS) void panoptic_stuff_ids_kernel(const PanopticBatch batch, int stuff_area_thr) {
+  __shared__ int stuff_id[PM_MAXSEM];
+  const U2PanopticImage im = batch.im[blockIdx.y];
+  const long long hw = (long long)im.H * im.W;
+  if (threadIdx.x == 0) {
+    int seg = 0;
+    for (int r = 0; r < im.K; ++r) seg = max(seg, im.inst_segment[r]);
+    stuff_id[0] = 0;
+    for (int lab = 1; lab < im.num_sem; ++lab) {  // label 0 = "thing" pixels of the semantic head
       int id = 0;
-      if (hist_all[lab] > 0 && hist_free[lab] >= stuff_area_thr) id = ++seg;
+      if (im.stuff_segment[lab] != 0 && im.stuff_area[lab] >= stuff_area_thr) id = ++seg;
       stuff_id[lab] = id;
-      if (lab < im.num_sem) { im.stuff_segment[lab] = id; im.stuff_area[lab] = hist_free[lab]; }
     }
-    if (im.num_sem > 0) { im.stuff_segment[0] = 0; im.stuff_area[0] = hist_free[0]; }
   }
   __syncthreads();
-  for (long long p = tid; p < hw; p += PM_THREADS) {
-    const long long lab = im.semantic[p];
-    if (lab > 0 && lab < PM_MAXSEM && im.panoptic[p] == 0) {
-      const int id = stuff_id[(int)lab];
-      if (id) im.panoptic[p] = id;
+  if (FILL) {
+    for (long long p = (long long)blockIdx.x * PM_THREADS + threadIdx.x; p < hw; p += (long long)gridDim.x * PM_THREADS) {
+      const long long lab = im.semantic[p];
+      if (lab > 0 && lab < im.num_sem && im.panoptic[p] == 0) {
+        const int id = stuff_id[(int)lab];
+        if (id) im.panoptic[p] = id;
+      }
     }
+  } else {
+    for (int i = threadIdx.x; i < im.num_sem; i += PM_THREADS) im.stuff_segment[i] = stuff_id[i];
   }
 }
 
@@ -184,15 +236,23 @@ __global__ __launch_bounds__(PM_THREADS) void panoptic_merge_kernel(const Panopt
 
 extern "C" int u2_panoptic_merge(const U2PanopticImage* images, int n_images, float overlap_thr, int stuff_area_thr,
                                  float score_thr, int mask_res, void* stream) {
-  for (int b0 = 0; b0 < n_images; b0 += 24) {
-    const int nb = n_images - b0 < 24 ? n_images - b0 : 24;
+  hipStream_t s = (hipStream_t)stream;
+  for (int b0 = 0; b0 < n_images; b0 += PM_MAXIMG) {
+    const int nb = n_images - b0 < PM_MAXIMG ? n_images - b0 : PM_MAXIMG;
     PanopticBatch batch;
     for (int i = 0; i < nb; ++i) {
       batch.im[i] = images[b0 + i];
-      if (batch.im[i].num_sem > PM_MAXSEM || batch.im[i].H <= 0 || batch.im[i].W <= 0) return -1;
+      if (batch.im[i].num_sem > PM_MAXSEM || batch.im[i].num_sem < 0 || batch.im[i].H <= 0 || batch.im[i].W <= 0) return -1;
     }
-    hipLaunchKernelGGL(panoptic_merge_kernel, dim3(nb), dim3(PM_THREADS), 0, (hipStream_t)stream, batch, overlap_thr,
-                       stuff_area_thr, score_thr, mask_res);
+    hipLaunchKernelGGL(panoptic_clear_kernel, dim3(PM_STRIPES, nb), dim3(PM_THREADS), 0, s, batch);
+    U2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(panoptic_merge_kernel, dim3(nb), dim3(PM_THREADS), 0, s, batch, overlap_thr, score_thr, mask_res);
+    U2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(panoptic_stuff_hist_kernel, dim3(PM_STRIPES, nb), dim3(PM_THREADS), 0, s, batch);
+    U2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(panoptic_stuff_ids_kernel<true>, dim3(PM_STRIPES, nb), dim3(PM_THREADS), 0, s, batch, stuff_area_thr);
+    U2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(panoptic_stuff_ids_kernel<false>, dim3(1, nb), dim3(PM_THREADS), 0, s, batch, stuff_area_thr);
     U2_CHECK_LAUNCH();
   }
   return 0;
