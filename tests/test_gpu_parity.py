@@ -312,6 +312,45 @@ def test_roi_align_fwd_bwd(F, G):
     assert torch.equal(out.cpu().bool(), ref)
 
 
+def test_roi_align_elongated_boxes(F):
+    """ROIAlign forward on boxes whose column footprint is wider than the forward kernel's LDS stage (40 pixels: the one-pass
+    form takes over) next to boxes that fit it, and the backward gather on the same boxes (bin rectangles that fit the 48-bin
+    stage and 14 x 14 grids that do not), all vs the C oracle."""
+    g = torch.Generator().manual_seed(31)
+    shapes, scales = [(24, 160), (12, 80), (6, 40), (3, 20)], [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    feats = [bf(torch.randn((2, 64, h, w), generator=g)) for h, w in shapes]
+    rows = []
+    for w_, h_ in ((150.0, 12.0), (300.0, 20.0), (520.0, 24.0), (600.0, 90.0), (158.0, 60.0), (40.0, 30.0), (630.0, 8.0)):
+        for x0, y0 in ((3.0, 2.0), (20.5, 30.25)):
+            rows.append([x0, y0, min(x0 + w_, 655.0), min(y0 + h_, 99.0)])
+    boxes = torch.tensor(rows)
+    n = boxes.shape[0]
+    bidx = (torch.arange(n) % 2).float()
+    rois = torch.cat([bidx[:, None], boxes], 1)
+    lv_ref = O.assign_boxes_to_levels(boxes, 2, 5)
+    lv = F.assign_levels(boxes.to(DEV), 2, 5)
+    assert torch.equal(lv.cpu().long(), lv_ref)
+    assert int(((boxes[:, 2] - boxes[:, 0]) * torch.tensor(scales)[lv_ref] > 41).sum()) >= 4  # some footprints exceed the stage
+    for ps in (7, 14):
+        fr = [f.clone().requires_grad_(True) for f in feats]
+        out_ref = torch.zeros((n, 64, ps, ps))
+        for l in range(4):
+            idx = torch.nonzero(lv_ref == l)[:, 0]
+            if len(idx):
+                out_ref = out_ref.index_put((idx,), O.roi_align(fr[l], rois[idx], ps, scales[l]))
+        gy = bf(torch.randn(out_ref.shape, generator=g))
+        out_ref.backward(gy)
+        fd = [nhwc(f).requires_grad_(True) for f in feats]
+        y = F.roi_align(fd, rois.to(DEV), lv, ps, scales, grad_scale=1.0)
+        assert rel_err(y.permute(0, 3, 1, 2).float().cpu(), out_ref.detach()) < 1e-2, ps
+        y.backward(gy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV))
+        for l in range(4):
+            if fr[l].grad is None:
+                assert float(fd[l].grad.abs().max()) == 0.0
+            else:
+                assert rel_err(nchw(fd[l].grad), fr[l].grad) < 1.5e-2, (ps, l)
+
+
 def test_roi_grad_tap_combines_poolers(F):
     """Three 7x7 poolers (gradient scale 1/3) and one 14x14 pooler on tapped FPN maps: the single deferred multi-set gather
     must give the sum of the four separate ROIAlign backward passes (what autograd forms without the tap)."""
@@ -436,6 +475,49 @@ def test_rpn_loss(F):
     for i in range(3):
         assert rel_err(od[i].grad[..., :A].float().cpu(), ov[i].grad) < 1e-2
         assert rel_err(dd[i].grad[..., : 4 * A].float().cpu(), dv[i].grad) < 1e-2
+
+
+def test_rpn_fused_predictors_equal_separate(F):
+    """StandardRPNHead runs the objectness and the anchor-delta 1x1 convs as ONE conv of 15 channels; the maps must be those of
+    the two separate convs (the reference's form, rpn.py:170-176) bit for bit, the losses equal, and the gradients of the shared
+    3x3 conv's output, of both predictors and of the level inputs equal to one bf16 ulp of their scale (the separate form
+    rounds two data gradients to bf16 and adds them, the fused form rounds their sum once)."""
+    from u2seg_amd.modeling.rpn import StandardRPNHead
+
+    g = torch.Generator().manual_seed(8)
+    B, A, grids = 2, 3, [(24, 32), (12, 16), (6, 8)]
+    head = StandardRPNHead(in_channels=64, num_anchors=A).to(DEV)
+    with torch.no_grad():
+        for m in (head.conv, head.objectness_logits, head.anchor_deltas):
+            m.weight.copy_(torch.randn(m.weight.shape, generator=g) * 0.05)
+            m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+    feats = [bf(torch.randn((B, h, w, 64), generator=g)) for h, w in grids]
+    atot = sum(h * w * A for h, w in grids)
+    labels = torch.randint(-1, 2, (B, atot), generator=g).to(torch.int8)
+    match = torch.randint(0, 3, (B, atot), generator=g).to(torch.int32)
+    gt = torch.rand((B, 3, 4), generator=g) * 50
+    gt[..., 2:] += gt[..., :2] + 4
+    anchors = []
+    for h, w in grids:
+        xy = torch.rand((h * w * A, 2), generator=g) * 80
+        anchors.append(torch.cat([xy, xy + 8 + torch.rand((h * w * A, 2), generator=g) * 40], 1).to(DEV))
+    res = {}
+    for fused in (True, False):
+        head.fuse_predictors = fused
+        head.zero_grad()
+        xs = [f.to(torch.bfloat16).to(DEV).requires_grad_(True) for f in feats]
+        objs, dlts = head(xs)
+        lc, ll = F.rpn_losses(labels.to(DEV), match.to(DEV), gt.to(DEV), anchors, A, 256.0 * B, objs, dlts)
+        (lc + 2.0 * ll).backward()
+        res[fused] = dict(objs=[o[..., :A].float().cpu() for o in objs], dlts=[d[..., : 4 * A].float().cpu() for d in dlts],
+                          losses=(float(lc), float(ll)), gx=[x.grad.float().cpu() for x in xs],
+                          gw=[p.grad.float().cpu().clone() for p in head.parameters()])
+    a, b = res[True], res[False]
+    for u, v in zip(a["objs"] + a["dlts"], b["objs"] + b["dlts"]):
+        assert torch.equal(u, v)
+    assert a["losses"] == b["losses"]
+    for u, v in zip(a["gx"] + a["gw"], b["gx"] + b["gw"]):
+        assert rel_err(u, v) < 8e-3
 
 
 def test_arena_direct_grads_and_cached_layouts(F):

@@ -291,7 +291,7 @@ class _Conv2dFn(Function):
         # bf16 autocast, tests/golden/bf16_units_golden.npz); a folded eval-mode norm shift is not a conv bias and stays fp32
         bias_f = None
         if bias is not None:
-            bias_f = (bias.detach().bfloat16().float() if round_bias else bias.detach().float()).contiguous()
+            bias_f = _conv_bias(bias, round_bias)
         _hip.call("u2_conv_igemm", x, wk, out, bias_f, None if _DET_STATS else stats, b, h, w_, cp, cp, ho, wo, n, npad, kh, kw,
                   pad, pad, stride, 1, int(relu), 0, 0)
         if want_stats and _DET_STATS:
@@ -372,6 +372,20 @@ class _Conv2dFn(Function):
             _hip.call("u2_colstats", dz, sums, 1, b * ho * wo, npad, npad)
             db = sums[0, 0, :n]
         return dx, dw, db, None, None, None, None, None, None
+
+
+def _conv_bias(bias, round_bias):
+    """The fp32 bias vector the conv epilogue adds (rounded through bf16 as autocast rounds it).  For a parameter owned by
+    solver.FlatSGD the rounded copy is kept until the optimizer's next step (two small cast launches per biased conv and pass
+    otherwise: 64 per training step)."""
+    stamp = getattr(bias, "_u2_stamp", None)
+    if stamp is None or not round_bias:
+        return (bias.detach().bfloat16().float() if round_bias else bias.detach().float()).contiguous()
+    ent = bias.__dict__.get("_u2_bias_rounded")
+    if ent is None or ent[1] != bias._version or ent[2] != stamp[0]:
+        ent = (bias.detach().bfloat16().float().contiguous(), bias._version, stamp[0])
+        bias.__dict__["_u2_bias_rounded"] = ent
+    return ent[0]
 
 
 def grad_slot(param):

@@ -121,6 +121,7 @@ class StandardRPNHead(nn.Module):
             nn.init.normal_(layer.weight, std=0.01)
             nn.init.constant_(layer.bias, 0)
         self.num_anchors = num_anchors
+        self.fuse_predictors = True  # both 1x1 predictors as one conv (forward()); False: two convs, as the reference runs them
 
     @classmethod
     def from_config(cls, cfg, input_shape):
@@ -141,7 +142,7 @@ class StandardRPNHead(nn.Module):
         two consumers (550 MB at the stride-4 level); the loss kernel writes both gradients into one map (F.rpn_losses)."""
         objs, dlts = [], []
         a = self.num_anchors
-        fused = a == 3 and self.anchor_deltas.out_channels == 4 * a
+        fused = self.fuse_predictors and a == 3 and self.anchor_deltas.out_channels == 4 * a
         if fused:
             w, bias = self._fused_predictor()
         for x in features:
