@@ -313,9 +313,9 @@ def test_roi_align_fwd_bwd(F, G):
 
 
 def test_roi_align_elongated_boxes(F):
-    """ROIAlign forward on boxes whose column footprint is wider than the forward kernel's LDS stage (40 pixels: the one-pass
-    form takes over) next to boxes that fit it, and the backward gather on the same boxes (bin rectangles that fit the 48-bin
-    stage and 14 x 14 grids that do not), all vs the C oracle."""
+    """ROIAlign on elongated boxes (column footprints of 40 ... 160 pixels at their level, bins wider than they are tall) next to
+    ordinary ones: the forward tables and the backward gather (bin rectangles that fit its 48-bin LDS stage and 14 x 14 grids
+    that do not) vs the C oracle."""
     g = torch.Generator().manual_seed(31)
     shapes, scales = [(24, 160), (12, 80), (6, 40), (3, 20)], [1 / 4, 1 / 8, 1 / 16, 1 / 32]
     feats = [bf(torch.randn((2, 64, h, w), generator=g)) for h, w in shapes]
@@ -330,7 +330,7 @@ def test_roi_align_elongated_boxes(F):
     lv_ref = O.assign_boxes_to_levels(boxes, 2, 5)
     lv = F.assign_levels(boxes.to(DEV), 2, 5)
     assert torch.equal(lv.cpu().long(), lv_ref)
-    assert int(((boxes[:, 2] - boxes[:, 0]) * torch.tensor(scales)[lv_ref] > 41).sum()) >= 4  # some footprints exceed the stage
+    assert int(((boxes[:, 2] - boxes[:, 0]) * torch.tensor(scales)[lv_ref] > 41).sum()) >= 4  # wide footprints are present
     for ps in (7, 14):
         fr = [f.clone().requires_grad_(True) for f in feats]
         out_ref = torch.zeros((n, 64, ps, ps))
