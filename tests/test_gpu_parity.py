@@ -479,7 +479,7 @@ def test_rpn_loss(F):
 
 def test_rpn_fused_predictors_equal_separate(F):
     """StandardRPNHead runs the objectness and the anchor-delta 1x1 convs as ONE conv of 15 channels; the maps must be those of
-    the two separate convs (the reference's form, rpn.py:170-176) bit for bit, the losses equal, and the gradients of the shared
+    the two separate convs (the reference's form, rpn.py:170-176) bit for bit, the losses equal up to summation order, and the gradients of the shared
     3x3 conv's output, of both predictors and of the level inputs equal to one bf16 ulp of their scale (the separate form
     rounds two data gradients to bf16 and adds them, the fused form rounds their sum once)."""
     from u2seg_amd.modeling.rpn import StandardRPNHead
@@ -515,7 +515,8 @@ def test_rpn_fused_predictors_equal_separate(F):
     a, b = res[True], res[False]
     for u, v in zip(a["objs"] + a["dlts"], b["objs"] + b["dlts"]):
         assert torch.equal(u, v)
-    assert a["losses"] == b["losses"]
+    for u, v in zip(a["losses"], b["losses"]):  # sums of per-block partial sums by float atomics: equal up to their order
+        assert abs(u - v) <= 1e-5 * abs(v)
     for u, v in zip(a["gx"] + a["gw"], b["gx"] + b["gw"]):
         assert rel_err(u, v) < 8e-3
 
