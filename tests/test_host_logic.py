@@ -454,3 +454,34 @@ def test_eval_fold_cache_and_block_flags():
         assert blocks[0].first_in_stage and not any(b.first_in_stage for b in blocks[1:])
         assert not any(b.third_handle for b in blocks[:-1])
         assert blocks[-1].third_handle == (name != bottom_up.stage_names[-1])      # res2-res4 feed the next stage AND the FPN
+
+
+def test_detector_postprocess_batch_equals_per_image_rule():
+    """detector_postprocess_batch rescales, clips and filters the boxes of all images with one set of tensor ops; the result
+    must be what postprocessing.py:9-74 does image by image (Boxes.scale, Boxes.clip, nonempty), including images with no
+    boxes, boxes that become empty after clipping and different output sizes per image."""
+    from u2seg_amd.modeling.inference import detector_postprocess_batch
+    from u2seg_amd.structures import Boxes, Instances
+
+    g = torch.Generator().manual_seed(0)
+    res, sizes = [], []
+    for i, n in enumerate([7, 0, 3, 12, 1]):
+        inst = Instances((480 + 10 * i, 640))
+        b = torch.rand((n, 4), generator=g) * 700 - 30
+        b[:, 2:] = b[:, :2] + torch.rand((n, 2), generator=g) * 200 - 20  # some with negative extent
+        inst.pred_boxes = Boxes(b)
+        inst.scores = torch.rand(n, generator=g)
+        inst.pred_classes = torch.randint(0, 5, (n,), generator=g)
+        res.append(inst)
+        sizes.append((400 + 7 * i, 500 + 3 * i))
+    out = detector_postprocess_batch(res, sizes)
+    dropped = 0
+    for inst, (oh, ow), o in zip(res, sizes, out):
+        sx, sy = ow / inst.image_size[1], oh / inst.image_size[0]
+        t = inst.pred_boxes.tensor * torch.tensor([sx, sy, sx, sy])
+        t = torch.stack((t[:, 0].clamp(0, ow), t[:, 1].clamp(0, oh), t[:, 2].clamp(0, ow), t[:, 3].clamp(0, oh)), -1)
+        keep = ((t[:, 2] - t[:, 0]) > 0) & ((t[:, 3] - t[:, 1]) > 0)
+        dropped += int((~keep).sum())
+        assert torch.equal(o.pred_boxes.tensor, t[keep]) and torch.equal(o.scores, inst.scores[keep])
+        assert torch.equal(o.pred_classes, inst.pred_classes[keep]) and o.image_size == (oh, ow)
+    assert dropped > 0

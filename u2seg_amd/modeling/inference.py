@@ -97,25 +97,42 @@ def detector_postprocess_batch(results_list, sizes, mask_threshold=0.5):
     """postprocessing.py:9-74 for a batch: rescale + clip the boxes, drop empty ones, paste the masks.  The "is any box
     empty" question is answered for all images with one host synchronisation (the reference indexes with a boolean mask,
     i.e. synchronises, per image)."""
-    staged = []
-    for results, (output_height, output_width) in zip(results_list, sizes):
-        scale_x, scale_y = output_width / results.image_size[1], output_height / results.image_size[0]
-        results = Instances((output_height, output_width), **results.get_fields())
-        name = "pred_boxes" if results.has("pred_boxes") else "proposal_boxes"
-        t = results.get(name).tensor
-        dev = t.device
-        # Boxes.scale + Boxes.clip (structures/boxes.py:27-34,58-60) without the per-call finiteness synchronisation
-        t = t * device_constant([scale_x, scale_y, scale_x, scale_y], torch.float32, dev)
-        finite = torch.isfinite(t).all()
-        t = torch.minimum(t.clamp(min=0), device_constant([output_width, output_height] * 2, torch.float32, dev))
-        boxes = Boxes(t)
-        results.set(name, boxes)
-        staged.append((results, boxes.nonempty(), finite))
-    flags = torch.stack([torch.stack([k.all(), f]) for _, k, f in staged]).tolist() if staged else []
+    if not results_list:
+        return []
+    # Boxes.scale + Boxes.clip + nonempty (structures/boxes.py:27-34,58-60) for the boxes of ALL images at once: the per-image
+    # form was ~14 small launches per image (450 per 32-image batch); per-row scale factors and limits come from cached constants
+    name = "pred_boxes" if results_list[0].has("pred_boxes") else "proposal_boxes"
+    counts = [len(r) for r in results_list]
+    tensors = [r.get(name).tensor for r in results_list]
+    dev = tensors[0].device
+    scl, lim = [], []
+    for i, (results, (output_height, output_width)) in enumerate(zip(results_list, sizes)):
+        sx, sy = output_width / results.image_size[1], output_height / results.image_size[0]
+        scl.append([sx, sy, sx, sy])
+        lim.append([output_width, output_height, output_width, output_height])
+    total = sum(counts)
+    if total:
+        img_idx = torch.repeat_interleave(device_constant(list(range(len(counts))), torch.int64, dev),
+                                          device_constant(counts, torch.int64, dev), output_size=total)
+        t = torch.cat(tensors).float() * device_constant(scl, torch.float32, dev)[img_idx]
+        finite_row = torch.isfinite(t).all(dim=1)
+        t = torch.minimum(t.clamp(min=0), device_constant(lim, torch.float32, dev)[img_idx])
+        keep_row = ((t[:, 2] - t[:, 0]) > 0.0) & ((t[:, 3] - t[:, 1]) > 0.0)
+        bad = torch.zeros((len(results_list), 2), dtype=torch.int32, device=dev)
+        bad.index_add_(0, img_idx, torch.stack([~keep_row, ~finite_row], dim=1).to(torch.int32))
+        flags = bad.tolist()  # the one host synchronisation
+        boxes_per_image, keep_per_image = t.split(counts), keep_row.split(counts)
+    else:
+        flags = [[0, 0]] * len(results_list)
+        boxes_per_image = [x.float() for x in tensors]
+        keep_per_image = [torch.ones(0, dtype=torch.bool, device=dev)] * len(results_list)
     out = []
-    for (results, keep, _), (all_ok, finite) in zip(staged, flags):
-        assert finite, "Box tensor contains infinite or NaN!"
-        if not all_ok:
+    for results, (output_height, output_width), bx, keep, (n_empty, n_nonfinite) in zip(results_list, sizes, boxes_per_image,
+                                                                                       keep_per_image, flags):
+        assert not n_nonfinite, "Box tensor contains infinite or NaN!"
+        results = Instances((output_height, output_width), **results.get_fields())
+        results.set(name, Boxes(bx))
+        if n_empty:
             results = results[keep]
         if results.has("pred_masks"):
             results.pred_masks = paste_masks_in_image(results.pred_masks[:, 0, :, :], results.pred_boxes.tensor,
