@@ -23,13 +23,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16_t* __restri
                                                           uint8_t* __restrict__ idx, int B, int H, int W, int C, int Ho,
                                                           int Wo) {
   const int cpr = C >> 3;
-  const size_t total = (size_t)B * Ho * Wo * cpr;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int cc = (int)(i % cpr);
-    size_t p = i / cpr;
-    const int ox = (int)(p % Wo); p /= Wo;
-    const int oy = (int)(p % Ho);
-    const int b = (int)(p / Ho);
+  for (int row_ = blockIdx.y; row_ < B * Ho; row_ += gridDim.y)  // grid.y = (image, row): no 64-bit divisions per item
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < Wo * cpr; t += gridDim.x * 256) {
+    const int b = row_ / Ho, oy = row_ - b * Ho;
+    const int ox = t / cpr, cc = t - ox * cpr;
     float best[8];
     uint8_t bi[8];
 #pragma unroll
@@ -64,14 +61,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16_t* __restri
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16_t* __restrict__ dy, const uint8_t* __restrict__ idx,
                                                           bf16_t* __restrict__ dx, int B, int H, int W, int C, int Ho,
                                                           int Wo) {
+  // grid.y = (image, input row): the row decomposition is scalar, a thread's (column, chunk) two 32-bit operations (three 64-bit
+  // divisions per 16-byte item were most of this kernel: 0.40 ms for a 550 MB map)
   const int cpr = C >> 3;
-  const size_t total = (size_t)B * H * W * cpr;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int cc = (int)(i % cpr);
-    size_t p = i / cpr;
-    const int ix = (int)(p % W); p /= W;
-    const int iy = (int)(p % H);
-    const int b = (int)(p / H);
+  for (int row_ = blockIdx.y; row_ < B * H; row_ += gridDim.y)  // grid.y = (image, row): no 64-bit divisions per item
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < W * cpr; t += gridDim.x * 256) {
+    const int b = row_ / H, iy = row_ - b * H;
+    const int ix = t / cpr, cc = t - ix * cpr;
+    const size_t i = ((size_t)row_ * W + ix) * cpr + cc;
     float g[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) g[e] = 0.f;
@@ -107,13 +104,11 @@ __global__ __launch_bounds__(256) void upadd_fwd_kernel(const bf16_t* __restrict
                                                         bf16_t* __restrict__ out, int B, int H, int W, int C) {
   const int cpr = C >> 3;
   const int Ht = H >> 1, Wt = W >> 1;
-  const size_t total = (size_t)B * H * W * cpr;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int cc = (int)(i % cpr);
-    size_t p = i / cpr;
-    const int x = (int)(p % W); p /= W;
-    const int y = (int)(p % H);
-    const int b = (int)(p / H);
+  for (int row_ = blockIdx.y; row_ < B * H; row_ += gridDim.y)  // grid.y = (image, row): no 64-bit divisions per item
+  for (int t_ = blockIdx.x * 256 + threadIdx.x; t_ < W * cpr; t_ += gridDim.x * 256) {
+    const int b = row_ / H, y = row_ - b * H;
+    const int x = t_ / cpr, cc = t_ - x * cpr;
+    const size_t i = ((size_t)row_ * W + x) * cpr + cc;
     bf16_t a[8], t[8], o[8];
     *reinterpret_cast<uint4*>(a) = *reinterpret_cast<const uint4*>(lat + i * 8);
     *reinterpret_cast<uint4*>(t) =
@@ -129,13 +124,11 @@ __global__ __launch_bounds__(256) void upadd_bwd_kernel(const bf16_t* __restrict
                                                         int H, int W, int C) {
   const int cpr = C >> 3;
   const int Ht = H >> 1, Wt = W >> 1;
-  const size_t total = (size_t)B * Ht * Wt * cpr;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int cc = (int)(i % cpr);
-    size_t p = i / cpr;
-    const int x = (int)(p % Wt); p /= Wt;
-    const int y = (int)(p % Ht);
-    const int b = (int)(p / Ht);
+  for (int row_ = blockIdx.y; row_ < B * Ht; row_ += gridDim.y)  // grid.y = (image, row): no 64-bit divisions per item
+  for (int t_ = blockIdx.x * 256 + threadIdx.x; t_ < Wt * cpr; t_ += gridDim.x * 256) {
+    const int b = row_ / Ht, y = row_ - b * Ht;
+    const int x = t_ / cpr, cc = t_ - x * cpr;
+    const size_t i = ((size_t)row_ * Wt + x) * cpr + cc;
     float g[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) g[e] = 0.f;
@@ -169,13 +162,11 @@ __global__ __launch_bounds__(256) void bilinear2_fwd_kernel(const bf16_t* __rest
                                                             bf16_t* __restrict__ out, int B, int H, int W, int C) {
   const int cpr = C >> 3;
   const int Ho = H * 2, Wo = W * 2;
-  const size_t total = (size_t)B * Ho * Wo * cpr;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int cc = (int)(i % cpr);
-    size_t p = i / cpr;
-    const int ox = (int)(p % Wo); p /= Wo;
-    const int oy = (int)(p % Ho);
-    const int b = (int)(p / Ho);
+  for (int row_ = blockIdx.y; row_ < B * Ho; row_ += gridDim.y)  // grid.y = (image, row): no 64-bit divisions per item
+  for (int t_ = blockIdx.x * 256 + threadIdx.x; t_ < Wo * cpr; t_ += gridDim.x * 256) {
+    const int b = row_ / Ho, oy = row_ - b * Ho;
+    const int ox = t_ / cpr, cc = t_ - ox * cpr;
+    const size_t i = ((size_t)row_ * Wo + ox) * cpr + cc;
     int y0, y1, x0, x1;
     float ly, lx;
     bil2_src(oy, H, y0, y1, ly);
@@ -205,13 +196,11 @@ __global__ __launch_bounds__(256) void bilinear2_bwd_kernel(const bf16_t* __rest
                                                             int H, int W, int C) {
   const int cpr = C >> 3;
   const int Ho = H * 2, Wo = W * 2;
-  const size_t total = (size_t)B * H * W * cpr;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int cc = (int)(i % cpr);
-    size_t p = i / cpr;
-    const int x = (int)(p % W); p /= W;
-    const int y = (int)(p % H);
-    const int b = (int)(p / H);
+  for (int row_ = blockIdx.y; row_ < B * H; row_ += gridDim.y)  // grid.y = (image, row): no 64-bit divisions per item
+  for (int t_ = blockIdx.x * 256 + threadIdx.x; t_ < W * cpr; t_ += gridDim.x * 256) {
+    const int b = row_ / H, y = row_ - b * H;
+    const int x = t_ / cpr, cc = t_ - x * cpr;
+    const size_t i = ((size_t)row_ * W + x) * cpr + cc;
     float g[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) g[e] = 0.f;
@@ -302,13 +291,15 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const StemImages imgs,
 
 }  // namespace
 
+static unsigned rows_grid(long long rows) { return (unsigned)(rows < 65535 ? (rows > 0 ? rows : 1) : 65535); }
+
 extern "C" int u2_maxpool3x3s2_fwd(const void* x, void* y, void* idx, int B, int H, int W, int C, void* stream) {
   if (C & 7) return -1;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const size_t total = (size_t)B * Ho * Wo * (C >> 3);
   if (!total) return 0;
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                     (bf16_t*)y, (uint8_t*)idx, B, H, W, C, Ho, Wo);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((Wo * (C >> 3) + 255) / 256, rows_grid(B * Ho)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (bf16_t*)y, (uint8_t*)idx, B, H, W, C, Ho, Wo);
   U2_CHECK_LAUNCH();
   return 0;
 }
@@ -318,8 +309,8 @@ extern "C" int u2_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, in
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const size_t total = (size_t)B * H * W * (C >> 3);
   if (!total) return 0;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
-                     (const uint8_t*)idx, (bf16_t*)dx, B, H, W, C, Ho, Wo);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((W * (C >> 3) + 255) / 256, rows_grid(B * H)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, (const uint8_t*)idx, (bf16_t*)dx, B, H, W, C, Ho, Wo);
   U2_CHECK_LAUNCH();
   return 0;
 }
@@ -329,7 +320,7 @@ extern "C" int u2_fpn_upsample_add_fwd(const void* lateral, const void* top, voi
   if ((C & 7) || (H & 1) || (W & 1)) return -1;
   const size_t total = (size_t)B * H * W * (C >> 3);
   if (!total) return 0;
-  hipLaunchKernelGGL(upadd_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)lateral,
+  hipLaunchKernelGGL(upadd_fwd_kernel, dim3((W * (C >> 3) + 255) / 256, rows_grid(B * H)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)lateral,
                      (const bf16_t*)top, (bf16_t*)out, B, H, W, C);
   U2_CHECK_LAUNCH();
   return 0;
@@ -339,7 +330,7 @@ extern "C" int u2_fpn_upsample_add_bwd(const void* dout, void* dtop, int B, int 
   if ((C & 7) || (H & 1) || (W & 1)) return -1;
   const size_t total = (size_t)B * (H / 2) * (W / 2) * (C >> 3);
   if (!total) return 0;
-  hipLaunchKernelGGL(upadd_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
+  hipLaunchKernelGGL(upadd_bwd_kernel, dim3(((W / 2) * (C >> 3) + 255) / 256, rows_grid(B * (H / 2))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
                      (bf16_t*)dtop, B, H, W, C);
   U2_CHECK_LAUNCH();
   return 0;
@@ -349,7 +340,7 @@ extern "C" int u2_bilinear_up2_fwd(const void* x, const void* addend, void* out,
   if (C & 7) return -1;
   const size_t total = (size_t)B * H * 2 * W * 2 * (C >> 3);
   if (!total) return 0;
-  hipLaunchKernelGGL(bilinear2_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+  hipLaunchKernelGGL(bilinear2_fwd_kernel, dim3((W * 2 * (C >> 3) + 255) / 256, rows_grid(B * H * 2)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      (const bf16_t*)addend, (bf16_t*)out, B, H, W, C);
   U2_CHECK_LAUNCH();
   return 0;
@@ -359,7 +350,7 @@ extern "C" int u2_bilinear_up2_bwd(const void* dout, void* dx, int B, int H, int
   if (C & 7) return -1;
   const size_t total = (size_t)B * H * W * (C >> 3);
   if (!total) return 0;
-  hipLaunchKernelGGL(bilinear2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
+  hipLaunchKernelGGL(bilinear2_bwd_kernel, dim3((W * (C >> 3) + 255) / 256, rows_grid(B * H)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
                      (bf16_t*)dx, B, H, W, C);
   U2_CHECK_LAUNCH();
   return 0;
