@@ -485,3 +485,33 @@ def test_detector_postprocess_batch_equals_per_image_rule():
         assert torch.equal(o.pred_boxes.tensor, t[keep]) and torch.equal(o.scores, inst.scores[keep])
         assert torch.equal(o.pred_classes, inst.pred_classes[keep]) and o.image_size == (oh, ow)
     assert dropped > 0
+
+
+def test_topk_rows_sorted_fallback_total_order():
+    """Selections with k beyond the HIP kernel's LDS-resident limit (16 384; e.g. the reference's default PRE_NMS_TOPK of 12 000
+    summed over the levels in the score sort before NMS) go through a stable device sort: same total order (value, then index),
+    same outputs as the kernel's contract - here against an explicit per-row stable sort, with ties, a mask, +-0 and the
+    (group, pitch) view of a 32-wide map."""
+    import u2seg_amd.layers.functional as F
+
+    g = torch.Generator().manual_seed(1)
+    rows, n, k = 3, 40000, 20000
+    v = (torch.randn((rows, n), generator=g) * 2).mul(4).round().div(4)
+    v[0, 5], v[0, 6] = -0.0, 0.0
+    mask = torch.randint(0, 2, (rows, n), generator=g).to(torch.int8)
+    mask[2] = 0
+    mask[2, :100] = 1  # fewer participants than k
+    for largest in (True, False):
+        out, idx, cnt = F._topk_rows_sorted(dict(vals=v, k=k, largest=largest, mask=mask, mask_value=1))
+        for r in range(rows):
+            sel = torch.nonzero(mask[r] == 1)[:, 0]
+            ref = sel[torch.sort(v[r, sel], descending=largest, stable=True)[1]][:k]
+            c = min(k, len(sel))
+            assert int(cnt[r]) == c and torch.equal(idx[r, :c].long(), ref[:c]) and torch.equal(out[r, :c], v[r, ref[:c]])
+            assert bool((idx[r, c:] == 0).all()) and bool(torch.isinf(out[r, c:]).all())
+    m = torch.randn((2, 5000, 32), generator=g).bfloat16()
+    out, idx, cnt = F._topk_rows_sorted(dict(vals=m, k=14000, largest=True, group=3, pitch=32, n=15000))
+    flat = m[..., :3].reshape(2, -1).float()
+    for r in range(2):
+        assert torch.equal(idx[r].long(), torch.sort(flat[r], descending=True, stable=True)[1][:14000])
+    assert F._TOPK_MAX_K == 16384

@@ -1163,6 +1163,11 @@ def topk_rows_multi(specs):
     keep = []  # the intermediate tensors are referenced by raw pointers only: they must outlive the launches below
     for j, sp in enumerate(specs):
         vals, k, largest = sp["vals"], int(sp["k"]), int(bool(sp.get("largest", True)))
+        if k > _TOPK_MAX_K:
+            # beyond the kernel's LDS-resident survivor list (e.g. PRE_NMS_TOPK = 12000 summed over the levels): a stable
+            # device sort gives the same total order
+            results[j] = _topk_rows_sorted(sp)
+            continue
         mask, mask_value = sp.get("mask"), int(sp.get("mask_value", 1))
         group, pitch, n, want_vals = int(sp.get("group", 1)), int(sp.get("pitch", 1)), sp.get("n"), sp.get("want_vals", True)
         assert vals.is_cuda and vals.dtype in (torch.float32, BF16) and vals.is_contiguous()
@@ -1201,6 +1206,40 @@ def topk_rows_multi(specs):
             _hip.call("u2_topk_rows_multi", (_TopkSeg * len(part))(*part), len(part))
     del keep
     return results
+
+
+_TOPK_MAX_K = 16384  # u2_topk_rows keeps the k survivors of a row in LDS (8 bytes each)
+
+
+def _topk_rows_sorted(sp):
+    """topk_rows for k beyond the kernel's limit: torch's stable sort on the device under the same total order (value descending /
+    ascending, index ascending; -0.0 equal to +0.0), same outputs (padding: index 0, value -/+ inf)."""
+    vals, k, largest = sp["vals"], int(sp["k"]), bool(sp.get("largest", True))
+    mask, mask_value = sp.get("mask"), int(sp.get("mask_value", 1))
+    group, pitch, n = int(sp.get("group", 1)), int(sp.get("pitch", 1)), sp.get("n")
+    rows = vals.shape[0]
+    if n is None:
+        n = vals.shape[1]
+    v = vals.reshape(rows, -1)
+    if group != 1 or pitch != 1:
+        v = v.reshape(rows, -1, pitch)[:, : n // group, :group].reshape(rows, n)
+    v = v[:, :n].float()
+    fill = float("-inf") if largest else float("inf")
+    part = torch.ones_like(v, dtype=torch.bool) if mask is None else (mask == mask_value)
+    order = torch.sort(torch.where(part, v, torch.full_like(v, fill)), dim=1, descending=largest, stable=True)[1]
+    # elements that do not take part may tie with real -inf / +inf values: rank them last explicitly
+    order = torch.gather(order, 1, torch.sort((~torch.gather(part, 1, order)).to(torch.int8), dim=1, stable=True)[1])[:, :k]
+    cnt = part.sum(dim=1).clamp(max=k).to(torch.int32)
+    real = torch.arange(order.shape[1], device=v.device)[None] < cnt[:, None]
+    idx = torch.where(real, order, torch.zeros_like(order)).to(torch.int32)
+    out = None
+    if sp.get("want_vals", True):
+        out = torch.where(real, torch.gather(v, 1, order), torch.full_like(v[:, : order.shape[1]], fill))
+    if idx.shape[1] < k:  # k larger than the row
+        pad = k - idx.shape[1]
+        idx = torch.nn.functional.pad(idx, (0, pad))
+        out = torch.nn.functional.pad(out, (0, pad), value=fill) if out is not None else None
+    return out, idx, cnt
 
 
 def _topk_segments(rows, n, group, pitch, row_stride, k):
