@@ -1,5 +1,5 @@
-"""Static check of the generated gfx950 code: registers that an inline-asm load still has in flight are never copied by the
-compiler before the hand-written wait (tools/check_inflight_moves.py; the failure mode of kmeans_screen_kernel in round 3:
+"""Static check of the generated gfx950 code: registers that an inline-asm load still has in flight are never touched by a
+compiler-generated instruction before the hand-written wait (tools/check_inflight_moves.py; the failure mode of kmeans_screen_kernel in round 3:
 loop-carried asm loads, a v_mov at the back-edge in front of the s_waitcnt, wrong labels in 1 run of the GPU suite in 6)."""
 import os
 import shutil

@@ -297,7 +297,12 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
-  for (int s = 0; s < nsteps; ++s) {
+  // One step; LOAD: x(s + 1) is fetched, STAGE: centroids(s + 2) are staged.  The three forms (steady state, last but one,
+  // last) are separate straight-line instances, so that the wait that closes a step is unconditional in the generated code
+  // (tools/check_inflight_moves.py follows every path of the control-flow graph, also the infeasible one that skips two
+  // complementary conditional waits).
+  auto step = [&](int s, auto load_tag, auto stage_tag) {
+    constexpr bool LOAD = decltype(load_tag)::value, STAGE = decltype(stage_tag)::value;
     __builtin_amdgcn_s_barrier();  // stage s is complete for every wave, and every wave is done with stage s - 1
     asm volatile("" ::: "memory");
     // split this step's x into its two bf16 pieces (MFMA A operands)
@@ -315,8 +320,8 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
       ah[m] = *reinterpret_cast<const s16x8*>(h);
       al[m] = *reinterpret_cast<const s16x8*>(l);
     }
-    if (s + 1 < nsteps) load_x();
-    if (s + 2 < nsteps) stage_c((s + 2) % KS_RING);
+    if (LOAD) load_x();
+    if (STAGE) stage_c((s + 2) % KS_RING);
     const unsigned char* sb = ks_smem + (s % KS_RING) * KS_STAGE + boff;
     // Two centroid blocks at a time, piece by piece: consecutive MFMAs go to four different accumulators, so the three products
     // of one accumulator (hi.hi, hi.lo, lo.hi) are four issue slots apart instead of back to back (-4 % kernel time; a second
@@ -342,10 +347,14 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
       acc[1][nb + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[1], bh1, acc[1][nb + 1], 0, 0, 0);
     }
     // close the step: centroids(s + 1) and x(s + 1) have landed, only centroids(s + 2) stays in flight over the back-edge
-    if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS_DMA) : "memory");
+    if (STAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS_DMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
-  }
+  };
+  int s = 0;
+  for (; s + 2 < nsteps; ++s) step(s, std::true_type{}, std::true_type{});
+  if (s + 1 < nsteps) { step(s, std::true_type{}, std::false_type{}); ++s; }
+  step(s, std::false_type{}, std::false_type{});
   __syncthreads();
   // |x| per point: the four k-chunk lanes of a row, then through LDS into the D layout (lane (fg, fr): points fg * 4 + r)
   float* norms = reinterpret_cast<float*>(ks_smem);
