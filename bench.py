@@ -268,7 +268,7 @@ def per_layer_report(timer, sampled):
         d[0] += 1
         d[1] += s.elapsed_time(e)
         d[2] += fl
-    for (name, shape), d in sorted(agg.items(), key=lambda kv: -kv[1][1])[:48]:
+    for (name, shape), d in sorted(agg.items(), key=lambda kv: -kv[1][1])[:90]:
         print("LAYER %-14s %-70s n=%3d  %7.3f ms/step  %7.1f TF/s" % (name, shape, d[0] / sampled, d[1] / sampled,
                                                                      d[2] / (d[1] * 1e-3) / 1e12), file=sys.stderr)
 

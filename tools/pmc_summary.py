@@ -15,5 +15,5 @@ for f in files:
         agg[k][1] += float(r.get("Counter_Value", 0) or 0)
 rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
 print("kernel,counter,launches,total,mean_per_launch")
-for (k, c), (n, tot) in rows[:40]:
+for (k, c), (n, tot) in rows[:120]:
     print('"%s",%s,%d,%.6g,%.6g' % (k, c, n, tot, tot / max(n, 1)))

@@ -278,6 +278,7 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
       cp[i] += 32;
     }
   };
+  const unsigned lds0 = (unsigned)(size_t)U2_LDS_PTR(ks_smem);
   const int boff = fr * 64 + ((fg ^ ks_swz(fr)) << 4);  // B fragment of block nb, plane pl: + (pl * 320 + nb * 16) * 64
 
   f32x4 acc[2][KS_NB];
@@ -322,30 +323,58 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     }
     if (LOAD) load_x();
     if (STAGE) stage_c((s + 2) % KS_RING);
-    const unsigned char* sb = ks_smem + (s % KS_RING) * KS_STAGE + boff;
     // Two centroid blocks at a time, piece by piece: consecutive MFMAs go to four different accumulators, so the three products
     // of one accumulator (hi.hi, hi.lo, lo.hi) are four issue slots apart instead of back to back (-4 % kernel time; a second
     // register set that keeps two steps of x in flight from HBM changed nothing: the waves' 43 % parked cycles - PMC, round 3 -
-    // are not the x loads)
-#pragma unroll
-    for (int nb = 0; nb < KS_NB; nb += 2) {
-      const s16x8 bh0 = *reinterpret_cast<const s16x8*>(sb + nb * 1024);
-      const s16x8 bh1 = *reinterpret_cast<const s16x8*>(sb + (nb + 1) * 1024);
-      const s16x8 bl0 = *reinterpret_cast<const s16x8*>(sb + KS_KMAX * 64 + nb * 1024);
-      const s16x8 bl1 = *reinterpret_cast<const s16x8*>(sb + KS_KMAX * 64 + (nb + 1) * 1024);
-      acc[0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bh0, acc[0][nb], 0, 0, 0);
-      acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], bh0, acc[1][nb], 0, 0, 0);
-      acc[0][nb + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bh1, acc[0][nb + 1], 0, 0, 0);
-      acc[1][nb + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], bh1, acc[1][nb + 1], 0, 0, 0);
-      acc[0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bl0, acc[0][nb], 0, 0, 0);
-      acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], bl0, acc[1][nb], 0, 0, 0);
-      acc[0][nb + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bl1, acc[0][nb + 1], 0, 0, 0);
-      acc[1][nb + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], bl1, acc[1][nb + 1], 0, 0, 0);
-      acc[0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[0], bh0, acc[0][nb], 0, 0, 0);
-      acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[1], bh0, acc[1][nb], 0, 0, 0);
-      acc[0][nb + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[0], bh1, acc[0][nb + 1], 0, 0, 0);
-      acc[1][nb + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[1], bh1, acc[1][nb + 1], 0, 0, 0);
+    // were not the x loads).  Round 4: they were the centroid fragments - the compiler had scheduled every pair as
+    // `4 x ds_read_b128; s_waitcnt lgkmcnt(0); 12 x v_mfma`, ten exposed LDS round trips per step with both waves of a SIMD in
+    // the same phase.  The fragments of pair g + 1 are now requested in front of the MFMAs of pair g (two register sets, the
+    // fences keep the order), so a read has twelve MFMAs to land.
+    // The reads and their waits are inline asm: with plain loads the compiler's wait-count pass answers every second pair with
+    // s_waitcnt lgkmcnt(0) although LDS returns in order (it will not count across the LDS-DMA in flight), which exposes the
+    // round trip it was supposed to hide.  The wait names the four registers it releases, so no MFMA can move in front of it.
+    s16x8 bq[2][4];   // [set][hi block 0, hi block 1, lo block 0, lo block 1]
+    const unsigned sba = lds0 + (unsigned)((s % KS_RING) * KS_STAGE) + (unsigned)boff;
+#define U2_KS_LDQ(SET, NB)                                                                                                    \
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t"         \
+                 "ds_read_b128 %3, %4 offset:%8"                                                                               \
+                 : "=&v"(bq[SET][0]), "=&v"(bq[SET][1]), "=&v"(bq[SET][2]), "=&v"(bq[SET][3])                                 \
+                 : "v"(sba), "n"((NB) * 1024), "n"(((NB) + 1) * 1024), "n"(KS_KMAX * 64 + (NB) * 1024),                       \
+                   "n"(KS_KMAX * 64 + ((NB) + 1) * 1024)                                                                      \
+                 : "memory")
+#define U2_KS_WAIT(SET, CNT)                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bq[SET][0]), "+v"(bq[SET][1]), "+v"(bq[SET][2]), "+v"(bq[SET][3]) : "n"(CNT) : "memory")
+#define U2_KS_PAIR(SET, NB)                                                                                                   \
+    {                                                                                                                          \
+      const s16x8 bh0 = bq[SET][0], bh1 = bq[SET][1], bl0 = bq[SET][2], bl1 = bq[SET][3];                                     \
+      acc[0][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bh0, acc[0][NB], 0, 0, 0);                                  \
+      acc[1][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], bh0, acc[1][NB], 0, 0, 0);                                  \
+      acc[0][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bh1, acc[0][NB + 1], 0, 0, 0);                          \
+      acc[1][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], bh1, acc[1][NB + 1], 0, 0, 0);                          \
+      acc[0][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bl0, acc[0][NB], 0, 0, 0);                                  \
+      acc[1][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], bl0, acc[1][NB], 0, 0, 0);                                  \
+      acc[0][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bl1, acc[0][NB + 1], 0, 0, 0);                          \
+      acc[1][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], bl1, acc[1][NB + 1], 0, 0, 0);                          \
+      acc[0][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[0], bh0, acc[0][NB], 0, 0, 0);                                  \
+      acc[1][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[1], bh0, acc[1][NB], 0, 0, 0);                                  \
+      acc[0][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[0], bh1, acc[0][NB + 1], 0, 0, 0);                          \
+      acc[1][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[1], bh1, acc[1][NB + 1], 0, 0, 0);                          \
     }
+    // pair g + 1 is requested in front of the MFMAs of pair g: the wait of pair g leaves the 4 younger reads in flight
+#define U2_KS_GROUP(SET, NB)                                                                                                  \
+    U2_KS_LDQ((SET) ^ 1, (NB) + 2);                                                                                            \
+    U2_KS_WAIT(SET, 4);                                                                                                        \
+    U2_KS_PAIR(SET, NB)
+    static_assert(KS_NB == 20, "the unrolled pair sequence below covers 20 centroid blocks");
+    U2_KS_LDQ(0, 0);
+    U2_KS_GROUP(0, 0) U2_KS_GROUP(1, 2) U2_KS_GROUP(0, 4) U2_KS_GROUP(1, 6) U2_KS_GROUP(0, 8)
+    U2_KS_GROUP(1, 10) U2_KS_GROUP(0, 12) U2_KS_GROUP(1, 14) U2_KS_GROUP(0, 16)
+    U2_KS_WAIT(1, 0);
+    U2_KS_PAIR(1, 18)
+#undef U2_KS_GROUP
+#undef U2_KS_PAIR
+#undef U2_KS_WAIT
+#undef U2_KS_LDQ
     // close the step: centroids(s + 1) and x(s + 1) have landed, only centroids(s + 2) stays in flight over the back-edge
     if (STAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS_DMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -367,36 +396,66 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
   }
   __syncthreads();
   const float margin_unit = 1e-4f * sqrtf(__uint_as_float(*cmax2));
+  // Branch-free arg-min (round 4: the first version - km_less per element, one global load of |c_j|^2 per use, ds_bpermute
+  // shuffles - compiled to ~700 divergent branches and was 0.32 of the kernel's 1.8 ms, with the matrix pipe idle meanwhile).
+  // NaN needs no ordering here: a NaN or Inf in x makes |x| and therefore the margin NaN / Inf, one in c makes max|c| NaN, and
+  // `!(gap >= margin)` then sends the point to the exact kernel, which orders NaNs like torch.argmin; v_min / v_cmp_lt simply
+  // skip the NaN operands.  Ties keep the lowest index: ascending blocks with a strict compare inside a lane, (value, index)
+  // order in the cross-lane steps.
+  float cnr[KS_NB];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int nb = 0; nb < KS_NB; ++nb) {
+    const int j = nb * 16 + fr;
+    cnr[nb] = cn[min(j, K - 1)];
+    cnr[nb] = j < K ? cnr[nb] : INFINITY;
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    float b[4], s2[4];
+    int bn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { b[r] = INFINITY; s2[r] = INFINITY; bn[r] = 0; }
+#pragma unroll
+    for (int nb = 0; nb < KS_NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = fmaf(acc[m][nb][r], -2.f, cnr[nb]);   // cn - 2 x.c (the product by 2 is exact: same value as before)
+        const bool lt = v < b[r];
+        s2[r] = fminf(s2[r], lt ? b[r] : v);
+        bn[r] = lt ? nb : bn[r];
+        b[r] = fminf(b[r], v);
+      }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float b = INFINITY, s2 = INFINITY;
-      int bj = 0x7fffffff;
-#pragma unroll
-      for (int nb = 0; nb < KS_NB; ++nb) {
-        const int j = nb * 16 + fr;
-        if (j < K) {
-          const float v = cn[j] - 2.f * acc[m][nb][r];
-          if (km_less(v, j, b, bj)) { s2 = b; b = v; bj = j; }
-          else if (v < s2) s2 = v;
-        }
+      int bj = bn[r] * 16 + fr;
+      float bb = b[r], ss = s2[r];
+      // the 16 lanes of a DPP row hold the 16 centroids of every block: xor 1, xor 2 (quad permutes), then the other quad of
+      // the half row, then the other half row (all lanes of a quad / a half row agree by then)
+#define U2_KS_MERGE(CTRL)                                                                                                   \
+      {                                                                                                                      \
+        const float ob = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bb), CTRL, 0xf, 0xf, true));           \
+        const float os = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), CTRL, 0xf, 0xf, true));           \
+        const int oj = __builtin_amdgcn_update_dpp(0, bj, CTRL, 0xf, 0xf, true);                                            \
+        const bool lt = ob < bb || (ob == bb && oj < bj);                                                                    \
+        ss = fminf(fminf(ss, os), lt ? bb : ob);                                                                             \
+        bj = lt ? oj : bj;                                                                                                   \
+        bb = fminf(bb, ob);                                                                                                  \
       }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        const float ob = __shfl_xor(b, o, 64), os2 = __shfl_xor(s2, o, 64);
-        const int obj = __shfl_xor(bj, o, 64);
-        if (km_less(ob, obj, b, bj)) { s2 = fminf(b, os2); b = ob; bj = obj; }
-        else s2 = fminf(s2, ob);
-      }
+      U2_KS_MERGE(0xB1)    // quad_perm [1, 0, 3, 2]
+      U2_KS_MERGE(0x4E)    // quad_perm [2, 3, 0, 1]
+      U2_KS_MERGE(0x141)   // row_half_mirror
+      U2_KS_MERGE(0x140)   // row_mirror
+#undef U2_KS_MERGE
       const int pl = m * 16 + fg * 4 + r;
       const int p = p0 + pl;
       if (fr == 0 && p < N) {
         labels[p] = (long long)bj;
-        if (!(s2 - b >= margin_unit * norms[w * 32 + pl])) list[atomicAdd(nlist, 1)] = p;  // also: NaN anywhere, K == 1
+        if (!(ss - bb >= margin_unit * norms[w * 32 + pl])) list[atomicAdd(nlist, 1)] = p;  // also: NaN anywhere, K == 1
       }
     }
+  }
 }
+
 
 // csum[K][D] += x rows by label; counts[K] += 1.  grid = (point chunks, D / DS); LDS holds [K][DS] partial sums.
 template <int DS>
