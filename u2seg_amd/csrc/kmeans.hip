@@ -210,12 +210,20 @@ __global__ __launch_bounds__(256) void csplit_kernel(const float* __restrict__ c
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= KS_KMAX) return;
   float s = 0.f;
+  // Within every 32-dimension step the dimensions are stored in the order the screening kernel's x loads deliver them: position
+  // fg * 8 + e holds dimension fg * 4 + e (e < 4) or 16 + fg * 4 + (e - 4) - a lane of the MFMA A operand then gets its eight
+  // values from two 16-byte loads that are 64 bytes apart, and the four lanes of a row read 64 contiguous bytes per instruction.
   for (int d = threadIdx.x & 63; d < D; d += 64) {
-    const float v = j < K ? c[(size_t)j * D + d] : 0.f;
+    const int pos = d & 31, fgp = pos >> 3, e = pos & 7;
+    const int src = (d & ~31) + ((e < 4) ? fgp * 4 + e : 16 + fgp * 4 + (e - 4));
+    const float v = j < K ? c[(size_t)j * D + src] : 0.f;
     const bf16_t h = f2bf(v);
     chl[(size_t)j * D + d] = h;
     chl[((size_t)KS_KMAX + j) * D + d] = f2bf(v - bf2f(h));
-    s += v * v;
+    // |c_j|^2 is summed over the UNPERMUTED dimensions, lane by lane exactly as cnorm_kernel does: the re-check must see the
+    // same bits as a run of the exact kernel alone, or near-duplicate centroids (exact-fp32 ties) are decided differently
+    const float u = j < K ? c[(size_t)j * D + d] : 0.f;
+    s += u * u;
   }
   if (j >= K) return;
   s = wave_sum(s);
@@ -245,10 +253,13 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
   const int p0 = blockIdx.x * KS_PTS + w * 32;
   const int nsteps = D >> 5;
 
-  // x: lane (fr, fg) owns row m * 16 + fr, dimensions d0 + fg * 8 .. + 7 of both 16-point blocks (the MFMA A layout)
+  // x: lane (fr, fg) owns row m * 16 + fr of both 16-point blocks and, per 32-dimension step, dimensions fg * 4 .. + 3 and
+  // 16 + fg * 4 .. + 3 (csplit_kernel stores the centroids' dimensions in the matching order): the four lanes of a row read 64
+  // contiguous bytes per load instruction, every 64-byte sector is requested once (with fg * 8 .. + 7 per lane each sector was
+  // requested by both instructions)
   const float* xp[2];
 #pragma unroll
-  for (int m = 0; m < 2; ++m) xp[m] = x + (size_t)min(p0 + m * 16 + fr, N - 1) * D + fg * 8;
+  for (int m = 0; m < 2; ++m) xp[m] = x + (size_t)min(p0 + m * 16 + fr, N - 1) * D + fg * 4;
   // Inline-asm loads (the compiler would drain the LDS-DMA ring in front of the first use of a load it can see).  The
   // registers are loaded in step s and split in step s + 1, i.e. loop-carried, and the compiler - which does not know the data is
   // in flight - is free to move them (it did: v_mov at the back-edge, in front of a wait that used to sit at the top of the
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
   auto load_x = [&]() {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+      asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64"
                    : "=&v"(raw[m][0]), "=&v"(raw[m][1]) : "v"(xp[m]) : "memory");
       xp[m] += 32;
     }
