@@ -149,6 +149,17 @@ int main(int argc, char** argv) {
   char* src; float* sink;
   HIPCHK(hipMalloc(&src, total + (1 << 20))); HIPCHK(hipMemset(src, 1, total)); HIPCHK(hipMalloc(&sink, 64));
   if (argc > 1 && argv[1][0] == 's') { store_bench(src, sink); return 0; }
+  if (argc > 1 && argv[1][0] == 'h') {
+    // 2 MiB per work-group: 512 MiB (one group per CU) / 1 GiB (two) of footprint cycled 16 / 8 times - beyond the 256 MiB MALL,
+    // i.e. the HBM read rate itself (the 1 MiB windows below stay MALL-resident)
+    const size_t window = (size_t)2 << 20;
+    run<3, 8>("glds 1 KiB contiguous", src, window, 512, sink);
+    run<2, 8>("glds 4 rows x 256 B (pitch 512)", src, window, 512, sink);
+    run<1, 8>("glds 8 rows x 128 B (pitch 512)", src, window, 512, sink);
+    run<0, 8>("glds 16 rows x 64 B (pitch 512)", src, window, 512, sink);
+    run<5, 8>("global_load_dwordx4 -> VGPR, 1 KiB contiguous", src, window, 512, sink);
+    return 0;
+  }
   for (size_t window : {(size_t)64 << 10, (size_t)1 << 20}) {   // 64 KiB per CU: L2-resident; 1 MiB per CU x 512: MALL / HBM
     run<0, 8>("glds 16 rows x 64 B (pitch 512)", src, window, 512, sink);
     run<1, 8>("glds 8 rows x 128 B (pitch 512)", src, window, 512, sink);

@@ -202,6 +202,8 @@ static void bench2(int argc, char** argv, bool wgrad) {
       {"res2 1x1 256->64 200x336", 16, 200, 336, 256, 64, 1, 0, 1, 0, 0, 1},
       {"res2 1x1 64->256 200x336", 16, 200, 336, 64, 256, 1, 0, 1, 0, 0, 1},
       {"lat2 1x1 256->256 200x336", 16, 200, 336, 256, 256, 1, 0, 1, 0, 0, 1},
+      {"sem 1x1 256->128 200x336", 16, 200, 336, 256, 128, 1, 0, 1, 0, 0, 1},
+      {"res2 1x1 64->64 200x336", 16, 200, 336, 64, 64, 1, 0, 1, 0, 0, 1},
       {"lat3 1x1 512->256 100x168", 16, 100, 168, 512, 256, 1, 0, 1, 0, 0, 1},
       {"res3 1x1 256->512 100x168", 16, 100, 168, 256, 512, 1, 0, 1, 0, 0, 0},
       {"res5 1x1 512->2048 25x42", 16, 25, 42, 512, 2048, 1, 0, 1, 0, 0, 1},
@@ -237,7 +239,9 @@ static void bench2(int argc, char** argv, bool wgrad) {
       HIPCHK(hipMemcpy(dw.d + o, pat.data(), std::min(pat.size(), w_elems - o) * 2, hipMemcpyHostToDevice));
   }
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  const char* only = getenv("U2_BENCH_LAYERS");   // substring filter on the layer names
   for (const auto& L : layers) {
+    if (only && !strstr(L.name, only)) continue;
     const int Hout = (L.H + 2 * L.pad - L.K) / L.stride + 1, Wout = (L.W + 2 * L.pad - L.K) / L.stride + 1;
     const double M = (double)L.B * Hout * Wout;
     const double flop = 2.0 * M * L.N * L.K * L.K * L.C;

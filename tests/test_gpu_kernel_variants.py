@@ -49,7 +49,7 @@ def nchw(x_nhwc, c):
 
 
 def rel_err(a, b):
-    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    return float((a.detach() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-12))
 
 
 @contextlib.contextmanager
@@ -144,6 +144,44 @@ def test_conv_forced_variant_fwd_bwd(F, variant, code):
     assert rel_err(wd.grad.cpu(), w.grad) < WG_TOL
 
 
+STREAM = 1 << 17   # conv_stream.hip wherever it applies; bit 16: 8 work-groups per 256-channel block (many tiles per group)
+
+
+@pytest.mark.parametrize("tiny", [0, 1])
+@pytest.mark.parametrize("cout", [40, 104, 264, 520])
+@pytest.mark.parametrize("cin", [32, 64, 128, 256])
+def test_conv_stream_kernel(F, cin, cout, tiny):
+    """conv_stream_kernel<KS, TM, PSW, NWV> (1x1, weights resident in registers, whole pixel rows through the LDS ring): all
+    twelve instantiations (C = 32 / 64 / 128 / 256 x 1 / 2 / 4 waves along the pixels; N = 520: three 256-channel blocks), a
+    ragged last pixel tile and a ragged last channel block, with BN statistics and with bias + ReLU, forward and data
+    gradient (the transposed 1x1) vs fp32."""
+    g = torch.Generator().manual_seed(cin * 1000 + cout + tiny)
+    b, h, w_ = 3, 37, 29   # M = 3219: not a multiple of any tile
+    x = bf(torch.randn((b, cin, h, w_), generator=g))
+    w = (torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5).requires_grad_(True)
+    bias = torch.randn(cout, generator=g) * 0.1
+    code = 700 + (cin // 32) * 10 + (0 if cout > 128 else 1 if cout > 64 else 2)
+    xr = x.clone().requires_grad_(True)
+    yr = TF.conv2d(xr, bf(w), None)
+    gy = bf(torch.randn(yr.shape, generator=g))
+    yr.backward(gy)
+    xd = nhwc(x).requires_grad_(True)
+    wd = w.detach().to(DEV).requires_grad_(True)
+    with forced(conv=STREAM | (tiny << 16)):
+        y, stats = F._Conv2dFn.apply(xd, wd, None, 1, 0, False, True)
+        assert last_kernel() == code, (last_kernel(), code)
+        yb = F.conv2d(nhwc(x), w.detach().to(DEV), bias.to(DEV), 1, 0, relu=True)
+        assert last_kernel() == code
+        y.backward(nhwc(gy))
+    yy = nchw(y, cout)
+    assert rel_err(yy, yr.detach()) < ULP
+    assert float(y[..., cout:].abs().max()) == 0.0
+    assert torch.allclose(stats[0].cpu(), yy.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(stats[1].cpu(), (yy * yy).sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert rel_err(nchw(yb, cout), TF.relu(TF.conv2d(x, bf(w.detach()), bf(bias)))) < ULP
+    assert rel_err(nchw(xd.grad, cin), xr.grad) < ULP
+
+
 @pytest.mark.parametrize("variant,code", [(NEVER_TILE, igemm_code(64, 256, 64, 2)), (NEVER_TILE | 1, igemm_code(64, 256, 64, 2, 0)),
                                           (NEVER_TILE | 32, igemm_code(64, 256, 64, 3)), (NEVER_TILE | 48, igemm_code(64, 256, 64, 4)),
                                           (NEVER_TILE | 4, igemm_code(32, 256, 64, 4)), (NEVER_TILE | 4 | 16, igemm_code(32, 256, 64, 2)),
@@ -227,7 +265,10 @@ FULL_SHAPES = [
     ("rpn conv 3x3 256->256 @100x168 bias relu", 16, 100, 168, 256, 256, 3, 1, True, 501),   # stream-K form of configuration 1
     ("res3 conv2 3x3 128->128 @100x168", 16, 100, 168, 128, 128, 3, 1, False, 300),
     ("res2 conv2 3x3 64->64 @200x336", 16, 200, 336, 64, 64, 3, 1, False, 300),
-    ("res4 conv3 1x1 256->1024 @50x84", 16, 50, 84, 256, 1024, 1, 0, False, 104),
+    ("res4 conv3 1x1 256->1024 @50x84", 16, 50, 84, 256, 1024, 1, 0, False, 780),            # conv_stream.hip
+    ("res2 conv3 1x1 64->256 @200x336", 16, 200, 336, 64, 256, 1, 0, False, 720),
+    ("res2 conv1 1x1 256->64 @200x336", 16, 200, 336, 256, 64, 1, 0, False, 782),
+    ("res3 conv3 1x1 128->512 @100x168", 16, 100, 168, 128, 512, 1, 0, False, 740),
     ("res5 conv1 1x1 2048->512 @25x42", 16, 25, 42, 2048, 512, 1, 0, False, 502),            # 132 tiles: stream-K
     ("fpn_output4 3x3 256->256 @50x84", 16, 50, 84, 256, 256, 3, 1, False, 501),            # 263 tiles: stream-K
     ("mask head 3x3 256->256 @261x14x14 bias relu", 261, 14, 14, 256, 256, 3, 1, True, 101),

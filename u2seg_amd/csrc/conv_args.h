@@ -60,6 +60,10 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s);
 // return convention as launch_conv_tile.  g_last_conv_kernel code: 300.
 int launch_conv_halo(ConvArgs& a, int N, int C, int variant, hipStream_t s);
 
+// conv_stream.hip: 1x1 / stride 1 layers with <= 256 input channels - weights resident in registers, whole pixel rows streamed
+// through an LDS ring; same return convention as launch_conv_tile.  g_last_conv_kernel code: 7xx.
+int launch_conv_stream(ConvArgs& a, int N, int C, int variant, hipStream_t s);
+
 // wgrad_halo.hip: 3x3 / stride 1 / pad 1 weight gradient, all nine taps per work-group with the input halo in LDS; same
 // return convention as launch_conv_tile.  g_last_conv_kernel code: 2900.
 int launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* dw, long long dw_sn, int dw_st, int dw_sc, int n_valid,

@@ -1129,6 +1129,11 @@ int env_variant(const char* name, int variant) {
 int launch_conv(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   variant = env_variant("U2_CONV_VARIANT", variant);
   a.abl = (variant >> 18) & 63;  // measurement switches (conv_args.h); bit 3 = `nt` output stores, applies to every kernel below
+  {  // 1x1 / stride 1 layers with <= 256 input channels on large maps: weights-resident streaming kernel (conv_stream.hip)
+    const int rc = launch_conv_stream(a, N, C, variant, s);
+    if (rc == 1) return 0;
+    if (rc < 0) return rc;
+  }
   {  // 3x3 / stride 1 / pad 1 layers on large maps: halo-staged kernel (conv_halo.hip)
     const int rc = launch_conv_halo(a, N, C, variant, s);
     if (rc == 1) return 0;
