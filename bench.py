@@ -281,6 +281,20 @@ def cpu_baselines_parallel(workloads):
         return dict(zip(workloads, ex.map(cpu_baseline, workloads)))
 
 
+def _spawn_ranks(n):
+    """Re-runs this command line under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1, a free port)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -307,9 +321,15 @@ def main():
         print(json.dumps(cpu_baseline_worker(args.workload)))
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU, the launcher the driver would
+        # use) and pass rank 0's JSON line through; under torchrun the environment already carries WORLD_SIZE
+        sys.exit(_spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is what runs" % (args.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     if world > 1:
@@ -508,14 +528,16 @@ def main():
     else:
         out.update(run_kmeans(args.steps, args.warmup, args.kmeans_data))
     extra = {}
-    if args.workload == "train" and world == 1 and not args.no_extra:
+    if args.workload == "train" and not args.no_extra:
         # BASELINE.json configs[3] and configs[4] in the same invocation, after the timed training region and
-        # with the training state released; each entry is a full bench object (own timed region, roofline, cpu_baseline)
+        # with the training state released; each entry is a full bench object (own timed region, roofline, cpu_baseline at N = 1).
+        # At N > 1 every rank takes part: k-means shards the rows (the M step all-reduces K*D + K partial sums), inference runs
+        # as independent replicas; the barriers of timed() keep the ranks together.
         release()
         for name, fn in (("kmeans", lambda: run_kmeans(10, 2, "mixture")), ("kmeans_randn", lambda: run_kmeans(10, 2, "randn")),
                          ("infer", lambda: run_infer(5, 2))):
             try:
-                extra[name] = dict({"n_gpus": 1, "data": "synthetic"}, **fn())
+                extra[name] = dict({"n_gpus": world, "data": "synthetic"}, **fn())
             except Exception as e:  # an auxiliary workload must never take the headline line down with it
                 extra[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             release()

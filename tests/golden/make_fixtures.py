@@ -1674,6 +1674,65 @@ def gen_checkpoint_matching_fixture():
     print("wrote checkpoint_matching_golden.json:", len(mapping), "entries,", sum(1 for a, b in mapping.items() if a != b), "renamed")
 
 
+REDUCED_MODEL_OPTS = ["MODEL.RESNETS.STEM_OUT_CHANNELS", 8, "MODEL.RESNETS.RES2_OUT_CHANNELS", 16, "MODEL.RESNETS.WIDTH_PER_GROUP", 4,
+                      "MODEL.FPN.OUT_CHANNELS", 32, "MODEL.ROI_BOX_HEAD.FC_DIM", 48, "MODEL.ROI_MASK_HEAD.CONV_DIM", 32,
+                      "MODEL.SEM_SEG_HEAD.CONVS_DIM", 32, "MODEL.ROI_HEADS.NUM_CLASSES", 6, "MODEL.SEM_SEG_HEAD.NUM_CLASSES", 5]
+
+
+def gen_checkpoint_files_fixture():
+    """files in the reference's two ON-DISK forms, written from the reference's own model object.
+      * checkpoint_small.pth - what fvcore's Checkpointer.save writes (checkpoint/detection_checkpoint.py:17-143 on top of it):
+        torch.save({"model": model.state_dict(), "optimizer": ..., "scheduler": ..., "iteration": ...}); model, optimizer and
+        LR scheduler are the reference's (build_model / build_optimizer / WarmupMultiStepLR), the model is u2seg_R50_800 with
+        the widths reduced through its own config keys so that the file stays small (every layer type and every one of the
+        431 state-dict keys is present);
+      * checkpoint_small_d2.pkl - the Detectron2 model-zoo pickle form of U2Seg's dino_RN50_pretrain_d2_format.pkl
+        (u2seg_R50_800.yaml:6): {"model": {backbone names without prefix: ndarray}, "__author__", "matching_heuristics": True};
+      * checkpoint_files_golden.json - crc32 of every tensor of the .pth by model key, and for the .pkl the key -> source key
+        assignment the reference's own align_and_update_state_dicts makes on this model."""
+    import pickle
+
+    import_reference()
+    os.environ.setdefault("CLUSTER_NUM", "800")
+    from detectron2.checkpoint.c2_model_loading import align_and_update_state_dicts
+    from detectron2.config import get_cfg
+    from detectron2.modeling import build_model
+    from detectron2.solver import build_optimizer
+    from detectron2.solver.lr_scheduler import WarmupMultiStepLR
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(REF, "configs/COCO-PanopticSegmentation/u2seg_R50_800.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "MODEL.WEIGHTS", ""] + REDUCED_MODEL_OPTS)
+    torch.manual_seed(11)
+    model = build_model(cfg)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if v.dtype.is_floating_point:
+                v.copy_(det_fill(k, v))
+    opt = build_optimizer(cfg, model)
+    # (the fvcore composite build_lr_scheduler assembles is absent here; the reference's own plain-python scheduler class)
+    sched = WarmupMultiStepLR(opt, list(cfg.SOLVER.STEPS), cfg.SOLVER.GAMMA, cfg.SOLVER.WARMUP_FACTOR, cfg.SOLVER.WARMUP_ITERS,
+                              cfg.SOLVER.WARMUP_METHOD)
+    sd = model.state_dict()
+    torch.save({"model": sd, "optimizer": opt.state_dict(), "scheduler": sched.state_dict(), "iteration": 1234},
+               os.path.join(HERE, "checkpoint_small.pth"))
+    prefix = "backbone.bottom_up."
+    zoo = {k[len(prefix):]: v.numpy().copy() + 1.0 for k, v in sd.items() if k.startswith(prefix) and "num_batches_tracked" not in k}
+    zoo["stem.fc.weight"] = np.zeros((10, 2048), dtype=np.float32)   # ImageNet classifier left-over: reported, not loaded
+    with open(os.path.join(HERE, "checkpoint_small_d2.pkl"), "wb") as f:
+        pickle.dump({"model": zoo, "__author__": "make_fixtures.py (reference model, reduced widths)", "matching_heuristics": True}, f)
+    as_t = {k: torch.from_numpy(v) for k, v in zoo.items()}
+    out = align_and_update_state_dicts(dict(sd), dict(as_t), c2_conversion=False)
+    tag = {id(v): k for k, v in as_t.items()}
+    mapping = {mk: tag[id(v)] for mk, v in out.items() if id(v) in tag}
+    crc = {k: zlib.crc32(v.contiguous().numpy().tobytes()) for k, v in sd.items()}
+    json.dump({"opts": REDUCED_MODEL_OPTS, "pth_crc32": crc, "pth_shapes": {k: list(v.shape) for k, v in sd.items()},
+               "pkl_assignment": mapping, "iteration": 1234},
+              open(os.path.join(HERE, "checkpoint_files_golden.json"), "w"), indent=0)
+    print("wrote checkpoint_small.pth (%d keys, %.2f MB), checkpoint_small_d2.pkl (%d arrays)" % (
+        len(sd), os.path.getsize(os.path.join(HERE, "checkpoint_small.pth")) / 1e6, len(zoo)))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -1690,6 +1749,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.only == "checkpoint":
         gen_checkpoint_matching_fixture()
+        sys.exit(0)
+    if a.only == "checkpoint_files":
+        gen_checkpoint_files_fixture()
         sys.exit(0)
     if a.only == "bf16_units":
         gen_bf16_units_fixture()

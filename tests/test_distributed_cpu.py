@@ -65,6 +65,61 @@ def test_flat_gradient_allreduce_gloo_world2():
         assert out[0] and out[1]
 
 
+def _real_arena_worker(rank, world, port, out):
+    """The real u2seg_R50_800 model's arena (76 M parameters in the optimizer's own layout, 64 MB buckets): the exchange the
+    trainer performs - the heads' tail of the arena started from the model's on_heads_backward_done hook while "backward" is
+    still filling the backbone part, the rest in all_reduce_grads - must give, bit for bit, the result of one unbucketed
+    all-reduce of the whole arena.  (The kernels need a GPU; the exchange, the bucket bounds, the hook and the tail offset do not.)"""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from u2seg_amd.config import get_cfg
+    from u2seg_amd.engine import SimpleTrainer
+    from u2seg_amd.modeling import build_model
+    from u2seg_amd.solver import build_optimizer
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs",
+                                     "COCO-PanopticSegmentation", "u2seg_R50_800.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu"])
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model.train()
+    opt = build_optimizer(cfg, model)
+    SimpleTrainer(model, opt)  # installs the hook that starts the tail exchange
+    ok = opt.total == 76066554 and opt.bucket_elems == (64 << 20) // 4
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = torch.randn(opt.total, generator=g) * torch.logspace(-6, 2, opt.total)  # eight decades of magnitudes
+    # reference: one all-reduce over the whole arena
+    ref = grads.clone()
+    dist.all_reduce(ref)
+    # the trainer's sequence: head gradients are final first -> hook -> backbone gradients arrive -> all_reduce_grads
+    heads = [m for name, m in model.named_children() if name != "backbone"]
+    tail = min(opt.offset_of(p) for m in heads for p in m.parameters() if p.requires_grad)
+    ok = ok and 0 < tail < opt.total and max(opt.offset_of(p) for p in model.backbone.parameters() if p.requires_grad) < tail
+    opt.zero_grad()
+    opt.flat_grad[tail:].copy_(grads[tail:])
+    model.on_heads_backward_done()
+    ok = ok and opt._tail_from == tail and len(opt._pending) == -(-(opt.total - tail) // opt.bucket_elems)
+    opt.flat_grad[:tail].copy_(grads[:tail])  # "backward" finishes the backbone while the tail is being summed
+    scale = opt.all_reduce_grads()
+    ok = ok and scale == 1.0 / world and opt._tail_from is None and not opt._pending
+    ok = ok and torch.equal(opt.flat_grad, ref)
+    # a parameter's gradient view sees the summed values (kernels and the optimizer read the arena through these views)
+    w = model.backbone.bottom_up.stem.conv1.weight
+    off = opt.offset_of(w)
+    ok = ok and torch.equal(w.grad.reshape(-1), ref[off : off + w.numel()])
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_real_model_arena_bucketed_overlapped_exchange_equals_single_allreduce():
+    port = _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_real_arena_worker, args=(2, port, out), nprocs=2, join=True)
+        assert out[0] and out[1]
+
+
 def _data_eval_worker(rank, world, port, out, gold):
     """Two ranks over the real data path and the evaluators: the unseeded TrainingSampler agrees on one seed and the ranks
     take alternating indices of the same permutation stream; the train loader hands each rank IMS_PER_BATCH / world images;

@@ -311,6 +311,59 @@ def test_checkpoint_name_matching_equals_reference():
     assert sum(1 for a, b in want.items() if a != b) == 264 and want["stem.fc.weight"] == "stem.fc.weight"  # unused: passed through
 
 
+def test_reference_checkpoint_files_load_through_the_loader():
+    """files in the reference's two on-disk forms, written from the REFERENCE's model / optimizer /
+    scheduler objects (make_fixtures.py --only checkpoint_files; u2seg_R50_800 with its widths reduced through its own config
+    keys), through u2seg_amd.checkpoint.DetectionCheckpointer (checkpoint/detection_checkpoint.py:70-143):
+      * the `.pth` form fvcore's Checkpointer writes - every one of the 431 tensors arrives bit-identical under its own name,
+        nothing is missing or unexpected, optimizer / scheduler / iteration come back untouched (load without --resume);
+      * the Detectron2 model-zoo `.pkl` form (prefix-free backbone arrays + matching_heuristics) - every array lands on the
+        model key the reference's align_and_update_state_dicts assigns it to, the classifier left-over is reported and not
+        loaded, everything outside the backbone keeps its initial value."""
+    import json
+    import pickle
+
+    from u2seg_amd.checkpoint import DetectionCheckpointer
+    from u2seg_amd.modeling import build_model
+
+    gdir = os.path.join(ROOT, "tests", "golden")
+    fx = json.load(open(os.path.join(gdir, "checkpoint_files_golden.json")))
+    cfg = _cfg()
+    cfg.merge_from_list(fx["opts"])
+    torch.manual_seed(3)
+    model = build_model(cfg)
+    assert {k: list(v.shape) for k, v in model.state_dict().items()} == fx["pth_shapes"]
+    ck = DetectionCheckpointer(model)
+    rest = ck.resume_or_load(os.path.join(gdir, "checkpoint_small.pth"), resume=False)
+    inc = ck.last_incompatible
+    assert not inc.missing_keys and not inc.unexpected_keys and not inc.incorrect_shapes
+    assert rest["iteration"] == fx["iteration"] and "optimizer" in rest and "scheduler" in rest
+    assert rest["optimizer"]["param_groups"] and "last_epoch" in rest["scheduler"]  # the reference objects' own state dicts
+    got = {k: zlib.crc32(v.contiguous().numpy().tobytes()) for k, v in model.state_dict().items()}
+    assert got == fx["pth_crc32"]
+
+    # the model-zoo pickle on a freshly initialised model
+    torch.manual_seed(4)
+    model = build_model(cfg)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    ck = DetectionCheckpointer(model)
+    ck.load(os.path.join(gdir, "checkpoint_small_d2.pkl"), checkpointables=[])
+    zoo = pickle.load(open(os.path.join(gdir, "checkpoint_small_d2.pkl"), "rb"))["model"]
+    assign = fx["pkl_assignment"]
+    after = model.state_dict()
+    loaded = 0
+    for mk, src in assign.items():
+        if mk == src:          # passed through unmatched by the reference (the classifier left-over): must not be in the model
+            assert mk not in after
+            continue
+        assert torch.equal(after[mk], torch.from_numpy(zoo[src])), mk
+        loaded += 1
+    assert loaded == 265 and ck.last_incompatible.unexpected_keys == ["stem.fc.weight"]
+    untouched = [k for k in after if k not in assign]
+    assert untouched and all(torch.equal(after[k], before[k]) for k in untouched)
+    assert sorted(k for k in ck.last_incompatible.missing_keys) == sorted(untouched)
+
+
 def test_resolved_configs_equal_reference():
     """Every key this package's config tree holds has the value the reference resolves for the same yaml (its defaults.py +
     _BASE_ chain; fixture: tests/golden/make_fixtures.py --only config), for the four U2Seg train / eval configs - both

@@ -56,13 +56,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // of the same stream update with atomics: a k-means run of the test-suite was seen (1 run in 8) with the list counter of the
 // screening pass reset WHILE the pass was appending to it - the 8-byte memset queued in front of two kernels had not been
 // executed in front of them.
-__global__ static void u2_zero_words_kernel(unsigned* __restrict__ p, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+__global__ static void u2_fill_words_kernel(unsigned* __restrict__ p, size_t n, unsigned v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
-static inline void u2_zero_words(void* p, size_t nwords, hipStream_t s) {
+static inline void u2_fill_words(void* p, size_t nwords, unsigned v, hipStream_t s) {
   if (nwords == 0) return;
   size_t g = (nwords + 255) / 256;
-  if (g > 256) g = 256;
-  hipLaunchKernelGGL(u2_zero_words_kernel, dim3((unsigned)g), dim3(256), 0, s, (unsigned*)p, nwords);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(u2_fill_words_kernel, dim3((unsigned)g), dim3(256), 0, s, (unsigned*)p, nwords, v);
 }
+static inline void u2_zero_words(void* p, size_t nwords, hipStream_t s) { u2_fill_words(p, nwords, 0u, s); }
 

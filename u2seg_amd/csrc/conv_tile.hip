@@ -17,6 +17,7 @@
 // Wave tile 64 channels x 128 pixels (4 x 8 v_mfma_f32_16x16x32_bf16 accumulators, 12 ds_read_b128 per 32 MFMA);
 // work-group = WCH x WPX waves: 4x2 (256 ch x 256 px, one group per CU), 2x2 and 4x1 (two groups per CU).
 #include <stdlib.h>
+#include <mutex>
 
 #include "common.h"
 #include "conv_args.h"
@@ -548,21 +549,37 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #undef U2_T_MFMA
 }
 
-// stream-K scratch: one fp32 partial-tile slot (256 KB at most) and one flag per work-group, per stream (convolutions of
-// independent branches run concurrently on several streams); allocated on first use, flags zeroed once - the kernel leaves
-// every flag it consumed at zero
-struct SkScratch { hipStream_t stream; float* ws; int* flags; };
+// stream-K scratch: one fp32 partial-tile slot and one flag per work-group, per (device, stream) - convolutions of independent
+// branches run concurrently on several streams, and a process may drive several devices.  Allocated on first use under a mutex
+// (the autograd backward thread and the forward thread both get here), flags zeroed once: the kernel leaves every flag it
+// consumed at zero.  64 MB per entry: the largest launch is 256 work-groups x 256 x 256 fp32 (one group per CU) or 512 x
+// 128 x 256 (two per CU), both 64 MB - a work-group's slot starts at blockIdx.x * TM * TN * 4.
+//
+// Progress: owners wait for peers at the END of their life, peers publish at the START of theirs, and nobody
+// waits before having published.  With the whole grid resident that is trivially deadlock-free.  When another kernel holds some
+// CUs (a side-stream weight gradient, a second stream-K convolution) only the LAST resident work-group of an XCD's chain can be
+// waiting for a peer that has not been dispatched yet - every other owner's peers are resident and have published - so all
+// but at most eight work-groups of the launch run to completion and free their CUs; the hardware dispatches work-groups of a
+// grid in index order, so the missing peer is the next one to get a CU.  The scheme relies on that in-order dispatch (as
+// every persistent-kernel hand-over does); it does NOT rely on co-residency of the whole grid.
+struct SkScratch { int device; hipStream_t stream; float* ws; int* flags; };
 constexpr int SK_MAX_GROUPS = 512;
-bool sk_scratch(hipStream_t s, ConvArgs& a) {
-  static SkScratch table[16];
+constexpr size_t SK_WS_BYTES = (size_t)64 << 20;
+bool sk_scratch(hipStream_t s, ConvArgs& a, size_t need_bytes) {
+  static SkScratch table[32];
   static int used = 0;
+  static std::mutex mu;
+  if (need_bytes > SK_WS_BYTES) return false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lock(mu);
   for (int i = 0; i < used; ++i)
-    if (table[i].stream == s) { a.sk_ws = table[i].ws; a.sk_flags = table[i].flags; return true; }
-  if (used == 16) return false;
-  SkScratch e{s, nullptr, nullptr};
-  if (hipMalloc(&e.ws, (size_t)SK_MAX_GROUPS * 256 * 256 * 4) != hipSuccess) return false;
+    if (table[i].device == dev && table[i].stream == s) { a.sk_ws = table[i].ws; a.sk_flags = table[i].flags; return true; }
+  if (used == 32) return false;
+  SkScratch e{dev, s, nullptr, nullptr};
+  if (hipMalloc(&e.ws, SK_WS_BYTES) != hipSuccess) return false;
   if (hipMalloc(&e.flags, SK_MAX_GROUPS * sizeof(int)) != hipSuccess) { (void)hipFree(e.ws); return false; }
-  if (hipMemset(e.flags, 0, SK_MAX_GROUPS * sizeof(int)) != hipSuccess) return false;
+  if (hipMemset(e.flags, 0, SK_MAX_GROUPS * sizeof(int)) != hipSuccess) { (void)hipFree(e.ws); (void)hipFree(e.flags); return false; }
   table[used++] = e;
   a.sk_ws = e.ws; a.sk_flags = e.flags;
   return true;
@@ -591,7 +608,7 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s, int
     const bool want = sk == 2 || (sk == 1 && WCH == 4 && WPX == 2 && T >= 8 && nkh >= 32 && (util < 0.7 || (util < 0.9 && T >= 512) || (nkh >= 128 && T >= 512)));
     long long Gs = cap;
     while (Gs > 8 && (T / 8) * nkh / (Gs / 8) < RING + 1) Gs -= 8;
-    if (want && (T / 8) * nkh / (Gs / 8) >= RING + 1 && sk_scratch(s, a)) {
+    if (want && Gs <= SK_MAX_GROUPS && (T / 8) * nkh / (Gs / 8) >= RING + 1 && sk_scratch(s, a, (size_t)Gs * TM * TN * 4)) {
       static bool attr_set_sk = false;
       if (!attr_set_sk) {
         (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

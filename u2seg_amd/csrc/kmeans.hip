@@ -543,7 +543,10 @@ __global__ __launch_bounds__(256) void km_hist_kernel(const long long* __restric
   extern __shared__ int hist[];
   for (int j = threadIdx.x; j < K; j += 256) hist[j] = 0;
   __syncthreads();
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)N; i += (size_t)gridDim.x * 256) atomicAdd(&hist[(int)labels[i]], 1);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)N; i += (size_t)gridDim.x * 256) {
+    const long long l = labels[i];
+    if (l >= 0 && l < K) atomicAdd(&hist[(int)l], 1);   // a label outside [0, K) is not a member of any cluster
+  }
   __syncthreads();
   for (int j = threadIdx.x; j < K; j += 256)
     if (hist[j]) atomicAdd(counts + j, hist[j]);
@@ -575,7 +578,8 @@ __global__ __launch_bounds__(256) void km_scatter_kernel(const long long* __rest
 #pragma unroll
   for (int u = 0; u < KM_SCAT / 256; ++u) {
     const int i = p0 + u * 256 + threadIdx.x;
-    lab[u] = i < p1 ? (int)labels[i] : -1;
+    const long long l = i < p1 ? labels[i] : -1;
+    lab[u] = (l >= 0 && l < K) ? (int)l : -1;   // out-of-range labels are skipped (they would index past the LDS table)
     if (lab[u] >= 0) atomicAdd(&slots[lab[u]], 1);
   }
   __syncthreads();
@@ -609,7 +613,7 @@ __global__ __launch_bounds__(256) void km_segsum_kernel(const float* __restrict_
 #pragma unroll
     for (int t = 0; t < DPT; ++t) {
       const int d = tid + t * 256;
-      if (d < D && acc[t] != 0.f) atomicAdd(csum + (size_t)label * D + d, acc[t]);
+      if (label >= 0 && d < D && acc[t] != 0.f) atomicAdd(csum + (size_t)label * D + d, acc[t]);
       acc[t] = 0.f;
     }
   };
@@ -619,8 +623,8 @@ __global__ __launch_bounds__(256) void km_segsum_kernel(const float* __restrict_
     int lab[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const bool ok = e + u < e1;
-      lab[u] = ok ? lab_sorted[e + u] : -1;
+      lab[u] = e + u < e1 ? lab_sorted[e + u] : -1;   // -1: beyond the list, or a slot no in-range label was scattered into
+      const bool ok = lab[u] >= 0;
       const float* row = x + (size_t)(ok ? order[e + u] : 0) * D;
 #pragma unroll
       for (int t = 0; t < DPT; ++t) {
@@ -699,12 +703,13 @@ extern "C" int u2_kmeans_update(const float* x, const long long* labels, float* 
                                 float* workspace, void* stream) {
   if (N <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  if (workspace && D <= 256 * 8) {
+  if (workspace && D <= 256 * 8 && (size_t)K * sizeof(int) <= 64 * 1024) {  // the [K] tables of the bucketing kernels live in LDS
     int* order = reinterpret_cast<int*>(workspace);
     int* lab_sorted = order + N;
     int* icounts = lab_sorted + N;
     int* cursor = icounts + K;
     u2_zero_words(icounts, (size_t)K, s);
+    u2_fill_words(lab_sorted, (size_t)N, 0xffffffffu, s);  // labels outside [0, K) leave holes at the end of the list: marked -1
     U2_CHECK_LAUNCH();
     hipLaunchKernelGGL(km_hist_kernel, dim3(1024), dim3(256), (size_t)K * sizeof(int), s, labels, icounts, N, K);
     hipLaunchKernelGGL(km_scan_kernel, dim3(1), dim3(256), 0, s, icounts, cursor, counts, K);

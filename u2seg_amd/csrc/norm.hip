@@ -739,7 +739,7 @@ extern "C" int u2_colstats(const void* x, float* out, int slots, int rows_per_sl
   if (rpb < 64) rpb = 64;
   const dim3 grid((rows_per_slot + rpb - 1) / rpb, slots);
   hipLaunchKernelGGL((colreduce_kernel<0, 0, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, nullptr,
-                     nullptr, nullptr, nullptr, out, rows_per_slot, C, ld, rpb, nullptr, nullptr, nullptr, nullptr, nullptr, stream_order() & 1);
+                     nullptr, nullptr, nullptr, out, rows_per_slot, C, ld, rpb, nullptr, nullptr, nullptr, nullptr, nullptr, (stream_order() >> 1) & 1);  // a reduction: bit 1
   U2_CHECK_LAUNCH();
   return 0;
 }

@@ -39,6 +39,17 @@ def device_constant(values, dtype, device):
     return out
 
 
+def device_upload(values, dtype, device):
+    """Host-known values that CHANGE from batch to batch (box counts, offsets): one pinned, non-blocking copy on the current
+    stream - no cache entry (they would only evict the constants that do repeat) and no synchronisation (the caching host
+    allocator keeps the pinned block alive until the stream has passed the copy)."""
+    host = torch.tensor(values, dtype=dtype)
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        return host.pin_memory().to(dev, non_blocking=True)
+    return host.to(dev)
+
+
 class LazyProposals(collections.abc.Sequence):
     """list[Instances] (fields proposal_boxes, objectness_logits) backed by padded tensors.
 
@@ -103,7 +114,7 @@ class PaddedTargets:
                 self.boxes[i, : self.num[i]] = inst.gt_boxes.tensor
                 if has_cls:
                     self.classes[i, : self.num[i]] = inst.gt_classes
-        self.counts = device_constant(self.num, torch.int32, device)
+        self.counts = device_upload(self.num, torch.int32, device)
 
     @classmethod
     def of(cls, gt_instances, device):
@@ -142,7 +153,7 @@ def proposals_from_list(proposals, training=False):
             boxes[i, : n[i]] = p.proposal_boxes.tensor
             if p.has("objectness_logits"):
                 logits[i, : n[i]] = p.objectness_logits
-    out = LazyProposals([p.image_size for p in proposals], boxes, logits, device_constant(n, torch.int32, dev),
+    out = LazyProposals([p.image_size for p in proposals], boxes, logits, device_upload(n, torch.int32, dev),
                         None, training)
     out._items = list(proposals)
     return out

@@ -8,7 +8,7 @@ import torch
 from .. import _hip
 from ..layers import functional as F
 from ..structures import Boxes, Instances
-from .batched import device_constant
+from .batched import device_constant, device_upload
 
 
 def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image):
@@ -37,7 +37,7 @@ def fast_rcnn_inference(boxes, scores, image_shapes, score_thresh, nms_thresh, t
         sc = torch.full((nimg, rmax, k + 1), -1.0, dtype=scores[0].dtype, device=dev)
         for i, (b_, s_) in enumerate(zip(boxes, scores)):
             bx[i, : b_.shape[0]], sc[i, : s_.shape[0]] = b_, s_
-        rvalid = torch.arange(rmax, device=dev)[None] < device_constant(counts_r, torch.int64, dev)[:, None]
+        rvalid = torch.arange(rmax, device=dev)[None] < device_upload(counts_r, torch.int64, dev)[:, None]
     valid = torch.isfinite(bx).all(dim=2) & torch.isfinite(sc).all(dim=2)
     if rvalid is not None:
         valid = valid & rvalid
@@ -60,7 +60,7 @@ def fast_rcnn_inference(boxes, scores, image_shapes, score_thresh, nms_thresh, t
         offs.append(offs[-1] + c)
     nmax = max(max(cnt), 1)
     s_img = c_img[order]
-    pos = torch.arange(total, device=dev) - device_constant(offs[:-1], torch.int64, dev)[s_img]
+    pos = torch.arange(total, device=dev) - device_upload(offs[:-1], torch.int64, dev)[s_img]
     pb = torch.zeros((nimg, nmax, 4), dtype=torch.float32, device=dev)
     pg = torch.zeros((nimg, nmax), dtype=torch.int32, device=dev)
     pb[s_img, pos] = c_boxes[order]
@@ -71,7 +71,7 @@ def fast_rcnn_inference(boxes, scores, image_shapes, score_thresh, nms_thresh, t
     # the kept candidates of all images with one gather per field (per image: seven small launches, 220 per 32-image batch);
     # the per-image results are views of the gathered tensors
     live = torch.arange(keep.shape[1], device=dev)[None] < nkeep[:, None]
-    sel_all = order[(device_constant(offs[:-1], torch.int64, dev)[:, None] + keep.long())[live]]  # image-major, kept order
+    sel_all = order[(device_upload(offs[:-1], torch.int64, dev)[:, None] + keep.long())[live]]  # image-major, kept order
     g_boxes, g_scores, g_cls, g_roi = c_boxes[sel_all], c_scores[sel_all], c_cls[sel_all], c_roi[sel_all]
     results, kept_rows = [], []
     for shape, b_, s_, c_, r_ in zip(image_shapes, g_boxes.split(nk), g_scores.split(nk), g_cls.split(nk), g_roi.split(nk)):
@@ -117,7 +117,7 @@ def detector_postprocess_batch(results_list, sizes, mask_threshold=0.5):
     total = sum(counts)
     if total:
         img_idx = torch.repeat_interleave(device_constant(list(range(len(counts))), torch.int64, dev),
-                                          device_constant(counts, torch.int64, dev), output_size=total)
+                                          device_upload(counts, torch.int64, dev), output_size=total)
         t = torch.cat(tensors).float() * device_constant(scl, torch.float32, dev)[img_idx]
         finite_row = torch.isfinite(t).all(dim=1)
         t = torch.minimum(t.clamp(min=0), device_constant(lim, torch.float32, dev)[img_idx])

@@ -15,7 +15,7 @@ from ..layers import Conv2d, ConvTranspose2d, Linear, ShapeSpec, c2_msra_fill, c
 from ..layers import functional as F
 from ..structures import Boxes, Instances
 from ..utils.registry import Registry
-from .batched import BatchList, PaddedTargets, check_finite, device_constant, image_index, proposals_from_list
+from .batched import BatchList, PaddedTargets, check_finite, device_constant, device_upload, image_index, proposals_from_list
 from .sampling import subsample_labels
 
 ROI_HEADS_REGISTRY = Registry("ROI_HEADS")
@@ -703,7 +703,7 @@ class CascadeROIHeads(StandardROIHeads):
             dev = boxes[0].device
             lim = device_constant([[s[1], s[0], s[1], s[0]] for s in image_sizes], torch.float32, dev)
             rows = torch.repeat_interleave(device_constant(list(range(len(counts))), torch.int64, dev),
-                                           device_constant(counts, torch.int64, dev), output_size=sum(counts))
+                                           device_upload(counts, torch.int64, dev), output_size=sum(counts))
             flat = torch.minimum(torch.cat([b.detach() for b in boxes]).float().clamp(min=0), lim[rows])
             clipped = [Boxes(t) for t in flat.split(counts)]
         else:

@@ -1,77 +1,88 @@
-"""Nx4 XYXY box container with the detectron2.structures.Boxes surface used on the hot path
-(detectron2/structures/boxes.py:130-358)."""
+"""Nx4 XYXY box container exposing the part of detectron2.structures.Boxes the hot path and the data mappers call
+(reference API: detectron2/structures/boxes.py:130-358 - names and semantics only; written for this package: every geometric
+method works on the (N, 2, 2) corner view of the tensor instead of on its four columns)."""
 import torch
+
+
+def _as_box_tensor(value):
+    """float32 [N, 4]; an empty input of any shape becomes [0, 4]."""
+    t = value if isinstance(value, torch.Tensor) else torch.as_tensor(value, dtype=torch.float32)
+    t = t.to(torch.float32)
+    if t.numel() == 0:
+        t = t.reshape(0, 4)
+    if t.dim() != 2 or t.shape[1] != 4:
+        raise AssertionError("boxes must be [N, 4], got %s" % (tuple(t.shape),))
+    return t
 
 
 class Boxes:
     def __init__(self, tensor):
-        if not isinstance(tensor, torch.Tensor):
-            tensor = torch.as_tensor(tensor, dtype=torch.float32, device=torch.device("cpu"))
-        else:
-            tensor = tensor.to(torch.float32)
-        if tensor.numel() == 0:
-            tensor = tensor.reshape((-1, 4)).to(dtype=torch.float32)
-        assert tensor.dim() == 2 and tensor.size(-1) == 4, tensor.size()
-        self.tensor = tensor
+        self.tensor = _as_box_tensor(tensor)
 
+    # ---- views -------------------------------------------------------------------------------------------------
+    def _corners(self):
+        """[N, 2 (min / max corner), 2 (x, y)] view of the storage."""
+        return self.tensor.unflatten(1, (2, 2))
+
+    def _extent(self):
+        """[N, 2] widths and heights."""
+        c = self._corners()
+        return c[:, 1] - c[:, 0]
+
+    # ---- detectron2 surface ------------------------------------------------------------------------------------
     def clone(self):
         return Boxes(self.tensor.clone())
 
     def to(self, device):
         return Boxes(self.tensor.to(device=device))
 
-    def area(self):
-        box = self.tensor
-        return (box[:, 2] - box[:, 0]) * (box[:, 3] - box[:, 1])
-
-    def clip(self, box_size):
-        assert torch.isfinite(self.tensor).all(), "Box tensor contains infinite or NaN!"
-        h, w = box_size
-        x1 = self.tensor[:, 0].clamp(min=0, max=w)
-        y1 = self.tensor[:, 1].clamp(min=0, max=h)
-        x2 = self.tensor[:, 2].clamp(min=0, max=w)
-        y2 = self.tensor[:, 3].clamp(min=0, max=h)
-        self.tensor = torch.stack((x1, y1, x2, y2), dim=-1)
-
-    def nonempty(self, threshold=0.0):
-        box = self.tensor
-        widths = box[:, 2] - box[:, 0]
-        heights = box[:, 3] - box[:, 1]
-        return (widths > threshold) & (heights > threshold)
-
-    def __getitem__(self, item):
-        if isinstance(item, int):
-            return Boxes(self.tensor[item].view(1, -1))
-        b = self.tensor[item]
-        assert b.dim() == 2, "Indexing on Boxes with {} failed to return a matrix!".format(item)
-        return Boxes(b)
-
-    def __len__(self):
-        return self.tensor.shape[0]
-
-    def __repr__(self):
-        return "Boxes(" + str(self.tensor) + ")"
-
-    def get_centers(self):
-        return (self.tensor[:, :2] + self.tensor[:, 2:]) / 2
-
-    def scale(self, scale_x, scale_y):
-        self.tensor[:, 0::2] *= scale_x
-        self.tensor[:, 1::2] *= scale_y
-
-    @classmethod
-    def cat(cls, boxes_list):
-        assert isinstance(boxes_list, (list, tuple))
-        if len(boxes_list) == 0:
-            return cls(torch.empty(0))
-        return cls(torch.cat([b.tensor for b in boxes_list], dim=0))
-
     @property
     def device(self):
         return self.tensor.device
 
+    def area(self):
+        return self._extent().prod(dim=1)
+
+    def clip(self, box_size):
+        """Clamp in place to the image rectangle [0, w] x [0, h]."""
+        if not bool(torch.isfinite(self.tensor).all()):
+            raise AssertionError("cannot clip boxes that contain Inf or NaN")
+        h, w = box_size
+        upper = self.tensor.new_tensor([w, h, w, h])
+        self.tensor = torch.minimum(self.tensor.clamp(min=0), upper)
+
+    def nonempty(self, threshold=0.0):
+        return (self._extent() > threshold).all(dim=1)
+
+    def get_centers(self):
+        return self._corners().mean(dim=1)
+
+    def scale(self, scale_x, scale_y):
+        self.tensor.mul_(self.tensor.new_tensor([scale_x, scale_y, scale_x, scale_y]))
+
+    def __getitem__(self, item):
+        picked = self.tensor[item]
+        if isinstance(item, int):
+            picked = picked.unsqueeze(0)
+        if picked.dim() != 2:
+            raise AssertionError("index %r selects a %d-d tensor from Boxes, expected rows of 4" % (item, picked.dim()))
+        return Boxes(picked)
+
+    def __len__(self):
+        return int(self.tensor.shape[0])
+
     def __iter__(self):
-        yield from self.tensor
+        return iter(self.tensor)
+
+    def __repr__(self):
+        return "Boxes(%s)" % (self.tensor,)
+
+    @classmethod
+    def cat(cls, boxes_list):
+        if not isinstance(boxes_list, (list, tuple)):
+            raise AssertionError("Boxes.cat takes a list or tuple of Boxes")
+        rows = [b.tensor for b in boxes_list]
+        return cls(torch.cat(rows, dim=0) if rows else torch.empty((0, 4)))
 
 
 def pairwise_iou(boxes1, boxes2):
