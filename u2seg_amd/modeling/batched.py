@@ -39,15 +39,56 @@ def device_constant(values, dtype, device):
     return out
 
 
+class _PinnedRing:
+    """A few pinned staging slots allocated ONCE per device: `tensor.pin_memory()` per upload goes to hipHostMalloc whenever
+    the caching host allocator has no block whose last copy has retired - milliseconds each, and it synchronises (measured:
+    batch-32 inference inside the default bench.py run, after the training workload, 47 -> 68 ms per batch).  A slot is
+    reused only after the event recorded behind its last copy has completed."""
+
+    SLOTS, SLOT_BYTES = 64, 16384
+    _rings = {}
+
+    def __init__(self, dev):
+        self.buf = torch.empty((self.SLOTS, self.SLOT_BYTES), dtype=torch.uint8).pin_memory()
+        self.events = [None] * self.SLOTS
+        self.next = 0
+        self.dev = dev
+
+    @classmethod
+    def get(cls, dev):
+        key = str(dev)
+        ring = cls._rings.get(key)
+        if ring is None:
+            ring = cls._rings[key] = cls(dev)
+        return ring
+
+    def upload(self, host):
+        nbytes = host.numel() * host.element_size()
+        i = self.next
+        self.next = (i + 1) % self.SLOTS
+        ev = self.events[i]
+        if ev is not None and not ev.query():
+            ev.synchronize()
+        stage = self.buf[i, :nbytes].view(host.dtype).view(host.shape)
+        stage.copy_(host)
+        out = torch.empty(host.shape, dtype=host.dtype, device=self.dev)
+        out.copy_(stage, non_blocking=True)
+        if ev is None:
+            ev = self.events[i] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        return out
+
+
 def device_upload(values, dtype, device):
-    """Host-known values that CHANGE from batch to batch (box counts, offsets): one pinned, non-blocking copy on the current
-    stream - no cache entry (they would only evict the constants that do repeat) and no synchronisation (the caching host
-    allocator keeps the pinned block alive until the stream has passed the copy)."""
+    """Host-known values that CHANGE from batch to batch (box counts, offsets): one non-blocking copy from a pinned staging slot
+    on the current stream - no cache entry (they would only evict the constants that do repeat) and no synchronisation."""
     host = torch.tensor(values, dtype=dtype)
     dev = torch.device(device)
-    if dev.type == "cuda":
+    if dev.type != "cuda":
+        return host.to(dev)
+    if host.numel() == 0 or host.numel() * host.element_size() > _PinnedRing.SLOT_BYTES:
         return host.pin_memory().to(dev, non_blocking=True)
-    return host.to(dev)
+    return _PinnedRing.get(dev).upload(host)
 
 
 class LazyProposals(collections.abc.Sequence):
