@@ -250,6 +250,12 @@ int u2_bilinear_resize_f32(const float* in, float* out, int C, int Hin, int Win,
  * boxes[k] = (x0, y0, x1, y1), zero outside the map, >= threshold. */
 int u2_paste_masks(const float* probs, const float* boxes, void* out, int n, int P, int H, int W, float threshold,
                    void* stream);
+/* The same for the masks of a batch of images in one launch (detectron2/modeling/postprocessing.py:9-74 pastes per image):
+ * image i owns rows [first, first + n) of probs / boxes and writes its n canvases of H x W bytes at byte out_offset (a multiple
+ * of 8) of `out`; `images` is a HOST array. */
+typedef struct U2PasteImage { int first, n, H, W; long long out_offset; } U2PasteImage;
+int u2_paste_masks_batch(const float* probs, const float* boxes, void* out, const U2PasteImage* images, int num_images, int P,
+                         float threshold, void* stream);
 /* Panoptic merge of a batch of images (one work-group each); `images` is a HOST array of descriptors holding device
  * pointers.  inst_segment[rank] = segment id given to the rank-th highest scoring instance (0 = rejected); stuff_segment /
  * stuff_area [num_sem] = id (0 = rejected) and free-pixel area per semantic label.  boxes (optional) + mask_res bound the

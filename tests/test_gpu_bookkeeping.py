@@ -460,3 +460,157 @@ def test_heads_teacher_forced_losses(F, hw):
     assert len(report) == 10
     for k, (got, exp) in report.items():
         assert got == pytest.approx(exp, rel=1e-3), (k, report)
+
+
+def test_inference_tails_full_size_800x1333(F):
+    """The inference tails at the benchmark size (missing #6): on ONE 800 x 1333 canvas, against the oracle on
+    identical inputs - 100 pasted masks (layers/mask_ops.py:17-147; exact except >= 0.5 ties of the bilinear sample), the panoptic
+    merge (meta_arch/panoptic_fpn.py:184-269; bit-identical map and segment list), detector_postprocess to a 1.5x output
+    (modeling/postprocessing.py:9-74; batch == per image) - and the batched launches (one paste launch / one merge launch for
+    several images with different canvas sizes) equal to the per-image ones bit for bit."""
+    from oracle.model import OracleModel
+    from u2seg_amd.modeling.inference import (combine_semantic_and_instance_outputs_batch, detector_postprocess,
+                                              detector_postprocess_batch, paste_masks_in_image, paste_masks_in_images)
+    from u2seg_amd.structures import Boxes, Instances
+
+    g = torch.Generator().manual_seed(800)
+    H, W, n = 800, 1333, 100
+    # smooth 28 x 28 probability maps (blobs), so that the >= 0.5 contour is a curve and not salt and pepper
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 28), torch.linspace(-1, 1, 28), indexing="ij")
+    cx, cy = torch.rand(n, generator=g) - 0.5, torch.rand(n, generator=g) - 0.5
+    rad = 0.4 + 0.5 * torch.rand(n, generator=g)
+    probs = torch.sigmoid(6 * (rad[:, None, None] - ((xx[None] - cx[:, None, None]) ** 2 + (yy[None] - cy[:, None, None]) ** 2).sqrt()))
+    x0 = torch.rand(n, generator=g) * (W - 40)
+    y0 = torch.rand(n, generator=g) * (H - 40)
+    bw = 8 + torch.rand(n, generator=g) ** 2 * 600
+    bh = 8 + torch.rand(n, generator=g) ** 2 * 500
+    boxes = torch.stack([x0, y0, (x0 + bw).clamp(max=W), (y0 + bh).clamp(max=H)], dim=1)
+    boxes[0] = torch.tensor([0.0, 0.0, W, H])            # the whole canvas
+    boxes[1] = torch.tensor([-30.0, -20.0, 50.0, 40.0])  # partly outside (an unclipped box)
+    boxes[2] = torch.tensor([700.25, 400.5, 701.0, 402.75])  # smaller than a source texel
+    boxes[3] = torch.tensor([W - 3.5, H - 2.5, W, H])    # the last pixels
+    ref = OracleModel.paste_masks(probs, boxes, (H, W))
+    got_dev = paste_masks_in_image(probs.to(DEV), boxes.to(DEV), (H, W))
+    got = got_dev.cpu()
+    assert got.shape == (n, H, W) and got.dtype == torch.bool
+    per_mask = (got != ref).flatten(1).sum(1)
+    assert int(per_mask.sum()) <= 1e-5 * n * H * W and int(per_mask.max()) <= 64, (int(per_mask.sum()), int(per_mask.max()))
+    assert torch.equal(got.flatten(1).any(1), ref.flatten(1).any(1))
+    # one launch for several images with their own canvas sizes == one launch per image
+    sizes = [(H, W), (600, 901), (1200, 2000), (37, 53)]
+    cut = [0, 60, 80, 100, 100]   # the last image has no masks
+    many = paste_masks_in_images([probs[a:b].to(DEV) for a, b in zip(cut[:-1], cut[1:])],
+                                 [boxes[a:b].to(DEV) for a, b in zip(cut[:-1], cut[1:])], sizes)
+    for (a, b), hw, m in zip(zip(cut[:-1], cut[1:]), sizes, many):
+        one = paste_masks_in_image(probs[a:b].to(DEV), boxes[a:b].to(DEV), hw)
+        assert m.shape == (b - a,) + hw and torch.equal(m, one)
+    assert torch.equal(many[0], got_dev[:60])
+
+    # panoptic merge on the pasted masks (the device's, so that tie pixels cannot differ) vs the oracle
+    scores = torch.rand(n, generator=g)
+    scores[5] = scores[6]   # a tie in the instance order
+    classes = torch.randint(0, 800, (n,), generator=g)
+    sem = torch.randint(0, 28, (H // 50 + 1, W // 50 + 1), generator=g).repeat_interleave(50, 0).repeat_interleave(50, 1)[:H, :W].contiguous()
+    sem[:100] = 0      # "things" region of the semantic map
+    sem[700:, :40] = 27  # a stuff region below the area limit (4000 < 4096)
+    inst = Instances((H, W))
+    inst.pred_masks, inst.pred_boxes = got_dev, Boxes(boxes.to(DEV))
+    inst.scores, inst.pred_classes = scores.to(DEV), classes.to(DEV)
+    ref_pan, ref_info = OracleModel.combine_panoptic(got, scores, classes, sem, 0.5, 4096, 0.5)
+    (pan, info), = combine_semantic_and_instance_outputs_batch([inst], [sem.to(DEV)], 0.5, 4096, 0.5, 28)
+    assert torch.equal(pan.cpu(), ref_pan)
+    key = lambda d: (d["id"], d["isthing"], d["category_id"], d.get("instance_id"), d.get("area"))  # noqa: E731
+    assert [key(d) for d in info] == [key(d) for d in ref_info] and len(info) > 20
+    # every pixel belongs to exactly one segment or to none; the segment areas are the histogram of the map
+    hist = torch.bincount(pan.flatten().long().cpu(), minlength=len(info) + 1)
+    assert int(hist.sum()) == H * W and all(int(hist[d["id"]]) > 0 for d in info) and int(pan.max()) == len(info)
+    assert all(int(hist[d["id"]]) == d["area"] for d in info if not d["isthing"])
+    # the same image merged together with two others of different sizes in one launch
+    small = Instances((600, 901))
+    small.pred_masks, small.pred_boxes = many[1], Boxes(boxes[60:80].to(DEV))
+    small.scores, small.pred_classes = scores[60:80].to(DEV), classes[60:80].to(DEV)
+    sem2 = sem[:600, :901].contiguous().to(DEV)
+    both = combine_semantic_and_instance_outputs_batch([small, inst, small], [sem2, sem.to(DEV), sem2], 0.5, 4096, 0.5, 28)
+    alone = combine_semantic_and_instance_outputs_batch([small], [sem2], 0.5, 4096, 0.5, 28)
+    assert torch.equal(both[1][0], pan) and both[1][1] == info
+    assert torch.equal(both[0][0], alone[0][0]) and torch.equal(both[2][0], alone[0][0]) and both[0][1] == alone[0][1]
+
+    # detector_postprocess to 1.5x the canvas: the batch routine == one image at a time
+    def raw(a, b, hw):
+        r = Instances(hw)
+        r.pred_boxes = Boxes(boxes[a:b].to(DEV).clone())
+        r.scores, r.pred_classes = scores[a:b].to(DEV), classes[a:b].to(DEV)
+        r.pred_masks = probs[a:b, None].to(DEV)
+        return r
+
+    outs = [(1200, 2000), (H, W), (450, 676)]
+    batch = detector_postprocess_batch([raw(0, 40, (H, W)), raw(40, 100, (H, W)), raw(60, 80, (600, 901))], outs)
+    for r, (a, b, hw), o in zip(batch, [(0, 40, (H, W)), (40, 100, (H, W)), (60, 80, (600, 901))], outs):
+        one = detector_postprocess(raw(a, b, hw), o[0], o[1])
+        assert r.image_size == o and r.pred_masks.shape == (len(one),) + o
+        assert torch.equal(r.pred_boxes.tensor, one.pred_boxes.tensor) and torch.equal(r.pred_masks, one.pred_masks)
+    sx = 2000 / W
+    assert torch.allclose(batch[0].pred_boxes.tensor[4, 0].cpu(), (boxes[4, 0] * sx).clamp(0, 2000), rtol=1e-6)
+
+
+def test_inference_batch32_ragged_full_size_properties(F):
+    """u2seg_eval_800 on a 32-image ragged batch at the benchmark resolution (the batch-32 path bench.py times), properties that
+    hold exactly whatever the weights: every output has its image's requested size; every pixel of the panoptic map carries 0
+    or the id of a listed segment; thing segments lie inside the pasted mask of their instance, stuff segments inside their
+    semantic label; stuff areas equal the histogram of the map; ids are 1..S in order; the merge of the batch in one launch
+    equals the merge of each image on its own."""
+    from tests.golden.make_fixtures import det_fill
+    from u2seg_amd.config import get_cfg
+    from u2seg_amd.data import make_synthetic_batch
+    from u2seg_amd.modeling import build_model
+    from u2seg_amd.modeling.inference import combine_semantic_and_instance_outputs_batch
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "COCO-PanopticSegmentation", "u2seg_eval_800.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", DEV, "MODEL.ROI_HEADS.SCORE_THRESH_TEST", 0.0015,
+                         "MODEL.PANOPTIC_FPN.COMBINE.INSTANCES_CONFIDENCE_THRESH", 0.0016])
+    model = build_model(cfg)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            v.copy_(det_fill(k, v.cpu()).to(DEV))
+    model.eval()
+    shapes = [(800, 1333), (800, 1216), (736, 1333), (800, 1066), (608, 1333), (800, 800)]
+    batch = []
+    for i in range(32):
+        h, w = shapes[i % len(shapes)]
+        x = make_synthetic_batch(1, start_index=i, height=h, width=w, device=DEV)[0]
+        x = {k: v for k, v in x.items() if k not in ("instances", "sem_seg")}
+        if i % 5 == 0:   # results requested at another resolution (detector_postprocess / sem_seg_postprocess rescale)
+            x["height"], x["width"] = h * 3 // 4, w * 3 // 4
+        batch.append(x)
+    with torch.no_grad():
+        out = model(batch)
+    assert len(out) == 32
+    merged_in = []
+    for x, o in zip(batch, out):
+        hw = (x["height"], x["width"])
+        inst, (pan, info) = o["instances"], o["panoptic_seg"]
+        assert o["sem_seg"].shape == (28,) + hw and pan.shape == hw and pan.dtype == torch.int32
+        assert inst.image_size == hw and inst.pred_masks.shape == (len(inst),) + hw and inst.pred_masks.dtype == torch.bool
+        assert len(inst) <= 100 and bool((inst.pred_boxes.tensor[:, 2] <= hw[1]).all()) and bool((inst.pred_boxes.tensor[:, 3] <= hw[0]).all())
+        assert [d["id"] for d in info] == list(range(1, len(info) + 1))
+        hist = torch.bincount(pan.flatten().long(), minlength=len(info) + 1).cpu()
+        assert hist.numel() == len(info) + 1 and int(hist.sum()) == hw[0] * hw[1]
+        sem = o["sem_seg"].argmax(0)
+        for d in info:
+            region = pan == d["id"]
+            assert int(hist[d["id"]]) > 0
+            if d["isthing"]:
+                assert bool((inst.pred_masks[d["instance_id"]] | ~region).all())   # region is a subset of the instance's mask
+                assert d["category_id"] == int(inst.pred_classes[d["instance_id"]])
+            else:
+                assert d["area"] == int(hist[d["id"]]) >= 4096 and bool((sem[region] == d["category_id"]).all())
+        merged_in.append((inst, sem))
+    assert sum(len(o["panoptic_seg"][1]) for o in out) > 32   # the lowered thresholds let instances through
+    # one launch for the batch == one launch per image
+    for i in (0, 5, 31):
+        inst, sem = merged_in[i]
+        (pan1, info1), = combine_semantic_and_instance_outputs_batch([inst], [sem], model.combine_overlap_thresh,
+                                                                    model.combine_stuff_area_thresh,
+                                                                    model.combine_instances_score_thresh, 28)
+        assert torch.equal(pan1, out[i]["panoptic_seg"][0]) and info1 == out[i]["panoptic_seg"][1]

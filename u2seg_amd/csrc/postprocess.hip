@@ -18,15 +18,15 @@ __device__ __forceinline__ float paste_axis_coord(float pix, float lo, float hi,
   return ((g + 1.f) * (float)P - 1.f) / 2.f;                   // grid_sample's unnormalisation, align_corners=False
 }
 
-__global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restrict__ probs, const float* __restrict__ boxes,
-                                                          uint8_t* __restrict__ out, long long total, int P, int H, int W,
-                                                          float thr) {
-  const long long i8 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+__device__ __forceinline__ void paste_masks_block(const float* __restrict__ probs, const float* __restrict__ boxes,
+                                                  uint8_t* __restrict__ out, long long total, int P, int H, int W, float thr,
+                                                  long long block) {
+  const long long i8 = (block * 256 + threadIdx.x) * 8;
   if (i8 >= total) return;
   const long long hw = (long long)H * W;
   // (mask, row, column) of the block's first byte by scalar divisions (uniform), of the thread's first byte by at most a few
   // subtractions: two 64-bit divisions per thread were a third of the kernel
-  const long long b8 = (long long)blockIdx.x * 2048;
+  const long long b8 = block * 2048;
   int k = (int)(b8 / hw);
   const long long rem = b8 - (long long)k * hw;
   int y = (int)(rem / W);
@@ -95,6 +95,27 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restric
   } else {
     for (int e = 0; e < nvalid; ++e) out[i8 + e] = (uint8_t)((bits >> (8 * e)) & 1ull);
   }
+}
+
+__global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restrict__ probs, const float* __restrict__ boxes,
+                                                          uint8_t* __restrict__ out, long long total, int P, int H, int W,
+                                                          float thr) {
+  paste_masks_block(probs, boxes, out, total, P, H, W, thr, (long long)blockIdx.x);
+}
+
+// The masks of a whole batch of images in ONE launch (detector_postprocess pastes per image: 32 launches per 32-image batch,
+// each with its own canvas size): blockIdx.y = image, the image's masks are rows [first, first + n) of probs / boxes and its
+// canvases start at byte out_offset of `out`.
+constexpr int PASTE_MAXIMG = 64;
+struct PasteBatch { U2PasteImage im[PASTE_MAXIMG]; };
+__global__ __launch_bounds__(256) void paste_masks_batch_kernel(const PasteBatch batch, const float* __restrict__ probs,
+                                                                const float* __restrict__ boxes, uint8_t* __restrict__ out, int P,
+                                                                float thr) {
+  const U2PasteImage im = batch.im[blockIdx.y];
+  const long long total = (long long)im.n * im.H * im.W;
+  if ((long long)blockIdx.x * 2048 >= total) return;
+  paste_masks_block(probs + (size_t)im.first * P * P, boxes + (size_t)im.first * 4, out + im.out_offset, total, P, im.H, im.W, thr,
+                    (long long)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -346,6 +367,29 @@ extern "C" int u2_semseg_upsample(const void* logits, float* out, long long* arg
   hipLaunchKernelGGL(semseg_upsample_kernel<64>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, out,
                      argmax, B, H, W, Cp, K, S);
   U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_paste_masks_batch(const float* probs, const float* boxes, void* out, const U2PasteImage* images, int num_images,
+                                    int P, float threshold, void* stream) {
+  if (num_images <= 0) return 0;
+  if (P < 1 || !images) return -1;
+  for (int i0 = 0; i0 < num_images; i0 += PASTE_MAXIMG) {
+    PasteBatch b;
+    const int nb = num_images - i0 < PASTE_MAXIMG ? num_images - i0 : PASTE_MAXIMG;
+    long long max_blocks = 0;
+    for (int i = 0; i < nb; ++i) {
+      b.im[i] = images[i0 + i];
+      if (b.im[i].n < 0 || b.im[i].H < 0 || b.im[i].W < 0 || (b.im[i].out_offset & 7)) return -1;
+      const long long blocks = ((long long)b.im[i].n * b.im[i].H * b.im[i].W + 2047) / 2048;
+      if (blocks > max_blocks) max_blocks = blocks;
+    }
+    if (max_blocks == 0) continue;
+    if (max_blocks > 0x7fffffffLL) return -1;
+    hipLaunchKernelGGL(paste_masks_batch_kernel, dim3((unsigned)max_blocks, (unsigned)nb), dim3(256), 0, (hipStream_t)stream, b, probs,
+                       boxes, (uint8_t*)out, P, threshold);
+    U2_CHECK_LAUNCH();
+  }
   return 0;
 }
 

@@ -138,10 +138,44 @@ def detector_postprocess_batch(results_list, sizes, mask_threshold=0.5):
         results.set(name, Boxes(bx))
         if n_empty:
             results = results[keep]
-        if results.has("pred_masks"):
-            results.pred_masks = paste_masks_in_image(results.pred_masks[:, 0, :, :], results.pred_boxes.tensor,
-                                                      results.image_size, mask_threshold)
         out.append(results)
+    if out[0].has("pred_masks"):
+        pasted = paste_masks_in_images([r.pred_masks[:, 0, :, :] for r in out], [r.pred_boxes.tensor for r in out],
+                                       [r.image_size for r in out], mask_threshold)
+        for r, m in zip(out, pasted):
+            r.pred_masks = m
+    return out
+
+
+class _PasteImage(ctypes.Structure):
+    """Mirror of U2PasteImage (include/u2seg_hip.h)."""
+
+    _fields_ = [("first", ctypes.c_int), ("n", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int),
+                ("out_offset", ctypes.c_longlong)]
+
+
+def paste_masks_in_images(masks_list, boxes_list, image_shapes, threshold=0.5):
+    """paste_masks_in_image for a batch of images with ONE kernel launch (the reference pastes per image,
+    postprocessing.py:61-70): the masks [n_i, P, P] and boxes [n_i, 4] of all images are concatenated, every image gets its own
+    canvas size; returns a list of bool [n_i, H_i, W_i] views of one allocation."""
+    counts = [int(m.shape[0]) for m in masks_list]
+    dev = masks_list[0].device
+    descs = (_PasteImage * len(masks_list))()
+    first, off = 0, 0
+    for i, (n, (h, w)) in enumerate(zip(counts, image_shapes)):
+        d = descs[i]
+        d.first, d.n, d.H, d.W, d.out_offset = first, n, int(h), int(w), off
+        first += n
+        off += (n * int(h) * int(w) + 7) // 8 * 8
+    flat = torch.empty(max(off, 8), dtype=torch.bool, device=dev)
+    if first:
+        p = int(masks_list[0].shape[-1])
+        _hip.call("u2_paste_masks_batch", torch.cat(masks_list).float().contiguous(), torch.cat(boxes_list).float().contiguous(),
+                  flat, descs, len(masks_list), p, float(threshold))
+    out = []
+    for i, (n, (h, w)) in enumerate(zip(counts, image_shapes)):
+        o = descs[i].out_offset
+        out.append(flat[o : o + n * int(h) * int(w)].view(n, int(h), int(w)))
     return out
 
 
