@@ -221,46 +221,66 @@ def combine_semantic_and_instance_outputs_batch(instance_results, semantic_resul
         return []
     dev = semantic_results[0].device
     descs = (_PanopticImage * n)()
+    ks = [len(inst) for inst in instance_results]
+    kmax, ktot = max(ks), sum(ks)
+    # The instance order of ALL images with one sort (per image: negate + sort + casts + gather, ~8 launches x 32 images): the
+    # scores go into a [n, kmax] matrix padded with -inf, torch.argsort(-scores) - the reference's expression, ties included
+    # (the radix sort is stable) - runs along its rows; row i's first k_i entries are image i's order.
+    if ktot:
+        flat_scores = torch.cat([inst.scores.float() for inst in instance_results])
+        rows = [i for i, k in enumerate(ks) for _ in range(k)]
+        cols = [j for k in ks for j in range(k)]
+        spad = torch.full((n, kmax), float("-inf"), dtype=torch.float32, device=dev)
+        spad[device_upload(rows, torch.int64, dev), device_upload(cols, torch.int64, dev)] = flat_scores
+        order2d = torch.argsort(-spad, dim=1)
+        sorted2d = torch.gather(spad, 1, order2d).contiguous()
+        order2d = order2d.to(torch.int32).contiguous()
+        classes_all = torch.cat([inst.pred_classes for inst in instance_results]).to(torch.int32)
+    else:
+        order2d = torch.zeros((n, 1), dtype=torch.int32, device=dev)
+        sorted2d = torch.zeros((n, 1), dtype=torch.float32, device=dev)
+        classes_all = torch.zeros(0, dtype=torch.int32, device=dev)
+        kmax = 1
+    out_all = torch.zeros(ktot + 2 * _NUM_SEM_SLOTS * n, dtype=torch.int32, device=dev)
     keep_alive, per_image = [], []
-    ints = []  # per image: order | inst_segment | stuff_segment | stuff_area | classes (read back together)
+    opos = 0
     for i, (inst, sem) in enumerate(zip(instance_results, semantic_results)):
         h, w = sem.shape
-        k = len(inst)
+        k = ks[i]
         sem = sem.to(torch.int64).contiguous()
         masks = inst.pred_masks.to(device=dev)
         masks = (masks if masks.dtype in (torch.bool, torch.uint8) else masks > 0).contiguous()
         assert masks.shape == (k, h, w), (masks.shape, (k, h, w))
-        scores = inst.scores.float()
-        order = torch.argsort(-scores).to(torch.int32)  # the reference's order, ties included
-        s_sorted = scores[order.long()].contiguous()
         boxes = inst.pred_boxes.tensor.float().contiguous() if (mask_res > 0 and inst.has("pred_boxes")) else None
         pan = torch.empty((h, w), dtype=torch.int32, device=dev)
-        out = torch.zeros(k + 2 * _NUM_SEM_SLOTS, dtype=torch.int32, device=dev)
         d = descs[i]
-        d.masks, d.order, d.scores_sorted = masks.data_ptr(), order.data_ptr(), s_sorted.data_ptr()
+        d.masks = masks.data_ptr()
+        d.order, d.scores_sorted = order2d.data_ptr() + 4 * kmax * i, sorted2d.data_ptr() + 4 * kmax * i
         d.boxes = boxes.data_ptr() if boxes is not None else None
         d.semantic, d.panoptic = sem.data_ptr(), pan.data_ptr()
-        d.inst_segment = out.data_ptr()
-        d.stuff_segment = out.data_ptr() + 4 * k
-        d.stuff_area = out.data_ptr() + 4 * (k + _NUM_SEM_SLOTS)
+        d.inst_segment = out_all.data_ptr() + 4 * opos
+        d.stuff_segment = out_all.data_ptr() + 4 * (opos + k)
+        d.stuff_area = out_all.data_ptr() + 4 * (opos + k + _NUM_SEM_SLOTS)
         d.K, d.H, d.W, d.num_sem = k, h, w, _NUM_SEM_SLOTS
-        keep_alive.append((masks, order, s_sorted, boxes, sem, out))
+        opos += k + 2 * _NUM_SEM_SLOTS
+        keep_alive.append((masks, boxes, sem))
         per_image.append((pan, k))
-        ints.append((out, order, inst.pred_classes.to(torch.int32)))
     _hip.call("u2_panoptic_merge", descs, n, float(overlap_threshold), int(stuff_area_thresh), float(instances_score_thresh),
               int(mask_res))
-    flat = torch.cat([t for trip in ints for t in trip]).tolist()  # (after the launch) the one host synchronisation
-    score_lists = torch.cat([ka[2] for ka in keep_alive]).tolist() if any(k for _, k in per_image) else []
-    results, pos, spos = [], 0, 0
-    for pan, k in per_image:
+    # (after the launch) the one host synchronisation: segment ids / areas, the orders and the classes in one transfer
+    flat = torch.cat([out_all, order2d.reshape(-1), classes_all]).tolist()
+    score_rows = sorted2d.tolist() if ktot else [[] for _ in range(n)]
+    o_base, c_base = out_all.numel(), out_all.numel() + order2d.numel()
+    results, pos, cpos = [], 0, 0
+    for i, (pan, k) in enumerate(per_image):
         inst_seg = flat[pos : pos + k]
         stuff_seg = flat[pos + k : pos + k + _NUM_SEM_SLOTS]
         stuff_area = flat[pos + k + _NUM_SEM_SLOTS : pos + k + 2 * _NUM_SEM_SLOTS]
-        order = flat[pos + k + 2 * _NUM_SEM_SLOTS : pos + 2 * k + 2 * _NUM_SEM_SLOTS]
-        classes = flat[pos + 2 * k + 2 * _NUM_SEM_SLOTS : pos + 3 * k + 2 * _NUM_SEM_SLOTS]
-        pos += 3 * k + 2 * _NUM_SEM_SLOTS
-        scores = score_lists[spos : spos + k]
-        spos += k
+        pos += k + 2 * _NUM_SEM_SLOTS
+        order = flat[o_base + i * kmax : o_base + i * kmax + k]
+        classes = flat[c_base + cpos : c_base + cpos + k]
+        cpos += k
+        scores = score_rows[i][:k]
         info = []
         for rank in range(k):
             if inst_seg[rank] > 0:
