@@ -201,7 +201,9 @@ def test_conv_narrow_tile_variants(F, variant, code):
 
 
 @pytest.mark.parametrize("variant,code", [(0, 2003), (1, 2001), (2, 2002), (3, 2000), (64, 2103), (128, 2003), (256, 2256),
-                                          (256 | 64, 2356), (16, 2003), (32, 2003)])
+                                          (256 | 64, 2356), (16, 2003), (32, 2003),
+                                          # bit 17: partial tiles + wgrad_reduce_kernel wherever there are >= 2 pixel splits, bit 16: atomics
+                                          (131072, 2003), (131072 | 256, 2256), (131072 | 64, 2103), (65536, 2003)])
 def test_wgrad_forced_variants(F, variant, code):
     """conv_wgrad_kernel<GLDS, TR> (all four), the XCD-grouped launch and conv_wgrad256_kernel on 3x3 s1 128 -> 136 (the plain
     layout) and on 1x1 (the direct-into-arena layout), vs fp32."""

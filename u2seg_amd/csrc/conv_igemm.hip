@@ -17,6 +17,7 @@
 // lane ends up with 4 consecutive channels of one pixel; the tile is then transposed through LDS
 // and written with 16-byte coalesced stores (bias / accumulate / ReLU / BN column statistics fused).
 #include <stdlib.h>
+#include <mutex>
 
 #include "common.h"
 #include "conv_args.h"
@@ -685,6 +686,12 @@ struct WgradArgs {
   int KH, KW, pad_h, pad_w, stride;
   int M, tiles_n, tiles_c, pix_per_wg;
   int tiles, xcd_group;  // tiles = tiles_n * tiles_c * taps; xcd_group: 1-D launch, all tiles of a pixel split on one XCD
+  // Partial tiles instead of atomics (round 4): when `part` is set a work-group stores its fp32 tile, [c][n] with n fastest, at
+  // part + (split * tiles + tile) * TILE * TILE and wgrad_reduce_kernel sums the splits into dw afterwards.  fp32 atomics retire
+  // at ~0.25 T operations/s on this part whatever their scope (tests/native/atomics_bench: ~1 TB/s of partial sums) - the
+  // 64 KB x 512 work-group epilogue of a small-map 1x1 layer was 30 of its 77 us - plain 16-byte stores + one pass that reads
+  // the partials back from the MALL move the same bytes at 5+ TB/s.
+  float* part;
 };
 
 constexpr int WP = 32;  // pixels per reduction step
@@ -919,6 +926,16 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradArgs a) {
 
   // D[i = n][j = c]: lane holds column c = fr, rows n = fg*4 + r
   const int T = a.KH * a.KW;
+  if (a.part) {  // 16 B per lane: rows fg * 4 .. + 3 of column c are consecutive in the [c][n] partial tile
+    const int tlin = (tap * a.tiles_n + tile_n) * a.tiles_c + tile_c;
+    float* pt = a.part + ((size_t)split * a.tiles + tlin) * (128 * 128);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(pt + (wc * 64 + j * 16 + fr) * 128 + wr * 64 + i * 16 + fg * 4) = acc[i][j];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1082,6 +1099,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
   }
 
   // D[i = n][j = c]: lane holds column c = fr, rows n = fg*4 + r
+  if (a.part) {
+    const int tlin = (tap * a.tiles_n + tile_n) * a.tiles_c + tile_c;
+    float* pt = a.part + ((size_t)split * a.tiles + tlin) * (256 * 256);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        *reinterpret_cast<f32x4*>(pt + (wc * 128 + (j >> 2) * 64 + (j & 3) * 16 + fr) * 256 + wr * 64 + i * 16 + fg * 4) = acc[i][j];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1095,6 +1122,77 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
         if (n < a.n_valid) atomicAdd(dst + n * a.dw_sn, acc[i][j][r]);
       }
     }
+}
+
+// Sums the partial tiles of a weight-gradient launch over its pixel splits and adds the result into dw (single owner per
+// element: plain read-modify-write).  TILE x TILE partials, [c][n] with n fastest; a work-group takes 8 columns c of one tile:
+// 32 lanes x 16 B per column and split (coalesced), the sums go through LDS so that the dw accesses run along c (the contiguous
+// direction of both gradient layouts).
+template <int TILE>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int tiles, int per_group,
+                                                           WgradArgs a) {
+  constexpr int NQ = TILE / 4;            // 16-byte groups per column
+  constexpr int CPW = 256 / NQ;           // columns per pass of the work-group (8 for 128, 4 for 256)
+  constexpr int COLS = 8;                 // columns per work-group
+  __shared__ float sm[COLS][TILE + 1];
+  const int tlin = blockIdx.x, slab = blockIdx.y;
+  int t = tlin;
+  const int tile_c = t % a.tiles_c; t /= a.tiles_c;
+  const int tile_n = t % a.tiles_n; t /= a.tiles_n;
+  const int tap = t;
+  const int tid = threadIdx.x;
+  const int nq = tid % NQ, ci = tid / NQ;
+#pragma unroll
+  for (int cc = 0; cc < COLS / CPW; ++cc) {
+    const int c_local = slab * COLS + cc * CPW + ci;
+    const float* src = part + (size_t)tlin * (TILE * TILE) + c_local * TILE + nq * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    // blockIdx.z = group of `per_group` consecutive splits (launches with few tiles and hundreds of splits: a work-group per
+    // (tile, 8 columns) alone would be 32 work-groups reading 2 MB each); several groups meet in dw through atomics
+    int sp = blockIdx.z * per_group;
+    const int sp_end = min(splits, sp + per_group);
+    for (; sp + 1 < sp_end; sp += 2) {   // two independent chains: the loads of a pair are in flight together
+      s0 += *reinterpret_cast<const f32x4*>(src + (size_t)sp * tiles * (TILE * TILE));
+      s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 1) * tiles * (TILE * TILE));
+    }
+    if (sp < sp_end) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)sp * tiles * (TILE * TILE));
+    s0 += s1;
+    float* row = sm[cc * CPW + ci] + nq * 4;
+    row[0] = s0[0]; row[1] = s0[1]; row[2] = s0[2]; row[3] = s0[3];
+  }
+  __syncthreads();
+  const int c_rel = tid & (COLS - 1);
+  const int c = tile_c * TILE + slab * COLS + c_rel;
+  if (c >= a.c_valid) return;
+  float* dst = a.dw + (size_t)tap * a.dw_st + (size_t)c * a.dw_sc;
+  for (int nl = tid / COLS; nl < TILE; nl += 256 / COLS) {
+    const int n = tile_n * TILE + nl;
+    if (n < a.n_valid) {
+      if (gridDim.z == 1) dst[n * a.dw_sn] += sm[c_rel][nl];
+      else atomicAdd(dst + n * a.dw_sn, sm[c_rel][nl]);
+    }
+  }
+}
+
+// partial-tile scratch of the weight-gradient kernels: one buffer per (device, stream), allocated on first use (the kernels of a
+// stream run one after the other, so consecutive launches can share it)
+struct WgScratch { int device; hipStream_t stream; float* buf; };
+constexpr size_t WG_SCRATCH_BYTES = (size_t)96 << 20;
+float* wgrad_scratch(hipStream_t s, size_t need_bytes) {
+  static WgScratch table[32];
+  static int used = 0;
+  static std::mutex mu;
+  if (need_bytes > WG_SCRATCH_BYTES) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < used; ++i)
+    if (table[i].device == dev && table[i].stream == s) return table[i].buf;
+  if (used == 32) return nullptr;
+  WgScratch e{dev, s, nullptr};
+  if (hipMalloc(&e.buf, WG_SCRATCH_BYTES) != hipSuccess) return nullptr;
+  table[used++] = e;
+  return e.buf;
 }
 
 __device__ __attribute__((aligned(256))) bf16_t g_zero_page[128];
@@ -1330,7 +1428,8 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
   int slots = (wide ? 256 : 1024) >> ((variant >> 4) & 3);  // resident work-groups; variant bits 4-5: tuning knob
   int splits = slots / tiles;
   if (splits < 1) splits = 1;
-  const int by_pixels = a.M / 2048 > 1 ? a.M / 2048 : 1;
+  static const int minpix = getenv("U2_WGRAD_MINPIX") ? atoi(getenv("U2_WGRAD_MINPIX")) : 2048;   // measurement knob
+  const int by_pixels = a.M / minpix > 1 ? a.M / minpix : 1;
   if (splits > by_pixels) splits = by_pixels;
   const int min_groups = wide ? 256 : 512;
   if (tiles * splits < min_groups) {
@@ -1349,6 +1448,30 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
   const dim3 grid = a.xcd_group ? dim3(tiles * splits) : dim3(tiles, splits);
   const dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
+  // partial tiles + one reduction pass instead of the fp32-atomic epilogue (variant bit 16 keeps the atomics); a single split
+  // has nothing to reduce and little to gain
+  a.part = nullptr;
+  // Measured (tests/native/selftest bench2w 0 65536, round 4): the atomics of a long kernel hide behind the work-groups that are
+  // still multiplying, so the pass only pays where the launch is short or has many tiles - 1x1 layers on the stride-8 ... 32 maps
+  // (res4 78 -> 72 us, res5 67 -> 58, lat3 126 -> 113, res3 256->512 138 -> 114), mid-size 3x3 layers (+3...10 %); it loses on
+  // the stride-4 1x1 layers with one or two tiles and 512 splits (64 MB of partials: 64->256 134 -> 156 us) and on the big 3x3
+  // layers (-2...4 %).  variant bit 17 forces the pass wherever splits >= 2.
+  const long long dw_elems = (long long)a.tiles_n * a.tiles_c * tw * tw;
+  const bool part_auto = dw_elems >= 4LL * 128 * 128 && !(KH * KW > 1 && a.M >= 200000);
+  if (!(variant & 65536) && splits >= 2 && (part_auto || (variant & 131072)))
+    a.part = wgrad_scratch(s, (size_t)tiles * splits * tw * tw * sizeof(float));
+  auto reduce = [&]() -> int {
+    if (!a.part) return 0;
+    const int slabs = tw / 8;
+    int groups = (512 + tiles * slabs - 1) / (tiles * slabs);   // >= ~512 work-groups in the reduction pass
+    if (groups > splits / 4) groups = splits / 4 > 1 ? splits / 4 : 1;
+    const int per_group = (splits + groups - 1) / groups;
+    groups = (splits + per_group - 1) / per_group;
+    if (wide) hipLaunchKernelGGL(wgrad_reduce_kernel<256>, dim3(tiles, slabs, groups), dim3(256), 0, s, a.part, splits, tiles, per_group, a);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<128>, dim3(tiles, slabs, groups), dim3(256), 0, s, a.part, splits, tiles, per_group, a);
+    U2_CHECK_LAUNCH();
+    return 0;
+  };
   const bool glds = (variant & 1) == 0, tr = (variant & 2) == 0;
   g_last_conv_kernel = (wide ? 2256 : 2000 + (glds ? 2 : 0) + (tr ? 1 : 0)) + (a.xcd_group ? 100 : 0);
   if (wide) {
@@ -1359,7 +1482,7 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
     }
     hipLaunchKernelGGL(conv_wgrad256_kernel, grid, dim3(512), WG256_STAGES * WG256_STAGE, s, a);
     U2_CHECK_LAUNCH();
-    return 0;
+    return reduce();
   }
   const int ring = (variant >> 9) & 3;  // bits 9-10: LDS ring depth of the LDS-DMA form (0 = two buffers, 1 = 3, 2 = 4)
   if (glds && tr && ring == 1)      hipLaunchKernelGGL((conv_wgrad_kernel<true, true, 3>), grid, block, 0, s, a);
@@ -1369,5 +1492,5 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
   else if (!glds && tr) hipLaunchKernelGGL((conv_wgrad_kernel<false, true>), grid, block, 0, s, a);
   else                  hipLaunchKernelGGL((conv_wgrad_kernel<false, false>), grid, block, 0, s, a);
   U2_CHECK_LAUNCH();
-  return 0;
+  return reduce();
 }
