@@ -26,9 +26,9 @@ def per_kernel(d, counter):
 
 
 def family(name):
-    if "conv_wgrad" in name:
+    if "conv_wgrad" in name or "wgrad_reduce_kernel" in name:  # the reduction pass belongs to the launch whose partial tiles it sums
         return "conv_wgrad"
-    if "conv_tile_kernel" in name or "conv_igemm" in name or "conv_halo_kernel" in name:
+    if "conv_tile_kernel" in name or "conv_igemm" in name or "conv_halo_kernel" in name or "conv_stream_kernel" in name:
         return "conv_igemm"
     return None
 
@@ -37,9 +37,9 @@ def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {}
     for fam in ("conv_igemm", "conv_wgrad"):
-        nf = sum(v[0] for k, v in fetch.items() if family(k) == fam)
+        nf = sum(v[0] for k, v in fetch.items() if family(k) == fam and "wgrad_reduce_kernel" not in k)
         fb = sum(v[1] for k, v in fetch.items() if family(k) == fam) * 1024 * 2
-        nw = sum(v[0] for k, v in write.items() if family(k) == fam)
+        nw = sum(v[0] for k, v in write.items() if family(k) == fam and "wgrad_reduce_kernel" not in k)
         wb = sum(v[1] for k, v in write.items() if family(k) == fam) * 1024
         if nf and nw:
             out[fam] = {"launches": nf, "fetch_bytes_per_launch": fb / nf, "write_bytes_per_launch": wb / nw,

@@ -259,7 +259,9 @@ def _fixed_order_stats(out, n):
 
 def _stats_buffer(n, device):
     """[sum | sum of squares] of a conv output's channels as a view of a zeroed [2n + 1] buffer: under SyncBN the extra slot
-    takes this rank's element count and the whole buffer is all-reduced as it stands (no concatenation, no host round trip)."""
+    takes this rank's element count and the whole buffer is all-reduced as it stands (no concatenation, no host round trip).
+    The buffer is CONSUMED by batch_norm_act under SyncBN: after it the `stats` a caller still holds are the sums over all ranks,
+    not this rank's (the only consumer in this package is the norm that follows the conv; clone before the norm if both are needed)."""
     packed = zeros_f32((2 * n + 1,), device)
     st = packed[: 2 * n].view(2, n)
     st._u2_packed = packed
