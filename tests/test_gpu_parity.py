@@ -55,7 +55,10 @@ def nchw(x_nhwc, c=None):
 
 
 def rel_err(a, b):
-    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    """max |a - b| over max |b|.  Round 4: the kernel-level bounds below are 4e-3 ... 5e-3 - one bf16 step (2^-8) of the largest
+    element, i.e. one rounding of the result plus accumulation-order noise; measured values are 2e-3 ... 3.5e-3 (scratch probe of
+    every call site), the two looser bounds carry their reason next to the assert."""
+    return float((a.detach() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-12))
 
 
 # -------------------------------------------------------------------------------------------------
@@ -109,9 +112,9 @@ def test_stem_conv(F):
     yr.backward(gy)
     wd = w.detach().to(DEV).requires_grad_(True)
     y, stats = F.stem_conv(wd, [i.to(DEV) for i in imgs], mean.to(DEV), std.to(DEV), 64, 96)
-    assert rel_err(nchw(y), yr.detach()) < 1e-2
+    assert rel_err(nchw(y), yr.detach()) < 4e-3
     y.backward(nhwc(gy))
-    assert rel_err(wd.grad.cpu(), w.grad) < 1e-2
+    assert rel_err(wd.grad.cpu(), w.grad) < 4e-3
 
 
 def test_batch_norm_residual_relu(F):
@@ -135,9 +138,9 @@ def test_batch_norm_residual_relu(F):
     assert rel_err(nchw(y), yr.detach()) < 4e-3
     assert torch.allclose(rmd.cpu(), rm, atol=1e-4) and torch.allclose(rvd.cpu(), rv, atol=1e-3)  # running stats
     y.backward(nhwc(gy))
-    assert rel_err(nchw(xd.grad), xr.grad) < 2e-2
-    assert rel_err(nchw(rd.grad), rr.grad) < 1e-2
-    assert rel_err(gd.grad.cpu(), gamma.grad) < 1e-2 and rel_err(bd.grad.cpu(), beta.grad) < 1e-2
+    assert rel_err(nchw(xd.grad), xr.grad) < 5e-3
+    assert rel_err(nchw(rd.grad), rr.grad) < 4e-3
+    assert rel_err(gd.grad.cpu(), gamma.grad) < 1e-4 and rel_err(bd.grad.cpu(), beta.grad) < 1e-4
 
 
 def test_group_norm_relu(F):
@@ -152,10 +155,10 @@ def test_group_norm_relu(F):
     xd = nhwc(x).requires_grad_(True)
     gd, bd = gamma.detach().to(DEV).requires_grad_(True), beta.detach().to(DEV).requires_grad_(True)
     y = F.group_norm_act(xd, gd, bd, 32, True, 1e-5)
-    assert rel_err(nchw(y), yr.detach()) < 1e-2
+    assert rel_err(nchw(y), yr.detach()) < 4e-3
     y.backward(nhwc(gy))
-    assert rel_err(nchw(xd.grad), xr.grad) < 2e-2
-    assert rel_err(gd.grad.cpu(), gamma.grad) < 1e-2 and rel_err(bd.grad.cpu(), beta.grad) < 1e-2
+    assert rel_err(nchw(xd.grad), xr.grad) < 5e-3
+    assert rel_err(gd.grad.cpu(), gamma.grad) < 1e-4 and rel_err(bd.grad.cpu(), beta.grad) < 1e-4
 
 
 def test_pool_and_resample(F):
@@ -169,7 +172,7 @@ def test_pool_and_resample(F):
     y = F.max_pool_3x3_s2(xd)
     assert torch.equal(nchw(y), yr.detach())  # max of bf16 values is exact
     y.backward(nhwc(gy))
-    assert rel_err(nchw(xd.grad), xr.grad) < 1e-2
+    assert rel_err(nchw(xd.grad), xr.grad) < 5e-3
     # FPN top-down: lateral + nearest x2
     lat, top = bf(torch.randn((2, 64, 12, 16), generator=g)), bf(torch.randn((2, 64, 6, 8), generator=g))
     lr_, tr_ = lat.clone().requires_grad_(True), top.clone().requires_grad_(True)
@@ -180,7 +183,7 @@ def test_pool_and_resample(F):
     y = F.fpn_upsample_add(ld, td)
     assert rel_err(nchw(y), yr.detach()) < 5e-3
     y.backward(nhwc(gy))
-    assert torch.equal(nchw(ld.grad), lr_.grad) and rel_err(nchw(td.grad), tr_.grad) < 1e-2
+    assert torch.equal(nchw(ld.grad), lr_.grad) and rel_err(nchw(td.grad), tr_.grad) < 5e-3
     # bilinear x2 (+ addend)
     a = bf(torch.randn((2, 32, 7, 9), generator=g))
     add = bf(torch.randn((2, 32, 14, 18), generator=g))
@@ -190,9 +193,9 @@ def test_pool_and_resample(F):
     yr.backward(gy)
     ad, addd = nhwc(a).requires_grad_(True), nhwc(add).requires_grad_(True)
     y = F.bilinear_up2(ad, addd)
-    assert rel_err(nchw(y), yr.detach()) < 1e-2
+    assert rel_err(nchw(y), yr.detach()) < 5e-3
     y.backward(nhwc(gy))
-    assert rel_err(nchw(ad.grad), ar.grad) < 1e-2 and torch.equal(nchw(addd.grad), gy)
+    assert rel_err(nchw(ad.grad), ar.grad) < 5e-3 and torch.equal(nchw(addd.grad), gy)
 
 
 def test_sem_seg_loss(F):
@@ -208,7 +211,7 @@ def test_sem_seg_loss(F):
     loss = F.sem_seg_loss(ld, tgt.to(torch.uint8).to(DEV), 28, 255)
     assert float(loss) == pytest.approx(float(loss_r), rel=1e-4)
     (loss * 0.5).backward()
-    assert rel_err(nchw(ld.grad, 28), lr_.grad) < 1e-2
+    assert rel_err(nchw(ld.grad, 28), lr_.grad) < 4e-3
     assert float(ld.grad[..., 28:].abs().max()) == 0.0
 
 
@@ -226,7 +229,7 @@ def test_head_losses(F):
     loss = F.softmax_cross_entropy(zd, lab.to(DEV), 801)
     assert float(loss) == pytest.approx(float(lr_), rel=1e-4)
     loss.backward()
-    assert rel_err(zd.grad[:, :801].float().cpu(), zr.grad) < 1e-2
+    assert rel_err(zd.grad[:, :801].float().cpu(), zr.grad) < 4e-3
     # class-agnostic box regression L1 over foreground rows
     prop = torch.rand((70, 2), generator=g) * 100
     prop = torch.cat([prop, prop + 10 + torch.rand((70, 2), generator=g) * 50], 1)
@@ -262,8 +265,8 @@ def test_head_losses(F):
     loss = F.mask_predict_bce_loss(xd, wd, bd, cls.to(DEV), tgt.to(torch.uint8).to(DEV))
     assert float(loss) == pytest.approx(float(lref), rel=2e-3)
     loss.backward()
-    assert rel_err(nchw(xd.grad), xr.grad) < 2e-2
-    assert rel_err(wd.grad.cpu(), w.grad) < 2e-2 and rel_err(bd.grad.cpu(), b.grad) < 2e-2
+    assert rel_err(nchw(xd.grad), xr.grad) < 8e-3  # measured 5.6e-3: the reference rounds the selected logit to bf16 BEFORE the loss (one extra half step of the gradient's range), the kernel differentiates the fp32 logit
+    assert rel_err(wd.grad.cpu(), w.grad) < 6e-3 and rel_err(bd.grad.cpu(), b.grad) < 6e-3
 
 
 def test_roi_align_fwd_bwd(F, G):
@@ -296,14 +299,14 @@ def test_roi_align_fwd_bwd(F, G):
             FF.ROI_ALIGN_BWD_ATOMIC = atomic
             fd = [nhwc(f).requires_grad_(True) for f in feats]
             y = F.roi_align(fd, rois.to(DEV), lv, ps, scales, grad_scale=1.0 / 3)
-            assert rel_err(y.permute(0, 3, 1, 2).float().cpu(), out_ref.detach()) < 1e-2
+            assert rel_err(y.permute(0, 3, 1, 2).float().cpu(), out_ref.detach()) < 5e-3
             assert float(y[1].abs().max()) == 0.0
             y.backward(gy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV))
             for l in range(4):
                 if fr[l].grad is None:  # no ROI routed to this level
                     assert float(fd[l].grad.abs().max()) == 0.0
                 else:
-                    assert rel_err(nchw(fd[l].grad), fr[l].grad / 3) < 1.5e-2, (ps, atomic, l)
+                    assert rel_err(nchw(fd[l].grad), fr[l].grad / 3) < 5e-3, (ps, atomic, l)
         FF.ROI_ALIGN_BWD_ATOMIC = False
     # ground-truth mask crop (golden from the reference; exact except threshold ties of the rotated stand-in)
     out = F.mask_crop(torch.from_numpy(G["crop_masks"]).to(torch.uint8).to(DEV), torch.cat(
@@ -342,13 +345,13 @@ def test_roi_align_elongated_boxes(F):
         out_ref.backward(gy)
         fd = [nhwc(f).requires_grad_(True) for f in feats]
         y = F.roi_align(fd, rois.to(DEV), lv, ps, scales, grad_scale=1.0)
-        assert rel_err(y.permute(0, 3, 1, 2).float().cpu(), out_ref.detach()) < 1e-2, ps
+        assert rel_err(y.permute(0, 3, 1, 2).float().cpu(), out_ref.detach()) < 5e-3, ps
         y.backward(gy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV))
         for l in range(4):
             if fr[l].grad is None:
                 assert float(fd[l].grad.abs().max()) == 0.0
             else:
-                assert rel_err(nchw(fd[l].grad), fr[l].grad) < 1.5e-2, (ps, l)
+                assert rel_err(nchw(fd[l].grad), fr[l].grad) < 5e-3, (ps, l)
 
 
 def test_roi_grad_tap_combines_poolers(F):
@@ -381,7 +384,7 @@ def test_roi_grad_tap_combines_poolers(F):
 
     ref, got = run(False), run(True)
     for l, (a, b) in enumerate(zip(got, ref)):
-        assert rel_err(a, b) < 1e-2, l  # bf16 rounding of one sum instead of four partial maps
+        assert rel_err(a, b) < 5e-3, l  # bf16 rounding of one sum instead of four partial maps
 
 
 def test_index_bookkeeping_bit_exact(F, G):
@@ -473,8 +476,8 @@ def test_rpn_loss(F):
     assert float(lc) == pytest.approx(float(cls), rel=1e-4) and float(ll) == pytest.approx(float(loc), rel=1e-4)
     (lc + ll).backward()
     for i in range(3):
-        assert rel_err(od[i].grad[..., :A].float().cpu(), ov[i].grad) < 1e-2
-        assert rel_err(dd[i].grad[..., : 4 * A].float().cpu(), dv[i].grad) < 1e-2
+        assert rel_err(od[i].grad[..., :A].float().cpu(), ov[i].grad) < 5e-3
+        assert rel_err(dd[i].grad[..., : 4 * A].float().cpu(), dv[i].grad) < 5e-3
 
 
 def test_rpn_fused_predictors_equal_separate(F):
@@ -565,12 +568,12 @@ def test_arena_direct_grads_and_cached_layouts(F):
         for (k, a), (_, b) in zip(arena.named_parameters(), plain.named_parameters()):
             assert a.grad.data_ptr() == a._u2_grad.data_ptr(), k  # still the arena view
             if it == 0:
-                assert rel_err(a.grad, b.grad) < 2e-2, (it, k)
+                assert rel_err(a.grad, b.grad) < (1e-4 if it == 0 else 2e-2), (it, k)
         opt.step(1.0)
         popt.step()
         if it == 0:
             for (k, a), (_, b) in zip(arena.named_parameters(), plain.named_parameters()):
-                assert rel_err(a.detach(), b.detach()) < 2e-2, (it, k)  # zero-initialised parameters are lr * gradient
+                assert rel_err(a.detach(), b.detach()) < (1e-4 if it == 0 else 2e-2), (it, k)  # zero-initialised parameters are lr * gradient
     assert len(opt._layout_entries) >= 10  # fwd + dgrad layouts were registered and refreshed by step()
     modes = set()
     for p_, key, ent in opt._layout_entries:  # the batched LDS-tiled refresh == the per-tensor kernel, bit for bit
@@ -884,6 +887,64 @@ def test_whole_model_vs_oracle(F, fixed_order_statistics, branch):
         assert 0.3 * float(ref[k]) < float(losses[k]) < 3.0 * float(ref[k]), (k, report)
     gn = float(model.backbone.bottom_up.stem.conv1.weight.grad.norm())
     assert gn == gn and gn > 0
+
+
+def test_whole_model_production_statistics_path(F):
+    """The same free-running comparison through the PRODUCTION forward (BN column statistics from the conv epilogues' fp32 atomics,
+    the path bench.py runs; the two tests above use the fixed-order switch so that they are bit-reproducible): the dense losses
+    stay inside the same 2 % band of the bf16 oracle, and so do two runs of the production path against each other - the atomics'
+    accumulation order is the only difference between them, a last-ulp difference of the statistics that the random-weight
+    network amplifies to 0.7 % of loss_sem_seg (measured), which is why the strict comparisons are teacher-forced."""
+    from oracle.model import OracleModel
+    from tests.golden.make_fixtures import det_fill
+    from tests.test_gpu_bookkeeping import KeyRecorder
+    from u2seg_amd.config import get_cfg
+    from u2seg_amd.data import make_synthetic_batch
+    from u2seg_amd.modeling import build_model, set_key_source
+
+    cfg = get_cfg()
+    cfg.merge_from_file(CFG)
+    cfg.merge_from_list(["MODEL.DEVICE", DEV])
+    model = build_model(cfg)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            v.copy_(det_fill(k, v.cpu()).to(DEV))
+    model.train()
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    batch = make_synthetic_batch(2, height=192, width=256, device=DEV)
+    F.set_deterministic_stats(False)
+    runs, recs = [], []
+    for _ in range(2):
+        rec = KeyRecorder(5)
+        set_key_source(rec)
+        try:
+            with torch.no_grad():
+                for k, v in model.state_dict().items():   # the forward updates the running statistics: same start for both runs
+                    v.copy_(sd[k].to(DEV))
+            losses = model(batch)
+            sum(losses.values()).backward()
+        finally:
+            set_key_source(None)
+        torch.cuda.synchronize()
+        runs.append({k: float(v) for k, v in losses.items()})
+        recs.append(rec)
+    rec = recs[0]
+    cpu_batch = make_synthetic_batch(2, height=192, width=256)
+    ngt = [len(x["instances"]) for x in cpu_batch]
+
+    def key_fn(stage, i, n):
+        if stage == "rpn":
+            return rec.calls[0][i, :n]
+        k = rec.calls[1]
+        npad = k.shape[1] - max(ngt)
+        return torch.cat([k[i, : n - ngt[i]], k[i, npad : npad + ngt[i]]])
+
+    ref = OracleModel(cfg, sd, emulate_bf16=True, key_fn=key_fn).train_forward(cpu_batch)
+    dense = ["loss_sem_seg", "loss_rpn_cls", "loss_cls_stage0", "loss_cls_stage1", "loss_cls_stage2", "loss_mask"]
+    for k in dense:
+        assert runs[0][k] == pytest.approx(float(ref[k]), rel=2e-2), (k, runs[0], float(ref[k]))
+        assert runs[1][k] == pytest.approx(runs[0][k], rel=2e-2), (k, runs)
+    assert runs[0]["loss_rpn_loc"] == pytest.approx(float(ref["loss_rpn_loc"]), rel=5e-2)
 
 
 def test_backbone_and_heads_blockwise_vs_oracle(F):
