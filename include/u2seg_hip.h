@@ -282,11 +282,14 @@ int u2_sgd_clip_step(float* params, const float* grads, float* momentum_buf, con
                      float clip, float grad_scale, void* stream);
 
 /* ---- k-means over DINO embeddings (kmeans.hip): u2seg/Instance_Clustering/shared/utils/nn_utils.py:304-379 ---- */
-/* labels[i] = argmin_j |x_i - c_j|^2 (first minimum).  workspace: u2_kmeans_assign_workspace_floats(N, D, K) floats.  The
- * distances are screened with split-bf16 MFMA products and every point whose two best candidates are closer than the
- * screening error bound is labelled again with exact fp32 products, so the result is that of the exact kernel
+/* labels[i] = argmin_j |x_i - c_j|^2 (first minimum).  workspace: u2_kmeans_assign_workspace_floats(N, D, K) floats (contents
+ * need no initialisation; keep the same buffer between the iterations of a run: it also carries the screening state).  The
+ * distances are screened on bf16 MFMA - first with the leading bf16 piece of x and c alone, then, for the points that pass
+ * cannot decide, with the split products hi.hi + hi.lo + lo.hi - and every point whose two best candidates are closer than
+ * the screening error bound is labelled again with exact fp32 products, so the result is that of the exact kernel
  * (exact_only = 1 runs only that one; it is also what D % 32 != 0 or K > 320 fall back to).  After the call
- * ((int*)workspace)[((K + 3) & ~3) + 1] holds the number of re-checked points. */
+ * ((int*)workspace)[((K + 3) & ~3) + 1] holds the number of points re-checked exactly, [... + 2] the number the first pass
+ * left undecided. */
 long long u2_kmeans_assign_workspace_floats(int N, int D, int K);
 int u2_kmeans_assign(const float* x, const float* c, float* workspace, long long* labels, int N, int D, int K, int exact_only,
                      void* stream);

@@ -242,11 +242,26 @@ __device__ __forceinline__ uint32_t ks_pack(float lo, float hi) {  // v_cvt_pk_b
 }
 __device__ __forceinline__ int ks_swz(int row) { return (-(row >> 2)) & 3; }  // 64-byte rows: conflict-free ds_read_b128
 
+// NP = 3: the three products hi.hi + hi.lo + lo.hi (error <= 1.2e-5 |x| |c|, margin_rel 1e-4).  NP = 1 (round 4): hi.hi only - a
+// third of the matrix work, error <= 2^-8 |x| |c| per product (both operands rounded to bf16), i.e. 2^-6 |x| max|c| between two
+// distances; with margin_rel 0.02 (1.28 x that worst case) it decides every point of well-separated data (the mixture: own
+// centroid vs the next differ by ~|c - c'|^2, two orders above the margin) and hands the rest to the NP = 3 pass.
+// rows / nrows: the kernel labels the points rows[0 .. *nrows) (the undecided list of the coarser pass) instead of 0 .. N - 1.
+// gate / gate_want: the launch is skipped (work-groups leave at once) unless (*gate == 1) == gate_want - the host queues the
+// coarse pass, the fine pass over its list and the fine pass over everything, and a flag in the workspace picks two of the three.
+template <int NP>
 __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restrict__ x, const bf16_t* __restrict__ chl,
                                                             const float* __restrict__ cn, const unsigned* __restrict__ cmax2,
                                                             long long* __restrict__ labels, int* __restrict__ list,
-                                                            int* __restrict__ nlist, int N, int D, int K) {
+                                                            int* __restrict__ nlist, int N, int D, int K, float margin_rel,
+                                                            const int* __restrict__ rows, const int* __restrict__ nrows,
+                                                            const int* __restrict__ gate, int gate_want) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
+  if (gate && (*gate == 1) != (gate_want != 0)) return;
+  if (rows) {
+    N = min(N, *nrows);
+    if ((int)blockIdx.x * KS_PTS >= N) return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
@@ -259,7 +274,10 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
   // requested by both instructions)
   const float* xp[2];
 #pragma unroll
-  for (int m = 0; m < 2; ++m) xp[m] = x + (size_t)min(p0 + m * 16 + fr, N - 1) * D + fg * 4;
+  for (int m = 0; m < 2; ++m) {
+    const int pi = min(p0 + m * 16 + fr, N - 1);
+    xp[m] = x + (size_t)(rows ? rows[pi] : pi) * D + fg * 4;
+  }
   // Inline-asm loads (the compiler would drain the LDS-DMA ring in front of the first use of a load it can see).  The
   // registers are loaded in step s and split in step s + 1, i.e. loop-carried, and the compiler - which does not know the data is
   // in flight - is free to move them (it did: v_mov at the back-edge, in front of a wait that used to sit at the top of the
@@ -327,7 +345,8 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
         const float v0 = raw[m][e >> 1][(e & 1) * 2], v1 = raw[m][e >> 1][(e & 1) * 2 + 1];
         n2[m] += v0 * v0 + v1 * v1;
         h[e] = ks_pack(v0, v1);
-        l[e] = ks_pack(v0 - __uint_as_float(h[e] << 16), v1 - __uint_as_float(h[e] & 0xffff0000u));
+        if constexpr (NP == 3) l[e] = ks_pack(v0 - __uint_as_float(h[e] << 16), v1 - __uint_as_float(h[e] & 0xffff0000u));
+        else l[e] = 0u;
       }
       ah[m] = *reinterpret_cast<const s16x8*>(h);
       al[m] = *reinterpret_cast<const s16x8*>(l);
@@ -347,14 +366,21 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     s16x8 bq[2][4];   // [set][hi block 0, hi block 1, lo block 0, lo block 1]
     const unsigned sba = lds0 + (unsigned)((s % KS_RING) * KS_STAGE) + (unsigned)boff;
 #define U2_KS_LDQ(SET, NB)                                                                                                    \
-    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t"         \
-                 "ds_read_b128 %3, %4 offset:%8"                                                                               \
-                 : "=&v"(bq[SET][0]), "=&v"(bq[SET][1]), "=&v"(bq[SET][2]), "=&v"(bq[SET][3])                                 \
-                 : "v"(sba), "n"((NB) * 1024), "n"(((NB) + 1) * 1024), "n"(KS_KMAX * 64 + (NB) * 1024),                       \
-                   "n"(KS_KMAX * 64 + ((NB) + 1) * 1024)                                                                      \
-                 : "memory")
+    if constexpr (NP == 3)                                                                                                     \
+      asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t"       \
+                   "ds_read_b128 %3, %4 offset:%8"                                                                             \
+                   : "=&v"(bq[SET][0]), "=&v"(bq[SET][1]), "=&v"(bq[SET][2]), "=&v"(bq[SET][3])                               \
+                   : "v"(sba), "n"((NB) * 1024), "n"(((NB) + 1) * 1024), "n"(KS_KMAX * 64 + (NB) * 1024),                     \
+                     "n"(KS_KMAX * 64 + ((NB) + 1) * 1024)                                                                    \
+                   : "memory");                                                                                                \
+    else                                                                                                                       \
+      asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"                                           \
+                   : "=&v"(bq[SET][0]), "=&v"(bq[SET][1]) : "v"(sba), "n"((NB) * 1024), "n"(((NB) + 1) * 1024) : "memory")
 #define U2_KS_WAIT(SET, CNT)                                                                                                  \
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bq[SET][0]), "+v"(bq[SET][1]), "+v"(bq[SET][2]), "+v"(bq[SET][3]) : "n"(CNT) : "memory")
+    if constexpr (NP == 3)                                                                                                     \
+      asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bq[SET][0]), "+v"(bq[SET][1]), "+v"(bq[SET][2]), "+v"(bq[SET][3]) : "n"(CNT) : "memory"); \
+    else                                                                                                                       \
+      asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bq[SET][0]), "+v"(bq[SET][1]) : "n"((CNT) / 2) : "memory")
 #define U2_KS_PAIR(SET, NB)                                                                                                   \
     {                                                                                                                          \
       const s16x8 bh0 = bq[SET][0], bh1 = bq[SET][1], bl0 = bq[SET][2], bl1 = bq[SET][3];                                     \
@@ -362,14 +388,16 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
       acc[1][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], bh0, acc[1][NB], 0, 0, 0);                                  \
       acc[0][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bh1, acc[0][NB + 1], 0, 0, 0);                          \
       acc[1][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], bh1, acc[1][NB + 1], 0, 0, 0);                          \
-      acc[0][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bl0, acc[0][NB], 0, 0, 0);                                  \
-      acc[1][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], bl0, acc[1][NB], 0, 0, 0);                                  \
-      acc[0][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bl1, acc[0][NB + 1], 0, 0, 0);                          \
-      acc[1][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], bl1, acc[1][NB + 1], 0, 0, 0);                          \
-      acc[0][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[0], bh0, acc[0][NB], 0, 0, 0);                                  \
-      acc[1][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[1], bh0, acc[1][NB], 0, 0, 0);                                  \
-      acc[0][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[0], bh1, acc[0][NB + 1], 0, 0, 0);                          \
-      acc[1][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[1], bh1, acc[1][NB + 1], 0, 0, 0);                          \
+      if constexpr (NP == 3) {                                                                                                 \
+        acc[0][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bl0, acc[0][NB], 0, 0, 0);                                \
+        acc[1][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], bl0, acc[1][NB], 0, 0, 0);                                \
+        acc[0][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], bl1, acc[0][NB + 1], 0, 0, 0);                        \
+        acc[1][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], bl1, acc[1][NB + 1], 0, 0, 0);                        \
+        acc[0][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[0], bh0, acc[0][NB], 0, 0, 0);                                \
+        acc[1][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[1], bh0, acc[1][NB], 0, 0, 0);                                \
+        acc[0][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[0], bh1, acc[0][NB + 1], 0, 0, 0);                        \
+        acc[1][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[1], bh1, acc[1][NB + 1], 0, 0, 0);                        \
+      }                                                                                                                        \
     }
     // pair g + 1 is requested in front of the MFMAs of pair g: the wait of pair g leaves the 4 younger reads in flight
 #define U2_KS_GROUP(SET, NB)                                                                                                  \
@@ -406,7 +434,7 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     if (fg == 0) norms[w * 32 + m * 16 + fr] = sqrtf(v);
   }
   __syncthreads();
-  const float margin_unit = 1e-4f * sqrtf(__uint_as_float(*cmax2));
+  const float margin_unit = margin_rel * sqrtf(__uint_as_float(*cmax2));
   // Branch-free arg-min (round 4: the first version - km_less per element, one global load of |c_j|^2 per use, ds_bpermute
   // shuffles - compiled to ~700 divergent branches and was 0.32 of the kernel's 1.8 ms, with the matrix pipe idle meanwhile).
   // NaN needs no ordering here: a NaN or Inf in x makes |x| and therefore the margin NaN / Inf, one in c makes max|c| NaN, and
@@ -460,8 +488,9 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
       const int pl = m * 16 + fg * 4 + r;
       const int p = p0 + pl;
       if (fr == 0 && p < N) {
-        labels[p] = (long long)bj;
-        if (!(ss - bb >= margin_unit * norms[w * 32 + pl])) list[atomicAdd(nlist, 1)] = p;  // also: NaN anywhere, K == 1
+        const int row = rows ? rows[p] : p;
+        labels[row] = (long long)bj;
+        if (!(ss - bb >= margin_unit * norms[w * 32 + pl])) list[atomicAdd(nlist, 1)] = row;  // also: NaN anywhere, K == 1
       }
     }
   }
@@ -652,9 +681,30 @@ __global__ void kmeans_finalize_kernel(const float* __restrict__ csum, const flo
 
 }  // namespace
 
+// ---- two-level screening (round 4) ---------------------------------------------------------------------------------------
+// Workspace words behind the lists: {magic, coarse_off, calls since the coarse pass was switched off, -}.  The coarse (hi.hi)
+// pass costs a third of the fine one and decides everything on clustered data; on unstructured data (randn: the two best of 300
+// distances are closer than its margin for most points) it decides little and would only be overhead.  The flag is sticky per
+// workspace: a coarse pass that leaves more than a quarter of the points undecided switches itself off, every 64th call tries
+// again.  Labels are those of the exact kernel in either mode - the modes differ in time only.
+constexpr unsigned KS_MAGIC = 0x4b533431u;
+__global__ void km_state_begin_kernel(unsigned* __restrict__ scal, unsigned* __restrict__ state) {
+  if (threadIdx.x < 4) scal[threadIdx.x] = 0u;
+  if (threadIdx.x == 0 && state[0] != KS_MAGIC) { state[0] = KS_MAGIC; state[1] = 0u; state[2] = 0u; state[3] = 0u; }
+}
+__global__ void km_state_end_kernel(const unsigned* __restrict__ scal, unsigned* __restrict__ state, int N) {
+  if (threadIdx.x != 0) return;
+  if (state[1] == 0u) {
+    if (scal[2] > (unsigned)N / 4u) { state[1] = 1u; state[2] = 0u; }
+  } else if (++state[2] >= 64u) {
+    state[1] = 0u; state[2] = 0u;
+  }
+}
+
 extern "C" long long u2_kmeans_assign_workspace_floats(int N, int D, int K) {
-  // |c|^2 [K] | max |c|^2, list length [2] | split centroids [2][320][D] bf16 | re-check list [N]
-  return (long long)K + 16 + (long long)KS_KMAX * D + N + 16;
+  // |c|^2 [K] | max |c|^2, exact-list length, coarse-list length [4] | split centroids [2][320][D] bf16 | exact re-check list [N]
+  // | undecided list of the coarse pass [N] | screening state [4]
+  return (long long)K + 16 + (long long)KS_KMAX * D + 2LL * N + 32;
 }
 
 extern "C" int u2_kmeans_assign(const float* x, const float* c, float* workspace, long long* labels, int N, int D, int K,
@@ -672,25 +722,47 @@ extern "C" int u2_kmeans_assign(const float* x, const float* c, float* workspace
     U2_CHECK_LAUNCH();
     return 0;
   }
-  unsigned* scal = reinterpret_cast<unsigned*>(workspace + ((K + 3) & ~3));  // [0] max |c|^2 bits, [1] list length
+  unsigned* scal = reinterpret_cast<unsigned*>(workspace + ((K + 3) & ~3));  // [0] max |c|^2 bits, [1] exact-list length, [2] coarse-list length
   bf16_t* chl = reinterpret_cast<bf16_t*>(workspace + ((K + 3) & ~3) + 4);
-  int* list = reinterpret_cast<int*>(workspace + ((K + 3) & ~3) + 4 + (size_t)KS_KMAX * D);
-  u2_zero_words(scal, 2, s);
+  int* list2 = reinterpret_cast<int*>(workspace + ((K + 3) & ~3) + 4 + (size_t)KS_KMAX * D);
+  int* list1 = list2 + N;
+  unsigned* state = reinterpret_cast<unsigned*>(list1 + N);
+  state += (4 - ((reinterpret_cast<size_t>(state) >> 2) & 3)) & 3;   // 16-byte aligned (the slack is in the + 32 of the size)
+  hipLaunchKernelGGL(km_state_begin_kernel, dim3(1), dim3(64), 0, s, scal, state);
   U2_CHECK_LAUNCH();
   hipLaunchKernelGGL(csplit_kernel, dim3(KS_KMAX / 4), dim3(256), 0, s, c, chl, cn, scal, D, K);
   U2_CHECK_LAUNCH();
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kmeans_screen_kernel, dim3((N + KS_PTS - 1) / KS_PTS), dim3(512), KS_RING * KS_STAGE, s, x, chl, cn, scal,
-                     labels, list, reinterpret_cast<int*>(scal + 1), N, D, K);
+  const dim3 grid((N + KS_PTS - 1) / KS_PTS), block(512);
+  const size_t lds = KS_RING * KS_STAGE;
+  const int* gate = reinterpret_cast<const int*>(state + 1);
+  static const int two_level = getenv("U2_KM_ONE_LEVEL") ? 0 : 1;   // measurement knob: the round-3 single (fine) pass
+  if (two_level) {
+    // coarse pass over everything -> list1; fine pass over list1 -> list2 (both skipped while the coarse pass is switched off)
+    hipLaunchKernelGGL(kmeans_screen_kernel<1>, grid, block, lds, s, x, chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D,
+                       K, 0.02f, (const int*)nullptr, (const int*)nullptr, gate, 0);
+    U2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(kmeans_screen_kernel<3>, grid, block, lds, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N, D,
+                       K, 1e-4f, (const int*)list1, reinterpret_cast<const int*>(scal + 2), gate, 0);
+    U2_CHECK_LAUNCH();
+  }
+  // fine pass over everything -> list2 (the only pass while the coarse one is switched off)
+  hipLaunchKernelGGL(kmeans_screen_kernel<3>, grid, block, lds, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N, D, K,
+                     1e-4f, (const int*)nullptr, (const int*)nullptr, two_level ? gate : (const int*)nullptr, 1);
   U2_CHECK_LAUNCH();
   // the undecided points, exactly; the grid covers the worst case, work-groups beyond the list return immediately
   hipLaunchKernelGGL(kmeans_assign_kernel, dim3((N + KM_PTS - 1) / KM_PTS), dim3(256), 0, s, x, c, cn, labels, N, D, K,
-                     (const int*)list, (const int*)(scal + 1));
+                     (const int*)list2, (const int*)(scal + 1));
   U2_CHECK_LAUNCH();
+  if (two_level) {
+    hipLaunchKernelGGL(km_state_end_kernel, dim3(1), dim3(64), 0, s, scal, state, N);
+    U2_CHECK_LAUNCH();
+  }
   return 0;
 }
 
