@@ -681,6 +681,32 @@ def test_kmeans_screened_assign_equals_exact():
     assert n_checked < 1000  # the last (well separated, K = 17) case re-checks almost nothing
 
 
+def test_kmeans_two_level_screen_modes():
+    """The two-level screen (round 4): on clustered data the first pass (leading bf16 pieces only) decides nearly everything and
+    the labels are the exact kernel's; on unstructured data it leaves most points undecided, the labels are still the exact
+    kernel's, and the pass switches itself off for the following calls on that workspace (its undecided count reads 0)."""
+    from u2seg_amd.cluster import kmeans as KM
+
+    g = torch.Generator().manual_seed(33)
+    n, d, k = 24000, 768, 300
+    centers = torch.randn((k, d), generator=g) * 2
+    xm = (centers[torch.randint(0, k, (n,), generator=g)] + 0.5 * torch.randn((n, d), generator=g)).to(DEV)
+    cm = (centers + 0.3 * torch.randn((k, d), generator=g)).to(DEV)
+    xr = torch.randn((n, d), generator=g).to(DEV)
+    cr = xr[torch.randperm(n, generator=g)[:k].to(DEV)].clone()
+    KM._ws_cache.pop("assign:" + str(xm.device), None)   # a fresh workspace: the screening state starts with the first pass on
+    fast = KM.assign(xm, cm)
+    und = KM.last_coarse_undecided(xm.device)
+    assert torch.equal(fast, KM.assign(xm, cm, exact=True)) and 0 <= und < n // 100, und
+    fast = KM.assign(xr, cr)
+    und = KM.last_coarse_undecided(xr.device)
+    assert und > n // 4, und                      # the first pass ran and decided little ...
+    assert torch.equal(fast, KM.assign(xr, cr, exact=True))
+    fast = KM.assign(xr, cr)                      # ... so it is switched off now
+    assert KM.last_coarse_undecided(xr.device) == 0 and torch.equal(fast, KM.assign(xr, cr, exact=True))
+    KM._ws_cache.pop("assign:" + str(xm.device), None)
+
+
 def _clustered_unit_rows(n, d, seed, nclusters=40):
     g = torch.Generator().manual_seed(seed)
     centers = torch.randn((nclusters, d), generator=g)

@@ -50,6 +50,16 @@ def last_recheck_count(device):
     return int(ws.view(torch.int32)[((k + 3) & ~3) + 1])
 
 
+def last_coarse_undecided(device):
+    """How many points the first (leading-bf16-piece) screening pass of the last assign() left undecided; 0 when that pass was
+    switched off or skipped (reads the workspace: one host sync)."""
+    ent = _ws_cache.get("assign:" + str(device))
+    if ent is None or not isinstance(ent, tuple) or ent[1] is None:
+        return None
+    ws, k = ent
+    return int(ws.view(torch.int32)[((k + 3) & ~3) + 2])
+
+
 def update(x, labels, k):
     """c = scatter_add(x by label) / bincount(label) -> (centroids [K, D], counts [K])."""
     n, d = x.shape
