@@ -45,7 +45,7 @@ class _PinnedRing:
     batch-32 inference inside the default bench.py run, after the training workload, 47 -> 68 ms per batch).  A slot is
     reused only after the event recorded behind its last copy has completed."""
 
-    SLOTS, SLOT_BYTES = 64, 16384
+    SLOTS, SLOT_BYTES = 64, 65536
     _rings = {}
 
     def __init__(self, dev):
