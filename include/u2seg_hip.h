@@ -108,6 +108,18 @@ int u2_bn_finalize_bwd(const float* sums, float count, const float* count_dev, c
 int u2_norm_bwd_apply(const void* dout, const void* mask, const void* x, const float* k1, const float* k2,
                       const float* k3, void* dx, void* dres, int slots, int rows_per_slot, int C, int ld, int relu,
                       const float* mask_scale, const float* mask_shift, void* stream);
+/* Round 4: nn.SyncBatchNorm's finalize and apply steps (layers/batch_norm.py:169-197 + the residual add / relu_ of
+ * backbone/resnet.py:204-210) as ONE launch each way - u2_bn_finalize_fwd + u2_affine_act (slots = 1), resp. u2_bn_finalize_bwd +
+ * u2_norm_bwd_apply, with identical results: every thread derives the coefficients of its channels from the column sums, one
+ * work-group writes mean / invstd / scale / shift and the running statistics (forward) or adds dgamma / dbeta (backward).
+ * k123: [3][C] scratch, only written when C is not served by the one-launch form (C / 8 must divide 256). */
+int u2_bn_act_fused(const void* x, const float* sums, float count, const float* count_dev, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                    float* shift, const void* resid, void* out, int rows, int C, int ld, int relu, void* relu_bits, void* stream);
+int u2_bn_bwd_apply_fused(const float* sums, float count, const float* count_dev, const float* gamma, const float* mean,
+                          const float* invstd, const float* local_sums, float* dgamma, float* dbeta, float* k123, int accumulate,
+                          const void* dout, const void* mask, const void* x, void* dx, void* dres, int rows, int C, int ld,
+                          int relu, const float* mask_scale, const float* mask_shift, void* stream);
 int u2_relu_bwd(const void* dout, const void* out, void* dz, long long numel, void* stream);
 /* out = a + b (+ c (+ d)) on bf16 tensors of numel elements (numel % 8 == 0), summed in fp32 and rounded once; out may alias an
  * input. The gradient sum autograd would otherwise make with k - 1 separate adds where a tensor has k consumers (the FPN

@@ -275,18 +275,59 @@ __global__ __launch_bounds__(256) void add_n_kernel(const bf16_t* __restrict__ a
 //      Two rows are in flight per thread (all loads issued before the first use) to cover the HBM latency. ----
 constexpr int EW_UNROLL = 2;
 
-template <bool RESID, bool RELU, int UN>
+// Round 4: the BatchNorm finalize step folded into the apply pass (FIN): every thread derives scale / shift of its eight channels
+// from the column sums with bn_finalize_fwd_kernel's own expressions (bit-identical: fp contraction is off), work-group (0, 0)
+// also writes mean / invstd / scale / shift (the backward pass and the mask recompute read them) and updates the running
+// statistics - 61 launches of ~4.5 us less on the forward critical path of a training step, as many in backward.
+struct BnFwdFin {
+  const float* sums; const float* count_dev; const float* gamma; const float* beta;
+  float* running_mean; float* running_var; float* mean; float* invstd; float* scale; float* shift;
+  float count, momentum, eps;
+};
+__device__ __forceinline__ void bn_fwd_coeffs(const BnFwdFin& f, float count, int C, int c, float& mu, float& var, float& is, float& sc,
+                                              float& sh) {
+  mu = f.sums[c] / count;
+  var = f.sums[C + c] / count - mu * mu;
+  var = fmaxf(var, 0.f);
+  is = rsqrtf(var + f.eps);
+  const float g = f.gamma[c];
+  sc = g * is;
+  sh = f.beta[c] - mu * g * is;
+}
+
+template <bool RESID, bool RELU, int UN, bool FIN = false>
 __global__ __launch_bounds__(256) void affine_act_fast_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const bf16_t* __restrict__ resid,
                                                               bf16_t* __restrict__ out, int rows_per_slot, int C, int ld,
-                                                              unsigned char* __restrict__ relu_bits, int rev) {
+                                                              unsigned char* __restrict__ relu_bits, int rev, const BnFwdFin fin) {
   const int cpr = C >> 3;
   const int rows_par = 256 / cpr;
   const int cc = threadIdx.x % cpr, rl = threadIdx.x / cpr;
   const int slot = blockIdx.y;
   float sc[8], sh[8];
+  if constexpr (FIN) {
+    const float count = fin.count_dev ? *fin.count_dev : fin.count;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { sc[e] = scale[(size_t)slot * C + cc * 8 + e]; sh[e] = shift[(size_t)slot * C + cc * 8 + e]; }
+    for (int e = 0; e < 8; ++e) {
+      float mu, var, is;
+      bn_fwd_coeffs(fin, count, C, cc * 8 + e, mu, var, is, sc[e], sh[e]);
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+      for (int c = threadIdx.x; c < C; c += 256) {
+        float mu, var, is, s_, h_;
+        bn_fwd_coeffs(fin, count, C, c, mu, var, is, s_, h_);
+        fin.mean[c] = mu; fin.invstd[c] = is; fin.scale[c] = s_; fin.shift[c] = h_;
+        if (fin.running_mean) {
+          const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+          fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * mu;
+          fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * unbiased;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = scale[(size_t)slot * C + cc * 8 + e]; sh[e] = shift[(size_t)slot * C + cc * 8 + e]; }
+  }
   const size_t base = (size_t)slot * rows_per_slot;
   const int stride = gridDim.x * rows_par;
   const bool nt = (size_t)rows_per_slot * gridDim.y * ld * 2 > NT_BYTES;
@@ -406,25 +447,57 @@ __global__ __launch_bounds__(256) void affine_upadd_fast_kernel(const bf16_t* __
 }
 
 // MASK: 0 no ReLU, 1 read the activation, 2 recompute x*ms + mh > 0
-template <int MASK, bool DRES, int UN>
+// the backward finalize step folded in the same way (FIN): k1 / k2 / k3 from the (all-reduced) sums per thread, work-group (0, 0)
+// adds the parameter gradients
+struct BnBwdFin {
+  const float* sums; const float* count_dev; const float* gamma; const float* mean; const float* invstd; const float* local_sums;
+  float* dgamma; float* dbeta;
+  float count; int accumulate;
+};
+__device__ __forceinline__ void bn_bwd_coeffs(const BnBwdFin& f, float count, int C, int c, float& k1, float& k2, float& k3) {
+  const float s1 = f.sums[c], s2 = f.sums[C + c];
+  const float g = f.gamma[c], is = f.invstd[c], mu = f.mean[c];
+  const float a = g * is;
+  const float b = a * is * s2 / count;
+  k1 = a;
+  k2 = -b;
+  k3 = -a * s1 / count + b * mu;
+}
+
+template <int MASK, bool DRES, int UN, bool FIN = false>
 __global__ __launch_bounds__(256) void norm_bwd_apply_fast_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ mask,
                                                                   const bf16_t* __restrict__ x, const float* __restrict__ k1,
                                                                   const float* __restrict__ k2, const float* __restrict__ k3,
                                                                   bf16_t* __restrict__ dx, bf16_t* __restrict__ dres,
                                                                   int rows_per_slot, int C, int ld,
-                                                                  const float* __restrict__ msc, const float* __restrict__ msh, int rev) {
+                                                                  const float* __restrict__ msc, const float* __restrict__ msh, int rev,
+                                                                  const BnBwdFin fin) {
   const int cpr = C >> 3;
   const int rows_par = 256 / cpr;
   const int cc = threadIdx.x % cpr, rl = threadIdx.x / cpr;
   const int slot = blockIdx.y;
   float a1[8], a2[8], a3[8], ms[8], mh[8];
+  if constexpr (FIN) {
+    const float count = fin.count_dev ? *fin.count_dev : fin.count;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    a1[e] = k1[(size_t)slot * C + cc * 8 + e];
-    a2[e] = k2[(size_t)slot * C + cc * 8 + e];
-    a3[e] = k3[(size_t)slot * C + cc * 8 + e];
-    if (MASK == 2) { ms[e] = msc[(size_t)slot * C + cc * 8 + e]; mh[e] = msh[(size_t)slot * C + cc * 8 + e]; }
+    for (int e = 0; e < 8; ++e) bn_bwd_coeffs(fin, count, C, cc * 8 + e, a1[e], a2[e], a3[e]);
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+      for (int c = threadIdx.x; c < C; c += 256) {
+        if (fin.accumulate) { fin.dbeta[c] += fin.local_sums[c]; fin.dgamma[c] += fin.local_sums[C + c]; }
+        else { fin.dbeta[c] = fin.local_sums[c]; fin.dgamma[c] = fin.local_sums[C + c]; }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a1[e] = k1[(size_t)slot * C + cc * 8 + e];
+      a2[e] = k2[(size_t)slot * C + cc * 8 + e];
+      a3[e] = k3[(size_t)slot * C + cc * 8 + e];
+    }
   }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (MASK == 2) { ms[e] = msc[(size_t)slot * C + cc * 8 + e]; mh[e] = msh[(size_t)slot * C + cc * 8 + e]; }
   const size_t base = (size_t)slot * rows_per_slot;
   const int stride = gridDim.x * rows_par;
   const bool nt = (size_t)rows_per_slot * gridDim.y * ld * 2 > NT_BYTES;
@@ -786,7 +859,7 @@ extern "C" int u2_affine_act(const void* x, const float* scale, const float* shi
 #define U2_AFFINE_U(RS_, RL_, UN_)                                                                                   \
   hipLaunchKernelGGL((affine_act_fast_kernel<RS_, RL_, UN_>), fast_grid(slots, rows_per_slot, C, UN_), dim3(256), 0,           \
                      (hipStream_t)stream, (const bf16_t*)x, scale, shift, (const bf16_t*)resid, (bf16_t*)out, rows_per_slot, C, \
-                     ld, (unsigned char*)relu_bits, stream_order() & 1)
+                     ld, (unsigned char*)relu_bits, stream_order() & 1, BnFwdFin{})
 #define U2_AFFINE(RS_, RL_) do { if (ew_unroll() == 4) U2_AFFINE_U(RS_, RL_, 4); else U2_AFFINE_U(RS_, RL_, 2); } while (0)
     if (resid) { if (relu) U2_AFFINE(true, true); else U2_AFFINE(true, false); }
     else { if (relu) U2_AFFINE(false, true); else U2_AFFINE(false, false); }
@@ -797,6 +870,62 @@ extern "C" int u2_affine_act(const void* x, const float* scale, const float* shi
   }
   hipLaunchKernelGGL(affine_act_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      scale, shift, (const bf16_t*)resid, (bf16_t*)out, rows_per_slot, M, C, ld, relu);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+// BatchNorm finalize + apply in one launch (slots = 1: BatchNorm statistics are per batch); shapes the fast kernel does not
+// serve run the two separate launches.
+extern "C" int u2_bn_act_fused(const void* x, const float* sums, float count, const float* count_dev, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                               float* invstd, float* scale, float* shift, const void* resid, void* out, int rows, int C, int ld,
+                               int relu, void* relu_bits, void* stream) {
+  if ((C & 7) || (ld & 7)) return -1;
+  if (relu_bits && !(fast_ok(C) && ld == C)) return -1;
+  if (rows <= 0) return 0;
+  if (!fast_ok(C)) {
+    const int rc = u2_bn_finalize_fwd(sums, count, count_dev, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
+                                      scale, shift, C, stream);
+    if (rc) return rc;
+    return u2_affine_act(x, scale, shift, resid, out, 1, rows, C, ld, relu, relu_bits, stream);
+  }
+  const BnFwdFin fin{sums, count_dev, gamma, beta, running_mean, running_var, mean, invstd, scale, shift, count, momentum, eps};
+#define U2_BNACT(RS_, RL_)                                                                                            \
+  hipLaunchKernelGGL((affine_act_fast_kernel<RS_, RL_, EW_UNROLL, true>), fast_grid(1, rows, C, EW_UNROLL), dim3(256), 0,      \
+                     (hipStream_t)stream, (const bf16_t*)x, (const float*)nullptr, (const float*)nullptr, (const bf16_t*)resid, \
+                     (bf16_t*)out, rows, C, ld, (unsigned char*)relu_bits, stream_order() & 1, fin)
+  if (resid) { if (relu) U2_BNACT(true, true); else U2_BNACT(true, false); }
+  else { if (relu) U2_BNACT(false, true); else U2_BNACT(false, false); }
+#undef U2_BNACT
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_bn_bwd_apply_fused(const float* sums, float count, const float* count_dev, const float* gamma, const float* mean,
+                                     const float* invstd, const float* local_sums, float* dgamma, float* dbeta, float* k123,
+                                     int accumulate, const void* dout, const void* mask, const void* x, void* dx, void* dres,
+                                     int rows, int C, int ld, int relu, const float* mask_scale, const float* mask_shift,
+                                     void* stream) {
+  if ((C & 7) || (ld & 7)) return -1;
+  if (relu && !mask && !mask_scale) return -1;
+  if (rows <= 0) return 0;
+  if (!fast_ok(C)) {
+    const int rc = u2_bn_finalize_bwd(sums, count, count_dev, gamma, mean, invstd, local_sums, dgamma, dbeta, k123, k123 + C,
+                                      k123 + 2 * C, C, accumulate, stream);
+    if (rc) return rc;
+    return u2_norm_bwd_apply(dout, mask, x, k123, k123 + C, k123 + 2 * C, dx, dres, 1, rows, C, ld, relu, mask_scale, mask_shift,
+                             stream);
+  }
+  const BnBwdFin fin{sums, count_dev, gamma, mean, invstd, local_sums, dgamma, dbeta, count, accumulate};
+  const int mm = !relu ? 0 : (mask_scale ? 2 : 1);
+#define U2_BNAPPLY(MM_, DR_)                                                                                          \
+  hipLaunchKernelGGL((norm_bwd_apply_fast_kernel<MM_, DR_, EW_UNROLL, true>), fast_grid(1, rows, C, EW_UNROLL), dim3(256), 0,  \
+                     (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)mask, (const bf16_t*)x, (const float*)nullptr,    \
+                     (const float*)nullptr, (const float*)nullptr, (bf16_t*)dx, (bf16_t*)dres, rows, C, ld, mask_scale,         \
+                     mask_shift, (stream_order() >> 2) & 1, fin)
+  if (dres) { if (mm == 0) U2_BNAPPLY(0, true); else if (mm == 1) U2_BNAPPLY(1, true); else U2_BNAPPLY(2, true); }
+  else { if (mm == 0) U2_BNAPPLY(0, false); else if (mm == 1) U2_BNAPPLY(1, false); else U2_BNAPPLY(2, false); }
+#undef U2_BNAPPLY
   U2_CHECK_LAUNCH();
   return 0;
 }
@@ -833,7 +962,7 @@ extern "C" int u2_norm_bwd_apply(const void* dout, const void* mask, const void*
 #define U2_APPLY_U(MM_, DR_, UN_)                                                                                    \
   hipLaunchKernelGGL((norm_bwd_apply_fast_kernel<MM_, DR_, UN_>), fast_grid(slots, rows_per_slot, C, UN_), dim3(256), 0,  \
                      (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)mask, (const bf16_t*)x, k1, k2, k3, (bf16_t*)dx, \
-                     (bf16_t*)dres, rows_per_slot, C, ld, mask_scale, mask_shift, (stream_order() >> 2) & 1)
+                     (bf16_t*)dres, rows_per_slot, C, ld, mask_scale, mask_shift, (stream_order() >> 2) & 1, BnBwdFin{})
 #define U2_APPLY(MM_, DR_) do { if (ew_unroll() == 4) U2_APPLY_U(MM_, DR_, 4); else U2_APPLY_U(MM_, DR_, 2); } while (0)
     if (dres) { if (mm == 0) U2_APPLY(0, true); else if (mm == 1) U2_APPLY(1, true); else U2_APPLY(2, true); }
     else { if (mm == 0) U2_APPLY(0, false); else if (mm == 1) U2_APPLY(1, false); else U2_APPLY(2, false); }

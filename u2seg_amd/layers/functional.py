@@ -516,13 +516,13 @@ class _BatchNormActFn(Function):
             stats, count_dev = packed[: 2 * c].view(2, c), packed[2 * c :]
         mean = torch.empty(c, dtype=torch.float32, device=y.device)
         invstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
-        _hip.call("u2_bn_finalize_fwd", stats, count, count_dev, gamma, beta, running_mean, running_var, momentum, eps, mean,
-                  invstd, scale, shift, c)
         out = torch.empty_like(y)
         bits = None
         if res_up:
             # FPN top-down step (backbone/fpn.py:153-155): the residual is the coarser level, nearest-upsampled on the fly
             assert residual is not None and not relu and tuple(residual.shape) == (b, h // 2, w // 2, c)
+            _hip.call("u2_bn_finalize_fwd", stats, count, count_dev, gamma, beta, running_mean, running_var, momentum, eps, mean,
+                      invstd, scale, shift, c)
             _hip.call("u2_affine_upadd", y, scale, shift, residual.contiguous(), out, b, h, w, c, 0)
         else:
             # a residual block's tail: backward needs only the sign of the activation - kept as one bit per element, so that
@@ -530,7 +530,9 @@ class _BatchNormActFn(Function):
             cpr = c // 8
             if relu and residual is not None and c % 8 == 0 and cpr <= 256 and 256 % cpr == 0:
                 bits = torch.empty((m, cpr), dtype=torch.uint8, device=y.device)
-            _hip.call("u2_affine_act", y, scale, shift, residual, out, 1, m, c, c, int(relu), bits)
+            # finalize + apply in one launch (round 4): the coefficients are derived per thread from the column sums
+            _hip.call("u2_bn_act_fused", y, stats, count, count_dev, gamma, beta, running_mean, running_var, momentum, eps, mean,
+                      invstd, scale, shift, residual, out, m, c, c, int(relu), bits)
         # ReLU mask in backward: without a residual it is recomputed from y (one activation read less per pass)
         remask = relu and residual is None
         keep_out = relu and not remask
@@ -575,15 +577,17 @@ class _BatchNormActFn(Function):
         coef = torch.empty((5, c), dtype=torch.float32, device=y.device)
         direct = ctx.grad_dst is not None
         dgamma, dbeta = ctx.grad_dst if direct else (coef[0], coef[1])
-        _hip.call("u2_bn_finalize_bwd", sums, count, ctx.count_dev, gamma, mean, invstd, local, dgamma, dbeta, coef[2], coef[3],
-                  coef[4], c, int(direct))
         dx = torch.empty_like(y)
+        # finalize (coefficients of dx, dgamma / dbeta) + apply in one launch (round 4); coef[2:5] is scratch for the channel
+        # counts the one-launch form does not serve
         if fuse:
-            _hip.call("u2_norm_bwd_apply", dz, None, y, coef[2], coef[3], coef[4], dx, None, 1, m, c, c, 0, None, None)
+            _hip.call("u2_bn_bwd_apply_fused", sums, count, ctx.count_dev, gamma, mean, invstd, local, dgamma, dbeta, coef[2:],
+                      int(direct), dz, None, y, dx, None, m, c, c, 0, None, None)
             dres = dz
         else:
             dres = torch.empty_like(y) if (has_res and not ctx.res_up) else None
-            _hip.call("u2_norm_bwd_apply", dout, out, y, coef[2], coef[3], coef[4], dx, dres, 1, m, c, c, int(relu), msc, msh)
+            _hip.call("u2_bn_bwd_apply_fused", sums, count, ctx.count_dev, gamma, mean, invstd, local, dgamma, dbeta, coef[2:],
+                      int(direct), dout, out, y, dx, dres, m, c, c, int(relu), msc, msh)
             if ctx.res_up:  # gradient of the coarser level: the 2x2 sums of dout
                 dres = torch.empty((b, h // 2, w // 2, c), dtype=BF16, device=y.device)
                 _hip.call("u2_fpn_upsample_add_bwd", dout, dres, b, h, w, c)
