@@ -1416,8 +1416,13 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
   // 256 x 256 tiles (half the operand traffic per flop) win where nothing else hides the memory stream: 1x1 layers over the
   // stride-4 / stride-8 maps and the 7x7 "fully connected" fc1 (tests/native/selftest bench2w, profiles/r02_wgrad_variants.txt);
   // variant bit 8 forces them, bit 11 forbids them
-  const bool wide_auto = !(variant & 2048) && (N % 256 == 0) && (C % 256 == 0) &&
-                         ((KH * KW == 1 && a.M >= 200000) || (KH * KW > 1 && a.M <= 16384 && Hout == 1 && Wout == 1));
+  // Round 4, with the partial-tile reduction in place of the 256 KB atomic epilogue (bench2w 0 256 2048, profiles/r04_wgrad_partials.txt):
+  // the 256-wide tiles also win on the stride-16 1x1 layers (res4 256 <-> 1024: 71 -> 67-69 us on two boxes, the stride-2 512 -> 1024
+  // 124 -> 112) - wherever both channel counts fill 256-wide tiles; with a 128-channel side (128 <-> 512, 256 -> 128) the result
+  // flipped between two boxes (+-10 %), so those stay on the 128-wide tiles; below ~50 k pixels (res5, the FC layers) they lose.
+  const bool wide_1x1 = KH * KW == 1 && a.M >= 50000 && N % 256 == 0 && C % 256 == 0;
+  const bool wide_auto = !(variant & 2048) &&
+                         (wide_1x1 || ((N % 256 == 0) && (C % 256 == 0) && KH * KW > 1 && a.M <= 16384 && Hout == 1 && Wout == 1));
   const bool wide = ((variant & 256) || wide_auto) && (variant & 3) == 0;
   const int tw = wide ? 256 : 128;
   a.tiles_n = (N + tw - 1) / tw;
