@@ -811,8 +811,7 @@ extern "C" int u2_colstats(const void* x, float* out, int slots, int rows_per_sl
   // ~2048 work-groups over all slots (512 per slot at most): with one slot per image (GroupNorm) 512 blocks per slot were
   // 16 K work-groups of 33 KB each at batch 32 and the per-block epilogue (LDS reduction + 2 C atomics) was most of the pass:
   // 1.5 TB/s on the semantic head's statistics at inference (2.5 ms per batch, round-4 profile)
-  static const int total_blocks = getenv("U2_COLRED_BLOCKS") ? atoi(getenv("U2_COLRED_BLOCKS")) : 2048;  // measurement knob
-  int per_slot = total_blocks / (slots > 0 ? slots : 1);
+  int per_slot = 2048 / (slots > 0 ? slots : 1);
   per_slot = per_slot < 8 ? 8 : per_slot > 512 ? 512 : per_slot;
   int rpb = (rows_per_slot + per_slot - 1) / per_slot;
   if (rpb < 64) rpb = 64;
@@ -831,8 +830,7 @@ extern "C" int u2_norm_bwd_reduce(const void* dout, const void* mask, const void
   if (mask_is_bits && (!mask || !relu || !dz_out || ld != C)) return -1;
   if ((dout2 && !dz_out) || (dout3 && !dout2)) return -1;
   if (slots <= 0 || rows_per_slot <= 0) return 0;
-  static const int total_blocks = getenv("U2_COLRED_BLOCKS") ? atoi(getenv("U2_COLRED_BLOCKS")) : 2048;
-  int per_slot = total_blocks / (slots > 0 ? slots : 1);   // see u2_colstats
+  int per_slot = 2048 / (slots > 0 ? slots : 1);   // see u2_colstats
   per_slot = per_slot < 8 ? 8 : per_slot > 512 ? 512 : per_slot;
   int rpb = (rows_per_slot + per_slot - 1) / per_slot;
   if (rpb < 64) rpb = 64;
