@@ -213,6 +213,15 @@ static void bench2(int argc, char** argv, bool wgrad) {
       {"fc1 dgrad gemm 1024->12544", 1, 8192, 1, 1024, 12544, 1, 0, 1, 0, 0, 0},
       {"fc2 gemm 1024->1024 M8192", 1, 8192, 1, 1024, 1024, 1, 0, 1, 1, 1, 0},
       {"gemm 8192^3", 1, 8192, 1, 8192, 8192, 1, 0, 1, 0, 0, 0},
+      {"stem gemm 160->64 M4.3M stats", 1, 4300800, 1, 160, 64, 1, 0, 1, 0, 0, 1},
+      {"stem gemm 160->64 M4.3M plain", 1, 4300800, 1, 160, 64, 1, 0, 1, 0, 0, 0},
+      {"res2 1x1 64->256 plain", 16, 200, 336, 64, 256, 1, 0, 1, 0, 0, 0},
+      {"res4 1x1 1024->256 plain", 16, 50, 84, 1024, 256, 1, 0, 1, 0, 0, 0},
+      {"res4 1x1 256->1024 plain", 16, 50, 84, 256, 1024, 1, 0, 1, 0, 0, 0},
+      {"res4 3x3 256->256 50x84 stats", 16, 50, 84, 256, 256, 3, 1, 1, 0, 0, 1},
+      {"res4 3x3 256->256 50x84 plain", 16, 50, 84, 256, 256, 3, 1, 1, 0, 0, 0},
+      {"res3 s2 3x3 128->128 stats", 16, 200, 336, 128, 128, 3, 1, 2, 0, 0, 1},
+      {"res3 s2 3x3 128->128 plain", 16, 200, 336, 128, 128, 3, 1, 2, 0, 0, 0},
   };
   std::vector<int> variants;
   for (int i = 2; i < argc; ++i) variants.push_back((int)strtol(argv[i], nullptr, 0));
@@ -220,7 +229,14 @@ static void bench2(int argc, char** argv, bool wgrad) {
     if (wgrad) variants = {2048, 0, 256, 4096, 4096 | (1 << 14)};
     else variants = {15 << 12, 0, 1 << 12, 2 << 12, 3 << 12, 4 << 12, 5 << 12, 6 << 12};
   }
-  const size_t in_elems = (size_t)16 * 200 * 336 * 256, w_elems = (size_t)8192 * 8192, out_elems = (size_t)16 * 200 * 336 * 256;
+  size_t in_elems = (size_t)16 * 200 * 336 * 256, out_elems = (size_t)16 * 200 * 336 * 256;
+  const size_t w_elems = (size_t)8192 * 8192;
+  for (const auto& L : layers) {   // the selected layers may need more (the stem GEMM reads 4.3 M x 160)
+    const char* f = getenv("U2_BENCH_LAYERS");
+    if (f && !strstr(L.name, f)) continue;
+    in_elems = std::max(in_elems, (size_t)L.B * L.H * L.W * L.C);
+    out_elems = std::max(out_elems, (size_t)L.B * L.H * L.W * L.N);
+  }
   DBuf<uint16_t> din(in_elems), dw(wgrad ? 16 : w_elems), dout(out_elems);
   DBuf<float> db(16384), dst(2 * 16384), dgw(wgrad ? w_elems : 16);
   if (wgrad) {  // the output gradient operand
@@ -311,13 +327,19 @@ int main(int argc, char** argv) {
       {1, 40, 31, 128, 136, 3, 3, 1, 1, 1, 0, 0, 0, 1, "halo 40x31 c128 n136 stats"},
       {3, 7, 9, 32, 72, 3, 3, 1, 1, 1, 0, 0, 1, 1, "halo 7x9 c32 n72 bias stats"},
       {1, 50, 84, 256, 256, 3, 3, 1, 1, 1, 0, 0, 0, 1, "halo 50x84 c256 n256 stats"},
+      // <= 64 output channels: the 64-channel tiles (code 301)
+      {2, 33, 70, 64, 64, 3, 3, 1, 1, 1, 0, 0, 0, 1, "halo 33x70 c64 n64 stats"},
+      {1, 19, 45, 96, 40, 3, 3, 1, 1, 1, 1, 0, 1, 0, "halo 19x45 c96 n40 bias relu"},
+      {3, 7, 9, 32, 8, 3, 3, 1, 1, 1, 0, 0, 1, 1, "halo 7x9 c32 n8 bias stats"},
+      {1, 50, 84, 256, 64, 3, 3, 1, 1, 1, 0, 0, 0, 1, "halo 50x84 c256 n64 stats"},
   };
   if (argc > 1 && !strcmp(argv[1], "chalo")) {
     const int extra = argc > 2 ? (int)strtol(argv[2], nullptr, 0) : 0;
     for (int tiny = 0; tiny < 2; ++tiny)
       for (const auto& c : hconvs) {
         fails += test_conv(c, (1 << 24) | (tiny << 16) | extra);
-        if (u2_conv_last_kernel() != 300) { printf("FAIL %-28s did not take the halo conv kernel (%d)\n", c.name, u2_conv_last_kernel()); ++fails; }
+        const int want = (c.N <= 64 && !((extra >> 17) & 1)) ? 301 : 300;
+        if (u2_conv_last_kernel() != want) { printf("FAIL %-28s did not take the halo conv kernel %d (%d)\n", c.name, want, u2_conv_last_kernel()); ++fails; }
       }
     printf("SELFTEST chalo %s (%d failures)\n", fails ? "FAILED" : "OK", fails);
     return fails ? 1 : 0;

@@ -144,6 +144,43 @@ def test_conv_forced_variant_fwd_bwd(F, variant, code):
     assert rel_err(wd.grad.cpu(), w.grad) < WG_TOL
 
 
+@pytest.mark.parametrize("tiny", [0, 1])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (96, 40), (256, 64), (32, 8)])
+def test_conv_halo_64_channel_tiles(F, cin, cout, tiny):
+    """conv_halo_kernel<16, 32, 3, 1> (<= 64 output channels: all eight waves along the pixels, four pixel fragments each):
+    ragged patches in both directions and a ragged channel tail, statistics / bias + ReLU, forward and both gradients vs fp32;
+    bit 17 puts the same launch on the 128-channel tiles (code 300) and the two must agree to the bit."""
+    g = torch.Generator().manual_seed(cin * 100 + cout + tiny)
+    x = bf(torch.randn((2, cin, 37, 45), generator=g))
+    w = (torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5).requires_grad_(True)
+    bias = torch.randn(cout, generator=g) * 0.1
+    xr = x.clone().requires_grad_(True)
+    yr = TF.conv2d(xr, bf(w), None, 1, 1)
+    gy = bf(torch.randn(yr.shape, generator=g))
+    yr.backward(gy)
+    xd = nhwc(x).requires_grad_(True)
+    wd = w.detach().to(DEV).requires_grad_(True)
+    with forced(conv=(1 << 24) | (tiny << 16)):
+        y, stats = F._Conv2dFn.apply(xd, wd, None, 1, 1, False, True)
+        assert last_kernel() == 301, last_kernel()
+        yb = F.conv2d(nhwc(x), w.detach().to(DEV), bias.to(DEV), 1, 1, relu=True)
+        assert last_kernel() == 301
+        y.backward(nhwc(gy))
+    with forced(conv=(1 << 24) | (1 << 17) | (tiny << 16)):
+        y128, stats128 = F._Conv2dFn.apply(nhwc(x), wd.detach(), None, 1, 1, False, True)
+        assert last_kernel() == 300, last_kernel()
+    assert torch.equal(y, y128)
+    yy = nchw(y, cout)
+    assert rel_err(yy, yr.detach()) < ULP
+    assert torch.allclose(stats[0].cpu(), yy.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(stats[1].cpu(), (yy * yy).sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(stats[0], stats128[0], rtol=1e-5, atol=1e-3)
+    ref_b = torch.relu(TF.conv2d(x, bf(w.detach()), bias, 1, 1))
+    assert rel_err(nchw(yb, cout), ref_b) < ULP
+    assert rel_err(nchw(xd.grad, cin), xr.grad) < ULP
+    assert rel_err(wd.grad.cpu(), w.grad) < WG_TOL
+
+
 STREAM = 1 << 17   # conv_stream.hip wherever it applies; bit 16: 8 work-groups per 256-channel block (many tiles per group)
 
 
@@ -266,7 +303,7 @@ FULL_SHAPES = [
     ("fpn_output2 3x3 256->256 @200x336", 16, 200, 336, 256, 256, 3, 1, False, 300),   # conv_halo.hip
     ("rpn conv 3x3 256->256 @100x168 bias relu", 16, 100, 168, 256, 256, 3, 1, True, 501),   # stream-K form of configuration 1
     ("res3 conv2 3x3 128->128 @100x168", 16, 100, 168, 128, 128, 3, 1, False, 300),
-    ("res2 conv2 3x3 64->64 @200x336", 16, 200, 336, 64, 64, 3, 1, False, 300),
+    ("res2 conv2 3x3 64->64 @200x336", 16, 200, 336, 64, 64, 3, 1, False, 301),   # 64-channel tiles
     ("res4 conv3 1x1 256->1024 @50x84", 16, 50, 84, 256, 1024, 1, 0, False, 780),            # conv_stream.hip
     ("res2 conv3 1x1 64->256 @200x336", 16, 200, 336, 64, 256, 1, 0, False, 720),
     ("res2 conv1 1x1 256->64 @200x336", 16, 200, 336, 256, 64, 1, 0, False, 782),

@@ -41,6 +41,39 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// Last flush of a work-group's BN column sums.  Lane `lane` of wave `w` holds the sums (st_s, st_ss) of channel st_n (< 0 or
+// >= N: none); waves that walked the same channels add up through LDS and the first of them sends the two atomics.
+// Why: the work-groups of a persistent kernel all finish together and their atomics meet on the same 2 N addresses, where they
+// serialize - 2048 per address with per-wave flushes of a 256 x 8-wave grid on 64 channels cost 36 us at the end of a 154 us
+// launch (res2 conv2, profiles/r04_stats_flush.txt).  `smem` is the kernel's LDS (12 bytes x threads used); every wave of the
+// work-group must call, after its last LDS read and with no LDS-DMA in flight.
+template <int NW>
+__device__ __forceinline__ void wg_flush_column_sums(float* stats, int N, int st_n, float st_s, float st_ss, int w, int lane,
+                                                     unsigned char* smem) {
+  __syncthreads();
+  int* rn = reinterpret_cast<int*>(smem);
+  float* rs = reinterpret_cast<float*>(smem) + NW * 64;
+  float* rq = rs + NW * 64;
+  rn[w * 64 + lane] = st_n;
+  rs[w * 64 + lane] = st_s;
+  rq[w * 64 + lane] = st_ss;
+  __syncthreads();
+  bool lead = st_n >= 0 && st_n < N;
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    const bool same = rn[k * 64 + lane] == st_n;
+    if (same && k < w) lead = false;
+    s += same ? rs[k * 64 + lane] : 0.f;
+    q += same ? rq[k * 64 + lane] : 0.f;
+  }
+  if (lead) {
+    atomicAdd(stats + st_n, s);
+    atomicAdd(stats + N + st_n, q);
+  }
+}
+
+
 // XCD-aware bijective remap of a linear block id: blocks that land on the same XCD (bid % 8)
 // get a contiguous range of logical tiles, so neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -79,25 +79,31 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 constexpr int HBUF = 49152;              // one halo buffer: 768 rows of 64 B (648 / 680 used)
 constexpr int HPIECES = 6;               // 1 KB pieces per wave and slab (8 waves x 6 x 16 rows = 768 rows)
 constexpr int WR = 7, WA = WR - 1;       // weight ring depth / how many steps ahead the weight cursor runs
-constexpr int TN = 128, WSLOT = TN * 64; // output channels of a tile / one (slab, tap) weight slot
+constexpr int TN = 128, WSLOT = TN * 64; // output channels of a tile (CW = 2) / one (slab, tap) weight slot
 constexpr int WBASE = 2 * HBUF;
 constexpr int LDS_BYTES = WBASE + WR * WSLOT;  // 155648
 
 // OPT bit 0: no s_setprio around the MFMA runs, bit 1: no sched_barrier fences between the MFMA runs and the LDS reads / staging.
 // Measured (profiles/r03_conv_halo_sched.txt): without both the kernel is 4 % faster (fpn_output2 1208 -> 1260 TFLOP/s), either
 // one alone +2 % / -1 %: the default is 3; variant bits 29-30 select OPT ^ 3 (so 0 there = the default).
-template <int PH, int PWD, int OPT = 3>
+// CW: waves along the output channels (64 each).  CW = 2: 128-channel tiles, wave tile 64 ch x 128 px (8 pixel fragments).  CW = 1
+// (round 4): 64-channel tiles for the layers with <= 64 output channels (res2 conv2 and its data gradient) - all eight waves along
+// the pixels, wave tile 64 ch x 64 px (4 fragments): no half of the MFMA and epilogue work spent on absent channels.
+template <int PH, int PWD, int OPT = 3, int CW = 2>
 __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
   constexpr int HPITCH = PWD + 4;
   constexpr int FPR = PWD / 16;       // 16-pixel fragments per patch row
-  constexpr int RPW = 8 / FPR;        // patch rows per wave (8 fragments)
-  static_assert(PH * PWD == 512 && (PH + 2) * HPITCH <= 768 && RPW * 4 == PH, "unsupported patch");
+  constexpr int PXW = 8 / CW;         // waves along the pixels
+  constexpr int RPW = PH / PXW;       // patch rows per wave
+  constexpr int NPF = RPW * FPR;      // pixel fragments per wave (8 or 4)
+  constexpr int TNC = CW * 64;        // output channels of a tile
+  static_assert(PH * PWD == 512 && (PH + 2) * HPITCH <= 768 && RPW * PXW == PH && (NPF == 8 || NPF == 4), "unsupported patch");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 2;  // 64-channel slice (0-1)
-  const int wc = w & 3;   // RPW patch rows (0-3)
+  const int wr = CW == 2 ? (w >> 2) : 0;  // 64-channel slice
+  const int wc = CW == 2 ? (w & 3) : w;   // group of RPW patch rows
   const int fr = lane & 15, fg = lane >> 4;
 
   // ---- tiles of this work-group (as conv_tile.hip): XCD x owns a contiguous range of the (patch, channel block) list
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
 
   auto tile_origin = [&](int tile, int& img, int& y0, int& x0, int& n0) {
     const int tm = tile / a.tiles_n;
-    n0 = (tile - tm * a.tiles_n) * TN;
+    n0 = (tile - tm * a.tiles_n) * TNC;
     img = tm / patches_per_img;
     const int p = tm - img * patches_per_img;
     const int py = p / px_cols;
@@ -168,8 +174,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
   unsigned w_base = 0xffffffffu;
   int w_tile = -1, w_slab = nslab - 1, w_tap = 9;  // cursor: the (tile, slab, tap) staged most recently
   auto setup_weights = [&](int tile) {
-    const int n0 = (tile % a.tiles_n) * TN;
-    const int R = w * 16 + row_in;
+    const int n0 = (tile % a.tiles_n) * TNC;
+    const int R = (CW == 2 ? w : (w & 3)) * 16 + row_in;   // CW = 1: waves 4-7 stage the rows of waves 0-3 again (same bytes)
     const int blk = (R >> 4) & 3, q = R & 15;
     const int n = n0 + (R & ~63) + (blk >> 1) * 32 + (q >> 2) * 8 + (blk & 1) * 4 + (q & 3);
     w_base = n < a.N ? (unsigned)(((size_t)n * (9 * (size_t)a.C) + cc * 8) * 2) : 0xffffffffu;
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
     const unsigned char* src = w_base != 0xffffffffu
                                    ? reinterpret_cast<const unsigned char*>(a.wt) + w_base + ((size_t)w_tap * a.C + (size_t)w_slab * 32) * 2
                                    : reinterpret_cast<const unsigned char*>(a.zero);
-    glds16(reinterpret_cast<const bf16_t*>(src), smem + WBASE + slot * WSLOT + w * 1024);
+    glds16(reinterpret_cast<const bf16_t*>(src), smem + WBASE + slot * WSLOT + (CW == 2 ? w : (w & 3)) * 1024);
     ++w_tap;
   };
 
@@ -199,8 +205,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
     pbase[k] = (wc * RPW * HPITCH + k + fr) * 64 + ((fg ^ ((((k + fr) >> 2) & 1) << 1)) << 4);
   auto ldw = [&](int slot, int t) { return *reinterpret_cast<const s16x8*>(smem + wfrag0 + slot * WSLOT + t * 1024); };
 
-  f32x4 acc[4][8];
-  s16x8 wfA[2], wfB[2], pf[8];
+  f32x4 acc[4][NPF];
+  s16x8 wfA[2], wfB[2], pf[NPF];
 
   // BN column statistics: a lane accumulates the sums of ONE channel over all tiles the work-group walks with the same
   // channel block and sends them with two full-wave atomics when the channel block changes or the work-group is done
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
   int st_base = -1;  // first channel of the 64-channel slice the lane sums belong to (wave-uniform; -1: none yet)
   auto stats_flush = [&]() {
     const int st_n = st_base + fg * 8 + (fr >> 3) * 32 + (fr & 7);
-    if (st_base >= 0 && st_n < a.N) {
+    if (st_base >= 0 && st_n < a.N && !(a.abl & 16)) {
       asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(a.stats + st_n), "v"(st_s) : "memory");
       asm volatile("global_atomic_add_f32 %0, %1, off\n\ts_nop 1" ::"v"(a.stats + a.N + st_n), "v"(st_ss) : "memory");
     }
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
     const bool do_stats = a.stats && !(a.abl & 2);
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NPF; ++j) {
       const int y = y0 + wc * RPW + j / FPR, x = x0 + (j % FPR) * 16 + fr;
       const bool row_ok = y < a.Hout && x < a.Wout;
       uint32_t pk[8];
@@ -302,7 +308,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   wfA[0] = ldw(0, 0); wfA[1] = ldw(0, 1);
-  pf[0] = U2_H_LDP(0, 0); pf[1] = U2_H_LDP(0, 1); pf[2] = U2_H_LDP(0, 2); pf[3] = U2_H_LDP(0, 3);
+#pragma unroll
+  for (int j = 0; j < NPF / 2; ++j) pf[j] = U2_H_LDP(0, j);
 
   // One step = one (slab, tap): 32 MFMA per wave, in conv_tile.hip's two phases
   //   A: 4 MFMA | read pixel fragments 4-7 and the second weight pair of this step; issue the halo piece of the NEXT slab
@@ -319,10 +326,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
     const int nslot = (slot + 1 == WR) ? 0 : slot + 1;                                                                   \
     const int sslot = (slot == 0) ? WR - 1 : slot - 1; /* slot of step g + WA = g - 1 (mod WR) */                        \
     if constexpr (!(OPT & 1)) __builtin_amdgcn_s_setprio(1);                                                                                       \
-    U2_H_MFMA(0, wfA[0], 0); U2_H_MFMA(1, wfA[1], 0); U2_H_MFMA(0, wfA[0], 1); U2_H_MFMA(1, wfA[1], 1);                  \
+    _Pragma("unroll") for (int j = 0; j < NPF / 4; ++j) { U2_H_MFMA(0, wfA[0], j); U2_H_MFMA(1, wfA[1], j); }            \
     if constexpr (!(OPT & 1)) __builtin_amdgcn_s_setprio(0);                                                                                       \
     if constexpr (!(OPT & 2)) __builtin_amdgcn_sched_barrier(0);                                                                                   \
-    pf[4] = U2_H_LDP(T, 4); pf[5] = U2_H_LDP(T, 5); pf[6] = U2_H_LDP(T, 6); pf[7] = U2_H_LDP(T, 7);                      \
+    _Pragma("unroll") for (int j = NPF / 2; j < NPF; ++j) pf[j] = U2_H_LDP(T, j);                                        \
     wfB[0] = ldw(slot, 2); wfB[1] = ldw(slot, 3);                                                                        \
     if ((T) < HPIECES && slab_g + 1 < total_slabs) {                                                                     \
       if ((T) == 0) halo_next_slab();                                                                                    \
@@ -331,15 +338,14 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
     if (g + WA < G) stage_weights(sslot);                                                                                \
     if constexpr (!(OPT & 2)) __builtin_amdgcn_sched_barrier(0);                                                                                   \
     if constexpr (!(OPT & 1)) __builtin_amdgcn_s_setprio(1);                                                                                       \
-    U2_H_MFMA(0, wfA[0], 2); U2_H_MFMA(1, wfA[1], 2); U2_H_MFMA(0, wfA[0], 3); U2_H_MFMA(1, wfA[1], 3);                  \
-    _Pragma("unroll") for (int j = 4; j < 8; ++j) { U2_H_MFMA(0, wfA[0], j); U2_H_MFMA(1, wfA[1], j); }                  \
+    _Pragma("unroll") for (int j = NPF / 4; j < NPF; ++j) { U2_H_MFMA(0, wfA[0], j); U2_H_MFMA(1, wfA[1], j); }          \
     if constexpr (!(OPT & 1)) __builtin_amdgcn_s_setprio(0);                                                                                       \
     if (tail) wait_vm<0>(); else wait_vm<VMCNT>();                                                                       \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
     __builtin_amdgcn_s_barrier();                                                                                        \
     asm volatile("" ::: "memory");                                                                                       \
     if constexpr (!(OPT & 1)) __builtin_amdgcn_s_setprio(1);                                                                                       \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) { U2_H_MFMA(2, wfB[0], j); U2_H_MFMA(3, wfB[1], j); }                  \
+    _Pragma("unroll") for (int j = 0; j < NPF / 2; ++j) { U2_H_MFMA(2, wfB[0], j); U2_H_MFMA(3, wfB[1], j); }            \
     if constexpr (!(OPT & 1)) __builtin_amdgcn_s_setprio(0);                                                                                       \
     if constexpr (!(OPT & 2)) __builtin_amdgcn_sched_barrier(0);                                                                                   \
     if ((T) == 8) { /* the next step reads the other halo buffer */                                                      \
@@ -348,12 +354,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
     }                                                                                                                    \
     if (g + 1 < G) {                                                                                                     \
       wfA[0] = ldw(nslot, 0); wfA[1] = ldw(nslot, 1);                                                                    \
-      pf[0] = U2_H_LDP(((T) + 1) % 9, 0); pf[1] = U2_H_LDP(((T) + 1) % 9, 1);                                            \
-      pf[2] = U2_H_LDP(((T) + 1) % 9, 2); pf[3] = U2_H_LDP(((T) + 1) % 9, 3);                                            \
+      _Pragma("unroll") for (int j = 0; j < NPF / 2; ++j) pf[j] = U2_H_LDP(((T) + 1) % 9, j);                            \
     }                                                                                                                    \
     if constexpr (!(OPT & 2)) __builtin_amdgcn_sched_barrier(0);                                                                                   \
     if constexpr (!(OPT & 1)) __builtin_amdgcn_s_setprio(1);                                                                                       \
-    _Pragma("unroll") for (int j = 4; j < 8; ++j) { U2_H_MFMA(2, wfB[0], j); U2_H_MFMA(3, wfB[1], j); }                  \
+    _Pragma("unroll") for (int j = NPF / 2; j < NPF; ++j) { U2_H_MFMA(2, wfB[0], j); U2_H_MFMA(3, wfB[1], j); }          \
     if constexpr (!(OPT & 1)) __builtin_amdgcn_s_setprio(0);                                                                                       \
     ++g;                                                                                                                 \
     slot = nslot;                                                                                                        \
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NPF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < nslab; ++s) {
       tail = slab_g + 2 >= total_slabs;
       U2_H_STEP(0, 7)
@@ -379,27 +384,27 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvArgs a) {
     }
     epilogue(first_tile + ti * stride);
   }
-  if (a.stats) stats_flush();
+  if (a.stats) wg_flush_column_sums<8>(a.stats, a.N, st_base < 0 ? -1 : st_base + fg * 8 + (fr >> 3) * 32 + (fr & 7), st_s, st_ss, w, lane, smem);
 #undef U2_H_STEP
 #undef U2_H_LDP
 #undef U2_H_MFMA
 }
 
-template <int PH, int PWD, int OPT = 3>
+template <int PH, int PWD, int OPT = 3, int CW = 2>
 int launch_halo_cfg(ConvArgs& a, int N, int tiny, hipStream_t s) {
   const long long patches = (long long)a.B * ((a.Hout + PH - 1) / PH) * ((a.Wout + PWD - 1) / PWD);
   a.tiles_m = (int)patches;
-  a.tiles_n = (N + TN - 1) / TN;
+  a.tiles_n = (N + CW * 64 - 1) / (CW * 64);
   const long long T = patches * a.tiles_n;
   if (T >= (1 << 30)) return 0;
   long long G = T < (tiny ? 8 : 256) ? T : (tiny ? 8 : 256);
   G = (G + 7) & ~7LL;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_halo_kernel<PH, PWD, OPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_halo_kernel<PH, PWD, OPT, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_halo_kernel<PH, PWD, OPT>), dim3((unsigned)G), dim3(512), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((conv_halo_kernel<PH, PWD, OPT, CW>), dim3((unsigned)G), dim3(512), LDS_BYTES, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return -1000 - (int)e;
   return 1;
@@ -415,7 +420,7 @@ double patch_fill(int H, int W, int ph, int pw) {
 // bit 25: never; otherwise automatic, from tests/native/selftest bench2 (profiles/r03_conv_halo.txt):
 // the halo kernel wins wherever its patches are reasonably full - the stride-4 maps (200 x 336: 92 % full, +7...31 %) and the
 // layers with <= 128 output channels on the stride-8 maps (78-84 % full, +11 %) - and loses on small maps (50 x 84 and below,
-// 14 x 14 ROI maps), which stay on the tile kernels.  g_last_conv_kernel code: 300.
+// 14 x 14 ROI maps), which stay on the tile kernels.  g_last_conv_kernel code: 300 (128-channel tiles) / 301 (64-channel tiles).
 int launch_conv_halo(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   if ((variant >> 25) & 1) return 0;
   if (((variant >> 12) & 15) != 0) return 0;  // a tile-kernel configuration was asked for explicitly
@@ -430,12 +435,17 @@ int launch_conv_halo(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   //  tile loop, and a scratch access there makes the compiler drain the LDS-DMA queue in every slab: not dispatched)
   const double fill = patch_fill(a.Hout, a.Wout, 16, 32);
   if (!forced) {
-    const long long tiles = (long long)a.B * ((a.Hout + 15) / 16) * ((a.Wout + 31) / 32) * ((N + TN - 1) / TN);
+    const int tnc = N <= 64 ? 64 : TN;
+    const long long tiles = (long long)a.B * ((a.Hout + 15) / 16) * ((a.Wout + 31) / 32) * ((N + tnc - 1) / tnc);
     if (tiles < 512) return 0;                          // less than two rounds of tiles: the tile kernels' finer grain wins
     if (!(fill >= 0.88 || (N <= 128 && fill >= 0.70))) return 0;
   }
   const int tiny = (variant >> 16) & 1;
   a.abl = (variant >> 18) & 63;
+  if (N <= 64 && !((variant >> 17) & 1)) {  // 64-channel tiles (bit 17: the 128-channel tiles anyway, for A/B runs)
+    g_last_conv_kernel = 301;
+    return launch_halo_cfg<16, 32, 3, 1>(a, N, tiny, s);
+  }
   g_last_conv_kernel = 300;
   switch ((variant >> 29) & 3) {
     case 1: return launch_halo_cfg<16, 32, 2>(a, N, tiny, s);

@@ -315,10 +315,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv_stream_kernel(const ConvArgs
    }
     if (!(a.abl & 4)) epilogue(ti);
   }
-  if (do_stats && st_n < a.N) {
-    asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(a.stats + st_n), "v"(st_s) : "memory");
-    asm volatile("global_atomic_add_f32 %0, %1, off\n\ts_nop 1" ::"v"(a.stats + a.N + st_n), "v"(st_ss) : "memory");
-  }
+  if (do_stats) wg_flush_column_sums<NWV>(a.stats, a.N, st_n, st_s, st_ss, w, lane, smem);
 }
 
 template <int KS, int TM, int PSW, int NWV, int KSS = KS>

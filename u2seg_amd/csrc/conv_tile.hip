@@ -545,7 +545,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       epilogue(first_tile + my_tiles - 1);
     }
   }
-  if (!ACC && a.stats) stats_flush();
+  if (!ACC && a.stats) wg_flush_column_sums<NW>(a.stats, a.N, st_n, st_s, st_ss, w, lane, smem);
 #undef U2_T_MFMA
 }
 
