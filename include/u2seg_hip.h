@@ -259,12 +259,12 @@ int u2_semseg_upsample(const void* logits, float* out, long long* argmax, int B,
 int u2_bilinear_resize_f32(const float* in, float* out, int C, int Hin, int Win, long long in_cs, long long in_rs, int Hout,
                            int Wout, void* stream);
 /* out[k][y][x] (uint8 0/1) = bilinear sample of probs[k] (P x P fp32) on F.grid_sample(align_corners=False)'s grid over
- * boxes[k] = (x0, y0, x1, y1), zero outside the map, >= threshold. */
+ * boxes[k] = (x0, y0, x1, y1), zero outside the map, >= threshold.  `out` is 16-byte aligned. */
 int u2_paste_masks(const float* probs, const float* boxes, void* out, int n, int P, int H, int W, float threshold,
                    void* stream);
 /* The same for the masks of a batch of images in one launch (detectron2/modeling/postprocessing.py:9-74 pastes per image):
  * image i owns rows [first, first + n) of probs / boxes and writes its n canvases of H x W bytes at byte out_offset (a multiple
- * of 8) of `out`; `images` is a HOST array. */
+ * of 16) of the 16-byte aligned `out` (the padding bytes between two images' canvases may be zeroed); `images` is a HOST array. */
 typedef struct U2PasteImage { int first, n, H, W; long long out_offset; } U2PasteImage;
 int u2_paste_masks_batch(const float* probs, const float* boxes, void* out, const U2PasteImage* images, int num_images, int P,
                          float threshold, void* stream);

@@ -568,3 +568,44 @@ def test_topk_rows_sorted_fallback_total_order():
     for r in range(2):
         assert torch.equal(idx[r].long(), torch.sort(flat[r], descending=True, stable=True)[1][:14000])
     assert F._TOPK_MAX_K == 16384
+
+
+def test_paste_reach_rectangle_contains_every_pixel_the_exact_condition_accepts():
+    """postprocess.hip paste_reach: the rectangle the interior pass of u2_paste_masks visits must contain every pixel whose
+    sampling coordinate passes the exact test (ix > -1 and ix < P, fp32, the expression of paste_axis_coord) - everything
+    outside is only zero-filled.  Restated in numpy float32 and checked on random and adversarial box sides."""
+    f = np.float32
+    rng = np.random.default_rng(5)
+
+    def exact_mask(b0, b1, P, n):
+        pix = np.arange(n, dtype=np.float32)
+        with np.errstate(all="ignore"):
+            g = (pix + f(0.5) - f(b0)) / (f(b1) - f(b0)) * f(2) - f(1)
+            ix = ((g + f(1)) * f(P) - f(1)) / f(2)
+        return (ix > -1) & (ix < P)
+
+    def reach(b0, b1, P, n):
+        b0, b1 = f(b0), f(b1)
+        with np.errstate(all="ignore"):
+            bw = np.abs(b1 - b0)
+            flo = np.fmin(b0, b1) - f(0.5) * bw / f(P) - f(2.5)
+            fhi = np.fmax(b0, b1) + f(0.5) * bw / f(P) + f(1.5)
+            lo = int(np.fmin(np.fmax(np.floor(flo), f(0)), f(n)))
+            hi = int(np.fmax(np.fmin(np.ceil(fhi), f(n - 1)), f(-1)))
+        return lo, hi
+
+    cases = []
+    for _ in range(3000):
+        n = int(rng.integers(1, 1400))
+        a = rng.uniform(-200, n + 200)
+        w = rng.choice([rng.uniform(0, 2), rng.uniform(0, 60), rng.uniform(0, 2 * n + 1)])
+        cases.append((a, a + w, int(rng.choice([7, 14, 28])), n))
+    cases += [(0, 1333, 28, 1333), (-1e6, 1e6, 28, 800), (5.0, 5.0, 28, 100), (50.0, 20.0, 28, 100), (1e-3, 2e-3, 28, 64),
+              (99.99, 100.0, 28, 100), (-30, -10, 28, 50), (60, 90, 28, 50), (float("inf"), 3.0, 28, 40), (-float("inf"), float("inf"), 28, 40),
+              (float("nan"), 3.0, 28, 40), (0.0, 2.0 ** 24, 28, 1333), (-0.4999, 0.4999, 28, 9)]
+    for b0, b1, P, n in cases:
+        m = exact_mask(b0, b1, P, n)
+        lo, hi = reach(b0, b1, P, n)
+        idx = np.nonzero(m)[0]
+        if idx.size:
+            assert lo <= idx[0] and idx[-1] <= hi, (b0, b1, P, n, lo, hi, idx[0], idx[-1])

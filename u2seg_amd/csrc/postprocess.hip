@@ -18,35 +18,65 @@ __device__ __forceinline__ float paste_axis_coord(float pix, float lo, float hi,
   return ((g + 1.f) * (float)P - 1.f) / 2.f;                   // grid_sample's unnormalisation, align_corners=False
 }
 
-__device__ __forceinline__ void paste_masks_block(const float* __restrict__ probs, const float* __restrict__ boxes,
-                                                  uint8_t* __restrict__ out, long long total, int P, int H, int W, float thr,
-                                                  long long block) {
-  const long long i8 = (block * 256 + threadIdx.x) * 8;
-  if (i8 >= total) return;
-  const long long hw = (long long)H * W;
-  // (mask, row, column) of the block's first byte by scalar divisions (uniform), of the thread's first byte by at most a few
-  // subtractions: two 64-bit divisions per thread were a third of the kernel
-  const long long b8 = block * 2048;
-  int k = (int)(b8 / hw);
-  const long long rem = b8 - (long long)k * hw;
-  int y = (int)(rem / W);
-  int x = (int)(rem - (long long)y * W) + (int)threadIdx.x * 8;
-  while (x >= W) { x -= W; ++y; }
-  while (y >= H) { y -= H; ++k; }
-  // 8 bytes inside one row that the mask's box does not reach (most of an 800 x 1333 canvas): zeros, no arithmetic
-  if (x + 8 <= W && i8 + 8 <= total) {
-    const float by0 = boxes[(size_t)k * 4 + 1], by1 = boxes[(size_t)k * 4 + 3];
-    const float bx0 = boxes[(size_t)k * 4 + 0], bx1 = boxes[(size_t)k * 4 + 2];
-    const float iy_ = paste_axis_coord((float)y, by0, by1, P);
-    bool empty = !(iy_ > -1.f && iy_ < (float)P);
-    if (!empty) {
-      const float ixa = paste_axis_coord((float)x, bx0, bx1, P), ixb = paste_axis_coord((float)(x + 7), bx0, bx1, P);
-      empty = !(fmaxf(ixa, ixb) > -1.f && fminf(ixa, ixb) < (float)P);
+// The canvases ([n][H][W] bytes per image, 3.4 GB for a 32-image batch of 100 masks at 800 x 1333) are zero except inside the
+// boxes (~4 % of the pixels).  Written in two passes on the same stream:
+//   1. paste_zero_kernel: plain 16-byte non-temporal zero fill of everything (6+ TB/s);
+//   2. paste_interior_kernel: per mask, the rows and the 8-byte words of each row that the box can reach (a conservative
+//      rectangle, two pixels wider than the exact condition) are computed pixel by pixel with the reference's arithmetic.
+// One pass over everything (every thread 8 or 16 bytes, zero store where its bytes miss the box) ran at 1.35 TB/s: a wave covers
+// most of a canvas row, so every wave on a row the box touches sat in the per-pixel loop with a fifth of its lanes busy
+// (profiles/r04_paste.txt).
+typedef unsigned long long paste_u64x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void paste_zero_kernel(uint8_t* __restrict__ out, long long n16) {
+  paste_u64x2* o = reinterpret_cast<paste_u64x2*>(out);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256)
+    __builtin_nontemporal_store(paste_u64x2{0ull, 0ull}, o + i);
+}
+
+// the 8 bytes at flat index i = (k, y, x) of an image's canvases, exactly as the reference computes them
+__device__ __forceinline__ void paste_group8(const float* __restrict__ probs, const float* __restrict__ boxes,
+                                             uint8_t* __restrict__ out, long long total, int P, int H, int W, float thr, int k,
+                                             int y, int x, long long i) {
+  if (x + 8 <= W && i + 8 <= total) {
+    // eight pixels of one row (nearly every group): the row terms once, the 32 source reads of the group issued together
+    // (clamped addresses, a term outside the P x P map contributes an exact 0 - the sum is the one the loop below forms)
+    const float bx0 = boxes[(size_t)k * 4 + 0], by0 = boxes[(size_t)k * 4 + 1], bx1 = boxes[(size_t)k * 4 + 2], by1 = boxes[(size_t)k * 4 + 3];
+    const float* pk = probs + (size_t)k * P * P;
+    const float iy = paste_axis_coord((float)y, by0, by1, P);
+    const float fy = floorf(iy);
+    unsigned long long bits = 0ull;
+    if (iy > -1.f && iy < (float)P) {
+      const int yn = (int)fy;
+      const float wy_s = iy - fy, wy_n = (fy + 1.f) - iy;
+      const bool yn_ok = yn >= 0 && yn < P, ys_ok = yn + 1 >= 0 && yn + 1 < P;
+      const float* rn = pk + min(max(yn, 0), P - 1) * P;
+      const float* rs = pk + min(max(yn + 1, 0), P - 1) * P;
+      float v[8];
+      bool in[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float ix = paste_axis_coord((float)(x + e), bx0, bx1, P);
+        in[e] = ix > -1.f && ix < (float)P;
+        const float fx = floorf(in[e] ? ix : 0.f);
+        const int xw = (int)fx;
+        const float wx_e = ix - fx, wx_w = (fx + 1.f) - ix;
+        const bool xw_ok = xw >= 0 && xw < P, xe_ok = xw + 1 >= 0 && xw + 1 < P;
+        const int cw = min(max(xw, 0), P - 1), ce = min(max(xw + 1, 0), P - 1);
+        const float p00 = rn[cw], p01 = rn[ce], p10 = rs[cw], p11 = rs[ce];
+        float a = 0.f;
+        a += (yn_ok && xw_ok) ? p00 * (wx_w * wy_n) : 0.f;
+        a += (yn_ok && xe_ok) ? p01 * (wx_e * wy_n) : 0.f;
+        a += (ys_ok && xw_ok) ? p10 * (wx_w * wy_s) : 0.f;
+        a += (ys_ok && xe_ok) ? p11 * (wx_e * wy_s) : 0.f;
+        v[e] = a;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (in[e] && v[e] >= thr) bits |= 1ull << (8 * e);
     }
-    if (empty) {
-      *reinterpret_cast<unsigned long long*>(out + i8) = 0ull;
-      return;
-    }
+    *reinterpret_cast<unsigned long long*>(out + i) = bits;
+    return;
   }
   unsigned long long bits = 0ull;
   int cur_k = -1, cur_y = -1;
@@ -54,7 +84,7 @@ __device__ __forceinline__ void paste_masks_block(const float* __restrict__ prob
   int yn = 0;
   bool row_in = false;
   const float* pk = probs;
-  const int nvalid = (int)((total - i8) < 8 ? (total - i8) : 8);
+  const int nvalid = (int)((total - i) < 8 ? (total - i) : 8);
   for (int e = 0; e < nvalid; ++e) {
     if (k != cur_k) {
       cur_k = k; cur_y = -1;
@@ -91,31 +121,95 @@ __device__ __forceinline__ void paste_masks_block(const float* __restrict__ prob
     if (++x == W) { x = 0; if (++y == H) { y = 0; ++k; } }
   }
   if (nvalid == 8) {
-    *reinterpret_cast<unsigned long long*>(out + i8) = bits;
+    *reinterpret_cast<unsigned long long*>(out + i) = bits;
   } else {
-    for (int e = 0; e < nvalid; ++e) out[i8 + e] = (uint8_t)((bits >> (8 * e)) & 1ull);
+    for (int e = 0; e < nvalid; ++e) out[i + e] = (uint8_t)((bits >> (8 * e)) & 1ull);
   }
 }
 
-__global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restrict__ probs, const float* __restrict__ boxes,
-                                                          uint8_t* __restrict__ out, long long total, int P, int H, int W,
-                                                          float thr) {
-  paste_masks_block(probs, boxes, out, total, P, H, W, thr, (long long)blockIdx.x);
+// pixels [lo, hi] of an axis of extent n that a box side (b0, b1) can light: ix > -1 and ix < P hold only for
+// b_lo - 0.5 bw / P - 0.5 < pix < b_hi + 0.5 bw / P - 0.5; two pixels of margin on either side absorb the rounding of this form
+// (the pixels inside are decided by the exact expression).  A NaN side gives the whole axis.
+__device__ __forceinline__ void paste_reach(float b0, float b1, int P, int n, int& lo, int& hi) {
+  const float bw = fabsf(b1 - b0);
+  const float flo = fminf(b0, b1) - 0.5f * bw / (float)P - 2.5f, fhi = fmaxf(b0, b1) + 0.5f * bw / (float)P + 1.5f;
+  lo = (int)fminf(fmaxf(floorf(flo), 0.f), (float)n);           // n: an empty range when the box lies beyond the axis
+  hi = (int)fmaxf(fminf(ceilf(fhi), (float)(n - 1)), -1.f);
 }
 
-// The masks of a whole batch of images in ONE launch (detector_postprocess pastes per image: 32 launches per 32-image batch,
-// each with its own canvas size): blockIdx.y = image, the image's masks are rows [first, first + n) of probs / boxes and its
-// canvases start at byte out_offset of `out`.
-constexpr int PASTE_MAXIMG = 64;
+constexpr int PASTE_MAXIMG = 64, PASTE_ROW_GROUPS = 16;
 struct PasteBatch { U2PasteImage im[PASTE_MAXIMG]; };
-__global__ __launch_bounds__(256) void paste_masks_batch_kernel(const PasteBatch batch, const float* __restrict__ probs,
-                                                                const float* __restrict__ boxes, uint8_t* __restrict__ out, int P,
-                                                                float thr) {
-  const U2PasteImage im = batch.im[blockIdx.y];
-  const long long total = (long long)im.n * im.H * im.W;
-  if ((long long)blockIdx.x * 2048 >= total) return;
-  paste_masks_block(probs + (size_t)im.first * P * P, boxes + (size_t)im.first * 4, out + im.out_offset, total, P, im.H, im.W, thr,
-                    (long long)blockIdx.x);
+// grid (PASTE_ROW_GROUPS, masks of the largest image, images)
+__global__ __launch_bounds__(256) void paste_interior_kernel(const PasteBatch batch, const float* __restrict__ probs,
+                                                             const float* __restrict__ boxes, uint8_t* __restrict__ out, int P,
+                                                             float thr) {
+  const U2PasteImage im = batch.im[blockIdx.z];
+  const int k = blockIdx.y;
+  if (k >= im.n) return;
+  const int H = im.H, W = im.W;
+  const float* bimg = boxes + (size_t)im.first * 4;
+  const float* pimg = probs + (size_t)im.first * P * P;
+  int xlo, xhi, ylo, yhi;
+  paste_reach(bimg[(size_t)k * 4 + 0], bimg[(size_t)k * 4 + 2], P, W, xlo, xhi);
+  paste_reach(bimg[(size_t)k * 4 + 1], bimg[(size_t)k * 4 + 3], P, H, ylo, yhi);
+  if (xlo > xhi || ylo > yhi) return;
+  const long long hw = (long long)H * W, total = (long long)im.n * hw;
+  uint8_t* o = out + im.out_offset;
+  // items = (row, 8-byte word of the row's span); a box is ~30 words wide, so the rows of a work-group are walked together
+  const int wpr = (xhi - xlo) / 8 + 2;                                    // words per row, at most
+  const int nrows = yhi - ylo + 1;
+  const int rpg = (nrows + PASTE_ROW_GROUPS - 1) / PASTE_ROW_GROUPS;      // rows of this work-group: [r0, r1)
+  const int r0 = (int)blockIdx.x * rpg, r1 = min(nrows, r0 + rpg);
+  for (int t = (int)threadIdx.x; t < (r1 - r0) * wpr; t += 256) {
+    const int y = ylo + r0 + t / wpr, wd = t % wpr;
+    const long long rowbase = (long long)k * hw + (long long)y * W;
+    const long long a = ((rowbase + xlo) & ~7LL) + 8LL * wd;               // the image's canvases start 16-byte aligned: a >= 0
+    if (a > rowbase + xhi) continue;
+    int dx = (int)(a - rowbase), yy = y, kk = k;
+    while (dx < 0) {  // the word begins in the previous row (or the previous mask's last row)
+      dx += W;
+      if (--yy < 0) { yy = H - 1; --kk; }
+    }
+    paste_group8(pimg, bimg, o, total, P, H, W, thr, kk, yy, dx, a);
+  }
+}
+
+static int paste_launch(const PasteBatch& b, int nb, const float* probs, const float* boxes, uint8_t* out, int P, float thr,
+                        hipStream_t s) {
+  int max_n = 0;
+  long long lo = -1, hi = 0, sum = 0;
+  for (int i = 0; i < nb; ++i) {
+    const long long bytes = (long long)b.im[i].n * b.im[i].H * b.im[i].W;
+    if (bytes <= 0) continue;
+    if (b.im[i].n > max_n) max_n = b.im[i].n;
+    if (lo < 0 || b.im[i].out_offset < lo) lo = b.im[i].out_offset;
+    if (b.im[i].out_offset + bytes > hi) hi = b.im[i].out_offset + bytes;
+    sum += bytes;
+  }
+  if (max_n == 0) return 0;
+  // zero fill.  Canvases laid out back to back (apart from the alignment padding between images, which is zeroed with them):
+  // one launch over the whole span; otherwise image by image.  Whole 16-byte words by the kernel, a ragged end by a memset.
+  auto zero = [&](long long off, long long bytes) {
+    const long long n16 = bytes / 16;
+    if (n16 > 0) {
+      long long g = (n16 + 255) / 256;
+      if (g > 256 * 64) g = 256 * 64;
+      hipLaunchKernelGGL(paste_zero_kernel, dim3((unsigned)g), dim3(256), 0, s, out + off, n16);
+    }
+    if (bytes & 15) (void)hipMemsetAsync(out + off + n16 * 16, 0, (size_t)(bytes & 15), s);
+  };
+  if (hi - lo <= sum + 16LL * nb) {
+    zero(lo, hi - lo);
+  } else {
+    for (int i = 0; i < nb; ++i) {
+      const long long bytes = (long long)b.im[i].n * b.im[i].H * b.im[i].W;
+      if (bytes > 0) zero(b.im[i].out_offset, bytes);
+    }
+  }
+  if (max_n > 65535) return -1;
+  hipLaunchKernelGGL(paste_interior_kernel, dim3(PASTE_ROW_GROUPS, (unsigned)max_n, (unsigned)nb), dim3(256), 0, s, b, probs, boxes,
+                     out, P, thr);
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -373,21 +467,14 @@ extern "C" int u2_semseg_upsample(const void* logits, float* out, long long* arg
 extern "C" int u2_paste_masks_batch(const float* probs, const float* boxes, void* out, const U2PasteImage* images, int num_images,
                                     int P, float threshold, void* stream) {
   if (num_images <= 0) return 0;
-  if (P < 1 || !images) return -1;
+  if (P < 1 || !images || ((uintptr_t)out & 15)) return -1;
+  for (int i = 0; i < num_images; ++i)
+    if (images[i].n < 0 || images[i].H < 0 || images[i].W < 0 || (images[i].out_offset & 15)) return -1;
   for (int i0 = 0; i0 < num_images; i0 += PASTE_MAXIMG) {
     PasteBatch b;
     const int nb = num_images - i0 < PASTE_MAXIMG ? num_images - i0 : PASTE_MAXIMG;
-    long long max_blocks = 0;
-    for (int i = 0; i < nb; ++i) {
-      b.im[i] = images[i0 + i];
-      if (b.im[i].n < 0 || b.im[i].H < 0 || b.im[i].W < 0 || (b.im[i].out_offset & 7)) return -1;
-      const long long blocks = ((long long)b.im[i].n * b.im[i].H * b.im[i].W + 2047) / 2048;
-      if (blocks > max_blocks) max_blocks = blocks;
-    }
-    if (max_blocks == 0) continue;
-    if (max_blocks > 0x7fffffffLL) return -1;
-    hipLaunchKernelGGL(paste_masks_batch_kernel, dim3((unsigned)max_blocks, (unsigned)nb), dim3(256), 0, (hipStream_t)stream, b, probs,
-                       boxes, (uint8_t*)out, P, threshold);
+    for (int i = 0; i < nb; ++i) b.im[i] = images[i0 + i];
+    if (paste_launch(b, nb, probs, boxes, (uint8_t*)out, P, threshold, (hipStream_t)stream)) return -1;
     U2_CHECK_LAUNCH();
   }
   return 0;
@@ -396,13 +483,10 @@ extern "C" int u2_paste_masks_batch(const float* probs, const float* boxes, void
 extern "C" int u2_paste_masks(const float* probs, const float* boxes, void* out, int n, int P, int H, int W, float threshold,
                               void* stream) {
   if (n <= 0 || H <= 0 || W <= 0) return 0;
-  if (P < 1) return -1;
-  const long long total = (long long)n * H * W;
-  const long long threads = (total + 7) / 8;
-  const long long blocks = (threads + 255) / 256;
-  if (blocks > 0x7fffffffLL) return -1;
-  hipLaunchKernelGGL(paste_masks_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, probs, boxes,
-                     (uint8_t*)out, total, P, H, W, threshold);
+  if (P < 1 || ((uintptr_t)out & 15)) return -1;
+  PasteBatch b;
+  b.im[0].first = 0; b.im[0].n = n; b.im[0].H = H; b.im[0].W = W; b.im[0].out_offset = 0;
+  if (paste_launch(b, 1, probs, boxes, (uint8_t*)out, P, threshold, (hipStream_t)stream)) return -1;
   U2_CHECK_LAUNCH();
   return 0;
 }

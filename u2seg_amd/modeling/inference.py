@@ -166,8 +166,8 @@ def paste_masks_in_images(masks_list, boxes_list, image_shapes, threshold=0.5):
         d = descs[i]
         d.first, d.n, d.H, d.W, d.out_offset = first, n, int(h), int(w), off
         first += n
-        off += (n * int(h) * int(w) + 7) // 8 * 8
-    flat = torch.empty(max(off, 8), dtype=torch.bool, device=dev)
+        off += (n * int(h) * int(w) + 15) // 16 * 16
+    flat = torch.empty(max(off, 16), dtype=torch.bool, device=dev)
     if first:
         p = int(masks_list[0].shape[-1])
         _hip.call("u2_paste_masks_batch", torch.cat(masks_list).float().contiguous(), torch.cat(boxes_list).float().contiguous(),
