@@ -262,6 +262,12 @@ int u2_bilinear_resize_f32(const float* in, float* out, int C, int Hin, int Win,
  * boxes[k] = (x0, y0, x1, y1), zero outside the map, >= threshold.  `out` is 16-byte aligned. */
 int u2_paste_masks(const float* probs, const float* boxes, void* out, int n, int P, int H, int W, float threshold,
                    void* stream);
+/* mask_rcnn_inference (detectron2/modeling/roi_heads/mask_head.py:115-158) with the 1x1 predictor folded in: only the predicted
+ * class's channel is formed.  x: bf16 [N][S2][S2][C] trunk output (C % 8 == 0, C <= 1024), or with phased = 1 the 2x2 / stride-2 deconvolution's
+ * GEMM output before its pixel shuffle, [N][S2/2][S2/2][2][2][C]; Wp [K][C], bp [K] fp32 master parameters (rounded to bf16 like the
+ * conv operands); cls int64 [N]; prob fp32 [N][S2][S2] = sigmoid(bf16(x . Wp[cls] + bp[cls])). */
+int u2_mask_predict_prob(const void* x, const float* Wp, const float* bp, const void* cls, float* prob, int N, int S2, int C,
+                         int phased, void* stream);
 /* The same for the masks of a batch of images in one launch (detectron2/modeling/postprocessing.py:9-74 pastes per image):
  * image i owns rows [first, first + n) of probs / boxes and writes its n canvases of H x W bytes at byte out_offset (a multiple
  * of 16) of the 16-byte aligned `out` (the padding bytes between two images' canvases may be zeroed); `images` is a HOST array. */

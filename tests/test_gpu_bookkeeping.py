@@ -614,3 +614,37 @@ def test_inference_batch32_ragged_full_size_properties(F):
                                                                     model.combine_stuff_area_thresh,
                                                                     model.combine_instances_score_thresh, 28)
         assert torch.equal(pan1, out[i]["panoptic_seg"][0]) and info1 == out[i]["panoptic_seg"][1]
+
+
+@pytest.mark.parametrize("n,side,c,k", [(37, 28, 256, 800), (5, 28, 256, 1), (3, 14, 64, 81), (2, 6, 512, 9)])
+def test_mask_predict_prob_equals_predictor_conv_then_channel_pick(F, n, side, c, k):
+    """u2_mask_predict_prob (mask_rcnn_inference, roi_heads/mask_head.py:115-158, with the 1x1 predictor folded in) against the
+    reference's order of operations on the same bf16 operands - the K-channel predictor conv (u2_conv_igemm), the predicted
+    class's channel, fp32 sigmoid - for the plain [n, 2P, 2P, C] trunk output and for the deconvolution's unshuffled phases
+    [n, P, P, 4 C].  The logits are sums of the same bf16 products in another order, rounded to bf16: they may differ by one
+    bf16 ulp where the fp32 sum sits on a rounding boundary (tolerance: <= 0.5 % of the logits, each by <= 1 ulp = 2^-7
+    relative, i.e. <= 0.8 % of a probability's logit); everything else is bit-identical."""
+    g = torch.Generator().manual_seed(n * 1000 + side)
+    x = torch.randn((n, side, side, c), generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn((k, c, 1, 1), generator=g) / c ** 0.5).to(DEV)
+    b = (torch.randn(k, generator=g) * 0.1).to(DEV)
+    cls = torch.randint(0, k, (n,), generator=g).to(DEV)
+    logits = F.conv2d(x, w, b, 1, 0)  # [n, side, side, ceil(K)]
+    sel = torch.gather(logits, 3, cls.view(n, 1, 1, 1).expand(n, side, side, 1))[..., 0].float()
+    ref = sel.sigmoid()[:, None]
+    got = F.mask_predict_prob(x, w, b, cls)
+    assert got.shape == (n, 1, side, side) and got.dtype == torch.float32
+    # back to logits to count ulps: z = log(p / (1 - p)) is monotone, compare through the bf16 grid of the reference logit
+    differs = got != ref
+    assert float(differs.float().mean()) <= 5e-3, float(differs.float().mean())
+    z_ref = sel[:, None]
+    ulp = torch.maximum(z_ref.abs(), torch.full_like(z_ref, 2.0 ** -126)) * 2.0 ** -7
+    z_got = torch.log(got / (1 - got))
+    ok = (~differs) | ((z_got - z_ref).abs() <= 1.5 * ulp + 1e-6)
+    assert bool(ok.all())
+    # phases: the pixel shuffle of ConvTranspose2d(k=2, s=2) applied to the same values gives the same probabilities
+    if side % 2 == 0:
+        h = side // 2
+        xp = x.view(n, h, 2, h, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(n, h, h, 4 * c).contiguous()  # [n, h, w, (dy, dx, c)]
+        got_p = F.mask_predict_prob(xp, w, b, cls, phased=True)
+        assert torch.equal(got_p, got)

@@ -464,6 +464,75 @@ extern "C" int u2_semseg_upsample(const void* logits, float* out, long long* arg
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// mask_rcnn_inference (roi_heads/mask_head.py:115-158) without the K-channel logit map: the reference runs the 1x1 predictor to
+// all K classes (800 here: 4 GB of logits for the 3200 detections of a 32-image batch) and keeps one channel per detection.
+// Here only that channel is formed:  prob[n][y][x] = sigmoid(bf16(x[n][y][x][:] . bf16(Wp[cls[n]][:]) + bf16(bp[cls[n]]))),
+// products of bf16 operands summed in fp32 and the logit rounded to bf16 as the conv's output is.
+// `phased`: x is the 2x2/stride-2 deconvolution's GEMM output before its pixel shuffle, [N][S][S][2 (dy)][2 (dx)][C] - output
+// pixel (2 h + dy, 2 w + dx) reads phase (dy, dx) of source pixel (h, w) - so the shuffled copy of the trunk output is never made.
+// One work-group per detection; a wave reads two positions per load, 8 channels per lane and 256-channel chunk (C % 8 == 0, <= 1024).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_predict_prob_kernel(const bf16_t* __restrict__ x, const float* __restrict__ Wp,
+                                                                const float* __restrict__ bp, const long long* __restrict__ cls,
+                                                                float* __restrict__ prob, int S2, int C, int phased) {
+  constexpr int MAXCH = 4;   // 256-channel chunks a lane pair row covers: C <= 1024
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int k = (int)cls[n];
+  float wq[MAXCH][8];
+#pragma unroll
+  for (int q = 0; q < MAXCH; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = q * 256 + l32 * 8 + e;
+      wq[q][e] = c < C ? bf2f(f2bf(Wp[(size_t)k * C + c])) : 0.f;
+    }
+  const float bias = bf2f(f2bf(bp[k]));
+  const int P = S2 * S2;
+  const bf16_t* xn = x + (size_t)n * P * C;
+  for (int p0 = wv * 2; p0 < P; p0 += 8) {   // positions in memory order (for `phased`: (h, w, dy, dx))
+    const int p = p0 + half;
+    float d = 0.f;
+    if (p < P) {
+#pragma unroll
+      for (int q = 0; q < MAXCH; ++q) {
+        const int c = q * 256 + l32 * 8;
+        if (c < C) {
+          bf16_t xv[8];
+          *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(xn + (size_t)p * C + c);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d += bf2f(xv[e]) * wq[q][e];
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+    if (l32 == 0 && p < P) {
+      const float z = bf2f(f2bf(d + bias));
+      int o = p;
+      if (phased) {
+        const int S = S2 >> 1;
+        const int dx = p & 1, dy = (p >> 1) & 1, hwi = p >> 2;
+        const int h = hwi / S, w = hwi - h * S;
+        o = (2 * h + dy) * S2 + 2 * w + dx;
+      }
+      prob[(size_t)n * P + o] = 1.f / (1.f + expf(-z));
+    }
+  }
+}
+
+extern "C" int u2_mask_predict_prob(const void* x, const float* Wp, const float* bp, const void* cls, float* prob, int N, int S2,
+                                    int C, int phased, void* stream) {
+  if (C < 8 || (C & 7) || C > 1024 || S2 < 1 || (phased && (S2 & 1))) return -1;
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(mask_predict_prob_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, Wp, bp,
+                     (const long long*)cls, prob, S2, C, phased);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int u2_paste_masks_batch(const float* probs, const float* boxes, void* out, const U2PasteImage* images, int num_images,
                                     int P, float threshold, void* stream) {
   if (num_images <= 0) return 0;

@@ -853,6 +853,21 @@ def mask_predict_bce_loss(x, weight, bias, classes, target_u8):
     return _MaskPredictBCEFn.apply(x, weight, bias, classes, target_u8)
 
 
+def mask_predict_prob(x, weight, bias, classes, phased=False):
+    """mask_rcnn_inference (roi_heads/mask_head.py:115-158) with the 1x1 predictor folded in: fp32 [n, 1, 2P, 2P] probabilities of
+    each detection's predicted class.  x: [n, 2P, 2P, 256] trunk output, or with `phased` the deconvolution's unshuffled GEMM
+    output [n, P, P, 4 * 256] (ConvTranspose2d(..., shuffle=False)).  No autograd."""
+    _check_act(x)
+    n = x.shape[0]
+    side = x.shape[1] * 2 if phased else x.shape[1]
+    c = x.shape[3] // 4 if phased else x.shape[3]
+    out = torch.empty((n, 1, side, side), dtype=torch.float32, device=x.device)
+    if n:
+        _hip.call("u2_mask_predict_prob", x.contiguous(), weight.detach().reshape(weight.shape[0], -1).contiguous(),
+                  bias.detach().contiguous(), classes.to(torch.int64).contiguous(), out, n, side, c, int(phased))
+    return out
+
+
 class _RPNLossFn(Function):
     """RPN objectness BCE(sum) + localisation L1(sum) over all levels, both / normalizer
     (proposal_generator/rpn.py:366-429).  `fused`: each level is ONE map holding objectness (columns 0-2) and deltas (3-14)."""

@@ -227,10 +227,14 @@ class ConvTranspose2d(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channels))
         nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
 
-    def forward(self, x, relu=False):
+    def forward(self, x, relu=False, shuffle=True):
+        """shuffle=False: the GEMM output [b, h, w, (dy, dx, co)] as it stands, for a consumer that works per output pixel and
+        reads phase (dy, dx) of source pixel (h, w) itself (functional.mask_predict_prob at inference)."""
         b, h, w, _ = x.shape
         co = self.out_channels
         w4 = self.weight.permute(2, 3, 1, 0).reshape(4 * co, self.in_channels, 1, 1)
         y = F.conv2d(x, w4, self.bias.repeat(4), 1, 0, relu=relu)  # [b, h, w, (dy, dx, co)]
+        if not shuffle:
+            return y
         y = y.view(b, h, w, 2, 2, co).permute(0, 1, 3, 2, 4, 5).reshape(b, 2 * h, 2 * w, co)
         return y.contiguous()

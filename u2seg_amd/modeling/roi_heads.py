@@ -233,17 +233,17 @@ class MaskRCNNConvUpsampleHead(nn.Module):
         ret["num_classes"] = 1 if cfg.MODEL.ROI_MASK_HEAD.CLS_AGNOSTIC_MASK else cfg.MODEL.ROI_HEADS.NUM_CLASSES
         return ret
 
-    def trunk(self, x):
+    def trunk(self, x, shuffle=True):
         for layer in self.conv_norm_relus:
             x = layer(x)
-        return self.deconv(x, relu=True)
+        return self.deconv(x, relu=True, shuffle=shuffle)
 
     def forward(self, x, instances):
         """Training: {"loss_mask"}; inference: adds pred_masks [n,1,2P,2P] to the instances (mask_head.py:186-212)."""
-        x = self.trunk(x)
         if self.training:
-            return {"loss_mask": self.mask_loss(x, instances) * self.loss_weight}
-        self.mask_inference(x, instances)
+            return {"loss_mask": self.mask_loss(self.trunk(x), instances) * self.loss_weight}
+        # inference: the deconvolution's phases go to the predictor unshuffled, and only the predicted class's channel is formed
+        self.mask_inference(self.trunk(x, shuffle=False), instances, phased=True)
         return instances
 
     def mask_loss(self, x, instances):
@@ -261,16 +261,15 @@ class MaskRCNNConvUpsampleHead(nn.Module):
             gt_classes = torch.zeros_like(gt_classes)
         return F.mask_predict_bce_loss(x, self.predictor.weight, self.predictor.bias, gt_classes, gt_masks)
 
-    def mask_inference(self, x, pred_instances):
-        """mask_rcnn_inference (mask_head.py:115-158): sigmoid of the predicted-class channel."""
-        logits = self.predictor(x)  # [n, 2P, 2P, ceil32(K)]
-        n = logits.shape[0]
-        if self.num_classes == 1:
-            probs = logits[..., 0].float().sigmoid()[:, None]
+    def mask_inference(self, x, pred_instances, phased=False):
+        """mask_rcnn_inference (mask_head.py:115-158): sigmoid of the predicted-class channel.  x: the trunk output
+        [n, 2P, 2P, C], or with `phased` the deconvolution's unshuffled phases [n, P, P, 4 C]."""
+        n = x.shape[0]
+        if self.num_classes == 1 or n == 0:
+            cls = torch.zeros(n, dtype=torch.long, device=x.device)
         else:
-            cls = torch.cat([i.pred_classes for i in pred_instances]) if n else torch.zeros(0, dtype=torch.long, device=x.device)
-            sel = torch.gather(logits, 3, cls.view(n, 1, 1, 1).expand(n, logits.shape[1], logits.shape[2], 1))
-            probs = sel[..., 0].float().sigmoid()[:, None]
+            cls = torch.cat([i.pred_classes for i in pred_instances])
+        probs = F.mask_predict_prob(x, self.predictor.weight, self.predictor.bias, cls, phased=phased)
         for prob, inst in zip(probs.split([len(i) for i in pred_instances], dim=0), pred_instances):
             inst.pred_masks = prob
 
