@@ -283,12 +283,13 @@ typedef struct U2PanopticImage {
   const int* order;           /* [K] instance index by descending score */
   const float* scores_sorted; /* [K] */
   const float* boxes;         /* [K][4] or NULL */
-  const long long* semantic;  /* [H][W] argmax of the semantic head */
+  const long long* semantic;  /* [H][W] argmax of the semantic head, rows sem_stride elements apart */
   int* panoptic;              /* [H][W] out */
   int* inst_segment;          /* [K] out */
   int* stuff_segment;         /* [num_sem] out */
   int* stuff_area;            /* [num_sem] out */
   int K, H, W, num_sem;
+  int sem_stride;             /* >= W: the label map may be a window of a wider (padded) map */
 } U2PanopticImage;
 int u2_panoptic_merge(const U2PanopticImage* images, int n_images, float overlap_thr, int stuff_area_thr, float score_thr,
                       int mask_res, void* stream);

@@ -648,3 +648,27 @@ def test_mask_predict_prob_equals_predictor_conv_then_channel_pick(F, n, side, c
         xp = x.view(n, h, 2, h, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(n, h, h, 4 * c).contiguous()  # [n, h, w, (dy, dx, c)]
         got_p = F.mask_predict_prob(xp, w, b, cls, phased=True)
         assert torch.equal(got_p, got)
+
+
+def test_fast_rcnn_inference_stacked_tensors_equal_per_image_lists():
+    """fast_rcnn_inference takes the cascade's averaged scores and last-stage boxes as stacked [B, R, .] tensors (no per-image
+    split / re-stack): same detections, in the same order, as with per-image lists and as image by image."""
+    from u2seg_amd.modeling.inference import fast_rcnn_inference, fast_rcnn_inference_single_image
+
+    g = torch.Generator().manual_seed(11)
+    b, r, k = 4, 300, 20
+    ctr = torch.rand((b, r, 2), generator=g) * torch.tensor([320.0, 240.0])
+    wh = 5 + torch.rand((b, r, 2), generator=g) * 80
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], dim=2).to(DEV)
+    scores = torch.softmax(torch.randn((b, r, k + 1), generator=g) * 3, dim=2).to(DEV)
+    scores[1, 7, 3] = float("nan")   # a row the filter drops entirely (fast_rcnn.py:138-141)
+    shapes = [(240, 320), (200, 300), (240, 320), (100, 100)]
+    res_t, kept_t = fast_rcnn_inference(boxes, scores, shapes, 0.05, 0.5, 100)
+    res_l, kept_l = fast_rcnn_inference(list(boxes), list(scores), shapes, 0.05, 0.5, 100)
+    for i in range(b):
+        one, kept_1 = fast_rcnn_inference_single_image(boxes[i], scores[i], shapes[i], 0.05, 0.5, 100)
+        for other, kept_o in ((res_l[i], kept_l[i]), (one, kept_1)):
+            assert torch.equal(res_t[i].pred_boxes.tensor, other.pred_boxes.tensor)
+            assert torch.equal(res_t[i].scores, other.scores) and torch.equal(res_t[i].pred_classes, other.pred_classes)
+            assert torch.equal(kept_t[i], kept_o)
+    assert len(res_t[0]) > 0 and 7 not in kept_t[1].tolist()

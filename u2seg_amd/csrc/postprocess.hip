@@ -294,6 +294,13 @@ __global__ __launch_bounds__(PM_THREADS) void panoptic_merge_kernel(const Panopt
   }
 }
 
+// semantic label of pixel p = y * W + x: the label map may be a window of a wider (padded) map, row pitch sem_stride elements
+__device__ __forceinline__ long long panoptic_sem_at(const U2PanopticImage& im, long long p) {
+  if (im.sem_stride == im.W) return im.semantic[p];
+  const int y = (int)(p / im.W);
+  return im.semantic[(long long)y * im.sem_stride + (p - (long long)y * im.W)];
+}
+
 // semantic histogram of a stripe: per label the free pixels (-> stuff_area) and whether the label occurs at all (-> a flag in
 // stuff_segment, replaced by the segment id in the last kernel)
 __global__ __launch_bounds__(PM_THREADS) void panoptic_stuff_hist_kernel(const PanopticBatch batch) {
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(PM_THREADS) void panoptic_stuff_hist_kernel(const P
   for (int i = threadIdx.x; i < PM_MAXSEM; i += PM_THREADS) { hist_all[i] = 0; hist_free[i] = 0; }
   __syncthreads();
   for (long long p = (long long)blockIdx.x * PM_THREADS + threadIdx.x; p < hw; p += (long long)gridDim.x * PM_THREADS) {
-    const long long lab = im.semantic[p];
+    const long long lab = panoptic_sem_at(im, p);
     if (lab >= 0 && lab < im.num_sem) {
       atomicAdd(&hist_all[(int)lab], 1);
       if (im.panoptic[p] == 0) atomicAdd(&hist_free[(int)lab], 1);
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(PM_THREADS) void panoptic_stuff_ids_kernel(const Pa
   __syncthreads();
   if (FILL) {
     for (long long p = (long long)blockIdx.x * PM_THREADS + threadIdx.x; p < hw; p += (long long)gridDim.x * PM_THREADS) {
-      const long long lab = im.semantic[p];
+      const long long lab = panoptic_sem_at(im, p);
       if (lab > 0 && lab < im.num_sem && im.panoptic[p] == 0) {
         const int id = stuff_id[(int)lab];
         if (id) im.panoptic[p] = id;
@@ -357,7 +364,9 @@ extern "C" int u2_panoptic_merge(const U2PanopticImage* images, int n_images, fl
     PanopticBatch batch;
     for (int i = 0; i < nb; ++i) {
       batch.im[i] = images[b0 + i];
-      if (batch.im[i].num_sem > PM_MAXSEM || batch.im[i].num_sem < 0 || batch.im[i].H <= 0 || batch.im[i].W <= 0) return -1;
+      if (batch.im[i].num_sem > PM_MAXSEM || batch.im[i].num_sem < 0 || batch.im[i].H <= 0 || batch.im[i].W <= 0 ||
+          batch.im[i].sem_stride < batch.im[i].W)
+        return -1;
     }
     hipLaunchKernelGGL(panoptic_clear_kernel, dim3(PM_STRIPES, nb), dim3(PM_THREADS), 0, s, batch);
     U2_CHECK_LAUNCH();

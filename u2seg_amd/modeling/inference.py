@@ -20,7 +20,7 @@ def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, n
 def fast_rcnn_inference(boxes, scores, image_shapes, score_thresh, nms_thresh, topk_per_image):
     """fast_rcnn.py:46-171 for the whole batch at once: score filter, per-class NMS and top-k with three host
     synchronisations per batch (candidate counts, the candidate list, keep counts) instead of four per image.
-    boxes: per image [R_i, 4] (class agnostic) or [R_i, K*4]; scores: per image [R_i, K+1]."""
+    boxes: per image [R_i, 4] (class agnostic) or [R_i, K*4]; scores: per image [R_i, K+1]; or both stacked, [B, R, .]."""
     nimg = len(boxes)
     if nimg == 0:
         return [], []
@@ -29,7 +29,10 @@ def fast_rcnn_inference(boxes, scores, image_shapes, score_thresh, nms_thresh, t
     nreg = boxes[0].shape[1] // 4
     counts_r = [b.shape[0] for b in boxes]
     rmax = max(max(counts_r), 1)
-    if len(set(counts_r)) == 1 and counts_r[0] > 0:
+    if isinstance(boxes, torch.Tensor) and isinstance(scores, torch.Tensor) and counts_r[0] > 0:
+        bx, sc = boxes, scores  # already stacked [B, R, .]: no copy
+        rvalid = None
+    elif len(set(counts_r)) == 1 and counts_r[0] > 0:
         bx, sc = torch.stack(list(boxes)), torch.stack(list(scores))
         rvalid = None
     else:  # ragged: pad with rows that never pass the score filter
@@ -44,9 +47,9 @@ def fast_rcnn_inference(boxes, scores, image_shapes, score_thresh, nms_thresh, t
     lim = device_constant([[[w, h] * 2] for h, w in image_shapes], torch.float32, dev)  # Boxes.clip per image
     bx = torch.minimum(bx.float().view(nimg, rmax, nreg, 4).clamp(min=0), lim[:, :, None, :])
     cand = (sc[..., :k] > score_thresh) & valid[..., None]  # [B, R, K]
-    ncand = cand.flatten(1).sum(dim=1)
-    cnt = ncand.tolist()  # sync 1
-    idx = cand.nonzero()  # sync 2; rows ordered by (image, roi, class) like the reference's per-image nonzero
+    idx = cand.nonzero()  # sync 1; rows ordered by (image, roi, class) like the reference's per-image nonzero
+    ncand = torch.bincount(idx[:, 0], minlength=nimg)  # (a sum over the [B, R * K] mask was 0.28 ms of a 32-image batch)
+    cnt = ncand.tolist()  # sync 2
     total = idx.shape[0]
     c_img, c_roi, c_cls = idx[:, 0], idx[:, 1], idx[:, 2]
     c_scores = sc[c_img, c_roi, c_cls]
@@ -203,7 +206,8 @@ class _PanopticImage(ctypes.Structure):
     _fields_ = [("masks", ctypes.c_void_p), ("order", ctypes.c_void_p), ("scores_sorted", ctypes.c_void_p),
                 ("boxes", ctypes.c_void_p), ("semantic", ctypes.c_void_p), ("panoptic", ctypes.c_void_p),
                 ("inst_segment", ctypes.c_void_p), ("stuff_segment", ctypes.c_void_p), ("stuff_area", ctypes.c_void_p),
-                ("K", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("num_sem", ctypes.c_int)]
+                ("K", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("num_sem", ctypes.c_int),
+                ("sem_stride", ctypes.c_int)]
 
 
 _NUM_SEM_SLOTS = 256  # semantic labels the merge kernel can number (PM_MAXSEM)
@@ -247,7 +251,9 @@ def combine_semantic_and_instance_outputs_batch(instance_results, semantic_resul
     for i, (inst, sem) in enumerate(zip(instance_results, semantic_results)):
         h, w = sem.shape
         k = ks[i]
-        sem = sem.to(torch.int64).contiguous()
+        # the label map is read in place when it is an int64 window of a wider map (the fused argmax of the padded batch)
+        if not (sem.dtype == torch.int64 and sem.stride(1) == 1 and sem.stride(0) >= w):
+            sem = sem.to(torch.int64).contiguous()
         masks = inst.pred_masks.to(device=dev)
         masks = (masks if masks.dtype in (torch.bool, torch.uint8) else masks > 0).contiguous()
         assert masks.shape == (k, h, w), (masks.shape, (k, h, w))
@@ -261,7 +267,7 @@ def combine_semantic_and_instance_outputs_batch(instance_results, semantic_resul
         d.inst_segment = out_all.data_ptr() + 4 * opos
         d.stuff_segment = out_all.data_ptr() + 4 * (opos + k)
         d.stuff_area = out_all.data_ptr() + 4 * (opos + k + _NUM_SEM_SLOTS)
-        d.K, d.H, d.W, d.num_sem = k, h, w, _NUM_SEM_SLOTS
+        d.K, d.H, d.W, d.num_sem, d.sem_stride = k, h, w, _NUM_SEM_SLOTS, sem.stride(0)
         opos += k + 2 * _NUM_SEM_SLOTS
         keep_alive.append((masks, boxes, sem))
         per_image.append((pan, k))
