@@ -185,6 +185,11 @@ int u2_roi_align_bwd(float* const* gfeats, const int* Hs, const int* Ws, const f
 int u2_roi_align_bwd_gather(void* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,
                             const float* rois, const int* order, const int* seg, const void* dout, int B, int C, int PH,
                             int PW, float gscale, void* stream);
+/* ROIs grouped by (image, level) for u2_roi_align_bwd_gather(_multi): order int32 [R] = ROI indices sorted by
+ * key = image * nlevels + level with equal keys in index order (stable, = torch.argsort(key, stable=True)); seg int32
+ * [num_images * nlevels + 1] = first position of every key, seg[last] = R.  rois [R][5] (image index first), level int32 [R].
+ * num_images * nlevels <= 256, R <= 32768. */
+int u2_roi_group(const float* rois, const int* level, int* order, int* seg, int R, int num_images, int nlevels, void* stream);
 /* The same gather over up to four ROI sets at once (the cascade's three box poolers and the mask pooler share the FPN
  * maps): set i has its own rois / order / seg / dout, pooled size P[i] x P[i] and gradient scale.  Each level's gradient
  * map is written once; the per-set gradient maps and their sums (autograd's accumulation) are never formed. */

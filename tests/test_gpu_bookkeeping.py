@@ -672,3 +672,24 @@ def test_fast_rcnn_inference_stacked_tensors_equal_per_image_lists():
             assert torch.equal(res_t[i].scores, other.scores) and torch.equal(res_t[i].pred_classes, other.pred_classes)
             assert torch.equal(kept_t[i], kept_o)
     assert len(res_t[0]) > 0 and 7 not in kept_t[1].tolist()
+
+
+@pytest.mark.parametrize("r,b,nl", [(8192, 16, 4), (251, 16, 4), (32000, 32, 4), (0, 2, 4), (1000, 64, 4), (777, 3, 1)])
+def test_roi_group_equals_stable_argsort_and_bincount(F, r, b, nl):
+    """u2_roi_group (the (image, level) grouping the ROIAlign backward gather walks) == torch.argsort(key, stable=True) and
+    cumsum(bincount(key)), bit for bit - the gather adds a pixel's ROIs in this order."""
+    g = torch.Generator().manual_seed(r + b)
+    rois = torch.zeros((r, 5))
+    rois[:, 0] = torch.randint(0, b, (r,), generator=g).float()
+    if r > 10:
+        rois[: r // 3, 0] = 1.0  # one crowded image
+    rois[:, 1:] = torch.rand((r, 4), generator=g) * 100
+    levels = torch.randint(0, nl, (r,), generator=g).to(torch.int32)
+    rois, levels = rois.to(DEV), levels.to(DEV)
+    order, seg = F._roi_group(rois, levels, b, nl)
+    key = rois[:, 0].to(torch.int64) * nl + levels.to(torch.int64)
+    ref_order = torch.argsort(key, stable=True).to(torch.int32)
+    ref_seg = torch.zeros(b * nl + 1, dtype=torch.int32, device=DEV)
+    ref_seg[1:] = torch.cumsum(torch.bincount(key, minlength=b * nl), 0)
+    assert order.dtype == torch.int32 and seg.dtype == torch.int32
+    assert torch.equal(order, ref_order) and torch.equal(seg, ref_seg)

@@ -882,6 +882,61 @@ extern "C" int u2_batched_nms(const float* boxes, const int* group, const int* c
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ROIs grouped by (image, level) for the gather above: order[R] = the ROI indices sorted by key = image * nlevels + level,
+// equal keys in index order (a stable sort: the gather adds a pixel's ROIs in this order), seg[k] = first position of key k,
+// seg[nkeys] = R.  One work-group: the keys sit in LDS, thread (segment s, key k) counts and then places the ROIs of key k in
+// the s-th slice of the index range (256 / nkeys slices), so every key's ROIs come out in ascending index order.
+// (torch: argsort(stable) + bincount + cumsum + casts, 0.18 ms and one host synchronisation per call, four calls per step.)
+// ---------------------------------------------------------------------------------------------
+constexpr int RG_MAXKEYS = 256, RG_MAXR = 32768;
+__global__ __launch_bounds__(256) void roi_group_kernel(const float* __restrict__ rois, const int* __restrict__ level,
+                                                        int* __restrict__ order, int* __restrict__ seg, int R, int nl,
+                                                        int nkeys) {
+  extern __shared__ unsigned short rg_keys[];
+  __shared__ int cnt[RG_MAXKEYS], first[RG_MAXKEYS];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < R; i += 256) {
+    int k = (int)rois[(size_t)i * 5] * nl + level[i];
+    rg_keys[i] = (unsigned short)min(max(k, 0), nkeys - 1);
+  }
+  const int nseg = 256 / nkeys;                  // >= 1
+  const int seglen = (R + nseg - 1) / nseg;
+  const int k = tid % nkeys, sgm = tid / nkeys;
+  const bool active = sgm < nseg;
+  const int i0 = sgm * seglen, i1 = min(R, i0 + seglen);
+  __syncthreads();
+  int c = 0;
+  if (active)
+    for (int i = i0; i < i1; ++i) c += rg_keys[i] == k;
+  cnt[tid] = active ? c : 0;                      // cnt[sgm * nkeys + k]
+  __syncthreads();
+  if (tid == 0) {
+    int pos = 0;
+    for (int kk = 0; kk < nkeys; ++kk) {
+      seg[kk] = pos;
+      for (int ss = 0; ss < nseg; ++ss) { first[ss * nkeys + kk] = pos; pos += cnt[ss * nkeys + kk]; }
+    }
+    seg[nkeys] = pos;
+  }
+  __syncthreads();
+  if (active) {
+    int pos = first[tid];
+    for (int i = i0; i < i1; ++i)
+      if (rg_keys[i] == k) order[pos++] = i;
+  }
+}
+
+extern "C" int u2_roi_group(const float* rois, const int* level, int* order, int* seg, int R, int num_images, int nlevels,
+                            void* stream) {
+  const int nkeys = num_images * nlevels;
+  if (R < 0 || nkeys < 1 || nkeys > RG_MAXKEYS || R > RG_MAXR) return -1;
+  hipLaunchKernelGGL(roi_group_kernel, dim3(1), dim3(256), (size_t)(R > 0 ? R : 1) * 2, (hipStream_t)stream, rois, level, order, seg,
+                     R, nlevels, nkeys);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int u2_roi_align_bwd_gather_multi(void* const* gfeats, const int* Hs, const int* Ws, const float* scales,
                                              int nlevels, int nsets, const void* const* rois, const void* const* order,
                                              const void* const* seg, const void* const* dout, const int* P,

@@ -937,6 +937,12 @@ def _level_arrays(feats, scales):
 
 def _roi_group(rois, levels, b, nl):
     """ROIs grouped by (image, level) for the per-pixel gather: order int32 [R], segment offsets int32 [b*nl+1]."""
+    r = rois.shape[0]
+    if b * nl <= 256 and r <= 32768 and levels.dtype == torch.int32:
+        order = torch.empty(r, dtype=torch.int32, device=rois.device)
+        seg = torch.empty(b * nl + 1, dtype=torch.int32, device=rois.device)
+        _hip.call("u2_roi_group", rois.contiguous(), levels.contiguous(), order, seg, r, b, nl)
+        return order, seg
     key = rois[:, 0].to(torch.int64) * nl + levels.to(torch.int64)
     order = torch.argsort(key, stable=True).to(torch.int32)
     seg = torch.zeros(b * nl + 1, dtype=torch.int32, device=rois.device)
