@@ -159,9 +159,11 @@ int u2_scale_to_bf16(const float* acc, const float* num, const float* den, float
                      void* stream);
 int u2_softmax_ce(const void* logits, const void* labels, void* dlogits, float* loss_sum, int R, int NC, int LP,
                   float gscale, void* stream);
+/* (u2_mask_predict_bce: phased_side = 0: x / dx are [N][P][C] in pixel order; phased_side = S2 (P = S2 * S2): they are the
+ * 2x2 / stride-2 deconvolution's unshuffled GEMM output [N][S2/2][S2/2][2][2][C], target / logit_out stay in pixel order.) */
 int u2_mask_predict_bce(const void* x, const float* Wp, const float* bp, const void* cls, const void* target, void* dx,
                         float* dWp, float* dbp, float* loss_sum, void* logit_out, int N, int P, int C, float gscale,
-                        void* stream);
+                        int phased_side, void* stream);
 /* proposal_generator/rpn.py:366-429, one feature level.  dlt == NULL (and ddlt == NULL, A == 3): `obj` is the output of the
  * objectness and anchor-delta 1x1 convs run as ONE conv (columns 0-2 objectness, 3-14 deltas of an LPo-wide NHWC map) and dobj
  * receives both gradients in the same columns - the map their common input's gradient is then formed from by one data-gradient

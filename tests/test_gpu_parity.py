@@ -267,6 +267,17 @@ def test_head_losses(F):
     loss.backward()
     assert rel_err(nchw(xd.grad), xr.grad) < 8e-3  # measured 5.6e-3: the reference rounds the selected logit to bf16 BEFORE the loss (one extra half step of the gradient's range), the kernel differentiates the fp32 logit
     assert rel_err(wd.grad.cpu(), w.grad) < 6e-3 and rel_err(bd.grad.cpu(), b.grad) < 6e-3
+    # the deconvolution's unshuffled phases [n, P, P, (dy, dx, C)] as input (what the mask head hands over): the same loss (its
+    # terms summed in another order) and bit for bit the same input gradient, in the phased layout
+    xs = nhwc(x)                                                                          # [6, 28, 28, 256]
+    xp = xs.view(6, 14, 2, 14, 2, 256).permute(0, 1, 3, 2, 4, 5).reshape(6, 14, 14, 1024).contiguous().requires_grad_(True)
+    wp, bp = w.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    loss_p = F.mask_predict_bce_loss(xp, wp, bp, cls.to(DEV), tgt.to(torch.uint8).to(DEV), True)
+    loss_p.backward()
+    assert float(loss_p) == pytest.approx(float(loss), rel=1e-6)
+    gp = xp.grad.view(6, 14, 14, 2, 2, 256).permute(0, 1, 3, 2, 4, 5).reshape(6, 28, 28, 256)
+    assert torch.equal(gp, xd.grad)
+    assert torch.allclose(wp.grad, wd.grad, rtol=1e-5, atol=1e-7) and torch.allclose(bp.grad, bd.grad, rtol=1e-5, atol=1e-7)
 
 
 def test_roi_align_fwd_bwd(F, G):

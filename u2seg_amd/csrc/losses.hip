@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void mask_predict_bce_kernel(const bf16_t* __r
                                                                const uint8_t* __restrict__ target, bf16_t* __restrict__ dx,
                                                                float* __restrict__ dWp, float* __restrict__ dbp,
                                                                float* __restrict__ loss_sum, bf16_t* __restrict__ logit_out,
-                                                               int P, int C, float gscale) {
+                                                               int P, int C, float gscale, int phased_side) {
   __shared__ float red[4][260];
   const int n = blockIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -335,7 +335,15 @@ __global__ __launch_bounds__(256) void mask_predict_bce_kernel(const bf16_t* __r
     for (int e = 0; e < 4; ++e) d += bf2f(xv[e]) * wq[e];
     d = wave_sum(d);
     const float z = bf2f(f2bf(d + bias));
-    const float t = (float)target[(size_t)n * P + p];
+    // phased: position p of x / dx is (h, w, dy, dx) of the deconvolution's unshuffled output = pixel (2 h + dy, 2 w + dx) of the
+    // target and of logit_out
+    int o = p;
+    if (phased_side) {
+      const int S = phased_side >> 1, hw = p >> 2;
+      const int h = hw / S, w = hw - h * S;
+      o = (2 * h + ((p >> 1) & 1)) * phased_side + 2 * w + (p & 1);
+    }
+    const float t = (float)target[(size_t)n * P + o];
     // max(z,0) - z*t + log1p(exp(-|z|))
     ls += fmaxf(z, 0.f) - z * t + log1pf(__expf(-fabsf(z)));
     const float sg = 1.f / (1.f + __expf(-z));
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(256) void mask_predict_bce_kernel(const bf16_t* __r
     }
     *reinterpret_cast<uint2*>(dx + off) = *reinterpret_cast<const uint2*>(ov);
     db += g;
-    if (logit_out && lane == 0) logit_out[(size_t)n * P + p] = f2bf(z);
+    if (logit_out && lane == 0) logit_out[(size_t)n * P + o] = f2bf(z);
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[wv][lane * 4 + e] = dw[e];
@@ -511,12 +519,12 @@ extern "C" int u2_softmax_ce(const void* logits, const void* labels, void* dlogi
 
 extern "C" int u2_mask_predict_bce(const void* x, const float* Wp, const float* bp, const void* cls, const void* target,
                                    void* dx, float* dWp, float* dbp, float* loss_sum, void* logit_out, int N, int P,
-                                   int C, float gscale, void* stream) {
-  if (C != 256) return -1;
+                                   int C, float gscale, int phased_side, void* stream) {
+  if (C != 256 || (phased_side && ((phased_side & 1) || phased_side * phased_side != P))) return -1;
   if (N <= 0) return 0;
   hipLaunchKernelGGL(mask_predict_bce_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, Wp, bp,
                      (const long long*)cls, (const uint8_t*)target, (bf16_t*)dx, dWp, dbp, loss_sum, (bf16_t*)logit_out,
-                     P, C, gscale);
+                     P, C, gscale, phased_side);
   U2_CHECK_LAUNCH();
   return 0;
 }

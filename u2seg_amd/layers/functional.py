@@ -827,8 +827,10 @@ class _MaskPredictBCEFn(Function):
     (roi_heads/mask_head.py:258 + :33-112)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, classes, target_u8):
+    def forward(ctx, x, weight, bias, classes, target_u8, phased=False):
         n, ph, pw, c = x.shape
+        if phased:  # x = the deconvolution's unshuffled phases [n, P, P, 4 C]: the kernel reads (and writes dx) in place
+            ph, pw, c = 2 * ph, 2 * pw, c // 4
         p = ph * pw
         k = weight.shape[0]
         w2 = weight.detach().reshape(k, c).float().contiguous()
@@ -838,7 +840,7 @@ class _MaskPredictBCEFn(Function):
         loss = torch.zeros(1, dtype=torch.float32, device=x.device)
         denom = float(max(n * p, 1))
         _hip.call("u2_mask_predict_bce", x.contiguous(), w2, bias.detach().float().contiguous(), classes.contiguous(),
-                  target_u8.contiguous(), dx, dw, db, loss, None, n, p, c, 1.0 / denom)
+                  target_u8.contiguous(), dx, dw, db, loss, None, n, p, c, 1.0 / denom, ph if phased else 0)
         ctx.save_for_backward(dx, dw, db)
         ctx.wshape = weight.shape
         return loss[0] / denom
@@ -846,11 +848,11 @@ class _MaskPredictBCEFn(Function):
     @staticmethod
     def backward(ctx, g):
         dx, dw, db = ctx.saved_tensors
-        return dx * g.to(dx.dtype), (dw * g).view(ctx.wshape), db * g, None, None
+        return dx * g.to(dx.dtype), (dw * g).view(ctx.wshape), db * g, None, None, None
 
 
-def mask_predict_bce_loss(x, weight, bias, classes, target_u8):
-    return _MaskPredictBCEFn.apply(x, weight, bias, classes, target_u8)
+def mask_predict_bce_loss(x, weight, bias, classes, target_u8, phased=False):
+    return _MaskPredictBCEFn.apply(x, weight, bias, classes, target_u8, phased)
 
 
 def mask_predict_prob(x, weight, bias, classes, phased=False):

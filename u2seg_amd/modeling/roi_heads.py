@@ -243,14 +243,16 @@ class MaskRCNNConvUpsampleHead(nn.Module):
     def forward(self, x, instances):
         """Training: {"loss_mask"}; inference: adds pred_masks [n,1,2P,2P] to the instances (mask_head.py:186-212)."""
         if self.training:
-            return {"loss_mask": self.mask_loss(self.trunk(x), instances) * self.loss_weight}
+            # (the deconvolution's phases go to the loss kernel unshuffled, as at inference: no pixel-shuffle copy either way)
+            return {"loss_mask": self.mask_loss(self.trunk(x, shuffle=False), instances, phased=True) * self.loss_weight}
         # inference: the deconvolution's phases go to the predictor unshuffled, and only the predicted class's channel is formed
         self.mask_inference(self.trunk(x, shuffle=False), instances, phased=True)
         return instances
 
-    def mask_loss(self, x, instances):
-        """mask_rcnn_loss (mask_head.py:33-112) fused with the predictor: only the gt-class channel is formed."""
-        side = x.shape[1]
+    def mask_loss(self, x, instances, phased=False):
+        """mask_rcnn_loss (mask_head.py:33-112) fused with the predictor: only the gt-class channel is formed.  x: the trunk
+        output [n, 2P, 2P, C], or with `phased` the deconvolution's unshuffled phases [n, P, P, 4 C]."""
+        side = x.shape[1] * 2 if phased else x.shape[1]
         from ..structures.masks import crop_and_resize_batch
 
         keep = [inst for inst in instances if len(inst) > 0]
@@ -261,7 +263,7 @@ class MaskRCNNConvUpsampleHead(nn.Module):
                                          side).to(torch.uint8)
         if self.num_classes == 1:
             gt_classes = torch.zeros_like(gt_classes)
-        return F.mask_predict_bce_loss(x, self.predictor.weight, self.predictor.bias, gt_classes, gt_masks)
+        return F.mask_predict_bce_loss(x, self.predictor.weight, self.predictor.bias, gt_classes, gt_masks, phased)
 
     def mask_inference(self, x, pred_instances, phased=False):
         """mask_rcnn_inference (mask_head.py:115-158): sigmoid of the predicted-class channel.  x: the trunk output
