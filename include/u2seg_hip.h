@@ -144,6 +144,12 @@ int u2_bilinear_up2_fwd(const void* x, const void* addend /*nullable, out = up2(
 int u2_bilinear_up2_bwd(const void* dout, void* dx, int B, int H, int W, int C, void* stream);
 int u2_stem_im2col(const void* img, int is_uint8, const float* mean, const float* stdv, void* col, int b, int h, int w,
                    int Hpad, int Wpad, int KP, void* stream);
+/* ImageList.from_tensors(gt_sem_seg, size_divisibility, ignore_value) (detectron2/structures/image_list.py:70-122 as called by
+ * modeling/meta_arch/panoptic_fpn.py:118-126) for the label maps of a batch in one launch: out uint8 [n_imgs][Hpad][Wpad]
+ * (16-byte aligned, Wpad % 16 == 0) = the image's labels (int64 if is_int64, else uint8; host arrays of device pointers / sizes,
+ * h <= Hpad, w <= Wpad) in the top-left corner, `pad` elsewhere. */
+int u2_label_pad_batch(const void* const* imgs, const int* hs, const int* ws, int n_imgs, int is_int64, void* out, int Hpad,
+                       int Wpad, int pad, void* stream);
 /* All images of the batch (host arrays of device pointers / sizes; images may differ in size) in one launch. */
 int u2_stem_im2col_batch(const void* const* imgs, const int* hs, const int* ws, int n_imgs, int is_uint8, const float* mean,
                          const float* stdv, void* col, int Hpad, int Wpad, int KP, void* stream);

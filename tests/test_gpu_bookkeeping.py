@@ -693,3 +693,71 @@ def test_roi_group_equals_stable_argsort_and_bincount(F, r, b, nl):
     ref_seg[1:] = torch.cumsum(torch.bincount(key, minlength=b * nl), 0)
     assert order.dtype == torch.int32 and seg.dtype == torch.int32
     assert torch.equal(order, ref_order) and torch.equal(seg, ref_seg)
+
+
+@pytest.mark.parametrize("dtype", [torch.int64, torch.uint8])
+def test_label_pad_batch_equals_from_tensors(F, dtype):
+    """u2_label_pad_batch == ImageList.from_tensors(gt_sem_seg, divisibility, pad_value=ignore) (image_list.py:70-122) converted to
+    uint8, for images of different sizes incl. one that fills the padded canvas and a 1 x 1 map."""
+    import ctypes
+
+    from u2seg_amd import _hip
+
+    g = torch.Generator().manual_seed(3)
+    sizes = [(37, 53), (64, 96), (1, 1), (50, 96), (64, 17)]
+    maps = [torch.randint(0, 256, s, generator=g).to(dtype).to(DEV) for s in sizes]
+    hp, wp, ignore = 64, 96, 255
+    out = torch.empty((len(maps), hp, wp), dtype=torch.uint8, device=DEV)
+    b = len(maps)
+    ptrs = (ctypes.c_void_p * b)(*[m.data_ptr() for m in maps])
+    hs = (ctypes.c_int * b)(*[m.shape[0] for m in maps])
+    ws = (ctypes.c_int * b)(*[m.shape[1] for m in maps])
+    _hip.call("u2_label_pad_batch", ptrs, hs, ws, b, int(dtype == torch.int64), out, hp, wp, ignore)
+    ref = torch.full((b, hp, wp), ignore, dtype=torch.uint8, device=DEV)
+    for i, m in enumerate(maps):
+        ref[i, : m.shape[0], : m.shape[1]] = m.to(torch.uint8)
+    assert torch.equal(out, ref)
+
+
+def test_select_foreground_proposals_stacked_equals_per_image_indexing():
+    """select_foreground_proposals on a stacked BatchList (the columns reordered for the whole batch, per-image views) returns
+    the tables the per-image form - every column indexed by the image's foreground rows, roi_heads.py:46-75 - returns."""
+    from u2seg_amd.modeling.batched import BatchList
+    from u2seg_amd.modeling.roi_heads import select_foreground_proposals
+    from u2seg_amd.structures import BitMasks, Boxes, Instances
+
+    g = torch.Generator().manual_seed(21)
+    nb, s, k, ng = 3, 64, 10, 5
+    boxes = (torch.rand((nb, s, 4), generator=g) * 100).to(DEV)
+    gtb = (torch.rand((nb, s, 4), generator=g) * 100).to(DEV)
+    cls = torch.randint(0, k + 1, (nb, s), generator=g).to(DEV)   # k = background
+    cls[1] = k                                                     # an image without foreground
+    cls[2, 5] = -1                                                 # an ignored row
+    logits = torch.randn((nb, s), generator=g).to(DEV)
+    match = torch.randint(0, ng, (nb, s), generator=g).to(DEV)
+    bases = [(torch.rand((ng, 12, 16), generator=g) > 0.5).to(DEV) for _ in range(nb)]
+    extra = torch.randn((nb, s, 3), generator=g).to(DEV)           # a column without a stacked form
+
+    def build(stacked):
+        out = BatchList()
+        for i in range(nb):
+            r = Instances((12, 16))
+            r.proposal_boxes, r.objectness_logits, r.gt_classes = Boxes(boxes[i]), logits[i], cls[i]
+            r.gt_boxes = Boxes(gtb[i])
+            r.gt_masks = BitMasks(bases[i])[match[i]]
+            r.gt_extra = extra[i]
+            out.append(r)
+        if stacked:
+            out.boxes, out.gt_classes, out.gt_boxes, out.logits, out.match = boxes, cls, gtb, logits, match
+        return out
+
+    fg_s, m_s = select_foreground_proposals(build(True), k)
+    fg_l, m_l = select_foreground_proposals(build(False), k)
+    for a, b_, ma, mb in zip(fg_s, fg_l, m_s, m_l):
+        assert torch.equal(ma, mb) and len(a) == len(b_)
+        assert sorted(a.get_fields()) == sorted(b_.get_fields())
+        for name in ("objectness_logits", "gt_classes", "gt_extra"):
+            assert torch.equal(a.get(name), b_.get(name)), name
+        assert torch.equal(a.proposal_boxes.tensor, b_.proposal_boxes.tensor) and torch.equal(a.gt_boxes.tensor, b_.gt_boxes.tensor)
+        assert torch.equal(a.gt_masks.tensor, b_.gt_masks.tensor)
+    assert len(fg_s[1]) == 0 and len(fg_s[0]) > 0

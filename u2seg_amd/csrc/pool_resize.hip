@@ -377,6 +377,51 @@ extern "C" int u2_stem_im2col_batch(const void* const* imgs, const int* hs, cons
   return 0;
 }
 
+// ImageList.from_tensors(gt_sem_seg, size_divisibility, ignore_value) (structures/image_list.py:70-122 as called by
+// meta_arch/panoptic_fpn.py:118-126) for the label maps of a batch in one launch: out[b][y][x] (uint8) = labels_b[y][x] inside the
+// image, `pad` outside.  Labels arrive as int64 (the dataset mapper's dtype) or uint8; per image it was a conversion and a strided
+// copy, 32 launches + the fill per 16-image step.  One thread = 16 output bytes (Wpad % 16 == 0).
+struct LabelImages { const void* img[32]; int h[32]; int w[32]; };
+template <typename T>
+__global__ __launch_bounds__(256) void label_pad_kernel(const LabelImages imgs, uint8_t* __restrict__ out, int b0, int Hpad, int Wpad,
+                                                        int pad) {
+  const int bi = blockIdx.y;
+  const T* __restrict__ src = reinterpret_cast<const T*>(imgs.img[bi]);
+  const int h = imgs.h[bi], w = imgs.w[bi];
+  const int wq = Wpad >> 4;
+  const long long total = (long long)Hpad * wq;
+  uint8_t* o = out + (size_t)(b0 + bi) * Hpad * Wpad;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int y = (int)(i / wq), x0 = (int)(i - (long long)y * wq) * 16;
+    __attribute__((aligned(16))) uint8_t v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = (y < h && x0 + e < w) ? (uint8_t)src[(size_t)y * w + x0 + e] : (uint8_t)pad;
+    *reinterpret_cast<uint4*>(o + (size_t)y * Wpad + x0) = *reinterpret_cast<const uint4*>(v);
+  }
+}
+
+extern "C" int u2_label_pad_batch(const void* const* imgs, const int* hs, const int* ws, int n_imgs, int is_int64, void* out,
+                                  int Hpad, int Wpad, int pad, void* stream) {
+  if (Hpad < 1 || Wpad < 16 || (Wpad & 15) || pad < 0 || pad > 255 || ((uintptr_t)out & 15)) return -1;
+  for (int b0 = 0; b0 < n_imgs; b0 += 32) {
+    const int nb = n_imgs - b0 < 32 ? n_imgs - b0 : 32;
+    LabelImages li;
+    for (int i = 0; i < nb; ++i) {
+      li.img[i] = imgs[b0 + i]; li.h[i] = hs[b0 + i]; li.w[i] = ws[b0 + i];
+      if (li.h[i] < 0 || li.w[i] < 0 || li.h[i] > Hpad || li.w[i] > Wpad) return -1;
+    }
+    long long gx = ((long long)Hpad * (Wpad >> 4) + 255) / 256;
+    if (gx > 128) gx = 128;
+    const dim3 grid((unsigned)gx, nb);
+    if (is_int64)
+      hipLaunchKernelGGL(label_pad_kernel<long long>, grid, dim3(256), 0, (hipStream_t)stream, li, (uint8_t*)out, b0, Hpad, Wpad, pad);
+    else
+      hipLaunchKernelGGL(label_pad_kernel<uint8_t>, grid, dim3(256), 0, (hipStream_t)stream, li, (uint8_t*)out, b0, Hpad, Wpad, pad);
+    U2_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
 extern "C" int u2_stem_im2col(const void* img, int is_uint8, const float* mean, const float* stdv, void* col, int b, int h,
                               int w, int Hpad, int Wpad, int KP, void* stream) {
   // single image written to batch slot b: shift the column base instead of the batch index

@@ -170,10 +170,11 @@ class PaddedTargets:
 
 class BatchList(list):
     """list[Instances] whose images all hold the same number of boxes, plus the stacked tensors the per-image fields
-    are views of: ``boxes`` [B, S, 4], ``gt_classes`` [B, S] and ``gt_boxes`` [B, S, 4] (training).  Heads use the
+    are views of: ``boxes`` [B, S, 4], ``gt_classes`` [B, S] and ``gt_boxes`` [B, S, 4] (training; optionally ``logits`` / ``match``).  Heads use the
     stacked form (no per-image concatenation); everything else sees a plain list."""
 
     boxes = gt_classes = gt_boxes = None
+    logits = match = None   # objectness logits [B, S] and matched gt row [B, S] of the sampler (the row index its lazy gt_masks hold)
 
     @property
     def stacked(self):

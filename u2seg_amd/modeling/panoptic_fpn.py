@@ -145,9 +145,24 @@ class PanopticFPN(GeneralizedRCNN):
         """ImageList.from_tensors(gt_sem_seg, size_divisibility, ignore_value) (panoptic_fpn.py:118-126) as uint8."""
         ignore = self.sem_seg_head.ignore_value
         b = len(batched_inputs)
+        maps = [x["sem_seg"].to(self.device) for x in batched_inputs]
+        if maps[0].is_cuda and padded_hw[1] % 16 == 0 and all(m.dtype == maps[0].dtype for m in maps) \
+                and maps[0].dtype in (torch.int64, torch.uint8):
+            # one launch for the batch (u2_label_pad_batch): per image it was a conversion and a strided copy
+            import ctypes
+
+            from .. import _hip
+
+            maps = [m.contiguous() for m in maps]
+            out = torch.empty((b, padded_hw[0], padded_hw[1]), dtype=torch.uint8, device=self.device)
+            ptrs = (ctypes.c_void_p * b)(*[m.data_ptr() for m in maps])
+            hs = (ctypes.c_int * b)(*[m.shape[0] for m in maps])
+            ws = (ctypes.c_int * b)(*[m.shape[1] for m in maps])
+            _hip.call("u2_label_pad_batch", ptrs, hs, ws, b, int(maps[0].dtype == torch.int64), out, padded_hw[0], padded_hw[1],
+                      int(ignore))
+            return out
         out = torch.full((b, padded_hw[0], padded_hw[1]), ignore, dtype=torch.uint8, device=self.device)
-        for i, x in enumerate(batched_inputs):
-            t = x["sem_seg"].to(self.device)
+        for i, t in enumerate(maps):
             out[i, : t.shape[0], : t.shape[1]] = t.to(torch.uint8)
         return out
 

@@ -13,7 +13,7 @@ from torch import nn
 from ..config import configurable
 from ..layers import Conv2d, ConvTranspose2d, Linear, ShapeSpec, c2_msra_fill, c2_xavier_fill
 from ..layers import functional as F
-from ..structures import Boxes, Instances
+from ..structures import BitMasks, Boxes, Instances
 from ..utils.registry import Registry
 from .batched import BatchList, PaddedTargets, check_finite, device_constant, device_upload, image_index, proposals_from_list
 from .sampling import subsample_labels
@@ -291,7 +291,31 @@ def select_foreground_proposals(proposals, bg_label):
         fgm = (gc != -1) & (gc != bg_label)
         order = torch.argsort((~fgm).to(torch.int8), dim=1, stable=True)
         counts = fgm.sum(dim=1).tolist()
-        return [p[order[i, :c]] for i, (p, c) in enumerate(zip(proposals, counts))], list(fgm)
+        # the stacked columns are reordered for the whole batch at once and the per-image tables take views of them (indexing every
+        # column of every image was 80 launches per 16-image step); a column without a stacked form is indexed per image
+        o4 = order[..., None].expand(-1, -1, 4)
+        fast = {"proposal_boxes": torch.gather(proposals.boxes, 1, o4), "gt_classes": torch.gather(gc, 1, order)}
+        if proposals.gt_boxes is not None:
+            fast["gt_boxes"] = torch.gather(proposals.gt_boxes, 1, o4)
+        if proposals.logits is not None:
+            fast["objectness_logits"] = torch.gather(proposals.logits, 1, order)
+        g_match = torch.gather(proposals.match, 1, order) if proposals.match is not None else None
+        out = []
+        for i, (p, c) in enumerate(zip(proposals, counts)):
+            res = Instances(p.image_size)
+            rows = None
+            for name, col in p.get_fields().items():
+                if name in fast and len(col) == order.shape[1]:
+                    v = fast[name][i, :c]
+                    res.set(name, Boxes(v) if isinstance(col, Boxes) else v)
+                elif g_match is not None and isinstance(col, BitMasks) and col._index is not None \
+                        and col._index.data_ptr() == proposals.match[i].data_ptr() and col._index.numel() == order.shape[1]:
+                    res.set(name, BitMasks(col._base, g_match[i, :c]))  # the sampler's lazy row index, composed with the order
+                else:
+                    rows = order[i, :c] if rows is None else rows
+                    res.set(name, col[rows])
+            out.append(res)
+        return out, list(fgm)
     masks = [(p.gt_classes != -1) & (p.gt_classes != bg_label) for p in proposals]
     counts = torch.stack([m.sum() for m in masks]).tolist() if masks else []
     idx_all = torch.nonzero(torch.cat(masks), as_tuple=True)[0] if masks else None
@@ -448,6 +472,7 @@ class ROIHeads(nn.Module):
             out.append(res)
         if all(c == s for c in counts):
             out.boxes, out.gt_classes, out.gt_boxes = s_boxes, s_cls, s_gtb
+            out.logits, out.match = s_logits, s_match
         return out
 
 
