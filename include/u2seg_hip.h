@@ -63,7 +63,9 @@ typedef struct U2LayoutDesc {
   void* dst;            /* device pointer of the bf16 layout */
   int N, Cin, T, Cp, Npad, mode;
   int block_begin;      /* first work-group of this entry: prefix sum of blocks(entry) = mode 0: N * ceil(Cp/64);
-                           modes 1, 2 (need Cp == Cin): ceil(Npad/64) * ceil(Cin*T/64) */
+                           modes 1, 2 (need Cp == Cin): ceil(Npad/64) * ceil(Cin*T/64); mode 3 (this table only): dst is an
+                           fp32 vector of N elements = the source rounded through bf16 (a conv bias under autocast),
+                           ceil(N/4096) blocks; mode 0 with T == 1 and Cp == Cin: ceil(N*Cp/4096) */
   int reserved;
 } U2LayoutDesc;
 int u2_weight_layout_batched(const float* base, const U2LayoutDesc* table, int n_entries, int total_blocks, void* stream);

@@ -761,3 +761,29 @@ def test_select_foreground_proposals_stacked_equals_per_image_indexing():
         assert torch.equal(a.proposal_boxes.tensor, b_.proposal_boxes.tensor) and torch.equal(a.gt_boxes.tensor, b_.gt_boxes.tensor)
         assert torch.equal(a.gt_masks.tensor, b_.gt_masks.tensor)
     assert len(fg_s[1]) == 0 and len(fg_s[0]) > 0
+
+
+def test_rounded_conv_biases_follow_the_optimizer_step(F):
+    """The bf16-rounded fp32 copy of a conv bias (what the epilogue adds under autocast) is registered with FlatSGD's layout
+    table and rewritten by the one batched launch after every step (mode 3 of u2_weight_layout_batched): after a step it must
+    equal bias.bfloat16().float() of the NEW parameter values, and the conv must use it."""
+    from u2seg_amd.layers import Conv2d
+    from u2seg_amd.solver.build import FlatSGD
+
+    torch.manual_seed(0)
+    conv = Conv2d(32, 40, 1, bias=True).to(DEV)
+    torch.nn.init.normal_(conv.bias, std=1.0)
+    opt = FlatSGD(conv, lr=0.5, momentum=0.0)
+    x = torch.randn((2, 5, 7, 32), device=DEV).to(torch.bfloat16)
+    for it in range(3):
+        y = conv(x)
+        ref_bias = conv.bias.detach().bfloat16().float()
+        ent = conv.bias.__dict__["_u2_bias_rounded"]
+        assert torch.equal(ent[0], ref_bias), it
+        w = conv.weight.detach().bfloat16().float().view(40, 32)
+        ref = (x.float().view(-1, 32) @ w.t() + ref_bias).view(2, 5, 7, 40)
+        assert (y[..., :40].float() - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
+        y.float().square().mean().backward()
+        opt.step()
+        opt.zero_grad()
+    assert any(key[5] == 3 for _, key, _ in opt._layout_entries)

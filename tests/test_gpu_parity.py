@@ -590,9 +590,12 @@ def test_arena_direct_grads_and_cached_layouts(F):
     for p_, key, ent in opt._layout_entries:  # the batched LDS-tiled refresh == the per-tensor kernel, bit for bit
         n_, cin_, t_, cp_, npad_, mode_ = key
         modes.add(mode_)
+        if mode_ == 3:  # a conv bias as the epilogue adds it: fp32, rounded through bf16 (round 4: refreshed by the same launch)
+            assert torch.equal(ent[0], p_.detach().bfloat16().float()), key
+            continue
         fresh = F._weight_layout(p_.detach().reshape(n_, cin_, t_, 1), cp_, npad_, mode_)
         assert torch.equal(fresh.reshape(-1), ent[0].reshape(-1)), key
-    assert modes == {0, 1, 2}
+    assert modes >= {0, 1, 2}
     # in-place edits through torch invalidate the cached layouts (autograd version check)
     with torch.no_grad():
         arena.c1.weight.mul_(2.0)

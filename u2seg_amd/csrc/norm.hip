@@ -710,6 +710,7 @@ __global__ __launch_bounds__(256) void weight_layout_kernel(const float* __restr
 //              (T == 1 and Cp == Cin: ceil(N * Cp / 4096) blocks of a plain conversion)
 //   mode 1, 2: ceil(Npad / 64) * ceil(Cin*T / 64) blocks - block (64 n, 64 contiguous (c,t) columns): reads 64 rows of
 //              256 B, writes 64 output rows of 64 n (requires Cp == Cin: no all-zero output rows)
+//   mode 3:    ceil(N / 4096) blocks - N fp32 values rounded through bf16, written as fp32 (conv biases under autocast)
 __global__ __launch_bounds__(256) void weight_layout_batched_kernel(const float* __restrict__ base,
                                                                     const U2LayoutDesc* __restrict__ table, int n_entries) {
   __shared__ float tile[64 * 65];
@@ -725,7 +726,13 @@ __global__ __launch_bounds__(256) void weight_layout_batched_kernel(const float*
   const int N = d.N, Cin = d.Cin, T = d.T, Cp = d.Cp, Npad = d.Npad, mode = d.mode;
   const int lb = b - d.block_begin;
   const int tid = threadIdx.x;
-  if (mode == 0 && T == 1 && Cp == Cin) {
+  if (mode == 3) {
+    // a bias vector as the conv epilogue adds it: fp32 values rounded through bf16 (autocast casts the bias), N elements, fp32 out
+    float* __restrict__ outf = (float*)d.dst;
+    const size_t i0 = (size_t)lb * 4096;
+    for (int i = tid; i < 4096; i += 256)
+      if (i0 + i < (size_t)N) outf[i0 + i] = bf2f(f2bf(w[i0 + i]));
+  } else if (mode == 0 && T == 1 && Cp == Cin) {
     // 1x1 filters / linear layers without channel padding: the layout IS the source order - a plain conversion in blocks of
     // 4096 elements (the tiled path below would give every block 64 floats; these entries were most of the kernel's time)
     const size_t total = (size_t)N * Cp, i0 = (size_t)lb * 4096;

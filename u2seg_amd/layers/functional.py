@@ -378,15 +378,23 @@ class _Conv2dFn(Function):
 
 def _conv_bias(bias, round_bias):
     """The fp32 bias vector the conv epilogue adds (rounded through bf16 as autocast rounds it).  For a parameter owned by
-    solver.FlatSGD the rounded copy is kept until the optimizer's next step (two small cast launches per biased conv and pass
-    otherwise: 64 per training step)."""
+    solver.FlatSGD the rounded copy is kept and rewritten by the optimizer's batched layout launch after every step (two small
+    cast launches per biased conv and pass otherwise: 64 per training step)."""
     stamp = getattr(bias, "_u2_stamp", None)
     if stamp is None or not round_bias:
         return (bias.detach().bfloat16().float() if round_bias else bias.detach().float()).contiguous()
     ent = bias.__dict__.get("_u2_bias_rounded")
-    if ent is None or ent[1] != bias._version or ent[2] != stamp[0]:
-        ent = (bias.detach().bfloat16().float().contiguous(), bias._version, stamp[0])
+    if ent is None:
+        # registered with the optimizer's layout table (mode 3): rewritten with the weight layouts in the one launch after each
+        # step (it was two cast launches per biased conv and step: 40 small launches)
+        ent = [torch.empty(bias.shape, dtype=torch.float32, device=bias.device), -1, -1]
         bias.__dict__["_u2_bias_rounded"] = ent
+        reg = getattr(bias, "_u2_layout_register", None)
+        if reg is not None and bias.dim() == 1:
+            reg(bias, (bias.numel(), 1, 1, 1, 0, 3), ent)
+    if ent[1] != bias._version or ent[2] != stamp[0]:
+        ent[0].copy_(bias.detach().bfloat16().float())
+        ent[1], ent[2] = bias._version, stamp[0]
     return ent[0]
 
 

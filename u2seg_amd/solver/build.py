@@ -70,6 +70,7 @@ class FlatSGD:
             p._u2_stamp = self._stamp
             p._u2_layout_register = self._register_layout
             p.__dict__.pop("_u2_layouts", None)
+            p.__dict__.pop("_u2_bias_rounded", None)
 
     def offset_of(self, param):
         """Element offset of a parameter inside the flat arena."""
@@ -142,7 +143,9 @@ class FlatSGD:
                 assert 0 <= off < self.total * 4 and off % 4 == 0
                 desc[i] = (off // 4, ent[0].data_ptr()) + tuple(key) + (blocks, 0)
                 n_, cin_, t_, cp_, npad_, mode_ = key
-                if mode_ == 0 and t_ == 1 and cp_ == cin_:
+                if mode_ == 3:
+                    blocks += (n_ + 4095) // 4096             # a bias vector rounded through bf16, fp32 out
+                elif mode_ == 0 and t_ == 1 and cp_ == cin_:
                     blocks += (n_ * cp_ + 4095) // 4096  # plain conversion (u2_weight_layout_batched: the same rule)
                 elif mode_ == 0:
                     blocks += n_ * ((cp_ + 63) // 64)
