@@ -146,6 +146,9 @@ int u2_bilinear_up2_fwd(const void* x, const void* addend /*nullable, out = up2(
 int u2_bilinear_up2_bwd(const void* dout, void* dx, int B, int H, int W, int C, void* stream);
 int u2_stem_im2col(const void* img, int is_uint8, const float* mean, const float* stdv, void* col, int b, int h, int w,
                    int Hpad, int Wpad, int KP, void* stream);
+/* Gradient of p6 = p5[:, ::2, ::2, :] (LastLevelMaxPool, detectron2/modeling/backbone/fpn.py:188-200): g bf16 [B][ceil(H/2)][ceil(W/2)][C]
+ * -> dx bf16 [B][H][W][C] = g at even (y, x), zero elsewhere.  C % 8 == 0. */
+int u2_subsample2_bwd(const void* g, void* dx, int B, int H, int W, int C, void* stream);
 /* ImageList.from_tensors(gt_sem_seg, size_divisibility, ignore_value) (detectron2/structures/image_list.py:70-122 as called by
  * modeling/meta_arch/panoptic_fpn.py:118-126) for the label maps of a batch in one launch: out uint8 [n_imgs][Hpad][Wpad]
  * (16-byte aligned, Wpad % 16 == 0) = the image's labels (int64 if is_int64, else uint8; host arrays of device pointers / sizes,
@@ -168,10 +171,12 @@ int u2_scale_to_bf16(const float* acc, const float* num, const float* den, float
 int u2_softmax_ce(const void* logits, const void* labels, void* dlogits, float* loss_sum, int R, int NC, int LP,
                   float gscale, void* stream);
 /* (u2_mask_predict_bce: phased_side = 0: x / dx are [N][P][C] in pixel order; phased_side = S2 (P = S2 * S2): they are the
- * 2x2 / stride-2 deconvolution's unshuffled GEMM output [N][S2/2][S2/2][2][2][C], target / logit_out stay in pixel order.) */
+ * 2x2 / stride-2 deconvolution's unshuffled GEMM output [N][S2/2][S2/2][2][2][C], target / logit_out stay in pixel order.
+ * dx, dWp, dbp, loss_sum may each be NULL (not produced): the forward pass asks for the loss alone, the backward pass for the
+ * gradients with gmul = the loss's upstream gradient, a device scalar the gradient scale gscale is multiplied with.) */
 int u2_mask_predict_bce(const void* x, const float* Wp, const float* bp, const void* cls, const void* target, void* dx,
                         float* dWp, float* dbp, float* loss_sum, void* logit_out, int N, int P, int C, float gscale,
-                        int phased_side, void* stream);
+                        int phased_side, const float* gmul, void* stream);
 /* proposal_generator/rpn.py:366-429, one feature level.  dlt == NULL (and ddlt == NULL, A == 3): `obj` is the output of the
  * objectness and anchor-delta 1x1 convs run as ONE conv (columns 0-2 objectness, 3-14 deltas of an LPo-wide NHWC map) and dobj
  * receives both gradients in the same columns - the map their common input's gradient is then formed from by one data-gradient

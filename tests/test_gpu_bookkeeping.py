@@ -787,3 +787,20 @@ def test_rounded_conv_biases_follow_the_optimizer_step(F):
         opt.step()
         opt.zero_grad()
     assert any(key[5] == 3 for _, key, _ in opt._layout_entries)
+
+
+@pytest.mark.parametrize("shape", [(2, 25, 42, 256), (1, 8, 6, 32), (3, 1, 7, 64)])
+def test_subsample2_backward_kernel(shape):
+    """LastLevelMaxPool's stride-2 subsample (fpn.py:188-200): forward == x[:, ::2, ::2, :], backward (u2_subsample2_bwd) ==
+    autograd's gradient of that slice, bit for bit."""
+    from u2seg_amd.modeling.backbone import _Subsample2Fn
+
+    g = torch.Generator().manual_seed(shape[1])
+    x = torch.randn(shape, generator=g).to(torch.bfloat16).to(DEV).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    y, yr = _Subsample2Fn.apply(x), xr[:, ::2, ::2, :].contiguous()
+    assert torch.equal(y, yr)
+    gy = torch.randn(yr.shape, generator=g).to(torch.bfloat16).to(DEV)
+    y.backward(gy)
+    yr.backward(gy)
+    assert torch.equal(x.grad, xr.grad)

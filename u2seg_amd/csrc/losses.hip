@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256) void mask_predict_bce_kernel(const bf16_t* __r
                                                                const uint8_t* __restrict__ target, bf16_t* __restrict__ dx,
                                                                float* __restrict__ dWp, float* __restrict__ dbp,
                                                                float* __restrict__ loss_sum, bf16_t* __restrict__ logit_out,
-                                                               int P, int C, float gscale, int phased_side) {
+                                                               int P, int C, float gscale, int phased_side,
+                                                               const float* __restrict__ gmul) {
   __shared__ float red[4][260];
   const int n = blockIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(256) void mask_predict_bce_kernel(const bf16_t* __r
 #pragma unroll
   for (int e = 0; e < 4; ++e) wq[e] = bf2f(f2bf(Wp[(size_t)k * C + lane * 4 + e]));
   const float bias = bf2f(f2bf(bp[k]));
+  if (gmul) gscale *= *gmul;   // the upstream gradient of the loss (a device scalar): the backward launch
   float dw[4] = {0.f, 0.f, 0.f, 0.f};
   float db = 0.f, ls = 0.f;
   for (int p = wv; p < P; p += 4) {
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256) void mask_predict_bce_kernel(const bf16_t* __r
       ov[e] = f2bf(g * wq[e]);
       dw[e] += g * bf2f(xv[e]);
     }
-    *reinterpret_cast<uint2*>(dx + off) = *reinterpret_cast<const uint2*>(ov);
+    if (dx) *reinterpret_cast<uint2*>(dx + off) = *reinterpret_cast<const uint2*>(ov);
     db += g;
     if (logit_out && lane == 0) logit_out[(size_t)n * P + o] = f2bf(z);
   }
@@ -364,10 +366,10 @@ __global__ __launch_bounds__(256) void mask_predict_bce_kernel(const bf16_t* __r
   __syncthreads();
   const int t = threadIdx.x;
   const float s = red[0][t] + red[1][t] + red[2][t] + red[3][t];
-  atomicAdd(dWp + (size_t)k * C + t, s);
+  if (dWp) atomicAdd(dWp + (size_t)k * C + t, s);
   if (t == 0) {
-    atomicAdd(dbp + k, red[0][256] + red[1][256] + red[2][256] + red[3][256]);
-    atomicAdd(loss_sum, red[0][257] + red[1][257] + red[2][257] + red[3][257]);
+    if (dbp) atomicAdd(dbp + k, red[0][256] + red[1][256] + red[2][256] + red[3][256]);
+    if (loss_sum) atomicAdd(loss_sum, red[0][257] + red[1][257] + red[2][257] + red[3][257]);
   }
 }
 
@@ -519,12 +521,12 @@ extern "C" int u2_softmax_ce(const void* logits, const void* labels, void* dlogi
 
 extern "C" int u2_mask_predict_bce(const void* x, const float* Wp, const float* bp, const void* cls, const void* target,
                                    void* dx, float* dWp, float* dbp, float* loss_sum, void* logit_out, int N, int P,
-                                   int C, float gscale, int phased_side, void* stream) {
+                                   int C, float gscale, int phased_side, const float* gmul, void* stream) {
   if (C != 256 || (phased_side && ((phased_side & 1) || phased_side * phased_side != P))) return -1;
   if (N <= 0) return 0;
   hipLaunchKernelGGL(mask_predict_bce_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, Wp, bp,
                      (const long long*)cls, (const uint8_t*)target, (bf16_t*)dx, dWp, dbp, loss_sum, (bf16_t*)logit_out,
-                     P, C, gscale, phased_side);
+                     P, C, gscale, phased_side, gmul);
   U2_CHECK_LAUNCH();
   return 0;
 }

@@ -170,6 +170,29 @@ def build_resnet_backbone(cfg, input_shape):
     return ResNet(stem, stages, out_features=r.OUT_FEATURES, freeze_at=cfg.MODEL.BACKBONE.FREEZE_AT)
 
 
+class _Subsample2Fn(torch.autograd.Function):
+    """x[:, ::2, ::2, :] as a contiguous tensor; the gradient map is written by one kernel (u2_subsample2_bwd; autograd's own chain
+    for the two slices and the copy is two zero fills and two strided copies)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return x[:, ::2, ::2, :].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        b, h, w, c = ctx.shape
+        if g.is_cuda and g.dtype == torch.bfloat16 and c % 8 == 0:
+            from .. import _hip
+
+            dx = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
+            _hip.call("u2_subsample2_bwd", g.contiguous(), dx, b, h, w, c)
+            return dx
+        dx = g.new_zeros(ctx.shape)
+        dx[:, ::2, ::2, :] = g
+        return dx
+
+
 class LastLevelMaxPool(nn.Module):
     """p6 = max_pool2d(p5, kernel 1, stride 2) = a stride-2 subsample (fpn.py:188-200)."""
 
@@ -179,7 +202,7 @@ class LastLevelMaxPool(nn.Module):
         self.in_feature = "p5"
 
     def forward(self, x):
-        return [x[:, ::2, ::2, :].contiguous()]
+        return [_Subsample2Fn.apply(x) if x.requires_grad else x[:, ::2, ::2, :].contiguous()]
 
 
 class FPN(Backbone):
