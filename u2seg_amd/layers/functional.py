@@ -380,6 +380,13 @@ def _conv_bias(bias, round_bias):
     """The fp32 bias vector the conv epilogue adds (rounded through bf16 as autocast rounds it).  For a parameter owned by
     solver.FlatSGD the rounded copy is kept and rewritten by the optimizer's batched layout launch after every step (two small
     cast launches per biased conv and pass otherwise: 64 per training step)."""
+    step_cache = getattr(bias, "_u2_step_bias", None)
+    if step_cache is not None and round_bias:
+        # a derived bias that lives for one pass (the RPN's concatenated predictor bias, used on five levels): rounded once
+        v = step_cache.get("v")
+        if v is None:
+            v = step_cache["v"] = bias.detach().bfloat16().float().contiguous()
+        return v
     stamp = getattr(bias, "_u2_stamp", None)
     if stamp is None or not round_bias:
         return (bias.detach().bfloat16().float() if round_bias else bias.detach().float()).contiguous()

@@ -165,6 +165,7 @@ class StandardRPNHead(nn.Module):
         if torch.is_grad_enabled() and (wo.requires_grad or wd.requires_grad):
             w, b = torch.cat([wo, wd], 0), torch.cat([bo, bd], 0)
             w._u2_step_layouts = {}
+            b._u2_step_bias = {}
             return w, b
         stamp = getattr(wo, "_u2_stamp", None)
         key = (wo._version, wd._version, bo._version, bd._version, wo.data_ptr(), wd.data_ptr(), stamp[0] if stamp else None)
@@ -172,6 +173,7 @@ class StandardRPNHead(nn.Module):
         if cached is None or cached[0] != key:
             w, b = torch.cat([wo.detach(), wd.detach()], 0), torch.cat([bo.detach(), bd.detach()], 0)
             w._u2_step_layouts = {}
+            b._u2_step_bias = {}
             cached = self.__dict__["_fused_eval"] = (key, w, b)
         return cached[1], cached[2]
 
