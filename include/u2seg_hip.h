@@ -203,7 +203,8 @@ int u2_roi_align_bwd_gather(void* const* gfeats, const int* Hs, const int* Ws, c
 /* ROIs grouped by (image, level) for u2_roi_align_bwd_gather(_multi): order int32 [R] = ROI indices sorted by
  * key = image * nlevels + level with equal keys in index order (stable, = torch.argsort(key, stable=True)); seg int32
  * [num_images * nlevels + 1] = first position of every key, seg[last] = R.  rois [R][5] (image index first), level int32 [R].
- * num_images * nlevels <= 256, R <= 32768. */
+ * num_images * nlevels <= 256, R <= 32768 and 512 * (num_images * nlevels + 2) + 2 * R <= 156 KB (the sort runs in one
+ * work-group's LDS); -1 otherwise. */
 int u2_roi_group(const float* rois, const int* level, int* order, int* seg, int R, int num_images, int nlevels, void* stream);
 /* The same gather over up to four ROI sets at once (the cascade's three box poolers and the mask pooler share the FPN
  * maps): set i has its own rois / order / seg / dout, pooled size P[i] x P[i] and gradient scale.  Each level's gradient

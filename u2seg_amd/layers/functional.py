@@ -961,7 +961,7 @@ def _level_arrays(feats, scales):
 def _roi_group(rois, levels, b, nl):
     """ROIs grouped by (image, level) for the per-pixel gather: order int32 [R], segment offsets int32 [b*nl+1]."""
     r = rois.shape[0]
-    if b * nl <= 256 and r <= 32768 and levels.dtype == torch.int32:
+    if b * nl <= 256 and r <= 32768 and 512 * (b * nl + 2) + 2 * r <= 155648 and levels.dtype == torch.int32:
         order = torch.empty(r, dtype=torch.int32, device=rois.device)
         seg = torch.empty(b * nl + 1, dtype=torch.int32, device=rois.device)
         _hip.call("u2_roi_group", rois.contiguous(), levels.contiguous(), order, seg, r, b, nl)
