@@ -37,6 +37,10 @@ constexpr size_t NT_BYTES = 160u << 20;
 // measured no gain (serial step 74.4-75.6 ms either way, overlapped step 71.2 -> 71.8 ms: profiles/r03_stream_order.txt) -
 // the large tensors are already streamed with the nt hint.  U2_STREAM_ORDER: bit 0 forward apply passes, bit 1 backward
 // reductions, bit 2 backward apply passes run back to front.
+// element-wise passes whose tensors are each beyond the MALL (and read or written once): non-temporal accesses
+// (add_n of three 550 MB maps 463 -> 448 us, relu_bwd 332 -> 317 us; no difference at 137 MB)
+static bool ew_nt(size_t bytes_per_tensor) { return bytes_per_tensor > NT_BYTES; }
+
 static int stream_order() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("U2_STREAM_ORDER"); v = e ? atoi(e) & 7 : 0; }
@@ -236,15 +240,15 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const bf16_t* __res
 
 // dz = dout * (out > 0)
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
-                                                       bf16_t* __restrict__ dz, size_t n8) {
+                                                       bf16_t* __restrict__ dz, size_t n8, bool nt) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     bf16_t dv[8], ov[8];
-    *reinterpret_cast<uint4*>(dv) = reinterpret_cast<const uint4*>(dout)[i];
-    *reinterpret_cast<uint4*>(ov) = reinterpret_cast<const uint4*>(out)[i];
+    *reinterpret_cast<uint4*>(dv) = ld_stream(dout + i * 8, nt);
+    *reinterpret_cast<uint4*>(ov) = ld_stream(out + i * 8, nt);
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       if (!(bf2f(ov[e]) > 0.f)) dv[e] = 0;
-    reinterpret_cast<uint4*>(dz)[i] = *reinterpret_cast<const uint4*>(dv);
+    st_stream(dz + i * 8, *reinterpret_cast<const uint4*>(dv), nt);
   }
 }
 
@@ -252,13 +256,13 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const bf16_t* __restrict_
 // out = a + b (+ c) (+ d), summed in fp32 and rounded once: the gradients that reach a tensor with several consumers
 __global__ __launch_bounds__(256) void add_n_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
                                                     const bf16_t* __restrict__ c, const bf16_t* __restrict__ d,
-                                                    bf16_t* __restrict__ out, size_t n8) {
+                                                    bf16_t* __restrict__ out, size_t n8, bool nt) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     bf16_t av[8], bv[8], cv[8], dv[8];
-    *reinterpret_cast<uint4*>(av) = reinterpret_cast<const uint4*>(a)[i];
-    *reinterpret_cast<uint4*>(bv) = reinterpret_cast<const uint4*>(b)[i];
-    if (c) *reinterpret_cast<uint4*>(cv) = reinterpret_cast<const uint4*>(c)[i];
-    if (d) *reinterpret_cast<uint4*>(dv) = reinterpret_cast<const uint4*>(d)[i];
+    *reinterpret_cast<uint4*>(av) = ld_stream(a + i * 8, nt);
+    *reinterpret_cast<uint4*>(bv) = ld_stream(b + i * 8, nt);
+    if (c) *reinterpret_cast<uint4*>(cv) = ld_stream(c + i * 8, nt);
+    if (d) *reinterpret_cast<uint4*>(dv) = ld_stream(d + i * 8, nt);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float v = bf2f(av[e]) + bf2f(bv[e]);
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256) void add_n_kernel(const bf16_t* __restrict__ a
       if (d) v += bf2f(dv[e]);
       av[e] = f2bf(v);
     }
-    reinterpret_cast<uint4*>(out)[i] = *reinterpret_cast<const uint4*>(av);
+    st_stream(out + i * 8, *reinterpret_cast<const uint4*>(av), nt);
   }
 }
 
@@ -988,7 +992,7 @@ extern "C" int u2_relu_bwd(const void* dout, const void* out, void* dz, long lon
   if (numel == 0) return 0;
   const size_t n8 = (size_t)numel >> 3;
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
-                     (const bf16_t*)out, (bf16_t*)dz, n8);
+                     (const bf16_t*)out, (bf16_t*)dz, n8, ew_nt(n8 * 16));
   U2_CHECK_LAUNCH();
   return 0;
 }
@@ -998,7 +1002,7 @@ extern "C" int u2_add_n(const void* a, const void* b, const void* c, const void*
   if (numel == 0) return 0;
   const size_t n8 = (size_t)numel >> 3;
   hipLaunchKernelGGL(add_n_kernel, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b,
-                     (const bf16_t*)c, (const bf16_t*)d, (bf16_t*)out, n8);
+                     (const bf16_t*)c, (const bf16_t*)d, (bf16_t*)out, n8, ew_nt(n8 * 16));
   U2_CHECK_LAUNCH();
   return 0;
 }
