@@ -609,3 +609,44 @@ def test_paste_reach_rectangle_contains_every_pixel_the_exact_condition_accepts(
         idx = np.nonzero(m)[0]
         if idx.size:
             assert lo <= idx[0] and idx[-1] <= hi, (b0, b1, P, n, lo, hi, idx[0], idx[-1])
+
+
+def test_select_foreground_proposals_stacked_equals_per_image_on_cpu():
+    """The stacked (batched-gather) form of select_foreground_proposals is plain torch: the same check as the GPU test of
+    tests/test_gpu_bookkeeping.py on the CPU - tables equal to per-image indexing of every column (roi_heads.py:46-75), incl.
+    the sampler's lazy mask index and a column without a stacked form."""
+    from u2seg_amd.modeling.batched import BatchList
+    from u2seg_amd.modeling.roi_heads import select_foreground_proposals
+    from u2seg_amd.structures import BitMasks, Boxes, Instances
+
+    g = torch.Generator().manual_seed(4)
+    nb, s, k, ng = 4, 48, 7, 6
+    boxes, gtb = torch.rand((nb, s, 4), generator=g) * 100, torch.rand((nb, s, 4), generator=g) * 100
+    cls = torch.randint(0, k + 1, (nb, s), generator=g)
+    cls[0] = k
+    cls[3, :3] = -1
+    logits = torch.randn((nb, s), generator=g)
+    match = torch.randint(0, ng, (nb, s), generator=g)
+    bases = [torch.rand((ng, 9, 11), generator=g) > 0.5 for _ in range(nb)]
+    extra = torch.randn((nb, s, 2), generator=g)
+
+    def build(stacked):
+        out = BatchList()
+        for i in range(nb):
+            r = Instances((9, 11))
+            r.proposal_boxes, r.objectness_logits, r.gt_classes = Boxes(boxes[i]), logits[i], cls[i]
+            r.gt_boxes, r.gt_masks, r.gt_extra = Boxes(gtb[i]), BitMasks(bases[i])[match[i]], extra[i]
+            out.append(r)
+        if stacked:
+            out.boxes, out.gt_classes, out.gt_boxes, out.logits, out.match = boxes, cls, gtb, logits, match
+        return out
+
+    fg_s, m_s = select_foreground_proposals(build(True), k)
+    fg_l, m_l = select_foreground_proposals(build(False), k)
+    for a, b, ma, mb in zip(fg_s, fg_l, m_s, m_l):
+        assert torch.equal(ma, mb) and len(a) == len(b) and sorted(a.get_fields()) == sorted(b.get_fields())
+        for name in ("objectness_logits", "gt_classes", "gt_extra"):
+            assert torch.equal(a.get(name), b.get(name)), name
+        assert torch.equal(a.proposal_boxes.tensor, b.proposal_boxes.tensor) and torch.equal(a.gt_boxes.tensor, b.gt_boxes.tensor)
+        assert torch.equal(a.gt_masks.tensor, b.gt_masks.tensor)
+    assert len(fg_s[0]) == 0 and len(fg_s[1]) > 0
