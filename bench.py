@@ -273,6 +273,23 @@ def per_layer_report(timer, sampled):
                                                                      d[2] / (d[1] * 1e-3) / 1e12), file=sys.stderr)
 
 
+def _per_step_stats(marks, sampled):
+    """Per-step times of the timed region from the (host time, HIP event) mark in front of every step: the mean hides a single
+    allocation or host hiccup in a short region, the median and the minimum do not.  `device_ms` is the distance of the marks on
+    the main stream, `host_ms` the distance of the host clock at submission (equal when the step ends in a host read-back)."""
+    dev = [marks[i][1].elapsed_time(marks[i + 1][1]) for i in range(len(marks) - 1)]
+    host = [(marks[i + 1][0] - marks[i][0]) * 1e3 for i in range(len(marks) - 1)]
+
+    def stats(v):
+        w = sorted(v)
+        return {"median": w[len(w) // 2], "min": w[0], "max": w[-1], "mean": sum(w) / len(w)}
+
+    over = dev[: len(dev) - sampled] or dev
+    return {"device_ms": stats(dev), "host_ms": stats(host), "device_ms_overlapped_steps": stats(over),
+            "device_ms_each": [round(x, 2) for x in dev], "host_ms_each": [round(x, 2) for x in host],
+            "note": "the last %d step(s) run in one stream with HIP events around every conv launch (roofline sample)" % sampled}
+
+
 def cpu_baselines_parallel(workloads):
     """The oracle samples of several workloads at once, one child process each (32 threads each, GPUs hidden)."""
     import concurrent.futures as cf
@@ -363,8 +380,12 @@ def main():
         barrier()
         sampled = max(1, steps // 8)
 
+        marks = []
         t0 = time.time()
         for i in range(steps):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((time.time(), ev))
             # The last `sampled` steps carry the per-launch HIP events of the roofline object and run all their kernels in ONE
             # stream: in the normal step the semantic head and the weight gradients run on further streams, and a kernel that
             # shares the CUs with another one is timed into it (the conv family measures 25-35 % longer per launch while the
@@ -374,8 +395,12 @@ def main():
             timer.tag = "serial" if serial else "overlapped"
             Fn.set_stream_overlap(not serial and not args.serial)
             step_fn(warmup + i)
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
         barrier()
         dt = time.time() - t0
+        marks.append((t0 + dt, ev))
+        timed.per_step = _per_step_stats(marks, sampled)
         timer.enabled = False
         Fn.set_stream_overlap(True)
         if world > 1:
@@ -414,7 +439,7 @@ def main():
                     "config": {"workload": "u2seg_R50_800.yaml bf16, batch %d per GPU, %dx%d synthetic COCO-panoptic batches, "
                                            "random init, SGD+per-param clip" % (batch, args.height, args.width),
                                "global_batch": batch * world, "parallelism": "dp%d" % world},
-                    "final_total_loss": total})
+                    "final_total_loss": total, "per_step": timed.per_step})
         if rank == 0:
             out["roofline"] = conv_roofline(timer, sampled, steps, imgs_per_s / world)
             if args.per_layer:
@@ -451,7 +476,8 @@ def main():
                                            "post-processing (box NMS, pasted masks, semantic argmax, panoptic merge)"
                                            % (batch, args.height, args.width),
                                "global_batch": batch * world, "parallelism": "replicas%d" % world},
-                    "instances_image0": len(res["out"][0]["instances"]), "segments_image0": len(res["out"][0]["panoptic_seg"][1])})
+                    "instances_image0": len(res["out"][0]["instances"]), "segments_image0": len(res["out"][0]["panoptic_seg"][1]),
+                    "per_step": timed.per_step})
         if rank == 0:
             out["roofline"] = conv_roofline(timer, sampled, steps)
             if args.per_layer:
@@ -493,7 +519,7 @@ def main():
                     "config": {"workload": "Lloyd iterations (assign + update) over %d x %d synthetic embeddings (%s), K = %d, rows "
                                            "sharded over the GPUs" % (n_local * world, KMEANS_D, what, KMEANS_K),
                                "parallelism": "rows%d" % world},
-                    "finite_centroids": bool(torch.isfinite(state["c"]).all())})
+                    "finite_centroids": bool(torch.isfinite(state["c"]).all()), "per_step": timed.per_step})
         if rank == 0:
             ks = timer.summary()
             a = ks.get("u2_kmeans_assign")
@@ -520,9 +546,12 @@ def main():
     def release():
         import gc
 
+        from u2seg_amd.layers import functional as Fn
+
         gc.collect()
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
+        Fn.release_library_scratch()  # the conv library's own scratch (not visible to torch's allocator)
 
     out = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "vs_baseline": None, "data": "synthetic"}
     if args.workload == "train":
@@ -538,8 +567,8 @@ def main():
         # At N > 1 every rank takes part: k-means shards the rows (the M step all-reduces K*D + K partial sums), inference runs
         # as independent replicas; the barriers of timed() keep the ranks together.
         release()
-        for name, fn in (("kmeans", lambda: run_kmeans(10, 2, "mixture")), ("kmeans_randn", lambda: run_kmeans(10, 2, "randn")),
-                         ("infer", lambda: run_infer(5, 2))):
+        for name, fn in (("kmeans", lambda: run_kmeans(30, 5, "mixture")), ("kmeans_randn", lambda: run_kmeans(30, 5, "randn")),
+                         ("infer", lambda: run_infer(20, 5))):
             try:
                 extra[name] = dict({"n_gpus": world, "data": "synthetic"}, **fn())
             except Exception as e:  # an auxiliary workload must never take the headline line down with it

@@ -53,6 +53,13 @@ int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int B, int Hin,
  * environment variables U2_CONV_VARIANT / U2_WGRAD_VARIANT (same bits as the variant argument). */
 int u2_conv_last_kernel(void);
 
+/* The only device memory the library owns: the conv kernels' scratch (stream-K hand-over slots of u2_conv_igemm, partial tiles of
+ * u2_conv_wgrad), one block per (device, stream), allocated on first need at the size of that launch and grown on demand.  This
+ * call drains the streams concerned and frees every block (the next launch that needs one allocates again); returns the number
+ * of blocks freed.  The reference's ops (ATen conv behind layers/wrappers.py:127-134) take such workspaces from torch's caching
+ * allocator, where torch.cuda.empty_cache() releases them - this is the equivalent for a plain C ABI. */
+int u2_release_scratch(void);
+
 /* fp32 master weights [N][Cin][T] -> bf16 kernel layouts: mode 0 [N][T][Cp] (forward / wgrad), mode 1 [Cp][T][Npad] with the
  * taps reversed (data gradient), mode 2 [T][Cp][Npad] (data gradient of a fully connected conv). Zero padded. */
 int u2_weight_layout(const float* w, void* out, int N, int Cin, int T, int Cp, int Npad, int mode, void* stream);

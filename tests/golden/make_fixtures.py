@@ -1733,6 +1733,98 @@ def gen_checkpoint_files_fixture():
         len(sd), os.path.getsize(os.path.join(HERE, "checkpoint_small.pth")) / 1e6, len(zoo)))
 
 
+def gen_resume_fixture(hw=(192, 256), nimg=2, seed=9, steps=4, save_after=1):
+    """SURVEY 8(f) row 2, the --resume leg: a checkpoint written by the REFERENCE in the middle of a run, and how that run went
+    on.  The reference's PanopticFPN (u2seg_R50_800, widths reduced through its own config keys: the file stays at a few MB),
+    its build_optimizer (per-parameter clip around torch.optim.SGD) and its WarmupMultiStepLR take `steps` steps with the
+    compressed schedule of the trajectory fixture; after step `save_after` the state is saved in the nesting DefaultTrainer's
+    checkpointer writes (engine/defaults.py:389-394,499-506, engine/train_loop.py:195-208,423-430, engine/hooks.py:365-367:
+    the trainer itself is the checkpointable, PeriodicCheckpointer adds iteration=...):
+        {"model", "trainer": {"iteration", "hooks": {"LRScheduler": scheduler.state_dict()},
+                              "_trainer": {"iteration", "optimizer": optimizer.state_dict()}}, "iteration"}
+    - every value is a state_dict() of a reference object; the momentum buffers are non-trivial (two steps of history).
+      * checkpoint_resume.pth   - that file;
+      * resume_golden.json      - torch's parameter numbering -> parameter name (the grouping of reduce_param_groups), crc32 of every
+                                  momentum buffer and saved weight by name, lr / losses of every step, where the parameters ended
+                                  up after the last step."""
+    import_reference()
+    os.environ.setdefault("CLUSTER_NUM", "800")
+    from detectron2.config import get_cfg
+    from detectron2.modeling import build_model
+    from detectron2.solver import build_optimizer
+    from detectron2.solver.lr_scheduler import WarmupMultiStepLR
+    from detectron2.utils.events import EventStorage
+
+    from u2seg_amd.data import make_synthetic_batch
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(REF, "configs/COCO-PanopticSegmentation/u2seg_R50_800.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "MODEL.WEIGHTS", ""] + REDUCED_MODEL_OPTS + list(TRAJ_OVERRIDES))
+    model = build_model(cfg)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            v.copy_(det_fill(k, v))
+    model.train()
+    opt = build_optimizer(cfg, model)
+    sched = WarmupMultiStepLR(opt, list(cfg.SOLVER.STEPS), cfg.SOLVER.GAMMA, cfg.SOLVER.WARMUP_FACTOR,
+                              cfg.SOLVER.WARMUP_ITERS, cfg.SOLVER.WARMUP_METHOD)
+    names = {id(p): k for k, p in model.named_parameters()}
+    numbering, n = {}, 0
+    for g in opt.param_groups:
+        for p in g["params"]:
+            numbering[n] = names[id(p)]
+            n += 1
+    picked = ["backbone.bottom_up.stem.conv1.weight", "backbone.bottom_up.res4.5.conv3.norm.weight", "backbone.fpn_output2.weight",
+              "roi_heads.box_predictor.1.cls_score.weight", "roi_heads.mask_head.deconv.weight", "sem_seg_head.predictor.bias"]
+    torch.manual_seed(seed)
+    per_step, lrs, saved, at_save = [], [], None, None
+    with EventStorage() as storage:
+        for it in range(steps):
+            batch = to_ref_batch(make_synthetic_batch(nimg, height=hw[0], width=hw[1], start_index=it * nimg,
+                                                      num_thing_classes=cfg.MODEL.ROI_HEADS.NUM_CLASSES,
+                                                      num_stuff_classes=cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES))
+            losses = model(batch)
+            opt.zero_grad()
+            sum(losses.values()).backward()
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sched.step()
+            storage.step()
+            per_step.append({k: float(v) for k, v in losses.items()})
+            print("step", it, "lr", lrs[-1], "total", sum(per_step[-1].values()))
+            if it == save_after:
+                osd, ssd = opt.state_dict(), sched.state_dict()
+                saved = {"model": {k: v.clone() for k, v in model.state_dict().items()},
+                         "trainer": {"iteration": it, "hooks": {"LRScheduler": ssd},
+                                     "_trainer": {"iteration": it, "optimizer": {
+                                         "state": {i: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                                                   for i, st in osd["state"].items()},
+                                         "param_groups": osd["param_groups"]}}},
+                         "iteration": it}
+                torch.save(saved, os.path.join(HERE, "checkpoint_resume.pth"))
+                at_save = {k: dict(model.named_parameters())[k].detach().clone() for k in picked}
+                # the sampler draws of the following steps come from torch's global CPU stream: the state it has HERE
+                rng_after_save = torch.get_rng_state()
+    params = dict(model.named_parameters())
+    crc = lambda t: zlib.crc32(t.detach().contiguous().numpy().tobytes())
+    mom = {numbering[i]: crc(st["momentum_buffer"]) for i, st in saved["trainer"]["_trainer"]["optimizer"]["state"].items()}
+    out = {"opts": REDUCED_MODEL_OPTS + [list(x) if isinstance(x, tuple) else x for x in TRAJ_OVERRIDES], "image_hw": list(hw),
+           "num_images": nimg, "seed": seed, "steps": steps, "saved_iteration": save_after,
+           "num_thing_classes": cfg.MODEL.ROI_HEADS.NUM_CLASSES, "num_stuff_classes": cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES, "lr": lrs, "losses": per_step,
+           "numbering": {str(i): k for i, k in numbering.items()},
+           "group_sizes": [len(g["params"]) for g in opt.param_groups],
+           "group_weight_decay": [g["weight_decay"] for g in opt.param_groups],
+           "momentum_crc32": mom, "model_crc32": {k: crc(v) for k, v in saved["model"].items()},
+           "momentum_norm": {numbering[i]: float(st["momentum_buffer"].double().norm())
+                             for i, st in saved["trainer"]["_trainer"]["optimizer"]["state"].items() if numbering[i] in picked},
+           "rng_state_after_save_b64": __import__("base64").b64encode(rng_after_save.numpy().tobytes()).decode(),
+           "param_norm": {k: float(params[k].double().norm()) for k in picked},
+           "param_delta_norm_since_save": {k: float((params[k].detach() - at_save[k]).double().norm()) for k in picked},
+           "num_batches_tracked": int(dict(model.named_buffers())["backbone.bottom_up.stem.conv1.norm.num_batches_tracked"])}
+    json.dump(out, open(os.path.join(HERE, "resume_golden.json"), "w"), indent=0)
+    print("wrote checkpoint_resume.pth (%.2f MB) and resume_golden.json" % (os.path.getsize(os.path.join(HERE, "checkpoint_resume.pth")) / 1e6))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -1752,6 +1844,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.only == "checkpoint_files":
         gen_checkpoint_files_fixture()
+        sys.exit(0)
+    if a.only == "resume":
+        gen_resume_fixture()
         sys.exit(0)
     if a.only == "bf16_units":
         gen_bf16_units_fixture()

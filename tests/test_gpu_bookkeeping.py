@@ -355,9 +355,7 @@ def test_heads_teacher_forced_losses(F, hw):
     from oracle.model import OracleModel
     from tests.golden.make_fixtures import det_fill
     from u2seg_amd.config import get_cfg
-    from u2seg_amd.data import make_synthetic_batch
-    from u2seg_amd.modeling import build_model, sampling
-    from u2seg_amd.structures import Boxes, Instances
+    from u2seg_amd.modeling import build_model
 
     cfg = get_cfg()
     cfg.merge_from_file(CFG)
@@ -368,10 +366,26 @@ def test_heads_teacher_forced_losses(F, hw):
             v.copy_(det_fill(k, v.cpu()).to(DEV))
     model.train()
     om = OracleModel(cfg, {k: v.cpu() for k, v in model.state_dict().items()}, emulate_bf16=True)
+    report = teacher_forced_report(cfg, model, om, hw)
+    import json
+
+    print(json.dumps(report, indent=1))
+    assert len(report) == 10
+    for k, (got, exp) in report.items():
+        assert got == pytest.approx(exp, rel=1e-3), (k, report)
+
+
+def teacher_forced_report(cfg, model, om, hw, **synthetic_kw):
+    """The ten (HIP, oracle) loss pairs of test_heads_teacher_forced_losses for a given model / oracle pair; asserts the discrete
+    decisions (sampled anchors and ROIs, the labels of the three cascade stages) to be identical on the way."""
+    from u2seg_amd.data import make_synthetic_batch
+    from u2seg_amd.modeling import sampling
+    from u2seg_amd.structures import Boxes, Instances
+
     h, w = hw
     torch.set_num_threads(min(32, os.cpu_count() or 1))  # the fp32 oracle's small convolutions slow down beyond that
-    batch_cpu = make_synthetic_batch(2, height=h, width=w)
-    batch = make_synthetic_batch(2, height=h, width=w, device=DEV)
+    batch_cpu = make_synthetic_batch(2, height=h, width=w, **synthetic_kw)
+    batch = make_synthetic_batch(2, height=h, width=w, device=DEV, **synthetic_kw)
     gt_cpu, gt_dev = [x["instances"] for x in batch_cpu], [x["instances"] for x in batch]
 
     with torch.no_grad():
@@ -454,12 +468,123 @@ def test_heads_teacher_forced_losses(F, hw):
             report["loss_box_reg_stage%d" % k] = (float(dl["loss_box_reg_stage%d" % k]),
                                                   float(lb) * cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT)
         report["loss_mask"] = (float(dl["loss_mask"]), float(om.mask_loss(rf, sampled)))
-    import json
+    return report
 
+
+def test_reference_checkpoint_on_the_device_and_resume(F):
+    """SURVEY 8(f) row 2 on the device (checkpoint/detection_checkpoint.py:70-143, engine/defaults.py:410-421 resume_or_load):
+    tests/golden/checkpoint_resume.pth - written by the REFERENCE in the middle of a run (model, torch.optim.SGD state with two
+    steps of momentum, WarmupMultiStepLR state, iteration; make_fixtures.py --only resume) - is loaded through
+    DetectionCheckpointer(model, optimizer=FlatSGD, scheduler=...) into a model on cuda:0 whose kernel layouts are already
+    cached from a step on other weights.  Then
+      * the arena holds the file's weights and momentum bit for bit, and every cached bf16 kernel layout was REWRITTEN from them
+        (new stamp, the forward layouts compared element by element);
+      * with those weights the HIP heads reproduce the bf16 oracle's ten losses to 1e-3 (teacher-forced, all discrete decisions
+        identical) and the eval forward agrees with the oracle's semantic map;
+      * resumed at iteration + 1 the run goes on like the reference's own did: lr of every step exactly, dense losses within the
+        single-step bands of the trajectory test, the parameters' displacement since the checkpoint (half of which is the loaded
+        momentum) and num_batches_tracked."""
+    import base64
+    import json
+    import zlib
+
+    from oracle.model import OracleModel
+    from u2seg_amd.checkpoint import DetectionCheckpointer
+    from u2seg_amd.config import get_cfg
+    from u2seg_amd.data import make_synthetic_batch
+    from u2seg_amd.engine.trainer import SimpleTrainer
+    from u2seg_amd.modeling import build_model, set_permutation_source
+    from u2seg_amd.solver import build_lr_scheduler, build_optimizer
+
+    gdir = os.path.join(ROOT, "tests", "golden")
+    fx = json.load(open(os.path.join(gdir, "resume_golden.json")))
+    path = os.path.join(gdir, "checkpoint_resume.pth")
+    cfg = get_cfg()
+    cfg.merge_from_file(CFG)
+    cfg.merge_from_list(["MODEL.DEVICE", DEV] + fx["opts"])
+    kw = dict(num_thing_classes=fx["num_thing_classes"], num_stuff_classes=fx["num_stuff_classes"])
+    n, (h, w) = fx["num_images"], fx["image_hw"]
+    torch.manual_seed(77)
+    model = build_model(cfg)
+    model.train()
+    opt = build_optimizer(cfg, model)
+    sched = build_lr_scheduler(cfg, opt)
+    trainer = SimpleTrainer(model, opt, sched)
+    trainer.run_step(make_synthetic_batch(n, height=h, width=w, start_index=40, device=DEV, **kw))  # caches every layout
+    ents = list(opt._layout_entries)
+    assert len(ents) > 100
+    stamp0 = opt._stamp[0]
+    ck = DetectionCheckpointer(model, optimizer=opt, scheduler=sched)
+    rest = ck.load(path)
+    assert rest["iteration"] == fx["saved_iteration"] and not ck.last_incompatible.missing_keys
+    crc = lambda t: zlib.crc32(t.detach().contiguous().cpu().numpy().tobytes())
+    assert {k: crc(v) for k, v in model.state_dict().items()} == fx["model_crc32"]
+    names = {id(p): k for k, p in model.named_parameters()}
+    assert {names[id(p)]: crc(opt.flat_mom[off : off + p.numel()]) for p, off in zip(opt.params, opt.param_offset)} == fx["momentum_crc32"]
+    assert opt._stamp[0] > stamp0
+    checked = 0
+    for p, key, ent in ents:
+        assert ent[2] == opt._stamp[0] and ent[1] == p._version
+        nn_, cin, t, cp, npad, mode = key
+        if mode == 0:  # forward layout [N][taps][cp] bf16, channels zero padded
+            want = torch.zeros((nn_, t, cp), dtype=torch.bfloat16, device=DEV)
+            want[:, :, :cin] = p.detach().reshape(nn_, cin, t).permute(0, 2, 1).bfloat16()
+            assert torch.equal(ent[0].reshape(nn_, t, cp), want), names[id(p)]
+            checked += 1
+    assert checked > 60
+    nxt = fx["saved_iteration"] + 1
+    assert opt.lr == fx["lr"][nxt] and sched.last_iter == nxt
+
+    # the loaded model against the oracle built from the same file
+    sd_cpu = {k: v.cpu() for k, v in model.state_dict().items()}
+    om = OracleModel(cfg, sd_cpu, emulate_bf16=True)
+    report = teacher_forced_report(cfg, model, om, (h, w), **kw)
     print(json.dumps(report, indent=1))
-    assert len(report) == 10
     for k, (got, exp) in report.items():
         assert got == pytest.approx(exp, rel=1e-3), (k, report)
+    model.eval()
+    strip = lambda b: [{k: v for k, v in x.items() if k != "instances"} for x in b]
+    with torch.no_grad():
+        out = model(strip(make_synthetic_batch(n, height=h, width=w, device=DEV, **kw)))
+    om.training = False
+    ref = om.inference(strip(make_synthetic_batch(n, height=h, width=w, **kw)))
+    om.training = True
+    for o, r in zip(out, ref):
+        assert o["sem_seg"].shape == r["sem_seg"].shape == (fx["num_stuff_classes"], h, w)
+        agree = float((o["sem_seg"].argmax(0).cpu() == r["sem_seg"].argmax(0)).float().mean())
+        assert agree > 0.97, agree
+        assert len(o["instances"]) <= cfg.TEST.DETECTIONS_PER_IMAGE and o["panoptic_seg"][0].shape == (h, w)
+    model.train()
+
+    # --resume: load once more (the passes above updated the BN running statistics) and continue the reference's run
+    ck.load(path)
+    trainer.iter = nxt
+    at_save = {k: dict(model.named_parameters())[k].detach().clone() for k in fx["param_norm"]}
+    set_permutation_source(lambda m, device=None: torch.randperm(m))
+    torch.set_rng_state(torch.frombuffer(bytearray(base64.b64decode(fx["rng_state_after_save_b64"])), dtype=torch.uint8).clone())
+    rows = []
+    try:
+        for it in range(nxt, fx["steps"]):
+            assert opt.lr == pytest.approx(fx["lr"][it], rel=1e-12), it
+            losses = trainer.run_step(make_synthetic_batch(n, height=h, width=w, start_index=it * n, device=DEV, **kw))
+            rows.append({k: (float(v.detach()), fx["losses"][it][k]) for k, v in losses.items()})
+    finally:
+        set_permutation_source(None)
+    print(json.dumps(rows, indent=1))
+    for i, row in enumerate(rows):  # bands of test_sgd_trajectory_vs_reference: first resumed step = a step on the reference's parameters
+        band, total_band = ((4e-2, 2e-2), (6e-2, 3e-2))[min(i, 1)]
+        for k in ("loss_sem_seg", "loss_rpn_cls", "loss_cls_stage0", "loss_cls_stage1", "loss_cls_stage2", "loss_mask"):
+            assert row[k][0] == pytest.approx(row[k][1], rel=band), (i, k, row)
+        assert sum(v[0] for v in row.values()) == pytest.approx(sum(v[1] for v in row.values()), rel=total_band), (i, row)
+    params = dict(model.named_parameters())
+    disp = {}
+    for k in fx["param_norm"]:
+        assert float(params[k].double().norm()) == pytest.approx(fx["param_norm"][k], rel=1e-3), k
+        disp[k] = (float((params[k].detach() - at_save[k]).double().norm()), fx["param_delta_norm_since_save"][k])
+    print(json.dumps(disp, indent=1))
+    for k, (got, want) in disp.items():
+        assert got == pytest.approx(want, rel=0.25), (k, disp)
+    assert int(model.state_dict()["backbone.bottom_up.stem.conv1.norm.num_batches_tracked"]) == fx["num_batches_tracked"]
 
 
 def test_inference_tails_full_size_800x1333(F):

@@ -1223,11 +1223,38 @@ def test_inference_tails_vs_oracle_and_reference(F, G):
             assert torch.equal(det.pred_boxes.tensor.cpu(), rb)
 
 
-def _two_rank_worker(rank, world, port, out):
+def _rank_device(rank, backend):
+    """Two ranks share cuda:0 over gloo (RCCL refuses two ranks on one device); over RCCL ("nccl") every rank owns a GPU."""
+    idx = rank if backend == "nccl" else 0
+    torch.cuda.set_device(idx)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return "cuda:%d" % idx
+
+
+def _spawn_two(worker, backend="gloo"):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(worker, args=(2, port, out, backend), nprocs=2, join=True)
+        return out[0], out[1]
+
+
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank; this box has one")
+
+
+def _two_rank_worker(rank, world, port, out, backend="gloo"):
     import torch.distributed as dist
 
+    DEV = _rank_device(rank, backend)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from tests.golden.make_fixtures import det_fill
     from u2seg_amd.config import get_cfg
     from u2seg_amd.data import make_synthetic_batch
@@ -1235,7 +1262,6 @@ def _two_rank_worker(rank, world, port, out):
     from u2seg_amd.modeling import build_model
     from u2seg_amd.solver import build_optimizer
 
-    torch.cuda.set_device(0)
     cfg = get_cfg()
     cfg.merge_from_file(CFG)
     cfg.merge_from_list(["MODEL.DEVICE", DEV])
@@ -1257,14 +1283,14 @@ def _two_rank_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def _kmeans_shard_worker(rank, world, port, out):
+def _kmeans_shard_worker(rank, world, port, out, backend="gloo"):
     import torch.distributed as dist
 
+    DEV = _rank_device(rank, backend)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from u2seg_amd.cluster import kmeans as KM
 
-    torch.cuda.set_device(0)
     g = np.load(os.path.join(ROOT, "tests", "golden", "kmeans_golden.npz"))
     x, init = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["init"]).to(DEV)
     n = x.shape[0]
@@ -1295,14 +1321,14 @@ def test_kmeans_row_sharded_two_ranks():
     assert np.array_equal(c0, c1)  # identical on both ranks
 
 
-def _syncbn_ragged_worker(rank, world, port, out):
+def _syncbn_ragged_worker(rank, world, port, out, backend="gloo"):
     import torch.distributed as dist
 
+    DEV = _rank_device(rank, backend)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from u2seg_amd.layers import functional as F
 
-    torch.cuda.set_device(0)
     g = torch.Generator().manual_seed(50 + rank)
     c = 64
     shape = (2, c, 11, 13) if rank == 0 else (3, c, 17, 9)  # different element counts per rank (286 vs 459)
@@ -1310,12 +1336,12 @@ def _syncbn_ragged_worker(rank, world, port, out):
     gy = bf(torch.randn(shape, generator=g))
     gg = torch.Generator().manual_seed(7)  # the parameters are replicated
     gamma, beta = 1 + 0.2 * torch.randn(c, generator=gg), 0.1 * torch.randn(c, generator=gg)
-    xd = nhwc(x).requires_grad_(True)
+    xd = nhwc(x).to(DEV).requires_grad_(True)
     gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
     rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
     stats = torch.stack([x.sum((0, 2, 3)), (x * x).sum((0, 2, 3))]).to(DEV)
     y = F.batch_norm_act(xd, stats, gd, bd, rm, rv, None, True, 0.1, 1e-5, sync=True)
-    y.backward(nhwc(gy))
+    y.backward(nhwc(gy).to(DEV))
     torch.cuda.synchronize()
     out[rank] = {"x": x, "gy": gy, "y": nchw(y.detach()), "dx": nchw(xd.grad), "dgamma": gd.grad.cpu(), "dbeta": bd.grad.cpu(),
                  "rm": rm.cpu(), "rv": rv.cpu()}
@@ -1383,6 +1409,43 @@ def test_two_rank_step_on_one_gpu():
         (t0, s0), (t1, s1) = out[0], out[1]
     assert t0 == t0 and t1 == t1
     assert s0[0] == s0[1] == s1[0] == s1[1], (s0, s1)  # identical parameter arena and running stats on both ranks
+
+
+# ---- the same three exchanges over RCCL (backend "nccl"), one GPU per rank: run wherever two GPUs are visible --------------
+@needs_two_gpus
+def test_two_rank_step_over_rccl():
+    """engine/defaults.py:60-79 (DDP) + layers/batch_norm.py:187 (SyncBN) over the backend the product uses on a node: 122 SyncBN
+    statistic all-reduces inside forward / backward, the head-tail gradient all-reduce started from the autograd hook, the
+    bucketed rest, grad_scale = 1 / world.  Both ranks must hold bit-identical parameters and running statistics afterwards, and
+    the step must equal the gloo run of the same two ranks to 1e-6 relative in those sums (a two-rank sum is order-free; what
+    differs from run to run is the order of the split-K gradient atomics inside a rank)."""
+    (t0, s0), (t1, s1) = _spawn_two(_two_rank_worker, "nccl")
+    assert t0 == t0 and t1 == t1
+    assert s0[0] == s0[1] == s1[0] == s1[1], (s0, s1)
+    (g0, gs0), _ = _spawn_two(_two_rank_worker, "gloo")
+    assert t0 == pytest.approx(g0, rel=1e-3)
+    np.testing.assert_allclose(np.array(s0[0]), np.array(gs0[0]), rtol=1e-6)
+
+
+@needs_two_gpus
+def test_syncbn_unequal_counts_over_rccl():
+    """The SyncBN exchange with different element counts per rank over RCCL: every output bit-identical to the gloo run (the
+    kernels are deterministic and a two-rank sum has one order)."""
+    a, b = _spawn_two(_syncbn_ragged_worker, "nccl"), _spawn_two(_syncbn_ragged_worker, "gloo")
+    for ra, rb in zip(a, b):
+        for k in ("y", "dx", "dgamma", "dbeta", "rm", "rv"):
+            assert torch.equal(ra[k], rb[k]), k
+
+
+@needs_two_gpus
+def test_kmeans_row_sharded_over_rccl():
+    """Row-sharded k-means (one all-reduce of K * D + K partial sums per iteration) over RCCL: the golden labels, centroids
+    bit-identical on both ranks and to the gloo run."""
+    (l0, c0), (l1, c1) = _spawn_two(_kmeans_shard_worker, "nccl")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "kmeans_golden.npz"))
+    assert np.array_equal(np.concatenate([l0, l1]), g["labels"]) and np.array_equal(c0, c1)
+    (_, cg), _ = _spawn_two(_kmeans_shard_worker, "gloo")
+    assert np.array_equal(c0, cg)
 
 
 def test_edge_cases_empty_and_ragged_batches(F):

@@ -364,6 +364,92 @@ def test_reference_checkpoint_files_load_through_the_loader():
     assert sorted(k for k in ck.last_incompatible.missing_keys) == sorted(untouched)
 
 
+def test_reference_optimizer_and_scheduler_state_round_trip(tmp_path):
+    """SURVEY 8(f) row 2, --resume: tests/golden/checkpoint_resume.pth was written by the REFERENCE after two steps of a run
+    (make_fixtures.py --only resume: its model, its clip-wrapped torch.optim.SGD, its WarmupMultiStepLR, in the nesting its
+    DefaultTrainer writes: checkpoint/detection_checkpoint.py:70-143, engine/defaults.py:389-421,499-506).  Through
+    DetectionCheckpointer(model, optimizer=FlatSGD, scheduler=...):
+      * FlatSGD forms the reference's parameter groups (reduce_param_groups, solver/build.py:255-279) and torch's numbering;
+      * every weight and every momentum buffer arrives bit-identical under its parameter's NAME, lr / iteration / schedule
+        position are the file's;
+      * FlatSGD.state_dict() is the dict torch.optim.SGD wrote (same group entries, same tensors) and a real torch.optim.SGD
+        over the same grouping loads it; a file written by this package's checkpointer carries the reference's nesting too and
+        reads back into a fresh optimizer unchanged."""
+    from u2seg_amd.checkpoint import DetectionCheckpointer
+    from u2seg_amd.modeling import build_model
+    from u2seg_amd.solver import build_lr_scheduler, build_optimizer
+
+    gdir = os.path.join(ROOT, "tests", "golden")
+    fx = json.load(open(os.path.join(gdir, "resume_golden.json")))
+    path = os.path.join(gdir, "checkpoint_resume.pth")
+    crc = lambda t: zlib.crc32(t.detach().contiguous().cpu().numpy().tobytes())
+
+    def fresh(seed):
+        torch.manual_seed(seed)
+        cfg = _cfg(opts=fx["opts"])
+        model = build_model(cfg)
+        opt = build_optimizer(cfg, model)
+        return cfg, model, opt, build_lr_scheduler(cfg, opt)
+
+    cfg, model, opt, sched = fresh(5)
+    names = {id(p): k for k, p in model.named_parameters()}
+    assert [len(m) for m in opt.group_members] == fx["group_sizes"] and opt.group_wd == fx["group_weight_decay"]
+    numbering = [names[id(opt.params[i])] for members in opt.group_members for i in members]
+    assert numbering == [fx["numbering"][str(i)] for i in range(len(numbering))]
+
+    ck = DetectionCheckpointer(model, optimizer=opt, scheduler=sched)
+    rest = ck.load(path)
+    assert rest["iteration"] == fx["saved_iteration"] and "optimizer" not in rest and "scheduler" not in rest
+    assert not ck.last_incompatible.missing_keys and not ck.last_incompatible.unexpected_keys
+    assert {k: crc(v) for k, v in model.state_dict().items()} == fx["model_crc32"]
+    mom = {names[id(p)]: crc(opt.flat_mom[off : off + p.numel()]) for p, off in zip(opt.params, opt.param_offset)}
+    assert mom == fx["momentum_crc32"]
+    nxt = fx["saved_iteration"] + 1
+    assert opt.lr == fx["lr"][nxt] and sched.last_iter == nxt and sched.get_lr(nxt) == pytest.approx(fx["lr"][nxt], rel=1e-12)
+    # parameters still alias the arena after load_state_dict (the kernels and the optimizer must see the loaded values)
+    assert all(p.data_ptr() == opt.flat_param.data_ptr() + 4 * off for p, off in zip(opt.params, opt.param_offset))
+
+    ref = torch.load(path, weights_only=False, map_location="cpu")["trainer"]
+    ref_opt, ref_sched = ref["_trainer"]["optimizer"], ref["hooks"]["LRScheduler"]
+    mine = opt.state_dict()
+    assert len(mine["param_groups"]) == len(ref_opt["param_groups"])
+    for a, b in zip(mine["param_groups"], ref_opt["param_groups"]):
+        assert a == b, (a, b)
+    assert sorted(mine["state"]) == sorted(ref_opt["state"])
+    assert all(torch.equal(mine["state"][i]["momentum_buffer"], ref_opt["state"][i]["momentum_buffer"]) for i in mine["state"])
+    ssd = sched.state_dict()
+    assert ssd["last_epoch"] == ref_sched["last_epoch"] and ssd["base_lrs"] == ref_sched["base_lrs"]
+    # torch's own optimizer accepts what FlatSGD wrote
+    clones = [torch.nn.Parameter(p.detach().clone()) for p in opt.params]
+    tsgd = torch.optim.SGD([{"params": [clones[i] for i in members], "weight_decay": wd}
+                            for wd, members in zip(opt.group_wd, opt.group_members)], lr=1.0, momentum=0.5)
+    tsgd.load_state_dict(mine)
+    assert tsgd.param_groups[0]["lr"] == opt.lr and tsgd.param_groups[0]["momentum"] == 0.9
+    assert all(torch.equal(tsgd.state[clones[i]]["momentum_buffer"].reshape(-1), opt.flat_mom[off : off + clones[i].numel()])
+               for i, off in enumerate(opt.param_offset))
+
+    # written by this package, read by this package: same state; the file has the reference's nesting as well
+    out = DetectionCheckpointer(model, str(tmp_path), optimizer=opt, scheduler=sched).save("model_0000001", iteration=1)
+    back = torch.load(out, weights_only=False, map_location="cpu")
+    assert back["trainer"]["iteration"] == 1 and back["trainer"]["hooks"]["LRScheduler"]["last_epoch"] == nxt
+    assert back["trainer"]["_trainer"]["optimizer"]["param_groups"] == mine["param_groups"]
+    cfg2, model2, opt2, sched2 = fresh(6)
+    ck2 = DetectionCheckpointer(model2, str(tmp_path), optimizer=opt2, scheduler=sched2)
+    assert ck2.has_checkpoint()
+    rest2 = ck2.resume_or_load("", resume=True)
+    assert rest2["iteration"] == 1 and torch.equal(opt2.flat_mom, opt.flat_mom) and torch.equal(opt2.flat_param, opt.flat_param)
+    assert opt2.lr == opt.lr and sched2.last_iter == nxt
+    # a plain_train_net.py-style file (top-level "optimizer" / "scheduler") loads the same way; weights only without --resume
+    torch.save({"model": back["model"], "optimizer": ref_opt, "scheduler": ref_sched, "iteration": 1}, str(tmp_path / "plain.pth"))
+    cfg3, model3, opt3, sched3 = fresh(7)
+    DetectionCheckpointer(model3, optimizer=opt3, scheduler=sched3).load(str(tmp_path / "plain.pth"))
+    assert torch.equal(opt3.flat_mom, opt.flat_mom) and opt3.lr == opt.lr and sched3.last_iter == nxt
+    cfg4, model4, opt4, sched4 = fresh(8)
+    rest4 = DetectionCheckpointer(model4, optimizer=opt4, scheduler=sched4).resume_or_load(path, resume=False)
+    assert torch.equal(opt4.flat_param, opt.flat_param) and float(opt4.flat_mom.abs().sum()) == 0.0 and sched4.last_iter == 0
+    assert "optimizer" in rest4 and rest4["iteration"] == fx["saved_iteration"]
+
+
 def test_resolved_configs_equal_reference():
     """Every key this package's config tree holds has the value the reference resolves for the same yaml (its defaults.py +
     _BASE_ chain; fixture: tests/golden/make_fixtures.py --only config), for the four U2Seg train / eval configs - both

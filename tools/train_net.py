@@ -98,11 +98,12 @@ def main(args):
     opt = build_optimizer(cfg, model)
     sched = build_lr_scheduler(cfg, opt)
     trainer = SimpleTrainer(model, opt, sched)
-    checkpointer = DetectionCheckpointer(model, cfg.OUTPUT_DIR, save_to_disk=rank == 0, optimizer=opt)
+    checkpointer = DetectionCheckpointer(model, cfg.OUTPUT_DIR, save_to_disk=rank == 0, optimizer=opt, scheduler=sched)
     start_iter = 0
     if (cfg.MODEL.WEIGHTS and os.path.isfile(cfg.MODEL.WEIGHTS)) or args.resume:
         rest = checkpointer.resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume)
-        start_iter = int(rest.get("iteration", -1)) + 1 if args.resume else 0
+        # engine/defaults.py:410-421: only a run that found its own last_checkpoint continues at iteration + 1
+        start_iter = int(rest.get("iteration", -1)) + 1 if args.resume and checkpointer.has_checkpoint() else 0
         sched.resume_at(start_iter)  # lr of iteration start_iter, milestones counted from iteration 0
     elif cfg.MODEL.WEIGHTS and rank == 0:
         print("MODEL.WEIGHTS %s not found: random initialisation" % cfg.MODEL.WEIGHTS)

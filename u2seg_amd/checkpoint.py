@@ -102,6 +102,7 @@ class DetectionCheckpointer:
         if incompatible.unexpected_keys:
             logger.warning("The checkpoint state_dict contains keys that are not used by the model: %s", incompatible.unexpected_keys)
         self.last_incompatible = incompatible
+        self._unnest_trainer_state(checkpoint)
         for key in self.checkpointables if checkpointables is None else checkpointables:
             if key in checkpoint:
                 self.checkpointables[key].load_state_dict(checkpoint.pop(key))
@@ -109,6 +110,29 @@ class DetectionCheckpointer:
         if opt is not None and hasattr(opt, "refresh_layouts"):
             opt.refresh_layouts()  # the weights changed: rewrite the cached kernel layouts
         return checkpoint
+
+    @staticmethod
+    def _unnest_trainer_state(checkpoint):
+        """The reference's DefaultTrainer registers ITSELF as the one checkpointable besides the model (engine/defaults.py:389-394):
+        its files hold {"model", "trainer": {"iteration", "hooks": {"LRScheduler": <scheduler state>}, "_trainer": {"iteration",
+        "optimizer": <torch.optim.SGD state>, ["grad_scaler"]}}, "iteration"} (engine/train_loop.py:195-208,423-430,523-530,
+        engine/defaults.py:499-506, engine/hooks.py:365-367), while plain_train_net.py-style files carry "optimizer" /
+        "scheduler" at the top level.  Both forms end up as top-level "optimizer" / "scheduler" / "iteration" entries here."""
+        tr = checkpoint.get("trainer")
+        if not isinstance(tr, dict):
+            return
+        inner = tr.get("_trainer", {})
+        if "optimizer" in inner:
+            checkpoint.setdefault("optimizer", inner["optimizer"])
+        sched = tr.get("hooks", {}).get("LRScheduler")
+        if sched is not None:
+            checkpoint.setdefault("scheduler", sched)
+        if "iteration" in tr:
+            checkpoint.setdefault("iteration", tr["iteration"])
+
+    def has_checkpoint(self):
+        """fvcore Checkpointer.has_checkpoint: a `last_checkpoint` file exists in the save directory."""
+        return bool(self.save_dir) and os.path.exists(os.path.join(self.save_dir, "last_checkpoint"))
 
     def resume_or_load(self, path, *, resume=True):
         last = os.path.join(self.save_dir, "last_checkpoint")
@@ -126,6 +150,13 @@ class DetectionCheckpointer:
         for key, obj in self.checkpointables.items():
             data[key] = obj.state_dict()
         data.update(kwargs)
+        if "optimizer" in data and "iteration" in data and "trainer" not in data:
+            # the same state once more in the nesting a reference DefaultTrainer reads back with --resume (see
+            # _unnest_trainer_state; the tensors are shared with the top-level entries, torch.save stores them once)
+            tr = {"iteration": data["iteration"], "_trainer": {"iteration": data["iteration"], "optimizer": data["optimizer"]}}
+            if "scheduler" in data:
+                tr["hooks"] = {"LRScheduler": data["scheduler"]}
+            data["trainer"] = tr
         basename = "{}.pth".format(name)
         os.makedirs(self.save_dir, exist_ok=True)
         save_file = os.path.join(self.save_dir, basename)

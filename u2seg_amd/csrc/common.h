@@ -8,6 +8,19 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// hipFuncSetAttribute (dynamic LDS above 64 KB) applies to the CURRENT device's copy of a kernel: remember it per device, not per
+// process - a process may drive several GPUs.  `static PerDeviceOnce once; if (once.first()) { ...set... }`
+struct PerDeviceOnce {
+  bool done[64] = {};
+  bool first() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;  // unknown device: set the attribute again (cheap)
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
+
 #define U2_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define U2_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 

@@ -70,4 +70,11 @@ int launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* dw, long long dw
                       int c_valid, const bf16_t* zero, int B, int H, int W, int C, int x_ld, int N, int dy_ld, int rounds,
                       int force, hipStream_t s);
 
+// Library-owned device scratch (conv_igemm.hip), one block per (device, stream, kind): the kernels of a stream run one after
+// the other, so consecutive launches share it.  Sized to the largest launch seen so far - allocated on first need, grown on
+// demand (the stream is drained before the old block is freed), never above `limit_bytes` (nullptr: the caller takes its
+// scratch-free path) - and released by u2_release_scratch().  kind 0: stream-K hand-over slots, 1: stream-K flags (zero on
+// allocation; their consumers leave them at zero), 2: weight-gradient partial tiles.
+void* scratch_get(int kind, hipStream_t s, size_t need_bytes, size_t limit_bytes, bool zero_on_alloc);
+
 }  // namespace u2conv

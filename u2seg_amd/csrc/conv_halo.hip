@@ -399,10 +399,9 @@ int launch_halo_cfg(ConvArgs& a, int N, int tiny, hipStream_t s) {
   if (T >= (1 << 30)) return 0;
   long long G = T < (tiny ? 8 : 256) ? T : (tiny ? 8 : 256);
   G = (G + 7) & ~7LL;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)conv_halo_kernel<PH, PWD, OPT, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv_halo_kernel<PH, PWD, OPT, CW>), dim3((unsigned)G), dim3(512), LDS_BYTES, s, a);
   hipError_t e = hipGetLastError();

@@ -1174,31 +1174,71 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-// partial-tile scratch of the weight-gradient kernels: one buffer per (device, stream), allocated on first use (the kernels of a
-// stream run one after the other, so consecutive launches can share it)
-struct WgScratch { int device; hipStream_t stream; float* buf; };
-constexpr size_t WG_SCRATCH_BYTES = (size_t)96 << 20;
+constexpr size_t WG_SCRATCH_LIMIT = (size_t)96 << 20;
 float* wgrad_scratch(hipStream_t s, size_t need_bytes) {
-  static WgScratch table[32];
-  static int used = 0;
-  static std::mutex mu;
-  if (need_bytes > WG_SCRATCH_BYTES) return nullptr;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  for (int i = 0; i < used; ++i)
-    if (table[i].device == dev && table[i].stream == s) return table[i].buf;
-  if (used == 32) return nullptr;
-  WgScratch e{dev, s, nullptr};
-  if (hipMalloc(&e.buf, WG_SCRATCH_BYTES) != hipSuccess) return nullptr;
-  table[used++] = e;
-  return e.buf;
+  return (float*)u2conv::scratch_get(2, s, need_bytes, WG_SCRATCH_LIMIT, false);
 }
 
 __device__ __attribute__((aligned(256))) bf16_t g_zero_page[128];
 }  // namespace
 namespace u2conv {
 int g_last_conv_kernel = 0;
+
+namespace {
+struct ScratchEnt { int device; hipStream_t stream; int kind; void* buf; size_t cap; };
+ScratchEnt g_scratch[128];
+int g_scratch_used = 0;
+std::mutex g_scratch_mu;
+}  // namespace
+
+void* scratch_get(int kind, hipStream_t s, size_t need_bytes, size_t limit_bytes, bool zero_on_alloc) {
+  if (need_bytes == 0 || need_bytes > limit_bytes) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  ScratchEnt* e = nullptr;
+  for (int i = 0; i < g_scratch_used; ++i)
+    if (g_scratch[i].device == dev && g_scratch[i].stream == s && g_scratch[i].kind == kind) { e = &g_scratch[i]; break; }
+  if (e && e->cap >= need_bytes) return e->buf;
+  if (!e) {
+    if (g_scratch_used == 128) return nullptr;
+    e = &g_scratch[g_scratch_used];
+    *e = ScratchEnt{dev, s, kind, nullptr, 0};
+  }
+  // grow: 1.5 x the old block at least (a sequence of slowly growing launches must not reallocate every time), 2 MB granules
+  size_t cap = need_bytes > e->cap + e->cap / 2 ? need_bytes : e->cap + e->cap / 2;
+  cap = (cap + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+  if (cap > limit_bytes) cap = limit_bytes;
+  if (e->buf) {
+    (void)hipStreamSynchronize(s);  // launches of this stream may still use the old block
+    (void)hipFree(e->buf);
+    e->buf = nullptr; e->cap = 0;
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
+  if (zero_on_alloc && hipMemset(p, 0, cap) != hipSuccess) { (void)hipFree(p); return nullptr; }
+  e->buf = p; e->cap = cap;
+  if (e == &g_scratch[g_scratch_used]) ++g_scratch_used;
+  return p;
+}
+}  // namespace u2conv
+
+extern "C" int u2_release_scratch(void) {
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  std::lock_guard<std::mutex> lock(u2conv::g_scratch_mu);
+  int freed = 0;
+  for (int i = 0; i < u2conv::g_scratch_used; ++i) {
+    u2conv::ScratchEnt& e = u2conv::g_scratch[i];
+    if (!e.buf) continue;
+    (void)hipSetDevice(e.device);
+    (void)hipStreamSynchronize(e.stream);
+    (void)hipFree(e.buf);
+    ++freed;
+  }
+  u2conv::g_scratch_used = 0;
+  (void)hipSetDevice(cur);
+  return freed;
 }
 extern "C" int u2_conv_last_kernel(void) { return u2conv::g_last_conv_kernel; }
 namespace {
@@ -1249,11 +1289,10 @@ int launch_conv(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   if (wide_ok && !(variant & 512) && ((variant & 256) || wide_auto)) {
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (N + 255) / 256;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
       (void)hipFuncSetAttribute((const void*)conv_igemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute((const void*)conv_igemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
     }
     a.stagger_by_parity = (variant & 2048) ? 1 : 0;
     g_last_conv_kernel = 256 + ((variant & 1024) ? 1024 : 0);
@@ -1287,11 +1326,10 @@ int launch_conv(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
 #define U2_LAUNCH_CONV(BK_, GL_, TM_, TN_, NST_)                                                                 \
   do {                                                                                                           \
     g_last_conv_kernel = 1000000 + BK_ * 10000 + (TM_ / 64) * 1000 + (TN_ / 64) * 100 + NST_ * 10 + (GL_ ? 1 : 0); \
-    static bool attr_set = false;                                                                                \
-    if (!attr_set) {                                                                                             \
+    static PerDeviceOnce attr_set;                                                                                \
+    if (attr_set.first()) {                                                                                             \
       (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BK_, GL_, TM_, TN_, NST_>,                        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
-      attr_set = true;                                                                                           \
     }                                                                                                            \
     hipLaunchKernelGGL((conv_igemm_kernel<BK_, GL_, TM_, TN_, NST_>), grid, block, lds, s, a);                   \
   } while (0)
@@ -1480,10 +1518,9 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
   const bool glds = (variant & 1) == 0, tr = (variant & 2) == 0;
   g_last_conv_kernel = (wide ? 2256 : 2000 + (glds ? 2 : 0) + (tr ? 1 : 0)) + (a.xcd_group ? 100 : 0);
   if (wide) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
       (void)hipFuncSetAttribute((const void*)conv_wgrad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
     }
     hipLaunchKernelGGL(conv_wgrad256_kernel, grid, dim3(512), WG256_STAGES * WG256_STAGE, s, a);
     U2_CHECK_LAUNCH();

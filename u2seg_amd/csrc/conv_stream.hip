@@ -335,10 +335,9 @@ int launch_stream_cfg(ConvArgs& a, int N, int tiny, int forced, int code, hipStr
   // at least ~6 pixel tiles per work-group: shorter-lived launches (stride-32 maps, ROI heads) stay on the tile kernels, whose
   // finer (tile, K) grain fills the chip better there
   if (!forced && !tiny && (long long)a.tiles_m * a.tiles_n < 6 * G) return 0;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)conv_stream_kernel<KS, TM, PSW, NWV, KSS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   g_last_conv_kernel = code;
   hipLaunchKernelGGL((conv_stream_kernel<KS, TM, PSW, NWV, KSS>), dim3((unsigned)G), dim3(NWV * 64), (size_t)ring * STAGE, s, a, ring);

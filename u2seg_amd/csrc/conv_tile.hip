@@ -562,26 +562,14 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 // but at most eight work-groups of the launch run to completion and free their CUs; the hardware dispatches work-groups of a
 // grid in index order, so the missing peer is the next one to get a CU.  The scheme relies on that in-order dispatch (as
 // every persistent-kernel hand-over does); it does NOT rely on co-residency of the whole grid.
-struct SkScratch { int device; hipStream_t stream; float* ws; int* flags; };
 constexpr int SK_MAX_GROUPS = 512;
-constexpr size_t SK_WS_BYTES = (size_t)64 << 20;
+constexpr size_t SK_WS_LIMIT = (size_t)64 << 20;
 bool sk_scratch(hipStream_t s, ConvArgs& a, size_t need_bytes) {
-  static SkScratch table[32];
-  static int used = 0;
-  static std::mutex mu;
-  if (need_bytes > SK_WS_BYTES) return false;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return false;
-  std::lock_guard<std::mutex> lock(mu);
-  for (int i = 0; i < used; ++i)
-    if (table[i].device == dev && table[i].stream == s) { a.sk_ws = table[i].ws; a.sk_flags = table[i].flags; return true; }
-  if (used == 32) return false;
-  SkScratch e{dev, s, nullptr, nullptr};
-  if (hipMalloc(&e.ws, SK_WS_BYTES) != hipSuccess) return false;
-  if (hipMalloc(&e.flags, SK_MAX_GROUPS * sizeof(int)) != hipSuccess) { (void)hipFree(e.ws); return false; }
-  if (hipMemset(e.flags, 0, SK_MAX_GROUPS * sizeof(int)) != hipSuccess) { (void)hipFree(e.ws); (void)hipFree(e.flags); return false; }
-  table[used++] = e;
-  a.sk_ws = e.ws; a.sk_flags = e.flags;
+  float* ws = (float*)scratch_get(0, s, need_bytes, SK_WS_LIMIT, false);
+  if (!ws) return false;
+  int* flags = (int*)scratch_get(1, s, SK_MAX_GROUPS * sizeof(int), (size_t)2 << 20, true);
+  if (!flags) return false;
+  a.sk_ws = ws; a.sk_flags = flags;
   return true;
 }
 
@@ -609,10 +597,9 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s, int
     long long Gs = cap;
     while (Gs > 8 && (T / 8) * nkh / (Gs / 8) < RING + 1) Gs -= 8;
     if (want && Gs <= SK_MAX_GROUPS && (T / 8) * nkh / (Gs / 8) >= RING + 1 && sk_scratch(s, a, (size_t)Gs * TM * TN * 4)) {
-      static bool attr_set_sk = false;
-      if (!attr_set_sk) {
+      static PerDeviceOnce attr_set_sk;
+      if (attr_set_sk.first()) {
         (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set_sk = true;
       }
       g_last_conv_kernel += 400;  // 5xx: the stream-K form of configuration xx
       hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, false, true>), dim3((unsigned)Gs), dim3(WCH * WPX * 64), LDS, s, a);
@@ -623,10 +610,9 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s, int
   }
   long long G = T < cap ? T : cap;
   G = (G + 7) & ~7LL;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, ACC>), dim3((unsigned)G), dim3(WCH * WPX * 64), LDS, s, a);
   hipError_t e = hipGetLastError();

@@ -732,11 +732,10 @@ extern "C" int u2_kmeans_assign(const float* x, const float* c, float* workspace
   U2_CHECK_LAUNCH();
   hipLaunchKernelGGL(csplit_kernel, dim3(KS_KMAX / 4), dim3(256), 0, s, c, chl, cn, scal, D, K);
   U2_CHECK_LAUNCH();
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   const dim3 grid((N + KS_PTS - 1) / KS_PTS), block(512);
   const size_t lds = KS_RING * KS_STAGE;

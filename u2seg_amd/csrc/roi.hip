@@ -940,10 +940,9 @@ extern "C" int u2_roi_group(const float* rois, const int* level, int* order, int
   if (R < 0 || nkeys < 1 || nkeys > RG_MAXKEYS || R > RG_MAXR) return -1;
   const size_t lds = ((size_t)256 * (nkeys + 2) + (size_t)(R > 0 ? R : 1)) * 2;
   if (lds > (size_t)RG_LDS_LIMIT) return -1;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)roi_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_LIMIT);
-    attr_set = true;
   }
   hipLaunchKernelGGL(roi_group_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, rois, level, order, seg, R, nlevels, nkeys);
   U2_CHECK_LAUNCH();

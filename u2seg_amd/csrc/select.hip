@@ -316,10 +316,9 @@ extern "C" int u2_topk_rows_multi(const U2TopkSeg* segs, int nseg, void* stream)
   if (m.nseg == 0) return 0;
   if (grid >= (1LL << 31)) return -1;
   const size_t lds = (size_t)max_cap * 8 + 272 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)topk_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)grid), dim3(SEL_THREADS), lds, (hipStream_t)stream, m);
   U2_CHECK_LAUNCH();

@@ -350,10 +350,9 @@ int launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* dw, long long dw
   int ppw = (int)((Mp + nsplit - 1) / nsplit);
   ppw = (ppw + HS - 1) / HS * HS;
   a.pix_per_wg = ppw;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL(conv_wgrad_halo_kernel, dim3((unsigned)(nsplit * a.tiles)), dim3(512), RING * STAGE, s, a);
   hipError_t e = hipGetLastError();

@@ -186,10 +186,9 @@ class RandomFlip(Augmentation):
     """augmentation_impl.py:82-112."""
 
     def __init__(self, prob=0.5, *, horizontal=True, vertical=False):
-        if horizontal and vertical:
-            raise ValueError("Cannot do both horiz and vert. Please use two Flip instead.")
-        if not horizontal and not vertical:
-            raise ValueError("At least one of horiz or vert has to be True!")
+        if horizontal == vertical:
+            raise ValueError("RandomFlip flips along exactly one axis: got horizontal=%r, vertical=%r (chain two RandomFlip "
+                             "augmentations to draw both)" % (horizontal, vertical))
         self.prob, self.horizontal, self.vertical = prob, horizontal, vertical
 
     def get_transform(self, image):

@@ -62,6 +62,12 @@ def zeros_f32(shape, device):
     return _zero_pool.take(tuple(shape), torch.device(device))
 
 
+def release_library_scratch():
+    """Frees the device memory libu2seg_hip.so owns (stream-K hand-over slots, weight-gradient partial tiles: include/u2seg_hip.h
+    u2_release_scratch); it is allocated again by the next launch that needs it.  Call it next to torch.cuda.empty_cache()."""
+    return _hip.call_nostream("u2_release_scratch")
+
+
 def _check_act(x):
     assert x.is_cuda and x.dtype == BF16 and x.is_contiguous() and x.dim() == 4 and x.shape[3] % 32 == 0, (
         "expected contiguous NHWC bf16 activation with C %% 32 == 0, got %s %s" % (tuple(x.shape), x.dtype)
@@ -203,6 +209,15 @@ def join_all_streams():
     join_wgrad_stream()
     for (dev, _index), s in _aux_streams.items():
         torch.cuda.current_stream(dev).wait_stream(s)
+
+
+def producer_streams(device):
+    """Every stream of this module that may hold gradient-producing work for `device` (weight-gradient side stream, the
+    further compute streams); the caller adds the stream it runs the step on."""
+    device = _cuda_device(device)
+    out = [s for dev, s in _side_streams.items() if _cuda_device(dev) == device]
+    out += [s for (dev, _index), s in _aux_streams.items() if dev == device]
+    return out
 
 
 def join_wgrad_stream(device=None):

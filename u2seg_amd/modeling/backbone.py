@@ -98,32 +98,34 @@ class BottleneckBlock(nn.Module):
 
 
 class ResNet(Backbone):
+    """stem + res2..res5 (resnet.py:362-458).  The feature table - one (name, stride, channels) row for the stem and every
+    stage - is built first; strides, channels and the default output are read from it."""
+
     def __init__(self, stem, stages, out_features=None, freeze_at=0):
         super().__init__()
+        if freeze_at != 0:
+            raise NotImplementedError("BACKBONE.FREEZE_AT > 0 is not used by the U2Seg configs")
         self.stem = stem
-        current_stride = stem.stride
-        self._out_feature_strides = {"stem": current_stride}
-        self._out_feature_channels = {"stem": stem.out_channels}
-        self.stage_names, self.stages = [], []
-        for i, blocks in enumerate(stages):
-            name = "res" + str(i + 2)
-            stage = nn.Sequential(*blocks)
-            self.add_module(name, stage)
-            self.stage_names.append(name)
-            self.stages.append(stage)
-            current_stride = int(current_stride * math.prod([k.stride for k in blocks]))
-            self._out_feature_strides[name] = current_stride
-            self._out_feature_channels[name] = blocks[-1].out_channels
-        self.stage_names = tuple(self.stage_names)
-        self._out_features = out_features if out_features is not None else [name]
-        for stage in self.stages:
-            for blk in list(stage)[1:]:
+        table = [("stem", stem.stride, stem.out_channels)]
+        self.stages = []
+        for number, blocks in enumerate(stages, start=2):
+            seq = nn.Sequential(*blocks)
+            self.add_module("res%d" % number, seq)  # state-dict prefix of the stage
+            self.stages.append(seq)
+            table.append(("res%d" % number, table[-1][1] * math.prod(blk.stride for blk in blocks), blocks[-1].out_channels))
+        self.stage_names = tuple(row[0] for row in table[1:])
+        self._out_feature_strides = {name: stride for name, stride, _ in table}
+        self._out_feature_channels = {name: channels for name, _, channels in table}
+        self._out_features = list(out_features) if out_features is not None else [table[-1][0]]
+        # autograd-handle bookkeeping of this implementation (see BottleneckBlock.forward): which block opens its stage, and
+        # which stage outputs are read by the next stage AND by the caller
+        for seq in self.stages:
+            for blk in list(seq)[1:]:
                 if hasattr(blk, "first_in_stage"):
                     blk.first_in_stage = False
-        for sname, stage in zip(self.stage_names[:-1], self.stages[:-1]):
-            if sname in self._out_features and hasattr(stage[-1], "third_handle"):
-                stage[-1].third_handle = True
-        assert freeze_at == 0, "BACKBONE.FREEZE_AT > 0 is not used by the U2Seg configs"
+        for name, seq in zip(self.stage_names[:-1], self.stages[:-1]):
+            if name in self._out_features and hasattr(seq[-1], "third_handle"):
+                seq[-1].third_handle = True
 
     def forward(self, images, pixel_mean, pixel_std, padded_hw):
         outputs = {}
@@ -206,37 +208,39 @@ class LastLevelMaxPool(nn.Module):
 
 
 class FPN(Backbone):
+    """Top-down pyramid over the bottom-up features (fpn.py:17-167).  A level table (level number = log2 stride, source feature,
+    its channels) is built first; the conv pairs are registered from it under the reference's state-dict names
+    fpn_lateral<level> / fpn_output<level> (finest level first, the bottom-up network last: the reference's key order)."""
+
     def __init__(self, bottom_up, in_features, out_channels, norm="", top_block=None, fuse_type="sum"):
         super().__init__()
-        assert fuse_type == "sum"
-        input_shapes = bottom_up.output_shape()
-        strides = [input_shapes[f].stride for f in in_features]
-        in_channels_per_feature = [input_shapes[f].channels for f in in_features]
-        lateral_convs, output_convs = [], []
-        use_bias = norm == ""
-        for idx, in_channels in enumerate(in_channels_per_feature):
-            lateral_conv = Conv2d(in_channels, out_channels, kernel_size=1, bias=use_bias, norm=get_norm(norm, out_channels))
-            output_conv = Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=use_bias,
-                                 norm=get_norm(norm, out_channels))
-            c2_xavier_fill(lateral_conv)
-            c2_xavier_fill(output_conv)
-            stage = int(math.log2(strides[idx]))
-            self.add_module("fpn_lateral{}".format(stage), lateral_conv)
-            self.add_module("fpn_output{}".format(stage), output_conv)
-            lateral_convs.append(lateral_conv)
-            output_convs.append(output_conv)
-        self.lateral_convs = lateral_convs[::-1]  # top-down order
-        self.output_convs = output_convs[::-1]
+        if fuse_type != "sum":
+            raise NotImplementedError("FPN.FUSE_TYPE %r: the U2Seg configs sum the two paths" % (fuse_type,))
+        shapes = bottom_up.output_shape()
+        levels = [(int(math.log2(shapes[f].stride)), f, shapes[f].channels) for f in in_features]
+        biased = norm == ""
+        pairs = {}
+        for level, _feature, channels in levels:
+            lateral = Conv2d(channels, out_channels, kernel_size=1, bias=biased, norm=get_norm(norm, out_channels))
+            output = Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=biased,
+                            norm=get_norm(norm, out_channels))
+            for conv in (lateral, output):
+                c2_xavier_fill(conv)
+            self.add_module("fpn_lateral%d" % level, lateral)
+            self.add_module("fpn_output%d" % level, output)
+            pairs[level] = (lateral, output)
+        # the order the pyramid is computed in: coarsest level first
+        self.top_down = [(level, feature) + pairs[level] for level, feature, _ in reversed(levels)]
         self.top_block = top_block
         self.in_features = tuple(in_features)
         self.bottom_up = bottom_up
-        self._out_feature_strides = {"p{}".format(int(math.log2(s))): s for s in strides}
-        if self.top_block is not None:
-            for s in range(stage, stage + self.top_block.num_levels):
-                self._out_feature_strides["p{}".format(s + 1)] = 2 ** (s + 1)
-        self._out_features = list(self._out_feature_strides.keys())
-        self._out_feature_channels = {k: out_channels for k in self._out_features}
-        self._size_divisibility = strides[-1]
+        out_levels = [level for level, _, _ in levels]
+        if top_block is not None:
+            out_levels += [out_levels[-1] + 1 + extra for extra in range(top_block.num_levels)]
+        self._out_features = ["p%d" % level for level in out_levels]
+        self._out_feature_strides = {"p%d" % level: 2 ** level for level in out_levels}
+        self._out_feature_channels = dict.fromkeys(self._out_features, out_channels)
+        self._size_divisibility = shapes[in_features[-1]].stride
 
     @property
     def size_divisibility(self):
@@ -251,19 +255,18 @@ class FPN(Backbone):
         return self.forward_features(self.bottom_up(images, pixel_mean, pixel_std, padded_hw))
 
     def forward_features(self, bottom_up_features):
-        results = []
-        prev = self.lateral_convs[0](bottom_up_features[self.in_features[-1]])
-        results.append(self.output_convs[0](prev))
-        for idx, (lateral_conv, output_conv) in enumerate(zip(self.lateral_convs, self.output_convs)):
-            if idx > 0:
-                # lateral 1x1 + its norm + nearest x2 of the coarser level + add: one pass over the map (fpn.py:141-158)
-                prev = lateral_conv(bottom_up_features[self.in_features[-idx - 1]], residual_up=prev)
-                results.insert(0, output_conv(prev))
+        maps, carry = {}, None
+        for level, feature, lateral, output in self.top_down:
+            # lateral 1x1 + its norm (+ nearest x2 of the coarser level + add: one pass over the map, fpn.py:141-158)
+            src = bottom_up_features[feature]
+            carry = lateral(src) if carry is None else lateral(src, residual_up=carry)
+            maps["p%d" % level] = output(carry)
+        ordered = [maps[name] for name in self._out_features if name in maps]
         if self.top_block is not None:
-            top_in = results[self._out_features.index(self.top_block.in_feature)]
-            results.extend(self.top_block(top_in))
-        assert len(self._out_features) == len(results)
-        return {f: res for f, res in zip(self._out_features, results)}
+            ordered += list(self.top_block(maps[self.top_block.in_feature]))
+        if len(ordered) != len(self._out_features):
+            raise RuntimeError("FPN produced %d maps for %d declared outputs" % (len(ordered), len(self._out_features)))
+        return dict(zip(self._out_features, ordered))
 
 
 @BACKBONE_REGISTRY.register()

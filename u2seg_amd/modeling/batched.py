@@ -6,6 +6,7 @@ tensors plus per-image counts that stay on the device; the ROI heads' training p
 host synchronisation, a handful of batched kernels), and the ragged ``list[Instances]`` the reference API promises is
 only materialised - with the one device->host copy it needs - when somebody actually indexes or iterates it."""
 import collections.abc
+import threading
 import weakref
 
 import torch
@@ -13,81 +14,123 @@ import torch
 from ..structures import Boxes, Instances
 
 
-_const_cache = collections.OrderedDict()
+_const_cache = collections.OrderedDict()  # key -> [tensor, upload event or None, stream id of the upload]
 
 
-def device_constant(values, dtype, device):
-    """Small host-known tensor on the device.  A pageable host->device copy makes the host wait for everything already
-    queued on the stream, i.e. it is a hidden synchronisation; values that repeat from step to step (image sizes, box
-    counts, ...) are therefore cached on the device (read-only!) and the rest goes through pinned memory."""
-    key = (repr(values), dtype, str(device))
-    hit = _const_cache.get(key)
-    if hit is not None:
-        _const_cache.move_to_end(key)
-        return hit
-    host = torch.tensor(values, dtype=dtype)
-    dev = torch.device(device)
+def _cache_get(key, dev):
+    """A cached constant for whichever stream asks: the stream that uploaded it is ordered by itself, any other stream waits
+    for the upload's event until that has completed once (then the entry is plain read-only memory).  No host synchronisation."""
+    ent = _const_cache.get(key)
+    if ent is None:
+        return None
+    _const_cache.move_to_end(key)
+    if ent[1] is not None:
+        if ent[1].query():
+            ent[1] = None
+        else:
+            cur = torch.cuda.current_stream(dev)
+            if cur.cuda_stream != ent[2]:
+                cur.wait_event(ent[1])
+                ent[0].record_stream(cur)
+    return ent[0]
+
+
+def _cache_put(key, host, dev):
     if dev.type == "cuda":
-        out = host.pin_memory().to(dev, non_blocking=True)
-        # a cached constant is handed to whichever stream asks next: finish the copy once, here (first use of a value only)
-        torch.cuda.current_stream(dev).synchronize()
+        out, ev = _PinnedRing.get(dev).upload(host, want_event=True)
+        _const_cache[key] = [out, ev, torch.cuda.current_stream(dev).cuda_stream]
     else:
         out = host.to(dev)
-    _const_cache[key] = out
+        _const_cache[key] = [out, None, 0]
     if len(_const_cache) > 512:
         _const_cache.popitem(last=False)
     return out
 
 
+def device_constant(values, dtype, device):
+    """Small host-known tensor on the device.  A pageable host->device copy makes the host wait for everything already
+    queued on the stream, i.e. it is a hidden synchronisation; values that repeat from step to step (image sizes, box
+    counts, ...) are therefore cached on the device (read-only!), uploaded once from the pinned staging ring; other streams
+    are ordered behind that upload by its event (round 5: was pin_memory() + a stream synchronisation per new value)."""
+    dev = torch.device(device)
+    key = (repr(values), dtype, str(dev))
+    hit = _cache_get(key, dev)
+    if hit is not None:
+        return hit
+    return _cache_put(key, torch.tensor(values, dtype=dtype), dev)
+
+
 class _PinnedRing:
-    """A few pinned staging slots allocated ONCE per device: `tensor.pin_memory()` per upload goes to hipHostMalloc whenever
+    """Pinned staging slots allocated ONCE per device: `tensor.pin_memory()` per upload goes to hipHostMalloc whenever
     the caching host allocator has no block whose last copy has retired - milliseconds each, and it synchronises (measured:
     batch-32 inference inside the default bench.py run, after the training workload, 47 -> 68 ms per batch).  A slot is
-    reused only after the event recorded behind its last copy has completed."""
+    reused only after the event recorded behind its last copy has completed.  64 slots of 64 KB for the usual vectors of
+    counts / offsets plus 4 slots of 4 MB for the rare long one (per-ROI image indices); anything larger is copied through a
+    one-off pinned block.  Slot selection is under a lock: uploads may come from the autograd thread as well."""
 
-    SLOTS, SLOT_BYTES = 64, 65536
+    RINGS = ((64, 65536), (4, 4 << 20))
     _rings = {}
+    _guard = threading.Lock()
 
     def __init__(self, dev):
-        self.buf = torch.empty((self.SLOTS, self.SLOT_BYTES), dtype=torch.uint8).pin_memory()
-        self.events = [None] * self.SLOTS
-        self.next = 0
+        self.bufs = [torch.empty((n, size), dtype=torch.uint8).pin_memory() for n, size in self.RINGS]
+        self.events = [[None] * n for n, _ in self.RINGS]
+        self.next = [0] * len(self.RINGS)
         self.dev = dev
+        self.lock = threading.Lock()
 
     @classmethod
     def get(cls, dev):
         key = str(dev)
         ring = cls._rings.get(key)
         if ring is None:
-            ring = cls._rings[key] = cls(dev)
+            with cls._guard:
+                ring = cls._rings.get(key)
+                if ring is None:
+                    ring = cls._rings[key] = cls(dev)
         return ring
 
-    def upload(self, host):
+    def upload(self, host, want_event=False):
         nbytes = host.numel() * host.element_size()
-        i = self.next
-        self.next = (i + 1) % self.SLOTS
-        ev = self.events[i]
-        if ev is not None and not ev.query():
-            ev.synchronize()
-        stage = self.buf[i, :nbytes].view(host.dtype).view(host.shape)
-        stage.copy_(host)
         out = torch.empty(host.shape, dtype=host.dtype, device=self.dev)
-        out.copy_(stage, non_blocking=True)
-        if ev is None:
-            ev = self.events[i] = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.dev))
-        return out
+        if nbytes == 0:
+            return (out, None) if want_event else out
+        r = next((k for k, (_, size) in enumerate(self.RINGS) if nbytes <= size), None)
+        cur = torch.cuda.current_stream(self.dev)
+        if r is None:  # larger than any slot: a one-off pinned block (the caching host allocator keeps it alive until the copy retires)
+            out.copy_(host.pin_memory(), non_blocking=True)
+            ev = None
+            if want_event:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+            return (out, ev) if want_event else out
+        with self.lock:
+            i = self.next[r]
+            self.next[r] = (i + 1) % self.RINGS[r][0]
+            ev = self.events[r][i]
+            if ev is not None and not ev.query():
+                ev.synchronize()
+            stage = self.bufs[r][i, :nbytes].view(host.dtype).view(host.shape)
+            stage.copy_(host)
+            out.copy_(stage, non_blocking=True)
+            ev = self.events[r][i] = torch.cuda.Event()  # a fresh event: the previous one may be held by a cache entry
+            ev.record(cur)
+        return (out, ev) if want_event else out
+
+    def warm(self):
+        """Touch every pinned page and create the events before a timed region (first touch of pinned memory faults it in)."""
+        for b in self.bufs:
+            b.zero_()
 
 
 def device_upload(values, dtype, device):
     """Host-known values that CHANGE from batch to batch (box counts, offsets): one non-blocking copy from a pinned staging slot
-    on the current stream - no cache entry (they would only evict the constants that do repeat) and no synchronisation."""
+    on the current stream - no cache entry (they would only evict the constants that do repeat), no allocation and no
+    synchronisation."""
     host = torch.tensor(values, dtype=dtype)
     dev = torch.device(device)
     if dev.type != "cuda":
         return host.to(dev)
-    if host.numel() == 0 or host.numel() * host.element_size() > _PinnedRing.SLOT_BYTES:
-        return host.pin_memory().to(dev, non_blocking=True)
     return _PinnedRing.get(dev).upload(host)
 
 
@@ -203,14 +246,10 @@ def proposals_from_list(proposals, training=False):
 
 def image_index(sizes, device):
     """float32 image index per ROI for per-image box counts `sizes` (host ints): built on the host, no device sync."""
-    key = ("image_index", tuple(sizes), str(device))
-    hit = _const_cache.get(key)
+    dev = torch.device(device)
+    key = ("image_index", tuple(sizes), str(dev))
+    hit = _cache_get(key, dev)
     if hit is None:
         idx = torch.repeat_interleave(torch.arange(len(sizes), dtype=torch.float32), torch.tensor(sizes, dtype=torch.int64))
-        dev = torch.device(device)
-        hit = _const_cache[key] = idx.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else idx.to(dev)
-        if dev.type == "cuda":
-            torch.cuda.current_stream(dev).synchronize()  # cached for any stream: finish the upload once
-        if len(_const_cache) > 512:
-            _const_cache.popitem(last=False)
+        hit = _cache_put(key, idx, dev)
     return hit

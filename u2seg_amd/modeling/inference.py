@@ -236,7 +236,7 @@ def combine_semantic_and_instance_outputs_batch(instance_results, semantic_resul
         cols = [j for k in ks for j in range(k)]
         spad = torch.full((n, kmax), float("-inf"), dtype=torch.float32, device=dev)
         spad[device_upload(rows, torch.int64, dev), device_upload(cols, torch.int64, dev)] = flat_scores
-        order2d = torch.argsort(-spad, dim=1)
+        order2d = torch.argsort(-spad, dim=1, stable=True)  # equal scores keep their detection order, as the 1-D per-image sort does
         sorted2d = torch.gather(spad, 1, order2d).contiguous()
         order2d = order2d.to(torch.int32).contiguous()
         classes_all = torch.cat([inst.pred_classes for inst in instance_results]).to(torch.int32)

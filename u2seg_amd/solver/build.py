@@ -18,11 +18,26 @@ CHUNK = 1 << 16
 class FlatSGD:
     def __init__(self, model, lr, momentum=0.9, weight_decay=0.0, weight_decay_norm=0.0, weight_decay_bias=None,
                  clip_value=0.0, bucket_bytes=64 << 20):
-        norm_params = set()
+        # per-parameter hyper-parameters by the reference's rule (solver/build.py:218-236 get_default_optimizer_params): the
+        # module tree is walked in named_modules order, a normalisation layer's parameters take WEIGHT_DECAY_NORM, and the
+        # legacy bias override - applied after it, to every parameter literally named "bias" - WEIGHT_DECAY_BIAS
+        wd_of, seen = {}, set()
         for mod in model.modules():
-            if isinstance(mod, (BatchNorm2d, GroupNorm)):
-                norm_params.update(id(p) for p in mod.parameters(recurse=False))
+            for pname, p in mod.named_parameters(recurse=False):
+                if not p.requires_grad or id(p) in seen:
+                    continue
+                seen.add(id(p))
+                wd = weight_decay_norm if isinstance(mod, (BatchNorm2d, GroupNorm)) else weight_decay
+                if pname == "bias" and weight_decay_bias is not None:
+                    wd = weight_decay_bias
+                wd_of[id(p)] = float(wd)
         self.params = [p for p in model.parameters() if p.requires_grad]
+        assert len(self.params) == len(wd_of)
+        # the reference merges parameters with equal hyper-parameters into one torch param group, groups in order of first
+        # appearance (reduce_param_groups, solver/build.py:255-279); torch numbers the parameters group after group.  That
+        # numbering is the key of a reference checkpoint's optimizer state (state_dict / load_state_dict below).
+        self.group_wd = list(dict.fromkeys(wd_of[id(p)] for p in self.params))
+        self.group_members = [[i for i, p in enumerate(self.params) if wd_of[id(p)] == g] for g in self.group_wd]
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
         self.total = total
@@ -38,12 +53,7 @@ class FlatSGD:
             p.data = self.flat_param[off : off + n].view(p.shape)
             p.grad = self.flat_grad[off : off + n].view(p.shape)
             p._u2_grad = p.grad  # layers/functional.py:grad_slot - kernels accumulate into the arena directly
-            if id(p) in norm_params:
-                wds.append(weight_decay_norm)
-            elif p.dim() == 1 and weight_decay_bias is not None:
-                wds.append(weight_decay_bias)
-            else:
-                wds.append(weight_decay)
+            wds.append(wd_of[id(p)])
             first_chunk.append(len(chunk_tensor))
             for s in range(0, n, CHUNK):
                 chunk_tensor.append(t)
@@ -58,8 +68,15 @@ class FlatSGD:
         self.first_chunk = torch.tensor(first_chunk, dtype=torch.int32, device=dev)
         self.partial = torch.zeros(len(chunk_tensor), dtype=torch.float32, device=dev)
         self.lr, self.momentum, self.clip_value = lr, momentum, clip_value
+        self.base_lr = lr  # "initial_lr" of the param groups once a torch LR scheduler has touched them
+        self.param_offset = []
+        off = 0
+        for p in self.params:
+            self.param_offset.append(off)
+            off += p.numel()
         self.bucket_elems = bucket_bytes // 4
         self._pending, self._tail_from = [], None
+        self._exchange_stream, self._step_stream = None, None
         # bf16 kernel layouts cached on the parameters (layers/functional.py:_weight_layout): [stamp] is shared with every
         # parameter; step() bumps it and rewrites all registered layouts with one launch.
         self._stamp = [0]
@@ -77,14 +94,39 @@ class FlatSGD:
         return (param.data_ptr() - self.flat_param.data_ptr()) // 4
 
     def zero_grad(self):
+        if self.flat_grad.is_cuda:
+            self._step_stream = torch.cuda.current_stream(self.flat_grad.device)  # the stream the training step is issued on
         self.flat_grad.zero_()
 
     def _distributed(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
     def _launch_all_reduce(self, lo, hi):
-        for s in range(lo, hi, self.bucket_elems):
-            self._pending.append(dist.all_reduce(self.flat_grad[s : min(s + self.bucket_elems, hi)], async_op=True))
+        """Async all-reduce of flat_grad[lo:hi] in buckets.  On the GPU the collectives are issued from a stream of their own
+        that first waits - explicitly, event by event - for every stream that produced gradients: the stream the step runs on,
+        the weight-gradient side stream and the branch streams.  ProcessGroupNCCL orders a collective behind whatever stream is
+        current when it is called; the tail exchange is called from an autograd hook, where "current" is whichever stream the
+        engine selected for that node, so nothing here depends on it."""
+        if not self.flat_grad.is_cuda:
+            for s in range(lo, hi, self.bucket_elems):
+                self._pending.append(dist.all_reduce(self.flat_grad[s : min(s + self.bucket_elems, hi)], async_op=True))
+            return
+        from ..layers.functional import producer_streams
+
+        dev = self.flat_grad.device
+        if self._exchange_stream is None:
+            self._exchange_stream = torch.cuda.Stream(device=dev)
+        ex = self._exchange_stream
+        producers = producer_streams(dev) + [torch.cuda.current_stream(dev)]
+        if self._step_stream is not None:
+            producers.append(self._step_stream)
+        for st in producers:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            ex.wait_event(ev)
+        with torch.cuda.stream(ex):
+            for s in range(lo, hi, self.bucket_elems):
+                self._pending.append(dist.all_reduce(self.flat_grad[s : min(s + self.bucket_elems, hi)], async_op=True))
 
     def begin_all_reduce_tail(self, first_elem):
         """Start summing the gradients of the arena's tail [first_elem, total) while backward is still running: the tail
@@ -92,22 +134,16 @@ class FlatSGD:
         exist; RCCL works on them over xGMI while the backbone backward (~40 % of the step) keeps the CUs busy."""
         if not self._distributed() or self._tail_from is not None:
             return
-        from ..layers.functional import join_all_streams
-
-        join_all_streams()  # the heads' gradients were produced on the side stream and on their branches' streams
-        self._tail_from = int(first_elem)
+        self._tail_from = int(first_elem)  # (_launch_all_reduce waits for the producing streams itself)
         self._launch_all_reduce(self._tail_from, self.total)
 
     def all_reduce_grads(self):
         """Sum gradients over ranks in a few large buckets (mean is folded into the step's grad_scale)."""
         if not self._distributed():
             return 1.0
-        from ..layers.functional import join_all_streams
-
-        join_all_streams()
         self._launch_all_reduce(0, self.total if self._tail_from is None else self._tail_from)
         for h in self._pending:
-            h.wait()
+            h.wait()  # the current stream (the optimizer's) waits for the collective; the host does not block on NCCL
         self._pending, self._tail_from = [], None
         return 1.0 / dist.get_world_size()
 
@@ -160,11 +196,52 @@ class FlatSGD:
             ent[1], ent[2] = p._version, stamp
 
     def state_dict(self):
-        return {"momentum": self.flat_mom.clone(), "lr": self.lr}
+        """The state dict `torch.optim.SGD` - the reference's optimizer (solver/build.py:119-139) - would write for this
+        model: `param_groups` in the reference's grouping with torch's parameter numbering, `state[i]["momentum_buffer"]` a
+        copy of parameter i's slice of the momentum arena.  A reference trainer can resume from it, and `load_state_dict`
+        reads what a reference trainer wrote.  (Before the first step torch has no state entries; here the buffers exist
+        from the start and are written as zeros, which is what torch's first step computes from: buf = grad.)"""
+        groups, state, n = [], {}, 0
+        for wd, members in zip(self.group_wd, self.group_members):
+            groups.append({"lr": float(self.lr), "momentum": float(self.momentum), "dampening": 0, "weight_decay": wd,
+                           "nesterov": False, "maximize": False, "foreach": True, "differentiable": False, "fused": None,
+                           "initial_lr": float(self.base_lr), "params": list(range(n, n + len(members)))})
+            for i in members:
+                off = self.param_offset[i]
+                p = self.params[i]
+                state[n] = {"momentum_buffer": self.flat_mom[off : off + p.numel()].view(p.shape).clone()}
+                n += 1
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self.flat_mom.copy_(sd["momentum"])
-        self.lr = sd["lr"]
+        if "param_groups" not in sd:  # this package's first on-disk form: the whole momentum arena + lr
+            self.flat_mom.copy_(sd["momentum"])
+            self.lr = sd["lr"]
+            return
+        groups = sd["param_groups"]
+        if [len(g["params"]) for g in groups] != [len(m) for m in self.group_members]:
+            raise ValueError("loaded state dict has a different number of parameter groups / parameters per group: %s vs %s"
+                             % ([len(g["params"]) for g in groups], [len(m) for m in self.group_members]))
+        lrs = {float(g["lr"]) for g in groups}
+        assert len(lrs) == 1, "per-group learning rates (BIAS_LR_FACTOR != 1) are not implemented"
+        self.lr = lrs.pop()
+        for g, wd, members in zip(groups, self.group_wd, self.group_members):
+            assert not g.get("nesterov", False) and not g.get("dampening", 0) and not g.get("maximize", False), g
+            self.momentum = float(g.get("momentum", self.momentum))
+            if float(g.get("weight_decay", wd)) != wd:
+                # torch takes a group's hyper-parameters from the file, not from the constructor (Optimizer.load_state_dict)
+                self.group_wd[self.group_wd.index(wd)] = float(g["weight_decay"])
+                self.wd[torch.tensor(members, device=self.wd.device)] = float(g["weight_decay"])
+            for key, i in zip(g["params"], members):
+                off, p = self.param_offset[i], self.params[i]
+                buf = (sd["state"].get(key) or {}).get("momentum_buffer")
+                dst = self.flat_mom[off : off + p.numel()]
+                if buf is None:  # torch creates the buffer in the first step: no entry = no history
+                    dst.zero_()
+                    continue
+                if tuple(buf.shape) != tuple(p.shape):
+                    raise ValueError("momentum buffer %s of parameter %d does not fit %s" % (tuple(buf.shape), key, tuple(p.shape)))
+                dst.copy_(buf.reshape(-1))
 
 
 def build_optimizer(cfg, model):
@@ -213,10 +290,13 @@ class WarmupMultiStepLR:
         self.optimizer.lr = self.get_lr(self.last_iter)
 
     def state_dict(self):
-        return {"last_iter": self.last_iter}
+        # "last_epoch" / "base_lrs" are what the reference's scheduler objects read back (fvcore's LRMultiplier and the plain
+        # WarmupMultiStepLR of solver/lr_scheduler.py are torch LRSchedulers: load_state_dict = __dict__.update)
+        groups = len(getattr(self.optimizer, "group_members", [0]))
+        return {"last_iter": self.last_iter, "last_epoch": self.last_iter, "base_lrs": [self.base_lr] * groups}
 
     def load_state_dict(self, state):
-        self.resume_at(state["last_iter"])
+        self.resume_at(state["last_iter"] if "last_iter" in state else state["last_epoch"])
 
 
 def build_lr_scheduler(cfg, optimizer):

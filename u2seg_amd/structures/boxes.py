@@ -48,8 +48,12 @@ class Boxes:
         if not bool(torch.isfinite(self.tensor).all()):
             raise AssertionError("cannot clip boxes that contain Inf or NaN")
         h, w = box_size
-        upper = self.tensor.new_tensor([w, h, w, h])
-        self.tensor = torch.minimum(self.tensor.clamp(min=0), upper)
+        # Python-scalar bounds per coordinate column: no host -> device upload (a pageable copy would block the host)
+        out = self.tensor.clamp(min=0)
+        xy = out.view(-1, 2, 2)
+        xy[..., 0].clamp_(max=w)
+        xy[..., 1].clamp_(max=h)
+        self.tensor = out
 
     def nonempty(self, threshold=0.0):
         return (self._extent() > threshold).all(dim=1)
@@ -58,7 +62,9 @@ class Boxes:
         return self._corners().mean(dim=1)
 
     def scale(self, scale_x, scale_y):
-        self.tensor.mul_(self.tensor.new_tensor([scale_x, scale_y, scale_x, scale_y]))
+        xy = self.tensor.view(-1, 2, 2)
+        xy[..., 0].mul_(scale_x)
+        xy[..., 1].mul_(scale_y)
 
     def __getitem__(self, item):
         picked = self.tensor[item]
