@@ -373,6 +373,31 @@ int main(int argc, char** argv) {
     }
     return f;
   };
+  // wgrad_stream.hip (variant bit 18 forces it on small maps; bits 21-23 block configuration, bit 20: 8 pixel ranges, bits 24-25
+  // work-groups per CU): M not a multiple of 32, channel tails on both sides, blocks tiled over N and over C, 1 .. many steps per range
+  const WgCase ws_cases[] = {
+      {1, 37, 29, 64, 256, 1, 1, 0, 1, "wstream 37x29 c64 n256"},
+      {2, 33, 21, 256, 64, 1, 1, 0, 1, "wstream 33x21 c256 n64"},
+      {1, 45, 23, 128, 136, 1, 1, 0, 1, "wstream 45x23 c128 n136"},
+      {1, 19, 45, 264, 520, 1, 1, 0, 1, "wstream 19x45 c264 n520"},
+      {3, 7, 9, 32, 32, 1, 1, 0, 1, "wstream 7x9 c32 n32 (few steps)"},
+      {1, 61, 67, 160, 64, 1, 1, 0, 1, "wstream 61x67 c160 n64 (stem)"},
+      {2, 40, 70, 512, 128, 1, 1, 0, 1, "wstream 40x70 c512 n128"},
+      {1, 1, 5, 64, 64, 1, 1, 0, 1, "wstream 5 px"},
+  };
+  if (argc > 1 && !strcmp(argv[1], "wstream")) {
+    for (int cfg = 0; cfg <= 4; ++cfg)
+      for (int tiny = 0; tiny < 2; ++tiny)
+        for (const auto& c : ws_cases) {
+          const int v = (1 << 18) | (tiny << 20) | (cfg << 21);
+          fails += test_wgrad(c, v);
+          if (u2_conv_last_kernel() / 100 != 27) { printf("FAIL %-28s did not take the streaming kernel (%d)\n", c.name, u2_conv_last_kernel()); ++fails; }
+          if (cfg == 0 || tiny) fails += test_wgrad(c, v, true);
+          if (cfg >= 1 && cfg <= 3 && !tiny) fails += test_wgrad(c, v | (1 << 24));   // one work-group per CU
+        }
+    printf("SELFTEST wstream %s (%d failures)\n", fails ? "FAILED" : "OK", fails);
+    return fails ? 1 : 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "halo")) {
     fails = run_halo();
     printf("SELFTEST halo %s (%d failures)\n", fails ? "FAILED" : "OK", fails);

@@ -259,6 +259,61 @@ def test_wgrad_forced_variants(F, variant, code):
         assert rel_err(wd.grad.cpu(), w.grad) < WG_TOL
 
 
+WS_FORCE, WS_TINY = 1 << 18, 1 << 20
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tiny", [0, 1])
+def test_wgrad_stream_kernel(F, cfg, tiny):
+    """wgrad_stream_kernel (1x1 / stride 1: a persistent work-group per pixel range holds a whole block of dW in registers),
+    every block configuration forced (U2_WGRAD_VARIANT bit 18, bits 21-23) with 8 pixel ranges and with the full grid, on maps
+    whose pixel count is not a multiple of the 32-pixel step, with channel tails on both operands (40, 104, 136, 264, 520: blocks
+    tiled over N and over C, half-empty blocks, 8-channel remainders) and a 5-pixel map (ranges without a step), vs fp32.  The 1x1
+    weight gradient goes through u2_conv_wgrad_into (the arena layout [N][Cin]) whenever the weight owns a gradient slot."""
+    g = torch.Generator().manual_seed(11 + cfg * 2 + tiny)
+    for (b, cin, cout, h, w_) in ((1, 64, 256, 37, 29), (2, 256, 40, 33, 21), (1, 128, 136, 45, 23), (1, 264, 520, 19, 45),
+                                 (1, 160, 64, 61, 67), (2, 512, 104, 40, 35), (1, 64, 64, 1, 5)):
+        x = bf(torch.randn((b, cin, h, w_), generator=g))
+        w = (torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5).requires_grad_(True)
+        yr = TF.conv2d(x, bf(w), None, 1, 0)
+        gy = bf(torch.randn(yr.shape, generator=g))
+        yr.backward(gy)
+        wd = w.detach().to(DEV).requires_grad_(True)
+        with forced(wgrad=WS_FORCE | (WS_TINY if tiny else 0) | (cfg << 21)):
+            y, _ = F._Conv2dFn.apply(nhwc(x), wd, None, 1, 0, False, False)
+            y.backward(nhwc(gy))
+            assert last_kernel() // 100 == 27, (cfg, last_kernel())
+            if cfg:
+                assert last_kernel() == 2700 + cfg
+        assert rel_err(wd.grad.cpu(), w.grad) < WG_TOL, (cfg, tiny, cin, cout)
+
+
+@pytest.mark.parametrize("name,b,h,w,cin,cout,code", [
+    ("res2 conv3 1x1 64->256 @200x336", 16, 200, 336, 64, 256, 2701),
+    ("res2 conv1 1x1 256->64 @200x336", 16, 200, 336, 256, 64, 2702),
+    ("res3 conv3 1x1 128->512 @100x168", 16, 100, 168, 128, 512, 2703),
+    ("fpn lateral2 1x1 256->256 @200x336", 16, 200, 336, 256, 256, 2704),
+    ("semantic predictor 1x1 128->28 @200x336", 16, 200, 336, 128, 28, 2702),
+    ("res4 conv3 1x1 256->1024 @50x84 (stays on the tile kernels)", 16, 50, 84, 256, 1024, 2256),
+])
+def test_wgrad_stream_full_shapes_auto_dispatch(F, name, b, h, w, cin, cout, code):
+    """Benchmark-shape 1x1 weight gradients through the automatic dispatch: the streaming kernel takes the stride-4 / stride-8
+    maps with the expected block configuration (the stride-16 layer stays where it was), and the result agrees with an fp32
+    reference formed on the GPU by torch (dW = dY^T X over all 268 800 / 1 075 200 pixels; independent of the HIP kernels)."""
+    g = torch.Generator().manual_seed(len(name))
+    x = torch.randn((b, h, w, cin), generator=g).bfloat16().to(DEV)
+    cp = (cout + 31) // 32 * 32
+    gy = torch.zeros((b, h, w, cp), dtype=torch.bfloat16, device=DEV)
+    gy[..., :cout] = torch.randn((b, h, w, cout), generator=g).bfloat16().to(DEV)
+    wd = (torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5).to(DEV).requires_grad_(True)
+    with forced():
+        y, _ = F._Conv2dFn.apply(x, wd, None, 1, 0, False, False)
+        y.backward(gy)
+        assert last_kernel() == code, (name, last_kernel())
+    ref = gy[..., :cout].reshape(-1, cout).float().t() @ x.reshape(-1, cin).float()
+    assert rel_err(wd.grad.reshape(cout, cin), ref) < 2e-3, name   # fp32 sums of the same bf16 products on both sides
+
+
 @pytest.mark.parametrize("variant", [4096, 4096 | (1 << 14)])
 @pytest.mark.parametrize("shape", [(2, 64, 64, 14, 14), (1, 128, 136, 13, 17), (3, 96, 200, 25, 42), (2, 64, 256, 40, 70),
                                    (2, 32, 8, 3, 11), (1, 32, 72, 5, 101)])

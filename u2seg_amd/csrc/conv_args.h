@@ -70,6 +70,13 @@ int launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* dw, long long dw
                       int c_valid, const bf16_t* zero, int B, int H, int W, int C, int x_ld, int N, int dy_ld, int rounds,
                       int force, hipStream_t s);
 
+// wgrad_stream.hip: 1x1 / stride 1 weight gradient over large maps - a persistent work-group per pixel range accumulates a whole
+// block of dW in registers, operands streamed once through an LDS ring of whole pixel rows; same return convention as
+// launch_conv_tile.  g_last_conv_kernel code: 2700 + block configuration.
+int launch_wgrad_stream(const bf16_t* x, const bf16_t* dy, float* dw, long long dw_sn, int dw_sc, int n_valid, int c_valid,
+                        const bf16_t* zero, int M, int C, int x_ld, int N, int dy_ld, int force, int tiny, int cfg, int per_cu,
+                        hipStream_t s);
+
 // Library-owned device scratch (conv_igemm.hip), one block per (device, stream, kind): the kernels of a stream run one after
 // the other, so consecutive launches share it.  Sized to the largest launch seen so far - allocated on first need, grown on
 // demand (the stream is drained before the old block is freed), never above `limit_bytes` (nullptr: the caller takes its

@@ -1441,6 +1441,17 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
   // one resident work-group per CU the transposing reads of a step are not hidden behind anything, while four resident
   // 128 x 128 groups hide them behind each other, which outweighs the halved operand traffic.
   variant = env_variant("U2_WGRAD_VARIANT", variant);
+  // 1x1 / stride 1 over large maps: streaming kernel with the whole dW block in registers (wgrad_stream.hip); variant bit 18
+  // forces it on any size, bit 19 forbids it (as does any of the per-tap kernel's own variant bits 0-11), bit 20: 8 pixel ranges
+  // only (tests), bits 21-23: block configuration (0 = automatic), bits 24-25: work-groups per CU (0 = the configuration's default)
+  if (KH * KW == 1 && stride == 1 && pad_h == 0 && pad_w == 0 && Hin == Hout && Win == Wout && !(variant & (1 << 19)) &&
+      (variant & 0xfff) == 0) {
+    const int rc = launch_wgrad_stream(a.x, a.dy, dw, dw_stride_n, dw_stride_c, n_valid, c_valid, a.zero, a.M, C, x_ld, N, dy_ld,
+                                       (variant >> 18) & 1, (variant >> 20) & 1, (variant >> 21) & 7, (variant >> 24) & 3,
+                                       (hipStream_t)stream);
+    if (rc == 1) return 0;
+    if (rc < 0) return rc;
+  }
   // 3x3 / stride 1 / pad 1: all nine taps per work-group, input halo in LDS (wgrad_halo.hip); variant bit 12 forces it,
   // bit 13 forbids it (as does any of the per-tap kernel's own variant bits 0-10), bits 14-15: rounds of work-groups (0 = one per CU);
   // automatic when a work-group gets >= 4000 positions to reduce

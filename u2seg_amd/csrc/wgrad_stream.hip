@@ -1,0 +1,286 @@
+// Streaming weight gradient of the 1x1 / stride-1 convolutions over large maps (gfx950, bf16 in / fp32 out):
+//
+//   dW[n][c] += sum over pixels m of dY[m][n] * X[m][c]
+//
+// autograd's weight gradient of F.conv2d behind detectron2/layers/wrappers.py:127-134 for conv1 / conv3 / shortcut of the res2 /
+// res3 bottlenecks (backbone/resnet.py:194-203), the FPN laterals (backbone/fpn.py:141-158), the semantic-head 1x1s
+// (meta_arch/semantic_seg.py:196-205) and the stem's im2col GEMM.
+//
+// Why (round-4 profile, profiles/r05_pmc_wgrad_sq.txt): these launches move 2 (N + C) bytes per pixel for 2 N C flop - 51 to 205
+// flop/B, HBM-bound by construction - and conv_wgrad_kernel ran them at 2.7-4.4 TB/s algorithmic with its waves parked 56 % of
+// the time: a work-group there is a (128 x 128 tile, pixel split) pair that lives for ~65 steps of 32 pixels with ONE step of
+// LDS-DMA in flight behind a drained wait, a 64-channel operand fills a quarter of its tile, an operand is streamed once per tile
+// of the other one, and 512-1024 work-groups each end in a 64 KB fp32 epilogue.  Here
+//   * a persistent work-group owns one contiguous pixel range for its whole life and accumulates a WHOLE (up to 256 x 256)
+//     block of dW in registers: every operand byte is read once by one work-group, one fp32 flush per work-group;
+//   * the LDS is a ring of 32-pixel steps; a step holds the dY rows and the X rows of its pixels as whole rows of NT / CT
+//     channels (64-1024 bytes, consecutive lanes of one LDS-DMA instruction), 16-byte chunks XOR-swizzled on the source side so
+//     that the transposing fragment reads (ds_read_b64_tr_b16: the reduction runs over pixels, both operands are pixel-strided)
+//     are conflict-free for every row length; 60-128 KB per CU in flight behind counted vmcnt waits, one raw barrier per step;
+//   * the MFMA operands of a step are read with 2 (FN + FC) transposing reads per wave for FN x FC MFMAs.
+// The flush adds the block into dW with fp32 atomics (other work-groups hold the other pixel ranges of the same block).
+#include <stdlib.h>
+
+#include "common.h"
+#include "conv_args.h"
+
+namespace u2conv {
+namespace {
+
+struct WsArgs {
+  const bf16_t* x;    // [M][x_ld]
+  const bf16_t* dy;   // [M][dy_ld]
+  float* dw;          // dw[n * dw_sn + c * dw_sc] += ..., n < n_valid, c < c_valid
+  long long dw_sn;
+  int dw_sc, n_valid, c_valid;
+  const bf16_t* zero;
+  int M, N, C, x_ld, dy_ld;   // N, C: physical channel counts of the rows (multiples of 8)
+  int tiles_n, tiles_c, ranges, steps;  // steps = ceil(M / 32); work-group = (pixel range, n-tile, c-tile)
+  int ring;
+};
+
+// XOR applied to the 16-byte chunk index of pixel row `pix` of a step image with rows of RB bytes.  A half-wave of
+// ds_read_b64_tr_b16 reads 32 bytes (one chunk pair) of each of the pixels {P .. P+3, P+8 .. P+11}; the eight pieces must cover
+// the 64 banks once.  RB >= 256: every row starts a bank row, eight different pairs (wgrad_halo.hip y_swz); RB = 128: two rows
+// per bank row, the four rows of equal parity need four different pairs (x_swz); RB = 64: four rows per bank row, rows P + k and
+// P + 8 + k need different pairs.
+template <int RB> __device__ __forceinline__ int ws_swz(int pix) {
+  if constexpr (RB >= 256) return ((pix & 3) << 1) | (pix & 8);
+  else if constexpr (RB == 128) return (((pix >> 1) & 1) | (((pix >> 3) & 1) << 1)) << 1;
+  else return ((pix >> 3) & 1) << 1;
+}
+
+__device__ __forceinline__ unsigned long long ws_tr_read(unsigned addr) {
+  unsigned long long r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
+union WsFrag {
+  unsigned long long u[2];
+  s16x8 v;
+};
+template <int N> __device__ __forceinline__ void ws_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// The MFMAs of column j (FN of them: every dY fragment against X fragment j) behind a counted wait: the X fragments were
+// requested in order after the dY fragments and LDS returns in order, so column j only needs the 2 (FC - 1 - j) youngest reads to
+// be outstanding still - the reads of the later columns land while the earlier columns multiply.
+template <int FN, int FC, int J = 0>
+__device__ __forceinline__ void ws_mfma_columns(f32x4 (&acc)[FN][FC], WsFrag (&yf)[FN], WsFrag (&xf)[FC]) {
+  if constexpr (J < FC) {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (FC - 1 - J)) : "memory");
+    asm volatile("" : "+v"(xf[J].u[0]), "+v"(xf[J].u[1])::"memory");   // ties the released registers to the wait
+    if constexpr (J == 0) {
+#pragma unroll
+      for (int i = 0; i < FN; ++i) asm volatile("" : "+v"(yf[i].u[0]), "+v"(yf[i].u[1])::"memory");
+    }
+#pragma unroll
+    for (int i = 0; i < FN; ++i) acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i].v, xf[J].v, acc[i][J], 0, 0, 0);
+    ws_mfma_columns<FN, FC, J + 1>(acc, yf, xf);
+  }
+}
+
+// WN x WC waves; a wave owns FN x FC blocks of 16 (n) x 16 (c): the work-group's block of dW is NT = WN FN 16 by CT = WC FC 16
+template <int WN, int WC, int FN, int FC>
+__global__ __launch_bounds__(WN * WC * 64, (WN * WC == 4 ? 2 : 1)) void wgrad_stream_kernel(const WsArgs a) {
+  constexpr int NWV = WN * WC, NT = WN * FN * 16, CT = WC * FC * 16;
+  constexpr int RBY = NT * 2, RBX = CT * 2;          // row bytes of the two step images
+  constexpr int PY = RBY / 32, PX = RBX / 32;        // 1 KB LDS-DMA pieces per step and image (32 rows x RB bytes)
+  constexpr int PT = PY + PX, PPW = PT / NWV, STAGE = PT * 1024;
+  static_assert(PT % NWV == 0 && PPW >= 1 && PPW <= 8 && RBY <= 1024 && RBX <= 1024 && RBY >= 64 && RBX >= 64, "unsupported block");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = w / WC, wc = w % WC;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // work-group -> (pixel range, tile): the tiles of one range stream the same pixels and sit on one XCD (b % 8)
+  const int tiles = a.tiles_n * a.tiles_c;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int range = (idx / tiles) * 8 + xcd;
+  const int tile = idx % tiles;
+  const int tile_n = tile / a.tiles_c, tile_c = tile - tile_n * a.tiles_c;
+  const int n0 = tile_n * NT, c0 = tile_c * CT;
+  const int s_beg = (int)((long long)a.steps * range / a.ranges), s_end = (int)((long long)a.steps * (range + 1) / a.ranges);
+  const int G = s_end - s_beg;
+  if (G <= 0) return;
+
+  // ---- LDS-DMA staging: piece p of a step (p < PY: dY rows, else X rows) = 1024 / RB consecutive pixel rows; lane i writes chunk
+  // position i % (RB / 16) of row i / (RB / 16), which holds source chunk position ^ swizzle(row).  Wave w moves pieces q NWV + w.
+  unsigned d_off[PPW];      // byte offset of the lane's source chunk from the operand's first row of the step
+  int d_row[PPW];           // pixel row of the step (bit 8: the chunk lies beyond the operand's channels -> zero page)
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    const int p = q * NWV + w;
+    const bool is_y = p < PY;
+    const int rb = is_y ? RBY : RBX, cpr = rb / 16;
+    const int piece = is_y ? p : p - PY;
+    const int row = piece * (1024 / rb) + lane / cpr;
+    const int pos = lane % cpr;
+    const int chunk = is_y ? (pos ^ ws_swz<RBY>(row)) : (pos ^ ws_swz<RBX>(row));
+    const int ch = (is_y ? n0 : c0) + chunk * 8;
+    const bool ok = ch < (is_y ? a.N : a.C);
+    d_row[q] = row | (ok ? 0 : 256);
+    d_off[q] = (unsigned)(((size_t)row * (is_y ? a.dy_ld : a.x_ld) + ch) * 2);
+  }
+  const unsigned char* yb = reinterpret_cast<const unsigned char*>(a.dy);
+  const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x);
+  const unsigned ypitch = (unsigned)a.dy_ld * 64u, xpitch = (unsigned)a.x_ld * 64u;   // bytes per 32-pixel step
+  auto issue = [&](int g, int slot) {
+    const int st = s_beg + g;
+    const int m0 = st * 32;
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const bool is_y = q * NWV + w < PY;    // wave-uniform
+      const unsigned char* base = is_y ? yb + (size_t)st * ypitch : xb + (size_t)st * xpitch;
+      const int row = d_row[q] & 255;
+      const unsigned char* src = (!(d_row[q] & 256) && m0 + row < a.M) ? base + d_off[q] : reinterpret_cast<const unsigned char*>(a.zero);
+      glds16(reinterpret_cast<const bf16_t*>(src), smem + slot * STAGE + (q * NWV + w) * 1024);
+    }
+  };
+
+  // ---- fragment addresses inside a stage.  A operand (dY^T): lane (fr, fg) of fragment i needs channel n = (wn FN + i) 16 + fr of
+  // pixels fg 8 .. + 7; the transposing read h (h = 0, 1) takes the address of 4 contiguous channels (fr & 3) 4 .. + 3 of pixel
+  // fg 8 + h 4 + (fr >> 2) and returns channel fr of pixels fg 8 + h 4 .. + 3.  The 16-channel block i only occupies bits 1-3 of the
+  // chunk index, disjoint from the wave's base and from the lane's bit 0: offset(i) = offset(0) ^ (i << 5).
+  const unsigned lds0 = (unsigned)(size_t)U2_LDS_PTR(smem);
+  unsigned yoff[2], xoff[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int pix = fg * 8 + h * 4 + (fr >> 2);
+    const int chy = wn * FN * 16 + (fr & 3) * 4, chx = wc * FC * 16 + (fr & 3) * 4;
+    yoff[h] = (unsigned)(pix * RBY + (((chy >> 3) ^ ws_swz<RBY>(pix)) << 4) + (chy & 7) * 2);
+    xoff[h] = (unsigned)(PY * 1024 + pix * RBX + (((chx >> 3) ^ ws_swz<RBX>(pix)) << 4) + (chx & 7) * 2);
+  }
+
+  f32x4 acc[FN][FC];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FC; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // a wave whose whole sub-block lies outside the valid N x C block (a 28-channel operand in a 64-wide block) only stages
+  const bool wave_active = (n0 + wn * FN * 16 < a.n_valid) && (c0 + wc * FC * 16 < a.c_valid);
+
+  // ---- pipeline: ring - 1 steps in flight; step g waits for its own pieces (counted), the barrier publishes the step and frees
+  // the slot of step g - 1 for step g + ring - 1
+  const int ring = a.ring;
+  for (int sl = 0; sl < ring - 1 && sl < G; ++sl) issue(sl, sl);
+  int slot = 0;
+  for (int g = 0; g < G; ++g) {
+    int nd = G - 1 - g;
+    if (nd > ring - 2) nd = ring - 2;
+    switch (nd) {
+      case 0: ws_wait_vm<0>(); break;
+      case 1: ws_wait_vm<PPW>(); break;
+      case 2: ws_wait_vm<2 * PPW>(); break;
+      case 3: ws_wait_vm<3 * PPW>(); break;
+      case 4: ws_wait_vm<4 * PPW>(); break;
+      case 5: ws_wait_vm<5 * PPW>(); break;
+      default: ws_wait_vm<6 * PPW>(); break;
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (g + ring - 1 < G) {
+      int s2 = slot - 1;
+      if (s2 < 0) s2 += ring;
+      issue(g + ring - 1, s2);
+    }
+    if (wave_active) {
+      const unsigned sb = lds0 + (unsigned)(slot * STAGE);
+      WsFrag yf[FN], xf[FC];
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) yf[i].u[h] = ws_tr_read(sb + (yoff[h] ^ (unsigned)(i << 5)));
+#pragma unroll
+      for (int j = 0; j < FC; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) xf[j].u[h] = ws_tr_read(sb + (xoff[h] ^ (unsigned)(j << 5)));
+      ws_mfma_columns<FN, FC>(acc, yf, xf);
+    }
+    slot = slot + 1 == ring ? 0 : slot + 1;
+  }
+
+  // ---- flush.  D[i = n][j = c]: lane holds column c = fr, rows n = fg 4 + r of its 16 x 16 blocks
+  if (!wave_active) return;
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FC; ++j) {
+      const int c = c0 + (wc * FC + j) * 16 + fr;
+      if (c >= a.c_valid) continue;
+      float* dst = a.dw + (size_t)c * a.dw_sc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + (wn * FN + i) * 16 + fg * 4 + r;
+        if (n < a.n_valid) atomicAdd(dst + n * a.dw_sn, acc[i][j][r]);
+      }
+    }
+}
+
+template <int WN, int WC, int FN, int FC>
+int launch_ws(WsArgs& a, int per_cu, int tiny, int code, hipStream_t s) {
+  constexpr int NWV = WN * WC, NT = WN * FN * 16, CT = WC * FC * 16;
+  constexpr int STAGE = (NT + CT) * 64;
+  a.tiles_n = (a.n_valid + NT - 1) / NT;
+  a.tiles_c = (a.c_valid + CT - 1) / CT;
+  const int tiles = a.tiles_n * a.tiles_c;
+  const int lds_budget = (per_cu == 2 ? 80 : 160) * 1024;
+  int ring = lds_budget / STAGE;
+  if (ring > 8) ring = 8;
+  if (const char* e = getenv("U2_WSTREAM_RING")) { const int r = atoi(e); if (r >= 2 && r < ring) ring = r; }  // measurement knob
+  if (ring < 2) return 0;
+  a.ring = ring;
+  // pixel ranges: one or two work-groups per CU in total, a multiple of 8 ranges (the tiles of a range share an XCD); never
+  // fewer than 2 steps per range
+  int ranges = tiny ? 8 : (256 * per_cu / tiles) & ~7;
+  if (ranges < 8) ranges = 8;
+  while (ranges > 8 && a.steps < 2 * ranges) ranges -= 8;
+  a.ranges = ranges;
+  static PerDeviceOnce attr_set;
+  if (attr_set.first()) {
+    (void)hipFuncSetAttribute((const void*)wgrad_stream_kernel<WN, WC, FN, FC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  g_last_conv_kernel = code;
+  hipLaunchKernelGGL((wgrad_stream_kernel<WN, WC, FN, FC>), dim3((unsigned)(ranges * tiles)), dim3(NWV * 64), (size_t)ring * STAGE, s, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return -1000 - (int)e;
+  return 1;
+}
+
+}  // namespace
+
+// 1x1 / stride 1 / unpadded weight gradients; returns 1 when it took the launch, 0 when the shape is not served, < 0 on a launch
+// failure.  `force`: every shape it can serve (tests); otherwise the large maps only.  cfg (tests / A-B runs): 0 = automatic,
+// 1 = 256(n) x 64(c), 2 = 64 x 256, 3 = 128 x 128, 4 = 256 x 256 (8 waves).  g_last_conv_kernel code: 2700 + configuration.
+int launch_wgrad_stream(const bf16_t* x, const bf16_t* dy, float* dw, long long dw_sn, int dw_sc, int n_valid, int c_valid,
+                        const bf16_t* zero, int M, int C, int x_ld, int N, int dy_ld, int force, int tiny, int cfg, int per_cu,
+                        hipStream_t s) {
+  if ((C & 7) || (N & 7) || (x_ld & 7) || (dy_ld & 7) || M < 1 || n_valid < 1 || c_valid < 1) return 0;
+  if ((unsigned long long)M * (unsigned)x_ld * 2ull >= 0xffffffffull || (unsigned long long)M * (unsigned)dy_ld * 2ull >= 0xffffffffull) return 0;
+  WsArgs a;
+  a.x = x; a.dy = dy; a.dw = dw; a.dw_sn = dw_sn; a.dw_sc = dw_sc; a.n_valid = n_valid; a.c_valid = c_valid; a.zero = zero;
+  a.M = M; a.N = N; a.C = C; a.x_ld = x_ld; a.dy_ld = dy_ld;
+  a.steps = (M + 31) / 32;
+  if (!force && M < 200000) return 0;   // >= ~25 steps per work-group: shorter launches stay on the tile kernels
+  if (cfg == 0) {
+    // the block shape follows the operands: the wider one along its 256, blocks beyond 256 x 256 are tiled (the narrower
+    // operand is then re-read from L2 by the tiles of a range)
+    // measured (tests/native/selftest bench2w, round 5): 128 x 128 blocks of two work-groups per CU beat the 256 x 256 block of
+    // one 8-wave work-group wherever that block would be tiled or half empty (res3 128 <-> 512: 0.084 vs 0.113 ms, 512 -> 256:
+    // 0.111 vs 0.129); on the full 256 x 256 layer the two are within 6 %
+    if (n_valid <= 64 && c_valid <= 64) cfg = 3;
+    else if (c_valid <= 64) cfg = 1;
+    else if (n_valid <= 64) cfg = 2;
+    else if (n_valid > 128 && n_valid <= 256 && c_valid > 128 && c_valid <= 256) cfg = 4;
+    else cfg = 3;
+  }
+  switch (cfg) {
+    case 1: return launch_ws<4, 1, 4, 4>(a, per_cu ? per_cu : 2, tiny, 2701, s);
+    case 2: return launch_ws<1, 4, 4, 4>(a, per_cu ? per_cu : 2, tiny, 2702, s);
+    case 3: return launch_ws<2, 2, 4, 4>(a, per_cu ? per_cu : 2, tiny, 2703, s);
+    case 4: return launch_ws<4, 2, 4, 8>(a, 1, tiny, 2704, s);
+    default: return 0;
+  }
+}
+
+}  // namespace u2conv
