@@ -197,8 +197,12 @@ int u2_box_reg_l1(const void* pred, const float* prop, const float* gtb, const v
 /* ---- ROI bookkeeping (roi.hip) -----------------------------------------------------------------
  * layers/roi_align.py:49-65 via modeling/poolers.py:206-263; structures/masks.py:191-218; modeling/poolers.py:23-59;
  * structures/boxes.py:312-358 + modeling/matcher.py:62-127; modeling/box_regression.py:78-116; layers/nms.py:9-20. */
+/* `order` (may be NULL): a permutation of 0 .. R-1, the order the ROIs are PROCESSED in (results stay at their own rows of `out`):
+ * with ROIs sorted by (level, image, row) the work-groups running at any one time read neighbouring feature rows, and each XCD
+ * takes a contiguous part of the list, so its L2 keeps the band it is working on. */
 int u2_roi_align_fwd(const void* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels,
-                     const float* rois, const int* level, void* out, int R, int C, int PH, int PW, void* stream);
+                     const float* rois, const int* level, const int* order, void* out, int R, int C, int PH, int PW,
+                     void* stream);
 int u2_roi_align_bwd(float* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,
                      const float* rois, const int* level, const void* dout, int R, int C, int PH, int PW, float gscale,
                      void* stream);

@@ -663,6 +663,10 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
       if (N >= 4096) sel = 1;                                      // fc1 data gradient (N = 12544)
       else if (a.M < 10000 && N <= 1024) sel = 0;                  // small fully connected layers
       else if (K >= 2048) sel = 2;
+      // round 5 (profiles/r05_conv_laggards.txt): the stride-16 1x1 layers with K = 1024 (res4 conv1 and the data gradient of
+      // conv3, 525 tiles of 256 ch x 128 px on 512 slots = two rounds, the second one 13 tiles) run 11 % faster as 263 tiles of
+      // 256 x 256 in equal stream-K shares: 0.065 -> 0.058 ms
+      else if (K >= 1024 && N >= 256 && t256 > 256 && t256 < 768) sel = 1;
       else sel = 4;                                                // 1x1 layers: 256 ch x 128 px, two groups per CU
     }
     if (sel == 0) return 0;

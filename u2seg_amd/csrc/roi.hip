@@ -9,6 +9,9 @@
 //   pairwise_iou + Matcher                                                  structures/boxes.py:312-358, modeling/matcher.py:62-127
 //   Box2BoxTransform.apply_deltas + Boxes.clip                              modeling/box_regression.py:78-116, structures/boxes.py:172-181
 //   batched_nms (per-group NMS, suppress iff IoU > thr)                      detectron2/layers/nms.py:9-20
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 #include "u2seg_hip.h"
 
@@ -19,6 +22,7 @@ struct RoiLevels {
   float* gfeat[4];
   int H[4], W[4];
   float scale[4];
+  int flags = 0;   // bit 0 (A/B runs: U2_ROI_FWD=bins): the forward pass takes the one-item-per-bin form of rounds 1-4
 };
 
 __device__ __forceinline__ bool bil_prep(float y, float x, int H, int W, int& yl, int& xl, int& yh, int& xh, float& w1,
@@ -142,13 +146,77 @@ __device__ __forceinline__ float axis_weight(float pos, int n, int p) {
 // ---------------------------------------------------------------------------------------------
 constexpr int FS_MAXP = 14, FS_MAXR = 16;
 
+// One work item = (bin row ph, 8-channel chunk) sweeping ALL bin columns of the row (round 5).  Neighbouring bins overlap by one or
+// two pixel columns (bin pw ends at floor(last sample) + 1, bin pw + 1 starts at floor(its first sample) >= floor(that last sample)),
+// and with one item per bin those columns were fetched once per bin: (roi width + 2 P) loads per pixel row where (roi width + 2) do,
+// 1.4-1.75x the 16-byte L1 / L2 requests for ROIs of 14-28 pixels - and the pass is bound by exactly those requests (19 TB/s of
+// them at inference, SQ counters: 71 % of the wave cycles parked on memory, profiles/r05_pmc_roi.txt).  The item keeps the last
+// two pixels it loaded; every bin still adds its terms in (ky, kx) order with the same products, so the result is bit-identical
+// to the per-bin form.
+template <int PP>
+__device__ __forceinline__ void roi_fwd_bin_rows(const bf16_t* __restrict__ f, size_t plane, int W, int C, int cpr,
+                                                 const float (*wtab)[FS_MAXP][FS_MAXR], const int (*lo)[FS_MAXP],
+                                                 const int (*cnt)[FS_MAXP], float inv_cnt, bf16_t* __restrict__ out, int r, int tid) {
+  for (int it = tid; it < PP * cpr; it += 256) {
+    const int cc = it % cpr, ph = it / cpr;
+    float acc[PP][8];
+#pragma unroll
+    for (int pw = 0; pw < PP; ++pw)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[pw][e] = 0.f;
+    const int ny = cnt[0][ph], y0 = lo[0][ph];
+    for (int ky = 0; ky < ny; ++ky) {
+      const float a = wtab[0][ph][ky];
+      if (a == 0.f) continue;
+      const bf16_t* rowp = f + (plane + (size_t)(y0 + ky) * W) * C + cc * 8;
+      int cx0 = -1, cx1 = -1;
+      uint4 cv0 = make_uint4(0, 0, 0, 0), cv1 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int pw = 0; pw < PP; ++pw) {
+        const int nx = cnt[1][pw], x0 = lo[1][pw];
+        for (int kx = 0; kx < nx; ++kx) {
+          const float wgt = a * wtab[1][pw][kx];
+          if (wgt == 0.f) continue;
+          const int x = x0 + kx;
+          uint4 u;
+          if (x == cx1) {
+            u = cv1;
+          } else if (x == cx0) {
+            u = cv0;
+          } else {
+            u = *reinterpret_cast<const uint4*>(rowp + (size_t)x * C);
+            cv0 = cv1; cx0 = cx1;
+            cv1 = u; cx1 = x;
+          }
+          const unsigned wd[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[pw][2 * e] += wgt * __uint_as_float(wd[e] << 16);
+            acc[pw][2 * e + 1] += wgt * __uint_as_float(wd[e] & 0xffff0000u);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int pw = 0; pw < PP; ++pw) {
+      bf16_t o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[pw][e] * inv_cnt);
+      *reinterpret_cast<uint4*>(out + (((size_t)r * PP + ph) * PP + pw) * C + cc * 8) = *reinterpret_cast<const uint4*>(o);
+    }
+  }
+}
+
+// PT: 7 / 14 = the bin-row form for that pooled size (its own instantiation: 56 / 112 accumulator registers), 0 = one item per bin
+template <int PT>
 __global__ __launch_bounds__(256) void roi_align_fwd_sep_kernel(const RoiLevels lv, const float* __restrict__ rois,
-                                                                const int* __restrict__ level, bf16_t* __restrict__ out, int C,
-                                                                int P) {
+                                                                const int* __restrict__ level, const int* __restrict__ order,
+                                                                bf16_t* __restrict__ out, int C, int P) {
   __shared__ float wtab[2][FS_MAXP][FS_MAXR];
   __shared__ int lo[2][FS_MAXP], cnt[2][FS_MAXP];
   __shared__ int s_fallback;
-  const int r = blockIdx.x;
+  // processing order: XCD x (work-groups x, x + 8, ...) takes a contiguous part of the (sorted) list
+  const int r = order ? order[xcd_remap((int)blockIdx.x, (int)gridDim.x)] : (int)blockIdx.x;
   const int tid = threadIdx.x;
   const int l = level[r];
   const int H = lv.H[l], W = lv.W[l];
@@ -230,6 +298,10 @@ __global__ __launch_bounds__(256) void roi_align_fwd_sep_kernel(const RoiLevels 
     wtab[axis][bin][k] = sum;
   }
   __syncthreads();
+  if constexpr (PT > 0) {
+    roi_fwd_bin_rows<PT>(f, plane, W, C, cpr, wtab, lo, cnt, inv_cnt, out, r, tid);
+    return;
+  }
   // (A rows-then-columns form - T[x][c] = sum_y Wy[ph][y] feat[y][x][c] per bin row staged in LDS as fp32, then the column sums -
   // reads every pixel of a bin row once, 22 k instead of 39 k 16-byte loads per 7 x 7 ROI, but its 40 KB stage leaves three
   // work-groups per CU and two barriers per bin row: measured equal to this one-pass form in training (1.36 ms per step) and at
@@ -761,7 +833,8 @@ static int ew_blocks(size_t total) {
 }
 
 extern "C" int u2_roi_align_fwd(const void* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels,
-                                const float* rois, const int* level, void* out, int R, int C, int PH, int PW, void* stream) {
+                                const float* rois, const int* level, const int* order, void* out, int R, int C, int PH, int PW,
+                                void* stream) {
   if (nlevels < 1 || nlevels > 4 || (C & 7)) return -1;
   if (R <= 0) return 0;
   RoiLevels lv;
@@ -770,8 +843,17 @@ extern "C" int u2_roi_align_fwd(const void* const* feats, const int* Hs, const i
     lv.feat[l] = (const bf16_t*)feats[s]; lv.gfeat[l] = nullptr; lv.H[l] = Hs[s]; lv.W[l] = Ws[s]; lv.scale[l] = scales[s];
   }
   if (PH == PW && PH <= FS_MAXP) {  // separable per-ROI kernel
-    hipLaunchKernelGGL(roi_align_fwd_sep_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, lv, rois, level, (bf16_t*)out, C,
-                       PH);
+    // measured (scratch-style A/B, 32 000 ROIs of 7 x 7 / 3 200 of 14 x 14, round 5): the bin-row form needs 28 % fewer L1 accesses
+    // and is 14 % / 44 % SLOWER (1.70 vs 1.49 ms, 0.62 vs 0.43) - the pass is bound by L2 misses (42 % hit rate, 6 GB of fabric
+    // reads per launch for 1.5 GB of maps, profiles/r05_pmc_roi.txt), not by hits; it stays selectable (U2_ROI_FWD=rows)
+    static const int per_bin = [] { const char* e = getenv("U2_ROI_FWD"); return e && !strcmp(e, "rows") ? 0 : 1; }();
+    lv.flags = per_bin;
+    if (PH == 7 && !per_bin)
+      hipLaunchKernelGGL(roi_align_fwd_sep_kernel<7>, dim3(R), dim3(256), 0, (hipStream_t)stream, lv, rois, level, order, (bf16_t*)out, C, PH);
+    else if (PH == 14 && !per_bin)
+      hipLaunchKernelGGL(roi_align_fwd_sep_kernel<14>, dim3(R), dim3(256), 0, (hipStream_t)stream, lv, rois, level, order, (bf16_t*)out, C, PH);
+    else
+      hipLaunchKernelGGL(roi_align_fwd_sep_kernel<0>, dim3(R), dim3(256), 0, (hipStream_t)stream, lv, rois, level, order, (bf16_t*)out, C, PH);
     U2_CHECK_LAUNCH();
     return 0;
   }

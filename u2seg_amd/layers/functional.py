@@ -1090,6 +1090,15 @@ def roi_grad_tap(feats):
     return list(outs)
 
 
+ROI_ORDER_MIN = int(os.environ.get("U2_ROI_ORDER_MIN", "1000000000"))
+
+
+def _roi_process_order(rois, levels, nimg, nlevels):
+    """Processing order of the ROIAlign forward: sorted by (level, image, top row of the box at its level / 8)."""
+    key = (levels.long() * nimg + rois[:, 0].long()) * 4096 + (rois[:, 2] * (0.25 / 8)).long().clamp_(0, 4095)
+    return torch.argsort(key).to(torch.int32)
+
+
 class _ROIAlignFn(Function):
     """Multi-level ROIAlign(aligned=True, sampling_ratio=0) (modeling/poolers.py:206-263)."""
 
@@ -1105,7 +1114,8 @@ class _ROIAlignFn(Function):
         ptrs = (ctypes.c_void_p * nl)(*[f.data_ptr() for f in feats])
         hs, ws, sc = _level_arrays(feats, scales)
         out = torch.empty((r, out_size, out_size, c), dtype=BF16, device=rois.device)
-        _hip.call("u2_roi_align_fwd", ptrs, hs, ws, sc, nl, rois.contiguous(), levels.contiguous(), out, r, c, out_size,
+        order = _roi_process_order(rois, levels, feats[0].shape[0], nl) if r >= ROI_ORDER_MIN else None
+        _hip.call("u2_roi_align_fwd", ptrs, hs, ws, sc, nl, rois.contiguous(), levels.contiguous(), order, out, r, c, out_size,
                   out_size)
         ctx.save_for_backward(rois, levels)
         ctx.cfg = (out_size, scales, grad_scale, [tuple(f.shape) for f in feats])
