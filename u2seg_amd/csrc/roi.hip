@@ -145,6 +145,16 @@ __device__ __forceinline__ float axis_weight(float pos, int n, int p) {
 // feature pixel its bin touches exactly once (~25-36 reads) instead of 4 per sample (64 at 4 x 4 samples per bin).
 // ---------------------------------------------------------------------------------------------
 constexpr int FS_MAXP = 14, FS_MAXR = 16;
+// Waves per SIMD the forward kernel is compiled for.  The pass is bound by the latency of one dependent 16-byte load per thread
+// times the number of threads resident (71-75 % of the wave cycles parked, 3.4 TB/s through the L1s): at 92 registers five
+// waves fit a SIMD, at <= 64 eight - measured 1.48 -> 1.23 ms for 32 000 ROIs of 7 x 7, 0.44 -> 0.37 for 3 200 of 14 x 14
+// (profiles/r05_pmc_roi.txt; the handful of spilled registers sit in the sample-by-sample fall-back)
+#ifndef FS_OCC
+#define FS_OCC 8
+#endif
+#ifndef FS_PAIR
+#define FS_PAIR 1
+#endif
 
 // One work item = (bin row ph, 8-channel chunk) sweeping ALL bin columns of the row (round 5).  Neighbouring bins overlap by one or
 // two pixel columns (bin pw ends at floor(last sample) + 1, bin pw + 1 starts at floor(its first sample) >= floor(that last sample)),
@@ -209,7 +219,7 @@ __device__ __forceinline__ void roi_fwd_bin_rows(const bf16_t* __restrict__ f, s
 
 // PT: 7 / 14 = the bin-row form for that pooled size (its own instantiation: 56 / 112 accumulator registers), 0 = one item per bin
 template <int PT>
-__global__ __launch_bounds__(256) void roi_align_fwd_sep_kernel(const RoiLevels lv, const float* __restrict__ rois,
+__global__ __launch_bounds__(256, FS_OCC) void roi_align_fwd_sep_kernel(const RoiLevels lv, const float* __restrict__ rois,
                                                                 const int* __restrict__ level, const int* __restrict__ order,
                                                                 bf16_t* __restrict__ out, int C, int P) {
   __shared__ float wtab[2][FS_MAXP][FS_MAXR];
@@ -317,7 +327,27 @@ __global__ __launch_bounds__(256) void roi_align_fwd_sep_kernel(const RoiLevels 
       const float a = wtab[0][ph][ky];
       if (a == 0.f) continue;
       const bf16_t* rowp = f + (plane + (size_t)(y0 + ky) * W + x0) * C + cc * 8;
-      for (int kx = 0; kx < nx; ++kx) {  // (four loads in flight per item measured 9 % slower: the loop is L2-throughput-bound)
+      int kx = 0;
+#if FS_PAIR
+      // two pixels of the row in flight per thread (the pass is latency-bound: profiles/r05_pmc_roi.txt); both loads are issued
+      // whatever their weights (every tabulated pixel lies inside the map), the terms are still added in kx order and a zero
+      // weight still adds nothing, so the result keeps its bits
+      for (; kx + 1 < nx; kx += 2) {
+        const float w0 = a * wtab[1][pw][kx], w1 = a * wtab[1][pw][kx + 1];
+        bf16_t v0[8], v1[8];
+        *reinterpret_cast<uint4*>(v0) = *reinterpret_cast<const uint4*>(rowp + (size_t)kx * C);
+        *reinterpret_cast<uint4*>(v1) = *reinterpret_cast<const uint4*>(rowp + (size_t)(kx + 1) * C);
+        if (w0 != 0.f) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += w0 * bf2f(v0[e]);
+        }
+        if (w1 != 0.f) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += w1 * bf2f(v1[e]);
+        }
+      }
+#endif
+      for (; kx < nx; ++kx) {
         const float wgt = a * wtab[1][pw][kx];
         if (wgt == 0.f) continue;
         bf16_t v[8];
