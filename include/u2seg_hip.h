@@ -48,6 +48,16 @@ int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int B, int Hin,
                        int stride, int n_valid, int c_valid, long long dw_stride_n, int dw_stride_tap,
                        int dw_stride_c, int variant, void* stream);
 
+/* Both gradients of a 1x1 / stride-1 convolution in ONE pass over dy (autograd's conv backward behind layers/wrappers.py:127-134
+ * for the expanding 1x1 layers of the bottlenecks, backbone/resnet.py:194-203): dx[m][c] = sum_n dy[m][n] wt[c][n] (bf16, all dx_ld
+ * physical channels written) and dw[n * dw_stride_n + c * dw_stride_c] += sum_m dy[m][n] x[m][c] (fp32, n < n_valid, c < c_valid).
+ * wt is the data-gradient layout of the filter, [C][wt_ld] with n contiguous (u2_weight_layout mode 1).  Returns 0 when launched,
+ * 1 when the shape is not served (blocks of N <= 256 by C <= 64 or N <= 512 by C <= 128 over >= 200 000 pixels; variant bit 0
+ * lifts the size rule, bit 1: 8 pixel ranges, bit 2: never) - the caller then issues u2_conv_igemm + u2_conv_wgrad_into. */
+int u2_conv1x1_bwd_fused(const void* x, const void* dy, const void* wt, void* dx, float* dw, int M, int C, int x_ld, int N, int dy_ld,
+                         int wt_ld, int dx_ld, int n_valid, int c_valid, long long dw_stride_n, int dw_stride_c, int variant,
+                         void* stream);
+
 /* Test / debugging aid: a code for the kernel (family, tile configuration) the most recent u2_conv_igemm or u2_conv_wgrad
  * call on this thread selected (encoding in csrc/conv_args.h).  With variant 0 the selection can be steered through the
  * environment variables U2_CONV_VARIANT / U2_WGRAD_VARIANT (same bits as the variant argument). */

@@ -142,6 +142,40 @@ static int test_wgrad(const WgCase& c, int variant, bool into = false) {
   return ok ? 0 : 1;
 }
 
+// u2_conv1x1_bwd_fused: dx = dy . W and dW += dy^T x in one pass over dy (wgrad_stream_kernel<.., DG>)
+static int test_wdgrad(int M, int C, int N, int cv, int nv, int variant, const char* name) {
+  std::vector<uint16_t> hx((size_t)M * C), hdy((size_t)M * N), hwt((size_t)C * N);
+  for (auto& v : hx) v = f2bf(frand());
+  for (auto& v : hdy) v = f2bf(frand());
+  for (auto& v : hwt) v = f2bf(frand() * 0.25f);      // wt[c][n]
+  for (int m = 0; m < M; ++m) for (int n = nv; n < N; ++n) hdy[(size_t)m * N + n] = 0;   // pad channels of dy are zero
+  DBuf<uint16_t> dx_in(hx.size()), ddy(hdy.size()), dwt(hwt.size()), ddx((size_t)M * C);
+  DBuf<float> ddw((size_t)nv * cv);
+  dx_in.up(hx); ddy.up(hdy); dwt.up(hwt);
+  std::vector<uint16_t> junk((size_t)M * C, 0x7fc0); ddx.up(junk);
+  int rc = u2_conv1x1_bwd_fused(dx_in.d, ddy.d, dwt.d, ddx.d, ddw.d, M, C, C, N, N, N, C, nv, cv, (long long)cv, 1, variant, nullptr);
+  HIPCHK(hipDeviceSynchronize());
+  if (rc) { printf("FAIL %-28s v%d launch rc=%d\n", name, variant, rc); return 1; }
+  auto gdx = ddx.down(); auto gdw = ddw.down();
+  double e1 = 0, r1 = 0, e2 = 0, r2 = 0;
+  for (int m = 0; m < M; ++m)
+    for (int c = 0; c < C; ++c) {
+      double acc = 0;
+      for (int n = 0; n < N; ++n) acc += (double)bf2f(hdy[(size_t)m * N + n]) * bf2f(hwt[(size_t)c * N + n]);
+      e1 = fmax(e1, fabs(acc - bf2f(gdx[(size_t)m * C + c]))); r1 = fmax(r1, fabs(acc));
+    }
+  std::vector<double> ref((size_t)nv * cv, 0.0);
+  for (int m = 0; m < M; ++m)
+    for (int n = 0; n < nv; ++n) {
+      const double g = bf2f(hdy[(size_t)m * N + n]);
+      for (int c = 0; c < cv; ++c) ref[(size_t)n * cv + c] += g * bf2f(hx[(size_t)m * C + c]);
+    }
+  for (size_t i = 0; i < ref.size(); ++i) { e2 = fmax(e2, fabs(ref[i] - gdw[i])); r2 = fmax(r2, fabs(ref[i])); }
+  const bool ok = e1 <= 0.01 * r1 + 1e-3 && e2 <= 2e-3 * r2 + 1e-3 && u2_conv_last_kernel() / 10 == 275;
+  printf("%s %-28s v%d  dx err %.4g (max %.4g)  dW err %.4g (max %.4g)  kernel %d\n", ok ? "PASS" : "FAIL", name, variant, e1, r1, e2, r2, u2_conv_last_kernel());
+  return ok ? 0 : 1;
+}
+
 static void bench_conv(const char* name, int B, int H, int W, int C, int N, int K, int pad, int stride, int variant) {
   const int Hout = (H + 2 * pad - K) / stride + 1, Wout = (W + 2 * pad - K) / stride + 1;
   const size_t M = (size_t)B * Hout * Wout;
@@ -385,6 +419,56 @@ int main(int argc, char** argv) {
       {2, 40, 70, 512, 128, 1, 1, 0, 1, "wstream 40x70 c512 n128"},
       {1, 1, 5, 64, 64, 1, 1, 0, 1, "wstream 5 px"},
   };
+  if (argc > 1 && !strcmp(argv[1], "bench_wd")) {
+    // both gradients of a 1x1 layer: two launches (u2_conv_igemm as the data gradient + u2_conv_wgrad) vs u2_conv1x1_bwd_fused
+    const int shapes[][3] = {{16 * 200 * 336, 64, 256}, {16 * 100 * 168, 128, 512}, {16 * 200 * 336, 32, 256}, {16 * 100 * 168, 64, 512}};
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    for (const auto& sh : shapes) {
+      const int M = sh[0], C = sh[1], N = sh[2];
+      DBuf<uint16_t> dx_in((size_t)M * C), ddy((size_t)M * N), dwt((size_t)C * N), ddx((size_t)M * C);
+      DBuf<float> ddw((size_t)N * C);
+      std::vector<uint16_t> pat((size_t)1 << 22);
+      for (auto& v : pat) v = f2bf(frand());
+      for (size_t o = 0; o < ddy.n; o += pat.size()) HIPCHK(hipMemcpy(ddy.d + o, pat.data(), std::min(pat.size(), ddy.n - o) * 2, hipMemcpyHostToDevice));
+      for (size_t o = 0; o < dx_in.n; o += pat.size()) HIPCHK(hipMemcpy(dx_in.d + o, pat.data(), std::min(pat.size(), dx_in.n - o) * 2, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(dwt.d, pat.data(), dwt.n * 2, hipMemcpyHostToDevice));
+      std::vector<float> t[2];
+      for (int r = 0; r < 5; ++r)
+        for (int mode = 0; mode < 2; ++mode) {
+          auto run = [&]() {
+            if (mode == 0) {
+              u2_conv_igemm(ddy.d, dwt.d, ddx.d, nullptr, nullptr, 1, M, 1, N, N, M, 1, C, C, 1, 1, 0, 0, 1, 1, 0, 0, 0, nullptr);
+              u2_conv_wgrad(dx_in.d, ddy.d, ddw.d, 1, M, 1, C, C, M, 1, N, N, 1, 1, 0, 0, 1, 0, nullptr);
+            } else {
+              u2_conv1x1_bwd_fused(dx_in.d, ddy.d, dwt.d, ddx.d, ddw.d, M, C, C, N, N, N, C, N, C, (long long)C, 1, 1, nullptr);
+            }
+          };
+          run();
+          HIPCHK(hipEventRecord(e0));
+          for (int i = 0; i < 3; ++i) run();
+          HIPCHK(hipEventRecord(e1)); HIPCHK(hipEventSynchronize(e1));
+          float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+          t[mode].push_back(ms / 3);
+        }
+      std::sort(t[0].begin(), t[0].end()); std::sort(t[1].begin(), t[1].end());
+      const double by2 = 2.0 * ((double)M * N * 2 + (double)M * C * 2), by1 = 2.0 * ((double)M * N + (double)M * C * 2);
+      printf("BENCH_WD M=%d %d->%d  two launches %.3f ms (%.2f TB/s of their %.0f MB)   fused %.3f ms (%.2f TB/s of its %.0f MB)\n", M, C, N,
+             t[0][2], by2 / t[0][2] * 1e-9, by2 * 1e-6, t[1][2], by1 / t[1][2] * 1e-9, by1 * 1e-6);
+    }
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "wdgrad")) {
+    for (int v = 1; v <= 3; v += 2) {   // forced, full grid / forced, 8 pixel ranges
+      fails += test_wdgrad(37 * 29, 64, 256, 64, 256, v, "wdgrad 64->256");
+      fails += test_wdgrad(33 * 21 * 2, 40, 200, 37, 196, v, "wdgrad 40->200 (tails)");
+      fails += test_wdgrad(19 * 45, 128, 512, 128, 512, v, "wdgrad 128->512");
+      fails += test_wdgrad(45 * 23, 72, 264, 70, 260, v, "wdgrad 72->264 (wide, tails)");
+      fails += test_wdgrad(5, 32, 136, 32, 136, v, "wdgrad 5 px");
+      fails += test_wdgrad(40 * 70, 8, 16, 8, 16, v, "wdgrad 8->16");
+    }
+    printf("SELFTEST wdgrad %s (%d failures)\n", fails ? "FAILED" : "OK", fails);
+    return fails ? 1 : 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "wstream")) {
     for (int cfg = 0; cfg <= 4; ++cfg)
       for (int tiny = 0; tiny < 2; ++tiny)

@@ -659,7 +659,7 @@ def test_reference_checkpoint_on_the_device_and_resume(F, tmp_path):
     params = dict(model.named_parameters())
     disp = {}
     for k in fx["param_norm"]:
-        assert float(params[k].double().norm()) == pytest.approx(fx["param_norm"][k], rel=1e-3), k
+        assert float(params[k].detach().double().norm()) == pytest.approx(fx["param_norm"][k], rel=1e-3), k
         disp[k] = (float((params[k].detach() - at_save[k]).double().norm()), fx["param_delta_norm_since_save"][k])
     print(json.dumps(disp, indent=1))
     for k, (got, want) in disp.items():

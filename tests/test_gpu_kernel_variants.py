@@ -314,6 +314,83 @@ def test_wgrad_stream_full_shapes_auto_dispatch(F, name, b, h, w, cin, cout, cod
     assert rel_err(wd.grad.reshape(cout, cin), ref) < 2e-3, name   # fp32 sums of the same bf16 products on both sides
 
 
+@pytest.mark.parametrize("tiny", [0, 1])
+def test_fused_1x1_backward(F, tiny):
+    """u2_conv1x1_bwd_fused (wgrad_stream_kernel<.., DG>): the data gradient and the weight gradient of a 1x1 / stride-1 conv in
+    one pass over the output gradient - reached from _Conv2dFn.backward when the weight owns an arena slot (solver.FlatSGD) -
+    forced on small maps (U2_WDGRAD_VARIANT bit 0; the automatic rule takes >= 200 000 pixels), both block shapes (all of N <= 256
+    by 64 input channels; N <= 512 by 64 in two c-tiles), pixel counts that are no multiple of the 32-pixel step, channel tails
+    on both sides, vs fp32: dx at one bf16 step, dW like the other weight-gradient kernels; the padded input channels of dx are
+    written as zeros.  The same module without the fused launch (bit 2: never) gives the same gradients to fp32 summation order."""
+    from u2seg_amd.layers.modules import Conv2d
+    from u2seg_amd.solver import FlatSGD
+
+    old_min = F.FUSED_BWD_MIN_PIXELS
+    g = torch.Generator().manual_seed(40 + tiny)
+    try:
+        F.FUSED_BWD_MIN_PIXELS = 0
+        for (b, cin, cout, h, w_, code) in ((1, 64, 256, 37, 29, 2751), (2, 40, 200, 33, 21, 2751), (1, 128, 512, 19, 45, 2752),
+                                           (1, 72, 264, 45, 23, 2752)):
+            x = bf(torch.randn((b, cin, h, w_), generator=g))
+            w = torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5
+            xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            yr = TF.conv2d(xr, bf(wr), None, 1, 0)
+            gy = bf(torch.randn(yr.shape, generator=g))
+            yr.backward(gy)
+            got = {}
+            for mode, variant in (("fused", 1 | (2 if tiny else 0)), ("separate", 4)):
+                conv = Conv2d(cin, cout, 1, bias=False).to(DEV)
+                with torch.no_grad():
+                    conv.weight.copy_(w.to(DEV))
+                opt = FlatSGD(conv, lr=0.1)
+                opt.zero_grad()
+                xd = nhwc(x).requires_grad_(True)
+                old = os.environ.get("U2_WDGRAD_VARIANT")
+                os.environ["U2_WDGRAD_VARIANT"] = str(variant)
+                try:
+                    y = conv(xd)
+                    y.backward(nhwc(gy))
+                    if mode == "fused":
+                        assert last_kernel() == code, (cin, cout, last_kernel())
+                finally:
+                    os.environ.pop("U2_WDGRAD_VARIANT") if old is None else os.environ.__setitem__("U2_WDGRAD_VARIANT", old)
+                F.join_all_streams()
+                got[mode] = (nchw(xd.grad, cin), conv.weight.grad.detach().float().cpu().clone(), xd.grad[..., cin:].float().abs().max() if xd.grad.shape[3] > cin else torch.zeros(()))
+            for mode, (dx, dw, padmax) in got.items():
+                assert rel_err(dx, xr.grad) < ULP, (mode, cin, cout)
+                assert rel_err(dw, wr.grad) < WG_TOL, (mode, cin, cout)
+                assert float(padmax) == 0.0, (mode, cin, cout)
+            assert rel_err(got["fused"][1], got["separate"][1]) < 1e-5     # fp32 sums of the same products
+    finally:
+        F.FUSED_BWD_MIN_PIXELS = old_min
+
+
+def test_fused_1x1_backward_full_shape_auto(F):
+    """res2 conv3 (1x1 64 -> 256 over 16 x 200 x 336 pixels) through the automatic dispatch: the fused launch (code 2751) takes it;
+    dW against an fp32 reference formed by torch on the GPU over all 1 075 200 pixels, dx at 4096 sampled pixels."""
+    from u2seg_amd.layers.modules import Conv2d
+    from u2seg_amd.solver import FlatSGD
+
+    g = torch.Generator().manual_seed(77)
+    b, h, w_, cin, cout = 16, 200, 336, 64, 256
+    x = torch.randn((b, h, w_, cin), generator=g).bfloat16().to(DEV).requires_grad_(True)
+    gy = torch.randn((b, h, w_, cout), generator=g).bfloat16().to(DEV)
+    conv = Conv2d(cin, cout, 1, bias=False).to(DEV)
+    opt = FlatSGD(conv, lr=0.1)
+    opt.zero_grad()
+    with forced():
+        y = conv(x)
+        y.backward(gy)
+        assert last_kernel() == 2751, last_kernel()
+    F.join_all_streams()
+    wq = conv.weight.detach().reshape(cout, cin).bfloat16().float()
+    ref_dw = gy.reshape(-1, cout).float().t() @ x.detach().reshape(-1, cin).float()
+    assert rel_err(conv.weight.grad.reshape(cout, cin), ref_dw) < 2e-3
+    idx = torch.randint(0, b * h * w_, (4096,), generator=g).to(DEV)
+    ref_dx = gy.reshape(-1, cout)[idx].float() @ wq
+    assert rel_err(x.grad.reshape(-1, cin)[idx].float(), ref_dx) < ULP
+
+
 @pytest.mark.parametrize("variant", [4096, 4096 | (1 << 14)])
 @pytest.mark.parametrize("shape", [(2, 64, 64, 14, 14), (1, 128, 136, 13, 17), (3, 96, 200, 25, 42), (2, 64, 256, 40, 70),
                                    (2, 32, 8, 3, 11), (1, 32, 72, 5, 101)])

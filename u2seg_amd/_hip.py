@@ -91,6 +91,16 @@ def call(name, *args):
         raise RuntimeError("%s failed with status %d" % (name, rc))
 
 
+def call_status(name, *args):
+    """Like `call`, for launchers that answer 1 = "shape not served, take the other path": returns that status (0 or 1) and raises
+    on anything else."""
+    lib = load()
+    rc = getattr(lib, name)(*[_conv(a) for a in args], stream_ptr())
+    if rc not in (0, 1):
+        raise RuntimeError("%s failed with status %d" % (name, rc))
+    return rc
+
+
 def call_nostream(name, *args):
     lib = load()
     return getattr(lib, name)(*[_conv(a) for a in args])

@@ -372,7 +372,10 @@ __global__ __launch_bounds__(256, FS_OCC) void roi_align_fwd_sep_kernel(const Ro
 struct RoiSetDev { const float* rois; const int* order; const int* seg; const bf16_t* dout; int P; float gscale; };
 struct RoiSetsDev { RoiSetDev s[4]; int n; };
 
-constexpr int GS_TS = 8, GS_MAXL = 256, GS_KB = 4, GS_MAXP = 14;
+#ifndef GS_MAXL_V
+#define GS_MAXL_V 256
+#endif
+constexpr int GS_TS = 8, GS_MAXL = GS_MAXL_V, GS_KB = 4, GS_MAXP = 14;
 constexpr int GS_STAGE_BYTES = 24576;  // 48 bins of 256 channels
 typedef float gs_f2 __attribute__((ext_vector_type(2)));
 
@@ -381,7 +384,10 @@ typedef float gs_f2 __attribute__((ext_vector_type(2)));
 // the 1.47 ms of the stride-4 level; 17 TB/s of 16-byte loads).  The bin rows a batch of ROIs has in common with the tile are
 // therefore staged in LDS once (coalesced 512-byte rows) and the quads read them from there; a ROI whose bins do not fit
 // the stage (a 14 x 14 mask ROI on a coarse level) keeps reading from L2.
-__global__ __launch_bounds__(256, 4) void roi_align_bwd_gather_kernel(const RoiSetsDev sets, bf16_t* __restrict__ gfeat, int level,
+#ifndef GS_OCC
+#define GS_OCC 4
+#endif
+__global__ __launch_bounds__(256, GS_OCC) void roi_align_bwd_gather_kernel(const RoiSetsDev sets, bf16_t* __restrict__ gfeat, int level,
                                                                    int nlevels, int H, int W, int C, float scale) {
   constexpr int TS = GS_TS;
   constexpr int NQ = 2;    // items per thread: an item = (tile row, 4-pixel quad of that row, 8-channel chunk)
@@ -415,7 +421,7 @@ __global__ __launch_bounds__(256, 4) void roi_align_bwd_gather_kernel(const RoiS
       if (tid == 0) nlist = 0;
       __syncthreads();
       const int idx = base + tid;
-      if (idx < end) {
+      if (tid < GS_MAXL && idx < end) {
         const int r = st.order[idx];
         const float* roi = st.rois + (size_t)r * 5;
         RoiGeom g;

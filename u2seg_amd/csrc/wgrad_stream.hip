@@ -37,6 +37,11 @@ struct WsArgs {
   int M, N, C, x_ld, dy_ld;   // N, C: physical channel counts of the rows (multiples of 8)
   int tiles_n, tiles_c, ranges, steps;  // steps = ceil(M / 32); work-group = (pixel range, n-tile, c-tile)
   int ring;
+  // fused data gradient (DG instantiations): dx[m][c] = sum_n dY[m][n] W[n][c], from the dY rows the step has in LDS anyway
+  const bf16_t* wt;   // [C][wt_ld] bf16, n contiguous (the data-gradient weight layout of a 1x1 filter)
+  bf16_t* dx;         // [M][dx_ld]
+  int wt_ld, dx_ld;
+  int c_cover;        // channels the c-tiles must cover (DG: the physical C, so that padded channels get their zero gradient; else 0)
 };
 
 // XOR applied to the 16-byte chunk index of pixel row `pix` of a step image with rows of RB bytes.  A half-wave of
@@ -64,10 +69,12 @@ template <int N> __device__ __forceinline__ void ws_wait_vm() { asm volatile("s_
 // The MFMAs of column j (FN of them: every dY fragment against X fragment j) behind a counted wait: the X fragments were
 // requested in order after the dY fragments and LDS returns in order, so column j only needs the 2 (FC - 1 - j) youngest reads to
 // be outstanding still - the reads of the later columns land while the earlier columns multiply.
-template <int FN, int FC, int J = 0>
+// EXTRA: LDS reads issued BEHIND the X fragments that may stay outstanding throughout (the fused data gradient's first fragments).
+template <int FN, int FC, int EXTRA = 0, int J = 0>
 __device__ __forceinline__ void ws_mfma_columns(f32x4 (&acc)[FN][FC], WsFrag (&yf)[FN], WsFrag (&xf)[FC]) {
   if constexpr (J < FC) {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (FC - 1 - J)) : "memory");
+    static_assert(2 * (FC - 1) + EXTRA <= 15, "lgkmcnt is a 4-bit counter");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (FC - 1 - J) + EXTRA) : "memory");
     asm volatile("" : "+v"(xf[J].u[0]), "+v"(xf[J].u[1])::"memory");   // ties the released registers to the wait
     if constexpr (J == 0) {
 #pragma unroll
@@ -75,18 +82,27 @@ __device__ __forceinline__ void ws_mfma_columns(f32x4 (&acc)[FN][FC], WsFrag (&y
     }
 #pragma unroll
     for (int i = 0; i < FN; ++i) acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i].v, xf[J].v, acc[i][J], 0, 0, 0);
-    ws_mfma_columns<FN, FC, J + 1>(acc, yf, xf);
+    ws_mfma_columns<FN, FC, EXTRA, J + 1>(acc, yf, xf);
   }
 }
 
 // WN x WC waves; a wave owns FN x FC blocks of 16 (n) x 16 (c): the work-group's block of dW is NT = WN FN 16 by CT = WC FC 16
-template <int WN, int WC, int FN, int FC>
+// DG (WC = 1, FC = 4 only: the block is all of N by 64 input channels): the same launch also forms the data gradient of its
+// pixels and channels.  The dY rows of a step are already in LDS for the weight gradient; as the MFMA B operand of
+// dx^T[c][m] = sum_n W^T[c][n] dY[m][n] they are read once more with plain ds_read_b128 (a pixel's 8 consecutive channels n per lane -
+// under the image's swizzle these reads are conflict-free as well), against W^T fragments that stay in registers for the whole launch
+// (wave w: 16 channels c, all of N: N / 8 registers).  Saves the second HBM pass over dY that a separate data-gradient launch
+// makes - dY is the large operand of the expanding 1x1 layers (res2 64 -> 256: 550 of the 825 MB both passes touch).
+template <int WN, int WC, int FN, int FC, bool DG = false>
 __global__ __launch_bounds__(WN * WC * 64, (WN * WC == 4 ? 2 : 1)) void wgrad_stream_kernel(const WsArgs a) {
+  static_assert(!DG || (WC == 1 && FC == 4 && (WN == 4 || WN == 8)), "fused data gradient: N-major blocks only");
   constexpr int NWV = WN * WC, NT = WN * FN * 16, CT = WC * FC * 16;
   constexpr int RBY = NT * 2, RBX = CT * 2;          // row bytes of the two step images
   constexpr int PY = RBY / 32, PX = RBX / 32;        // 1 KB LDS-DMA pieces per step and image (32 rows x RB bytes)
-  constexpr int PT = PY + PX, PPW = PT / NWV, STAGE = PT * 1024;
-  static_assert(PT % NWV == 0 && PPW >= 1 && PPW <= 8 && RBY <= 1024 && RBX <= 1024 && RBY >= 64 && RBX >= 64, "unsupported block");
+  // every wave issues the same number of pieces per step (the counted waits are immediates): a stage is rounded up to a multiple of
+  // NWV pieces, the filler pieces read the zero page into the unused tail of the stage
+  constexpr int PT = PY + PX, PPW = (PT + NWV - 1) / NWV, STAGE = PPW * NWV * 1024;
+  static_assert(PPW >= 1 && PPW <= 8 && RBY <= 1024 && RBX <= 1024 && RBY >= 64 && RBX >= 64, "unsupported block");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,8 +134,8 @@ __global__ __launch_bounds__(WN * WC * 64, (WN * WC == 4 ? 2 : 1)) void wgrad_st
     const int pos = lane % cpr;
     const int chunk = is_y ? (pos ^ ws_swz<RBY>(row)) : (pos ^ ws_swz<RBX>(row));
     const int ch = (is_y ? n0 : c0) + chunk * 8;
-    const bool ok = ch < (is_y ? a.N : a.C);
-    d_row[q] = row | (ok ? 0 : 256);
+    const bool ok = p < PT && ch < (is_y ? a.N : a.C);
+    d_row[q] = (row & 255) | (ok ? 0 : 256);
     d_off[q] = (unsigned)(((size_t)row * (is_y ? a.dy_ld : a.x_ld) + ch) * 2);
   }
   const unsigned char* yb = reinterpret_cast<const unsigned char*>(a.dy);
@@ -160,6 +176,52 @@ __global__ __launch_bounds__(WN * WC * 64, (WN * WC == 4 ? 2 : 1)) void wgrad_st
   // a wave whose whole sub-block lies outside the valid N x C block (a 28-channel operand in a 64-wide block) only stages
   const bool wave_active = (n0 + wn * FN * 16 < a.n_valid) && (c0 + wc * FC * 16 < a.c_valid);
 
+  // ---- fused data gradient: resident W^T fragments, B-fragment addresses, the step's result held back one step
+  constexpr int KSN = DG ? NT / 32 : 1;           // 32-channel steps of the reduction over n
+  constexpr int DPX = DG ? (NWV == 4 ? 2 : 1) : 1; // 16-pixel blocks per wave: 4 waves x (1 c-block, 2 px-blocks), 8 x (1, 1)
+  constexpr int KG = 4;                           // reduction steps whose fragments are requested together
+  s16x8 wreg[KSN];
+  unsigned dyoff[DPX];
+  unsigned pend[DPX][2];
+  long long pend_m[DPX];
+  const int dcb = NWV == 4 ? w : (w & 3);
+  const int dpb0 = NWV == 4 ? 0 : (w >> 2);
+  const int dxc = c0 + dcb * 16 + fg * 4;         // first of the lane's 4 output channels
+  if constexpr (DG) {
+    const int crow = c0 + dcb * 16 + fr;          // A operand row: channel c
+    const bf16_t* wsrc = a.wt + (size_t)(crow < a.C ? crow : 0) * a.wt_ld + fg * 8;
+#pragma unroll
+    for (int ks = 0; ks < KSN; ++ks) {
+      s16x8 v = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (crow < a.C && ks * 32 + fg * 8 < a.wt_ld) v = *reinterpret_cast<const s16x8*>(wsrc + ks * 32);
+      wreg[ks] = v;
+    }
+    // landed before the first LDS-DMA is issued: a later compiler-generated wait for them would have to drain the ring
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < KSN; ++ks) asm volatile("" : "+v"(wreg[ks]));
+#pragma unroll
+    for (int p = 0; p < DPX; ++p) {
+      const int pix = (dpb0 + p) * 16 + fr;
+      dyoff[p] = (unsigned)(pix * RBY + ((fg ^ ws_swz<RBY>(pix)) << 4));   // reduction step ks: ^ (ks << 6)
+      pend_m[p] = -1;
+      pend[p][0] = pend[p][1] = 0u;
+    }
+  }
+  auto store_pending = [&]() {
+    if constexpr (DG) {
+#pragma unroll
+      for (int p = 0; p < DPX; ++p) {
+        if (pend_m[p] >= 0 && dxc < a.dx_ld) {
+          typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+          const u32x2_t v = {pend[p][0], pend[p][1]};
+          bf16_t* dst = a.dx + (size_t)pend_m[p] * a.dx_ld + dxc;
+          asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+        }
+      }
+    }
+  };
+
   // ---- pipeline: ring - 1 steps in flight; step g waits for its own pieces (counted), the barrier publishes the step and frees
   // the slot of step g - 1 for step g + ring - 1
   const int ring = a.ring;
@@ -184,8 +246,21 @@ __global__ __launch_bounds__(WN * WC * 64, (WN * WC == 4 ? 2 : 1)) void wgrad_st
       if (s2 < 0) s2 += ring;
       issue(g + ring - 1, s2);
     }
+    // the data gradient of the PREVIOUS step leaves now: its stores have a whole step to retire before the next counted wait
+    // (which, counting only the LDS-DMA pieces issued behind it, waits for them as well)
+    store_pending();
+    const unsigned sb = lds0 + (unsigned)(slot * STAGE);
+    // fused data gradient: the B fragments (dY rows as they lie, 8 channels n per lane) of reduction steps k0 .. k0 + KG - 1
+    constexpr int NGRP = DG ? KSN / KG : 1, NRD = KG * DPX;
+    s16x8 bf[2][KG][DPX];
+    auto dg_read = [&](int grp, int buf) {
+#pragma unroll
+      for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+        for (int p = 0; p < DPX; ++p)
+          asm volatile("ds_read_b128 %0, %1" : "=v"(bf[buf][kk][p]) : "v"(sb + (dyoff[p] ^ (unsigned)((grp * KG + kk) << 6))) : "memory");
+    };
     if (wave_active) {
-      const unsigned sb = lds0 + (unsigned)(slot * STAGE);
       WsFrag yf[FN], xf[FC];
 #pragma unroll
       for (int i = 0; i < FN; ++i)
@@ -195,10 +270,50 @@ __global__ __launch_bounds__(WN * WC * 64, (WN * WC == 4 ? 2 : 1)) void wgrad_st
       for (int j = 0; j < FC; ++j)
 #pragma unroll
         for (int h = 0; h < 2; ++h) xf[j].u[h] = ws_tr_read(sb + (xoff[h] ^ (unsigned)(j << 5)));
-      ws_mfma_columns<FN, FC>(acc, yf, xf);
+      if constexpr (DG) {
+        dg_read(0, 0);   // lands behind the weight gradient's MFMAs
+        ws_mfma_columns<FN, FC, NRD>(acc, yf, xf);
+      } else {
+        ws_mfma_columns<FN, FC>(acc, yf, xf);
+      }
+    } else if constexpr (DG) {
+      dg_read(0, 0);
+    }
+    if constexpr (DG) {
+      f32x4 dacc[DPX];
+#pragma unroll
+      for (int p = 0; p < DPX; ++p) dacc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int grp = 0; grp < NGRP; ++grp) {
+        const int cur = grp & 1;
+        if (grp + 1 < NGRP) {
+          dg_read(grp + 1, cur ^ 1);
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NRD) : "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+          for (int p = 0; p < DPX; ++p) asm volatile("" : "+v"(bf[cur][kk][p]));
+#pragma unroll
+        for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+          for (int p = 0; p < DPX; ++p)
+            dacc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[grp * KG + kk], bf[cur][kk][p], dacc[p], 0, 0, 0);
+      }
+      // D[c][m]: the lane holds channels dxc .. dxc + 3 of pixel (dpb0 + p) 16 + fr: 8 bytes of that pixel's row
+#pragma unroll
+      for (int p = 0; p < DPX; ++p) {
+        const long long m = (long long)(s_beg + g) * 32 + (dpb0 + p) * 16 + fr;
+        pend_m[p] = m < a.M ? m : -1;
+        pend[p][0] = (unsigned)f2bf(dacc[p][0]) | ((unsigned)f2bf(dacc[p][1]) << 16);
+        pend[p][1] = (unsigned)f2bf(dacc[p][2]) | ((unsigned)f2bf(dacc[p][3]) << 16);
+      }
     }
     slot = slot + 1 == ring ? 0 : slot + 1;
   }
+  store_pending();
 
   // ---- flush.  D[i = n][j = c]: lane holds column c = fr, rows n = fg 4 + r of its 16 x 16 blocks
   if (!wave_active) return;
@@ -217,12 +332,12 @@ __global__ __launch_bounds__(WN * WC * 64, (WN * WC == 4 ? 2 : 1)) void wgrad_st
     }
 }
 
-template <int WN, int WC, int FN, int FC>
+template <int WN, int WC, int FN, int FC, bool DG = false>
 int launch_ws(WsArgs& a, int per_cu, int tiny, int code, hipStream_t s) {
   constexpr int NWV = WN * WC, NT = WN * FN * 16, CT = WC * FC * 16;
-  constexpr int STAGE = (NT + CT) * 64;
+  constexpr int STAGE = ((NT + CT) / 16 + NWV - 1) / NWV * NWV * 1024;
   a.tiles_n = (a.n_valid + NT - 1) / NT;
-  a.tiles_c = (a.c_valid + CT - 1) / CT;
+  a.tiles_c = ((a.c_cover > a.c_valid ? a.c_cover : a.c_valid) + CT - 1) / CT;
   const int tiles = a.tiles_n * a.tiles_c;
   const int lds_budget = (per_cu == 2 ? 80 : 160) * 1024;
   int ring = lds_budget / STAGE;
@@ -238,10 +353,10 @@ int launch_ws(WsArgs& a, int per_cu, int tiny, int code, hipStream_t s) {
   a.ranges = ranges;
   static PerDeviceOnce attr_set;
   if (attr_set.first()) {
-    (void)hipFuncSetAttribute((const void*)wgrad_stream_kernel<WN, WC, FN, FC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)wgrad_stream_kernel<WN, WC, FN, FC, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   g_last_conv_kernel = code;
-  hipLaunchKernelGGL((wgrad_stream_kernel<WN, WC, FN, FC>), dim3((unsigned)(ranges * tiles)), dim3(NWV * 64), (size_t)ring * STAGE, s, a);
+  hipLaunchKernelGGL((wgrad_stream_kernel<WN, WC, FN, FC, DG>), dim3((unsigned)(ranges * tiles)), dim3(NWV * 64), (size_t)ring * STAGE, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return -1000 - (int)e;
   return 1;
@@ -261,6 +376,7 @@ int launch_wgrad_stream(const bf16_t* x, const bf16_t* dy, float* dw, long long 
   a.x = x; a.dy = dy; a.dw = dw; a.dw_sn = dw_sn; a.dw_sc = dw_sc; a.n_valid = n_valid; a.c_valid = c_valid; a.zero = zero;
   a.M = M; a.N = N; a.C = C; a.x_ld = x_ld; a.dy_ld = dy_ld;
   a.steps = (M + 31) / 32;
+  a.wt = nullptr; a.dx = nullptr; a.wt_ld = a.dx_ld = 0; a.c_cover = 0;
   if (!force && M < 200000) return 0;   // >= ~25 steps per work-group: shorter launches stay on the tile kernels
   if (cfg == 0) {
     // the block shape follows the operands: the wider one along its 256, blocks beyond 256 x 256 are tiled (the narrower
@@ -281,6 +397,28 @@ int launch_wgrad_stream(const bf16_t* x, const bf16_t* dy, float* dw, long long 
     case 4: return launch_ws<4, 2, 4, 8>(a, 1, tiny, 2704, s);
     default: return 0;
   }
+}
+
+// The same launch with the data gradient fused in (wgrad_stream_kernel<.., DG>): dx[m][c] = sum_n dy[m][n] wt[c][n] for the 1x1 /
+// stride-1 layers whose block is all of N (<= 512) by 64 input channels.  Returns 1 when it took the launch, 0 when the shape is
+// not served (the caller runs the two separate launches), < 0 on a launch failure.  g_last_conv_kernel code: 2750 + N block / 256.
+int launch_wdgrad_stream(const bf16_t* x, const bf16_t* dy, const bf16_t* wt, bf16_t* dx, float* dw, long long dw_sn, int dw_sc,
+                         int n_valid, int c_valid, const bf16_t* zero, int M, int C, int x_ld, int N, int dy_ld, int wt_ld,
+                         int dx_ld, int force, int tiny, hipStream_t s) {
+  if ((C & 7) || (N & 7) || (x_ld & 7) || (dy_ld & 7) || (wt_ld & 7) || (dx_ld & 7) || M < 1 || n_valid < 1 || c_valid < 1) return 0;
+  if (dx_ld < C || wt_ld < N) return 0;
+  if ((unsigned long long)M * (unsigned)x_ld * 2ull >= 0xffffffffull || (unsigned long long)M * (unsigned)dy_ld * 2ull >= 0xffffffffull) return 0;
+  const bool small = N <= 256 && C <= 64, wide = N > 256 && N <= 512 && C <= 128;
+  if (!small && !wide) return 0;
+  if (!force && (M < 200000 || n_valid <= 128)) return 0;
+  WsArgs a;
+  a.x = x; a.dy = dy; a.dw = dw; a.dw_sn = dw_sn; a.dw_sc = dw_sc; a.n_valid = n_valid; a.c_valid = c_valid; a.zero = zero;
+  a.M = M; a.N = N; a.C = C; a.x_ld = x_ld; a.dy_ld = dy_ld;
+  a.steps = (M + 31) / 32;
+  a.wt = wt; a.dx = dx; a.wt_ld = wt_ld; a.dx_ld = dx_ld;
+  a.c_cover = C;   // the c-tiles cover the PHYSICAL input channels: padded channels get their zero data gradient written too
+  if (small) return launch_ws<4, 1, 4, 4, true>(a, 2, tiny, 2751, s);
+  return launch_ws<8, 1, 4, 4, true>(a, 1, tiny, 2752, s);
 }
 
 }  // namespace u2conv

@@ -344,7 +344,20 @@ class _Conv2dFn(Function):
         else:
             dz = dout
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        fused = False
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ctx.wgrad_dst is not None and kh == 1 and kw == 1 \
+                and stride == 1 and pad == 0 and n > 128 and b * h * w_ >= FUSED_BWD_MIN_PIXELS:
+            # both gradients of an expanding 1x1 layer in one pass over dz (u2_conv1x1_bwd_fused: dz is the large operand); the
+            # launcher answers 1 for a shape it does not serve
+            dst = ctx.wgrad_dst
+            assert dst.is_contiguous() and dst.dtype == torch.float32 and dst.numel() == n * cin
+            wd = weight_dgrad_layout(weight, cp, npad, ctx.param)
+            dx = torch.empty_like(x)
+            fused = _hip.call_status("u2_conv1x1_bwd_fused", x, dz, wd, dx, dst, b * h * w_, cp, cp, npad, npad, npad, cp, n, cin,
+                                     cin, 1, 0) == 0
+        if fused:
+            pass
+        elif ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if ho == 1 and wo == 1 and pad == 0 and h == kh and w_ == kw and kh * kw > 1:
                 # "fully connected" conv (box head fc1): every input pixel meets exactly one tap, so the data gradient
@@ -356,7 +369,7 @@ class _Conv2dFn(Function):
                 wd = weight_dgrad_layout(weight, cp, npad, ctx.param)
                 _hip.call("u2_conv_igemm", dz, wd, dx, None, None, b, ho, wo, npad, npad, h, w_, cp, cp, kh, kw,
                           kh - 1 - pad, kw - 1 - pad, 1, stride, 0, 0, 0)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not fused:
             dst = ctx.wgrad_dst
             arena = ctx.arena
             if dst is not None:
@@ -1090,6 +1103,7 @@ def roi_grad_tap(feats):
     return list(outs)
 
 
+FUSED_BWD_MIN_PIXELS = int(os.environ.get("U2_FUSED_BWD_MIN_PIXELS", "200000"))
 ROI_ORDER_MIN = int(os.environ.get("U2_ROI_ORDER_MIN", "1000000000"))
 
 
