@@ -43,20 +43,25 @@ class KernelTimer:
     def install(self):
         from u2seg_amd import _hip
 
-        orig = _hip.call
         timer = self
 
-        def timed_call(name, *args):
-            if not timer.enabled or name not in timer.names:
-                return orig(name, *args)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            orig(name, *args)
-            e.record()
-            (timer.records if timer.tag == "serial" else timer.overlapped).append(
-                (name, timer.flops(name, args), s, e, tuple(a for a in args if isinstance(a, int)), timer.alg_bytes(name, args)))
+        def wrap(orig):
+            def timed_call(name, *args):
+                if not timer.enabled or name not in timer.names:
+                    return orig(name, *args)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                rc = orig(name, *args)
+                e.record()
+                if rc in (None, 0):   # (a launcher that answered "shape not served" launched nothing)
+                    (timer.records if timer.tag == "serial" else timer.overlapped).append(
+                        (name, timer.flops(name, args), s, e, tuple(a for a in args if isinstance(a, int)), timer.alg_bytes(name, args)))
+                return rc
 
-        _hip.call = timed_call
+            return timed_call
+
+        _hip.call = wrap(_hip.call)
+        _hip.call_status = wrap(_hip.call_status)
 
     @staticmethod
     def alg_bytes(name, a):
@@ -69,10 +74,15 @@ class KernelTimer:
             return 2.0 * (b * hin * win * c + b * ho * wo * n) + 4.0 * n * kh * kw * c
         if name in ("u2_kmeans_assign", "u2_kmeans_update"):
             return 4.0 * a[4] * a[5]  # x read once (the fused ideal reads it once per iteration)
+        if name == "u2_conv1x1_bwd_fused":   # (x, dy, wt, dx, dw, M, C, x_ld, N, ...): dy and x read once, dx written, dW
+            m, c, n = a[5], a[6], a[8]
+            return 2.0 * m * (n + 2 * c) + 2.0 * n * c + 4.0 * n * c
         return 0.0
 
     @staticmethod
     def flops(name, a):
+        if name == "u2_conv1x1_bwd_fused":   # data gradient + weight gradient
+            return 4.0 * a[5] * a[6] * a[8]
         if name == "u2_conv_igemm":
             # (in, wt, out, bias, stats, B, Hin, Win, C, in_ld, Hout, Wout, N, out_ld, KH, KW, ph, pw, mul, div, ...)
             b, c, ho, wo, n, kh, kw, div = a[5], a[8], a[10], a[11], a[12], a[14], a[15], a[19]
@@ -183,7 +193,7 @@ def cpu_baseline(workload):
 
 def _pmc_traffic(kernel_key):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/rNN_pmc_traffic.json)."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             pj = json.load(open(path))
@@ -356,7 +366,8 @@ def main():
     from u2seg_amd import _hip
 
     _hip.load()
-    timer = KernelTimer(["u2_conv_igemm", "u2_conv_wgrad", "u2_conv_wgrad_into", "u2_kmeans_assign", "u2_kmeans_update"])
+    timer = KernelTimer(["u2_conv_igemm", "u2_conv_wgrad", "u2_conv_wgrad_into", "u2_conv1x1_bwd_fused", "u2_kmeans_assign",
+                         "u2_kmeans_update"])
     timer.install()
 
     def barrier():

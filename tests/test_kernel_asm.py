@@ -13,7 +13,7 @@ CSRC = os.path.join(ROOT, "u2seg_amd", "csrc")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # the sources with inline-asm loads into registers (global_load_* / ds_read_*)
-SOURCES = ["kmeans", "conv_igemm", "wgrad_halo", "conv_tile", "conv_halo", "conv_stream"]
+SOURCES = ["kmeans", "conv_igemm", "wgrad_halo", "conv_tile", "conv_halo", "conv_stream", "wgrad_stream"]
 
 
 def test_checker_flags_a_move_of_an_in_flight_register(tmp_path):

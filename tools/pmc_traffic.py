@@ -26,6 +26,8 @@ def per_kernel(d, counter):
 
 
 def family(name):
+    if "wgrad_stream_kernel" in name:  # the 1x1 streaming kernel; its DG instantiations carry a data gradient as well
+        return "conv_wgrad"
     if "conv_wgrad" in name or "wgrad_reduce_kernel" in name:  # the reduction pass belongs to the launch whose partial tiles it sums
         return "conv_wgrad"
     if "conv_tile_kernel" in name or "conv_igemm" in name or "conv_halo_kernel" in name or "conv_stream_kernel" in name:
