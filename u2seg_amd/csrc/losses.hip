@@ -28,12 +28,6 @@ namespace {
 constexpr int SS_OW = 15, SS_OH = 7;                 // owned taps per work-group
 constexpr int SS_LW = SS_OW + 2, SS_LH = SS_OH + 2;  // staged taps (one halo ring)
 constexpr int SS_MAXC = 32, SS_PITCH = 36;           // 36 floats: 16-byte aligned rows, tap columns on distinct banks
-// Gradient accumulator: its own, ODD pitch.  A ds_add_f32 is served 32 lanes at a time over 32 four-byte banks; lane (cell qx,
-// class group cj) adds to float qx * pitch + cj * 8 + e, and with pitch 36 the 32 lanes of a half-wave met in 8 banks (4 qx + 8 cj
-// are all multiples of 4): every one of the 32 atomics per cell was a 4-way conflict and the waves spent 44 % of their cycles
-// stalled on the LDS (profiles/r05_pmc_wgrad_sq.txt run, SQ_WAIT_INST_LDS).  With pitch 37, 5 qx + 8 cj covers all 32 banks.
-constexpr int SS_GPITCH = 37;
-constexpr int SS_GFLOATS = (SS_LH * SS_LW * SS_GPITCH + 3) / 4 * 4;
 
 // reductions over the 4 lanes of a quad: DPP quad_perm [1,0,3,2] (0xB1) and [2,3,0,1] (0x4E)
 template <int CTRL>
@@ -54,7 +48,7 @@ __global__ __launch_bounds__(256) void semseg_ce_kernel(const bf16_t* __restrict
                                                         float* __restrict__ valid_cnt, int B, int h, int w, int LP, int NC,
                                                         int ignore) {
   __shared__ __attribute__((aligned(16))) float zt[SS_LH * SS_LW * SS_PITCH];
-  __shared__ __attribute__((aligned(16))) float gt[SS_GFLOATS];
+  __shared__ __attribute__((aligned(16))) float gt[SS_LH * SS_LW * SS_PITCH];
   __shared__ __attribute__((aligned(16))) uint8_t lab[32 * 64];  // the tile's labels; `ignore` outside the image
   __shared__ float red[4];
   const int H = 4 * h, W = 4 * w;
@@ -93,10 +87,12 @@ __global__ __launch_bounds__(256) void semseg_ce_kernel(const bf16_t* __restrict
       for (int e = 0; e < 8; ++e) f[e] = 0.f;
     }
     float* zd = zt + t * SS_PITCH + ch * 8;
+    float* gd = gt + t * SS_PITCH + ch * 8;
     *reinterpret_cast<float4*>(zd) = make_float4(f[0], f[1], f[2], f[3]);
     *reinterpret_cast<float4*>(zd + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    *reinterpret_cast<float4*>(gd) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(gd + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int i = tid; i < SS_GFLOATS / 4; i += 256) reinterpret_cast<float4*>(gt)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
 
   const int cj = tid & 3;          // class group: classes 8cj .. 8cj+7
@@ -191,18 +187,16 @@ __global__ __launch_bounds__(256) void semseg_ce_kernel(const bf16_t* __restrict
       }
     }
     if (any) {
-      // contributions to taps outside the owned block land in the (discarded) halo ring of gt; the padding classes add exact
-      // zeros (their softmax term is exp(-inf) = 0), so no per-class branch
-      const int o00 = ((y0 - ly0) * SS_LW + (x0 - lx0)) * SS_GPITCH + cj * 8;
-      const int o01 = ((y0 - ly0) * SS_LW + (x1 - lx0)) * SS_GPITCH + cj * 8;
-      const int o10 = ((y1 - ly0) * SS_LW + (x0 - lx0)) * SS_GPITCH + cj * 8;
-      const int o11 = ((y1 - ly0) * SS_LW + (x1 - lx0)) * SS_GPITCH + cj * 8;
+      // contributions to taps outside the owned block land in the (discarded) halo ring of gt
+      const int o00 = i00, o01 = i01, o10 = i10, o11 = i11;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        atomicAdd(&gt[o00 + e], a00[e]);
-        atomicAdd(&gt[o01 + e], a01[e]);
-        atomicAdd(&gt[o10 + e], a10[e]);
-        atomicAdd(&gt[o11 + e], a11[e]);
+        if (cvalid[e]) {
+          atomicAdd(&gt[o00 + e], a00[e]);
+          atomicAdd(&gt[o01 + e], a01[e]);
+          atomicAdd(&gt[o10 + e], a10[e]);
+          atomicAdd(&gt[o11 + e], a11[e]);
+        }
       }
     }
   }
@@ -217,7 +211,7 @@ __global__ __launch_bounds__(256) void semseg_ce_kernel(const bf16_t* __restrict
     const int ox = t % SS_OW, oy = t / SS_OW;
     const int lx = ox0 + ox, ly = oy0 + oy;
     if (lx >= w || ly >= h) continue;
-    const float g = c < NC ? gt[((oy + 1) * SS_LW + (ox + 1)) * SS_GPITCH + c] : 0.f;
+    const float g = c < NC ? gt[((oy + 1) * SS_LW + (ox + 1)) * SS_PITCH + c] : 0.f;
     grad_acc[(((size_t)b * h + ly) * w + lx) * LP + c] = g;
   }
 }
