@@ -77,12 +77,17 @@ class KernelTimer:
         if name == "u2_conv1x1_bwd_fused":   # (x, dy, wt, dx, dw, M, C, x_ld, N, ...): dy and x read once, dx written, dW
             m, c, n = a[5], a[6], a[8]
             return 2.0 * m * (n + 2 * c) + 2.0 * n * c + 4.0 * n * c
+        if name == "u2_conv1x1_bwd_fused_bn":   # (x, dz, y, k1, k2, k3, wt, dx, dw, M, C, x_ld, N, ...): dz, y and x read once
+            m, c, n = a[9], a[10], a[12]
+            return 2.0 * m * (2 * n + 2 * c) + 2.0 * n * c + 4.0 * n * c
         return 0.0
 
     @staticmethod
     def flops(name, a):
         if name == "u2_conv1x1_bwd_fused":   # data gradient + weight gradient
             return 4.0 * a[5] * a[6] * a[8]
+        if name == "u2_conv1x1_bwd_fused_bn":
+            return 4.0 * a[9] * a[10] * a[12]
         if name == "u2_conv_igemm":
             # (in, wt, out, bias, stats, B, Hin, Win, C, in_ld, Hout, Wout, N, out_ld, KH, KW, ph, pw, mul, div, ...)
             b, c, ho, wo, n, kh, kw, div = a[5], a[8], a[10], a[11], a[12], a[14], a[15], a[19]
@@ -366,7 +371,8 @@ def main():
     from u2seg_amd import _hip
 
     _hip.load()
-    timer = KernelTimer(["u2_conv_igemm", "u2_conv_wgrad", "u2_conv_wgrad_into", "u2_conv1x1_bwd_fused", "u2_kmeans_assign",
+    timer = KernelTimer(["u2_conv_igemm", "u2_conv_wgrad", "u2_conv_wgrad_into", "u2_conv1x1_bwd_fused", "u2_conv1x1_bwd_fused_bn",
+                         "u2_kmeans_assign",
                          "u2_kmeans_update"])
     timer.install()
 

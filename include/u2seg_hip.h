@@ -58,6 +58,16 @@ int u2_conv1x1_bwd_fused(const void* x, const void* dy, const void* wt, void* dx
                          int wt_ld, int dx_ld, int n_valid, int c_valid, long long dw_stride_n, int dw_stride_c, int variant,
                          void* stream);
 
+/* The same pass for a layer whose output y feeds a batch normalisation (layers/batch_norm.py:169-197 behind layers/wrappers.py:
+ * 127-134: conv3 + norm of a bottleneck, the projection shortcut): the normalisation's backward apply step
+ * dy[m][n] = k1[n] dz[m][n] + k2[n] y[m][n] + k3[n] (u2_norm_bwd_apply with relu = 0, coefficients of u2_bn_finalize_bwd) is
+ * evaluated on the staged rows instead of being written and read back; dx and dw are those of u2_conv1x1_bwd_fused on that dy.
+ * Served: N <= 256 by C <= 64 (same size rule and variant bits); returns 1 otherwise - the caller then runs u2_norm_bwd_apply
+ * followed by u2_conv1x1_bwd_fused (or the two separate launches). */
+int u2_conv1x1_bwd_fused_bn(const void* x, const void* dz, const void* y, const float* k1, const float* k2, const float* k3,
+                            const void* wt, void* dx, float* dw, int M, int C, int x_ld, int N, int dy_ld, int wt_ld, int dx_ld,
+                            int n_valid, int c_valid, long long dw_stride_n, int dw_stride_c, int variant, void* stream);
+
 /* Test / debugging aid: a code for the kernel (family, tile configuration) the most recent u2_conv_igemm or u2_conv_wgrad
  * call on this thread selected (encoding in csrc/conv_args.h).  With variant 0 the selection can be steered through the
  * environment variables U2_CONV_VARIANT / U2_WGRAD_VARIANT (same bits as the variant argument). */

@@ -176,6 +176,46 @@ static int test_wdgrad(int M, int C, int N, int cv, int nv, int variant, const c
   return ok ? 0 : 1;
 }
 
+
+// u2_conv1x1_bwd_fused_bn against its definition: u2_norm_bwd_apply (relu = 0) into a dy buffer, then u2_conv1x1_bwd_fused on it.
+// The data gradient must agree bit for bit (same rounded dy, same MFMA order per block shape is NOT guaranteed between the 4- and
+// 8-wave blocks, so a tolerance on dx / dW and bit-equality of the dy the kernel formed, probed through an identity filter).
+static int test_wdgrad_bn(int M, int C, int N, int cv, int nv, int variant, const char* name) {
+  std::vector<uint16_t> hx((size_t)M * C), hdz((size_t)M * N), hy((size_t)M * N), hwt((size_t)C * N);
+  std::vector<float> k1(N), k2(N), k3(N);
+  for (auto& v : hx) v = f2bf(frand());
+  for (auto& v : hdz) v = f2bf(frand());
+  for (auto& v : hy) v = f2bf(frand() * 2.f);
+  for (auto& v : hwt) v = f2bf(frand() * 0.25f);
+  for (int n = 0; n < N; ++n) { k1[n] = 0.5f + frand(); k2[n] = 0.1f * frand(); k3[n] = 0.05f * frand(); }
+  for (int n = nv; n < N; ++n) k1[n] = k2[n] = k3[n] = 0.f;
+  for (int m = 0; m < M; ++m) for (int n = nv; n < N; ++n) hdz[(size_t)m * N + n] = hy[(size_t)m * N + n] = 0;
+  DBuf<uint16_t> dx_in(hx.size()), ddz(hdz.size()), dy(hy.size()), ddy(hdz.size()), dwt(hwt.size()), ddx((size_t)M * C), ddx2((size_t)M * C);
+  DBuf<float> ddw((size_t)nv * cv), ddw2((size_t)nv * cv), dk1(N), dk2(N), dk3(N);
+  dx_in.up(hx); ddz.up(hdz); dy.up(hy); dwt.up(hwt); dk1.up(k1); dk2.up(k2); dk3.up(k3);
+  std::vector<uint16_t> junk((size_t)M * C, 0x7fc0); ddx.up(junk); ddx2.up(junk);
+  int rc = u2_norm_bwd_apply(ddz.d, nullptr, dy.d, dk1.d, dk2.d, dk3.d, ddy.d, nullptr, 1, M, N, N, 0, nullptr, nullptr, nullptr);
+  if (!rc) rc = u2_conv1x1_bwd_fused(dx_in.d, ddy.d, dwt.d, ddx2.d, ddw2.d, M, C, C, N, N, N, C, nv, cv, (long long)cv, 1, variant, nullptr);
+  HIPCHK(hipDeviceSynchronize());
+  if (rc) { printf("FAIL %-28s v%d reference launches rc=%d\n", name, variant, rc); return 1; }
+  rc = u2_conv1x1_bwd_fused_bn(dx_in.d, ddz.d, dy.d, dk1.d, dk2.d, dk3.d, dwt.d, ddx.d, ddw.d, M, C, C, N, N, N, C, nv, cv, (long long)cv, 1, variant, nullptr);
+  HIPCHK(hipDeviceSynchronize());
+  if (rc) { printf("FAIL %-28s v%d launch rc=%d\n", name, variant, rc); return 1; }
+  const int code = u2_conv_last_kernel();
+  auto gdx = ddx.down(); auto gdx2 = ddx2.down(); auto gdw = ddw.down(); auto gdw2 = ddw2.down();
+  double e1 = 0, r1 = 0, e2 = 0, r2 = 0; size_t ndiff = 0;
+  for (size_t i = 0; i < gdx.size(); ++i) {
+    e1 = fmax(e1, fabs((double)bf2f(gdx[i]) - bf2f(gdx2[i]))); r1 = fmax(r1, fabs((double)bf2f(gdx2[i])));
+    ndiff += gdx[i] != gdx2[i];
+  }
+  for (size_t i = 0; i < gdw.size(); ++i) { e2 = fmax(e2, fabs((double)gdw[i] - gdw2[i])); r2 = fmax(r2, fabs((double)gdw2[i])); }
+  // fp32 accumulation order differs between the block shapes: one bf16 ulp on dx, 1e-4 relative on dW
+  const bool ok = e1 <= 0.008 * r1 + 1e-6 && e2 <= 2e-4 * r2 + 1e-4 && code == ((variant & 8) ? 2762 : 2761);
+  printf("%s %-28s v%d  dx diff %.4g (max %.4g, %zu of %zu differ)  dW diff %.4g (max %.4g)  kernel %d\n", ok ? "PASS" : "FAIL", name, variant, e1,
+         r1, ndiff, gdx.size(), e2, r2, code);
+  return ok ? 0 : 1;
+}
+
 static void bench_conv(const char* name, int B, int H, int W, int C, int N, int K, int pad, int stride, int variant) {
   const int Hout = (H + 2 * pad - K) / stride + 1, Wout = (W + 2 * pad - K) / stride + 1;
   const size_t M = (size_t)B * Hout * Wout;
@@ -455,6 +495,57 @@ int main(int argc, char** argv) {
       printf("BENCH_WD M=%d %d->%d  two launches %.3f ms (%.2f TB/s of their %.0f MB)   fused %.3f ms (%.2f TB/s of its %.0f MB)\n", M, C, N,
              t[0][2], by2 / t[0][2] * 1e-9, by2 * 1e-6, t[1][2], by1 / t[1][2] * 1e-9, by1 * 1e-6);
     }
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "wdgrad_bn")) {
+    for (int v : {1, 3, 1 | 8, 3 | 8}) {   // forced; | 2: 8 pixel ranges; | 8: the 4-wave block, two work-groups per CU
+      fails += test_wdgrad_bn(37 * 29, 64, 256, 64, 256, v, "wdgrad_bn 64->256");
+      fails += test_wdgrad_bn(33 * 21 * 2, 40, 200, 37, 196, v, "wdgrad_bn 40->200 (tails)");
+      fails += test_wdgrad_bn(5, 32, 136, 32, 136, v, "wdgrad_bn 5 px");
+      fails += test_wdgrad_bn(40 * 70, 8, 16, 8, 16, v, "wdgrad_bn 8->16");
+      fails += test_wdgrad_bn(64 * 131, 64, 256, 64, 256, v, "wdgrad_bn 64->256 8384 px");
+    }
+    printf("SELFTEST wdgrad_bn %s (%d failures)\n", fails ? "FAILED" : "OK", fails);
+    return fails ? 1 : 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "bench_wd_bn")) {
+    // the tail of a res2 block: apply + fused (two launches) vs the one launch
+    const int M = 16 * 200 * 336, C = 64, N = 256;
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    DBuf<uint16_t> dx_in((size_t)M * C), ddz((size_t)M * N), dy((size_t)M * N), ddy((size_t)M * N), dwt((size_t)C * N), ddx((size_t)M * C);
+    DBuf<float> ddw((size_t)N * C), dk((size_t)3 * N);
+    std::vector<uint16_t> pat((size_t)1 << 22);
+    for (auto& v : pat) v = f2bf(frand());
+    for (size_t o = 0; o < ddz.n; o += pat.size()) {
+      HIPCHK(hipMemcpy(ddz.d + o, pat.data(), std::min(pat.size(), ddz.n - o) * 2, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(dy.d + o, pat.data() + 17, std::min(pat.size() - 32, dy.n - o) * 2, hipMemcpyHostToDevice));
+    }
+    for (size_t o = 0; o < dx_in.n; o += pat.size()) HIPCHK(hipMemcpy(dx_in.d + o, pat.data(), std::min(pat.size(), dx_in.n - o) * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dwt.d, pat.data(), dwt.n * 2, hipMemcpyHostToDevice));
+    std::vector<float> hk((size_t)3 * N, 0.25f); dk.up(hk);
+    std::vector<float> t[3];
+    for (int r = 0; r < 5; ++r)
+      for (int mode = 0; mode < 3; ++mode) {
+        auto run = [&]() {
+          if (mode == 0) {
+            u2_norm_bwd_apply(ddz.d, nullptr, dy.d, dk.d, dk.d + N, dk.d + 2 * N, ddy.d, nullptr, 1, M, N, N, 0, nullptr, nullptr, nullptr);
+            u2_conv1x1_bwd_fused(dx_in.d, ddy.d, dwt.d, ddx.d, ddw.d, M, C, C, N, N, N, C, N, C, (long long)C, 1, 1, nullptr);
+          } else {
+            u2_conv1x1_bwd_fused_bn(dx_in.d, ddz.d, dy.d, dk.d, dk.d + N, dk.d + 2 * N, dwt.d, ddx.d, ddw.d, M, C, C, N, N, N, C, N, C, (long long)C, 1,
+                                    mode == 1 ? 1 : 1 | 8, nullptr);
+          }
+        };
+        run();
+        HIPCHK(hipEventRecord(e0));
+        for (int i = 0; i < 3; ++i) run();
+        HIPCHK(hipEventRecord(e1)); HIPCHK(hipEventSynchronize(e1));
+        float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        t[mode].push_back(ms / 3);
+      }
+    for (auto& v : t) std::sort(v.begin(), v.end());
+    const double by2 = 2.0 * ((double)M * N * 4 + (double)M * C * 2), by1 = 2.0 * ((double)M * N * 2 + (double)M * C * 2);
+    printf("BENCH_WD_BN M=%d %d->%d  apply + fused %.3f ms (%.2f TB/s of their %.0f MB)   one launch %.3f ms (%.2f TB/s of its %.0f MB)   "
+           "4-wave form %.3f ms\n", M, C, N, t[0][2], by2 / t[0][2] * 1e-9, by2 * 1e-6, t[1][2], by1 / t[1][2] * 1e-9, by1 * 1e-6, t[2][2]);
     return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "wdgrad")) {

@@ -365,6 +365,72 @@ def test_fused_1x1_backward(F, tiny):
         F.FUSED_BWD_MIN_PIXELS = old_min
 
 
+@pytest.mark.parametrize("tail", [True, False])
+def test_fused_1x1_backward_with_batch_norm_apply(F, tail):
+    """u2_conv1x1_bwd_fused_bn (wgrad_stream_kernel<8, 1, 2, 4, DG, AP>, code 2761): conv -> batch norm (-> + residual -> ReLU), whose
+    backward apply step dx = k1 dz + k2 y + k3 is evaluated by the conv's fused backward launch on the staged rows - autograd carries a
+    placeholder from _BatchNormActFn.backward to _Conv2dFn.backward.  Against the same module with the step as its own launch
+    (F.LAZY_BN_APPLY False, the fused launch 2751 on the stored dy): the input gradient to the few bf16 roundings of dy that the
+    atomically summed coefficients flip between two runs (bit for bit on fixed coefficients: tests/native/selftest wdgrad_bn), dW and
+    dgamma / dbeta to fp32 summation order, the residual's gradient identical.  Third leg: the deferral is taken but the fused launcher declines (variant bit 2) -
+    the conv materialises dy with u2_norm_bwd_apply and takes the separate launches; same gradients."""
+    from u2seg_amd.layers.modules import BatchNorm2d, Conv2d
+    from u2seg_amd.solver import FlatSGD
+
+    old_min, old_lazy = F.FUSED_BWD_MIN_PIXELS, F.LAZY_BN_APPLY
+    old_env = os.environ.get("U2_WDGRAD_VARIANT")
+    g = torch.Generator().manual_seed(91 + int(tail))
+    try:
+        F.FUSED_BWD_MIN_PIXELS = 0
+        F.set_deterministic_stats(True)   # fixed-order batch statistics: the three legs normalise with the same mean / invstd
+        for (b, cin, cout, h, w_) in ((1, 64, 256, 37, 29), (2, 40, 192, 33, 21), (3, 64, 256, 64, 50)):   # norm layers: C % 32 == 0
+            x = bf(torch.randn((b, cin, h, w_), generator=g))
+            w = torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5
+            gam, bet = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+            res = bf(torch.randn((b, cout, h, w_), generator=g))
+            gy = bf(torch.randn((b, cout, h, w_), generator=g))
+            got = {}
+            for mode in ("in the conv", "own launch", "declined"):
+                F.LAZY_BN_APPLY = mode != "own launch"
+                conv = Conv2d(cin, cout, 1, bias=False, norm=BatchNorm2d(cout, sync=False)).to(DEV)
+                conv.train()
+                with torch.no_grad():
+                    conv.weight.copy_(w.to(DEV))
+                    conv.norm.weight.copy_(gam.to(DEV))
+                    conv.norm.bias.copy_(bet.to(DEV))
+                opt = FlatSGD(conv, lr=0.1)
+                opt.zero_grad()
+                xd = nhwc(x).requires_grad_(True)
+                rd = nhwc(res).requires_grad_(True) if tail else None
+                os.environ["U2_WDGRAD_VARIANT"] = "1"
+                out = conv(xd, residual=rd, relu=tail)
+                if mode == "declined":
+                    os.environ["U2_WDGRAD_VARIANT"] = "4"
+                out.backward(nhwc(gy))
+                if mode == "in the conv":
+                    assert last_kernel() == 2761, (cin, cout, last_kernel())
+                F.assert_no_deferred_gradients()
+                F.join_all_streams()
+                got[mode] = (xd.grad.clone(), conv.weight.grad.detach().float().clone(), conv.norm.weight.grad.detach().clone(),
+                             conv.norm.bias.grad.detach().clone(), rd.grad.clone() if tail else None)
+            ref = got["own launch"]
+            for mode in ("in the conv", "declined"):
+                dx, dw, dg, db, dr = got[mode]
+                # (the backward column sums are fp32 atomics: the coefficients differ in their last bits between two runs, which
+                # flips a few bf16 roundings of dy; tests/native/selftest wdgrad_bn holds the bit-for-bit comparison on fixed k)
+                assert rel_err(dx.float(), ref[0].float()) < 2 * ULP, (mode, cin, cout)   # one bf16 step of single elements
+                assert float((dx != ref[0]).float().mean()) < (1.0 if mode == "declined" else 0.02), (mode, cin, cout)
+                assert rel_err(dw, ref[1]) < 1e-4, (mode, cin, cout)
+                assert rel_err(dg, ref[2]) < 1e-5 and rel_err(db, ref[3]) < 1e-5, (mode, cin, cout)
+                if tail:
+                    assert torch.equal(dr, ref[4]), (mode, cin, cout)
+            assert float(ref[0].float().abs().max()) > 0
+    finally:
+        F.FUSED_BWD_MIN_PIXELS, F.LAZY_BN_APPLY = old_min, old_lazy
+        F.set_deterministic_stats(False)
+        os.environ.pop("U2_WDGRAD_VARIANT") if old_env is None else os.environ.__setitem__("U2_WDGRAD_VARIANT", old_env)
+
+
 def test_fused_1x1_backward_full_shape_auto(F):
     """res2 conv3 (1x1 64 -> 256 over 16 x 200 x 336 pixels) through the automatic dispatch: the fused launch (code 2751) takes it;
     dW against an fp32 reference formed by torch on the GPU over all 1 075 200 pixels, dx at 4096 sampled pixels."""

@@ -79,7 +79,8 @@ int launch_wgrad_stream(const bf16_t* x, const bf16_t* dy, float* dw, long long 
 
 int launch_wdgrad_stream(const bf16_t* x, const bf16_t* dy, const bf16_t* wt, bf16_t* dx, float* dw, long long dw_sn, int dw_sc,
                          int n_valid, int c_valid, const bf16_t* zero, int M, int C, int x_ld, int N, int dy_ld, int wt_ld,
-                         int dx_ld, int force, int tiny, hipStream_t s);
+                         int dx_ld, int force, int tiny, hipStream_t s, const bf16_t* yn = nullptr, const float* k1 = nullptr,
+                         const float* k2 = nullptr, const float* k3 = nullptr);
 
 // Library-owned device scratch (conv_igemm.hip), one block per (device, stream, kind): the kernels of a stream run one after
 // the other, so consecutive launches share it.  Sized to the largest launch seen so far - allocated on first need, grown on

@@ -1431,6 +1431,24 @@ extern "C" int u2_conv1x1_bwd_fused(const void* x, const void* dy, const void* w
   return rc < 0 ? rc : 1;
 }
 
+extern "C" int u2_conv1x1_bwd_fused_bn(const void* x, const void* dz, const void* y, const float* k1, const float* k2,
+                                       const float* k3, const void* wt, void* dx, float* dw, int M, int C, int x_ld, int N, int dy_ld,
+                                       int wt_ld, int dx_ld, int n_valid, int c_valid, long long dw_stride_n, int dw_stride_c,
+                                       int variant, void* stream) {
+  if (n_valid > N || c_valid > C || !y || !k1 || !k2 || !k3) return -1;
+  const bf16_t* zero = zero_page_ptr();
+  if (!zero) return -2;
+  if (M <= 0) return 0;
+  variant = env_variant("U2_WDGRAD_VARIANT", variant);
+  if (variant & 4) return 1;
+  const int rc = launch_wdgrad_stream((const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)wt, (bf16_t*)dx, dw, dw_stride_n,
+                                      dw_stride_c, n_valid, c_valid, zero, M, C, x_ld, N, dy_ld, wt_ld, dx_ld,
+                                      (variant & 1) | ((variant >> 2) & 2), (variant >> 1) & 1, (hipStream_t)stream, (const bf16_t*)y,
+                                      k1, k2, k3);
+  if (rc == 1) return 0;
+  return rc < 0 ? rc : 1;
+}
+
 extern "C" int u2_conv_wgrad(const void* x, const void* dy, float* dw, int B, int Hin, int Win, int C, int x_ld,
                              int Hout, int Wout, int N, int dy_ld, int KH, int KW, int pad_h, int pad_w,
                              int stride, int variant, void* stream) {

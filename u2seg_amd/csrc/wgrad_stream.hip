@@ -42,7 +42,13 @@ struct WsArgs {
   bf16_t* dx;         // [M][dx_ld]
   int wt_ld, dx_ld;
   int c_cover;        // channels the c-tiles must cover (DG: the physical C, so that padded channels get their zero gradient; else 0)
+  // batch-norm apply step in front (AP instantiations): dy[m][n] = k1[n] dy_in[m][n] + k2[n] yn[m][n] + k3[n], never stored
+  const bf16_t* yn;   // [M][dy_ld]: the normalisation's input = this layer's forward output
+  const float *k1, *k2, *k3;
 };
+
+// the expression of norm.hip's apply kernels, spelled the same way (same contraction by the compiler)
+__device__ __forceinline__ float ws_apply(float a1, float dz, float a2, float xf, float a3) { return a1 * dz + a2 * xf + a3; }
 
 // XOR applied to the 16-byte chunk index of pixel row `pix` of a step image with rows of RB bytes.  A half-wave of
 // ds_read_b64_tr_b16 reads 32 bytes (one chunk pair) of each of the pixels {P .. P+3, P+8 .. P+11}; the eight pieces must cover
@@ -93,16 +99,22 @@ __device__ __forceinline__ void ws_mfma_columns(f32x4 (&acc)[FN][FC], WsFrag (&y
 // under the image's swizzle these reads are conflict-free as well), against W^T fragments that stay in registers for the whole launch
 // (wave w: 16 channels c, all of N: N / 8 registers).  Saves the second HBM pass over dY that a separate data-gradient launch
 // makes - dY is the large operand of the expanding 1x1 layers (res2 64 -> 256: 550 of the 825 MB both passes touch).
-template <int WN, int WC, int FN, int FC, bool DG = false>
+// AP (with DG): the incoming gradient is not stored anywhere - the layer's output went through a batch normalisation whose
+// backward apply step dy = k1[n] dz + k2[n] y + k3[n] (norm.hip: norm_bwd_apply) is evaluated here, in the staged step image: the
+// step stages dz and the normalisation's input y (the conv's own output) next to X, every thread rewrites its share of the dz
+// image in place, a second barrier publishes it.  One read of dz and y replaces write(dy) + read(dy) of the separate pass.
+template <int WN, int WC, int FN, int FC, bool DG = false, bool AP = false>
 __global__ __launch_bounds__(WN * WC * 64, (WN * WC == 4 ? 2 : 1)) void wgrad_stream_kernel(const WsArgs a) {
   static_assert(!DG || (WC == 1 && FC == 4 && (WN == 4 || WN == 8)), "fused data gradient: N-major blocks only");
+  static_assert(!AP || DG, "the normalisation's apply step rides on the fused form");
   constexpr int NWV = WN * WC, NT = WN * FN * 16, CT = WC * FC * 16;
   constexpr int RBY = NT * 2, RBX = CT * 2;          // row bytes of the two step images
   constexpr int PY = RBY / 32, PX = RBX / 32;        // 1 KB LDS-DMA pieces per step and image (32 rows x RB bytes)
+  constexpr int PYS = AP ? 2 * PY : PY;              // AP: a second N-wide image (y) behind the first
   // every wave issues the same number of pieces per step (the counted waits are immediates): a stage is rounded up to a multiple of
   // NWV pieces, the filler pieces read the zero page into the unused tail of the stage
-  constexpr int PT = PY + PX, PPW = (PT + NWV - 1) / NWV, STAGE = PPW * NWV * 1024;
-  static_assert(PPW >= 1 && PPW <= 8 && RBY <= 1024 && RBX <= 1024 && RBY >= 64 && RBX >= 64, "unsupported block");
+  constexpr int PT = PYS + PX, PPW = (PT + NWV - 1) / NWV, STAGE = PPW * NWV * 1024;
+  static_assert(PPW >= 1 && PPW <= 10 && RBY <= 1024 && RBX <= 1024 && RBY >= 64 && RBX >= 64, "unsupported block");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,9 +139,9 @@ __global__ __launch_bounds__(WN * WC * 64, (WN * WC == 4 ? 2 : 1)) void wgrad_st
 #pragma unroll
   for (int q = 0; q < PPW; ++q) {
     const int p = q * NWV + w;
-    const bool is_y = p < PY;
+    const bool is_y = p < PYS;
     const int rb = is_y ? RBY : RBX, cpr = rb / 16;
-    const int piece = is_y ? p : p - PY;
+    const int piece = is_y ? (p < PY ? p : p - PY) : p - PYS;
     const int row = piece * (1024 / rb) + lane / cpr;
     const int pos = lane % cpr;
     const int chunk = is_y ? (pos ^ ws_swz<RBY>(row)) : (pos ^ ws_swz<RBX>(row));
@@ -139,6 +151,7 @@ __global__ __launch_bounds__(WN * WC * 64, (WN * WC == 4 ? 2 : 1)) void wgrad_st
     d_off[q] = (unsigned)(((size_t)row * (is_y ? a.dy_ld : a.x_ld) + ch) * 2);
   }
   const unsigned char* yb = reinterpret_cast<const unsigned char*>(a.dy);
+  const unsigned char* y2b = reinterpret_cast<const unsigned char*>(AP ? a.yn : a.dy);
   const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x);
   const unsigned ypitch = (unsigned)a.dy_ld * 64u, xpitch = (unsigned)a.x_ld * 64u;   // bytes per 32-pixel step
   auto issue = [&](int g, int slot) {
@@ -146,8 +159,8 @@ __global__ __launch_bounds__(WN * WC * 64, (WN * WC == 4 ? 2 : 1)) void wgrad_st
     const int m0 = st * 32;
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
-      const bool is_y = q * NWV + w < PY;    // wave-uniform
-      const unsigned char* base = is_y ? yb + (size_t)st * ypitch : xb + (size_t)st * xpitch;
+      const int p = q * NWV + w;             // wave-uniform
+      const unsigned char* base = p < PY ? yb + (size_t)st * ypitch : p < PYS ? y2b + (size_t)st * ypitch : xb + (size_t)st * xpitch;
       const int row = d_row[q] & 255;
       const unsigned char* src = (!(d_row[q] & 256) && m0 + row < a.M) ? base + d_off[q] : reinterpret_cast<const unsigned char*>(a.zero);
       glds16(reinterpret_cast<const bf16_t*>(src), smem + slot * STAGE + (q * NWV + w) * 1024);
@@ -165,7 +178,7 @@ __global__ __launch_bounds__(WN * WC * 64, (WN * WC == 4 ? 2 : 1)) void wgrad_st
     const int pix = fg * 8 + h * 4 + (fr >> 2);
     const int chy = wn * FN * 16 + (fr & 3) * 4, chx = wc * FC * 16 + (fr & 3) * 4;
     yoff[h] = (unsigned)(pix * RBY + (((chy >> 3) ^ ws_swz<RBY>(pix)) << 4) + (chy & 7) * 2);
-    xoff[h] = (unsigned)(PY * 1024 + pix * RBX + (((chx >> 3) ^ ws_swz<RBX>(pix)) << 4) + (chx & 7) * 2);
+    xoff[h] = (unsigned)(PYS * 1024 + pix * RBX + (((chx >> 3) ^ ws_swz<RBX>(pix)) << 4) + (chx & 7) * 2);
   }
 
   f32x4 acc[FN][FC];
@@ -187,6 +200,27 @@ __global__ __launch_bounds__(WN * WC * 64, (WN * WC == 4 ? 2 : 1)) void wgrad_st
   const int dcb = NWV == 4 ? w : (w & 3);
   const int dpb0 = NWV == 4 ? 0 : (w >> 2);
   const int dxc = c0 + dcb * 16 + fg * 4;         // first of the lane's 4 output channels
+  // AP: the thread rewrites chunk `acg` (8 channels) of APR rows per step; its 24 coefficients stay in registers
+  constexpr int CPR = RBY / 16, APR = AP ? 32 * CPR / (NWV * 64) : 1;
+  float ak1[8], ak2[8], ak3[8];
+  unsigned aoff[APR];
+  if constexpr (AP) {
+    static_assert(32 * CPR % (NWV * 64) == 0 && (NWV * 64) % CPR == 0, "rows per thread");
+    const int acg = tid % CPR;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int n = n0 + acg * 8 + e;
+      const bool ok = n < a.n_valid;
+      ak1[e] = ok ? a.k1[n] : 0.f;
+      ak2[e] = ok ? a.k2[n] : 0.f;
+      ak3[e] = ok ? a.k3[n] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < APR; ++j) {
+      const int row = tid / CPR + j * (NWV * 64 / CPR);
+      aoff[j] = (unsigned)(row * RBY + ((acg ^ ws_swz<RBY>(row)) << 4));
+    }
+  }
   if constexpr (DG) {
     const int crow = c0 + dcb * 16 + fr;          // A operand row: channel c
     const bf16_t* wsrc = a.wt + (size_t)(crow < a.C ? crow : 0) * a.wt_ld + fg * 8;
@@ -200,6 +234,10 @@ __global__ __launch_bounds__(WN * WC * 64, (WN * WC == 4 ? 2 : 1)) void wgrad_st
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int ks = 0; ks < KSN; ++ks) asm volatile("" : "+v"(wreg[ks]));
+    if constexpr (AP) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(ak1[e]), "+v"(ak2[e]), "+v"(ak3[e]));
+    }
 #pragma unroll
     for (int p = 0; p < DPX; ++p) {
       const int pix = (dpb0 + p) * 16 + fr;
@@ -250,6 +288,28 @@ __global__ __launch_bounds__(WN * WC * 64, (WN * WC == 4 ? 2 : 1)) void wgrad_st
     // (which, counting only the LDS-DMA pieces issued behind it, waits for them as well)
     store_pending();
     const unsigned sb = lds0 + (unsigned)(slot * STAGE);
+    if constexpr (AP) {
+      // dy = k1 dz + k2 y + k3, evaluated and rounded as norm_bwd_apply does, over the dz image in place
+      s16x8 zv[APR], yv[APR];
+#pragma unroll
+      for (int j = 0; j < APR; ++j) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(zv[j]) : "v"(sb + aoff[j]) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(yv[j]) : "v"(sb + aoff[j] + (unsigned)(PY * 1024)) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < APR; ++j) {
+        asm volatile("" : "+v"(zv[j]), "+v"(yv[j]));
+        s16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          ov[e] = (short)f2bf(ws_apply(ak1[e], bf2f((unsigned short)zv[j][e]), ak2[e], bf2f((unsigned short)yv[j][e]), ak3[e]));
+        asm volatile("ds_write_b128 %0, %1" ::"v"(sb + aoff[j]), "v"(ov) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
     // fused data gradient: the B fragments (dY rows as they lie, 8 channels n per lane) of reduction steps k0 .. k0 + KG - 1
     constexpr int NGRP = DG ? KSN / KG : 1, NRD = KG * DPX;
     s16x8 bf[2][KG][DPX];
@@ -329,10 +389,10 @@ __global__ __launch_bounds__(WN * WC * 64, (WN * WC == 4 ? 2 : 1)) void wgrad_st
     }
 }
 
-template <int WN, int WC, int FN, int FC, bool DG = false>
+template <int WN, int WC, int FN, int FC, bool DG = false, bool AP = false>
 int launch_ws(WsArgs& a, int per_cu, int tiny, int code, hipStream_t s) {
   constexpr int NWV = WN * WC, NT = WN * FN * 16, CT = WC * FC * 16;
-  constexpr int STAGE = ((NT + CT) / 16 + NWV - 1) / NWV * NWV * 1024;
+  constexpr int STAGE = (((AP ? 2 : 1) * NT + CT) / 16 + NWV - 1) / NWV * NWV * 1024;
   a.tiles_n = (a.n_valid + NT - 1) / NT;
   a.tiles_c = ((a.c_cover > a.c_valid ? a.c_cover : a.c_valid) + CT - 1) / CT;
   const int tiles = a.tiles_n * a.tiles_c;
@@ -350,10 +410,10 @@ int launch_ws(WsArgs& a, int per_cu, int tiny, int code, hipStream_t s) {
   a.ranges = ranges;
   static PerDeviceOnce attr_set;
   if (attr_set.first()) {
-    (void)hipFuncSetAttribute((const void*)wgrad_stream_kernel<WN, WC, FN, FC, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)wgrad_stream_kernel<WN, WC, FN, FC, DG, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   g_last_conv_kernel = code;
-  hipLaunchKernelGGL((wgrad_stream_kernel<WN, WC, FN, FC, DG>), dim3((unsigned)(ranges * tiles)), dim3(NWV * 64), (size_t)ring * STAGE, s, a);
+  hipLaunchKernelGGL((wgrad_stream_kernel<WN, WC, FN, FC, DG, AP>), dim3((unsigned)(ranges * tiles)), dim3(NWV * 64), (size_t)ring * STAGE, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return -1000 - (int)e;
   return 1;
@@ -374,6 +434,7 @@ int launch_wgrad_stream(const bf16_t* x, const bf16_t* dy, float* dw, long long 
   a.M = M; a.N = N; a.C = C; a.x_ld = x_ld; a.dy_ld = dy_ld;
   a.steps = (M + 31) / 32;
   a.wt = nullptr; a.dx = nullptr; a.wt_ld = a.dx_ld = 0; a.c_cover = 0;
+  a.yn = nullptr; a.k1 = a.k2 = a.k3 = nullptr;
   if (!force && M < 200000) return 0;   // >= ~25 steps per work-group: shorter launches stay on the tile kernels
   if (cfg == 0) {
     // the block shape follows the operands: the wider one along its 256, blocks beyond 256 x 256 are tiled (the narrower
@@ -399,21 +460,31 @@ int launch_wgrad_stream(const bf16_t* x, const bf16_t* dy, float* dw, long long 
 // The same launch with the data gradient fused in (wgrad_stream_kernel<.., DG>): dx[m][c] = sum_n dy[m][n] wt[c][n] for the 1x1 /
 // stride-1 layers whose block is all of N (<= 512) by 64 input channels.  Returns 1 when it took the launch, 0 when the shape is
 // not served (the caller runs the two separate launches), < 0 on a launch failure.  g_last_conv_kernel code: 2750 + N block / 256.
+// yn / k1..k3 (optional): dy is the gradient in front of a batch normalisation's apply step, evaluated on the fly (AP above).
 int launch_wdgrad_stream(const bf16_t* x, const bf16_t* dy, const bf16_t* wt, bf16_t* dx, float* dw, long long dw_sn, int dw_sc,
                          int n_valid, int c_valid, const bf16_t* zero, int M, int C, int x_ld, int N, int dy_ld, int wt_ld,
-                         int dx_ld, int force, int tiny, hipStream_t s) {
+                         int dx_ld, int force, int tiny, hipStream_t s, const bf16_t* yn, const float* k1, const float* k2,
+                         const float* k3) {
   if ((C & 7) || (N & 7) || (x_ld & 7) || (dy_ld & 7) || (wt_ld & 7) || (dx_ld & 7) || M < 1 || n_valid < 1 || c_valid < 1) return 0;
   if (dx_ld < C || wt_ld < N) return 0;
   if ((unsigned long long)M * (unsigned)x_ld * 2ull >= 0xffffffffull || (unsigned long long)M * (unsigned)dy_ld * 2ull >= 0xffffffffull) return 0;
   const bool small = N <= 256 && C <= 64, wide = N > 256 && N <= 512 && C <= 128;
   if (!small && !wide) return 0;
-  if (!force && (M < 200000 || n_valid <= 128)) return 0;
+  if (!(force & 1) && (M < 200000 || n_valid <= 128)) return 0;
   WsArgs a;
   a.x = x; a.dy = dy; a.dw = dw; a.dw_sn = dw_sn; a.dw_sc = dw_sc; a.n_valid = n_valid; a.c_valid = c_valid; a.zero = zero;
   a.M = M; a.N = N; a.C = C; a.x_ld = x_ld; a.dy_ld = dy_ld;
   a.steps = (M + 31) / 32;
   a.wt = wt; a.dx = dx; a.wt_ld = wt_ld; a.dx_ld = dx_ld;
   a.c_cover = C;   // the c-tiles cover the PHYSICAL input channels: padded channels get their zero data gradient written too
+  a.yn = yn; a.k1 = k1; a.k2 = k2; a.k3 = k3;
+  if (yn) {
+    // with the normalisation's apply step in front: two N-wide images per step, so only the 256-channel block (one 8-wave
+    // work-group per CU, 40 KB stages, ring of 4); code 2761
+    if (!small || !k1 || !k2 || !k3) return 0;
+    if (force & 2) return launch_ws<4, 1, 4, 4, true, true>(a, 2, tiny, 2762, s);   // two 4-wave work-groups per CU, ring of 2
+    return launch_ws<8, 1, 2, 4, true, true>(a, 1, tiny, 2761, s);
+  }
   if (small) return launch_ws<4, 1, 4, 4, true>(a, 2, tiny, 2751, s);
   return launch_ws<8, 1, 4, 4, true>(a, 1, tiny, 2752, s);
 }

@@ -9,6 +9,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from ..layers import functional as F
+
 
 def launch_info():
     """(rank, local_rank, world_size) from the torchrun environment."""
@@ -36,6 +38,7 @@ class SimpleTrainer:
         loss_dict = self.model(batched_inputs)
         losses = sum(loss_dict.values())
         losses.backward()
+        F.assert_no_deferred_gradients()
         grad_scale = self.optimizer.all_reduce_grads()
         self.optimizer.step(grad_scale)
         if self.scheduler is not None:

@@ -337,6 +337,22 @@ class _Conv2dFn(Function):
         n, cin, kh, kw = weight.shape
         b, h, w_, cp = x.shape
         _, ho, wo, npad = dout.shape
+        lazy = _LAZY_GRADS.pop(dout.data_ptr(), None) if _LAZY_GRADS else None
+        if lazy is not None:
+            # the gradient is still (dz, y, coefficients) of the batch normalisation behind this layer
+            _ph, lz_dz, lz_y, lz_k = lazy
+            assert not relu and not has_bias and kh == 1 and kw == 1 and stride == 1 and pad == 0
+            dst = ctx.wgrad_dst
+            wd = weight_dgrad_layout(weight, cp, npad, ctx.param)
+            dx = torch.empty_like(x)
+            if dst is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and _hip.call_status(
+                    "u2_conv1x1_bwd_fused_bn", x, lz_dz, lz_y, lz_k[2], lz_k[3], lz_k[4], wd, dx, dst, b * h * w_, cp, cp, npad, npad,
+                    npad, cp, n, cin, cin, 1, 0) == 0:
+                return dx, None, None, None, None, None, None, None, None
+            dout = torch.empty_like(lz_y)   # not served after all: the apply step as its own launch, then the usual paths
+            _hip.call("u2_norm_bwd_apply", lz_dz, None, lz_y, lz_k[2], lz_k[3], lz_k[4], dout, None, 1, b * h * w_, npad, npad, 0,
+                      None, None)
+            dx = None
         dout = dout.contiguous()
         if relu:
             dz = torch.empty_like(dout)
@@ -444,8 +460,14 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, want_stats=False, 
     itself when that is a Parameter); it carries the optimizer's gradient slot and the cached kernel layouts."""
     if param is None and isinstance(weight, torch.nn.Parameter):
         param = weight
+    slot = grad_slot(param) if param is not None else None
     out, stats = _Conv2dFn.apply(x, weight, bias, stride, pad, relu, want_stats,
-                                 (param, grad_slot(param)) if param is not None else None, round_bias)
+                                 (param, slot) if param is not None else None, round_bias)
+    if LAZY_BN_APPLY and want_stats and slot is not None and bias is None and not relu and stride == 1 and pad == 0 \
+            and x.requires_grad and tuple(weight.shape[2:]) == (1, 1) and 128 < weight.shape[0] <= 256 and x.shape[3] <= 64 \
+            and x.shape[0] * x.shape[1] * x.shape[2] >= FUSED_BWD_MIN_PIXELS:
+        # a batch normalisation on this output may leave its backward apply step to this layer's fused backward launch
+        out._u2_lazy_ok = True
     return (out, stats) if want_stats else out
 
 
@@ -542,10 +564,11 @@ class _BatchNormActFn(Function):
 
     @staticmethod
     def forward(ctx, y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, grad_dst=None,
-                twin=False, sync=True, res_up=False):
+                twin=False, sync=True, res_up=False, lazy_ok=False):
         _check_act(y)
         b, h, w, c = y.shape
         m = b * h * w
+        ctx.lazy_ok = lazy_ok
         world = _world() if sync else 1
         count, count_dev = float(m), None
         if world > 1:
@@ -598,7 +621,7 @@ class _BatchNormActFn(Function):
         relu, count, world, has_res = ctx.cfg
         b, h, w, c = y.shape
         m = b * h * w
-        nret = 14
+        nret = 15
         arrived = [g.contiguous() for g in (dout, dout2, dout3) if g is not None]
         if not arrived:
             return (None,) * nret
@@ -620,6 +643,18 @@ class _BatchNormActFn(Function):
         coef = torch.empty((5, c), dtype=torch.float32, device=y.device)
         direct = ctx.grad_dst is not None
         dgamma, dbeta = ctx.grad_dst if direct else (coef[0], coef[1])
+        if ctx.lazy_ok and LAZY_BN_APPLY and (fuse or (not relu and not has_res)):
+            # the producing 1x1 conv evaluates the apply step dx = k1 dz + k2 y + k3 on its staged rows (u2_conv1x1_bwd_fused_bn,
+            # round 5): only the coefficients (and dgamma / dbeta) are computed here, dx is never stored.  What autograd carries
+            # to the conv is a one-element placeholder expanded to the shape; _Conv2dFn.backward finds the operands by its address.
+            _hip.call("u2_bn_finalize_bwd", sums, count, ctx.count_dev, gamma, mean, invstd, local, dgamma, dbeta, coef[2], coef[3],
+                      coef[4], c, int(direct))
+            ph = torch.empty(1, dtype=BF16, device=y.device).expand(y.shape)
+            _LAZY_GRADS[ph.data_ptr()] = (ph, dz if fuse else dout, y, coef)
+            if len(_LAZY_GRADS) > 8:
+                raise RuntimeError("deferred batch-norm gradients were not consumed by their convolutions")
+            return ph, None, (None if direct else dgamma), (None if direct else dbeta), None, None, (dz if fuse else None), \
+                None, None, None, None, None, None, None, None
         dx = torch.empty_like(y)
         # finalize (coefficients of dx, dgamma / dbeta) + apply in one launch (round 4); coef[2:5] is scratch for the channel
         # counts the one-launch form does not serve
@@ -636,7 +671,7 @@ class _BatchNormActFn(Function):
                 _hip.call("u2_fpn_upsample_add_bwd", dout, dres, b, h, w, c)
         if direct:
             dgamma = dbeta = None
-        return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
+        return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
 
 
 def batch_norm_act(y, stats, gamma, beta, running_mean, running_var, residual=None, relu=False, momentum=0.1,
@@ -649,7 +684,7 @@ def batch_norm_act(y, stats, gamma, beta, running_mean, running_var, residual=No
     grad_dst = (gd, bd) if gd is not None and bd is not None else None
     twin = (3 if twin == 3 else int(bool(twin))) if torch.is_grad_enabled() else 0
     out = _BatchNormActFn.apply(y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, grad_dst,
-                                twin, sync, res_up)
+                                twin, sync, res_up, bool(getattr(y, "_u2_lazy_ok", False)))
     if twin == 3:  # a third handle (`._u2_third`) for a third consumer, e.g. the FPN lateral conv on a stage output
         out, other, third = out
         out._u2_twin, out._u2_third = other, third
@@ -1104,6 +1139,17 @@ def roi_grad_tap(feats):
 
 
 FUSED_BWD_MIN_PIXELS = int(os.environ.get("U2_FUSED_BWD_MIN_PIXELS", "200000"))
+# the batch-norm backward apply step of an expanding 1x1 layer evaluated inside that layer's fused backward launch (0: separate)
+LAZY_BN_APPLY = os.environ.get("U2_LAZY_BN_APPLY", "1") != "0"
+_LAZY_GRADS = {}   # placeholder address -> (placeholder, dz, y, coefficients [5][C]: rows 2-4 = k1, k2, k3)
+
+
+def assert_no_deferred_gradients():
+    """After a backward pass: every deferred batch-norm gradient must have been consumed by its convolution."""
+    if _LAZY_GRADS:
+        n = len(_LAZY_GRADS)
+        _LAZY_GRADS.clear()
+        raise RuntimeError("%d deferred batch-norm gradients were not consumed by their convolutions" % n)
 ROI_ORDER_MIN = int(os.environ.get("U2_ROI_ORDER_MIN", "1000000000"))
 
 
