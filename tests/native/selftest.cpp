@@ -497,6 +497,25 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (argc > 1 && !strcmp(argv[1], "tile7")) {
+    // conv_tile configuration 7 (whole K tiles of 64 channels per ring stage): whole tiles / stream-K shares, full grid / 8 groups
+    const ConvCase k64[] = {
+        {1, 700, 3, 256, 512, 1, 1, 0, 1, 1, 0, 0, 0, 1, "tile7 1x1 c256 n512 stats"},
+        {1, 700, 3, 256, 512, 1, 1, 0, 1, 1, 1, 0, 1, 0, "tile7 1x1 c256 n512 bias relu"},
+        {1, 300, 3, 1024, 256, 1, 1, 0, 1, 1, 0, 0, 0, 1, "tile7 1x1 c1024 n256 stats"},
+        {2, 36, 32, 64, 256, 3, 3, 1, 1, 1, 0, 0, 0, 1, "tile7 3x3 c64 n256 stats"},
+        {2, 18, 20, 128, 128, 3, 3, 1, 1, 2, 0, 0, 0, 0, "tile7 dgrad(3x3 s2) c128 n128"},
+        {2, 37, 41, 192, 136, 1, 1, 0, 2, 1, 0, 0, 0, 1, "tile7 1x1 s2 c192 n136 stats"},
+        {1, 1100, 1, 512, 264, 1, 1, 0, 1, 1, 0, 0, 0, 0, "tile7 gemm k512 n264"},
+    };
+    for (int v : {7 << 12, (7 << 12) | (1 << 16), (7 << 12) | (1 << 27), (7 << 12) | (1 << 27) | (1 << 16), (7 << 12) | (1 << 28)})
+      for (const auto& c : k64) {
+        fails += test_conv(c, v);
+        if (u2_conv_last_kernel() % 100 != 7) { printf("FAIL %-28s v%x did not take configuration 7 (%d)\n", c.name, v, u2_conv_last_kernel()); ++fails; }
+      }
+    printf("SELFTEST tile7 %s (%d failures)\n", fails ? "FAILED" : "OK", fails);
+    return fails ? 1 : 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "wdgrad_bn")) {
     for (int v : {1, 3, 1 | 8, 3 | 8}) {   // forced; | 2: 8 pixel ranges; | 8: the 4-wave block, two work-groups per CU
       fails += test_wdgrad_bn(37 * 29, 64, 256, 64, 256, v, "wdgrad_bn 64->256");

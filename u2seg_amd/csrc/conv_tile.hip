@@ -91,16 +91,25 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 // launch is resident (grid <= CUs x work-groups per CU), and nobody waits before having published, so the hand-over cannot
 // deadlock; slot stores and loads are both `sc0 sc1` (coherent for any placement of the two work-groups, MI355X_MICROARCH.md
 // "Workgroup dispatch ..."), the flag is a relaxed agent-scope atomic behind s_waitcnt vmcnt(0) + barrier.
-template <int WCH, int WPX, int RING, bool ACC = false, bool SK = false>
+// KT = 2 (round 5): a stage of the ring is a WHOLE K tile - rows of 64 channels, 128 bytes, so that an LDS-DMA instruction moves
+// 8 rows x 128 contiguous bytes instead of 16 x 64 (tests/native/dma_bench: 64-byte pieces at a 1-4 KB pitch stream at 3.5 TB/s,
+// 128-byte pieces at 6.3).  For the HBM-streaming 1x1 layers with long rows (K >= 512).  Two half-tile MFMA sequences per stage;
+// staging, the counted wait and the barrier happen once per stage (weights at the first half, pixels behind the barrier of the
+// second).  In the text below "half K tile" then reads "K tile" wherever it means the ring's unit.
+template <int WCH, int WPX, int RING, bool ACC = false, bool SK = false, int KT = 1>
 __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const ConvArgs a) {
   constexpr int NW = WCH * WPX, NT = NW * 64;
   constexpr int TN = WCH * 64, TM = WPX * 128;
-  constexpr int LP = TM * 4 / NT;   // 16-byte chunks a thread moves per half K tile, pixel operand
-  constexpr int LW = TN * 4 / NT;   //                                                weight operand
+  constexpr int KU = 32 * KT;        // channels per stage
+  constexpr int ROWB = 64 * KT;      // bytes per staged row
+  constexpr int CPRW = ROWB / 16;    // 16-byte chunks per row
+  constexpr int RPI = 1024 / ROWB;   // rows one LDS-DMA instruction moves
+  constexpr int LP = TM * CPRW / NT;   // 16-byte chunks a thread moves per stage, pixel operand
+  constexpr int LW = TN * CPRW / NT;   //                                         weight operand
   constexpr int LPT = LP + LW;
-  constexpr int PBYTES = TM * 64, WBYTES = TN * 64, BUF = PBYTES + WBYTES;  // one half K tile: rows of 32 bf16
+  constexpr int PBYTES = TM * ROWB, WBYTES = TN * ROWB, BUF = PBYTES + WBYTES;  // one stage: rows of KU bf16
   constexpr int AHEAD = RING - 1;
-  static_assert(LP >= 1 && LW >= 1 && RING >= 3 && RING <= 5, "unsupported configuration");
+  static_assert(LP >= 1 && LW >= 1 && RING >= (KT == 2 ? 2 : 3) && RING <= 5 && (KT == 1 || KT == 2), "unsupported configuration");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -114,7 +123,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   const int q8 = T >> 3, r8 = T & 7;
   const int xbase = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
   const int xcnt = q8 + (xcd < r8 ? 1 : 0);
-  const int kh_per_tap = a.C >> 5;           // half K tiles (32 channels) per filter tap
+  const int kh_per_tap = a.C / KU;           // stages (KU channels) per filter tap
   const int nkh = a.ntaps * kh_per_tap;      // >= RING (host)
   int my_tiles, first_tile, H;
   int sk_k0 = 0, sk_k1 = nkh;                // SK: first half K tile of the first tile / end of the last tile of this share
@@ -141,8 +150,8 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   // ---- staging cursors.  The pixel cursor runs AHEAD + 1 half tiles in front of the MFMAs, the weight cursor AHEAD; both
   // cross tile boundaries on their own.  Per row a thread keeps the address of the tap-(0,0) source pixel and its (y, x):
   // a tap only adds a wave-uniform offset and a bounds test (rows that fall into the padding read the zero page).
-  const int row_in = lane >> 2;
-  const int cc = (lane & 3) ^ swz<32>(row_in);
+  const int row_in = lane / CPRW;
+  const int cc = (lane % CPRW) ^ swz<KU>(row_in);
   const int hw = a.Hout * a.Wout;
   const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)a.Wout;
   const bool linear = a.ntaps == 1 && a.mul == 1 && a.Hin == a.Hout && a.Win == a.Wout &&
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     const int m0 = (tile / a.tiles_n) * TM;
 #pragma unroll
     for (int i = 0; i < LP; ++i) {
-      const int m = m0 + (i * NW + w) * 16 + row_in;
+      const int m = m0 + (i * NW + w) * RPI + row_in;
       if (m < a.M) {
         if (linear) {
           p_center[i] = (unsigned)(((size_t)m * a.in_ld + cc * 8) * 2);
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       for (int i = 0; i < LP; ++i) {
         const int sy = (int)(short)(p_yx[i] & 0xffff) + dy, sx = (p_yx[i] >> 16) + dx;
         const bool ok = (unsigned)sy < (unsigned)a.Hin && (unsigned)sx < (unsigned)a.Win;
-        p_src[i] = ok ? reinterpret_cast<const bf16_t*>(tap_base + p_center[i]) + skip * 32 : a.zero;
+        p_src[i] = ok ? reinterpret_cast<const bf16_t*>(tap_base + p_center[i]) + skip * KU : a.zero;
         p_okmask |= ok ? (1u << i) : 0u;
       }
       ++p_tap;
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #pragma unroll
     for (int i = 0; i < LP; ++i) {
       glds16(p_src[i], base + (i * NW + w) * 1024);
-      p_src[i] += (p_okmask >> i & 1u) * 32;
+      p_src[i] += (p_okmask >> i & 1u) * KU;
     }
   };
 
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     const int n0 = (tile % a.tiles_n) * TN;
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
-      const int R = (i * NW + w) * 16 + row_in;
+      const int R = (i * NW + w) * RPI + row_in;
       const int blk = (R >> 4) & 3, q = R & 15;
       const int n = n0 + (R & ~63) + (blk >> 1) * 32 + (q >> 2) * 8 + (blk & 1) * 4 + (q & 3);
       w_base[i] = n < a.N ? (unsigned)(((size_t)n * ((size_t)a.wt_taps * a.C) + cc * 8) * 2) : 0xffffffffu;
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   };
   auto weight_tap = [&](int skip) {
       const int wtap = a.remap_out ? (a.tap_pk[__builtin_amdgcn_readfirstlane(w_tap)] >> 16) : w_tap;
-      const unsigned char* tap_base = reinterpret_cast<const unsigned char*>(a.wt) + ((size_t)wtap * a.C + (size_t)skip * 32) * 2;
+      const unsigned char* tap_base = reinterpret_cast<const unsigned char*>(a.wt) + ((size_t)wtap * a.C + (size_t)skip * KU) * 2;
 #pragma unroll
       for (int i = 0; i < LW; ++i)
         w_src[i] = w_base[i] != 0xffffffffu ? reinterpret_cast<const bf16_t*>(tap_base + w_base[i]) : a.zero;
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
       glds16(w_src[i], base + (i * NW + w) * 1024);
-      w_src[i] += w_base[i] != 0xffffffffu ? 32 : 0;
+      w_src[i] += w_base[i] != 0xffffffffu ? KU : 0;
     }
   };
 
@@ -266,10 +275,11 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   const int fr = lane & 15;
   const int fg = lane >> 4;
   // the swizzle has a period of 16 rows: fragment t of a wave is fragment 0 + t * 1024 bytes (an immediate offset)
-  const int wfrag0 = PBYTES + (wr * 64 + fr) * 64 + ((fg ^ swz<32>(fr)) << 4);
-  const int pfrag0 = (wc * 128 + fr) * 64 + ((fg ^ swz<32>(fr)) << 4);
-  auto ldw = [&](int hb, int t) { return *reinterpret_cast<const s16x8*>(smem + hb * BUF + wfrag0 + t * 1024); };
-  auto ldp = [&](int hb, int t) { return *reinterpret_cast<const s16x8*>(smem + hb * BUF + pfrag0 + t * 1024); };
+  // (KT = 2: the second half's chunks 4-7 of a row sit at the first half's position ^ 64 bytes)
+  const int wfrag0 = PBYTES + (wr * 64 + fr) * ROWB + ((fg ^ swz<KU>(fr)) << 4);
+  const int pfrag0 = (wc * 128 + fr) * ROWB + ((fg ^ swz<KU>(fr)) << 4);
+  auto ldw = [&](int hb, int t, int half = 0) { return *reinterpret_cast<const s16x8*>(smem + hb * BUF + (wfrag0 ^ (half << 6)) + t * 16 * ROWB); };
+  auto ldp = [&](int hb, int t, int half = 0) { return *reinterpret_cast<const s16x8*>(smem + hb * BUF + (pfrag0 ^ (half << 6)) + t * 16 * ROWB); };
 
   f32x4 acc[4][8];
   s16x8 wfA[2], wfB[2], pf[8];
@@ -486,15 +496,44 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     const int h_begin = (SK && ti == 0) ? sk_k0 : 0, h_end = (SK && ti == my_tiles - 1) ? sk_k1 : nkh;
     for (int h = h_begin; h < h_end; ++h) {
       const int nb = (hb + 1 == RING) ? 0 : hb + 1;
-      const int sb = (hb == 0) ? RING - 1 : hb - 1;  // buffer of half tile gh + AHEAD (= gh - 1 mod RING)
+      const int sb = (hb == 0) ? RING - 1 : hb - 1;  // buffer of stage gh + AHEAD (= gh - 1 mod RING)
+      if constexpr (KT == 2) {
+        // ---- first half of the stage: no staging of pixels, no wait, no barrier; the second half's fragments are in the same buffer
+        __builtin_amdgcn_s_setprio(1);
+        U2_T_MFMA(0, wfA[0], 0); U2_T_MFMA(1, wfA[1], 0); U2_T_MFMA(0, wfA[0], 1); U2_T_MFMA(1, wfA[1], 1);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        pf[4] = ldp(hb, 4); pf[5] = ldp(hb, 5); pf[6] = ldp(hb, 6); pf[7] = ldp(hb, 7);
+        wfB[0] = ldw(hb, 2); wfB[1] = ldw(hb, 3);
+        if (gh + AHEAD < H) stage_weights(sb);   // the buffer of stage gh - 1: every wave left it at the last barrier
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        U2_T_MFMA(0, wfA[0], 2); U2_T_MFMA(1, wfA[1], 2); U2_T_MFMA(0, wfA[0], 3); U2_T_MFMA(1, wfA[1], 3);
+#pragma unroll
+        for (int j = 4; j < 8; ++j) { U2_T_MFMA(0, wfA[0], j); U2_T_MFMA(1, wfA[1], j); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { U2_T_MFMA(2, wfB[0], j); U2_T_MFMA(3, wfB[1], j); }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        wfA[0] = ldw(hb, 0, 1); wfA[1] = ldw(hb, 1, 1);
+        pf[0] = ldp(hb, 0, 1); pf[1] = ldp(hb, 1, 1); pf[2] = ldp(hb, 2, 1); pf[3] = ldp(hb, 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 4; j < 8; ++j) { U2_T_MFMA(2, wfB[0], j); U2_T_MFMA(3, wfB[1], j); }
+        __builtin_amdgcn_s_setprio(0);
+      }
+      constexpr int LH = KT - 1;   // the half of the stage the sequence below multiplies (its fragments 0-3 / first weight pair are in registers)
       // phase A
       __builtin_amdgcn_s_setprio(1);
       U2_T_MFMA(0, wfA[0], 0); U2_T_MFMA(1, wfA[1], 0); U2_T_MFMA(0, wfA[0], 1); U2_T_MFMA(1, wfA[1], 1);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      pf[4] = ldp(hb, 4); pf[5] = ldp(hb, 5); pf[6] = ldp(hb, 6); pf[7] = ldp(hb, 7);
-      wfB[0] = ldw(hb, 2); wfB[1] = ldw(hb, 3);
-      if (gh + AHEAD < H) stage_weights(sb);
+      pf[4] = ldp(hb, 4, LH); pf[5] = ldp(hb, 5, LH); pf[6] = ldp(hb, 6, LH); pf[7] = ldp(hb, 7, LH);
+      wfB[0] = ldw(hb, 2, LH); wfB[1] = ldw(hb, 3, LH);
+      if constexpr (KT == 1) {
+        if (gh + AHEAD < H) stage_weights(sb);
+      }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
       U2_T_MFMA(0, wfA[0], 2); U2_T_MFMA(1, wfA[1], 2); U2_T_MFMA(0, wfA[0], 3); U2_T_MFMA(1, wfA[1], 3);
@@ -503,7 +542,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       __builtin_amdgcn_s_setprio(0);
       // phase B
       {
-        const int rem = H - 2 - gh;  // half tiles staged behind gh + 1
+        const int rem = H - 2 - gh;  // stages staged behind gh + 1
         if (rem >= AHEAD - 1) wait_vm<LPT * (AHEAD - 1)>();
         else if (AHEAD > 3 && rem == 2) wait_vm<LPT * 2>();
         else if (rem == 1) wait_vm<LPT>();
@@ -574,17 +613,17 @@ bool sk_scratch(hipStream_t s, ConvArgs& a, size_t need_bytes) {
 }
 
 // sk: 0 = never, 1 = where the tile count fills its last round badly, 2 = always (tests)
-template <int WCH, int WPX, int RING, bool ACC = false>
+template <int WCH, int WPX, int RING, bool ACC = false, int KT = 1>
 int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s, int sk = 0) {
   constexpr int TN = WCH * 64, TM = WPX * 128;
-  constexpr int LDS = RING * (TM + TN) * 64;
+  constexpr int LDS = RING * (TM + TN) * 64 * KT;
   a.tiles_m = (a.M + TM - 1) / TM;
   a.tiles_n = (N + TN - 1) / TN;
   const long long T = (long long)a.tiles_m * a.tiles_n;
   if (T >= (1 << 30)) return 0;
   long long cap = tiny_grid ? (sk == 2 ? 24 : 8) : 256LL * per_cu;
   if constexpr (!ACC) {
-    const long long nkh = (long long)a.ntaps * (a.C >> 5);
+    const long long nkh = (long long)a.ntaps * (a.C / (32 * KT));   // stages per tile
     const long long rounds = (T + cap - 1) / cap;
     // Measured (tests/native/selftest bench2, profiles/r03_conv_streamk.txt): equal shares pay for the 256 x 256 configurations
     // on deep reductions when whole tiles fill the chip badly - 263 tiles (3x3 256->256 at stride 16: 642 -> 866 TFLOP/s), 132
@@ -593,16 +632,16 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s, int
     // the second, independent work-group hides) and where nearly every tile would be split for a small gain (mask head 3x3,
     // 203 tiles: -13 %).  The stream-K instantiation also spills a dozen registers (reloaded once per filter tap).
     const double util = (double)T / (double)(rounds * cap);
-    const bool want = sk == 2 || (sk == 1 && WCH == 4 && WPX == 2 && T >= 8 && nkh >= 32 && (util < 0.7 || (util < 0.9 && T >= 512) || (nkh >= 128 && T >= 512)));
+    const bool want = sk == 2 || (sk == 1 && WCH == 4 && WPX == 2 && T >= 8 && nkh * KT >= 32 && (util < 0.7 || (util < 0.9 && T >= 512) || (nkh * KT >= 128 && T >= 512)));
     long long Gs = cap;
     while (Gs > 8 && (T / 8) * nkh / (Gs / 8) < RING + 1) Gs -= 8;
     if (want && Gs <= SK_MAX_GROUPS && (T / 8) * nkh / (Gs / 8) >= RING + 1 && sk_scratch(s, a, (size_t)Gs * TM * TN * 4)) {
       static PerDeviceOnce attr_set_sk;
       if (attr_set_sk.first()) {
-        (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, false, true, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       }
       g_last_conv_kernel += 400;  // 5xx: the stream-K form of configuration xx
-      hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, false, true>), dim3((unsigned)Gs), dim3(WCH * WPX * 64), LDS, s, a);
+      hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, false, true, KT>), dim3((unsigned)Gs), dim3(WCH * WPX * 64), LDS, s, a);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return -1000 - (int)e;
       return 1;
@@ -612,9 +651,9 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s, int
   G = (G + 7) & ~7LL;
   static PerDeviceOnce attr_set;
   if (attr_set.first()) {
-    (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, ACC, false, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, ACC>), dim3((unsigned)G), dim3(WCH * WPX * 64), LDS, s, a);
+  hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, ACC, false, KT>), dim3((unsigned)G), dim3(WCH * WPX * 64), LDS, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return -1000 - (int)e;
   return 1;
@@ -625,6 +664,7 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s, int
 // variant bits 12-15 select the tile configuration: 0 = automatic, 1 = 256ch x 256px ring 4, 2 = 256 x 256 ring 5,
 // 3 = 128ch x 256px (ring 3, two groups per CU), 4 = 256ch x 128px (ring 3, two groups per CU), 5 = 128ch x 256px ring 4,
 // 6 = 64ch x 512px ring 4 (layers with <= 64 output channels: no MFMA spent on absent channels),
+// 7 = 256 x 256 with whole K tiles (64 channels, 128-byte rows) in a ring of 2 (C % 64 == 0; the long-row 1x1 layers),
 // 15 = never (conv_igemm.hip kernels only); bit 16: 8 work-groups only (tests: forces several tiles per work-group).
 // Tried and removed (numbers in profiles/r02_conv_ablation.txt, r02_conv_pingpong.txt): a j-split schedule
 // with every LDS read 12+ MFMAs ahead of its use (+0 %), and a ping-pong schedule with the two wave groups half a sequence
@@ -671,7 +711,16 @@ int launch_conv_tile(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
     }
     if (sel == 0) return 0;
   }
-  if (sel > 6) return 0;
+  if (sel > 7) return 0;
+  if (sel == 7) {
+    if ((C & 63) || a.accumulate) return 0;
+    const int nks = a.ntaps * (C >> 6);
+    const long long T7 = (long long)((a.M + 255) / 256) * ((N + 255) / 256);
+    if (nks * (T7 < 256 ? 1 : T7 / 256) < 3) return 0;   // a work-group needs ring + 1 stages over all its tiles
+    g_last_conv_kernel = 107;
+    const int sk7 = ((variant >> 28) & 1) ? 0 : ((variant >> 27) & 1) ? 2 : 1;
+    return launch_cfg<4, 2, 2, false, 2>(a, N, 1, tiny, s, sk7);
+  }
   int ring = (sel == 2) ? 5 : (sel == 1 || sel == 5 || sel == 6) ? 4 : 3;
   if (nkh < ring) {
     // a work-group only needs RING half tiles over ALL the tiles it walks; in automatic mode fall back to the ring-3

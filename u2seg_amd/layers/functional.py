@@ -169,7 +169,7 @@ _side_dirty = {}
 def _side_stream(device):
     s = _side_streams.get(device)
     if s is None:
-        s = _side_streams[device] = torch.cuda.Stream(device=device)
+        s = _side_streams[device] = torch.cuda.Stream(device=device, priority=int(os.environ.get("U2_SIDE_PRIORITY", "0")))
     return s
 
 
@@ -189,7 +189,7 @@ def aux_stream(device, index=0):
     key = (_cuda_device(device), index)
     s = _aux_streams.get(key)
     if s is None:
-        s = _aux_streams[key] = torch.cuda.Stream(device=key[0])
+        s = _aux_streams[key] = torch.cuda.Stream(device=key[0], priority=int(os.environ.get("U2_AUX_PRIORITY", "0")))
     return s
 
 
