@@ -100,6 +100,10 @@ int u2_weight_layout_batched(const float* base, const U2LayoutDesc* table, int n
 /* ---- normalisation / activation (norm.hip) ----------------------------------------------------
  * Replaces nn.SyncBatchNorm / nn.GroupNorm / relu_ chosen by detectron2/layers/batch_norm.py:169-197. */
 int u2_colstats(const void* x, float* out /*[slots][2][C]*/, int slots, int rows_per_slot, int C, int ld, void* stream);
+/* dst[c] += sum over rows of x[row][c] for c < n_valid (x: [rows][ld] bf16, C physical channels): the bias gradient of a conv /
+ * linear layer (autograd's sum over the output gradient behind layers/wrappers.py:127-134) accumulated straight into the
+ * parameter's fp32 gradient storage - no temporary, no AccumulateGrad add. */
+int u2_colsum_add(const void* x, float* dst, int rows, int C, int ld, int n_valid, void* stream);
 /* nn.GroupNorm finalize (layers/batch_norm.py:189 "GN", semantic_seg.py:196-205). fwd: stats [B][2][C] (u2_colstats per image)
  * -> mean / invstd / scale / shift [B][C], n = H*W*(C/groups) elements per group. bwd: sums [B][2][C] (u2_norm_bwd_reduce)
  * -> k1/k2/k3 [B][C] for u2_norm_bwd_apply and dgamma / dbeta [C] summed over the images in order. */
@@ -274,6 +278,22 @@ int u2_batched_nms(const float* boxes, const int* group, const int* cnt, void* w
 int u2_topk_rows(const void* vals, int dtype, int rows, int n, long long row_stride, int group, int pitch,
                  const signed char* mask, int mask_value, int k, int largest, float* out_vals, int* out_idx,
                  int* out_cnt, const int* idx_in, void* stream);
+
+/* Proposal decoding of all feature levels in one launch (proposal_generator/rpn.py:482-533, proposal_utils.py:56-91, the part
+ * between the per-level top-k and the NMS): for level l and image b the k_l candidates idx[b][j] (anchor index = pixel * A + anchor,
+ * ranked) with logits scores[b][j] are decoded from the NHWC bf16 deltas map (`deltas` points at channel 0 of the 4 A delta channels
+ * of pixel 0, `pitch` channels per pixel) against anchors [hwa][4], clipped to sizes[b] = (h, w), and written as rows of kmax >= k_l:
+ * boxes / scores [B * L][kmax] with row = b * L + l (padding: zero box, score -3e38), keep[row][j] = finite and wider / taller than
+ * min_size; *nonfinite (pre-zeroed) counts candidates with a non-finite box or logit. */
+typedef struct U2RpnLevel {
+  const void* deltas;
+  const float* anchors;
+  const int* idx;
+  const float* scores;
+  int hwa, k, pitch, reserved;
+} U2RpnLevel;
+int u2_rpn_decode(const U2RpnLevel* levels, int L, int A, int B, int kmax, const float* sizes, float wx, float wy, float ww, float wh,
+                  float clamp, float min_size, float* boxes, float* scores, signed char* keep, int* nonfinite, void* stream);
 
 /* Several selections in one launch (up to 8 segments; a work-group per row of every segment): the per-level pre-NMS top-k of
  * proposal_utils.py:79-96 over all feature levels at once, or the positive and the negative draw of sampling.py:38-54 over the

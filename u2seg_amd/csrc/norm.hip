@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
                                                         int rows_per_slot, int C, int ld, int rows_per_block,
                                                         const float* __restrict__ msc, const float* __restrict__ msh,
                                                         const bf16_t* __restrict__ dout2, bf16_t* __restrict__ dz_out,
-                                                        const bf16_t* __restrict__ dout3, int rev) {
+                                                        const bf16_t* __restrict__ dout3, int rev, int sum_limit = 0) {
+  // sum_limit > 0 (MODE 0): only the column sums of channels < sum_limit, added at out[c] (a bias gradient accumulated into the
+  // parameter's arena slice: u2_colsum_add)
   __shared__ float part[2][2048];
   constexpr int U = 2;  // rows in flight per thread
   const int cpr = C >> 3;
@@ -159,6 +161,10 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
     for (int j = tid; j < ncol * 8; j += 256) {
       float t0 = 0.f, t1 = 0.f;
       for (int q = 0; q < rows_par; ++q) { t0 += part[0][q * ncol * 8 + j]; t1 += part[1][q * ncol * 8 + j]; }
+      if (sum_limit > 0) {
+        if (cbase * 8 + j < sum_limit) atomicAdd(out + cbase * 8 + j, t0);
+        continue;
+      }
       atomicAdd(out + ((size_t)slot * 2 + 0) * C + cbase * 8 + j, t0);
       atomicAdd(out + ((size_t)slot * 2 + 1) * C + cbase * 8 + j, t1);
     }
@@ -829,6 +835,19 @@ extern "C" int u2_colstats(const void* x, float* out, int slots, int rows_per_sl
   const dim3 grid((rows_per_slot + rpb - 1) / rpb, slots);
   hipLaunchKernelGGL((colreduce_kernel<0, 0, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, nullptr,
                      nullptr, nullptr, nullptr, out, rows_per_slot, C, ld, rpb, nullptr, nullptr, nullptr, nullptr, nullptr, (stream_order() >> 1) & 1);  // a reduction: bit 1
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_colsum_add(const void* x, float* dst, int rows, int C, int ld, int n_valid, void* stream) {
+  if ((C & 7) || (ld & 7) || n_valid < 1 || n_valid > C) return -1;
+  if (rows <= 0) return 0;
+  int rpb = (rows + 511) / 512;
+  if (rpb < 64) rpb = 64;
+  const dim3 grid((rows + rpb - 1) / rpb, 1);
+  hipLaunchKernelGGL((colreduce_kernel<0, 0, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, nullptr,
+                     nullptr, nullptr, nullptr, dst, rows, C, ld, rpb, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     (stream_order() >> 1) & 1, n_valid);
   U2_CHECK_LAUNCH();
   return 0;
 }

@@ -754,6 +754,57 @@ __global__ void apply_deltas_kernel(const float* __restrict__ src, const float* 
   o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2;
 }
 
+// ---- RPN proposal decoding, all levels in one launch (round 5) ---------------------------------------------------------------
+// rpn.py:482-533 + proposal_utils.py:56-91 for the candidates the per-level top-k selected: gather the 4 deltas of anchor idx from
+// the NHWC bf16 map (pixel idx / A, channels (idx % A) * 4 .. + 3 of the deltas view), apply them to the anchor, clip to the image,
+// and emit the row layout the per-(image, level) NMS works on: boxes / scores [B * L][kmax] (row = image * L + level, a short
+// level padded with zero boxes and score -3e38) and keep = finite & wider and taller than min_size.  Non-finite candidates are
+// counted (the caller raises on the host when it first reads counts).  Same arithmetic as apply_deltas_kernel above.
+struct RpnDecodeArgs {
+  U2RpnLevel lv[8];
+  int L, A, B, kmax;
+  const float* sizes;
+  float wx, wy, ww, wh, clamp, min_size;
+  float* boxes; float* scores; signed char* keep; int* nonfinite;
+};
+__global__ __launch_bounds__(256) void rpn_decode_kernel(const RpnDecodeArgs a) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = blockIdx.y;             // image * L + level
+  if (j >= a.kmax) return;
+  const int b = row / a.L, l = row - b * a.L;
+  const U2RpnLevel lv = a.lv[l];
+  float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, sc = -3.0e38f;
+  bool keep = false;
+  if (j < lv.k) {
+    const int i = lv.idx[(size_t)b * lv.k + j];
+    const int pix = i / a.A, anc = i - pix * a.A;
+    const bf16_t* dp = reinterpret_cast<const bf16_t*>(lv.deltas) + ((size_t)b * (lv.hwa / a.A) + pix) * lv.pitch + anc * 4;
+    const float* s = lv.anchors + (size_t)i * 4;
+    const float d0 = bf2f(dp[0]), d1 = bf2f(dp[1]), d2 = bf2f(dp[2]), d3 = bf2f(dp[3]);
+    const float w = s[2] - s[0], h = s[3] - s[1];
+    const float cx = s[0] + 0.5f * w, cy = s[1] + 0.5f * h;
+    const float dx = d0 / a.wx, dy = d1 / a.wy;
+    float dw = d2 / a.ww, dh = d3 / a.wh;
+    dw = fminf(dw, a.clamp);
+    dh = fminf(dh, a.clamp);
+    const float pcx = dx * w + cx, pcy = dy * h + cy;
+    const float pw = expf(dw) * w, ph = expf(dh) * h;
+    x1 = pcx - 0.5f * pw; y1 = pcy - 0.5f * ph; x2 = pcx + 0.5f * pw; y2 = pcy + 0.5f * ph;
+    const float H = a.sizes[b * 2 + 0], W = a.sizes[b * 2 + 1];
+    x1 = fminf(fmaxf(x1, 0.f), W); x2 = fminf(fmaxf(x2, 0.f), W);
+    y1 = fminf(fmaxf(y1, 0.f), H); y2 = fminf(fmaxf(y2, 0.f), H);
+    sc = lv.scores[(size_t)b * lv.k + j];
+    const bool finite = isfinite(x1) && isfinite(y1) && isfinite(x2) && isfinite(y2) && isfinite(sc);
+    if (!finite) atomicAdd(a.nonfinite, 1);
+    keep = finite && (x2 - x1) > a.min_size && (y2 - y1) > a.min_size;
+  }
+  const size_t o = (size_t)row * a.kmax + j;
+  float* bo = a.boxes + o * 4;
+  bo[0] = x1; bo[1] = y1; bo[2] = x2; bo[3] = y2;
+  a.scores[o] = sc;
+  a.keep[o] = keep ? 1 : 0;
+}
+
 // ---- NMS: suppression bit matrix, then an in-order scan (64 rows at a time) ----
 // boxes [B][n][4] sorted by descending score, group [B][n] int32, cnt [B]
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ group,
@@ -976,6 +1027,24 @@ extern "C" int u2_apply_deltas(const float* src, const float* deltas, const int*
   if (n <= 0) return 0;
   hipLaunchKernelGGL(apply_deltas_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, deltas, img, sizes,
                      out, n, wx, wy, ww, wh, clamp, do_clip);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_rpn_decode(const U2RpnLevel* levels, int L, int A, int B, int kmax, const float* sizes, float wx, float wy, float ww,
+                             float wh, float clamp, float min_size, float* boxes, float* scores, signed char* keep, int* nonfinite,
+                             void* stream) {
+  if (L < 1 || L > 8 || A < 1 || kmax < 1) return -1;
+  if (B <= 0) return 0;
+  RpnDecodeArgs a;
+  for (int l = 0; l < L; ++l) {
+    a.lv[l] = levels[l];
+    if (levels[l].k > kmax || levels[l].k < 0 || levels[l].hwa % A || (levels[l].pitch & 3)) return -1;
+  }
+  a.L = L; a.A = A; a.B = B; a.kmax = kmax; a.sizes = sizes;
+  a.wx = wx; a.wy = wy; a.ww = ww; a.wh = wh; a.clamp = clamp; a.min_size = min_size;
+  a.boxes = boxes; a.scores = scores; a.keep = keep; a.nonfinite = nonfinite;
+  hipLaunchKernelGGL(rpn_decode_kernel, dim3((kmax + 255) / 256, B * L), dim3(256), 0, (hipStream_t)stream, a);
   U2_CHECK_LAUNCH();
   return 0;
 }

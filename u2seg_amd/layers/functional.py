@@ -323,6 +323,8 @@ class _Conv2dFn(Function):
         if wgrad_dst is not None and wgrad_dst.numel() == weight.numel() and wgrad_dst.is_contiguous():
             ctx.arena = wgrad_dst if tuple(wgrad_dst.shape) == tuple(weight.shape) else wgrad_dst.view(weight.shape)
         ctx.param = param
+        # the bias gradient goes straight into the bias' arena slice as well (u2_colsum_add)
+        ctx.bias_dst = param_ref[2] if param_ref is not None and len(param_ref) > 2 and bias is not None else None
         ctx.set_materialize_grads(False)  # no zero tensor for the (non-differentiable) statistics output
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -414,9 +416,13 @@ class _Conv2dFn(Function):
                 _hip.call("u2_conv_wgrad", x, dz, dwk, b, h, w_, cp, cp, ho, wo, npad, npad, kh, kw, pad, pad, stride, 0)
                 dw = dwk[:n, :, :cin].view(n, kh, kw, cin).permute(0, 3, 1, 2)
         if has_bias and ctx.needs_input_grad[2]:
-            sums = zeros_f32((1, 2, npad), x.device)
-            _hip.call("u2_colstats", dz, sums, 1, b * ho * wo, npad, npad)
-            db = sums[0, 0, :n]
+            bdst = ctx.bias_dst
+            if bdst is not None and bdst.is_contiguous() and bdst.dtype == torch.float32 and bdst.numel() == n:
+                _hip.call("u2_colsum_add", dz, bdst, b * ho * wo, npad, npad, n)
+            else:
+                sums = zeros_f32((1, 2, npad), x.device)
+                _hip.call("u2_colstats", dz, sums, 1, b * ho * wo, npad, npad)
+                db = sums[0, 0, :n]
         return dx, dw, db, None, None, None, None, None, None
 
 
@@ -461,8 +467,9 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, want_stats=False, 
     if param is None and isinstance(weight, torch.nn.Parameter):
         param = weight
     slot = grad_slot(param) if param is not None else None
+    bslot = grad_slot(bias) if isinstance(bias, torch.nn.Parameter) else None
     out, stats = _Conv2dFn.apply(x, weight, bias, stride, pad, relu, want_stats,
-                                 (param, slot) if param is not None else None, round_bias)
+                                 (param, slot, bslot) if param is not None else None, round_bias)
     if LAZY_BN_APPLY and want_stats and slot is not None and bias is None and not relu and stride == 1 and pad == 0 \
             and x.requires_grad and tuple(weight.shape[2:]) == (1, 1) and 128 < weight.shape[0] <= 256 and x.shape[3] <= 64 \
             and x.shape[0] * x.shape[1] * x.shape[2] >= FUSED_BWD_MIN_PIXELS:
@@ -869,7 +876,7 @@ class _SoftmaxCEFn(Function):
     @staticmethod
     def backward(ctx, g):
         (d,) = ctx.saved_tensors
-        return d * g.to(d.dtype), None, None
+        return d * g, None, None   # g: 0-dim fp32, the product keeps d's dtype (one launch)
 
 
 def softmax_cross_entropy(logits, labels, num_classes):
@@ -893,7 +900,7 @@ class _BoxRegL1Fn(Function):
     @staticmethod
     def backward(ctx, g):
         (d,) = ctx.saved_tensors
-        return d * g.to(d.dtype), None, None, None, None, None, None
+        return d * g, None, None, None, None, None, None
 
 
 def box_reg_l1_loss(pred, proposals, gt_boxes, labels, bg_label, weights, normalizer):
@@ -995,8 +1002,8 @@ class _RPNLossFn(Function):
             scale[a : 5 * a] = g_loc
             scale = scale.to(go0.dtype)
             return (None, None, None, None, None, None, None, *[go * scale for go, _ in ctx.grads])
-        gos = [go * g_cls.to(go.dtype) for go, _ in ctx.grads]
-        gds = [gd * g_loc.to(gd.dtype) for _, gd in ctx.grads]
+        gos = [go * g_cls for go, _ in ctx.grads]   # 0-dim fp32 factors: the products keep the maps' dtype
+        gds = [gd * g_loc for _, gd in ctx.grads]
         return (None, None, None, None, None, None, None, *gos, *gds)
 
 
@@ -1402,6 +1409,36 @@ def apply_deltas(src, deltas, weights, img_idx=None, sizes=None, clamp=math.log(
     _hip.call("u2_apply_deltas", src.contiguous(), deltas.contiguous(), img_idx, sizes, out, n, weights[0], weights[1],
               weights[2], weights[3], float(clamp), int(do_clip))
     return out
+
+
+class _RpnLevel(ctypes.Structure):
+    """U2RpnLevel of include/u2seg_hip.h."""
+    _fields_ = ([(f, ctypes.c_void_p) for f in ("deltas", "anchors", "idx", "scores")]
+                + [(f, ctypes.c_int) for f in ("hwa", "k", "pitch", "reserved")])
+
+
+def rpn_decode(levels, num_anchors, batch, kmax, sizes, weights, clamp, min_size):
+    """Decoded, clipped and filtered RPN candidates of all levels in one launch (u2_rpn_decode).  levels: list of dicts with
+    deltas (NHWC bf16 view whose channel 0 is the first delta), anchors [hwa, 4] fp32, idx [B, k] int32, scores [B, k] fp32.
+    Returns boxes [B * L, kmax, 4], scores [B * L, kmax] (row = image * L + level), keep int8 [B * L, kmax], nonfinite int32 [1]."""
+    dev = sizes.device
+    rows = batch * len(levels)
+    boxes = torch.empty((rows, kmax, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((rows, kmax), dtype=torch.float32, device=dev)
+    keep = torch.empty((rows, kmax), dtype=torch.int8, device=dev)
+    nonfinite = zeros_f32((1,), dev).view(torch.int32)
+    segs = []
+    for lv in levels:
+        d, anc, idx, sc = lv["deltas"], lv["anchors"], lv["idx"], lv["scores"]
+        assert d.dtype == BF16 and d.dim() == 4 and d.stride(3) == 1 and d.stride(2) == d.stride(1) // d.shape[2]
+        assert anc.dtype == torch.float32 and anc.is_contiguous() and idx.dtype == torch.int32 and idx.is_contiguous()
+        assert sc.dtype == torch.float32 and sc.is_contiguous() and tuple(idx.shape) == tuple(sc.shape) == (batch, idx.shape[1])
+        hwa = d.shape[1] * d.shape[2] * num_anchors
+        assert anc.shape[0] == hwa and d.stride(0) == d.shape[1] * d.shape[2] * d.stride(2)
+        segs.append(_RpnLevel(d.data_ptr(), anc.data_ptr(), idx.data_ptr(), sc.data_ptr(), hwa, idx.shape[1], d.stride(2), 0))
+    _hip.call("u2_rpn_decode", (_RpnLevel * len(segs))(*segs), len(segs), num_anchors, batch, kmax, sizes, float(weights[0]),
+              float(weights[1]), float(weights[2]), float(weights[3]), float(clamp), float(min_size), boxes, scores, keep, nonfinite)
+    return boxes, scores, keep, nonfinite
 
 
 def batched_nms(boxes, group, counts, thr, max_keep):

@@ -193,11 +193,15 @@ class PaddedTargets:
         self.boxes = torch.zeros((b, g, 4), dtype=torch.float32, device=device)
         has_cls = all(x.has("gt_classes") for x in gt_instances)
         self.classes = torch.zeros((b, g), dtype=torch.int64, device=device) if has_cls else None
-        for i, inst in enumerate(gt_instances):
-            if self.num[i]:
-                self.boxes[i, : self.num[i]] = inst.gt_boxes.tensor
-                if has_cls:
-                    self.classes[i, : self.num[i]] = inst.gt_classes
+        some = [inst for i, inst in enumerate(gt_instances) if self.num[i]]
+        if some:
+            # one concatenation + one indexed copy per field instead of a slice assignment per image (32 small launches per step)
+            rows = device_constant([i * g + j for i in range(b) for j in range(self.num[i])], torch.int64, device)
+            self.boxes.view(b * g, 4).index_copy_(0, rows, torch.cat([x.gt_boxes.tensor.to(device=device, dtype=torch.float32)
+                                                                      for x in some]))
+            if has_cls:
+                self.classes.view(b * g).index_copy_(0, rows, torch.cat([x.gt_classes.to(device=device, dtype=torch.int64)
+                                                                        for x in some]))
         self.counts = device_upload(self.num, torch.int32, device)
 
     @classmethod

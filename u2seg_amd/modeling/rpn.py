@@ -293,46 +293,29 @@ class RPN(nn.Module):
         dev = objs[0].device
         pre, post = self.pre_nms_topk[self.training], self.post_nms_topk[self.training]
         sizes = device_constant([list(x) for x in image_sizes], torch.float32, dev)
-        scores_l, boxes_l = [], []
         # the k best logits of every image and level, ranked (logit descending, anchor index ascending), read straight from the
         # A valid columns of the 32-wide NHWC maps; all levels in one pair of launches
         tops = F.topk_rows_multi([dict(vals=o.contiguous(), k=min(o.shape[1] * o.shape[2] * a, pre), largest=True, group=a,
                                        pitch=o.shape[-1], n=o.shape[1] * o.shape[2] * a) for o in objs])
         kmax = max(min(o.shape[1] * o.shape[2] * a, pre) for o in objs)
-        for lvl, (anc, o, d) in enumerate(zip(anchors_per_level, objs, dlts)):
-            hwa = o.shape[1] * o.shape[2] * a
-            k = min(hwa, pre)
-            top_scores, top_idx, _ = tops[lvl]
-            top_idx = top_idx.long()
-            deltas = d[..., : 4 * a].reshape(b, hwa, 4)
-            sel = torch.gather(deltas, 1, top_idx[..., None].expand(b, k, 4)).float().reshape(b * k, 4)
-            src = anc[top_idx.reshape(-1)]
-            img = torch.arange(b, device=dev, dtype=torch.int32).repeat_interleave(k)
-            boxes = F.apply_deltas(src, sel, self.bbox_reg_weights, img, sizes, _SCALE_CLAMP).view(b, k, 4)
-            if k < kmax:  # a short level (819 anchors at stride 64): padded with empty boxes, which the filter below drops
-                top_scores = torch.nn.functional.pad(top_scores, (0, kmax - k), value=-3.0e38)
-                boxes = torch.nn.functional.pad(boxes, (0, 0, 0, kmax - k))
-            scores_l.append(top_scores)
-            boxes_l.append(boxes)
         # Round 5: NMS per (image, level) row.  batched_nms never lets boxes of different levels meet (layers/nms.py:9-20 offsets
         # them apart), so the suppression decisions of a level only depend on that level's boxes in score order: the L lists of
         # <= PRE_NMS_TOPK boxes are L independent problems - L n^2 / 2 instead of (L n)^2 / 2 box pairs and scans of n / 64
         # instead of L n / 64 dependent steps (training: 0.80 -> 0.2 ms of kernels on the critical path) - and the survivors are
         # merged by score afterwards.  The merge ranks by (score descending, position in the level-major list ascending), the
         # same total order the single list was sorted in, so the proposals and their order are unchanged.
+        # The rows themselves - deltas gathered from the NHWC maps, decoded against the anchors, clipped, short levels padded
+        # (819 anchors at stride 64: zero boxes, score -3e38), finite / min-size filter - come from ONE launch over all levels
+        # (F.rpn_decode; it was ~12 small launches per level and ~15 for the stacking and the masks).
         nl = len(objs)
         rows = b * nl
-        scores = torch.stack(scores_l, dim=1).reshape(rows, kmax).contiguous()   # row = image * L + level
-        boxes = torch.stack(boxes_l, dim=1).reshape(rows, kmax, 4)
-        finite = torch.isfinite(boxes).all(dim=2) & torch.isfinite(scores)   # (the padding is finite: zero boxes, -3e38)
-        all_finite = finite.all()  # raised as FloatingPointError when the counts are first read on the host
-        klev = device_constant([min(o.shape[1] * o.shape[2] * a, pre) for o in objs], torch.int64, dev)
-        real = (torch.arange(kmax, device=dev)[None] < klev[:, None]).repeat(b, 1)   # [rows, kmax]: not padding
-        keep = finite & real & ((boxes[..., 2] - boxes[..., 0]) > self.min_box_size) & \
-            ((boxes[..., 3] - boxes[..., 1]) > self.min_box_size)
+        boxes, scores, keep, nonfinite = F.rpn_decode(
+            [dict(deltas=d, anchors=anc, idx=tops[lvl][1], scores=tops[lvl][0])
+             for lvl, (anc, d) in enumerate(zip(anchors_per_level, dlts))],
+            a, b, kmax, sizes, self.bbox_reg_weights, _SCALE_CLAMP, self.min_box_size)
+        all_finite = nonfinite == 0  # raised as FloatingPointError when the counts are first read on the host
         # stable descending sort of every row's kept candidates by score (layers/nms.py:9-20 hands batched_nms score order)
-        _, order, counts = F.topk_rows(scores, kmax, largest=True, mask=keep.to(torch.int8).contiguous(), mask_value=1,
-                                       want_vals=False)
+        _, order, counts = F.topk_rows(scores, kmax, largest=True, mask=keep, mask_value=1, want_vals=False)
         order = order.long()
         s_boxes = torch.gather(boxes, 1, order[..., None].expand(-1, -1, 4)).contiguous()
         s_scores = torch.gather(scores, 1, order).contiguous()
