@@ -333,6 +333,62 @@ def test_rpn_proposals_on_identical_maps(F, model_and_oracle):
             np.testing.assert_allclose(lp.boxes[i, : counts[i]].cpu().numpy(), exp["proposal_boxes"].numpy(), atol=1e-4, rtol=0)
 
 
+def test_rpn_decode_rows_equal_the_per_level_composition(F):
+    """u2_rpn_decode (all levels, one launch) vs the per-level composition it replaced - gather the selected deltas from the NHWC
+    map, F.apply_deltas with clipping, pad the short level, finite / min-size filter - bit for bit: deltas read through the
+    channel-offset view of the fused predictor map (objectness in channels 0-2, deltas in 3-14 of 32) and from a map of their own,
+    a level shorter than kmax, a non-finite logit (counted, filtered), a non-finite delta (clipped to an empty box) and a
+    degenerate box (filtered)."""
+    import math
+
+    g = torch.Generator().manual_seed(5)
+    a, b, kmax = 3, 2, 40
+    weights, clamp, min_size = (1.0, 1.0, 1.0, 1.0), math.log(1000.0 / 16), 0.0
+    sizes = torch.tensor([[64.0, 80.0], [50.0, 77.0]], device=DEV)
+    levels, ref_boxes, ref_scores, ref_keep = [], [], [], []
+    for li, (gh, gw, k) in enumerate(((16, 20, 40), (8, 10, 40), (3, 4, 36))):
+        hwa = gh * gw * a
+        fused = li != 1
+        m = (torch.randn((b, gh, gw, 32), generator=g) * 0.4).bfloat16().to(DEV)
+        if li == 0:
+            m[0, 2, 3, 3 + 4] = float("inf")     # anchor 1 of pixel (2, 3) of image 0: a non-finite dx (the clip makes the box finite)
+            m[1, 0, 0, 3 + 2] = -40.0            # anchor 0 of pixel (0, 0) of image 1: width exp(-40) * w -> an empty box after the clip
+        d = m[..., a:] if fused else m
+        anc = torch.rand((hwa, 4), generator=g) * 30
+        anc[:, 2:] += anc[:, :2] + 4
+        anc = anc.to(DEV)
+        idx = torch.stack([torch.randperm(hwa, generator=g)[:k] for _ in range(b)]).to(torch.int32)
+        if li == 0:
+            idx[0, 0] = (2 * gw + 3) * a + 1
+            idx[1, 0] = 0
+        idx = idx.to(DEV)
+        sc = torch.randn((b, k), generator=g).to(DEV)
+        if li == 0:
+            sc[0, 1] = float("inf")              # a non-finite logit: counted and filtered
+        levels.append(dict(deltas=d, anchors=anc, idx=idx, scores=sc))
+        # the composition: modeling/rpn.py before round 5
+        deltas = d[..., : 4 * a].reshape(b, hwa, 4)
+        sel = torch.gather(deltas, 1, idx.long()[..., None].expand(b, k, 4)).float().reshape(b * k, 4)
+        img = torch.arange(b, device=DEV, dtype=torch.int32).repeat_interleave(k)
+        bx = F.apply_deltas(anc[idx.long().reshape(-1)], sel, weights, img, sizes, clamp).view(b, k, 4)
+        fin = torch.isfinite(bx).all(dim=2) & torch.isfinite(sc)
+        kp = fin & ((bx[..., 2] - bx[..., 0]) > min_size) & ((bx[..., 3] - bx[..., 1]) > min_size)
+        ref_boxes.append(torch.nn.functional.pad(bx, (0, 0, 0, kmax - k)))
+        ref_scores.append(torch.nn.functional.pad(sc, (0, kmax - k), value=-3.0e38))
+        ref_keep.append(torch.nn.functional.pad(kp, (0, kmax - k)))
+    boxes, scores, keep, nonfinite = F.rpn_decode(levels, a, b, kmax, sizes, weights, clamp, min_size)
+    rb = torch.stack(ref_boxes, dim=1).reshape(b * 3, kmax, 4)
+    rs = torch.stack(ref_scores, dim=1).reshape(b * 3, kmax)
+    rk = torch.stack(ref_keep, dim=1).reshape(b * 3, kmax)
+    same = (boxes == rb) | (torch.isnan(boxes) & torch.isnan(rb))
+    assert bool(same.all())
+    assert torch.equal(scores, rs)
+    assert torch.equal(keep.bool(), rk)
+    assert int(nonfinite.item()) == 1
+    assert not bool(keep[0, 1]) and not bool(keep[3, 0])   # the non-finite candidate and the empty box are filtered
+    assert int(keep.sum()) == int(rk.sum()) > b * 100
+
+
 def _nhwc(x_nchw):
     b, c, h, w = x_nchw.shape
     cp = (c + 31) // 32 * 32

@@ -249,7 +249,7 @@ __device__ __forceinline__ int ks_swz(int row) { return (-(row >> 2)) & 3; }  //
 // rows / nrows: the kernel labels the points rows[0 .. *nrows) (the undecided list of the coarser pass) instead of 0 .. N - 1.
 // gate / gate_want: the launch is skipped (work-groups leave at once) unless (*gate == 1) == gate_want - the host queues the
 // coarse pass, the fine pass over its list and the fine pass over everything, and a flag in the workspace picks two of the three.
-template <int NP>
+template <int NP, bool XR3 = false>
 __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restrict__ x, const bf16_t* __restrict__ chl,
                                                             const float* __restrict__ cn, const unsigned* __restrict__ cmax2,
                                                             long long* __restrict__ labels, int* __restrict__ list,
@@ -267,6 +267,19 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
   const int fr = lane & 15, fg = lane >> 4;
   const int p0 = blockIdx.x * KS_PTS + w * 32;
   const int nsteps = D >> 5;
+  // Round 5, XR: the x rows come through a wave-private LDS-DMA ring of two 4 KB slots instead of registers: a slot is re-filled
+  // with x(s + 2) as soon as the wave has read x(s) out of it, so two steps of x (64 KB per CU) are in flight instead of one - the
+  // coarse pass streamed x at 2.9 TB/s with 32 KB per CU in flight, which is what a ~2.5 us round trip allows - and nothing that is
+  // in flight lives in a register the compiler could move.  NP = 1 stages only the hi plane of the centroids (3 instead of 5
+  // LDS-DMA instructions per wave and step: rows 320-383 of the stage are filler from the lo plane), ring of 3 as before; NP = 3
+  // with XR keeps both planes in a ring of 2 (centroids(s + 1) requested at the start of step s, 144 KB in all).
+  constexpr bool XR = NP == 1 || XR3;
+  constexpr int CDMA = NP == 1 ? 3 : KS_DMA;           // centroid LDS-DMA instructions per wave and step
+  constexpr int CSTAGE = CDMA * 8 * 1024;              // bytes of a centroid stage
+  constexpr int CRING = (NP == 3 && XR) ? 2 : KS_RING; // centroid stages
+  constexpr int XDMA = 4;                              // x: 32 rows x 128 bytes per wave and step
+  constexpr int XSLOT = KS_PTS * 128;                  // bytes of an x slot of the work-group
+  unsigned char* const xring = ks_smem + CRING * CSTAGE;
 
   // x: lane (fr, fg) owns row m * 16 + fr of both 16-point blocks and, per 32-dimension step, dimensions fg * 4 .. + 3 and
   // 16 + fg * 4 .. + 3 (csplit_kernel stores the centroids' dimensions in the matching order): the four lanes of a row read 64
@@ -278,6 +291,31 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     const int pi = min(p0 + m * 16 + fr, N - 1);
     xp[m] = x + (size_t)(rows ? rows[pi] : pi) * D + fg * 4;
   }
+  // XR: instruction q of the wave moves rows q * 8 .. + 7 of its 32 points, 8 lanes per 128-byte row; LDS position (lane & 7)
+  // of row r holds the row's 16-byte chunk (lane & 7) ^ ((r >> 1) & 7): rows of equal parity share a bank half (128-byte pitch),
+  // and the fragment reads below - 16 rows per quarter wave, one chunk each - then hit eight different positions per half
+  const float* xq[XDMA];
+  unsigned xrd[2];
+  if constexpr (XR) {
+#pragma unroll
+    for (int q = 0; q < XDMA; ++q) {
+      const int r = q * 8 + (lane >> 3);
+      const int pi = min(p0 + r, N - 1);
+      xq[q] = x + (size_t)(rows ? rows[pi] : pi) * D + (((lane & 7) ^ ((r >> 1) & 7)) << 2);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int r = m * 16 + fr;
+      xrd[m] = (unsigned)(w * 4096 + r * 128 + ((fg ^ ((r >> 1) & 7)) << 4));   // chunk fg; chunk 4 + fg is at ^ 64
+    }
+  }
+  auto stage_x = [&](int slot) {
+#pragma unroll
+    for (int q = 0; q < XDMA; ++q) {
+      __builtin_amdgcn_global_load_lds(U2_GLB_PTR(xq[q]), U2_LDS_PTR(xring + slot * XSLOT + w * 4096 + q * 1024), 16, 0, 0);
+      xq[q] += 32;
+    }
+  };
   // Inline-asm loads (the compiler would drain the LDS-DMA ring in front of the first use of a load it can see).  The
   // registers are loaded in step s and split in step s + 1, i.e. loop-carried, and the compiler - which does not know the data is
   // in flight - is free to move them (it did: v_mov at the back-edge, in front of a wait that used to sit at the top of the
@@ -294,16 +332,16 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     }
   };
   // centroids: instruction i of wave w fills LDS rows (w * 5 + i) * 16 .. + 15 (row = plane * 320 + centroid)
-  const bf16_t* cp[KS_DMA];
+  const bf16_t* cp[CDMA];
 #pragma unroll
-  for (int i = 0; i < KS_DMA; ++i) {
-    const int row = (w * KS_DMA + i) * 16 + (lane >> 2);
+  for (int i = 0; i < CDMA; ++i) {
+    const int row = (w * CDMA + i) * 16 + (lane >> 2);
     cp[i] = chl + (size_t)row * D + (((lane & 3) ^ ks_swz(lane >> 2)) << 3);
   }
   auto stage_c = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < KS_DMA; ++i) {
-      __builtin_amdgcn_global_load_lds(U2_GLB_PTR(cp[i]), U2_LDS_PTR(ks_smem + buf * KS_STAGE + (w * KS_DMA + i) * 1024), 16, 0, 0);
+    for (int i = 0; i < CDMA; ++i) {
+      __builtin_amdgcn_global_load_lds(U2_GLB_PTR(cp[i]), U2_LDS_PTR(ks_smem + buf * CSTAGE + (w * CDMA + i) * 1024), 16, 0, 0);
       cp[i] += 32;
     }
   };
@@ -318,15 +356,37 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
   float n2[2] = {0.f, 0.f};
 
   // in flight when step s begins: centroids(s + 1) only - centroids(s) and x(s) were waited for at the end of step s - 1
-  stage_c(0);
-  load_x();
-  if (nsteps > 1) {
-    stage_c(1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS_DMA) : "memory");
+  // (NP = 1: x(s + 1) and centroids(s + 1))
+  if constexpr (XR && CRING == 3) {
+    stage_x(0);
+    stage_c(0);
+    if (nsteps > 1) {
+      stage_x(1);
+      stage_c(1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDMA + CDMA) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  } else if constexpr (XR) {   // ring of 2: in flight when step s begins: x(s + 1) only
+    stage_c(0);
+    stage_x(0);
+    if (nsteps > 1) {
+      stage_x(1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDMA) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stage_c(0);
+    load_x();
+    if (nsteps > 1) {
+      stage_c(1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CDMA) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
   }
-  asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
   // One step; LOAD: x(s + 1) is fetched, STAGE: centroids(s + 2) are staged.  The three forms (steady state, last but one,
   // last) are separate straight-line instances, so that the wait that closes a step is unconditional in the generated code
   // (tools/check_inflight_moves.py follows every path of the control-flow graph, also the infeasible one that skips two
@@ -335,6 +395,18 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     constexpr bool LOAD = decltype(load_tag)::value, STAGE = decltype(stage_tag)::value;
     __builtin_amdgcn_s_barrier();  // stage s is complete for every wave, and every wave is done with stage s - 1
     asm volatile("" ::: "memory");
+    if constexpr (XR) {
+      // this step's x out of the wave's slot; the slot is free for x(s + 2) once the reads have returned
+      const unsigned xs = (unsigned)(size_t)U2_LDS_PTR(xring) + (unsigned)((s & 1) * XSLOT);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(raw[m][0]), "=&v"(raw[m][1]) : "v"(xs + xrd[m]), "v"(xs + (xrd[m] ^ 64u)) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
+      if constexpr (CRING == 2) {   // centroids(s + 1) go first: the wait that closes the step leaves only x(s + 2) in flight
+        if (LOAD) stage_c((s + 1) & 1);
+      }
+      if (STAGE) stage_x(s & 1);
+    }
     // split this step's x into its two bf16 pieces (MFMA A operands)
     s16x8 ah[2], al[2];
 #pragma unroll
@@ -351,8 +423,12 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
       ah[m] = *reinterpret_cast<const s16x8*>(h);
       al[m] = *reinterpret_cast<const s16x8*>(l);
     }
-    if (LOAD) load_x();
-    if (STAGE) stage_c((s + 2) % KS_RING);
+    if constexpr (!XR) {
+      if (LOAD) load_x();
+    }
+    if constexpr (CRING == 3) {
+      if (STAGE) stage_c((s + 2) % KS_RING);
+    }
     // Two centroid blocks at a time, piece by piece: consecutive MFMAs go to four different accumulators, so the three products
     // of one accumulator (hi.hi, hi.lo, lo.hi) are four issue slots apart instead of back to back (-4 % kernel time; a second
     // register set that keeps two steps of x in flight from HBM changed nothing: the waves' 43 % parked cycles - PMC, round 3 -
@@ -364,7 +440,7 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     // s_waitcnt lgkmcnt(0) although LDS returns in order (it will not count across the LDS-DMA in flight), which exposes the
     // round trip it was supposed to hide.  The wait names the four registers it releases, so no MFMA can move in front of it.
     s16x8 bq[2][4];   // [set][hi block 0, hi block 1, lo block 0, lo block 1]
-    const unsigned sba = lds0 + (unsigned)((s % KS_RING) * KS_STAGE) + (unsigned)boff;
+    const unsigned sba = lds0 + (unsigned)((s % CRING) * CSTAGE) + (unsigned)boff;
 #define U2_KS_LDQ(SET, NB)                                                                                                    \
     if constexpr (NP == 3)                                                                                                     \
       asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t"       \
@@ -415,9 +491,9 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
 #undef U2_KS_WAIT
 #undef U2_KS_LDQ
     // close the step: centroids(s + 1) and x(s + 1) have landed, only centroids(s + 2) stays in flight over the back-edge
-    if (STAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS_DMA) : "memory");
+    if (STAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(!XR ? CDMA : CRING == 3 ? XDMA + CDMA : XDMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
+    if constexpr (!XR) asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
   };
   int s = 0;
   for (; s + 2 < nsteps; ++s) step(s, std::true_type{}, std::true_type{});
@@ -736,23 +812,35 @@ extern "C" int u2_kmeans_assign(const float* x, const float* c, float* workspace
   if (attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const dim3 grid((N + KS_PTS - 1) / KS_PTS), block(512);
-  const size_t lds = KS_RING * KS_STAGE;
+  const size_t lds = KS_RING * KS_STAGE;                               // fine pass: both centroid planes, x through registers
+  const size_t lds1 = KS_RING * 3 * 8 * 1024 + 2 * KS_PTS * 128;      // coarse pass: hi plane (24 KB stages) + two x slots
+  const size_t lds3 = 2 * KS_STAGE + 2 * KS_PTS * 128;                // fine pass with the x ring: two centroid stages + two x slots
+  static const int xring3 = getenv("U2_KM_XRING3") ? atoi(getenv("U2_KM_XRING3")) : 1;   // measurement knob: 0 = x through registers
   const int* gate = reinterpret_cast<const int*>(state + 1);
   static const int two_level = getenv("U2_KM_ONE_LEVEL") ? 0 : 1;   // measurement knob: the round-3 single (fine) pass
   if (two_level) {
     // coarse pass over everything -> list1; fine pass over list1 -> list2 (both skipped while the coarse pass is switched off)
-    hipLaunchKernelGGL(kmeans_screen_kernel<1>, grid, block, lds, s, x, chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D,
+    hipLaunchKernelGGL(kmeans_screen_kernel<1>, grid, block, lds1, s, x, chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D,
                        K, 0.02f, (const int*)nullptr, (const int*)nullptr, gate, 0);
     U2_CHECK_LAUNCH();
-    hipLaunchKernelGGL(kmeans_screen_kernel<3>, grid, block, lds, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N, D,
-                       K, 1e-4f, (const int*)list1, reinterpret_cast<const int*>(scal + 2), gate, 0);
+    if (xring3)
+      hipLaunchKernelGGL((kmeans_screen_kernel<3, true>), grid, block, lds3, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1),
+                         N, D, K, 1e-4f, (const int*)list1, reinterpret_cast<const int*>(scal + 2), gate, 0);
+    else
+      hipLaunchKernelGGL(kmeans_screen_kernel<3>, grid, block, lds, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N, D,
+                         K, 1e-4f, (const int*)list1, reinterpret_cast<const int*>(scal + 2), gate, 0);
     U2_CHECK_LAUNCH();
   }
   // fine pass over everything -> list2 (the only pass while the coarse one is switched off)
-  hipLaunchKernelGGL(kmeans_screen_kernel<3>, grid, block, lds, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N, D, K,
-                     1e-4f, (const int*)nullptr, (const int*)nullptr, two_level ? gate : (const int*)nullptr, 1);
+  if (xring3)
+    hipLaunchKernelGGL((kmeans_screen_kernel<3, true>), grid, block, lds3, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N,
+                       D, K, 1e-4f, (const int*)nullptr, (const int*)nullptr, two_level ? gate : (const int*)nullptr, 1);
+  else
+    hipLaunchKernelGGL(kmeans_screen_kernel<3>, grid, block, lds, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N, D, K,
+                       1e-4f, (const int*)nullptr, (const int*)nullptr, two_level ? gate : (const int*)nullptr, 1);
   U2_CHECK_LAUNCH();
   // the undecided points, exactly; the grid covers the worst case, work-groups beyond the list return immediately
   hipLaunchKernelGGL(kmeans_assign_kernel, dim3((N + KM_PTS - 1) / KM_PTS), dim3(256), 0, s, x, c, cn, labels, N, D, K,
