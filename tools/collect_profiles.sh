@@ -22,6 +22,8 @@ python $R/tools/pmc_summary.py $R/gpurun_out/${TAG}_pmc_write > $R/gpurun_out/${
 python $R/tools/pmc_traffic.py $R/gpurun_out/${TAG}_pmc_fetch $R/gpurun_out/${TAG}_pmc_write $R/gpurun_out/${TAG}_pmc_traffic.json \
   "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) of \`python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra --serial\` (tools/collect_profiles.sh ${TAG}); KiB units; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md; WRITE_SIZE uncalibrated" > /dev/null
 find $R/gpurun_out/${TAG}_pmc_fetch $R/gpurun_out/${TAG}_pmc_write -name "*.csv" -delete
+python $R/tools/step_census.py $R/gpurun_out/${TAG}_train > $R/gpurun_out/${TAG}_step_census.txt
+python $R/tools/step_census.py $R/gpurun_out/${TAG}_train_serial > $R/gpurun_out/${TAG}_step_census_serial.txt
 # keep the merge small: the per-dispatch traces are not needed, only the statistics and the counter rows
 find $R/gpurun_out -name "*kernel_trace.csv" -path "*${TAG}_*" ! -path "*pmc*" -delete
 ls -la $R/gpurun_out/${TAG}_*/ | head -40
