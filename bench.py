@@ -288,6 +288,21 @@ def per_layer_report(timer, sampled):
                                                                      d[2] / (d[1] * 1e-3) / 1e12), file=sys.stderr)
 
 
+def _cgroup_cpu_stat():
+    """nr_throttled / throttled_usec of this container's CPU controller (cgroup v2), {} where it is not readable."""
+    out = {}
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as fh:
+            for line in fh:
+                k, v = line.split()
+                out[k] = int(v)
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            out["cpu_max"] = fh.read().strip()
+    except (OSError, ValueError):
+        pass
+    return out
+
+
 def _per_step_stats(marks, sampled):
     """Per-step times of the timed region from the (host time, HIP event) mark in front of every step: the mean hides a single
     allocation or host hiccup in a short region, the median and the minimum do not.  `device_ms` is the distance of the marks on
@@ -328,6 +343,11 @@ def _spawn_ranks(n):
 
 
 def main():
+    from u2seg_amd.utils.env import configure_host_threads
+
+    # the OpenMP pool sized for the container's CPU quota, not the host's cores (U2_HOST_THREADS=0: leave it alone, for A/B runs)
+    if os.environ.get("U2_HOST_THREADS", "1") != "0":
+        configure_host_threads()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -398,6 +418,7 @@ def main():
         sampled = max(1, steps // 8)
 
         marks = []
+        cg0, cpu0 = _cgroup_cpu_stat(), time.process_time()
         t0 = time.time()
         for i in range(steps):
             ev = torch.cuda.Event(enable_timing=True)
@@ -418,6 +439,14 @@ def main():
         dt = time.time() - t0
         marks.append((t0 + dt, ev))
         timed.per_step = _per_step_stats(marks, sampled)
+        # host CPU of the timed region: this process' CPU seconds per wall second, and what the container's CPU quota did to it
+        # (cgroup v2 cpu.stat: a throttled period stops EVERY thread of the container, the launching thread included)
+        cg1 = _cgroup_cpu_stat()
+        timed.per_step["host_cpu"] = {"process_cpu_s_per_wall_s": round((time.process_time() - cpu0) / max(dt, 1e-9), 2),
+                                      "torch_threads": torch.get_num_threads(),
+                                      "cgroup_throttled_periods": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0),
+                                      "cgroup_throttled_ms": round((cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e3, 1),
+                                      "cgroup_cpu_max": cg1.get("cpu_max")}
         timer.enabled = False
         Fn.set_stream_overlap(True)
         if world > 1:

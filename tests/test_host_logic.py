@@ -736,3 +736,34 @@ def test_select_foreground_proposals_stacked_equals_per_image_on_cpu():
         assert torch.equal(a.proposal_boxes.tensor, b.proposal_boxes.tensor) and torch.equal(a.gt_boxes.tensor, b.gt_boxes.tensor)
         assert torch.equal(a.gt_masks.tensor, b.gt_masks.tensor)
     assert len(fg_s[0]) == 0 and len(fg_s[1]) > 0
+
+
+def test_host_thread_cap_and_image_index(monkeypatch):
+    """utils/env.configure_host_threads caps torch's intra-op pool (never raises it, leaves an explicit OMP_NUM_THREADS alone) and
+    reads the container's CPU quota; batched.image_index (numpy instead of ATen's CPU repeat_interleave, whose grain-1 parallel
+    region wakes the whole OpenMP pool) still numbers the ROIs image by image."""
+    import torch
+
+    from u2seg_amd.modeling.batched import image_index
+    from u2seg_amd.utils import env
+
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+        torch.set_num_threads(max(before, 2))
+        monkeypatch.setattr(env, "cgroup_cpu_quota", lambda: 2.0)
+        assert env.configure_host_threads(max_threads=8) == 1          # half of a 2-CPU quota
+        torch.set_num_threads(1)
+        monkeypatch.setattr(env, "cgroup_cpu_quota", lambda: None)
+        assert env.configure_host_threads(max_threads=8) == 1          # never raised
+        torch.set_num_threads(max(before, 2))
+        monkeypatch.setenv("OMP_NUM_THREADS", "5")
+        assert env.configure_host_threads(max_threads=1) == max(before, 2)   # an explicit setting is the user's
+    finally:
+        torch.set_num_threads(before)
+    q = env.cgroup_cpu_quota()
+    assert q is None or q > 0
+    sizes = [3, 0, 2, 5]
+    got = image_index(sizes, "cpu")
+    want = torch.repeat_interleave(torch.arange(4, dtype=torch.float32), torch.tensor(sizes))
+    assert got.dtype == torch.float32 and torch.equal(got, want)

@@ -22,6 +22,7 @@ from u2seg_amd.data import (DatasetCatalog, DevicePrefetcher, MetadataCatalog, b
 from u2seg_amd.engine import SimpleTrainer, default_argument_parser, launch_info  # noqa: E402
 from u2seg_amd.modeling import build_model  # noqa: E402
 from u2seg_amd.solver import build_lr_scheduler, build_optimizer  # noqa: E402
+from u2seg_amd.utils.env import configure_host_threads  # noqa: E402
 
 
 def setup(args):
@@ -66,6 +67,7 @@ def evaluate_on_disk_datasets(cfg, model, eval_mode, device):
 
 
 def main(args):
+    configure_host_threads()
     rank, local_rank, world = launch_info()
     cfg = setup(args)
     if cfg.MODEL.DEVICE.startswith("cuda"):

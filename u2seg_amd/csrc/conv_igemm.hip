@@ -1443,7 +1443,7 @@ extern "C" int u2_conv1x1_bwd_fused_bn(const void* x, const void* dz, const void
   if (variant & 4) return 1;
   const int rc = launch_wdgrad_stream((const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)wt, (bf16_t*)dx, dw, dw_stride_n,
                                       dw_stride_c, n_valid, c_valid, zero, M, C, x_ld, N, dy_ld, wt_ld, dx_ld,
-                                      (variant & 1) | ((variant >> 2) & 2), (variant >> 1) & 1, (hipStream_t)stream, (const bf16_t*)y,
+                                      (variant & 1) | ((variant >> 2) & 2) | ((variant >> 2) & 4), (variant >> 1) & 1, (hipStream_t)stream, (const bf16_t*)y,
                                       k1, k2, k3);
   if (rc == 1) return 0;
   return rc < 0 ? rc : 1;

@@ -481,7 +481,11 @@ int launch_wdgrad_stream(const bf16_t* x, const bf16_t* dy, const bf16_t* wt, bf
   if (yn) {
     // with the normalisation's apply step in front: two N-wide images per step, so only the 256-channel block (one 8-wave
     // work-group per CU, 40 KB stages, ring of 4); code 2761
-    if (!small || !k1 || !k2 || !k3) return 0;
+    if (!k1 || !k2 || !k3) return 0;
+    // N <= 512 (res3 tails, 128 input channels = two c-tiles that each stage and transform dz and y): 72 KB stages, ring of 2;
+    // code 2763.  Only on request (force bit 2): see the measurement in DESIGN.md 5.0 item 8
+    if (wide) return (force & 4) ? launch_ws<8, 1, 4, 4, true, true>(a, 1, tiny, 2763, s) : 0;
+    if (!small) return 0;
     if (force & 2) return launch_ws<4, 1, 4, 4, true, true>(a, 2, tiny, 2762, s);   // two 4-wave work-groups per CU, ring of 2
     return launch_ws<8, 1, 2, 4, true, true>(a, 1, tiny, 2761, s);
   }

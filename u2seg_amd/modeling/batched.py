@@ -9,6 +9,7 @@ import collections.abc
 import threading
 import weakref
 
+import numpy as np
 import torch
 
 from ..structures import Boxes, Instances
@@ -254,6 +255,8 @@ def image_index(sizes, device):
     key = ("image_index", tuple(sizes), str(dev))
     hit = _cache_get(key, dev)
     if hit is None:
-        idx = torch.repeat_interleave(torch.arange(len(sizes), dtype=torch.float32), torch.tensor(sizes, dtype=torch.int64))
+        # numpy on purpose: ATen's CPU repeat_interleave is a parallel region with a grain of 1 - it wakes the whole OpenMP pool for
+        # 16 elements, and the woken threads spin for milliseconds (u2seg_amd/utils/env.py)
+        idx = torch.from_numpy(np.repeat(np.arange(len(sizes), dtype=np.float32), np.asarray(sizes, dtype=np.int64)))
         hit = _cache_put(key, idx, dev)
     return hit
