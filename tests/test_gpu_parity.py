@@ -932,7 +932,7 @@ def test_whole_model_vs_oracle(F, fixed_order_statistics, branch):
 def test_whole_model_production_statistics_path(F):
     """The same free-running comparison through the PRODUCTION forward (BN column statistics from the conv epilogues' fp32 atomics,
     the path bench.py runs; the two tests above use the fixed-order switch so that they are bit-reproducible): the dense losses
-    stay inside a 4 % band of the bf16 oracle, and two runs of the production path within 3 % of each other - the atomics'
+    stay inside a 2.5 % band of the bf16 oracle, and two runs of the production path within 2 % of each other - the atomics'
     accumulation order is the only difference between them, a last-ulp difference of the statistics that the random-weight
     network amplifies to 0.7 % of loss_sem_seg (measured), which is why the strict comparisons are teacher-forced."""
     from oracle.model import OracleModel
@@ -981,11 +981,14 @@ def test_whole_model_production_statistics_path(F):
 
     ref = OracleModel(cfg, sd, emulate_bf16=True, key_fn=key_fn).train_forward(cpu_batch)
     dense = ["loss_sem_seg", "loss_rpn_cls", "loss_cls_stage0", "loss_cls_stage1", "loss_cls_stage2", "loss_mask"]
-    # Bands: 4 % against the oracle (the trajectory test's step-0 band: without the fixed-order switch the run is not
-    # bit-reproducible, and one full-suite run of this test at 2 % failed where four runs in isolation had passed), 3 % run to run.
+    # Bands: 2.5 % against the oracle and 2 % run to run (without the fixed-order switch the run is not bit-reproducible; round 4
+    # had 4 % / 3 % after one full-suite run at 2 % had failed).
+    # Round 5, measured over five runs of this test on one box: the dense losses deviate from the oracle by at most 1.3 %
+    # (loss_sem_seg; the others <= 0.45 %) and two production runs from each other by at most 0.8 %; loss_rpn_loc (a few dozen
+    # foreground anchors) by 4.3 % / 5.4 %.
     for k in dense:
-        assert runs[0][k] == pytest.approx(float(ref[k]), rel=4e-2), (k, runs[0], float(ref[k]))
-        assert runs[1][k] == pytest.approx(runs[0][k], rel=3e-2), (k, runs)
+        assert runs[0][k] == pytest.approx(float(ref[k]), rel=2.5e-2), (k, runs[0], float(ref[k]))
+        assert runs[1][k] == pytest.approx(runs[0][k], rel=2e-2), (k, runs)
     assert runs[0]["loss_rpn_loc"] == pytest.approx(float(ref["loss_rpn_loc"]), rel=8e-2)
 
 
@@ -1378,16 +1381,18 @@ def test_syncbn_unequal_counts_two_ranks():
     for i, t in enumerate(r):
         sl = slice(0, n0) if i == 0 else slice(n0, None)
         got_y = t["y"].permute(0, 2, 3, 1).reshape(-1, c)
-        assert rel_err(got_y, bf(yc.detach()[sl])) < 1e-2
+        # bounds: measured 3e-5 (y, the bf16 rounding of the fp32 reference is applied on both sides), 3.1e-3 (dx: one bf16 step
+        # of the output) and 2e-7 (the affine gradients, fp32 sums) - round 5: tightened from 1e-2 / 1.5e-2 / 1e-2
+        assert rel_err(got_y, bf(yc.detach()[sl])) < 1e-3
         got_dx = t["dx"].permute(0, 2, 3, 1).reshape(-1, c)
-        assert rel_err(got_dx, xc.grad[sl]) < 1.5e-2
+        assert rel_err(got_dx, xc.grad[sl]) < 5e-3
         # running statistics: identical on both ranks, equal to the concatenated batch's
         assert torch.allclose(t["rm"], rm, atol=1e-4) and torch.allclose(t["rv"], rv, atol=1e-3)
         # affine gradients are local sums (DDP averages them afterwards): this rank's pixels only
         mu, var = xc.detach().mean(0), xc.detach().var(0, unbiased=False)
         xhat = (xc.detach()[sl] - mu) * torch.rsqrt(var + 1e-5)
         dz = gyc[sl] * (yc.detach()[sl] > 0)
-        assert rel_err(t["dbeta"], dz.sum(0)) < 1e-2 and rel_err(t["dgamma"], (dz * xhat).sum(0)) < 1e-2
+        assert rel_err(t["dbeta"], dz.sum(0)) < 1e-5 and rel_err(t["dgamma"], (dz * xhat).sum(0)) < 1e-5
     assert torch.equal(r[0]["rm"], r[1]["rm"]) and torch.equal(r[0]["rv"], r[1]["rv"])
 
 
