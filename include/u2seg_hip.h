@@ -154,6 +154,10 @@ int u2_bn_bwd_apply_fused(const float* sums, float count, const float* count_dev
                           const void* dout, const void* mask, const void* x, void* dx, void* dres, int rows, int C, int ld,
                           int relu, const float* mask_scale, const float* mask_shift, void* stream);
 int u2_relu_bwd(const void* dout, const void* out, void* dz, long long numel, void* stream);
+/* The same with the bias gradient of the layer in the same pass: dst[c] += sum over rows of dz[row][c] for c < n_valid (dz: [rows][ld],
+ * C physical channels; zeros: C floats of 0).  Replaces u2_relu_bwd + u2_colsum_add for a conv with bias and ReLU. */
+int u2_relu_bwd_colsum(const void* dout, const void* out, void* dz, float* dst, const float* zeros, int rows, int C, int ld, int n_valid,
+                       void* stream);
 /* out = a + b (+ c (+ d)) on bf16 tensors of numel elements (numel % 8 == 0), summed in fp32 and rounded once; out may alias an
  * input. The gradient sum autograd would otherwise make with k - 1 separate adds where a tensor has k consumers (the FPN
  * outputs feed the RPN head, the ROI poolers and the semantic head: meta_arch/panoptic_fpn.py:105-131). */

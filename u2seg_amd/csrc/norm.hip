@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
             xq[u] = ld_stream(x + off, nt);
             if (MODE == 1) {
               dq[u] = ld_stream(dout + off, nt);
-              if (MASK == 1) mq[u] = ld_stream(mask + off, nt);
+              if (MASK == 1) mq[u] = (mask == x) ? xq[u] : ld_stream(mask + off, nt);   // u2_relu_bwd_colsum: the activation is both
               if (MASK == 3) mq[u].x = reinterpret_cast<const unsigned char*>(mask)[(row0 + r) * (size_t)cpr + cbase + chunk];
               if (DZ && dout2) eq[u] = ld_stream(dout2 + off, nt);
               if (DZ && dout3) fq[u] = ld_stream(dout3 + off, nt);
@@ -1012,6 +1012,23 @@ extern "C" int u2_relu_bwd(const void* dout, const void* out, void* dz, long lon
   const size_t n8 = (size_t)numel >> 3;
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
                      (const bf16_t*)out, (bf16_t*)dz, n8, ew_nt(n8 * 16));
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+// dz = dout * (out > 0) AND dst[c] += sum over rows of dz[row][c] (c < n_valid) in one pass: the ReLU backward of a biased conv and
+// its bias gradient (u2_relu_bwd + u2_colsum_add read dz a second time).  colreduce_kernel<1, 1, true> with the sum-only flush: the
+// second running sum it keeps (dz x_hat) is not written; `zeros` (C floats of 0) stands in for the mean / invstd it reads.
+extern "C" int u2_relu_bwd_colsum(const void* dout, const void* out, void* dz, float* dst, const float* zeros, int rows, int C, int ld,
+                                  int n_valid, void* stream) {
+  if ((C & 7) || (ld & 7) || n_valid < 1 || n_valid > C || !zeros) return -1;
+  if (rows <= 0) return 0;
+  int rpb = (rows + 511) / 512;
+  if (rpb < 64) rpb = 64;
+  const dim3 grid((rows + rpb - 1) / rpb, 1);
+  hipLaunchKernelGGL((colreduce_kernel<1, 1, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)out, (const bf16_t*)dout,
+                     (const bf16_t*)out, zeros, zeros, dst, rows, C, ld, rpb, nullptr, nullptr, nullptr, (bf16_t*)dz, nullptr,
+                     (stream_order() >> 1) & 1, n_valid);
   U2_CHECK_LAUNCH();
   return 0;
 }

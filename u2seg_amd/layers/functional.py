@@ -356,9 +356,16 @@ class _Conv2dFn(Function):
                       None, None)
             dx = None
         dout = dout.contiguous()
+        bias_done = False
         if relu:
             dz = torch.empty_like(dout)
-            _hip.call("u2_relu_bwd", dout, out, dz, dout.numel())
+            bdst = ctx.bias_dst if (has_bias and ctx.needs_input_grad[2]) else None
+            if bdst is not None and bdst.is_contiguous() and bdst.dtype == torch.float32 and bdst.numel() == n:
+                # ReLU backward and the bias gradient (into its arena slice) in one pass over dout / out
+                _hip.call("u2_relu_bwd_colsum", dout, out, dz, bdst, zeros_f32((npad,), dout.device), b * ho * wo, npad, npad, n)
+                bias_done = True
+            else:
+                _hip.call("u2_relu_bwd", dout, out, dz, dout.numel())
         else:
             dz = dout
         dx = dw = db = None
@@ -415,7 +422,7 @@ class _Conv2dFn(Function):
                 dwk = zeros_f32((npad, kh * kw, cp), x.device)
                 _hip.call("u2_conv_wgrad", x, dz, dwk, b, h, w_, cp, cp, ho, wo, npad, npad, kh, kw, pad, pad, stride, 0)
                 dw = dwk[:n, :, :cin].view(n, kh, kw, cin).permute(0, 3, 1, 2)
-        if has_bias and ctx.needs_input_grad[2]:
+        if has_bias and ctx.needs_input_grad[2] and not bias_done:
             bdst = ctx.bias_dst
             if bdst is not None and bdst.is_contiguous() and bdst.dtype == torch.float32 and bdst.numel() == n:
                 _hip.call("u2_colsum_add", dz, bdst, b * ho * wo, npad, npad, n)
