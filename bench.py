@@ -122,10 +122,12 @@ def _timed_iterations(fn, warmup=1, timed=3):
     """1 warm-up + 3 timed iterations; returns the mean seconds of the timed ones."""
     for _ in range(warmup):
         fn()
-    t0 = time.time()
+    t0, c0 = time.time(), time.process_time()
     for _ in range(timed):
         fn()
-    return (time.time() - t0) / timed
+    dt = time.time() - t0
+    _timed_iterations.cpus_effective = (time.process_time() - c0) / max(dt, 1e-9)   # CPU seconds per wall second of the sample
+    return dt / timed
 
 
 def cpu_baseline_worker(workload):
@@ -370,7 +372,13 @@ def main():
     ap.add_argument("--per-layer", action="store_true", help="debug: print the conv launches grouped by shape")
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline_worker(args.workload)))
+        res = cpu_baseline_worker(args.workload)
+        # what the threads actually got: the container's CPU quota is shared by the oracle samples running side by side
+        from u2seg_amd.utils.env import cgroup_cpu_quota
+
+        res["cpus_effective"] = round(getattr(_timed_iterations, "cpus_effective", 0.0), 1)
+        res["cgroup_cpu_quota"] = cgroup_cpu_quota()
+        print(json.dumps(res))
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
