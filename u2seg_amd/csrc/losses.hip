@@ -28,6 +28,8 @@ namespace {
 constexpr int SS_OW = 15, SS_OH = 7;                 // owned taps per work-group
 constexpr int SS_LW = SS_OW + 2, SS_LH = SS_OH + 2;  // staged taps (one halo ring)
 constexpr int SS_MAXC = 32, SS_PITCH = 36;           // 36 floats: 16-byte aligned rows, tap columns on distinct banks
+constexpr int SS_ZPITCH = 40;                        // the staged logits stay bf16 (round 5): 80-byte rows, 12 KB instead of 22 KB -
+                                                     // four work-groups per CU instead of three
 
 // reductions over the 4 lanes of a quad: DPP quad_perm [1,0,3,2] (0xB1) and [2,3,0,1] (0x4E)
 template <int CTRL>
@@ -43,11 +45,11 @@ __device__ __forceinline__ float quad_sum(float v) {
   return v + quad_swap<0x4E>(v);
 }
 
-__global__ __launch_bounds__(256) void semseg_ce_kernel(const bf16_t* __restrict__ logits, const uint8_t* __restrict__ target,
+__global__ __launch_bounds__(256, 4) void semseg_ce_kernel(const bf16_t* __restrict__ logits, const uint8_t* __restrict__ target,
                                                         float* __restrict__ grad_acc, float* __restrict__ loss_sum,
                                                         float* __restrict__ valid_cnt, int B, int h, int w, int LP, int NC,
                                                         int ignore) {
-  __shared__ __attribute__((aligned(16))) float zt[SS_LH * SS_LW * SS_PITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t zt[SS_LH * SS_LW * SS_ZPITCH];
   __shared__ __attribute__((aligned(16))) float gt[SS_LH * SS_LW * SS_PITCH];
   __shared__ __attribute__((aligned(16))) uint8_t lab[32 * 64];  // the tile's labels; `ignore` outside the image
   __shared__ float red[4];
@@ -76,20 +78,17 @@ __global__ __launch_bounds__(256) void semseg_ce_kernel(const bf16_t* __restrict
     const int t = i / (SS_MAXC / 8);
     const int tx = t % SS_LW, ty = t / SS_LW;
     const int lx = min(max(lx0 + tx, 0), w - 1), ly = min(max(ly0 + ty, 0), h - 1);
-    float f[8];
+    bf16_t v[8];
     if (ch * 8 < LP) {
-      bf16_t v[8];
       *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(logits + (((size_t)b * h + ly) * w + lx) * LP + ch * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = (ch * 8 + e < NC) ? bf2f(v[e]) : 0.f;
+      for (int e = 0; e < 8; ++e) v[e] = (ch * 8 + e < NC) ? v[e] : (bf16_t)0;
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = 0.f;
+      for (int e = 0; e < 8; ++e) v[e] = 0;
     }
-    float* zd = zt + t * SS_PITCH + ch * 8;
     float* gd = gt + t * SS_PITCH + ch * 8;
-    *reinterpret_cast<float4*>(zd) = make_float4(f[0], f[1], f[2], f[3]);
-    *reinterpret_cast<float4*>(zd + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    *reinterpret_cast<uint4*>(zt + t * SS_ZPITCH + ch * 8) = *reinterpret_cast<const uint4*>(v);
     *reinterpret_cast<float4*>(gd) = make_float4(0.f, 0.f, 0.f, 0.f);
     *reinterpret_cast<float4*>(gd + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -111,18 +110,17 @@ __global__ __launch_bounds__(256) void semseg_ce_kernel(const bf16_t* __restrict
     // tap coordinates of the cell (clamped exactly as the per-pixel formulas below would produce them)
     const int x0 = max(gx, 0), y0 = max(gy, 0);
     const int x1 = x0 + (x0 < w - 1 ? 1 : 0), y1 = y0 + (y0 < h - 1 ? 1 : 0);
-    const int i00 = ((y0 - ly0) * SS_LW + (x0 - lx0)) * SS_PITCH + cj * 8;
-    const int i01 = ((y0 - ly0) * SS_LW + (x1 - lx0)) * SS_PITCH + cj * 8;
-    const int i10 = ((y1 - ly0) * SS_LW + (x0 - lx0)) * SS_PITCH + cj * 8;
-    const int i11 = ((y1 - ly0) * SS_LW + (x1 - lx0)) * SS_PITCH + cj * 8;
-    float v00[8], v01[8], v10[8], v11[8];
-#pragma unroll
-    for (int e = 0; e < 8; e += 4) {
-      *reinterpret_cast<float4*>(v00 + e) = *reinterpret_cast<const float4*>(zt + i00 + e);
-      *reinterpret_cast<float4*>(v01 + e) = *reinterpret_cast<const float4*>(zt + i01 + e);
-      *reinterpret_cast<float4*>(v10 + e) = *reinterpret_cast<const float4*>(zt + i10 + e);
-      *reinterpret_cast<float4*>(v11 + e) = *reinterpret_cast<const float4*>(zt + i11 + e);
-    }
+    const int t00 = (y0 - ly0) * SS_LW + (x0 - lx0), t01 = (y0 - ly0) * SS_LW + (x1 - lx0);
+    const int t10 = (y1 - ly0) * SS_LW + (x0 - lx0), t11 = (y1 - ly0) * SS_LW + (x1 - lx0);
+    const int i00 = t00 * SS_PITCH + cj * 8, i01 = t01 * SS_PITCH + cj * 8;   // the taps' rows of the gradient tile
+    const int i10 = t10 * SS_PITCH + cj * 8, i11 = t11 * SS_PITCH + cj * 8;
+    // the four taps stay packed (16 registers instead of 32: the kernel is compiled for four waves per SIMD) and are widened
+    // where a pixel column uses them
+    bf16_t h00[8], h01[8], h10[8], h11[8];
+    *reinterpret_cast<uint4*>(h00) = *reinterpret_cast<const uint4*>(zt + t00 * SS_ZPITCH + cj * 8);
+    *reinterpret_cast<uint4*>(h01) = *reinterpret_cast<const uint4*>(zt + t01 * SS_ZPITCH + cj * 8);
+    *reinterpret_cast<uint4*>(h10) = *reinterpret_cast<const uint4*>(zt + t10 * SS_ZPITCH + cj * 8);
+    *reinterpret_cast<uint4*>(h11) = *reinterpret_cast<const uint4*>(zt + t11 * SS_ZPITCH + cj * 8);
     const bool own_cell = y0 >= oy0 && y0 < oy0 + SS_OH && x0 >= ox0 && x0 < ox0 + SS_OW;
     unsigned labrow[4];  // the cell's 4 x 4 labels: row r = bytes of labrow[r]
 #pragma unroll
@@ -140,8 +138,8 @@ __global__ __launch_bounds__(256) void semseg_ce_kernel(const bf16_t* __restrict
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         // same association as ATen's upsample_bilinear2d: hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11)
-        p[e] = hx * v00[e] + lx * v01[e];
-        q[e] = hx * v10[e] + lx * v11[e];
+        p[e] = hx * bf2f(h00[e]) + lx * bf2f(h01[e]);
+        q[e] = hx * bf2f(h10[e]) + lx * bf2f(h11[e]);
         u0[e] = 0.f;
         u1[e] = 0.f;
       }
