@@ -365,6 +365,37 @@ def test_fused_1x1_backward(F, tiny):
         F.FUSED_BWD_MIN_PIXELS = old_min
 
 
+def test_bias_gradient_kernels(F):
+    """u2_colsum_add (bias gradient accumulated into its arena slice) and u2_relu_bwd_colsum (ReLU backward + that sum in one pass)
+    through the C ABI: dz bit-equal to u2_relu_bwd, the sums against fp32 column sums of the same bf16 values (1e-5 relative: fp32
+    atomics over a few hundred partial sums), accumulation on top of what the slice already holds, channels >= n_valid untouched;
+    row counts that are no multiple of the block, channel counts with and without padding."""
+    from u2seg_amd import _hip
+
+    g = torch.Generator().manual_seed(12)
+    for rows, cp, n in ((1000, 32, 15), (16 * 37 * 29, 256, 256), (4111, 64, 40), (7, 32, 32)):
+        dout = torch.randn((rows, cp), generator=g).bfloat16().to(DEV)
+        out = torch.randn((rows, cp), generator=g).bfloat16().to(DEV)
+        base = torch.randn(cp, generator=g).to(DEV)
+        # column sums only
+        dst = base.clone()
+        _hip.call("u2_colsum_add", dout, dst, rows, cp, cp, n)
+        want = base.clone()
+        want[:n] += dout.float().sum(0)[:n]
+        assert rel_err(dst[:n], want[:n]) < 1e-5 and torch.equal(dst[n:], base[n:])
+        # ReLU backward + column sums
+        dz_ref = torch.empty_like(dout)
+        _hip.call("u2_relu_bwd", dout, out, dz_ref, dout.numel())
+        dz = torch.empty_like(dout)
+        dst = base.clone()
+        _hip.call("u2_relu_bwd_colsum", dout, out, dz, dst, torch.zeros(cp, device=DEV), rows, cp, cp, n)
+        assert torch.equal(dz, dz_ref)
+        assert torch.equal(dz_ref.float(), dout.float() * (out.float() > 0))
+        want = base.clone()
+        want[:n] += dz_ref.float().sum(0)[:n]
+        assert rel_err(dst[:n], want[:n]) < 1e-5 and torch.equal(dst[n:], base[n:])
+
+
 @pytest.mark.parametrize("tail", [True, False])
 def test_fused_1x1_backward_with_batch_norm_apply(F, tail):
     """u2_conv1x1_bwd_fused_bn (wgrad_stream_kernel<8, 1, 2, 4, DG, AP>, code 2761): conv -> batch norm (-> + residual -> ReLU), whose
