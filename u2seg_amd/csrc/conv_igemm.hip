@@ -1355,6 +1355,21 @@ int launch_conv(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
 
 inline int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
+// Data gradient of a strided conv: the output pixels whose parity class (y % div, x % div) meets no filter tap (three of the four
+// classes of a 1x1 / stride-2 layer) are zero.  One fill launch over all such classes (bit py * div + px of `classes`) instead of
+// a GEMM-shaped launch per class that multiplies nothing (round 5).
+__global__ __launch_bounds__(256) void parity_zero_fill_kernel(bf16_t* __restrict__ out, long long pixels, int H, int W, int ld, int chunks,
+                                                               int div, unsigned classes) {
+  const long long total = pixels * chunks;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long p = i / chunks;
+    const int c = (int)(i - p * chunks);
+    const int x = (int)(p % W), y = (int)((p / W) % H);
+    if ((classes >> ((y % div) * div + (x % div))) & 1u)
+      *reinterpret_cast<uint4*>(out + (size_t)p * ld + c * 8) = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
 }  // namespace
 
 extern "C" int u2_conv_igemm(const void* in, const void* wt, void* out, const float* bias, float* stats,
@@ -1389,8 +1404,28 @@ extern "C" int u2_conv_igemm(const void* in, const void* wt, void* out, const fl
   // Data gradient of a stride-`div` conv: output pixels of parity class (py, px) only meet the taps with
   // (py - pad + kh) % div == 0, so each class is its own small stride-1 conv (1, 2, 2 and 4 taps for 3x3 / stride 2)
   // instead of 9 taps of which 3/4 would multiply the zero page.
+  // classes without a tap: one fill launch (a class with a bias, statistics or an accumulating epilogue keeps its own launch)
+  unsigned empty = 0;
+  if (!bias && !stats && !accumulate && div * div <= 32 && (N & 7) == 0) {
+    for (int py = 0; py < div; ++py)
+      for (int px = 0; px < div; ++px) {
+        bool any = false;
+        for (int kh = 0; kh < KH && !any; ++kh)
+          for (int kw = 0; kw < KW && !any; ++kw)
+            any = ((((py - pad_h + kh) % div) + div) % div) == 0 && ((((px - pad_w + kw) % div) + div) % div) == 0;
+        if (!any && py < Hout && px < Wout) empty |= 1u << (py * div + px);
+      }
+    if (empty) {
+      const long long pixels = (long long)B * Hout * Wout;
+      long long g = (pixels * (N / 8) + 255) / 256;
+      if (g > 256 * 32) g = 256 * 32;
+      hipLaunchKernelGGL(parity_zero_fill_kernel, dim3((unsigned)g), dim3(256), 0, s, a.out, pixels, Hout, Wout, out_ld, N / 8, div, empty);
+      U2_CHECK_LAUNCH();
+    }
+  }
   for (int py = 0; py < div; ++py)
     for (int px = 0; px < div; ++px) {
+      if ((empty >> (py * div + px)) & 1u) continue;
       const int Hq = (Hout - py + div - 1) / div, Wq = (Wout - px + div - 1) / div;
       if (Hq <= 0 || Wq <= 0) continue;
       int nt = 0;
