@@ -827,9 +827,24 @@ class _BilinearUp2Fn(Function):
     def backward(ctx, dout):
         b, h, w, c = ctx.shape
         dout = dout.contiguous()
-        dx = torch.empty((b, h, w, c), dtype=BF16, device=dout.device)
-        _hip.call("u2_bilinear_up2_bwd", dout, dx, b, h, w, c)
+        # The semantic head sums its per-level branches at the common stride (semantic_seg.py:246-253), the last x2 upsample of
+        # every branch adding the running sum: the SAME gradient tensor arrives here once per branch (it is handed on unchanged
+        # as the addend's gradient), and its transposed upsample is the same tensor each time - computed once, shared (round 5:
+        # 0.43 -> 0.16 ms of bilinear2_bwd_kernel per step).  The entry holds `dout` itself, so its address cannot be reused.
+        global _UP2_BWD_LAST
+        key = (dout.data_ptr(), dout._version, tuple(dout.shape), torch.cuda.current_stream(dout.device).cuda_stream)
+        hit = _UP2_BWD_LAST
+        if hit is not None and hit[0] == key:
+            dx = hit[2]
+        else:
+            dx = torch.empty((b, h, w, c), dtype=BF16, device=dout.device)
+            _hip.call("u2_bilinear_up2_bwd", dout, dx, b, h, w, c)
+            if ctx.has_add:   # (the engine runs a whole branch before the next one's node: the other upsamples must not evict it)
+                _UP2_BWD_LAST = (key, dout, dx)
         return dx, (dout if ctx.has_add else None)
+
+
+_UP2_BWD_LAST = None
 
 
 def bilinear_up2(x, addend=None):
@@ -1160,6 +1175,8 @@ _LAZY_GRADS = {}   # placeholder address -> (placeholder, dz, y, coefficients [5
 
 def assert_no_deferred_gradients():
     """After a backward pass: every deferred batch-norm gradient must have been consumed by its convolution."""
+    global _UP2_BWD_LAST
+    _UP2_BWD_LAST = None   # the shared upsample gradient of the semantic head: nothing of this pass stays referenced
     if _LAZY_GRADS:
         n = len(_LAZY_GRADS)
         _LAZY_GRADS.clear()
