@@ -339,7 +339,7 @@ class _Conv2dFn(Function):
         n, cin, kh, kw = weight.shape
         b, h, w_, cp = x.shape
         _, ho, wo, npad = dout.shape
-        lazy = _LAZY_GRADS.pop(dout.data_ptr(), None) if _LAZY_GRADS else None
+        lazy = _LAZY_GRADS.pop((dout.device.index, dout.data_ptr()), None) if _LAZY_GRADS else None
         if lazy is not None:
             # the gradient is still (dz, y, coefficients) of the batch normalisation behind this layer
             _ph, lz_dz, lz_y, lz_k = lazy
@@ -664,7 +664,7 @@ class _BatchNormActFn(Function):
             _hip.call("u2_bn_finalize_bwd", sums, count, ctx.count_dev, gamma, mean, invstd, local, dgamma, dbeta, coef[2], coef[3],
                       coef[4], c, int(direct))
             ph = torch.empty(1, dtype=BF16, device=y.device).expand(y.shape)
-            _LAZY_GRADS[ph.data_ptr()] = (ph, dz if fuse else dout, y, coef)
+            _LAZY_GRADS[(ph.device.index, ph.data_ptr())] = (ph, dz if fuse else dout, y, coef)
             if len(_LAZY_GRADS) > 8:
                 raise RuntimeError("deferred batch-norm gradients were not consumed by their convolutions")
             return ph, None, (None if direct else dgamma), (None if direct else dbeta), None, None, (dz if fuse else None), \
@@ -832,7 +832,7 @@ class _BilinearUp2Fn(Function):
         # as the addend's gradient), and its transposed upsample is the same tensor each time - computed once, shared (round 5:
         # 0.43 -> 0.16 ms of bilinear2_bwd_kernel per step).  The entry holds `dout` itself, so its address cannot be reused.
         global _UP2_BWD_LAST
-        key = (dout.data_ptr(), dout._version, tuple(dout.shape), torch.cuda.current_stream(dout.device).cuda_stream)
+        key = (dout.device.index, dout.data_ptr(), dout._version, tuple(dout.shape), torch.cuda.current_stream(dout.device).cuda_stream)
         hit = _UP2_BWD_LAST
         if hit is not None and hit[0] == key:
             dx = hit[2]
@@ -1170,7 +1170,7 @@ def roi_grad_tap(feats):
 FUSED_BWD_MIN_PIXELS = int(os.environ.get("U2_FUSED_BWD_MIN_PIXELS", "200000"))
 # the batch-norm backward apply step of an expanding 1x1 layer evaluated inside that layer's fused backward launch (0: separate)
 LAZY_BN_APPLY = os.environ.get("U2_LAZY_BN_APPLY", "1") != "0"
-_LAZY_GRADS = {}   # placeholder address -> (placeholder, dz, y, coefficients [5][C]: rows 2-4 = k1, k2, k3)
+_LAZY_GRADS = {}   # (device, placeholder address) -> (placeholder, dz, y, coefficients [5][C]: rows 2-4 = k1, k2, k3)
 
 
 def assert_no_deferred_gradients():
