@@ -1825,6 +1825,37 @@ def gen_resume_fixture(hw=(192, 256), nimg=2, seed=9, steps=4, save_after=1):
     print("wrote checkpoint_resume.pth (%.2f MB) and resume_golden.json" % (os.path.getsize(os.path.join(HERE, "checkpoint_resume.pth")) / 1e6))
 
 
+def gen_param_groups_fixture():
+    """the reference groups parameters by their per-parameter override DICT, not by the weight-decay value
+    (solver/build.py:123-129,181-236,255-279).  For several (WEIGHT_DECAY, WEIGHT_DECAY_NORM, WEIGHT_DECAY_BIAS) triples -
+    including overrides that EQUAL the default - record what the reference's build_optimizer forms on the reduced
+    u2seg_R50_800: group sizes, each group's weight decay, and a crc32 of torch's parameter numbering (names in group order)."""
+    import_reference()
+    os.environ.setdefault("CLUSTER_NUM", "800")
+    from detectron2.config import get_cfg
+    from detectron2.modeling import build_model
+    from detectron2.solver import build_optimizer
+
+    cases = []
+    for wd, wdn, wdb in [(1e-4, 0.0, None), (1e-4, 1e-4, None), (1e-4, 0.0, 1e-4), (1e-4, 1e-4, 1e-4), (1e-4, 0.0, 0.0),
+                         (5e-5, 1e-4, 5e-5), (1e-4, None, None), (1e-4, None, 0.0)]:
+        cfg = get_cfg()
+        cfg.merge_from_file(os.path.join(REF, "configs/COCO-PanopticSegmentation/u2seg_R50_800.yaml"))
+        cfg.merge_from_list(["MODEL.DEVICE", "cpu", "MODEL.WEIGHTS", ""] + REDUCED_MODEL_OPTS)
+        cfg.SOLVER.WEIGHT_DECAY, cfg.SOLVER.WEIGHT_DECAY_NORM, cfg.SOLVER.WEIGHT_DECAY_BIAS = wd, wdn, wdb
+        model = build_model(cfg)
+        opt = build_optimizer(cfg, model)
+        names = {id(p): k for k, p in model.named_parameters()}
+        order = [names[id(p)] for g in opt.param_groups for p in g["params"]]
+        cases.append({"weight_decay": wd, "weight_decay_norm": wdn, "weight_decay_bias": wdb,
+                      "group_sizes": [len(g["params"]) for g in opt.param_groups],
+                      "group_weight_decay": [g["weight_decay"] for g in opt.param_groups],
+                      "first_names": [names[id(g["params"][0])] for g in opt.param_groups],
+                      "numbering_crc32": zlib.crc32("\n".join(order).encode())})
+        print(cases[-1]["group_sizes"], cases[-1]["group_weight_decay"])
+    json.dump({"opts": REDUCED_MODEL_OPTS, "cases": cases}, open(os.path.join(HERE, "param_groups_golden.json"), "w"), indent=0)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -1847,6 +1878,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.only == "resume":
         gen_resume_fixture()
+        sys.exit(0)
+    if a.only == "param_groups":
+        gen_param_groups_fixture()
         sys.exit(0)
     if a.only == "bf16_units":
         gen_bf16_units_fixture()

@@ -337,8 +337,8 @@ def test_rpn_decode_rows_equal_the_per_level_composition(F):
     """u2_rpn_decode (all levels, one launch) vs the per-level composition it replaced - gather the selected deltas from the NHWC
     map, F.apply_deltas with clipping, pad the short level, finite / min-size filter - bit for bit: deltas read through the
     channel-offset view of the fused predictor map (objectness in channels 0-2, deltas in 3-14 of 32) and from a map of their own,
-    a level shorter than kmax, a non-finite logit (counted, filtered), a non-finite delta (clipped to an empty box) and a
-    degenerate box (filtered)."""
+    a level shorter than kmax, a non-finite logit (counted, filtered), a non-finite delta (counted on the unclipped box as the
+    reference does, filtered) and a degenerate box (filtered)."""
     import math
 
     g = torch.Generator().manual_seed(5)
@@ -371,7 +371,9 @@ def test_rpn_decode_rows_equal_the_per_level_composition(F):
         sel = torch.gather(deltas, 1, idx.long()[..., None].expand(b, k, 4)).float().reshape(b * k, 4)
         img = torch.arange(b, device=DEV, dtype=torch.int32).repeat_interleave(k)
         bx = F.apply_deltas(anc[idx.long().reshape(-1)], sel, weights, img, sizes, clamp).view(b, k, 4)
-        fin = torch.isfinite(bx).all(dim=2) & torch.isfinite(sc)
+        # the reference tests the UNCLIPPED boxes (proposal_utils.py:93-99): the clip swallows NaN and clamps Inf
+        raw = F.apply_deltas(anc[idx.long().reshape(-1)], sel, weights, None, None, clamp).view(b, k, 4)
+        fin = torch.isfinite(raw).all(dim=2) & torch.isfinite(sc)
         kp = fin & ((bx[..., 2] - bx[..., 0]) > min_size) & ((bx[..., 3] - bx[..., 1]) > min_size)
         ref_boxes.append(torch.nn.functional.pad(bx, (0, 0, 0, kmax - k)))
         ref_scores.append(torch.nn.functional.pad(sc, (0, kmax - k), value=-3.0e38))
@@ -384,8 +386,8 @@ def test_rpn_decode_rows_equal_the_per_level_composition(F):
     assert bool(same.all())
     assert torch.equal(scores, rs)
     assert torch.equal(keep.bool(), rk)
-    assert int(nonfinite.item()) == 1
-    assert not bool(keep[0, 1]) and not bool(keep[3, 0])   # the non-finite candidate and the empty box are filtered
+    assert int(nonfinite.item()) == 2                      # the non-finite logit AND the non-finite delta
+    assert not bool(keep[0, 0]) and not bool(keep[0, 1]) and not bool(keep[3, 0])   # both of them and the empty box are filtered
     assert int(keep.sum()) == int(rk.sum()) > b * 100
 
 

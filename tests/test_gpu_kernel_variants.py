@@ -462,6 +462,53 @@ def test_fused_1x1_backward_with_batch_norm_apply(F, tail):
         os.environ.pop("U2_WDGRAD_VARIANT") if old_env is None else os.environ.__setitem__("U2_WDGRAD_VARIANT", old_env)
 
 
+def test_deferred_batch_norm_gradient_guards(F):
+    """the deferral hands autograd a placeholder instead of the conv output's gradient.  (i) the placeholder is
+    zero-filled and comes from a fixed pool; (ii) a conv output with a SECOND consumer makes autograd sum the placeholder with
+    that consumer's gradient - the tensor hook on the conv output raises inside that backward pass instead of letting the
+    convolution see a sum without the normalisation's part; (iii) entries a failed backward left behind are dropped (and
+    reported) by the next FlatSGD.zero_grad, and a clean pass afterwards still takes the fused launch."""
+    from u2seg_amd.layers.modules import BatchNorm2d, Conv2d
+    from u2seg_amd.solver import FlatSGD
+
+    old_min, old_env = F.FUSED_BWD_MIN_PIXELS, os.environ.get("U2_WDGRAD_VARIANT")
+    g = torch.Generator().manual_seed(5)
+    try:
+        F.FUSED_BWD_MIN_PIXELS = 0
+        os.environ["U2_WDGRAD_VARIANT"] = "1"
+        conv = Conv2d(64, 256, 1, bias=False, norm=BatchNorm2d(256, sync=False)).to(DEV)
+        conv.train()
+        opt = FlatSGD(conv, lr=0.1)
+        x = nhwc(bf(torch.randn((2, 64, 33, 21), generator=g)))
+        ph = F._lazy_placeholder(x.device)
+        assert float(ph.float().abs().sum()) == 0.0 and ph.numel() == 1
+        # (ii) second consumer of the conv output
+        opt.zero_grad()
+        xd = x.clone().requires_grad_(True)
+        y, stats = F.conv2d(xd, conv.weight, None, want_stats=True)
+        assert getattr(y, "_u2_lazy_ok", False)
+        n = conv.norm
+        out = F.batch_norm_act(y, stats, n.weight, n.bias, n.running_mean, n.running_var, sync=False)
+        with pytest.raises(RuntimeError, match="second consumer"):
+            (out.float().sum() + y.float().sum()).backward()
+        assert not F._LAZY_GRADS
+        # (iii) a stale entry is reported by the next zero_grad, then the path works again
+        F._LAZY_GRADS[(x.device.index, ph.data_ptr())] = (ph, None, None, None)
+        with pytest.raises(RuntimeError, match="never consumed"):
+            opt.zero_grad()
+        opt.zero_grad()
+        xd = x.clone().requires_grad_(True)
+        conv(xd).float().sum().backward()
+        assert last_kernel() == 2761
+        F.assert_no_deferred_gradients()
+        F.join_all_streams()
+        assert float(xd.grad.float().abs().max()) >= 0 and torch.isfinite(conv.weight.grad).all()
+    finally:
+        F.FUSED_BWD_MIN_PIXELS = old_min
+        F._LAZY_GRADS.clear()
+        os.environ.pop("U2_WDGRAD_VARIANT") if old_env is None else os.environ.__setitem__("U2_WDGRAD_VARIANT", old_env)
+
+
 def test_fused_1x1_backward_full_shape_auto(F):
     """res2 conv3 (1x1 64 -> 256 over 16 x 200 x 336 pixels) through the automatic dispatch: the fused launch (code 2751) takes it;
     dW against an fp32 reference formed by torch on the GPU over all 1 075 200 pixels, dx at 4096 sampled pixels."""

@@ -721,6 +721,72 @@ def test_kmeans_two_level_screen_modes():
     KM._ws_cache.pop("assign:" + str(xm.device), None)
 
 
+@pytest.mark.parametrize("data_kind", ["mixture", "randn"])
+def test_kmeans_config4_full_size_properties(data_kind):
+    """BASELINE config 4 at its OWN size: N = 1 000 000 x 768, K = 300 - more than 65 535 row blocks,
+    label buckets of ~3 300 rows, the two-level screen's full workspace; both of bench.py's data kinds.  One Lloyd iteration
+    through the C ABI, checked by size-independent properties (nn_utils.py:353-364):
+      * screened labels == the exact-fp32 kernel's labels on a 50 000-row sample spread over the whole range INCLUDING the
+        last block (and == the fp64 argmin except at fp32-level ties);
+      * counts sum to N and equal bincount(labels);
+      * centroids == the mean of their rows, in fp64, for the clusters the sample touches first + a stride over all K;
+      * an empty cluster (a far-away centroid) comes out as a NaN row with count 0;
+      * a second iteration on the updated centroids still agrees with the exact kernel on the sample."""
+    from u2seg_amd.cluster import kmeans as KM
+
+    n, d, k = 1000000, 768, 300
+    g = torch.Generator(device=DEV).manual_seed(7)
+    if data_kind == "mixture":
+        centers = torch.randn((k, d), generator=g, device=DEV) * 2
+        x = centers[torch.randint(0, k, (n,), generator=g, device=DEV)] + 0.5 * torch.randn((n, d), generator=g, device=DEV)
+        c = centers + 0.3 * torch.randn((k, d), generator=g, device=DEV)
+    else:
+        x = torch.randn((n, d), generator=g, device=DEV)
+        c = x[torch.randperm(n, generator=g, device=DEV)[:k]].clone()
+    c[k - 1] = 1.0e3                                   # nobody's nearest centroid: the empty cluster
+    KM._ws_cache.pop("assign:" + str(x.device), None)
+    sample = torch.cat([torch.arange(0, n, 21, device=DEV)[:47000], torch.arange(n - 3000, n, device=DEV)])
+    xs = x[sample]
+
+    def check_labels(lab, cc):
+        assert lab.dtype == torch.int64 and int(lab.min()) >= 0 and int(lab.max()) < k
+        exact = KM.assign(xs, cc, exact=True)
+        assert torch.equal(lab[sample], exact), int((lab[sample] != exact).sum())
+        dd = (xs[:8000].double() ** 2).sum(1, keepdim=True) - 2 * xs[:8000].double() @ cc.double().t() + (cc.double() ** 2).sum(1)[None]
+        dd = torch.nan_to_num(dd, nan=float("inf"))
+        ref = dd.argmin(1)
+        bad = torch.nonzero(exact[:8000] != ref)[:, 0]
+        assert bad.numel() <= 8
+        if bad.numel():
+            a, b = dd[bad, exact[bad]], dd[bad, ref[bad]]
+            assert torch.allclose(a, b, rtol=1e-5)
+
+    lab = KM.assign(x, c)
+    check_labels(lab, c)
+    cn, cnt = KM.update(x, lab, k)
+    bc = torch.bincount(lab, minlength=k)
+    assert float(cnt.double().sum()) == float(n) and torch.equal(cnt.long(), bc)
+    assert int(bc[k - 1]) == 0 and bool(torch.isnan(cn[k - 1]).all()) and bool(torch.isfinite(cn[: k - 1][bc[: k - 1] > 0]).all())
+    picked = sorted(set(lab[sample[:40]].tolist()) | set(range(0, k - 1, 37)))
+    for j in picked:
+        rows = torch.nonzero(lab == j)[:, 0]
+        if rows.numel() == 0:
+            assert bool(torch.isnan(cn[j]).all())
+            continue
+        want = x[rows].double().mean(0)
+        assert float((cn[j].double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())), j
+    # second iteration on the updated centroids (the empty cluster's NaN row parked far away again: what a NaN centroid does to
+    # the arg-min is the subject of test_kmeans_vs_oracle, not of this size test)
+    c2 = cn.clone()
+    c2[k - 1] = 1.0e3
+    lab2 = KM.assign(x, c2)
+    check_labels(lab2, c2)
+    assert int((lab2 == k - 1).sum()) == 0
+    del x, xs
+    KM._ws_cache.pop("assign:" + str(DEV), None)
+    torch.cuda.empty_cache()
+
+
 def _clustered_unit_rows(n, d, seed, nclusters=40):
     g = torch.Generator().manual_seed(seed)
     centers = torch.randn((nclusters, d), generator=g)

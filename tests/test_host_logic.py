@@ -450,6 +450,49 @@ def test_reference_optimizer_and_scheduler_state_round_trip(tmp_path):
     assert "optimizer" in rest4 and rest4["iteration"] == fx["saved_iteration"]
 
 
+def test_param_groups_follow_the_reference_override_dicts():
+    """The reference merges parameters by their override DICT (solver/build.py:123-129,181-236,255-279): a norm / bias override
+    that equals WEIGHT_DECAY still forms a group of its own, and all overridden parameters of one value share one.  Fixture:
+    make_fixtures.py --only param_groups (the reference's build_optimizer on the reduced u2seg_R50_800, eight triples).  The
+    numbering decides whether a reference checkpoint's optimizer state loads at all."""
+    from u2seg_amd.modeling import build_model
+    from u2seg_amd.solver import build_optimizer
+
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "param_groups_golden.json")))
+    cfg = _cfg(opts=fx["opts"])
+    model = build_model(cfg)
+    names = {id(p): k for k, p in model.named_parameters()}
+    for case in fx["cases"]:
+        cfg.SOLVER.WEIGHT_DECAY = case["weight_decay"]
+        cfg.SOLVER.WEIGHT_DECAY_NORM = case["weight_decay_norm"]
+        cfg.SOLVER.WEIGHT_DECAY_BIAS = case["weight_decay_bias"]
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+        opt = build_optimizer(cfg, model)
+        assert [len(m) for m in opt.group_members] == case["group_sizes"], case
+        assert opt.group_wd == case["group_weight_decay"], case
+        assert [names[id(opt.params[m[0]])] for m in opt.group_members] == case["first_names"]
+        order = [names[id(opt.params[i])] for m in opt.group_members for i in m]
+        assert zlib.crc32("\n".join(order).encode()) == case["numbering_crc32"]
+        # per-parameter decay the kernel applies = the group's value
+        wd = opt.wd.tolist()
+        assert all(wd[i] == pytest.approx(g) for g, m in zip(opt.group_wd, opt.group_members) for i in m)
+        # what it writes loads into torch's SGD over the same grouping, and a group's decay is addressed by POSITION on load
+        sd = opt.state_dict()
+        clones = [torch.nn.Parameter(p.detach().clone()) for p in opt.params]
+        tsgd = torch.optim.SGD([{"params": [clones[i] for i in m], "weight_decay": g}
+                                for g, m in zip(opt.group_wd, opt.group_members)], lr=1.0, momentum=0.9)
+        tsgd.load_state_dict(sd)
+        if len(opt.group_wd) >= 2:
+            sd["param_groups"][-1]["weight_decay"] = 0.125
+            for g in sd["param_groups"]:
+                g["initial_lr"] = 0.5
+            opt.load_state_dict(sd)
+            assert opt.group_wd[-1] == 0.125 and opt.group_wd[:-1] == case["group_weight_decay"][:-1] and opt.base_lr == 0.5
+            wd = opt.wd.tolist()
+            assert all(wd[i] == pytest.approx(g) for g, m in zip(opt.group_wd, opt.group_members) for i in m)
+        model.load_state_dict(state)
+
+
 def test_resolved_configs_equal_reference():
     """Every key this package's config tree holds has the value the reference resolves for the same yaml (its defaults.py +
     _BASE_ chain; fixture: tests/golden/make_fixtures.py --only config), for the four U2Seg train / eval configs - both

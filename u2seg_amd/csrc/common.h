@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <mutex>
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -9,15 +11,32 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // hipFuncSetAttribute (dynamic LDS above 64 KB) applies to the CURRENT device's copy of a kernel: remember it per device, not per
-// process - a process may drive several GPUs.  `static PerDeviceOnce once; if (once.first()) { ...set... }`
+// process - a process may drive several GPUs - and from several host threads (main + autograd):
+// `static PerDeviceOnce once; if (auto g = once.first()) { ...set... }` - the guard holds the lock until the block is left, so a
+// second thread cannot launch between "somebody is setting the attribute" and "it is set".
 struct PerDeviceOnce {
-  bool done[64] = {};
-  bool first() {
+  std::mutex mu;
+  std::atomic<bool> done[64];
+  PerDeviceOnce() { for (auto& d : done) d.store(false, std::memory_order_relaxed); }
+  struct Guard {
+    PerDeviceOnce* o; int d;
+    Guard(PerDeviceOnce* o_, int d_) : o(o_), d(d_) {}
+    Guard(const Guard&) = delete;
+    Guard& operator=(const Guard&) = delete;
+    explicit operator bool() const { return o != nullptr; }
+    ~Guard() {
+      if (!o) return;
+      if (d >= 0) o->done[d].store(true, std::memory_order_release);
+      o->mu.unlock();
+    }
+  };
+  Guard first() {
     int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;  // unknown device: set the attribute again (cheap)
-    if (done[d]) return false;
-    done[d] = true;
-    return true;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = -1;  // unknown device: set the attribute again (cheap)
+    if (d >= 0 && done[d].load(std::memory_order_acquire)) return Guard(nullptr, d);
+    mu.lock();
+    if (d >= 0 && done[d].load(std::memory_order_relaxed)) { mu.unlock(); return Guard(nullptr, d); }
+    return Guard(this, d);
   }
 };
 

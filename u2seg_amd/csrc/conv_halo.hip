@@ -400,7 +400,7 @@ int launch_halo_cfg(ConvArgs& a, int N, int tiny, hipStream_t s) {
   long long G = T < (tiny ? 8 : 256) ? T : (tiny ? 8 : 256);
   G = (G + 7) & ~7LL;
   static PerDeviceOnce attr_set;
-  if (attr_set.first()) {
+  if (auto once_guard = attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)conv_halo_kernel<PH, PWD, OPT, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   hipLaunchKernelGGL((conv_halo_kernel<PH, PWD, OPT, CW>), dim3((unsigned)G), dim3(512), LDS_BYTES, s, a);

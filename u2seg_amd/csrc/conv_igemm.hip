@@ -18,6 +18,7 @@
 // and written with 16-byte coalesced stores (bias / accumulate / ReLU / BN column statistics fused).
 #include <stdlib.h>
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 #include "conv_args.h"
@@ -1189,6 +1190,11 @@ struct ScratchEnt { int device; hipStream_t stream; int kind; void* buf; size_t 
 ScratchEnt g_scratch[128];
 int g_scratch_used = 0;
 std::mutex g_scratch_mu;
+// blocks replaced by a larger one: another host thread (main / autograd) may hold the old pointer between scratch_get's return
+// and its launch, which no stream synchronisation here can see - so an outgrown block is only FREED by u2_release_scratch().
+// Growth is geometric (x 1.5) under a per-kind limit: the retired blocks of an entry sum to less than twice its final size.
+struct RetiredEnt { int device; void* buf; };
+std::vector<RetiredEnt> g_retired;
 }  // namespace
 
 void* scratch_get(int kind, hipStream_t s, size_t need_bytes, size_t limit_bytes, bool zero_on_alloc) {
@@ -1210,8 +1216,7 @@ void* scratch_get(int kind, hipStream_t s, size_t need_bytes, size_t limit_bytes
   cap = (cap + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
   if (cap > limit_bytes) cap = limit_bytes;
   if (e->buf) {
-    (void)hipStreamSynchronize(s);  // launches of this stream may still use the old block
-    (void)hipFree(e->buf);
+    g_retired.push_back(RetiredEnt{dev, e->buf});   // freed by u2_release_scratch (see g_retired)
     e->buf = nullptr; e->cap = 0;
   }
   void* p = nullptr;
@@ -1237,6 +1242,13 @@ extern "C" int u2_release_scratch(void) {
     ++freed;
   }
   u2conv::g_scratch_used = 0;
+  for (const u2conv::RetiredEnt& r : u2conv::g_retired) {
+    (void)hipSetDevice(r.device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(r.buf);
+    ++freed;
+  }
+  u2conv::g_retired.clear();
   (void)hipSetDevice(cur);
   return freed;
 }
@@ -1290,7 +1302,7 @@ int launch_conv(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (N + 255) / 256;
     static PerDeviceOnce attr_set;
-    if (attr_set.first()) {
+    if (auto once_guard = attr_set.first()) {
       (void)hipFuncSetAttribute((const void*)conv_igemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute((const void*)conv_igemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
@@ -1327,7 +1339,7 @@ int launch_conv(ConvArgs& a, int N, int C, int variant, hipStream_t s) {
   do {                                                                                                           \
     g_last_conv_kernel = 1000000 + BK_ * 10000 + (TM_ / 64) * 1000 + (TN_ / 64) * 100 + NST_ * 10 + (GL_ ? 1 : 0); \
     static PerDeviceOnce attr_set;                                                                                \
-    if (attr_set.first()) {                                                                                             \
+    if (auto once_guard = attr_set.first()) {                                                                                             \
       (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BK_, GL_, TM_, TN_, NST_>,                        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
     }                                                                                                            \
@@ -1599,7 +1611,7 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
   g_last_conv_kernel = (wide ? 2256 : 2000 + (glds ? 2 : 0) + (tr ? 1 : 0)) + (a.xcd_group ? 100 : 0);
   if (wide) {
     static PerDeviceOnce attr_set;
-    if (attr_set.first()) {
+    if (auto once_guard = attr_set.first()) {
       (void)hipFuncSetAttribute((const void*)conv_wgrad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     hipLaunchKernelGGL(conv_wgrad256_kernel, grid, dim3(512), WG256_STAGES * WG256_STAGE, s, a);

@@ -336,7 +336,7 @@ int launch_stream_cfg(ConvArgs& a, int N, int tiny, int forced, int code, hipStr
   // finer (tile, K) grain fills the chip better there
   if (!forced && !tiny && (long long)a.tiles_m * a.tiles_n < 6 * G) return 0;
   static PerDeviceOnce attr_set;
-  if (attr_set.first()) {
+  if (auto once_guard = attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)conv_stream_kernel<KS, TM, PSW, NWV, KSS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   g_last_conv_kernel = code;

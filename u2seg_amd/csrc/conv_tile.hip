@@ -637,7 +637,7 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s, int
     while (Gs > 8 && (T / 8) * nkh / (Gs / 8) < RING + 1) Gs -= 8;
     if (want && Gs <= SK_MAX_GROUPS && (T / 8) * nkh / (Gs / 8) >= RING + 1 && sk_scratch(s, a, (size_t)Gs * TM * TN * 4)) {
       static PerDeviceOnce attr_set_sk;
-      if (attr_set_sk.first()) {
+      if (auto once_guard = attr_set_sk.first()) {
         (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, false, true, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       }
       g_last_conv_kernel += 400;  // 5xx: the stream-K form of configuration xx
@@ -650,7 +650,7 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s, int
   long long G = T < cap ? T : cap;
   G = (G + 7) & ~7LL;
   static PerDeviceOnce attr_set;
-  if (attr_set.first()) {
+  if (auto once_guard = attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, ACC, false, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, ACC, false, KT>), dim3((unsigned)G), dim3(WCH * WPX * 64), LDS, s, a);

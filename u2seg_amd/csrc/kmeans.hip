@@ -809,7 +809,7 @@ extern "C" int u2_kmeans_assign(const float* x, const float* c, float* workspace
   hipLaunchKernelGGL(csplit_kernel, dim3(KS_KMAX / 4), dim3(256), 0, s, c, chl, cn, scal, D, K);
   U2_CHECK_LAUNCH();
   static PerDeviceOnce attr_set;
-  if (attr_set.first()) {
+  if (auto once_guard = attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -790,11 +790,13 @@ __global__ __launch_bounds__(256) void rpn_decode_kernel(const RpnDecodeArgs a) 
     const float pcx = dx * w + cx, pcy = dy * h + cy;
     const float pw = expf(dw) * w, ph = expf(dh) * h;
     x1 = pcx - 0.5f * pw; y1 = pcy - 0.5f * ph; x2 = pcx + 0.5f * pw; y2 = pcy + 0.5f * ph;
+    sc = lv.scores[(size_t)b * lv.k + j];
+    // the reference tests the UNCLIPPED boxes (proposal_utils.py:93-99, clip comes after): fminf / fmaxf swallow NaN and
+    // clamp Inf, so a test behind the clamp could never fire and diverged deltas would turn into silently dropped empty boxes
+    const bool finite = isfinite(x1) && isfinite(y1) && isfinite(x2) && isfinite(y2) && isfinite(sc);
     const float H = a.sizes[b * 2 + 0], W = a.sizes[b * 2 + 1];
     x1 = fminf(fmaxf(x1, 0.f), W); x2 = fminf(fmaxf(x2, 0.f), W);
     y1 = fminf(fmaxf(y1, 0.f), H); y2 = fminf(fmaxf(y2, 0.f), H);
-    sc = lv.scores[(size_t)b * lv.k + j];
-    const bool finite = isfinite(x1) && isfinite(y1) && isfinite(x2) && isfinite(y2) && isfinite(sc);
     if (!finite) atomicAdd(a.nonfinite, 1);
     keep = finite && (x2 - x1) > a.min_size && (y2 - y1) > a.min_size;
   }
@@ -1128,7 +1130,7 @@ extern "C" int u2_roi_group(const float* rois, const int* level, int* order, int
   const size_t lds = ((size_t)256 * (nkeys + 2) + (size_t)(R > 0 ? R : 1)) * 2;
   if (lds > (size_t)RG_LDS_LIMIT) return -1;
   static PerDeviceOnce attr_set;
-  if (attr_set.first()) {
+  if (auto once_guard = attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)roi_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_LIMIT);
   }
   hipLaunchKernelGGL(roi_group_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, rois, level, order, seg, R, nlevels, nkeys);

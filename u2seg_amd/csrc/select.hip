@@ -317,7 +317,7 @@ extern "C" int u2_topk_rows_multi(const U2TopkSeg* segs, int nseg, void* stream)
   if (grid >= (1LL << 31)) return -1;
   const size_t lds = (size_t)max_cap * 8 + 272 * 4;
   static PerDeviceOnce attr_set;
-  if (attr_set.first()) {
+  if (auto once_guard = attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)topk_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)grid), dim3(SEL_THREADS), lds, (hipStream_t)stream, m);

@@ -351,7 +351,7 @@ int launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* dw, long long dw
   ppw = (ppw + HS - 1) / HS * HS;
   a.pix_per_wg = ppw;
   static PerDeviceOnce attr_set;
-  if (attr_set.first()) {
+  if (auto once_guard = attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   hipLaunchKernelGGL(conv_wgrad_halo_kernel, dim3((unsigned)(nsplit * a.tiles)), dim3(512), RING * STAGE, s, a);

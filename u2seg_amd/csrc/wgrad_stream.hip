@@ -409,7 +409,7 @@ int launch_ws(WsArgs& a, int per_cu, int tiny, int code, hipStream_t s) {
   while (ranges > 8 && a.steps < 2 * ranges) ranges -= 8;
   a.ranges = ranges;
   static PerDeviceOnce attr_set;
-  if (attr_set.first()) {
+  if (auto once_guard = attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)wgrad_stream_kernel<WN, WC, FN, FC, DG, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   g_last_conv_kernel = code;

@@ -11,6 +11,7 @@ Every function here launches HIP kernels; none has a CPU or ATen compute fallbac
 import ctypes
 import math
 
+import functools
 import os
 
 import torch
@@ -663,10 +664,10 @@ class _BatchNormActFn(Function):
             # to the conv is a one-element placeholder expanded to the shape; _Conv2dFn.backward finds the operands by its address.
             _hip.call("u2_bn_finalize_bwd", sums, count, ctx.count_dev, gamma, mean, invstd, local, dgamma, dbeta, coef[2], coef[3],
                       coef[4], c, int(direct))
-            ph = torch.empty(1, dtype=BF16, device=y.device).expand(y.shape)
+            ph = _lazy_placeholder(y.device).expand(y.shape)
             _LAZY_GRADS[(ph.device.index, ph.data_ptr())] = (ph, dz if fuse else dout, y, coef)
-            if len(_LAZY_GRADS) > 8:
-                raise RuntimeError("deferred batch-norm gradients were not consumed by their convolutions")
+            if isinstance(ctx.lazy_ok, dict):
+                ctx.lazy_ok["key"] = (ph.device.index, ph.data_ptr())   # what _lazy_guard must see arrive at the conv output
             return ph, None, (None if direct else dgamma), (None if direct else dbeta), None, None, (dz if fuse else None), \
                 None, None, None, None, None, None, None, None
         dx = torch.empty_like(y)
@@ -697,8 +698,14 @@ def batch_norm_act(y, stats, gamma, beta, running_mean, running_var, residual=No
     gd, bd = grad_slot(gamma), grad_slot(beta)
     grad_dst = (gd, bd) if gd is not None and bd is not None else None
     twin = (3 if twin == 3 else int(bool(twin))) if torch.is_grad_enabled() else 0
+    lazy_ok = bool(getattr(y, "_u2_lazy_ok", False)) and y.requires_grad and torch.is_grad_enabled()
+    if lazy_ok:
+        # the conv output must reach its convolution's backward as the placeholder itself: a second consumer of y, or anything
+        # else that makes autograd form a sum, would silently drop the deferred gradient - fail there and then instead
+        lazy_ok = {"key": None}
+        y.register_hook(functools.partial(_lazy_guard, lazy_ok))
     out = _BatchNormActFn.apply(y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, grad_dst,
-                                twin, sync, res_up, bool(getattr(y, "_u2_lazy_ok", False)))
+                                twin, sync, res_up, lazy_ok)
     if twin == 3:  # a third handle (`._u2_third`) for a third consumer, e.g. the FPN lateral conv on a stage output
         out, other, third = out
         out._u2_twin, out._u2_third = other, third
@@ -1171,6 +1178,50 @@ FUSED_BWD_MIN_PIXELS = int(os.environ.get("U2_FUSED_BWD_MIN_PIXELS", "200000"))
 # the batch-norm backward apply step of an expanding 1x1 layer evaluated inside that layer's fused backward launch (0: separate)
 LAZY_BN_APPLY = os.environ.get("U2_LAZY_BN_APPLY", "1") != "0"
 _LAZY_GRADS = {}   # (device, placeholder address) -> (placeholder, dz, y, coefficients [5][C]: rows 2-4 = k1, k2, k3)
+
+
+_LAZY_POOL = {}    # device index -> [zero-filled bf16 pool, next slot]: placeholders are ZEROS, so that a sum autograd forms with
+                   # one by accident is numerically the other addend (and is then caught by _lazy_guard / the checks below)
+_LAZY_SLOTS = 64
+
+
+def _lazy_placeholder(device):
+    ent = _LAZY_POOL.get(device.index)
+    if ent is None:
+        ent = _LAZY_POOL[device.index] = [torch.zeros(_LAZY_SLOTS, dtype=BF16, device=device), 0]
+    for _ in range(_LAZY_SLOTS):
+        slot = ent[0][ent[1] : ent[1] + 1]
+        ent[1] = (ent[1] + 1) % _LAZY_SLOTS
+        if (device.index, slot.data_ptr()) not in _LAZY_GRADS:
+            return slot
+    n = len(_LAZY_GRADS)
+    _LAZY_GRADS.clear()
+    raise RuntimeError("%d deferred batch-norm gradients were not consumed by their convolutions" % n)
+
+
+def _lazy_guard(state, grad):
+    """Tensor hook on a conv output whose batch normalisation defers its backward apply step: the gradient autograd delivers
+    must be the placeholder that normalisation registered (`state["key"]`, None when it did not defer), untouched."""
+    key, state["key"] = state["key"], None
+    if key is not None and (grad.device.index, grad.data_ptr()) != key:
+        pend = len(_LAZY_GRADS)
+        _LAZY_GRADS.clear()
+        raise RuntimeError("a convolution output with a deferred batch-norm gradient has a second consumer (autograd summed "
+                           "the placeholder with another gradient); %d deferred gradients dropped - set U2_LAZY_BN_APPLY=0 "
+                           "for graphs that re-use conv outputs" % pend)
+    return None
+
+
+def reset_deferred_gradients(strict=True):
+    """Start of a training step (solver.FlatSGD.zero_grad): nothing deferred may be left over from an earlier backward pass -
+    one that raised midway leaves entries behind, which must not meet the addresses of the next pass."""
+    global _UP2_BWD_LAST
+    _UP2_BWD_LAST = None
+    if _LAZY_GRADS:
+        n = len(_LAZY_GRADS)
+        _LAZY_GRADS.clear()
+        if strict:
+            raise RuntimeError("%d deferred batch-norm gradients of an earlier backward pass were never consumed" % n)
 
 
 def assert_no_deferred_gradients():

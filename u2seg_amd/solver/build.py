@@ -21,23 +21,31 @@ class FlatSGD:
         # per-parameter hyper-parameters by the reference's rule (solver/build.py:218-236 get_default_optimizer_params): the
         # module tree is walked in named_modules order, a normalisation layer's parameters take WEIGHT_DECAY_NORM, and the
         # legacy bias override - applied after it, to every parameter literally named "bias" - WEIGHT_DECAY_BIAS
-        wd_of, seen = {}, set()
+        # `key_of` is the reference's grouping key: its per-parameter dict starts as {"lr": base_lr} - build_optimizer never
+        # hands weight_decay to get_default_optimizer_params (solver/build.py:123-129), torch fills it in from the SGD default -
+        # and gains a "weight_decay" entry only where an override applied.  So a parameter without override (key None) and one
+        # whose override EQUALS the default still sit in different groups, and all overridden parameters of one value share one.
+        wd_of, key_of, seen = {}, {}, set()
         for mod in model.modules():
             for pname, p in mod.named_parameters(recurse=False):
                 if not p.requires_grad or id(p) in seen:
                     continue
                 seen.add(id(p))
-                wd = weight_decay_norm if isinstance(mod, (BatchNorm2d, GroupNorm)) else weight_decay
+                key = None
+                if isinstance(mod, (BatchNorm2d, GroupNorm)) and weight_decay_norm is not None:
+                    key = float(weight_decay_norm)
                 if pname == "bias" and weight_decay_bias is not None:
-                    wd = weight_decay_bias
-                wd_of[id(p)] = float(wd)
+                    key = float(weight_decay_bias)
+                key_of[id(p)] = key
+                wd_of[id(p)] = float(weight_decay) if key is None else key
         self.params = [p for p in model.parameters() if p.requires_grad]
         assert len(self.params) == len(wd_of)
-        # the reference merges parameters with equal hyper-parameters into one torch param group, groups in order of first
+        # the reference merges parameters with equal hyper-parameter dicts into one torch param group, groups in order of first
         # appearance (reduce_param_groups, solver/build.py:255-279); torch numbers the parameters group after group.  That
         # numbering is the key of a reference checkpoint's optimizer state (state_dict / load_state_dict below).
-        self.group_wd = list(dict.fromkeys(wd_of[id(p)] for p in self.params))
-        self.group_members = [[i for i, p in enumerate(self.params) if wd_of[id(p)] == g] for g in self.group_wd]
+        group_keys = list(dict.fromkeys(key_of[id(p)] for p in self.params))
+        self.group_wd = [float(weight_decay) if k is None else k for k in group_keys]
+        self.group_members = [[i for i, p in enumerate(self.params) if key_of[id(p)] == k] for k in group_keys]
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
         self.total = total
@@ -94,6 +102,9 @@ class FlatSGD:
         return (param.data_ptr() - self.flat_param.data_ptr()) // 4
 
     def zero_grad(self):
+        from ..layers.functional import reset_deferred_gradients
+
+        reset_deferred_gradients()   # a backward pass that raised midway must not leave deferred gradients behind
         if self.flat_grad.is_cuda:
             self._step_stream = torch.cuda.current_stream(self.flat_grad.device)  # the stream the training step is issued on
         self.flat_grad.zero_()
@@ -225,13 +236,19 @@ class FlatSGD:
         lrs = {float(g["lr"]) for g in groups}
         assert len(lrs) == 1, "per-group learning rates (BIAS_LR_FACTOR != 1) are not implemented"
         self.lr = lrs.pop()
-        for g, wd, members in zip(groups, self.group_wd, self.group_members):
+        if all("initial_lr" in g for g in groups):  # written once a torch LR scheduler has touched the optimizer
+            base = {float(g["initial_lr"]) for g in groups}
+            assert len(base) == 1, base
+            self.base_lr = base.pop()
+        for gi, (g, members) in enumerate(zip(groups, self.group_members)):
             assert not g.get("nesterov", False) and not g.get("dampening", 0) and not g.get("maximize", False), g
             self.momentum = float(g.get("momentum", self.momentum))
-            if float(g.get("weight_decay", wd)) != wd:
-                # torch takes a group's hyper-parameters from the file, not from the constructor (Optimizer.load_state_dict)
-                self.group_wd[self.group_wd.index(wd)] = float(g["weight_decay"])
-                self.wd[torch.tensor(members, device=self.wd.device)] = float(g["weight_decay"])
+            wd = float(g.get("weight_decay", self.group_wd[gi]))
+            if wd != self.group_wd[gi]:
+                # torch takes a group's hyper-parameters from the file, not from the constructor (Optimizer.load_state_dict);
+                # groups are addressed by position: two groups may hold equal values
+                self.group_wd[gi] = wd
+                self.wd[torch.tensor(members, device=self.wd.device)] = wd
             for key, i in zip(g["params"], members):
                 off, p = self.param_offset[i], self.params[i]
                 buf = (sd["state"].get(key) or {}).get("momentum_buffer")

@@ -49,10 +49,9 @@ class Boxes:
             raise AssertionError("cannot clip boxes that contain Inf or NaN")
         h, w = box_size
         # Python-scalar bounds per coordinate column: no host -> device upload (a pageable copy would block the host)
-        out = self.tensor.clamp(min=0)
-        xy = out.view(-1, 2, 2)
-        xy[..., 0].clamp_(max=w)
-        xy[..., 1].clamp_(max=h)
+        out = self.tensor.clamp(min=0)   # a fresh tensor: the strided column slices below are views of it
+        out[:, 0::2].clamp_(max=w)
+        out[:, 1::2].clamp_(max=h)
         self.tensor = out
 
     def nonempty(self, threshold=0.0):
@@ -62,9 +61,9 @@ class Boxes:
         return self._corners().mean(dim=1)
 
     def scale(self, scale_x, scale_y):
-        xy = self.tensor.view(-1, 2, 2)
-        xy[..., 0].mul_(scale_x)
-        xy[..., 1].mul_(scale_y)
+        # strided column slices (structures/boxes.py:212-217 indexes the same way): works on non-contiguous box tensors too
+        self.tensor[:, 0::2].mul_(scale_x)
+        self.tensor[:, 1::2].mul_(scale_y)
 
     def __getitem__(self, item):
         picked = self.tensor[item]
