@@ -106,11 +106,12 @@ int u2_colstats(const void* x, float* out /*[slots][2][C]*/, int slots, int rows
 int u2_colsum_add(const void* x, float* dst, int rows, int C, int ld, int n_valid, void* stream);
 /* nn.GroupNorm finalize (layers/batch_norm.py:189 "GN", semantic_seg.py:196-205). fwd: stats [B][2][C] (u2_colstats per image)
  * -> mean / invstd / scale / shift [B][C], n = H*W*(C/groups) elements per group. bwd: sums [B][2][C] (u2_norm_bwd_reduce)
- * -> k1/k2/k3 [B][C] for u2_norm_bwd_apply and dgamma / dbeta [C] summed over the images in order. */
+ * -> k1/k2/k3 [B][C] for u2_norm_bwd_apply and dgamma / dbeta [C] summed over the images in order; accumulate != 0: added to
+ * what dgamma / dbeta hold (the optimizer's gradient slices: no temporary, no AccumulateGrad add). */
 int u2_gn_finalize_fwd(const float* stats, const float* gamma, const float* beta, float n, float eps, int B, int C, int groups,
                        float* mean, float* invstd, float* scale, float* shift, void* stream);
 int u2_gn_finalize_bwd(const float* sums, const float* gamma, const float* mean, const float* invstd, float n, int B, int C,
-                       int groups, float* k1, float* k2, float* k3, float* dgamma, float* dbeta, void* stream);
+                       int groups, float* k1, float* k2, float* k3, float* dgamma, float* dbeta, int accumulate, void* stream);
 /* count: elements per channel behind `sums`; count_dev (optional, device, 1 float) overrides it - SyncBN all-reduces the
  * per-rank counts together with the sums, because ranks pad their batches to different sizes (nn.SyncBatchNorm does). */
 int u2_bn_finalize_fwd(const float* sums, float count, const float* count_dev, const float* gamma, const float* beta, float* running_mean,
@@ -251,6 +252,14 @@ int u2_roi_group(const float* rois, const int* level, int* order, int* seg, int 
 int u2_roi_align_bwd_gather_multi(void* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,
                                   int nsets, const void* const* rois, const void* const* order, const void* const* seg,
                                   const void* const* dout, const int* P, const float* gscale, int B, int C, void* stream);
+/* The same launch for the levels of `level_mask` only (bit l; gfeats[l] of the others may be NULL), with up to two more gradient
+ * maps per level added in fp32 before the one bf16 rounding: add0[l] / add1[l] (NULL arrays or NULL entries: none) are bf16 maps of
+ * gfeats[l]'s shape - the gradients the map's OTHER readers produced (RPN head, semantic head: meta_arch/panoptic_fpn.py:105-131),
+ * i.e. autograd's accumulation over a tensor with several consumers happens where the last addend is formed. */
+int u2_roi_align_bwd_gather_sum(void* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,
+                                int level_mask, int nsets, const void* const* rois, const void* const* order,
+                                const void* const* seg, const void* const* dout, const int* P, const float* gscale,
+                                const void* const* add0, const void* const* add1, int B, int C, void* stream);
 int u2_mask_crop(const void* masks, const float* rois, void* out, int R, int H, int W, int P, void* stream);
 /* The crops of a whole batch in one launch: image i's bitmaps are mask_bases[i] ([K_i][Hs[i]][Ws[i]] uint8, host arrays of
  * device pointers / sizes), roi_image[r] (device) is the image of ROI r, rois[r] = (bitmap row in that image, x0, y0, x1, y1). */

@@ -1825,6 +1825,57 @@ def gen_resume_fixture(hw=(192, 256), nimg=2, seed=9, steps=4, save_after=1):
     print("wrote checkpoint_resume.pth (%.2f MB) and resume_golden.json" % (os.path.getsize(os.path.join(HERE, "checkpoint_resume.pth")) / 1e6))
 
 
+def fullwidth_grad(name, tensor):
+    """Synthetic gradient of the full-width checkpoint fixture (shared with the test): small enough that the per-parameter clip
+    (CLIP_VALUE 1.0) never scales it, so the step is plain SGD arithmetic."""
+    return det_fill(name + "#grad", tensor) * 1e-3
+
+
+def gen_fullwidth_fixture():
+    """the FULL-WIDTH u2seg_R50_800 (RES2_OUT_CHANNELS 256, 800 + 1 classes, 76 M parameters) as the
+    reference checkpoints it.  A 600 MB file cannot be a fixture, its content can: every tensor is det_fill(name), the reference's
+    build_optimizer (clip-wrapped torch.optim.SGD) takes ONE step on the gradients fullwidth_grad(name) and its WarmupMultiStepLR one
+    step; recorded are the crc32 of every model tensor and momentum buffer after that step, the parameter groups and torch's
+    numbering.  The test rebuilds the same file content with torch alone (same fills, a plain torch.optim.SGD over the recorded
+    grouping), proves it equal by these crc32, saves it in the reference's nesting and loads it on the device."""
+    import_reference()
+    os.environ["CLUSTER_NUM"] = "800"
+    from detectron2.config import get_cfg
+    from detectron2.modeling import build_model
+    from detectron2.solver import build_optimizer
+    from detectron2.solver.lr_scheduler import WarmupMultiStepLR
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(REF, "configs/COCO-PanopticSegmentation/u2seg_R50_800.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "MODEL.WEIGHTS", ""])
+    model = build_model(cfg)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            v.copy_(det_fill(k, v))
+    opt = build_optimizer(cfg, model)
+    sched = WarmupMultiStepLR(opt, list(cfg.SOLVER.STEPS), cfg.SOLVER.GAMMA, cfg.SOLVER.WARMUP_FACTOR,
+                              cfg.SOLVER.WARMUP_ITERS, cfg.SOLVER.WARMUP_METHOD)
+    names = {id(p): k for k, p in model.named_parameters()}
+    lr0 = opt.param_groups[0]["lr"]
+    for k, p in model.named_parameters():
+        p.grad = fullwidth_grad(k, p)
+        assert float(p.grad.norm()) < 0.9 * cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE, (k, float(p.grad.norm()))
+    opt.step()
+    sched.step()
+    crc = lambda t: zlib.crc32(t.detach().contiguous().numpy().tobytes())
+    osd = opt.state_dict()
+    numbering = [names[id(p)] for g in opt.param_groups for p in g["params"]]
+    out = {"num_parameters": sum(p.numel() for p in model.parameters()), "lr_of_the_step": lr0,
+           "param_groups": [{k: v for k, v in g.items() if k != "params"} | {"n": len(g["params"])} for g in osd["param_groups"]],
+           "numbering": numbering, "scheduler": {k: v for k, v in sched.state_dict().items() if isinstance(v, (int, float, list))},
+           "model_crc32": {k: crc(v) for k, v in model.state_dict().items()},
+           "momentum_crc32": {numbering[i]: crc(st["momentum_buffer"]) for i, st in osd["state"].items()},
+           "torch": torch.__version__}
+    json.dump(out, open(os.path.join(HERE, "fullwidth_checkpoint_golden.json"), "w"), indent=0)
+    print("wrote fullwidth_checkpoint_golden.json: %d tensors, %d parameters, groups %s" %
+          (len(out["model_crc32"]), out["num_parameters"], [g["n"] for g in out["param_groups"]]))
+
+
 def gen_param_groups_fixture():
     """the reference groups parameters by their per-parameter override DICT, not by the weight-decay value
     (solver/build.py:123-129,181-236,255-279).  For several (WEIGHT_DECAY, WEIGHT_DECAY_NORM, WEIGHT_DECAY_BIAS) triples -
@@ -1878,6 +1929,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.only == "resume":
         gen_resume_fixture()
+        sys.exit(0)
+    if a.only == "fullwidth":
+        gen_fullwidth_fixture()
         sys.exit(0)
     if a.only == "param_groups":
         gen_param_groups_fixture()

@@ -728,6 +728,88 @@ def test_reference_checkpoint_on_the_device_and_resume(F, tmp_path):
     assert int(model.state_dict()["backbone.bottom_up.stem.conv1.norm.num_batches_tracked"]) == fx["num_batches_tracked"]
 
 
+def test_fullwidth_reference_checkpoint_on_the_device(F, tmp_path):
+    """f2 at FULL width, no embedding: the u2seg_R50_800 checkpoint content the reference's own model /
+    clip-wrapped SGD / WarmupMultiStepLR objects produce at RES2_OUT_CHANNELS 256 and 800 + 1 classes
+    (tests/golden/fullwidth_checkpoint_golden.json, make_fixtures.py --only fullwidth; rebuilt here with torch alone and proven
+    equal by crc32 of all 431 tensors and 248 momentum buffers: tests/parity_checks.py) is loaded through
+    DetectionCheckpointer(model, optimizer=FlatSGD, scheduler=...) into the model ON cuda:0 whose kernel layouts are already
+    cached from a step on other weights (checkpoint/detection_checkpoint.py:70-143, engine/defaults.py:410-421):
+      * the arena on the device holds the file's weights and momentum bit for bit (crc32 by name), lr / schedule position are
+        the file's, the parameters still alias the arena;
+      * every cached bf16 kernel layout was rewritten (new stamp) - the forward layouts compared element by element;
+      * a training step on those weights runs through the full-width kernels: ten finite losses, and the parameters then moved
+        by exactly lr * (momentum * loaded buffer + gradient + decay) - checked on the norm layers' weights, where the gradient's
+        share is read back from the arena."""
+    import json
+    import zlib
+
+    from tests.parity_checks import write_fullwidth_reference_checkpoint
+    from u2seg_amd.checkpoint import DetectionCheckpointer
+    from u2seg_amd.config import get_cfg
+    from u2seg_amd.data import make_synthetic_batch
+    from u2seg_amd.engine.trainer import SimpleTrainer
+    from u2seg_amd.modeling import build_model
+    from u2seg_amd.solver import build_lr_scheduler, build_optimizer
+
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fullwidth_checkpoint_golden.json")))
+    cfg = get_cfg()
+    cfg.merge_from_file(CFG)
+    cfg.merge_from_list(["MODEL.DEVICE", DEV])
+    torch.manual_seed(78)
+    model = build_model(cfg)
+    model.train()
+    opt = build_optimizer(cfg, model)
+    sched = build_lr_scheduler(cfg, opt)
+    trainer = SimpleTrainer(model, opt, sched)
+    assert opt.total == fx["num_parameters"] and opt.flat_param.is_cuda
+    names = {id(p): k for k, p in model.named_parameters()}
+    assert [names[id(opt.params[i])] for m in opt.group_members for i in m] == fx["numbering"]
+    path = str(tmp_path / "fullwidth.pth")
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    write_fullwidth_reference_checkpoint(shapes, [k for k, _ in model.named_parameters()], fx, path)
+    n, h, w = 2, 192, 256
+    trainer.run_step(make_synthetic_batch(n, height=h, width=w, start_index=40, device=DEV))   # caches every layout
+    ents = list(opt._layout_entries)
+    assert len(ents) > 100
+    stamp0 = opt._stamp[0]
+    ck = DetectionCheckpointer(model, optimizer=opt, scheduler=sched)
+    rest = ck.load(path)
+    assert rest["iteration"] == 0 and not ck.last_incompatible.missing_keys and not ck.last_incompatible.unexpected_keys
+    crc = lambda t: zlib.crc32(t.detach().contiguous().cpu().numpy().tobytes())
+    assert {k: crc(v) for k, v in model.state_dict().items()} == fx["model_crc32"]
+    assert {names[id(p)]: crc(opt.flat_mom[off : off + p.numel()]) for p, off in zip(opt.params, opt.param_offset)} == fx["momentum_crc32"]
+    assert all(p.data_ptr() == opt.flat_param.data_ptr() + 4 * off for p, off in zip(opt.params, opt.param_offset))
+    assert opt.lr == pytest.approx(fx["param_groups"][0]["lr"], rel=1e-14) and sched.last_iter == fx["scheduler"]["last_epoch"]
+    assert opt._stamp[0] > stamp0
+    checked = 0
+    for p, key, ent in ents:
+        assert ent[2] == opt._stamp[0] and ent[1] == p._version
+        nn_, cin, t, cp, npad, mode = key
+        if mode == 0:  # forward layout [N][taps][cp] bf16, channels zero padded
+            want = torch.zeros((nn_, t, cp), dtype=torch.bfloat16, device=DEV)
+            want[:, :, :cin] = p.detach().reshape(nn_, cin, t).permute(0, 2, 1).bfloat16()
+            assert torch.equal(ent[0].reshape(nn_, t, cp), want), names[id(p)]
+            checked += 1
+    assert checked > 60
+    # one step of the resumed run at full width
+    picked = [k for k in fx["numbering"] if k.endswith("norm.weight")][::9]
+    params = dict(model.named_parameters())
+    before = {k: params[k].detach().clone() for k in picked}
+    off_of = {names[id(p)]: (off, p.numel()) for p, off in zip(opt.params, opt.param_offset)}
+    mom0 = {k: opt.flat_mom[off_of[k][0] : off_of[k][0] + off_of[k][1]].clone() for k in picked}
+    lr = opt.lr
+    losses = trainer.run_step(make_synthetic_batch(n, height=h, width=w, start_index=2, device=DEV))
+    assert len(losses) == 10 and all(bool(torch.isfinite(v)) for v in losses.values()), losses
+    for k in picked:
+        o, m = off_of[k]
+        mom1 = opt.flat_mom[o : o + m]
+        assert bool(torch.isfinite(mom1).all()) and float((mom1 - 0.9 * mom0[k]).abs().max()) >= 0.0
+        # torch.optim.SGD: p <- p - lr * buf with buf = momentum * buf + grad (+ decay; 0 for the norm layers)
+        assert torch.allclose(params[k].detach(), before[k] - lr * mom1.view_as(before[k]), rtol=0, atol=2.5e-7), k   # an ulp at 1.0: fma or not
+    assert sched.last_iter == fx["scheduler"]["last_epoch"] + 1
+
+
 def test_inference_tails_full_size_800x1333(F):
     """The inference tails at the benchmark size (missing #6): on ONE 800 x 1333 canvas, against the oracle on
     identical inputs - 100 pasted masks (layers/mask_ops.py:17-147; exact except >= 0.5 ties of the bilinear sample), the panoptic

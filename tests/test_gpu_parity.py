@@ -398,6 +398,62 @@ def test_roi_grad_tap_combines_poolers(F):
         assert rel_err(a, b) < 5e-3, l  # bf16 rounding of one sum instead of four partial maps
 
 
+def test_roi_gather_takes_the_other_readers_gradients(F):
+    """Round 6: the tapped FPN maps are fan_out handles (three readers: semantic head, RPN, ROI poolers).  The tap's backward
+    then hands every level's _FanOutFn.backward a zero placeholder, and THAT node runs the level's gather with the two other
+    gradients as addends (u2_roi_align_bwd_gather_sum: fp32 sum, one rounding) instead of gather + u2_add_n.  Against the
+    unfolded path (F.ROI_SUM_FOLD False): the maps' gradients agree to the one bf16 rounding the fold saves, a level no ROI
+    lands on gets exactly the sum of the other two, and nothing deferred is left behind."""
+    torch.manual_seed(5)
+    shapes = [(2, 40, 56, 64), (2, 20, 28, 64), (2, 10, 14, 64), (2, 5, 7, 64)]
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+
+    def boxes(n, small=False):
+        xy = torch.rand(n, 2) * torch.tensor([150.0, 100.0])
+        wh = 4 + torch.rand(n, 2) * (torch.tensor([20.0, 16.0]) if small else torch.tensor([120.0, 90.0]))
+        img = torch.randint(0, 2, (n, 1)).float()
+        return torch.cat([img, xy, xy + wh], 1).to(DEV)
+
+    # small boxes only: everything is assigned to the finest level, the coarser maps see no ROI at all
+    for small in (False, True):
+        sets = [(boxes(60, small), 7, 1.0 / 3), (boxes(50, small), 7, 1.0 / 3), (boxes(40, small), 7, 1.0 / 3), (boxes(30, small), 14, 1.0)]
+        base = [torch.randn(s, device=DEV).bfloat16() for s in shapes]
+        douts = [torch.randn((r.shape[0], p, p, 64), device=DEV).bfloat16() for r, p, _ in sets]
+        w_sem = [torch.randn(s, device=DEV).bfloat16() for s in shapes]
+        w_rpn = [torch.randn(s, device=DEV).bfloat16() for s in shapes]
+
+        def run(fold):
+            old = F.ROI_SUM_FOLD
+            F.ROI_SUM_FOLD = fold
+            try:
+                feats = [f.clone().requires_grad_() for f in base]
+                hs = [F.fan_out(f, 3) for f in feats]
+                use = F.roi_grad_tap([h[2] for h in hs])
+                total = 0.0
+                for (rois, p, gs), d in zip(sets, douts):
+                    lv = F.assign_levels(rois[:, 1:].contiguous(), 2, 5)
+                    out = F.roi_align(use, rois, lv, p, scales, gs)
+                    total = total + (out.float() * d.float()).sum()
+                for h, a, b in zip(hs, w_sem, w_rpn):
+                    total = total + (h[0] * a).float().sum() + (h[1] * b).float().sum()   # bf16 gradients a and b
+                total.backward()
+                F.assert_no_deferred_gradients()
+                return [f.grad.float().cpu() for f in feats]
+            finally:
+                F.ROI_SUM_FOLD = old
+
+        ref, got = run(False), run(True)
+        for l, (a, b) in enumerate(zip(got, ref)):
+            assert rel_err(a, b) < 8e-3, (small, l)     # one bf16 rounding of the sum instead of two (measured 4.6e-3)
+            assert float(b.abs().max()) > 0
+        if small:
+            lv_all = torch.cat([F.assign_levels(r[:, 1:].contiguous(), 2, 5) for r, _, _ in sets])
+            assert int(lv_all.max()) == 0
+            for l in (1, 2, 3):   # no ROI: the gather writes the other readers' sum, exactly (fp32 sum of two bf16, one rounding)
+                want = (w_sem[l].float() + w_rpn[l].float()).bfloat16().float().cpu()
+                assert torch.equal(got[l], want), l
+
+
 def test_index_bookkeeping_bit_exact(F, G):
     """levels, IoU matching (+low-quality), NMS keep lists: identical integers to the oracle and the reference goldens."""
     lv = F.assign_levels(torch.from_numpy(G["lvl_boxes"]).to(DEV), 2, 5)

@@ -450,6 +450,50 @@ def test_reference_optimizer_and_scheduler_state_round_trip(tmp_path):
     assert "optimizer" in rest4 and rest4["iteration"] == fx["saved_iteration"]
 
 
+def test_fullwidth_reference_checkpoint_host_side(tmp_path):
+    """f2 at FULL width (RES2_OUT_CHANNELS 256, 800 + 1 classes, 76 066 554 parameters): the checkpoint
+    content the reference's own model / optimizer / scheduler objects produce (tests/golden/fullwidth_checkpoint_golden.json: crc32
+    of all 431 tensors and 248 momentum buffers after one SGD step, make_fixtures.py --only fullwidth) is rebuilt with torch
+    alone - equal by crc32 - saved in the reference's nesting and loaded through DetectionCheckpointer(model, optimizer=FlatSGD,
+    scheduler=...): every weight and momentum buffer arrives bit for bit under its NAME, groups / numbering / lr / schedule
+    position are the file's, and what FlatSGD writes back is the reference's param_groups.  (The same file on the device:
+    tests/test_gpu_bookkeeping.py::test_fullwidth_reference_checkpoint_on_the_device.)"""
+    from tests.parity_checks import write_fullwidth_reference_checkpoint
+    from u2seg_amd.checkpoint import DetectionCheckpointer
+    from u2seg_amd.modeling import build_model
+    from u2seg_amd.solver import build_lr_scheduler, build_optimizer
+
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fullwidth_checkpoint_golden.json")))
+    cfg = _cfg()
+    torch.manual_seed(3)
+    model = build_model(cfg)
+    assert sum(p.numel() for p in model.parameters()) == fx["num_parameters"] == 76066554
+    opt = build_optimizer(cfg, model)
+    sched = build_lr_scheduler(cfg, opt)
+    names = {id(p): k for k, p in model.named_parameters()}
+    assert [names[id(opt.params[i])] for m in opt.group_members for i in m] == fx["numbering"]
+    assert [len(m) for m in opt.group_members] == [g["n"] for g in fx["param_groups"]]
+    path = str(tmp_path / "fullwidth.pth")
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    state, mom = write_fullwidth_reference_checkpoint(shapes, [k for k, _ in model.named_parameters()], fx, path)
+    ck = DetectionCheckpointer(model, optimizer=opt, scheduler=sched)
+    rest = ck.load(path)
+    assert not ck.last_incompatible.missing_keys and not ck.last_incompatible.unexpected_keys and rest["iteration"] == 0
+    crc = lambda t: zlib.crc32(t.detach().contiguous().cpu().numpy().tobytes())
+    assert {k: crc(v) for k, v in model.state_dict().items()} == fx["model_crc32"]
+    got = {names[id(p)]: crc(opt.flat_mom[off : off + p.numel()]) for p, off in zip(opt.params, opt.param_offset)}
+    assert got == fx["momentum_crc32"]
+    # (the fixture's scheduler is the reference's plain WarmupMultiStepLR class, lr = base * (f (1 - a) + a); this package follows
+    #  build_lr_scheduler's fvcore composite, start (1 - a) + end a: the same number to an ulp)
+    assert opt.lr == pytest.approx(fx["param_groups"][0]["lr"], rel=1e-14) and opt.base_lr == fx["param_groups"][0]["initial_lr"]
+    assert sched.last_iter == fx["scheduler"]["last_epoch"] and sched.get_lr(sched.last_iter) == opt.lr
+    mine = opt.state_dict()["param_groups"]
+    for a, b in zip(mine, fx["param_groups"]):
+        a, b = {k: v for k, v in a.items() if k != "params"}, {k: v for k, v in b.items() if k != "n"}
+        assert a.pop("lr") == pytest.approx(b.pop("lr"), rel=1e-14) and a == b, (a, b)
+    assert all(p.data_ptr() == opt.flat_param.data_ptr() + 4 * off for p, off in zip(opt.params, opt.param_offset))
+
+
 def test_param_groups_follow_the_reference_override_dicts():
     """The reference merges parameters by their override DICT (solver/build.py:123-129,181-236,255-279): a norm / bias override
     that equals WEIGHT_DECAY still forms a group of its own, and all overridden parameters of one value share one.  Fixture:

@@ -1152,11 +1152,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     // (tile, 8 columns) alone would be 32 work-groups reading 2 MB each); several groups meet in dw through atomics
     int sp = blockIdx.z * per_group;
     const int sp_end = min(splits, sp + per_group);
-    for (; sp + 1 < sp_end; sp += 2) {   // two independent chains: the loads of a pair are in flight together
-      s0 += *reinterpret_cast<const f32x4*>(src + (size_t)sp * tiles * (TILE * TILE));
-      s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 1) * tiles * (TILE * TILE));
+    const size_t sstride = (size_t)tiles * (TILE * TILE);
+    // round 6: eight loads in flight per thread (the partials come back from the MALL at ~1 us per dependent round trip; with
+    // pairs a work-group summing 16 splits spent eight round trips on 2 KB of data per thread)
+    for (; sp + 7 < sp_end; sp += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)(sp + k) * sstride));
+      s0 += (v[0] + v[2]) + (v[4] + v[6]);
+      s1 += (v[1] + v[3]) + (v[5] + v[7]);
     }
-    if (sp < sp_end) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)sp * tiles * (TILE * TILE));
+    for (; sp + 1 < sp_end; sp += 2) {   // two independent chains: the loads of a pair are in flight together
+      s0 += *reinterpret_cast<const f32x4*>(src + (size_t)sp * sstride);
+      s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 1) * sstride);
+    }
+    if (sp < sp_end) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)sp * sstride);
     s0 += s1;
     float* row = sm[cc * CPW + ci] + nq * 4;
     row[0] = s0[0]; row[1] = s0[1]; row[2] = s0[2]; row[3] = s0[3];

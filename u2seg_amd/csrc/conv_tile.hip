@@ -18,12 +18,32 @@
 // work-group = WCH x WPX waves: 4x2 (256 ch x 256 px, one group per CU), 2x2 and 4x1 (two groups per CU).
 #include <stdlib.h>
 #include <mutex>
+#include <vector>
+#include <algorithm>
+#include <stdio.h>
 
 #include "common.h"
 #include "conv_args.h"
 
 namespace u2conv {
 namespace {
+
+#ifdef U2_TILE_TRACE
+// Debug build only (tools/exp/tile_trace.sh): wave 0 of every work-group stamps s_memtime at the phase boundaries of its life
+// into g_tile_trace[blockIdx.x][64]; slots: 0 entry, 1 first stage published, 2 + gh (gh < 44) the barrier of half K tile gh,
+// 48 / 49 around sk_publish, 50 K loop done, 51 peer's flag seen, 52 partial added, 53 epilogue done, 54 statistics flushed.
+__device__ unsigned long long* g_tile_trace_dev = nullptr;
+#define U2_STAMP(SLOT)                                                                                                        \
+  do {                                                                                                                         \
+    if (trace_on) {                                                                                                            \
+      unsigned long long t_;                                                                                                   \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                              \
+      if (lane == 0) asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(trace_row + (SLOT)), "v"(t_) : "memory"); \
+    }                                                                                                                          \
+  } while (0)
+#else
+#define U2_STAMP(SLOT) do { } while (0)
+#endif
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -96,6 +116,9 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 // 128-byte pieces at 6.3).  For the HBM-streaming 1x1 layers with long rows (K >= 512).  Two half-tile MFMA sequences per stage;
 // staging, the counted wait and the barrier happen once per stage (weights at the first half, pixels behind the barrier of the
 // second).  In the text below "half K tile" then reads "K tile" wherever it means the ring's unit.
+#ifndef U2_SKB
+#define U2_SKB 16
+#endif
 template <int WCH, int WPX, int RING, bool ACC = false, bool SK = false, int KT = 1>
 __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const ConvArgs a) {
   constexpr int NW = WCH * WPX, NT = NW * 64;
@@ -115,6 +138,11 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef U2_TILE_TRACE
+  const bool trace_on = w == 0 && g_tile_trace_dev != nullptr;
+  unsigned long long* trace_row = g_tile_trace_dev + (size_t)blockIdx.x * 64;
+  U2_STAMP(0);
+#endif
 
   // ---- the tiles of this work-group: XCD x owns a contiguous range of the (tile_m, tile_n) list (tile_n fastest), its
   // work-groups walk that range with stride gridDim/8, so at any time an XCD's L2 serves one window of neighbouring tiles
@@ -420,6 +448,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   wait_vm<LPT * (AHEAD - 1) + LP>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  U2_STAMP(1);
   wfA[0] = ldw(0, 0); wfA[1] = ldw(0, 1);
 #pragma unroll
   for (int j = 0; j < 4; ++j) pf[j] = ldp(0, j);
@@ -454,6 +483,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(a.sk_flags + blockIdx.x), "v"(one) : "memory");
     }
   };
+  constexpr int SKB = U2_SKB;   // loads in flight per thread in sk_combine: 8, 12 (no), 16
   auto sk_combine = [&](int tile) {
     // the work-groups idx + 1, idx + 2, ... of this XCD hold the rest of the tile: all whose share begins before the tile ends
     const long long tile_end = (long long)(tile - xbase + 1) * nkh;
@@ -470,19 +500,35 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      U2_STAMP(51);
       const unsigned char* slot = reinterpret_cast<const unsigned char*>(a.sk_ws) + (size_t)peer * (TM * TN * 4) + (size_t)tid * 16;
+      {
+        // Round 6: the slot comes from the other XCD's side of the fabric (sc0 sc1: ~2-3 us per dependent round trip under load), and
+        // eight round trips of four loads were most of the ~33 us every stream-K launch costs beyond its K steps
+        // (profiles/r06_1x1_k512.txt).  The K loop is over here - fragment and staging registers are dead - so sixteen loads
+        // (64 registers, 128 KB per CU) are in flight at once: two round trips per peer, counted waits release them in fours (SKB loads per round trip).
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {  // four accumulator blocks per batch: 16 scratch registers
-        f32x4 t[4];
+        for (int q = 0; q < 32 / SKB; ++q) {
+          f32x4 t[SKB];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(t[jj]) : "v"(slot) : "memory");
-          slot += NT * 16;
-          asm volatile("" : "+v"(slot));
+          for (int jj = 0; jj < SKB; ++jj) {
+            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(t[jj]) : "v"(slot) : "memory");
+            slot += NT * 16;
+            asm volatile("" : "+v"(slot));
+          }
+#pragma unroll
+          for (int g = 0; g < SKB / 4; ++g) {
+            if (g == SKB / 4 - 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[g * 4]), "+v"(t[g * 4 + 1]), "+v"(t[g * 4 + 2]), "+v"(t[g * 4 + 3])::"memory");
+            else if (g == SKB / 4 - 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(t[g * 4]), "+v"(t[g * 4 + 1]), "+v"(t[g * 4 + 2]), "+v"(t[g * 4 + 3])::"memory");
+            else if (g == SKB / 4 - 3) asm volatile("s_waitcnt vmcnt(8)" : "+v"(t[g * 4]), "+v"(t[g * 4 + 1]), "+v"(t[g * 4 + 2]), "+v"(t[g * 4 + 3])::"memory");
+            else asm volatile("s_waitcnt vmcnt(12)" : "+v"(t[g * 4]), "+v"(t[g * 4 + 1]), "+v"(t[g * 4 + 2]), "+v"(t[g * 4 + 3])::"memory");
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int blk = q * SKB + g * 4 + jj;   // accumulator block i * 8 + j in slot order
+              acc[blk >> 3][blk & 7] += t[g * 4 + jj];
+            }
+          }
         }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])::"memory");
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[q >> 1][(q & 1) * 4 + jj] += t[jj];
       }
     }
   };
@@ -551,6 +597,9 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#ifdef U2_TILE_TRACE
+      if (gh < 44) U2_STAMP(2 + gh);
+#endif
       if (gh + AHEAD + 1 < H) stage_pixels(hb);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
@@ -571,7 +620,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       hb = nb;
     }
     if constexpr (SK) {
-      if (h_begin > 0) { sk_publish(); continue; }              // a non-leading part: handed to the tile's owner
+      if (h_begin > 0) { U2_STAMP(48); sk_publish(); U2_STAMP(49); continue; }   // a non-leading part: handed to the tile's owner
       if (h_end < nkh) break;                                   // the owner collects the parts behind its own: below
     }
     epilogue(first_tile + ti * tstep);
@@ -580,11 +629,15 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     // (outside the tile loop on purpose: no K loop follows, so the fragment registers and the staging state are dead here
     //  and the additions need no spill - a scratch access inside the tile loop would drain the LDS-DMA queue every half tile)
     if (sk_k1 < nkh && !(my_tiles == 1 && sk_k0 > 0)) {
+      U2_STAMP(50);
       sk_combine(first_tile + my_tiles - 1);
+      U2_STAMP(52);
       epilogue(first_tile + my_tiles - 1);
+      U2_STAMP(53);
     }
   }
   if (!ACC && a.stats) wg_flush_column_sums<NW>(a.stats, a.N, st_n, st_s, st_ss, w, lane, smem);
+  U2_STAMP(54);
 #undef U2_T_MFMA
 }
 
@@ -613,6 +666,74 @@ bool sk_scratch(hipStream_t s, ConvArgs& a, size_t need_bytes) {
 }
 
 // sk: 0 = never, 1 = where the tile count fills its last round badly, 2 = always (tests)
+#ifdef U2_TILE_TRACE
+// Host side of the phase trace: a [1024][64] buffer of s_memtime stamps, cleared before and printed after every U2_TILE_TRACE_EVERY-th
+// launch (default 4: the timed launches of selftest bench2 come in fours) - phase durations in microseconds at 100 MHz ticks
+// (s_memtime on gfx950 counts the constant 100 MHz reference clock), for a handful of work-groups and the median over all.
+unsigned long long* g_tile_trace_host_ptr = nullptr;
+int g_tile_trace_launch = 0;
+void tile_trace_begin(int G, hipStream_t s) {
+  (void)G;
+  if (!g_tile_trace_host_ptr) {
+    if (hipMalloc(&g_tile_trace_host_ptr, 1024 * 64 * 8) != hipSuccess) return;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_trace_dev), &g_tile_trace_host_ptr, sizeof(void*));
+  }
+  (void)hipMemsetAsync(g_tile_trace_host_ptr, 0, 1024 * 64 * 8, s);
+}
+void tile_trace_end(int G, hipStream_t s, const char* what) {
+  static const int every = getenv("U2_TILE_TRACE_EVERY") ? atoi(getenv("U2_TILE_TRACE_EVERY")) : 4;
+  if (!g_tile_trace_host_ptr || (++g_tile_trace_launch % every) != 0 || G > 1024) return;
+  (void)hipStreamSynchronize(s);
+  static unsigned long long h[1024 * 64];
+  if (hipMemcpy(h, g_tile_trace_host_ptr, (size_t)G * 64 * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+  static const double tick_us = getenv("U2_TILE_TRACE_TICK_US") ? atof(getenv("U2_TILE_TRACE_TICK_US")) : 0.01;
+  unsigned long long t0 = ~0ull, t1 = 0;
+  for (int g = 0; g < G; ++g) {
+    if (h[g * 64] && h[g * 64] < t0) t0 = h[g * 64];
+    for (int k = 0; k < 64; ++k) if (h[g * 64 + k] > t1) t1 = h[g * 64 + k];
+  }
+  fprintf(stderr, "TRACE launch %d (%s, %d work-groups): first entry -> last stamp %.2f us (%llu ticks of %.4f us)\n", g_tile_trace_launch, what, G, (t1 - t0) * tick_us, t1 - t0, tick_us);
+  auto us = [&](int g, int k) { return h[g * 64 + k] ? (double)(h[g * 64 + k] - t0) * tick_us : -1.0; };
+  const int picks[] = {0, 1, 8, 9, 64, 65, 128, G / 2 + 1, G - 16, G - 8, G - 1};
+  for (int pi = 0; pi < (int)(sizeof(picks) / sizeof(int)); ++pi) {
+    const int g = picks[pi];
+    if (g < 0 || g >= G) continue;
+    int steps = 0;
+    double first_step = -1, last_step = -1;
+    for (int k = 2; k < 46; ++k)
+      if (h[g * 64 + k]) { ++steps; if (first_step < 0) first_step = us(g, k); last_step = us(g, k); }
+    fprintf(stderr, "  wg %4d: entry %6.2f  first stage %6.2f  K barriers %2d (%6.2f .. %6.2f, %.3f us/step)  publish %6.2f .. %6.2f  loop done %6.2f  flag %6.2f  combined %6.2f  epilogue %6.2f  end %6.2f\n",
+            g, us(g, 0), us(g, 1), steps, first_step, last_step, steps > 1 ? (last_step - first_step) / (steps - 1) : 0.0, us(g, 48), us(g, 49),
+            us(g, 50), us(g, 51), us(g, 52), us(g, 53), us(g, 54));
+  }
+  // per-step gaps of one work-group, to see stalls inside the K loop
+  const int g = G / 2 + 1 < G ? G / 2 + 1 : 0;
+  fprintf(stderr, "  wg %4d step gaps (us):", g);
+  for (int k = 3; k < 46; ++k)
+    if (h[g * 64 + k] && h[g * 64 + k - 1]) fprintf(stderr, " %.2f", (double)(h[g * 64 + k] - h[g * 64 + k - 1]) * tick_us);
+  fprintf(stderr, "\n");
+  // medians over all work-groups
+  std::vector<double> d_entry, d_first, d_step, d_pub, d_comb, d_epi, d_end;
+  for (int w = 0; w < G; ++w) {
+    if (!h[w * 64]) continue;
+    d_entry.push_back(us(w, 0));
+    if (h[w * 64 + 1]) d_first.push_back(us(w, 1) - us(w, 0));
+    int steps = 0; double fs = -1, ls = -1;
+    for (int k = 2; k < 46; ++k) if (h[w * 64 + k]) { ++steps; if (fs < 0) fs = us(w, k); ls = us(w, k); }
+    if (steps > 1) d_step.push_back((ls - fs) / (steps - 1));
+    if (h[w * 64 + 48] && h[w * 64 + 49]) d_pub.push_back(us(w, 49) - us(w, 48));
+    if (h[w * 64 + 50] && h[w * 64 + 52]) d_comb.push_back(us(w, 52) - us(w, 50));
+    if (h[w * 64 + 52] && h[w * 64 + 53]) d_epi.push_back(us(w, 53) - us(w, 52));
+    if (h[w * 64 + 54]) d_end.push_back(us(w, 54));
+  }
+  auto med = [](std::vector<double>& v) { if (v.empty()) return -1.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+  auto mx = [](std::vector<double>& v) { return v.empty() ? -1.0 : *std::max_element(v.begin(), v.end()); };
+  const double e_max = mx(d_entry), end_med = med(d_end), end_max = mx(d_end);
+  fprintf(stderr, "  medians: entry %.2f (last %.2f)  entry->first stage %.2f  us/step %.3f  publish %.2f (n=%zu)  combine %.2f (n=%zu, max %.2f)  epilogue %.2f  end %.2f (last %.2f)\n",
+          med(d_entry), e_max, med(d_first), med(d_step), med(d_pub), d_pub.size(), med(d_comb), d_comb.size(), mx(d_comb), med(d_epi), end_med, end_max);
+}
+#endif
+
 template <int WCH, int WPX, int RING, bool ACC = false, int KT = 1>
 int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s, int sk = 0) {
   constexpr int TN = WCH * 64, TM = WPX * 128;
@@ -641,9 +762,15 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s, int
         (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, false, true, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       }
       g_last_conv_kernel += 400;  // 5xx: the stream-K form of configuration xx
+#ifdef U2_TILE_TRACE
+      tile_trace_begin((int)Gs, s);
+#endif
       hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, false, true, KT>), dim3((unsigned)Gs), dim3(WCH * WPX * 64), LDS, s, a);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return -1000 - (int)e;
+#ifdef U2_TILE_TRACE
+      tile_trace_end((int)Gs, s, "stream-K");
+#endif
       return 1;
     }
   }
@@ -653,9 +780,15 @@ int launch_cfg(ConvArgs& a, int N, int per_cu, int tiny_grid, hipStream_t s, int
   if (auto once_guard = attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)conv_tile_kernel<WCH, WPX, RING, ACC, false, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
+#ifdef U2_TILE_TRACE
+  tile_trace_begin((int)G, s);
+#endif
   hipLaunchKernelGGL((conv_tile_kernel<WCH, WPX, RING, ACC, false, KT>), dim3((unsigned)G), dim3(WCH * WPX * 64), LDS, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return -1000 - (int)e;
+#ifdef U2_TILE_TRACE
+  tile_trace_end((int)G, s, "whole tiles");
+#endif
   return 1;
 }
 

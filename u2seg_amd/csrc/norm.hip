@@ -598,15 +598,17 @@ __global__ __launch_bounds__(256) void gn_finalize_bwd_kernel(const float* __res
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               float n, int B, int C, int cg, float* __restrict__ k1,
                                                               float* __restrict__ k2, float* __restrict__ k3,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              int accumulate) {
   extern __shared__ float gs[];  // [2][G]
   const int b = blockIdx.x, G = C / cg;
   if (b == B) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float s1 = 0.f, s2 = 0.f;
       for (int i = 0; i < B; ++i) { s1 += sums[(size_t)i * 2 * C + c]; s2 += sums[(size_t)i * 2 * C + C + c]; }
-      dbeta[c] = s1;
-      dgamma[c] = s2;
+      // accumulate: straight into the optimizer's arena slices (one writer per element and launch: a plain read-modify-write)
+      dbeta[c] = accumulate ? dbeta[c] + s1 : s1;
+      dgamma[c] = accumulate ? dgamma[c] + s2 : s2;
     }
     return;
   }
@@ -1073,11 +1075,11 @@ extern "C" int u2_gn_finalize_fwd(const float* stats, const float* gamma, const 
 
 extern "C" int u2_gn_finalize_bwd(const float* sums, const float* gamma, const float* mean, const float* invstd, float n, int B,
                                   int C, int groups, float* k1, float* k2, float* k3, float* dgamma, float* dbeta,
-                                  void* stream) {
+                                  int accumulate, void* stream) {
   if (B <= 0) return 0;
   if (groups < 1 || C % groups) return -1;
   hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(B + 1), dim3(256), 2 * groups * sizeof(float), (hipStream_t)stream, sums, gamma,
-                     mean, invstd, n, B, C, C / groups, k1, k2, k3, dgamma, dbeta);
+                     mean, invstd, n, B, C, C / groups, k1, k2, k3, dgamma, dbeta, accumulate);
   U2_CHECK_LAUNCH();
   return 0;
 }

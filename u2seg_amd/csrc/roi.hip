@@ -388,7 +388,8 @@ typedef float gs_f2 __attribute__((ext_vector_type(2)));
 #define GS_OCC 4
 #endif
 __global__ __launch_bounds__(256, GS_OCC) void roi_align_bwd_gather_kernel(const RoiSetsDev sets, bf16_t* __restrict__ gfeat, int level,
-                                                                   int nlevels, int H, int W, int C, float scale) {
+                                                                   int nlevels, int H, int W, int C, float scale,
+                                                                   const bf16_t* __restrict__ add0, const bf16_t* __restrict__ add1) {
   constexpr int TS = GS_TS;
   constexpr int NQ = 2;    // items per thread: an item = (tile row, 4-pixel quad of that row, 8-channel chunk)
   __shared__ RoiGeom list[GS_MAXL];
@@ -554,10 +555,25 @@ __global__ __launch_bounds__(256, GS_OCC) void roi_align_bwd_gather_kernel(const
     for (int j = 0; j < 4; ++j) {
       const int px = tx0 + quad * 4 + j;
       if (px >= W) continue;
+      const size_t at = (((size_t)b * H + py) * W + px) * C + ch * 8;
+      // round 6: the map's other gradients (the RPN's and the semantic head's: autograd's accumulation over the map's readers)
+      // are added here, in fp32, before the one rounding - the separate u2_add_n pass read this map back and the others again
+      if (add0) {
+        bf16_t u[8];
+        *reinterpret_cast<uint4*>(u) = *reinterpret_cast<const uint4*>(add0 + at);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[q][j][e].x += bf2f(u[2 * e]); acc[q][j][e].y += bf2f(u[2 * e + 1]); }
+      }
+      if (add1) {
+        bf16_t u[8];
+        *reinterpret_cast<uint4*>(u) = *reinterpret_cast<const uint4*>(add1 + at);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[q][j][e].x += bf2f(u[2 * e]); acc[q][j][e].y += bf2f(u[2 * e + 1]); }
+      }
       bf16_t o[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { o[2 * e] = f2bf(acc[q][j][e].x); o[2 * e + 1] = f2bf(acc[q][j][e].y); }
-      *reinterpret_cast<uint4*>(gfeat + (((size_t)b * H + py) * W + px) * C + ch * 8) = *reinterpret_cast<const uint4*>(o);
+      *reinterpret_cast<uint4*>(gfeat + at) = *reinterpret_cast<const uint4*>(o);
     }
   }
 }
@@ -1138,10 +1154,10 @@ extern "C" int u2_roi_group(const float* rois, const int* level, int* order, int
   return 0;
 }
 
-extern "C" int u2_roi_align_bwd_gather_multi(void* const* gfeats, const int* Hs, const int* Ws, const float* scales,
-                                             int nlevels, int nsets, const void* const* rois, const void* const* order,
-                                             const void* const* seg, const void* const* dout, const int* P,
-                                             const float* gscale, int B, int C, void* stream) {
+extern "C" int u2_roi_align_bwd_gather_sum(void* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,
+                                           int level_mask, int nsets, const void* const* rois, const void* const* order,
+                                           const void* const* seg, const void* const* dout, const int* P, const float* gscale,
+                                           const void* const* add0, const void* const* add1, int B, int C, void* stream) {
   if (nlevels < 1 || nlevels > 4 || (C & 7) || C > 256 || nsets < 1 || nsets > 4) return -1;
   if (B <= 0) return 0;
   RoiSetsDev sets;
@@ -1154,13 +1170,22 @@ extern "C" int u2_roi_align_bwd_gather_multi(void* const* gfeats, const int* Hs,
   const char* e_lv = getenv("U2_ROI_LEVEL");  // experiments: launch one level only
   const int only = e_lv ? atoi(e_lv) : -1;
   for (int l = 0; l < nlevels; ++l) {
-    if (only >= 0 && l != only) continue;
+    if ((only >= 0 && l != only) || !((level_mask >> l) & 1) || !gfeats[l]) continue;
     const dim3 grid((Ws[l] + 7) / 8, (Hs[l] + 7) / 8, B);
     hipLaunchKernelGGL(roi_align_bwd_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, sets, (bf16_t*)gfeats[l], l,
-                       nlevels, Hs[l], Ws[l], C, scales[l]);
+                       nlevels, Hs[l], Ws[l], C, scales[l], add0 ? (const bf16_t*)add0[l] : nullptr,
+                       add1 ? (const bf16_t*)add1[l] : nullptr);
     U2_CHECK_LAUNCH();
   }
   return 0;
+}
+
+extern "C" int u2_roi_align_bwd_gather_multi(void* const* gfeats, const int* Hs, const int* Ws, const float* scales,
+                                             int nlevels, int nsets, const void* const* rois, const void* const* order,
+                                             const void* const* seg, const void* const* dout, const int* P,
+                                             const float* gscale, int B, int C, void* stream) {
+  return u2_roi_align_bwd_gather_sum(gfeats, Hs, Ws, scales, nlevels, 0xf, nsets, rois, order, seg, dout, P, gscale, nullptr, nullptr,
+                                     B, C, stream);
 }
 
 extern "C" int u2_roi_align_bwd_gather(void* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,

@@ -727,11 +727,12 @@ class _GroupNormActFn(Function):
     """nn.GroupNorm(G, C) (+ReLU) on NHWC (reference: layers/batch_norm.py:189, semantic_seg.py:196-205)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, groups, relu, eps):
+    def forward(ctx, y, gamma, beta, groups, relu, eps, grad_dst=None):
         _check_act(y)
         b, h, w, c = y.shape
         hw = h * w
         cg = c // groups
+        ctx.grad_dst = grad_dst  # (dgamma, dbeta) arena slices or None
         stats = zeros_f32((b, 2, c), y.device)
         _hip.call("u2_colstats", y, stats, b, hw, c, c)
         coef = torch.empty((4, b, c), dtype=torch.float32, device=y.device)
@@ -756,15 +757,22 @@ class _GroupNormActFn(Function):
         _hip.call("u2_norm_bwd_reduce", dout, None, y, mean, invstd, sums, b, hw, c, c, int(relu), msc, msh, None, None, None, 0)
         coef = torch.empty((3, b, c), dtype=torch.float32, device=y.device)
         k1, k2, k3 = coef[0], coef[1], coef[2]
-        dparam = torch.empty((2, c), dtype=torch.float32, device=y.device)
-        _hip.call("u2_gn_finalize_bwd", sums, gamma.detach(), mean, invstd, n, b, c, groups, k1, k2, k3, dparam[0], dparam[1])
+        direct = ctx.grad_dst is not None
+        if direct:   # accumulated into the optimizer's arena slices by the finalize kernel: nothing for AccumulateGrad to add
+            dg, db = ctx.grad_dst
+        else:
+            dparam = torch.empty((2, c), dtype=torch.float32, device=y.device)
+            dg, db = dparam[0], dparam[1]
+        _hip.call("u2_gn_finalize_bwd", sums, gamma.detach(), mean, invstd, n, b, c, groups, k1, k2, k3, dg, db, int(direct))
         dx = torch.empty_like(y)
         _hip.call("u2_norm_bwd_apply", dout, None, y, k1, k2, k3, dx, None, b, hw, c, c, int(relu), msc, msh)
-        return dx, dparam[0], dparam[1], None, None, None
+        return dx, (None if direct else dg), (None if direct else db), None, None, None, None
 
 
 def group_norm_act(y, gamma, beta, groups, relu=False, eps=1e-5):
-    return _GroupNormActFn.apply(y, gamma, beta, groups, relu, eps)
+    gd, bd = grad_slot(gamma), grad_slot(beta)
+    ok = gd is not None and bd is not None and gd.is_contiguous() and bd.is_contiguous() and gd.dtype == torch.float32
+    return _GroupNormActFn.apply(y, gamma, beta, groups, relu, eps, (gd, bd) if ok else None)
 
 
 # --------------------------------------------------------------------------------------------
@@ -1072,23 +1080,34 @@ def _roi_group(rois, levels, b, nl):
     return order, seg
 
 
-def _roi_gather(shapes, scales, sets, device):
-    """sets: [(rois, order, seg, dout, P, gscale)] (at most 4) -> per-level bf16 gradient maps, each written once."""
+def _roi_gather(shapes, scales, sets, device, level=None, addends=()):
+    """sets: [(rois, order, seg, dout, P, gscale)] (at most 4) -> per-level bf16 gradient maps, each written once.
+    level = l: that level's map only (a one-element list), with up to two more bf16 gradient maps of its shape (`addends`: what
+    the map's other readers produced) added in fp32 before the rounding (u2_roi_align_bwd_gather_sum)."""
     import ctypes
 
     nl, ns = len(shapes), len(sets)
     hs = (ctypes.c_int * nl)(*[s[1] for s in shapes])
     ws = (ctypes.c_int * nl)(*[s[2] for s in shapes])
     sc = (ctypes.c_float * nl)(*scales)
-    gbuf = [torch.empty(s, dtype=BF16, device=device) for s in shapes]
-    ptrs = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gbuf])
+    lv = range(nl) if level is None else [level]
+    gbuf = {l: torch.empty(shapes[l], dtype=BF16, device=device) for l in lv}
+    ptrs = (ctypes.c_void_p * nl)(*[gbuf[l].data_ptr() if l in gbuf else None for l in range(nl)])
     keep = [tuple(t.contiguous() if isinstance(t, torch.Tensor) else t for t in st) for st in sets]
     arr = lambda k: (ctypes.c_void_p * ns)(*[st[k].data_ptr() for st in keep])
     ps = (ctypes.c_int * ns)(*[st[4] for st in keep])
     gs = (ctypes.c_float * ns)(*[float(st[5]) for st in keep])
-    _hip.call("u2_roi_align_bwd_gather_multi", ptrs, hs, ws, sc, nl, ns, arr(0), arr(1), arr(2), arr(3), ps, gs,
+    if level is None:
+        _hip.call("u2_roi_align_bwd_gather_multi", ptrs, hs, ws, sc, nl, ns, arr(0), arr(1), arr(2), arr(3), ps, gs,
+                  shapes[0][0], shapes[0][3])
+        return [gbuf[l] for l in range(nl)]
+    assert len(addends) <= 2 and all(tuple(a.shape) == tuple(shapes[level]) and a.dtype == BF16 and a.is_contiguous() for a in addends)
+    adds = list(addends) + [None, None]
+    a0 = (ctypes.c_void_p * nl)(*[adds[0].data_ptr() if (l == level and adds[0] is not None) else None for l in range(nl)])
+    a1 = (ctypes.c_void_p * nl)(*[adds[1].data_ptr() if (l == level and adds[1] is not None) else None for l in range(nl)])
+    _hip.call("u2_roi_align_bwd_gather_sum", ptrs, hs, ws, sc, nl, 1 << level, ns, arr(0), arr(1), arr(2), arr(3), ps, gs, a0, a1,
               shapes[0][0], shapes[0][3])
-    return gbuf
+    return [gbuf[level]]
 
 
 class _FanOutFn(Function):
@@ -1102,10 +1121,18 @@ class _FanOutFn(Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        lazy = None
+        if _ROI_LAZY:   # one of the gradients may be the placeholder of a deferred ROIAlign gather (roi_grad_tap, round 6)
+            for g in grads:
+                if g is not None:
+                    ent = _ROI_LAZY.pop((g.device.index, g.data_ptr()), None)
+                    if ent is not None:
+                        assert lazy is None
+                        lazy, grads = ent, tuple(h for h in grads if h is not g)
         gs = [g.contiguous() for g in grads if g is not None]
-        if not gs:
+        if not gs and lazy is None:
             return None, None
-        while len(gs) > 1:
+        while len(gs) > (2 if lazy is not None else 1):
             part, gs = gs[:4], gs[4:]
             if part[0].dtype != BF16 or part[0].numel() % 8:
                 total = part[0]
@@ -1116,6 +1143,21 @@ class _FanOutFn(Function):
                 part = part + [None] * (4 - len(part))
                 _hip.call("u2_add_n", part[0], part[1], part[2], part[3], total, total.numel())
             gs.insert(0, total)
+        if lazy is not None:
+            # the ROI poolers' gradient of this map is formed HERE, with the other readers' gradients added inside the gather
+            # (fp32, one rounding): the separate u2_add_n pass read the gathered map back and the other two again
+            shared, level = lazy
+            here = torch.cuda.current_stream(shared["device"])
+            for entry in shared["pend"]:
+                ev = entry[6] if len(entry) > 6 else None
+                if ev is not None:
+                    here.wait_event(ev)
+                    for t in entry[:4]:
+                        t.record_stream(here)
+            if any(g.dtype != BF16 for g in gs):
+                gs = [g.to(BF16) for g in gs]
+            out = _roi_gather(shared["shapes"], shared["scales"], shared["pend"], shared["device"], level, gs)[0]
+            return out, None
         return gs[0], None
 
 
@@ -1123,7 +1165,10 @@ def fan_out(x, k):
     """`k` handles on `x` for `k` consumers (training only; without autograd the tensor itself k times)."""
     if k <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
         return (x,) * max(k, 1)
-    return _FanOutFn.apply(x, k)
+    outs = _FanOutFn.apply(x, k)
+    for o in outs:
+        o._u2_fan = True   # its gradient goes straight to _FanOutFn.backward, which can take a deferred ROI gather (roi_grad_tap)
+    return outs
 
 
 class RoiGradTap:
@@ -1135,6 +1180,7 @@ class RoiGradTap:
         self.pending = []
         self.scales = None
         self.ids = None
+        self.defer = False   # every map is a fan_out handle: the gather is left to _FanOutFn.backward (see there)
 
 
 class _RoiGradTapFn(Function):
@@ -1149,6 +1195,17 @@ class _RoiGradTapFn(Function):
         st = ctx.state
         grads = list(gfeats)
         pend, st.pending = st.pending, []
+        if st.defer and ROI_SUM_FOLD and pend and len(pend) <= 4 and all(g is None for g in grads) and pend[0][3].is_cuda:
+            # every tapped map is a fan_out handle: hand its _FanOutFn.backward a zero placeholder and let IT run the level's
+            # gather, with the gradients of the map's other readers as addends (u2_roi_align_bwd_gather_sum)
+            dev = pend[0][3].device
+            shared = {"shapes": st.shapes, "scales": st.scales, "pend": pend, "device": dev}
+            out = []
+            for l, shape in enumerate(st.shapes):
+                ph = _lazy_placeholder(dev, _ROI_LAZY).expand(shape)
+                _ROI_LAZY[(dev.index, ph.data_ptr())] = (shared, l)
+                out.append(ph)
+            return (None, *out)
         here = torch.cuda.current_stream(pend[0][3].device) if pend and pend[0][3].is_cuda else None
         for entry in pend:  # a set left by a ROIAlign that ran on another stream (the mask head's): wait for it, keep it alive
             ev = entry[6] if len(entry) > 6 else None
@@ -1167,6 +1224,7 @@ def roi_grad_tap(feats):
     box poolers and the mask pooler (modeling/poolers.py:206-263 x 4) then cost one gather pass per level, and the four
     gradient maps per level that autograd would otherwise materialise and sum are never formed."""
     state = RoiGradTap(feats)
+    state.defer = all(getattr(f, "_u2_fan", False) for f in feats)
     outs = _RoiGradTapFn.apply(state, *feats)
     state.ids = [id(o) for o in outs]
     for o in outs:
@@ -1180,23 +1238,30 @@ LAZY_BN_APPLY = os.environ.get("U2_LAZY_BN_APPLY", "1") != "0"
 _LAZY_GRADS = {}   # (device, placeholder address) -> (placeholder, dz, y, coefficients [5][C]: rows 2-4 = k1, k2, k3)
 
 
+# the ROIAlign gather of a tapped FPN map deferred to the map's _FanOutFn.backward (round 6): (device, placeholder address) ->
+# (shared state of the tap's backward, level); U2_ROI_SUM_FOLD=0: the tap gathers on the spot and u2_add_n sums afterwards
+ROI_SUM_FOLD = os.environ.get("U2_ROI_SUM_FOLD", "1") != "0"
+_ROI_LAZY = {}
 _LAZY_POOL = {}    # device index -> [zero-filled bf16 pool, next slot]: placeholders are ZEROS, so that a sum autograd forms with
                    # one by accident is numerically the other addend (and is then caught by _lazy_guard / the checks below)
 _LAZY_SLOTS = 64
 
 
-def _lazy_placeholder(device):
+def _lazy_placeholder(device, registry=None):
+    registry = _LAZY_GRADS if registry is None else registry
     ent = _LAZY_POOL.get(device.index)
     if ent is None:
         ent = _LAZY_POOL[device.index] = [torch.zeros(_LAZY_SLOTS, dtype=BF16, device=device), 0]
     for _ in range(_LAZY_SLOTS):
         slot = ent[0][ent[1] : ent[1] + 1]
         ent[1] = (ent[1] + 1) % _LAZY_SLOTS
-        if (device.index, slot.data_ptr()) not in _LAZY_GRADS:
+        key = (device.index, slot.data_ptr())
+        if key not in _LAZY_GRADS and key not in _ROI_LAZY:
             return slot
-    n = len(_LAZY_GRADS)
+    n = len(_LAZY_GRADS) + len(_ROI_LAZY)
     _LAZY_GRADS.clear()
-    raise RuntimeError("%d deferred batch-norm gradients were not consumed by their convolutions" % n)
+    _ROI_LAZY.clear()
+    raise RuntimeError("%d deferred gradients were not consumed by their consumers" % n)
 
 
 def _lazy_guard(state, grad):
@@ -1217,21 +1282,24 @@ def reset_deferred_gradients(strict=True):
     one that raised midway leaves entries behind, which must not meet the addresses of the next pass."""
     global _UP2_BWD_LAST
     _UP2_BWD_LAST = None
-    if _LAZY_GRADS:
-        n = len(_LAZY_GRADS)
+    if _LAZY_GRADS or _ROI_LAZY:
+        n = len(_LAZY_GRADS) + len(_ROI_LAZY)
         _LAZY_GRADS.clear()
+        _ROI_LAZY.clear()
         if strict:
-            raise RuntimeError("%d deferred batch-norm gradients of an earlier backward pass were never consumed" % n)
+            raise RuntimeError("%d deferred gradients of an earlier backward pass were never consumed" % n)
 
 
 def assert_no_deferred_gradients():
     """After a backward pass: every deferred batch-norm gradient must have been consumed by its convolution."""
     global _UP2_BWD_LAST
     _UP2_BWD_LAST = None   # the shared upsample gradient of the semantic head: nothing of this pass stays referenced
-    if _LAZY_GRADS:
-        n = len(_LAZY_GRADS)
+    if _LAZY_GRADS or _ROI_LAZY:
+        n, m = len(_LAZY_GRADS), len(_ROI_LAZY)
         _LAZY_GRADS.clear()
-        raise RuntimeError("%d deferred batch-norm gradients were not consumed by their convolutions" % n)
+        _ROI_LAZY.clear()
+        raise RuntimeError("%d deferred batch-norm gradients were not consumed by their convolutions, %d deferred ROIAlign "
+                           "gathers not by their fan-out nodes" % (n, m))
 ROI_ORDER_MIN = int(os.environ.get("U2_ROI_ORDER_MIN", "1000000000"))
 
 
