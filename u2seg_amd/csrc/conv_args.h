@@ -31,7 +31,8 @@ struct ConvArgs {
   int* sk_flags;
   int abl;                 // conv_halo.hip measurement switches (tests/native/selftest bench2 only; 0 in production):
                            // bit 0 no output stores, bit 1 no BN statistics, bit 2 no epilogue at all, bit 3 `nt` stores for outputs > 160 MB
-                           // (rounds 1-2 default; round 3 measured it 29-38 % SLOWER on the write-heavy 1x1 layers, -0.55 ms per step)
+                           // (rounds 1-2 default; round 3 measured it 29-38 % SLOWER on the write-heavy 1x1 layers, -0.55 ms per step);
+                           // bits 4-5 (conv_tile.hip, round 6, TIMING ONLY - wrong results): which waves issue the LDS-DMA staging
 };
 
 // Tile shapes: (TM pixels x TN output channels) = 128x128 (default) or 256x64 (layers with <= 64 output channels,

@@ -247,9 +247,13 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     }
     --p_kc;
     unsigned char* base = smem + buf * BUF;
+    // measurement switches (timing only, results are wrong): abl bit 4 = the pixel operand is staged by waves 0 .. NW/2-1 only and
+    // the weights by the others (half of the LDS-DMA instructions, the two waves of a SIMD issue theirs in different phases);
+    // bit 5 = no wave stages weights (half of the instructions, every wave in the same phase); both = no staging at all
+    const bool skip_p = ((a.abl & 48) == 16 && w >= NW / 2) || (a.abl & 48) == 48;
 #pragma unroll
     for (int i = 0; i < LP; ++i) {
-      glds16(p_src[i], base + (i * NW + w) * 1024);
+      if (!skip_p) glds16(p_src[i], base + (i * NW + w) * 1024);
       p_src[i] += (p_okmask >> i & 1u) * KU;
     }
   };
@@ -291,9 +295,10 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     }
     --w_kc;
     unsigned char* base = smem + buf * BUF + PBYTES;
+    const bool skip_w = ((a.abl & 48) == 16 && w < NW / 2) || (a.abl & 32);
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
-      glds16(w_src[i], base + (i * NW + w) * 1024);
+      if (!skip_w) glds16(w_src[i], base + (i * NW + w) * 1024);
       w_src[i] += w_base[i] != 0xffffffffu ? KU : 0;
     }
   };
