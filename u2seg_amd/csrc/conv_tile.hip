@@ -18,6 +18,7 @@
 // work-group = WCH x WPX waves: 4x2 (256 ch x 256 px, one group per CU), 2x2 and 4x1 (two groups per CU).
 #include <stdlib.h>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 #include <algorithm>
 #include <stdio.h>
@@ -43,6 +44,13 @@ __device__ unsigned long long* g_tile_trace_dev = nullptr;
   } while (0)
 #else
 #define U2_STAMP(SLOT) do { } while (0)
+#endif
+
+// measurement switch: -DU2_TILE_NOPRIO compiles the s_setprio brackets around the MFMA groups out (tools/exp/tile_noprio_ab.sh)
+#ifdef U2_TILE_NOPRIO
+#define U2_TILE_SETPRIO(P) do { } while (0)
+#else
+#define U2_TILE_SETPRIO(P) __builtin_amdgcn_s_setprio(P)
 #endif
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -118,6 +126,9 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 // second).  In the text below "half K tile" then reads "K tile" wherever it means the ring's unit.
 #ifndef U2_SKB
 #define U2_SKB 16
+#endif
+#ifndef U2_TILE_PEEL
+#define U2_TILE_PEEL 0   // measured: not faster (profiles/r06_tile_loop_experiments.txt)
 #endif
 template <int WCH, int WPX, int RING, bool ACC = false, bool SK = false, int KT = 1>
 __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const ConvArgs a) {
@@ -250,7 +261,13 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     // measurement switches (timing only, results are wrong): abl bit 4 = the pixel operand is staged by waves 0 .. NW/2-1 only and
     // the weights by the others (half of the LDS-DMA instructions, the two waves of a SIMD issue theirs in different phases);
     // bit 5 = no wave stages weights (half of the instructions, every wave in the same phase); both = no staging at all
+    // (compiled in with -DU2_TILE_DMA_ABLATION only - tools/exp/dma_phase_ablation.sh: the test puts a branch around every staging
+    //  instruction of the production loop otherwise)
+#ifdef U2_TILE_DMA_ABLATION
     const bool skip_p = ((a.abl & 48) == 16 && w >= NW / 2) || (a.abl & 48) == 48;
+#else
+    constexpr bool skip_p = false;
+#endif
 #pragma unroll
     for (int i = 0; i < LP; ++i) {
       if (!skip_p) glds16(p_src[i], base + (i * NW + w) * 1024);
@@ -295,7 +312,11 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     }
     --w_kc;
     unsigned char* base = smem + buf * BUF + PBYTES;
+#ifdef U2_TILE_DMA_ABLATION
     const bool skip_w = ((a.abl & 48) == 16 && w < NW / 2) || (a.abl & 32);
+#else
+    constexpr bool skip_w = false;
+#endif
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
       if (!skip_w) glds16(w_src[i], base + (i * NW + w) * 1024);
@@ -545,54 +566,63 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int h_begin = (SK && ti == 0) ? sk_k0 : 0, h_end = (SK && ti == my_tiles - 1) ? sk_k1 : nkh;
-    for (int h = h_begin; h < h_end; ++h) {
+    // One half K tile (the sequence documented above).  FAST: the step lies in the interior of the work-group's life
+    // (gh + AHEAD + 1 < H), where every staging / read-ahead condition holds and the counted wait is the steady-state one - the
+    // interior steps run without the five compare-and-branch pairs and the wait ladder of the general form (round 6: the waves of
+    // a SIMD sit in the same phase behind the step's barrier, so every cycle of this bookkeeping is a cycle the matrix pipe idles:
+    // profiles/r06_1x1_k512.txt).  MEASURED NOT FASTER (26 instructions and 7 branches fewer per step, 0 ... 4 % slower on the 256 x 256
+    // configurations: profiles/r06_tile_loop_experiments.txt), so the default is the single general loop; -DU2_TILE_PEEL=1 selects this form.
+    auto step = [&](auto fast_tag) {
+      constexpr bool FAST = decltype(fast_tag)::value;
       const int nb = (hb + 1 == RING) ? 0 : hb + 1;
       const int sb = (hb == 0) ? RING - 1 : hb - 1;  // buffer of stage gh + AHEAD (= gh - 1 mod RING)
       if constexpr (KT == 2) {
         // ---- first half of the stage: no staging of pixels, no wait, no barrier; the second half's fragments are in the same buffer
-        __builtin_amdgcn_s_setprio(1);
+        U2_TILE_SETPRIO(1);
         U2_T_MFMA(0, wfA[0], 0); U2_T_MFMA(1, wfA[1], 0); U2_T_MFMA(0, wfA[0], 1); U2_T_MFMA(1, wfA[1], 1);
-        __builtin_amdgcn_s_setprio(0);
+        U2_TILE_SETPRIO(0);
         __builtin_amdgcn_sched_barrier(0);
         pf[4] = ldp(hb, 4); pf[5] = ldp(hb, 5); pf[6] = ldp(hb, 6); pf[7] = ldp(hb, 7);
         wfB[0] = ldw(hb, 2); wfB[1] = ldw(hb, 3);
-        if (gh + AHEAD < H) stage_weights(sb);   // the buffer of stage gh - 1: every wave left it at the last barrier
+        if (FAST || gh + AHEAD < H) stage_weights(sb);   // the buffer of stage gh - 1: every wave left it at the last barrier
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        U2_TILE_SETPRIO(1);
         U2_T_MFMA(0, wfA[0], 2); U2_T_MFMA(1, wfA[1], 2); U2_T_MFMA(0, wfA[0], 3); U2_T_MFMA(1, wfA[1], 3);
 #pragma unroll
         for (int j = 4; j < 8; ++j) { U2_T_MFMA(0, wfA[0], j); U2_T_MFMA(1, wfA[1], j); }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { U2_T_MFMA(2, wfB[0], j); U2_T_MFMA(3, wfB[1], j); }
-        __builtin_amdgcn_s_setprio(0);
+        U2_TILE_SETPRIO(0);
         __builtin_amdgcn_sched_barrier(0);
         wfA[0] = ldw(hb, 0, 1); wfA[1] = ldw(hb, 1, 1);
         pf[0] = ldp(hb, 0, 1); pf[1] = ldp(hb, 1, 1); pf[2] = ldp(hb, 2, 1); pf[3] = ldp(hb, 3, 1);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        U2_TILE_SETPRIO(1);
 #pragma unroll
         for (int j = 4; j < 8; ++j) { U2_T_MFMA(2, wfB[0], j); U2_T_MFMA(3, wfB[1], j); }
-        __builtin_amdgcn_s_setprio(0);
+        U2_TILE_SETPRIO(0);
       }
       constexpr int LH = KT - 1;   // the half of the stage the sequence below multiplies (its fragments 0-3 / first weight pair are in registers)
       // phase A
-      __builtin_amdgcn_s_setprio(1);
+      U2_TILE_SETPRIO(1);
       U2_T_MFMA(0, wfA[0], 0); U2_T_MFMA(1, wfA[1], 0); U2_T_MFMA(0, wfA[0], 1); U2_T_MFMA(1, wfA[1], 1);
-      __builtin_amdgcn_s_setprio(0);
+      U2_TILE_SETPRIO(0);
       __builtin_amdgcn_sched_barrier(0);
       pf[4] = ldp(hb, 4, LH); pf[5] = ldp(hb, 5, LH); pf[6] = ldp(hb, 6, LH); pf[7] = ldp(hb, 7, LH);
       wfB[0] = ldw(hb, 2, LH); wfB[1] = ldw(hb, 3, LH);
       if constexpr (KT == 1) {
-        if (gh + AHEAD < H) stage_weights(sb);
+        if (FAST || gh + AHEAD < H) stage_weights(sb);
       }
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
+      U2_TILE_SETPRIO(1);
       U2_T_MFMA(0, wfA[0], 2); U2_T_MFMA(1, wfA[1], 2); U2_T_MFMA(0, wfA[0], 3); U2_T_MFMA(1, wfA[1], 3);
 #pragma unroll
       for (int j = 4; j < 8; ++j) { U2_T_MFMA(0, wfA[0], j); U2_T_MFMA(1, wfA[1], j); }
-      __builtin_amdgcn_s_setprio(0);
+      U2_TILE_SETPRIO(0);
       // phase B
-      {
+      if constexpr (FAST) {
+        wait_vm<LPT * (AHEAD - 1)>();
+      } else {
         const int rem = H - 2 - gh;  // stages staged behind gh + 1
         if (rem >= AHEAD - 1) wait_vm<LPT * (AHEAD - 1)>();
         else if (AHEAD > 3 && rem == 2) wait_vm<LPT * 2>();
@@ -605,25 +635,35 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #ifdef U2_TILE_TRACE
       if (gh < 44) U2_STAMP(2 + gh);
 #endif
-      if (gh + AHEAD + 1 < H) stage_pixels(hb);
+      if (FAST || gh + AHEAD + 1 < H) stage_pixels(hb);
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
+      U2_TILE_SETPRIO(1);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { U2_T_MFMA(2, wfB[0], j); U2_T_MFMA(3, wfB[1], j); }
-      __builtin_amdgcn_s_setprio(0);
+      U2_TILE_SETPRIO(0);
       __builtin_amdgcn_sched_barrier(0);
-      if (gh + 1 < H) {
+      if (FAST || gh + 1 < H) {
         wfA[0] = ldw(nb, 0); wfA[1] = ldw(nb, 1);
         pf[0] = ldp(nb, 0); pf[1] = ldp(nb, 1); pf[2] = ldp(nb, 2); pf[3] = ldp(nb, 3);
       }
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
+      U2_TILE_SETPRIO(1);
 #pragma unroll
       for (int j = 4; j < 8; ++j) { U2_T_MFMA(2, wfB[0], j); U2_T_MFMA(3, wfB[1], j); }
-      __builtin_amdgcn_s_setprio(0);
+      U2_TILE_SETPRIO(0);
       ++gh;
       hb = nb;
+    };
+    int h = h_begin;
+#if U2_TILE_PEEL
+    while (h < h_end) {
+      int nfast = min(h_end - h, H - (AHEAD + 1) - gh);
+      for (; nfast > 0; --nfast, ++h) step(std::true_type{});
+      if (h < h_end) { step(std::false_type{}); ++h; }
     }
+#else
+    for (; h < h_end; ++h) step(std::false_type{});
+#endif
     if constexpr (SK) {
       if (h_begin > 0) { U2_STAMP(48); sk_publish(); U2_STAMP(49); continue; }   // a non-leading part: handed to the tile's owner
       if (h_end < nkh) break;                                   // the owner collects the parts behind its own: below
