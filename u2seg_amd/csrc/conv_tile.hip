@@ -127,6 +127,9 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 #ifndef U2_SKB
 #define U2_SKB 16
 #endif
+#ifndef U2_TILE_READS_FIRST
+#define U2_TILE_READS_FIRST 0   // measured: not faster (profiles/r06_tile_loop_experiments.txt)
+#endif
 #ifndef U2_TILE_PEEL
 #define U2_TILE_PEEL 0   // measured: not faster (profiles/r06_tile_loop_experiments.txt)
 #endif
@@ -334,6 +337,15 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   const int pfrag0 = (wc * 128 + fr) * ROWB + ((fg ^ swz<KU>(fr)) << 4);
   auto ldw = [&](int hb, int t, int half = 0) { return *reinterpret_cast<const s16x8*>(smem + hb * BUF + (wfrag0 ^ (half << 6)) + t * 16 * ROWB); };
   auto ldp = [&](int hb, int t, int half = 0) { return *reinterpret_cast<const s16x8*>(smem + hb * BUF + (pfrag0 ^ (half << 6)) + t * 16 * ROWB); };
+#if U2_TILE_READS_FIRST
+  // Fragment reads as inline asm with counted waits (KT = 1 only): the compiler answers a plain LDS load it must wait for with
+  // s_waitcnt lgkmcnt(0) whenever LDS-DMA is in flight (it will not count across it), which forbids having a SECOND batch of reads in
+  // flight while the first is consumed.  LDS returns in order, so `lgkmcnt(6)` with twelve reads outstanding releases the older six.
+  const unsigned lds_base = (unsigned)(size_t)U2_LDS_PTR(smem);
+#define U2_T_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+#define U2_T_WAIT6(CNT, R0, R1, R2, R3, R4, R5) \
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(R0), "+v"(R1), "+v"(R2), "+v"(R3), "+v"(R4), "+v"(R5) : "n"(CNT) : "memory")
+#endif
 
   f32x4 acc[4][8];
   s16x8 wfA[2], wfB[2], pf[8];
@@ -475,9 +487,20 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   U2_STAMP(1);
+#if U2_TILE_READS_FIRST
+  if constexpr (KT == 1) {
+    // (asm like the reads of the loop: a compiler-visible LDS load pending at the loop header would make the wait-count pass put
+    //  s_waitcnt lgkmcnt(0) in front of the loop's first counted wait in EVERY iteration)
+    const unsigned pa = lds_base + (unsigned)pfrag0, wa = lds_base + (unsigned)wfrag0;
+    U2_T_RD(wfA[0], wa, 0); U2_T_RD(wfA[1], wa, 16 * ROWB);
+    U2_T_RD(pf[0], pa, 0); U2_T_RD(pf[1], pa, 16 * ROWB); U2_T_RD(pf[2], pa, 2 * 16 * ROWB); U2_T_RD(pf[3], pa, 3 * 16 * ROWB);
+  } else
+#endif
+  {
   wfA[0] = ldw(0, 0); wfA[1] = ldw(0, 1);
 #pragma unroll
   for (int j = 0; j < 4; ++j) pf[j] = ldp(0, j);
+  }
 
   // One half K tile gh (buffer hb = gh % RING), two phases:
   //   A: 4 MFMA | read pixel fragments 4-7 and the second weight pair of gh, stage weights(gh + AHEAD) | 12 MFMA
@@ -604,6 +627,34 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       }
       constexpr int LH = KT - 1;   // the half of the stage the sequence below multiplies (its fragments 0-3 / first weight pair are in registers)
       // phase A
+#if U2_TILE_READS_FIRST
+      // round 6 experiment (MEASURED NOT FASTER, default off): the fragments the second half of phase A needs are requested at its very start (their registers are
+      // free: the last MFMAs of the previous step read them), so that eight MFMAs and the weight staging cover their LDS round trip
+      // instead of four MFMAs - all eight waves request 6 KB each at the same moment, ~190 cycles of LDS bandwidth alone
+      if constexpr (KT == 1) {
+        {
+          const unsigned pa = lds_base + (unsigned)(hb * BUF + pfrag0), wa = lds_base + (unsigned)(hb * BUF + wfrag0);
+          U2_T_RD(pf[4], pa, 4 * 16 * ROWB); U2_T_RD(pf[5], pa, 5 * 16 * ROWB); U2_T_RD(pf[6], pa, 6 * 16 * ROWB);
+          U2_T_RD(pf[7], pa, 7 * 16 * ROWB); U2_T_RD(wfB[0], wa, 2 * 16 * ROWB); U2_T_RD(wfB[1], wa, 3 * 16 * ROWB);
+        }
+        // the six reads of the previous step's phase B (or the prologue's) have returned once at most six are outstanding
+        U2_T_WAIT6(6, wfA[0], wfA[1], pf[0], pf[1], pf[2], pf[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        U2_TILE_SETPRIO(1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { U2_T_MFMA(0, wfA[0], j); U2_T_MFMA(1, wfA[1], j); }
+        U2_TILE_SETPRIO(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (FAST || gh + AHEAD < H) stage_weights(sb);
+        U2_T_WAIT6(0, pf[4], pf[5], pf[6], pf[7], wfB[0], wfB[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        U2_TILE_SETPRIO(1);
+#pragma unroll
+        for (int j = 4; j < 8; ++j) { U2_T_MFMA(0, wfA[0], j); U2_T_MFMA(1, wfA[1], j); }
+        U2_TILE_SETPRIO(0);
+      } else
+#endif
+      {
       U2_TILE_SETPRIO(1);
       U2_T_MFMA(0, wfA[0], 0); U2_T_MFMA(1, wfA[1], 0); U2_T_MFMA(0, wfA[0], 1); U2_T_MFMA(1, wfA[1], 1);
       U2_TILE_SETPRIO(0);
@@ -619,6 +670,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #pragma unroll
       for (int j = 4; j < 8; ++j) { U2_T_MFMA(0, wfA[0], j); U2_T_MFMA(1, wfA[1], j); }
       U2_TILE_SETPRIO(0);
+      }
       // phase B
       if constexpr (FAST) {
         wait_vm<LPT * (AHEAD - 1)>();
@@ -643,8 +695,17 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       U2_TILE_SETPRIO(0);
       __builtin_amdgcn_sched_barrier(0);
       if (FAST || gh + 1 < H) {
+#if U2_TILE_READS_FIRST
+        if constexpr (KT == 1) {
+          const unsigned pa = lds_base + (unsigned)(nb * BUF + pfrag0), wa = lds_base + (unsigned)(nb * BUF + wfrag0);
+          U2_T_RD(wfA[0], wa, 0); U2_T_RD(wfA[1], wa, 16 * ROWB);
+          U2_T_RD(pf[0], pa, 0); U2_T_RD(pf[1], pa, 16 * ROWB); U2_T_RD(pf[2], pa, 2 * 16 * ROWB); U2_T_RD(pf[3], pa, 3 * 16 * ROWB);
+        } else
+#endif
+        {
         wfA[0] = ldw(nb, 0); wfA[1] = ldw(nb, 1);
         pf[0] = ldp(nb, 0); pf[1] = ldp(nb, 1); pf[2] = ldp(nb, 2); pf[3] = ldp(nb, 3);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       U2_TILE_SETPRIO(1);
