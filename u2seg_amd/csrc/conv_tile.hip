@@ -130,6 +130,9 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 #ifndef U2_TILE_READS_FIRST
 #define U2_TILE_READS_FIRST 0   // measured: not faster (profiles/r06_tile_loop_experiments.txt)
 #endif
+#ifndef U2_TILE_LATE_PIXELS
+#define U2_TILE_LATE_PIXELS 0
+#endif
 #ifndef U2_TILE_PEEL
 #define U2_TILE_PEEL 0   // measured: not faster (profiles/r06_tile_loop_experiments.txt)
 #endif
@@ -687,13 +690,22 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #ifdef U2_TILE_TRACE
       if (gh < 44) U2_STAMP(2 + gh);
 #endif
+      // U2_TILE_LATE_PIXELS (round 6 experiment): the pixel staging of the step behind the first eight MFMAs of phase B instead of in
+      // front of them - all eight waves leave the barrier together and queue on the CU's one vector-memory path (16 instructions
+      // of 16 cycles each) before any of them issues an MFMA; the order of the VMEM operations of a wave is unchanged
+#if !U2_TILE_LATE_PIXELS
       if (FAST || gh + AHEAD + 1 < H) stage_pixels(hb);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       U2_TILE_SETPRIO(1);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { U2_T_MFMA(2, wfB[0], j); U2_T_MFMA(3, wfB[1], j); }
       U2_TILE_SETPRIO(0);
       __builtin_amdgcn_sched_barrier(0);
+#if U2_TILE_LATE_PIXELS
+      if (FAST || gh + AHEAD + 1 < H) stage_pixels(hb);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       if (FAST || gh + 1 < H) {
 #if U2_TILE_READS_FIRST
         if constexpr (KT == 1) {
