@@ -42,8 +42,28 @@ __device__ unsigned long long* g_tile_trace_dev = nullptr;
       if (lane == 0) asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(trace_row + (SLOT)), "v"(t_) : "memory"); \
     }                                                                                                                          \
   } while (0)
+// Sub-step timeline (-DU2_TILE_TRACE_POINT=k, k = 1 .. 6): waves 0 and 4 of a work-group - the two waves of one SIMD - stamp the
+// barrier of every half K tile (kind 0) and ONE further point of the step (kind 1; one point per build, so that a build carries one extra
+// blocking stamp per step): 1 = behind the pixel staging and the first eight MFMAs of phase B, 2 = end of the step, 3 = behind the
+// first four MFMAs of phase A, 4 = behind phase A's fragment reads and weight staging, 5 = behind its twelve MFMAs, 6 = behind the
+// counted vmcnt wait (in front of lgkmcnt(0) + barrier).  g_tile_sub_dev[blockIdx.x][wave 0 | 4][kind][48 steps].
+#ifndef U2_TILE_TRACE_POINT
+#define U2_TILE_TRACE_POINT 0
+#endif
+__device__ unsigned long long* g_tile_sub_dev = nullptr;
+#define U2_SUB(KIND)                                                                                                           \
+  do {                                                                                                                         \
+    if (sub_on && gh < 48) {                                                                                                   \
+      unsigned long long t_;                                                                                                   \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                              \
+      if (lane == 0) asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(sub_row + (KIND) * 48 + gh), "v"(t_) : "memory"); \
+    }                                                                                                                          \
+  } while (0)
+#define U2_SUBK(K) do { if constexpr (U2_TILE_TRACE_POINT == (K)) U2_SUB(1); } while (0)
 #else
 #define U2_STAMP(SLOT) do { } while (0)
+#define U2_SUB(KIND) do { } while (0)
+#define U2_SUBK(K) do { } while (0)
 #endif
 
 // measurement switch: -DU2_TILE_NOPRIO compiles the s_setprio brackets around the MFMA groups out (tools/exp/tile_noprio_ab.sh)
@@ -133,6 +153,9 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 #ifndef U2_TILE_LATE_PIXELS
 #define U2_TILE_LATE_PIXELS 0
 #endif
+#ifndef U2_TILE_W_FIRST
+#define U2_TILE_W_FIRST 0
+#endif
 #ifndef U2_TILE_PEEL
 #define U2_TILE_PEEL 0   // measured: not faster (profiles/r06_tile_loop_experiments.txt)
 #endif
@@ -158,6 +181,8 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #ifdef U2_TILE_TRACE
   const bool trace_on = w == 0 && g_tile_trace_dev != nullptr;
   unsigned long long* trace_row = g_tile_trace_dev + (size_t)blockIdx.x * 64;
+  const bool sub_on = U2_TILE_TRACE_POINT != 0 && (w == 0 || w == 4) && g_tile_sub_dev != nullptr;
+  unsigned long long* sub_row = g_tile_sub_dev + ((size_t)blockIdx.x * 2 + (w >> 2)) * 96;
   U2_STAMP(0);
 #endif
 
@@ -662,17 +687,30 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       U2_T_MFMA(0, wfA[0], 0); U2_T_MFMA(1, wfA[1], 0); U2_T_MFMA(0, wfA[0], 1); U2_T_MFMA(1, wfA[1], 1);
       U2_TILE_SETPRIO(0);
       __builtin_amdgcn_sched_barrier(0);
+      U2_SUBK(3);
+#if U2_TILE_W_FIRST
+      // round 6 experiment: the weight staging in FRONT of phase A's fragment reads (an LDS-DMA instruction issued behind six
+      // outstanding ds_read_b128 is the expensive case of MI355X_MICROARCH.md's price list)
+      if constexpr (KT == 1) {
+        if (FAST || gh + AHEAD < H) stage_weights(sb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
       pf[4] = ldp(hb, 4, LH); pf[5] = ldp(hb, 5, LH); pf[6] = ldp(hb, 6, LH); pf[7] = ldp(hb, 7, LH);
       wfB[0] = ldw(hb, 2, LH); wfB[1] = ldw(hb, 3, LH);
+#if !U2_TILE_W_FIRST
       if constexpr (KT == 1) {
         if (FAST || gh + AHEAD < H) stage_weights(sb);
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);
+      U2_SUBK(4);
       U2_TILE_SETPRIO(1);
       U2_T_MFMA(0, wfA[0], 2); U2_T_MFMA(1, wfA[1], 2); U2_T_MFMA(0, wfA[0], 3); U2_T_MFMA(1, wfA[1], 3);
 #pragma unroll
       for (int j = 4; j < 8; ++j) { U2_T_MFMA(0, wfA[0], j); U2_T_MFMA(1, wfA[1], j); }
       U2_TILE_SETPRIO(0);
+      U2_SUBK(5);
       }
       // phase B
       if constexpr (FAST) {
@@ -684,11 +722,13 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
         else if (rem == 1) wait_vm<LPT>();
         else wait_vm<0>();
       }
+      U2_SUBK(6);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
 #ifdef U2_TILE_TRACE
       if (gh < 44) U2_STAMP(2 + gh);
+      U2_SUB(0);
 #endif
       // U2_TILE_LATE_PIXELS (round 6 experiment): the pixel staging of the step behind the first eight MFMAs of phase B instead of in
       // front of them - all eight waves leave the barrier together and queue on the CU's one vector-memory path (16 instructions
@@ -702,6 +742,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       for (int j = 0; j < 4; ++j) { U2_T_MFMA(2, wfB[0], j); U2_T_MFMA(3, wfB[1], j); }
       U2_TILE_SETPRIO(0);
       __builtin_amdgcn_sched_barrier(0);
+      U2_SUBK(1);
 #if U2_TILE_LATE_PIXELS
       if (FAST || gh + AHEAD + 1 < H) stage_pixels(hb);
       __builtin_amdgcn_sched_barrier(0);
@@ -724,6 +765,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #pragma unroll
       for (int j = 4; j < 8; ++j) { U2_T_MFMA(2, wfB[0], j); U2_T_MFMA(3, wfB[1], j); }
       U2_TILE_SETPRIO(0);
+      U2_SUBK(2);
       ++gh;
       hb = nb;
     };
@@ -789,6 +831,7 @@ bool sk_scratch(hipStream_t s, ConvArgs& a, size_t need_bytes) {
 // launch (default 4: the timed launches of selftest bench2 come in fours) - phase durations in microseconds at 100 MHz ticks
 // (s_memtime on gfx950 counts the constant 100 MHz reference clock), for a handful of work-groups and the median over all.
 unsigned long long* g_tile_trace_host_ptr = nullptr;
+unsigned long long* g_tile_sub_host_ptr = nullptr;
 int g_tile_trace_launch = 0;
 void tile_trace_begin(int G, hipStream_t s) {
   (void)G;
@@ -797,6 +840,13 @@ void tile_trace_begin(int G, hipStream_t s) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_trace_dev), &g_tile_trace_host_ptr, sizeof(void*));
   }
   (void)hipMemsetAsync(g_tile_trace_host_ptr, 0, 1024 * 64 * 8, s);
+#if U2_TILE_TRACE_POINT
+  if (!g_tile_sub_host_ptr) {
+    if (hipMalloc(&g_tile_sub_host_ptr, 1024 * 2 * 96 * 8) != hipSuccess) return;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_sub_dev), &g_tile_sub_host_ptr, sizeof(void*));
+  }
+  (void)hipMemsetAsync(g_tile_sub_host_ptr, 0, 1024 * 2 * 96 * 8, s);
+#endif
 }
 void tile_trace_end(int G, hipStream_t s, const char* what) {
   static const int every = getenv("U2_TILE_TRACE_EVERY") ? atoi(getenv("U2_TILE_TRACE_EVERY")) : 4;
@@ -804,6 +854,33 @@ void tile_trace_end(int G, hipStream_t s, const char* what) {
   (void)hipStreamSynchronize(s);
   static unsigned long long h[1024 * 64];
   if (hipMemcpy(h, g_tile_trace_host_ptr, (size_t)G * 64 * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+#if U2_TILE_TRACE_POINT
+  {
+    // sub-step timeline: cycles from the step's barrier to point U2_TILE_TRACE_POINT, waves 0 and 4 of a few work-groups, mean over
+    // the interior steps; points 3-6 lie in front of the barrier of their step and are counted from the PREVIOUS barrier
+    static unsigned long long sb[1024 * 2 * 96];
+    if (hipMemcpy(sb, g_tile_sub_host_ptr, (size_t)G * 2 * 96 * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+      const int picks[] = {1, 9, G / 2 + 1, G - 15};
+      for (int pi = 0; pi < 4; ++pi) {
+        const int g = picks[pi];
+        if (g < 0 || g >= G) continue;
+        for (int wv = 0; wv < 2; ++wv) {
+          const unsigned long long* r = sb + ((size_t)g * 2 + wv) * 96;
+          double step = 0, off = 0; int ns = 0, no = 0;
+          for (int k = 6; k < 30; ++k) {
+            if (r[k] && r[k + 1]) { step += (double)(r[k + 1] - r[k]); ++ns; }
+            const int ref = (U2_TILE_TRACE_POINT >= 3) ? k - 1 : k;
+            if (r[48 + k] && r[ref] && r[48 + k] > r[ref]) { off += (double)(r[48 + k] - r[ref]); ++no; }
+          }
+          const unsigned long long* r0 = sb + ((size_t)g * 2) * 96;
+          fprintf(stderr, "SUB point %d wg %4d wave %d: step %.0f cycles (n=%d), point at +%.0f cycles behind the %s barrier (n=%d), barrier of wave 4 - wave 0 at step 10: %lld\n",
+                  U2_TILE_TRACE_POINT, g, wv * 4, ns ? step / ns : -1.0, ns, no ? off / no : -1.0, U2_TILE_TRACE_POINT >= 3 ? "previous" : "same", no,
+                  (long long)(r0[96 + 10]) - (long long)(r0[10]));
+        }
+      }
+    }
+  }
+#endif
   static const double tick_us = getenv("U2_TILE_TRACE_TICK_US") ? atof(getenv("U2_TILE_TRACE_TICK_US")) : 0.01;
   unsigned long long t0 = ~0ull, t1 = 0;
   for (int g = 0; g < G; ++g) {
