@@ -156,6 +156,9 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 #ifndef U2_TILE_W_FIRST
 #define U2_TILE_W_FIRST 0
 #endif
+#ifndef U2_TILE_PINGPONG
+#define U2_TILE_PINGPONG 0
+#endif
 #ifndef U2_TILE_PEEL
 #define U2_TILE_PEEL 0   // measured: not faster (profiles/r06_tile_loop_experiments.txt)
 #endif
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   const int pfrag0 = (wc * 128 + fr) * ROWB + ((fg ^ swz<KU>(fr)) << 4);
   auto ldw = [&](int hb, int t, int half = 0) { return *reinterpret_cast<const s16x8*>(smem + hb * BUF + (wfrag0 ^ (half << 6)) + t * 16 * ROWB); };
   auto ldp = [&](int hb, int t, int half = 0) { return *reinterpret_cast<const s16x8*>(smem + hb * BUF + (pfrag0 ^ (half << 6)) + t * 16 * ROWB); };
-#if U2_TILE_READS_FIRST
+#if U2_TILE_READS_FIRST || U2_TILE_PINGPONG
   // Fragment reads as inline asm with counted waits (KT = 1 only): the compiler answers a plain LDS load it must wait for with
   // s_waitcnt lgkmcnt(0) whenever LDS-DMA is in flight (it will not count across it), which forbids having a SECOND batch of reads in
   // flight while the first is consumed.  LDS returns in order, so `lgkmcnt(6)` with twelve reads outstanding releases the older six.
@@ -515,6 +518,11 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   U2_STAMP(1);
+#if U2_TILE_PINGPONG
+  if constexpr (KT == 1 && !ACC) {
+    // ping-pong form: both wave groups enter their first step "cold" (they read its fragments themselves)
+  } else
+#endif
 #if U2_TILE_READS_FIRST
   if constexpr (KT == 1) {
     // (asm like the reads of the loop: a compiler-visible LDS load pending at the loop header would make the wait-count pass put
@@ -769,7 +777,97 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       ++gh;
       hb = nb;
     };
+#if U2_TILE_PINGPONG
+    // Round 6 experiment (profiles/r06_tile_substep.txt): the two wave groups of the work-group - waves 0 .. NW/2-1 and the rest, one wave
+    // of each on every SIMD - run each HALF step in opposite order: group X stages and reads first and multiplies then, group Y
+    // multiplies first (on fragments it read at the end of the previous half) and stages / reads for the next half then, so that
+    // on every SIMD one wave issues LDS-DMA and LDS reads while the other owns the matrix pipe.  Half A = weight rows 0-1 x pixel
+    // fragments 0-7 (ten fragment reads), half B = weight rows 2-3 x the same pixel fragments (two reads).  One barrier per half:
+    // #1 (behind half A, with the counted vmcnt wait in front of it) publishes stage gh + 1 and frees the pixel region of this
+    // stage's buffer; #2 (end of the step) frees its weight region for the next step's weight staging.  Group Y does not read ahead
+    // across a tile boundary (the first step of a tile is "cold" for both groups): no fragment register is live in the epilogue.
+    // Same products into the same accumulators in the same K order as the lock-step form: bit-identical results.
+    auto step_pp = [&](bool first_of_tile, bool last_of_tile) {
+      constexpr bool FAST = false;
+      const int nb = (hb + 1 == RING) ? 0 : hb + 1;
+      const int sb = (hb == 0) ? RING - 1 : hb - 1;
+      const bool grp_x = w < NW / 2;
+      const bool cold = grp_x || first_of_tile;
+      const unsigned pa = lds_base + (unsigned)(hb * BUF + pfrag0), wa = lds_base + (unsigned)(hb * BUF + wfrag0);
+#define U2_PP_WAIT10()                                                                                                          \
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wfA[0]), "+v"(wfA[1]), "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3])::"memory");  \
+      asm volatile("" : "+v"(pf[4]), "+v"(pf[5]), "+v"(pf[6]), "+v"(pf[7])::"memory")
+#define U2_PP_MA()                                                                                                               \
+      U2_TILE_SETPRIO(1);                                                                                                        \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) { U2_T_MFMA(0, wfA[0], j); U2_T_MFMA(1, wfA[1], j); }                        \
+      U2_TILE_SETPRIO(0)
+#define U2_PP_MB()                                                                                                               \
+      U2_TILE_SETPRIO(1);                                                                                                        \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) { U2_T_MFMA(2, wfB[0], j); U2_T_MFMA(3, wfB[1], j); }                        \
+      U2_TILE_SETPRIO(0)
+      // ---------------- half A  (ONE copy of every MFMA group: the group-dependent pieces around them are reads and staging only)
+      if (cold) {
+        U2_T_RD(wfA[0], wa, 0); U2_T_RD(wfA[1], wa, 16 * ROWB);
+        U2_T_RD(pf[0], pa, 0); U2_T_RD(pf[1], pa, 16 * ROWB); U2_T_RD(pf[2], pa, 2 * 16 * ROWB); U2_T_RD(pf[3], pa, 3 * 16 * ROWB);
+        U2_T_RD(pf[4], pa, 4 * 16 * ROWB); U2_T_RD(pf[5], pa, 5 * 16 * ROWB); U2_T_RD(pf[6], pa, 6 * 16 * ROWB); U2_T_RD(pf[7], pa, 7 * 16 * ROWB);
+        if (gh + AHEAD < H) stage_weights(sb);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      U2_PP_WAIT10();   // cold: the reads just issued; otherwise the ones this wave issued at the end of the previous half B
+      U2_PP_MA();
+      __builtin_amdgcn_sched_barrier(0);
+      if (!cold) {
+        if (gh + AHEAD < H) stage_weights(sb);
+      }
+      if (!grp_x) { U2_T_RD(wfB[0], wa, 2 * 16 * ROWB); U2_T_RD(wfB[1], wa, 3 * 16 * ROWB); }   // group Y: half B's weights now
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const int rem = H - 2 - gh;  // stages staged behind gh + 1
+        if (rem >= AHEAD - 1) wait_vm<LPT * (AHEAD - 1)>();
+        else if (AHEAD > 3 && rem == 2) wait_vm<LPT * 2>();
+        else if (rem == 1) wait_vm<LPT>();
+        else wait_vm<0>();
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#ifdef U2_TILE_TRACE
+      if (gh < 44) U2_STAMP(2 + gh);
+#endif
+      // ---------------- half B
+      if (grp_x) {
+        U2_T_RD(wfB[0], wa, 2 * 16 * ROWB); U2_T_RD(wfB[1], wa, 3 * 16 * ROWB);
+        if (gh + AHEAD + 1 < H) stage_pixels(hb);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wfB[0]), "+v"(wfB[1])::"memory");
+      U2_PP_MB();
+      __builtin_amdgcn_sched_barrier(0);
+      if (!grp_x) {
+        if (gh + AHEAD + 1 < H) stage_pixels(hb);
+        if (!last_of_tile && gh + 1 < H) {   // next step's half A fragments (stage gh + 1: published by barrier #1)
+          const unsigned pn = lds_base + (unsigned)(nb * BUF + pfrag0), wn = lds_base + (unsigned)(nb * BUF + wfrag0);
+          U2_T_RD(wfA[0], wn, 0); U2_T_RD(wfA[1], wn, 16 * ROWB);
+          U2_T_RD(pf[0], pn, 0); U2_T_RD(pf[1], pn, 16 * ROWB); U2_T_RD(pf[2], pn, 2 * 16 * ROWB); U2_T_RD(pf[3], pn, 3 * 16 * ROWB);
+          U2_T_RD(pf[4], pn, 4 * 16 * ROWB); U2_T_RD(pf[5], pn, 5 * 16 * ROWB); U2_T_RD(pf[6], pn, 6 * 16 * ROWB); U2_T_RD(pf[7], pn, 7 * 16 * ROWB);
+        }
+      }
+      __builtin_amdgcn_s_barrier();   // #2: the weight region of this stage's buffer is free for the next step's weight staging
+      asm volatile("" ::: "memory");
+#undef U2_PP_WAIT10
+#undef U2_PP_MA
+#undef U2_PP_MB
+      ++gh;
+      hb = nb;
+    };
+#endif
     int h = h_begin;
+#if U2_TILE_PINGPONG
+    if constexpr (KT == 1 && !ACC) {
+      for (; h < h_end; ++h) step_pp(h == h_begin, h + 1 == h_end);
+    } else
+#endif
+    {
 #if U2_TILE_PEEL
     while (h < h_end) {
       int nfast = min(h_end - h, H - (AHEAD + 1) - gh);
@@ -779,6 +877,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #else
     for (; h < h_end; ++h) step(std::false_type{});
 #endif
+    }
     if constexpr (SK) {
       if (h_begin > 0) { U2_STAMP(48); sk_publish(); U2_STAMP(49); continue; }   // a non-leading part: handed to the tile's owner
       if (h_end < nkh) break;                                   // the owner collects the parts behind its own: below
