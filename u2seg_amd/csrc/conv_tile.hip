@@ -813,14 +813,18 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
         if (gh + AHEAD < H) stage_weights(sb);
       }
       __builtin_amdgcn_sched_barrier(0);
+      U2_SUBK(11);
       U2_PP_WAIT10();   // cold: the reads just issued; otherwise the ones this wave issued at the end of the previous half B
+      U2_SUBK(12);
       U2_PP_MA();
       __builtin_amdgcn_sched_barrier(0);
+      U2_SUBK(13);
       if (!cold) {
         if (gh + AHEAD < H) stage_weights(sb);
       }
       if (!grp_x) { U2_T_RD(wfB[0], wa, 2 * 16 * ROWB); U2_T_RD(wfB[1], wa, 3 * 16 * ROWB); }   // group Y: half B's weights now
       __builtin_amdgcn_sched_barrier(0);
+      U2_SUBK(14);
       {
         const int rem = H - 2 - gh;  // stages staged behind gh + 1
         if (rem >= AHEAD - 1) wait_vm<LPT * (AHEAD - 1)>();
@@ -833,6 +837,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
       asm volatile("" ::: "memory");
 #ifdef U2_TILE_TRACE
       if (gh < 44) U2_STAMP(2 + gh);
+      U2_SUB(0);
 #endif
       // ---------------- half B
       if (grp_x) {
@@ -840,9 +845,12 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
         if (gh + AHEAD + 1 < H) stage_pixels(hb);
       }
       __builtin_amdgcn_sched_barrier(0);
+      U2_SUBK(15);
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wfB[0]), "+v"(wfB[1])::"memory");
+      U2_SUBK(16);
       U2_PP_MB();
       __builtin_amdgcn_sched_barrier(0);
+      U2_SUBK(17);
       if (!grp_x) {
         if (gh + AHEAD + 1 < H) stage_pixels(hb);
         if (!last_of_tile && gh + 1 < H) {   // next step's half A fragments (stage gh + 1: published by barrier #1)
@@ -852,6 +860,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
           U2_T_RD(pf[4], pn, 4 * 16 * ROWB); U2_T_RD(pf[5], pn, 5 * 16 * ROWB); U2_T_RD(pf[6], pn, 6 * 16 * ROWB); U2_T_RD(pf[7], pn, 7 * 16 * ROWB);
         }
       }
+      U2_SUBK(18);
       __builtin_amdgcn_s_barrier();   // #2: the weight region of this stage's buffer is free for the next step's weight staging
       asm volatile("" ::: "memory");
 #undef U2_PP_WAIT10
@@ -968,12 +977,12 @@ void tile_trace_end(int G, hipStream_t s, const char* what) {
           double step = 0, off = 0; int ns = 0, no = 0;
           for (int k = 6; k < 30; ++k) {
             if (r[k] && r[k + 1]) { step += (double)(r[k + 1] - r[k]); ++ns; }
-            const int ref = (U2_TILE_TRACE_POINT >= 3) ? k - 1 : k;
+            const int ref = ((U2_TILE_TRACE_POINT >= 3 && U2_TILE_TRACE_POINT <= 6) || (U2_TILE_TRACE_POINT >= 11 && U2_TILE_TRACE_POINT <= 14)) ? k - 1 : k;
             if (r[48 + k] && r[ref] && r[48 + k] > r[ref]) { off += (double)(r[48 + k] - r[ref]); ++no; }
           }
           const unsigned long long* r0 = sb + ((size_t)g * 2) * 96;
           fprintf(stderr, "SUB point %d wg %4d wave %d: step %.0f cycles (n=%d), point at +%.0f cycles behind the %s barrier (n=%d), barrier of wave 4 - wave 0 at step 10: %lld\n",
-                  U2_TILE_TRACE_POINT, g, wv * 4, ns ? step / ns : -1.0, ns, no ? off / no : -1.0, U2_TILE_TRACE_POINT >= 3 ? "previous" : "same", no,
+                  U2_TILE_TRACE_POINT, g, wv * 4, ns ? step / ns : -1.0, ns, no ? off / no : -1.0, ((U2_TILE_TRACE_POINT >= 3 && U2_TILE_TRACE_POINT <= 6) || (U2_TILE_TRACE_POINT >= 11 && U2_TILE_TRACE_POINT <= 14)) ? "previous" : "same", no,
                   (long long)(r0[96 + 10]) - (long long)(r0[10]));
         }
       }
