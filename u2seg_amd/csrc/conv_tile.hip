@@ -73,7 +73,13 @@ __device__ unsigned long long* g_tile_sub_dev = nullptr;
 #define U2_TILE_SETPRIO(P) __builtin_amdgcn_s_setprio(P)
 #endif
 
+#ifdef U2_TILE_DMA_BY_HALF
+template <int N> __device__ __forceinline__ void wait_vm() {   // (the issuing half has twice the loads per stage in flight)
+  if ((threadIdx.x >> 6) < (blockDim.x >> 7)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * N > 63 ? 63 : 2 * N) : "memory");
+}
+#else
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#endif
 
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
@@ -159,6 +165,9 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 #ifndef U2_TILE_PINGPONG
 #define U2_TILE_PINGPONG 0
 #endif
+#ifndef U2_TILE_ROLES
+#define U2_TILE_ROLES 0
+#endif
 #ifndef U2_TILE_PEEL
 #define U2_TILE_PEEL 0   // measured: not faster (profiles/r06_tile_loop_experiments.txt)
 #endif
@@ -170,9 +179,16 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   constexpr int ROWB = 64 * KT;      // bytes per staged row
   constexpr int CPRW = ROWB / 16;    // 16-byte chunks per row
   constexpr int RPI = 1024 / ROWB;   // rows one LDS-DMA instruction moves
-  constexpr int LP = TM * CPRW / NT;   // 16-byte chunks a thread moves per stage, pixel operand
-  constexpr int LW = TN * CPRW / NT;   //                                         weight operand
-  constexpr int LPT = LP + LW;
+  // U2_TILE_ROLES (round 6, profiles/r06_tile_loop_experiments.txt item 8): in the eight-wave work-groups the WEIGHT operand is staged by
+  // waves 0-3 alone and the PIXEL operand by waves 4-7 alone (twice the rows per issuing thread), so that on every SIMD one wave
+  // issues a phase's four LDS-DMA instructions back to back while its partner goes on multiplying - an LDS-DMA instruction costs
+  // the issuing wave ~100+ cycles when both waves of a SIMD issue two each in the same phase.  Loads per wave and stage stay 4.
+  constexpr bool ROLES = U2_TILE_ROLES && NW == 8 && KT == 1;
+  constexpr int SNW = ROLES ? NW / 2 : NW;          // waves that stage one operand
+  constexpr int LP = TM * CPRW / (SNW * 64);        // 16-byte chunks an ISSUING thread moves per stage, pixel operand
+  constexpr int LW = TN * CPRW / (SNW * 64);        //                                                   weight operand
+  constexpr int LPT = ROLES ? LP : LP + LW;         // LDS-DMA instructions per wave and stage
+  static_assert(!ROLES || LP == LW, "the role split needs equally many pixel and weight rows per stage");
   constexpr int PBYTES = TM * ROWB, WBYTES = TN * ROWB, BUF = PBYTES + WBYTES;  // one stage: rows of KU bf16
   constexpr int AHEAD = RING - 1;
   static_assert(LP >= 1 && LW >= 1 && RING >= (KT == 2 ? 2 : 3) && RING <= 5 && (KT == 1 || KT == 2), "unsupported configuration");
@@ -181,6 +197,8 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sw_ = ROLES ? (w & (SNW - 1)) : w;            // this wave's index among the waves that stage an operand
+  const bool p_issuer = !ROLES || w >= SNW, w_issuer = !ROLES || w < SNW;
 #ifdef U2_TILE_TRACE
   const bool trace_on = w == 0 && g_tile_trace_dev != nullptr;
   unsigned long long* trace_row = g_tile_trace_dev + (size_t)blockIdx.x * 64;
@@ -239,7 +257,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     const int m0 = (tile / a.tiles_n) * TM;
 #pragma unroll
     for (int i = 0; i < LP; ++i) {
-      const int m = m0 + (i * NW + w) * RPI + row_in;
+      const int m = m0 + (i * SNW + sw_) * RPI + row_in;
       if (m < a.M) {
         if (linear) {
           p_center[i] = (unsigned)(((size_t)m * a.in_ld + cc * 8) * 2);
@@ -302,11 +320,26 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #else
     constexpr bool skip_p = false;
 #endif
+#ifdef U2_TILE_DMA_BY_HALF
+    // TIMING ONLY (wrong results): waves 0 .. NW/2-1 issue the staging instructions of the whole work-group - their own and, with
+    // their own source rows, their SIMD partner's - and the other waves issue none: does an LDS-DMA instruction cost less when one
+    // wave of a SIMD issues them back to back than when both waves issue two each?
+    if (w < NW / 2) {
+#pragma unroll
+      for (int i = 0; i < LP; ++i) {
+        glds16(p_src[i], base + (i * NW + w) * 1024);
+        glds16(p_src[i], base + (i * NW + w + NW / 2) * 1024);   // (ablation build: not combined with U2_TILE_ROLES)
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < LP; ++i) p_src[i] += (p_okmask >> i & 1u) * KU;
+#else
 #pragma unroll
     for (int i = 0; i < LP; ++i) {
-      if (!skip_p) glds16(p_src[i], base + (i * NW + w) * 1024);
+      if (!skip_p && p_issuer) glds16(p_src[i], base + (i * SNW + sw_) * 1024);
       p_src[i] += (p_okmask >> i & 1u) * KU;
     }
+#endif
   };
 
   // Weight rows: LDS row rho = blk * 16 + q of a wave's 64-channel slice holds channel
@@ -320,7 +353,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
     const int n0 = (tile % a.tiles_n) * TN;
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
-      const int R = (i * NW + w) * RPI + row_in;
+      const int R = (i * SNW + sw_) * RPI + row_in;
       const int blk = (R >> 4) & 3, q = R & 15;
       const int n = n0 + (R & ~63) + (blk >> 1) * 32 + (q >> 2) * 8 + (blk & 1) * 4 + (q & 3);
       w_base[i] = n < a.N ? (unsigned)(((size_t)n * ((size_t)a.wt_taps * a.C) + cc * 8) * 2) : 0xffffffffu;
@@ -351,11 +384,23 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #else
     constexpr bool skip_w = false;
 #endif
+#ifdef U2_TILE_DMA_BY_HALF
+    if (w < NW / 2) {
+#pragma unroll
+      for (int i = 0; i < LW; ++i) {
+        glds16(w_src[i], base + (i * NW + w) * 1024);
+        glds16(w_src[i], base + (i * NW + w + NW / 2) * 1024);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < LW; ++i) w_src[i] += w_base[i] != 0xffffffffu ? KU : 0;
+#else
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
-      if (!skip_w) glds16(w_src[i], base + (i * NW + w) * 1024);
+      if (!skip_w && w_issuer) glds16(w_src[i], base + (i * SNW + sw_) * 1024);
       w_src[i] += w_base[i] != 0xffffffffu ? KU : 0;
     }
+#endif
   };
 
   const int wr = w / WPX;  // 64-channel slice of the tile
@@ -514,7 +559,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 #pragma unroll
   for (int i = 0; i < AHEAD; ++i) { stage_pixels(i); stage_weights(i); }
   stage_pixels(AHEAD);
-  wait_vm<LPT * (AHEAD - 1) + LP>();
+  wait_vm<ROLES ? LPT * (AHEAD - 1) : LPT * (AHEAD - 1) + LP>();   // (ROLES: a weight wave has stages 0 .. AHEAD - 1 in flight, a pixel wave one more)
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   U2_STAMP(1);
