@@ -390,11 +390,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is what runs" % (args.gpus, world), file=sys.stderr)
+    # U2_BENCH_SHARE_GPU=1 (a smoke test of the N > 1 code path on a one-GPU box, never a measurement): every rank on cuda:0 over
+    # gloo - RCCL refuses two ranks on one device.  The line it prints says so in `data`.
+    share_gpu = world > 1 and os.environ.get("U2_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
 
     from u2seg_amd import _hip
 
@@ -610,6 +618,8 @@ def main():
         Fn.release_library_scratch()  # the conv library's own scratch (not visible to torch's allocator)
 
     out = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "vs_baseline": None, "data": "synthetic"}
+    if share_gpu:
+        out["data"] = "synthetic; SMOKE TEST of the multi-rank code path: %d ranks share cuda:0 over gloo (U2_BENCH_SHARE_GPU=1) - not a measurement" % world
     if args.workload == "train":
         out.update(run_train(args.steps, args.warmup))
     elif args.workload == "infer":
