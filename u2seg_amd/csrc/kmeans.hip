@@ -202,6 +202,9 @@ constexpr int KS_NB = 20;                    // 16-centroid blocks: 320 centroid
 constexpr int KS_KMAX = KS_NB * 16;
 constexpr int KS_STAGE = 2 * KS_KMAX * 64;   // [hi | lo][320 rows][32 bf16]
 constexpr int KS_RING = 3;
+#ifndef U2_KM_X3
+#define U2_KM_X3 1
+#endif
 constexpr int KS_DMA = KS_STAGE / 1024 / 8;  // LDS-DMA instructions per wave per step (5)
 
 // chl [2][320][D] bf16 (hi plane, lo plane; rows >= K zero), cn[j] = |c_j|^2 in fp32, *cmax2 = max_j cn[j]
@@ -273,12 +276,20 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
   // in flight lives in a register the compiler could move.  NP = 1 stages only the hi plane of the centroids (3 instead of 5
   // LDS-DMA instructions per wave and step: rows 320-383 of the stage are filler from the lo plane), ring of 3 as before; NP = 3
   // with XR keeps both planes in a ring of 2 (centroids(s + 1) requested at the start of step s, 144 KB in all).
+  // Round 6, X3 (coarse pass only, -DU2_KM_X3=0 restores the round-5 form): THREE x slots.  The coarse pass is bound by how many bytes of x
+  // a CU has in flight (3.8 TB/s with two steps = 64 KB); a third slot needs (i) the centroid stage without its filler rows - 320 rows
+  // x 64 B = 20 KB, twenty LDS-DMA instructions: waves 0-5 issue three, wave 6 two, wave 7 none - so that 3 x 20 + 3 x 32 KB = 156 KB
+  // fit, and (ii) the centroids of a step requested BEFORE the step's x: vmcnt retires in order, so with x(s + 2) queued in front of
+  // centroids(s + 1) the wait for the centroids waited for that x as well and a third slot bought nothing (round 5's note).  Issue
+  // order now: ... c(s + 1) x(s + 2) | c(s + 2) x(s + 3) | ...; the wait that closes step s leaves x(s + 2), c(s + 2), x(s + 3) in flight.
   constexpr bool XR = NP == 1 || XR3;
-  constexpr int CDMA = NP == 1 ? 3 : KS_DMA;           // centroid LDS-DMA instructions per wave and step
-  constexpr int CSTAGE = CDMA * 8 * 1024;              // bytes of a centroid stage
+  constexpr bool X3 = NP == 1 && U2_KM_X3;
+  constexpr int CDMA = NP == 1 ? 3 : KS_DMA;           // centroid LDS-DMA instructions per wave and step (X3: at most)
+  constexpr int CSTAGE = X3 ? KS_KMAX * 64 : CDMA * 8 * 1024;   // bytes of a centroid stage
   constexpr int CRING = (NP == 3 && XR) ? 2 : KS_RING; // centroid stages
   constexpr int XDMA = 4;                              // x: 32 rows x 128 bytes per wave and step
   constexpr int XSLOT = KS_PTS * 128;                  // bytes of an x slot of the work-group
+  constexpr int XSLOTS = X3 ? 3 : 2;
   unsigned char* const xring = ks_smem + CRING * CSTAGE;
 
   // x: lane (fr, fg) owns row m * 16 + fr of both 16-point blocks and, per 32-dimension step, dimensions fg * 4 .. + 3 and
@@ -341,10 +352,20 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
   auto stage_c = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < CDMA; ++i) {
-      __builtin_amdgcn_global_load_lds(U2_GLB_PTR(cp[i]), U2_LDS_PTR(ks_smem + buf * CSTAGE + (w * CDMA + i) * 1024), 16, 0, 0);
+      if (!X3 || w * CDMA + i < KS_NB)
+        __builtin_amdgcn_global_load_lds(U2_GLB_PTR(cp[i]), U2_LDS_PTR(ks_smem + buf * CSTAGE + (w * CDMA + i) * 1024), 16, 0, 0);
       cp[i] += 32;
     }
   };
+  // X3: centroid LDS-DMA instructions THIS wave issues per stage (the counted waits below are per wave)
+  const int cw = min(max(KS_NB - w * CDMA, 0), CDMA);
+  // s_waitcnt vmcnt(XDMA * NX + cw): cw is wave-uniform but not a compile-time constant
+#define U2_KS_WAIT_VM(NX)                                                                                                       \
+  do {                                                                                                                           \
+    if (cw == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDMA * (NX) + 3) : "memory");                                          \
+    else if (cw == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDMA * (NX) + 2) : "memory");                                     \
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDMA * (NX)) : "memory");                                                      \
+  } while (0)
   const unsigned lds0 = (unsigned)(size_t)U2_LDS_PTR(ks_smem);
   const int boff = fr * 64 + ((fg ^ ks_swz(fr)) << 4);  // B fragment of block nb, plane pl: + (pl * 320 + nb * 16) * 64
 
@@ -357,7 +378,16 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
 
   // in flight when step s begins: centroids(s + 1) only - centroids(s) and x(s) were waited for at the end of step s - 1
   // (NP = 1: x(s + 1) and centroids(s + 1))
-  if constexpr (XR && CRING == 3) {
+  if constexpr (X3) {
+    // issue order of the steady state from the start: x(0) | c(0) x(1) | c(1) x(2); complete before step 0: x(0), c(0)
+    stage_x(0);
+    stage_c(0);
+    if (nsteps > 1) { stage_x(1); stage_c(1); }
+    if (nsteps > 2) stage_x(2);
+    if (nsteps > 2) U2_KS_WAIT_VM(2);            // x(1), c(1), x(2) may be in flight
+    else if (nsteps > 1) U2_KS_WAIT_VM(1);       // x(1), c(1)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if constexpr (XR && CRING == 3) {
     stage_x(0);
     stage_c(0);
     if (nsteps > 1) {
@@ -397,15 +427,21 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     asm volatile("" ::: "memory");
     if constexpr (XR) {
       // this step's x out of the wave's slot; the slot is free for x(s + 2) once the reads have returned
-      const unsigned xs = (unsigned)(size_t)U2_LDS_PTR(xring) + (unsigned)((s & 1) * XSLOT);
+      const int xsl = X3 ? s % 3 : (s & 1);
+      const unsigned xs = (unsigned)(size_t)U2_LDS_PTR(xring) + (unsigned)(xsl * XSLOT);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(raw[m][0]), "=&v"(raw[m][1]) : "v"(xs + xrd[m]), "v"(xs + (xrd[m] ^ 64u)) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
-      if constexpr (CRING == 2) {   // centroids(s + 1) go first: the wait that closes the step leaves only x(s + 2) in flight
-        if (LOAD) stage_c((s + 1) & 1);
+      if constexpr (X3) {           // (LOAD: centroids(s + 2) exist, STAGE: x(s + 3) exists) centroids first, see the head comment
+        if (LOAD) stage_c((s + 2) % 3);
+        if (STAGE) stage_x(xsl);
+      } else {
+        if constexpr (CRING == 2) {   // centroids(s + 1) go first: the wait that closes the step leaves only x(s + 2) in flight
+          if (LOAD) stage_c((s + 1) & 1);
+        }
+        if (STAGE) stage_x(s & 1);
       }
-      if (STAGE) stage_x(s & 1);
     }
     // split this step's x into its two bf16 pieces (MFMA A operands)
     s16x8 ah[2], al[2];
@@ -426,7 +462,7 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     if constexpr (!XR) {
       if (LOAD) load_x();
     }
-    if constexpr (CRING == 3) {
+    if constexpr (CRING == 3 && !X3) {
       if (STAGE) stage_c((s + 2) % KS_RING);
     }
     // Two centroid blocks at a time, piece by piece: consecutive MFMAs go to four different accumulators, so the three products
@@ -491,14 +527,28 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
 #undef U2_KS_WAIT
 #undef U2_KS_LDQ
     // close the step: centroids(s + 1) and x(s + 1) have landed, only centroids(s + 2) stays in flight over the back-edge
+    if constexpr (X3) {
+      // complete behind this wait: everything up to c(s + 1), i.e. x(s + 1) and c(s + 1); may stay in flight: x(s + 2), c(s + 2), x(s + 3)
+      if (LOAD && STAGE) U2_KS_WAIT_VM(2);
+      else if (LOAD) U2_KS_WAIT_VM(1);                        // s = nsteps - 3: x(s + 2), c(s + 2)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
     if (STAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(!XR ? CDMA : CRING == 3 ? XDMA + CDMA : XDMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if constexpr (!XR) asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
   };
   int s = 0;
+  if constexpr (X3) {
+    for (; s + 3 < nsteps; ++s) step(s, std::true_type{}, std::true_type{});     // c(s + 2) and x(s + 3) exist
+    if (s + 2 < nsteps) { step(s, std::true_type{}, std::false_type{}); ++s; }   // s = nsteps - 3
+    if (s + 1 < nsteps) { step(s, std::false_type{}, std::false_type{}); ++s; }  // s = nsteps - 2
+    step(s, std::false_type{}, std::false_type{});
+  } else {
   for (; s + 2 < nsteps; ++s) step(s, std::true_type{}, std::true_type{});
   if (s + 1 < nsteps) { step(s, std::true_type{}, std::false_type{}); ++s; }
   step(s, std::false_type{}, std::false_type{});
+  }
   __syncthreads();
   // |x| per point: the four k-chunk lanes of a row, then through LDS into the D layout (lane (fg, fr): points fg * 4 + r)
   float* norms = reinterpret_cast<float*>(ks_smem);
@@ -816,7 +866,8 @@ extern "C" int u2_kmeans_assign(const float* x, const float* c, float* workspace
   }
   const dim3 grid((N + KS_PTS - 1) / KS_PTS), block(512);
   const size_t lds = KS_RING * KS_STAGE;                               // fine pass: both centroid planes, x through registers
-  const size_t lds1 = KS_RING * 3 * 8 * 1024 + 2 * KS_PTS * 128;      // coarse pass: hi plane (24 KB stages) + two x slots
+  const size_t lds1 = U2_KM_X3 ? (size_t)KS_RING * KS_KMAX * 64 + 3 * KS_PTS * 128     // coarse pass: hi plane (20 KB stages) + three x slots
+                               : (size_t)KS_RING * 3 * 8 * 1024 + 2 * KS_PTS * 128;   // round 5: 24 KB stages with filler rows + two x slots
   const size_t lds3 = 2 * KS_STAGE + 2 * KS_PTS * 128;                // fine pass with the x ring: two centroid stages + two x slots
   static const int xring3 = getenv("U2_KM_XRING3") ? atoi(getenv("U2_KM_XRING3")) : 1;   // measurement knob: 0 = x through registers
   const int* gate = reinterpret_cast<const int*>(state + 1);
