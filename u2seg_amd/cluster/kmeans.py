@@ -3,6 +3,9 @@
 ``run_kmeans`` mirrors the reference's ``run_kMeans`` / ``KMeans`` contract: initial centroids are
 ``x[randperm(N)[:K]]`` drawn from the CPU generator after ``torch.manual_seed(seed)``, a fixed number of iterations,
 no convergence test, empty clusters turn into NaN rows (the reference notes this at usl-imagenet.py:135)."""
+import os
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -22,11 +25,45 @@ def _update_workspace(n, d, k, device):
     return ws
 
 
+_shadow_cache = {}
+SHADOW = os.environ.get("U2_KM_SHADOW", "1") != "0"     # measurement switch: 0 = every E step reads the fp32 x
+SHADOW_MIN_POINTS = 1 << 16                             # below this the E step is a few microseconds either way
+
+
+def _shadow(x):
+    """bf16 shadow of x for the first screening pass (u2_kmeans_prepare), made once per tensor: the entry is keyed by the tensor
+    OBJECT (weak reference - a new tensor at a recycled address cannot match) and its version counter (any in-place write to the
+    storage, through any view, invalidates it)."""
+    n, d = x.shape
+    if not SHADOW or n < SHADOW_MIN_POINTS or d % 32 != 0:
+        return None
+    key = str(x.device)
+    ent = _shadow_cache.get(key)
+    if ent is not None and ent[0]() is x and ent[1] == x._version and ent[2] == (n, d):
+        return ent[3]
+    need = _hip.call_nostream("u2_kmeans_shadow_floats", n, d)
+    sh = ent[3] if ent is not None and ent[3].numel() >= need else None
+    _shadow_cache.pop(key, None)
+    if sh is None:
+        ent = None                                          # frees the old shadow before the new one is allocated
+        sh = torch.empty(need, dtype=torch.float32, device=x.device)
+    _hip.call("u2_kmeans_prepare", x, sh, n, d)
+    _shadow_cache[key] = (weakref.ref(x), x._version, (n, d), sh)
+    return sh
+
+
+def release_shadow():
+    """Drops the cached shadows (half the bytes of the x they were made from)."""
+    _shadow_cache.clear()
+
+
 def assign(x, c, exact=False):
-    """argmin_j sum_d (x_id - c_jd)^2 -> int64 [N] (u2_kmeans_assign: split-bf16 MFMA screening, exact-fp32 MFMA products for
-    the points it cannot decide; exact=True: the exact kernel for every point)."""
+    """argmin_j sum_d (x_id - c_jd)^2 -> int64 [N] (u2_kmeans_assign_shadow: split-bf16 MFMA screening - the first pass over a bf16
+    shadow of x that is made on the first call with a given x - and exact-fp32 MFMA products for the points it cannot decide;
+    exact=True: the exact kernel for every point)."""
     n, d = x.shape
     k = c.shape[0]
+    x = x.contiguous()
     labels = torch.empty(n, dtype=torch.int64, device=x.device)
     need = _hip.call_nostream("u2_kmeans_assign_workspace_floats", n, d, k)
     key = "assign:" + str(x.device)
@@ -35,7 +72,8 @@ def assign(x, c, exact=False):
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.float32, device=x.device)
     _ws_cache[key] = (ws, k)
-    _hip.call("u2_kmeans_assign", x.contiguous(), c.contiguous(), ws, labels, n, d, k, int(exact))
+    sh = None if exact or k < 2 or k > 320 else _shadow(x)
+    _hip.call("u2_kmeans_assign_shadow", x, sh, c.contiguous(), ws, labels, n, d, k, int(exact))
     return labels
 
 

@@ -245,6 +245,43 @@ __device__ __forceinline__ uint32_t ks_pack(float lo, float hi) {  // v_cvt_pk_b
 }
 __device__ __forceinline__ int ks_swz(int row) { return (-(row >> 2)) & 3; }  // 64-byte rows: conflict-free ds_read_b128
 
+// ---- the leading-bf16 shadow of x (round 6) ---------------------------------------------------------------------------------
+// x does not change between Lloyd iterations, and the coarse pass only ever uses bf16(x): u2_kmeans_prepare writes that once, in the
+// order the coarse pass consumes it, and every later E step streams 2 instead of 4 bytes per element (the values are the ones the
+// kernel packed on the fly before - same products, same labels).  Layout: [D / 32 steps][G groups of 16 points][64 lanes][8 bf16],
+// G = 16 * ceil(N / 256); the 16 bytes of lane (fg, fr) = fg * 16 + fr are point fr's positions fg * 8 .. + 7 of the step in
+// csplit_kernel's dimension order - a group is 1 KB, one LDS-DMA instruction, and lands in LDS as the MFMA A fragment of 16 points
+// (lane L reads byte L * 16: conflict-free by construction).  Points >= N are zero.  Behind it: |x_p| in fp32, [G * 16].
+__global__ __launch_bounds__(256) void km_shadow_kernel(const float* __restrict__ x, uint4* __restrict__ xh, int N, int D, int G) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = (int)(t & 63), fr = lane & 15, fg = lane >> 4;
+  const size_t gi = t >> 6;                     // step * G + group
+  const int step = (int)(gi / (size_t)G), g = (int)(gi % (size_t)G);
+  if (step >= (D >> 5)) return;
+  const int p = g * 16 + fr;
+  float4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+  if (p < N) {
+    const float* src = x + (size_t)p * D + step * 32 + fg * 4;
+    a = *reinterpret_cast<const float4*>(src);
+    b = *reinterpret_cast<const float4*>(src + 16);
+  }
+  uint4 o;
+  o.x = ks_pack(a.x, a.y); o.y = ks_pack(a.z, a.w); o.z = ks_pack(b.x, b.y); o.w = ks_pack(b.z, b.w);
+  xh[t] = o;
+}
+__global__ __launch_bounds__(256) void km_xnorm_kernel(const float* __restrict__ x, float* __restrict__ xn, int N, int D, int NP16) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= NP16) return;
+  float s = 0.f;
+  if (p < N)
+    for (int d = (threadIdx.x & 63) * 4; d < D; d += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * D + d);
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) xn[p] = sqrtf(s);
+}
+
 // NP = 3: the three products hi.hi + hi.lo + lo.hi (error <= 1.2e-5 |x| |c|, margin_rel 1e-4).  NP = 1 (round 4): hi.hi only - a
 // third of the matrix work, error <= 2^-8 |x| |c| per product (both operands rounded to bf16), i.e. 2^-6 |x| max|c| between two
 // distances; with margin_rel 0.02 (1.28 x that worst case) it decides every point of well-separated data (the mixture: own
@@ -252,13 +289,22 @@ __device__ __forceinline__ int ks_swz(int row) { return (-(row >> 2)) & 3; }  //
 // rows / nrows: the kernel labels the points rows[0 .. *nrows) (the undecided list of the coarser pass) instead of 0 .. N - 1.
 // gate / gate_want: the launch is skipped (work-groups leave at once) unless (*gate == 1) == gate_want - the host queues the
 // coarse pass, the fine pass over its list and the fine pass over everything, and a flag in the workspace picks two of the three.
-template <int NP, bool XR3 = false>
+// SH (round 6, coarse pass over all points): x is the bf16 shadow written by u2_kmeans_prepare (layout at km_shadow_kernel) and
+// xnorm the |x_p| behind it.  Half the bytes per step - and the LDS-DMA queues are split by wave so that more of them can be in
+// flight: vmcnt retires in order, so a wave that requests both centroids and x can never wait for "the centroids of the next step"
+// without also waiting for every x it requested before them (two steps of slack at most, whatever the ring depth).  With SH waves
+// 0-3 request the centroid stages (five instructions each, ring of three 20 KB stages) and waves 4-7 the x slots of the whole
+// work-group (four 1 KB groups each, ring of six 16 KB slots): the x waves wait for x(s + 1) only and leave x(s + 2 .. s + 5)
+// in flight - 64 KB of bf16 per CU, what used to be 128 KB of fp32 - and the step-start barrier publishes both to all eight waves.
+template <int NP, bool XR3 = false, bool SH = false>
 __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restrict__ x, const bf16_t* __restrict__ chl,
                                                             const float* __restrict__ cn, const unsigned* __restrict__ cmax2,
                                                             long long* __restrict__ labels, int* __restrict__ list,
                                                             int* __restrict__ nlist, int N, int D, int K, float margin_rel,
                                                             const int* __restrict__ rows, const int* __restrict__ nrows,
-                                                            const int* __restrict__ gate, int gate_want) {
+                                                            const int* __restrict__ gate, int gate_want,
+                                                            const float* __restrict__ xnorm) {
+  static_assert(!SH || (NP == 1 && !XR3), "the shadow is the coarse pass's");
   extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
   if (gate && (*gate == 1) != (gate_want != 0)) return;
   if (rows) {
@@ -282,10 +328,12 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
   // fit, and (ii) the centroids of a step requested BEFORE the step's x: vmcnt retires in order, so with x(s + 2) queued in front of
   // centroids(s + 1) the wait for the centroids waited for that x as well and a third slot bought nothing (round 5's note).  Issue
   // order now: ... c(s + 1) x(s + 2) | c(s + 2) x(s + 3) | ...; the wait that closes step s leaves x(s + 2), c(s + 2), x(s + 3) in flight.
-  constexpr bool XR = NP == 1 || XR3;
-  constexpr bool X3 = NP == 1 && U2_KM_X3;
-  constexpr int CDMA = NP == 1 ? 3 : KS_DMA;           // centroid LDS-DMA instructions per wave and step (X3: at most)
-  constexpr int CSTAGE = X3 ? KS_KMAX * 64 : CDMA * 8 * 1024;   // bytes of a centroid stage
+  constexpr bool XR = (NP == 1 || XR3) && !SH;
+  constexpr bool X3 = NP == 1 && U2_KM_X3 && !SH;
+  constexpr int CDMA = SH ? 5 : NP == 1 ? 3 : KS_DMA;  // centroid LDS-DMA instructions per (requesting) wave and step (X3: at most)
+  constexpr int CSTAGE = (X3 || SH) ? KS_KMAX * 64 : CDMA * 8 * 1024;   // bytes of a centroid stage
+  constexpr int SHR = 6;                               // SH: x slots of the work-group ...
+  constexpr int SHSLOT = KS_PTS * 64;                  // ... of 16 groups x 1 KB
   constexpr int CRING = (NP == 3 && XR) ? 2 : KS_RING; // centroid stages
   constexpr int XDMA = 4;                              // x: 32 rows x 128 bytes per wave and step
   constexpr int XSLOT = KS_PTS * 128;                  // bytes of an x slot of the work-group
@@ -357,6 +405,34 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
       cp[i] += 32;
     }
   };
+  // SH: waves 0-3 use cp / stage_c as they are (rows (w * 5 + i) * 16 .. + 15); waves 4-7 request groups (w - 4) * 4 .. + 3 of the
+  // work-group's sixteen, one step of the shadow is gridDim.x * 16 KB further on
+  const bool xrole = SH && w >= 4;
+  const unsigned char* xg[4];
+  if constexpr (SH) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      xg[q] = reinterpret_cast<const unsigned char*>(x) + ((size_t)blockIdx.x * 16 + (size_t)((w & 3) * 4 + q)) * 1024 + lane * 16;
+  }
+  const size_t xgstep = (size_t)gridDim.x * 16 * 1024;
+  auto stage_x_sh = [&](int slot) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_global_load_lds(U2_GLB_PTR(xg[q]), U2_LDS_PTR(xring + slot * SHSLOT + ((w & 3) * 4 + q) * 1024), 16, 0, 0);
+      xg[q] += xgstep;
+    }
+  };
+  // s_waitcnt vmcnt(n) for a wave-uniform n that is not a compile-time constant (the x waves of SH near the end of the loop)
+  auto wait_vm_x = [&](int steps_in_flight) {
+    switch (steps_in_flight) {
+      case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
+  static_assert(SHR - 2 == 4, "wait_vm_x covers 0 .. SHR - 2 steps of x in flight");
   // X3: centroid LDS-DMA instructions THIS wave issues per stage (the counted waits below are per wave)
   const int cw = min(max(KS_NB - w * CDMA, 0), CDMA);
   // s_waitcnt vmcnt(XDMA * NX + cw): cw is wave-uniform but not a compile-time constant
@@ -378,7 +454,21 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
 
   // in flight when step s begins: centroids(s + 1) only - centroids(s) and x(s) were waited for at the end of step s - 1
   // (NP = 1: x(s + 1) and centroids(s + 1))
-  if constexpr (X3) {
+  if constexpr (SH) {
+    if (!xrole) {                                  // c(0), c(1); complete before step 0: c(0)
+      stage_c(0);
+      if (nsteps > 1) {
+        stage_c(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CDMA) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    } else {                                       // x(0 .. SHR - 2) (step s requests x(s + SHR - 1)); complete before step 0: x(0)
+      const int npre = min(SHR - 1, nsteps);
+      for (int j = 0; j < npre; ++j) stage_x_sh(j);
+      wait_vm_x(npre - 1);
+    }
+  } else if constexpr (X3) {
     // issue order of the steady state from the start: x(0) | c(0) x(1) | c(1) x(2); complete before step 0: x(0), c(0)
     stage_x(0);
     stage_c(0);
@@ -425,6 +515,20 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     constexpr bool LOAD = decltype(load_tag)::value, STAGE = decltype(stage_tag)::value;
     __builtin_amdgcn_s_barrier();  // stage s is complete for every wave, and every wave is done with stage s - 1
     asm volatile("" ::: "memory");
+    s16x8 ah[2], al[2];
+    if constexpr (SH) {
+      // this step's A fragments as they lie in the slot; then the requests of the step: the stage / slot they go to was read in
+      // step s - 1 by every wave, which the barrier above has seen
+      const unsigned xs = (unsigned)(size_t)U2_LDS_PTR(xring) + (unsigned)((s % SHR) * SHSLOT + w * 2048 + lane * 16);
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(ah[0]), "=&v"(ah[1]) : "v"(xs) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(ah[1])::"memory");
+      al[0] = al[1] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (!xrole) {
+        if (s + 2 < nsteps) stage_c((s + 2) % 3);
+      } else {
+        if (s + SHR - 1 < nsteps) stage_x_sh((s + SHR - 1) % SHR);
+      }
+    }
     if constexpr (XR) {
       // this step's x out of the wave's slot; the slot is free for x(s + 2) once the reads have returned
       const int xsl = X3 ? s % 3 : (s & 1);
@@ -444,7 +548,7 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
       }
     }
     // split this step's x into its two bf16 pieces (MFMA A operands)
-    s16x8 ah[2], al[2];
+    if constexpr (!SH) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       uint32_t h[4], l[4];
@@ -459,10 +563,11 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
       ah[m] = *reinterpret_cast<const s16x8*>(h);
       al[m] = *reinterpret_cast<const s16x8*>(l);
     }
-    if constexpr (!XR) {
+    }
+    if constexpr (!XR && !SH) {
       if (LOAD) load_x();
     }
-    if constexpr (CRING == 3 && !X3) {
+    if constexpr (CRING == 3 && !X3 && !SH) {
       if (STAGE) stage_c((s + 2) % KS_RING);
     }
     // Two centroid blocks at a time, piece by piece: consecutive MFMAs go to four different accumulators, so the three products
@@ -527,7 +632,15 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
 #undef U2_KS_WAIT
 #undef U2_KS_LDQ
     // close the step: centroids(s + 1) and x(s + 1) have landed, only centroids(s + 2) stays in flight over the back-edge
-    if constexpr (X3) {
+    if constexpr (SH) {
+      // the centroid waves leave c(s + 2) in flight, the x waves x(s + 2 .. s + SHR - 1) as far as they exist
+      if (!xrole) {
+        if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        wait_vm_x(min(max(nsteps - s - 2, 0), SHR - 2));
+      }
+    } else if constexpr (X3) {
       // complete behind this wait: everything up to c(s + 1), i.e. x(s + 1) and c(s + 1); may stay in flight: x(s + 2), c(s + 2), x(s + 3)
       if (LOAD && STAGE) U2_KS_WAIT_VM(2);
       else if (LOAD) U2_KS_WAIT_VM(1);                        // s = nsteps - 3: x(s + 2), c(s + 2)
@@ -536,10 +649,12 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     if (STAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(!XR ? CDMA : CRING == 3 ? XDMA + CDMA : XDMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if constexpr (!XR) asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
+    if constexpr (!XR && !SH) asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
   };
   int s = 0;
-  if constexpr (X3) {
+  if constexpr (SH) {
+    for (; s < nsteps; ++s) step(s, std::true_type{}, std::true_type{});
+  } else if constexpr (X3) {
     for (; s + 3 < nsteps; ++s) step(s, std::true_type{}, std::true_type{});     // c(s + 2) and x(s + 3) exist
     if (s + 2 < nsteps) { step(s, std::true_type{}, std::false_type{}); ++s; }   // s = nsteps - 3
     if (s + 1 < nsteps) { step(s, std::false_type{}, std::false_type{}); ++s; }  // s = nsteps - 2
@@ -557,7 +672,9 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     float v = n2[m];
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
-    if (fg == 0) norms[w * 32 + m * 16 + fr] = sqrtf(v);
+    if constexpr (SH) v = xnorm[p0 + m * 16 + fr];     // |x_p| from u2_kmeans_prepare, padded to the grid
+    else v = sqrtf(v);
+    if (fg == 0) norms[w * 32 + m * 16 + fr] = v;
   }
   __syncthreads();
   const float margin_unit = margin_rel * sqrtf(__uint_as_float(*cmax2));
@@ -833,8 +950,33 @@ extern "C" long long u2_kmeans_assign_workspace_floats(int N, int D, int K) {
   return (long long)K + 16 + (long long)KS_KMAX * D + 2LL * N + 32;
 }
 
+// words (floats) of the bf16 shadow itself; |x_p| follows it
+static size_t km_shadow_words(int N, int D) { return (size_t)(D >> 5) * (size_t)((N + KS_PTS - 1) / KS_PTS) * 16 * 256; }
+
+extern "C" long long u2_kmeans_shadow_floats(int N, int D) {
+  if (N <= 0 || D % 32 != 0) return 0;
+  return (long long)(km_shadow_words(N, D) + (size_t)((N + KS_PTS - 1) / KS_PTS) * KS_PTS);
+}
+
+extern "C" int u2_kmeans_prepare(const float* x, float* shadow, int N, int D, void* stream) {
+  if (N <= 0 || D % 32 != 0 || !shadow) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const int G = ((N + KS_PTS - 1) / KS_PTS) * 16;
+  const size_t threads = (size_t)(D >> 5) * G * 64;
+  hipLaunchKernelGGL(km_shadow_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, reinterpret_cast<uint4*>(shadow), N, D, G);
+  U2_CHECK_LAUNCH();
+  hipLaunchKernelGGL(km_xnorm_kernel, dim3((G * 16 + 3) / 4), dim3(256), 0, s, x, shadow + km_shadow_words(N, D), N, D, G * 16);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int u2_kmeans_assign(const float* x, const float* c, float* workspace, long long* labels, int N, int D, int K,
                                 int exact_only, void* stream) {
+  return u2_kmeans_assign_shadow(x, nullptr, c, workspace, labels, N, D, K, exact_only, stream);
+}
+
+extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, const float* c, float* workspace, long long* labels, int N,
+                                       int D, int K, int exact_only, void* stream) {
   if (D % KM_BD != 0 || K < 1 || !workspace) return -1;
   if (N <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
@@ -863,35 +1005,42 @@ extern "C" int u2_kmeans_assign(const float* x, const float* c, float* workspace
     (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const dim3 grid((N + KS_PTS - 1) / KS_PTS), block(512);
   const size_t lds = KS_RING * KS_STAGE;                               // fine pass: both centroid planes, x through registers
   const size_t lds1 = U2_KM_X3 ? (size_t)KS_RING * KS_KMAX * 64 + 3 * KS_PTS * 128     // coarse pass: hi plane (20 KB stages) + three x slots
                                : (size_t)KS_RING * 3 * 8 * 1024 + 2 * KS_PTS * 128;   // round 5: 24 KB stages with filler rows + two x slots
+  const size_t lds_sh = (size_t)KS_RING * KS_KMAX * 64 + 6 * KS_PTS * 64;   // coarse pass over the shadow: 3 x 20 KB + six 16 KB x slots
   const size_t lds3 = 2 * KS_STAGE + 2 * KS_PTS * 128;                // fine pass with the x ring: two centroid stages + two x slots
   static const int xring3 = getenv("U2_KM_XRING3") ? atoi(getenv("U2_KM_XRING3")) : 1;   // measurement knob: 0 = x through registers
   const int* gate = reinterpret_cast<const int*>(state + 1);
   static const int two_level = getenv("U2_KM_ONE_LEVEL") ? 0 : 1;   // measurement knob: the round-3 single (fine) pass
   if (two_level) {
     // coarse pass over everything -> list1; fine pass over list1 -> list2 (both skipped while the coarse pass is switched off)
+    if (shadow) {
+      const float* xn = shadow + km_shadow_words(N, D);
+      hipLaunchKernelGGL((kmeans_screen_kernel<1, false, true>), grid, block, lds_sh, s, shadow, chl, cn, scal, labels, list1,
+                         reinterpret_cast<int*>(scal + 2), N, D, K, 0.02f, (const int*)nullptr, (const int*)nullptr, gate, 0, xn);
+    } else
     hipLaunchKernelGGL(kmeans_screen_kernel<1>, grid, block, lds1, s, x, chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D,
-                       K, 0.02f, (const int*)nullptr, (const int*)nullptr, gate, 0);
+                       K, 0.02f, (const int*)nullptr, (const int*)nullptr, gate, 0, (const float*)nullptr);
     U2_CHECK_LAUNCH();
     if (xring3)
       hipLaunchKernelGGL((kmeans_screen_kernel<3, true>), grid, block, lds3, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1),
-                         N, D, K, 1e-4f, (const int*)list1, reinterpret_cast<const int*>(scal + 2), gate, 0);
+                         N, D, K, 1e-4f, (const int*)list1, reinterpret_cast<const int*>(scal + 2), gate, 0, (const float*)nullptr);
     else
       hipLaunchKernelGGL(kmeans_screen_kernel<3>, grid, block, lds, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N, D,
-                         K, 1e-4f, (const int*)list1, reinterpret_cast<const int*>(scal + 2), gate, 0);
+                         K, 1e-4f, (const int*)list1, reinterpret_cast<const int*>(scal + 2), gate, 0, (const float*)nullptr);
     U2_CHECK_LAUNCH();
   }
   // fine pass over everything -> list2 (the only pass while the coarse one is switched off)
   if (xring3)
     hipLaunchKernelGGL((kmeans_screen_kernel<3, true>), grid, block, lds3, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N,
-                       D, K, 1e-4f, (const int*)nullptr, (const int*)nullptr, two_level ? gate : (const int*)nullptr, 1);
+                       D, K, 1e-4f, (const int*)nullptr, (const int*)nullptr, two_level ? gate : (const int*)nullptr, 1, (const float*)nullptr);
   else
     hipLaunchKernelGGL(kmeans_screen_kernel<3>, grid, block, lds, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N, D, K,
-                       1e-4f, (const int*)nullptr, (const int*)nullptr, two_level ? gate : (const int*)nullptr, 1);
+                       1e-4f, (const int*)nullptr, (const int*)nullptr, two_level ? gate : (const int*)nullptr, 1, (const float*)nullptr);
   U2_CHECK_LAUNCH();
   // the undecided points, exactly; the grid covers the worst case, work-groups beyond the list return immediately
   hipLaunchKernelGGL(kmeans_assign_kernel, dim3((N + KM_PTS - 1) / KM_PTS), dim3(256), 0, s, x, c, cn, labels, N, D, K,
