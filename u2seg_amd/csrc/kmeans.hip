@@ -289,22 +289,13 @@ __global__ __launch_bounds__(256) void km_xnorm_kernel(const float* __restrict__
 // rows / nrows: the kernel labels the points rows[0 .. *nrows) (the undecided list of the coarser pass) instead of 0 .. N - 1.
 // gate / gate_want: the launch is skipped (work-groups leave at once) unless (*gate == 1) == gate_want - the host queues the
 // coarse pass, the fine pass over its list and the fine pass over everything, and a flag in the workspace picks two of the three.
-// SH (round 6, coarse pass over all points): x is the bf16 shadow written by u2_kmeans_prepare (layout at km_shadow_kernel) and
-// xnorm the |x_p| behind it.  Half the bytes per step - and the LDS-DMA queues are split by wave so that more of them can be in
-// flight: vmcnt retires in order, so a wave that requests both centroids and x can never wait for "the centroids of the next step"
-// without also waiting for every x it requested before them (two steps of slack at most, whatever the ring depth).  With SH waves
-// 0-3 request the centroid stages (five instructions each, ring of three 20 KB stages) and waves 4-7 the x slots of the whole
-// work-group (four 1 KB groups each, ring of six 16 KB slots): the x waves wait for x(s + 1) only and leave x(s + 2 .. s + 5)
-// in flight - 64 KB of bf16 per CU, what used to be 128 KB of fp32 - and the step-start barrier publishes both to all eight waves.
-template <int NP, bool XR3 = false, bool SH = false>
+template <int NP, bool XR3 = false>
 __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restrict__ x, const bf16_t* __restrict__ chl,
                                                             const float* __restrict__ cn, const unsigned* __restrict__ cmax2,
                                                             long long* __restrict__ labels, int* __restrict__ list,
                                                             int* __restrict__ nlist, int N, int D, int K, float margin_rel,
                                                             const int* __restrict__ rows, const int* __restrict__ nrows,
-                                                            const int* __restrict__ gate, int gate_want,
-                                                            const float* __restrict__ xnorm) {
-  static_assert(!SH || (NP == 1 && !XR3), "the shadow is the coarse pass's");
+                                                            const int* __restrict__ gate, int gate_want) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
   if (gate && (*gate == 1) != (gate_want != 0)) return;
   if (rows) {
@@ -328,12 +319,10 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
   // fit, and (ii) the centroids of a step requested BEFORE the step's x: vmcnt retires in order, so with x(s + 2) queued in front of
   // centroids(s + 1) the wait for the centroids waited for that x as well and a third slot bought nothing (round 5's note).  Issue
   // order now: ... c(s + 1) x(s + 2) | c(s + 2) x(s + 3) | ...; the wait that closes step s leaves x(s + 2), c(s + 2), x(s + 3) in flight.
-  constexpr bool XR = (NP == 1 || XR3) && !SH;
-  constexpr bool X3 = NP == 1 && U2_KM_X3 && !SH;
-  constexpr int CDMA = SH ? 5 : NP == 1 ? 3 : KS_DMA;  // centroid LDS-DMA instructions per (requesting) wave and step (X3: at most)
-  constexpr int CSTAGE = (X3 || SH) ? KS_KMAX * 64 : CDMA * 8 * 1024;   // bytes of a centroid stage
-  constexpr int SHR = 6;                               // SH: x slots of the work-group ...
-  constexpr int SHSLOT = KS_PTS * 64;                  // ... of 16 groups x 1 KB
+  constexpr bool XR = NP == 1 || XR3;
+  constexpr bool X3 = NP == 1 && U2_KM_X3;
+  constexpr int CDMA = NP == 1 ? 3 : KS_DMA;           // centroid LDS-DMA instructions per wave and step (X3: at most)
+  constexpr int CSTAGE = X3 ? KS_KMAX * 64 : CDMA * 8 * 1024;   // bytes of a centroid stage
   constexpr int CRING = (NP == 3 && XR) ? 2 : KS_RING; // centroid stages
   constexpr int XDMA = 4;                              // x: 32 rows x 128 bytes per wave and step
   constexpr int XSLOT = KS_PTS * 128;                  // bytes of an x slot of the work-group
@@ -405,34 +394,6 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
       cp[i] += 32;
     }
   };
-  // SH: waves 0-3 use cp / stage_c as they are (rows (w * 5 + i) * 16 .. + 15); waves 4-7 request groups (w - 4) * 4 .. + 3 of the
-  // work-group's sixteen, one step of the shadow is gridDim.x * 16 KB further on
-  const bool xrole = SH && w >= 4;
-  const unsigned char* xg[4];
-  if constexpr (SH) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      xg[q] = reinterpret_cast<const unsigned char*>(x) + ((size_t)blockIdx.x * 16 + (size_t)((w & 3) * 4 + q)) * 1024 + lane * 16;
-  }
-  const size_t xgstep = (size_t)gridDim.x * 16 * 1024;
-  auto stage_x_sh = [&](int slot) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      __builtin_amdgcn_global_load_lds(U2_GLB_PTR(xg[q]), U2_LDS_PTR(xring + slot * SHSLOT + ((w & 3) * 4 + q) * 1024), 16, 0, 0);
-      xg[q] += xgstep;
-    }
-  };
-  // s_waitcnt vmcnt(n) for a wave-uniform n that is not a compile-time constant (the x waves of SH near the end of the loop)
-  auto wait_vm_x = [&](int steps_in_flight) {
-    switch (steps_in_flight) {
-      case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-  };
-  static_assert(SHR - 2 == 4, "wait_vm_x covers 0 .. SHR - 2 steps of x in flight");
   // X3: centroid LDS-DMA instructions THIS wave issues per stage (the counted waits below are per wave)
   const int cw = min(max(KS_NB - w * CDMA, 0), CDMA);
   // s_waitcnt vmcnt(XDMA * NX + cw): cw is wave-uniform but not a compile-time constant
@@ -454,21 +415,7 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
 
   // in flight when step s begins: centroids(s + 1) only - centroids(s) and x(s) were waited for at the end of step s - 1
   // (NP = 1: x(s + 1) and centroids(s + 1))
-  if constexpr (SH) {
-    if (!xrole) {                                  // c(0), c(1); complete before step 0: c(0)
-      stage_c(0);
-      if (nsteps > 1) {
-        stage_c(1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CDMA) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    } else {                                       // x(0 .. SHR - 2) (step s requests x(s + SHR - 1)); complete before step 0: x(0)
-      const int npre = min(SHR - 1, nsteps);
-      for (int j = 0; j < npre; ++j) stage_x_sh(j);
-      wait_vm_x(npre - 1);
-    }
-  } else if constexpr (X3) {
+  if constexpr (X3) {
     // issue order of the steady state from the start: x(0) | c(0) x(1) | c(1) x(2); complete before step 0: x(0), c(0)
     stage_x(0);
     stage_c(0);
@@ -515,20 +462,6 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     constexpr bool LOAD = decltype(load_tag)::value, STAGE = decltype(stage_tag)::value;
     __builtin_amdgcn_s_barrier();  // stage s is complete for every wave, and every wave is done with stage s - 1
     asm volatile("" ::: "memory");
-    s16x8 ah[2], al[2];
-    if constexpr (SH) {
-      // this step's A fragments as they lie in the slot; then the requests of the step: the stage / slot they go to was read in
-      // step s - 1 by every wave, which the barrier above has seen
-      const unsigned xs = (unsigned)(size_t)U2_LDS_PTR(xring) + (unsigned)((s % SHR) * SHSLOT + w * 2048 + lane * 16);
-      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(ah[0]), "=&v"(ah[1]) : "v"(xs) : "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(ah[1])::"memory");
-      al[0] = al[1] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (!xrole) {
-        if (s + 2 < nsteps) stage_c((s + 2) % 3);
-      } else {
-        if (s + SHR - 1 < nsteps) stage_x_sh((s + SHR - 1) % SHR);
-      }
-    }
     if constexpr (XR) {
       // this step's x out of the wave's slot; the slot is free for x(s + 2) once the reads have returned
       const int xsl = X3 ? s % 3 : (s & 1);
@@ -548,7 +481,7 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
       }
     }
     // split this step's x into its two bf16 pieces (MFMA A operands)
-    if constexpr (!SH) {
+    s16x8 ah[2], al[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       uint32_t h[4], l[4];
@@ -563,11 +496,10 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
       ah[m] = *reinterpret_cast<const s16x8*>(h);
       al[m] = *reinterpret_cast<const s16x8*>(l);
     }
-    }
-    if constexpr (!XR && !SH) {
+    if constexpr (!XR) {
       if (LOAD) load_x();
     }
-    if constexpr (CRING == 3 && !X3 && !SH) {
+    if constexpr (CRING == 3 && !X3) {
       if (STAGE) stage_c((s + 2) % KS_RING);
     }
     // Two centroid blocks at a time, piece by piece: consecutive MFMAs go to four different accumulators, so the three products
@@ -632,15 +564,7 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
 #undef U2_KS_WAIT
 #undef U2_KS_LDQ
     // close the step: centroids(s + 1) and x(s + 1) have landed, only centroids(s + 2) stays in flight over the back-edge
-    if constexpr (SH) {
-      // the centroid waves leave c(s + 2) in flight, the x waves x(s + 2 .. s + SHR - 1) as far as they exist
-      if (!xrole) {
-        if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {
-        wait_vm_x(min(max(nsteps - s - 2, 0), SHR - 2));
-      }
-    } else if constexpr (X3) {
+    if constexpr (X3) {
       // complete behind this wait: everything up to c(s + 1), i.e. x(s + 1) and c(s + 1); may stay in flight: x(s + 2), c(s + 2), x(s + 3)
       if (LOAD && STAGE) U2_KS_WAIT_VM(2);
       else if (LOAD) U2_KS_WAIT_VM(1);                        // s = nsteps - 3: x(s + 2), c(s + 2)
@@ -649,12 +573,10 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     if (STAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(!XR ? CDMA : CRING == 3 ? XDMA + CDMA : XDMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if constexpr (!XR && !SH) asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
+    if constexpr (!XR) asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])::"memory");
   };
   int s = 0;
-  if constexpr (SH) {
-    for (; s < nsteps; ++s) step(s, std::true_type{}, std::true_type{});
-  } else if constexpr (X3) {
+  if constexpr (X3) {
     for (; s + 3 < nsteps; ++s) step(s, std::true_type{}, std::true_type{});     // c(s + 2) and x(s + 3) exist
     if (s + 2 < nsteps) { step(s, std::true_type{}, std::false_type{}); ++s; }   // s = nsteps - 3
     if (s + 1 < nsteps) { step(s, std::false_type{}, std::false_type{}); ++s; }  // s = nsteps - 2
@@ -672,9 +594,7 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     float v = n2[m];
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
-    if constexpr (SH) v = xnorm[p0 + m * 16 + fr];     // |x_p| from u2_kmeans_prepare, padded to the grid
-    else v = sqrtf(v);
-    if (fg == 0) norms[w * 32 + m * 16 + fr] = v;
+    if (fg == 0) norms[w * 32 + m * 16 + fr] = sqrtf(v);
   }
   __syncthreads();
   const float margin_unit = margin_rel * sqrtf(__uint_as_float(*cmax2));
@@ -739,6 +659,237 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
   }
 }
 
+
+// ---- coarse pass over the shadow (round 6) ----------------------------------------------------------------------------------------
+// hi.hi only, all points, x from the bf16 shadow (km_shadow_kernel) - the first pass of the two-level screening when a shadow is given;
+// same products, margin and list as kmeans_screen_kernel<1>, so the labels and the undecided set are the same.  What differs:
+//  * Wave tile 64 points x 160 centroids (waves (pg, ch) = (w >> 1, w & 1)) instead of 32 x 320: with one MFMA per (point block,
+//    centroid block, step) the 32 x 320 tile reads 20 KB of centroid fragments out of LDS per wave and step for 40 MFMAs - 160 KB per
+//    CU and step, 1280 cycles of the LDS pipe for 1280 cycles of MFMA, plus the LDS-DMA writes: the pass was LDS-bound (2850 cycles per
+//    step measured).  64 x 160: 10 KB of centroid + 4 KB of x fragments per wave, 112 KB per CU; 8 MFMAs per fragment pair instead
+//    of 4 to cover the next pair's read.  The two centroid halves of a point meet in LDS after the loop.
+//  * The LDS-DMA queues are split by wave: vmcnt retires in order, so a wave that requests both centroids and x cannot wait for "the
+//    centroids of the next step" without also waiting for every x it requested before them - two steps of slack whatever the ring
+//    depth.  Waves 0-3 request the centroid stages (five 1 KB instructions each, ring of three 20 KB stages), waves 4-7 the x slots
+//    of the whole work-group (four 1 KB groups each, ring of six 16 KB slots) and wait for x(s + 1) only: x(s + 2 .. s + 5) stay
+//    in flight, 64 KB of bf16 per CU.  The step-start barrier publishes both to all eight waves.
+constexpr int KC_SLOTS = 6;
+constexpr int KC_SLOT = KS_PTS * 64;           // 16 groups x 1 KB
+constexpr int KC_STAGE = KS_KMAX * 64;         // hi plane: 320 rows x 64 B
+constexpr int KC_LDS = KS_RING * KC_STAGE + KC_SLOTS * KC_SLOT;
+__global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char* __restrict__ xh, const float* __restrict__ xnorm,
+                                                            const bf16_t* __restrict__ chl, const float* __restrict__ cn,
+                                                            const unsigned* __restrict__ cmax2, long long* __restrict__ labels,
+                                                            int* __restrict__ list, int* __restrict__ nlist, int N, int D, int K,
+                                                            float margin_rel, const int* __restrict__ gate, int gate_want) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
+  if (gate && (*gate == 1) != (gate_want != 0)) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int pg = w >> 1, ch = w & 1;
+  const int p0 = blockIdx.x * KS_PTS + pg * 64;
+  const int nsteps = D >> 5;
+  unsigned char* const xring = ks_smem + KS_RING * KC_STAGE;
+  const bool xrole = w >= 4;
+  // one address set per wave: centroid rows (w * 5 + i) * 16 .. + 15 (64 bytes further per step) or x groups (w - 4) * 4 + i
+  // (gridDim.x * 16 KB further per step); i = 4 is unused by the x waves
+  const unsigned char* gp[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int row = (w * 5 + i) * 16 + (lane >> 2);
+    gp[i] = xrole ? xh + ((size_t)blockIdx.x * 16 + (size_t)((w - 4) * 4 + (i & 3))) * 1024 + lane * 16
+                  : reinterpret_cast<const unsigned char*>(chl + (size_t)min(row, KS_KMAX - 1) * D + (((lane & 3) ^ ks_swz(lane >> 2)) << 3));
+  }
+  const size_t gstep = xrole ? (size_t)gridDim.x * 16 * 1024 : 64;
+  auto stage_c = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      __builtin_amdgcn_global_load_lds(U2_GLB_PTR(gp[i]), U2_LDS_PTR(ks_smem + buf * KC_STAGE + (w * 5 + i) * 1024), 16, 0, 0);
+      gp[i] += gstep;
+    }
+  };
+  auto stage_x = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds(U2_GLB_PTR(gp[i]), U2_LDS_PTR(xring + slot * KC_SLOT + ((w - 4) * 4 + i) * 1024), 16, 0, 0);
+      gp[i] += gstep;
+    }
+  };
+  // s_waitcnt vmcnt for a wave-uniform count that is not a compile-time constant: `n` steps of x (four instructions each) may stay in flight
+  auto wait_x = [&](int n) {
+    switch (n) {
+      case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
+  static_assert(KC_SLOTS - 2 == 4, "wait_x covers 0 .. KC_SLOTS - 2 steps in flight");
+  const unsigned lds0 = (unsigned)(size_t)U2_LDS_PTR(ks_smem);
+  const unsigned boff = (unsigned)(fr * 64 + ((fg ^ ks_swz(fr)) << 4) + ch * 10 * 1024);   // B fragment of this wave's block nb: + nb * 1024
+  const unsigned xoff = (unsigned)(size_t)U2_LDS_PTR(xring) + (unsigned)(pg * 4096 + lane * 16);   // A fragment of point block m: + m * 1024
+
+  f32x4 acc[4][10];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int nb = 0; nb < 10; ++nb) acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (!xrole) {                                  // c(0), c(1); complete before step 0: c(0)
+    stage_c(0);
+    if (nsteps > 1) {
+      stage_c(1);
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  } else {                                       // x(0 .. KC_SLOTS - 2) (step s requests x(s + KC_SLOTS - 1)); complete before step 0: x(0)
+    const int npre = min(KC_SLOTS - 1, nsteps);
+    for (int j = 0; j < npre; ++j) stage_x(j);
+    wait_x(npre - 1);
+  }
+  int cbuf = 0, xslot = 0;                       // s % 3, s % KC_SLOTS
+  for (int s = 0; s < nsteps; ++s) {
+    __builtin_amdgcn_s_barrier();   // stage / slot s are complete for every wave, and every wave is done with step s - 1
+    asm volatile("" ::: "memory");
+    s16x8 ah[4];
+    const unsigned xs = xoff + (unsigned)(xslot * KC_SLOT);
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                 : "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(ah[2]), "=&v"(ah[3]) : "v"(xs) : "memory");
+    // this step's requests go to the stage / slot that every wave read in step s - 1 (the barrier above has seen that)
+    if (!xrole) {
+      if (s + 2 < nsteps) stage_c(cbuf == 0 ? 2 : cbuf - 1);
+    } else {
+      if (s + KC_SLOTS - 1 < nsteps) stage_x(xslot == 0 ? KC_SLOTS - 1 : xslot - 1);
+    }
+    // centroid fragments two blocks at a time, pair g + 1 requested in front of the MFMAs of pair g (in-order LDS returns, counted waits)
+    s16x8 bq[2][2];
+    const unsigned sba = lds0 + (unsigned)(cbuf * KC_STAGE) + boff;
+#define U2_KC_LDQ(SET, NB)                                                                                                    \
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"                                             \
+                 : "=&v"(bq[SET][0]), "=&v"(bq[SET][1]) : "v"(sba), "n"((NB) * 1024), "n"(((NB) + 1) * 1024) : "memory")
+#define U2_KC_WAIT(SET, CNT) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bq[SET][0]), "+v"(bq[SET][1]) : "n"(CNT) : "memory")
+#define U2_KC_PAIR(SET, NB)                                                                                                   \
+    {                                                                                                                          \
+      const s16x8 b0 = bq[SET][0], b1 = bq[SET][1];                                                                            \
+      acc[0][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b0, acc[0][NB], 0, 0, 0);                                    \
+      acc[1][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b0, acc[1][NB], 0, 0, 0);                                    \
+      acc[2][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[2], b0, acc[2][NB], 0, 0, 0);                                    \
+      acc[3][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[3], b0, acc[3][NB], 0, 0, 0);                                    \
+      acc[0][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b1, acc[0][NB + 1], 0, 0, 0);                            \
+      acc[1][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b1, acc[1][NB + 1], 0, 0, 0);                            \
+      acc[2][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[2], b1, acc[2][NB + 1], 0, 0, 0);                            \
+      acc[3][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[3], b1, acc[3][NB + 1], 0, 0, 0);                            \
+    }
+    U2_KC_LDQ(0, 0);
+    U2_KC_LDQ(1, 2);
+    // the x fragments were requested first: behind this wait they and pair 0 are there, pair 1 is in flight
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(bq[0][0]), "+v"(bq[0][1])::"memory");
+    U2_KC_PAIR(0, 0)
+    U2_KC_LDQ(0, 4);
+    U2_KC_WAIT(1, 2);
+    U2_KC_PAIR(1, 2)
+    U2_KC_LDQ(1, 6);
+    U2_KC_WAIT(0, 2);
+    U2_KC_PAIR(0, 4)
+    U2_KC_LDQ(0, 8);
+    U2_KC_WAIT(1, 2);
+    U2_KC_PAIR(1, 6)
+    U2_KC_WAIT(0, 0);
+    U2_KC_PAIR(0, 8)
+#undef U2_KC_PAIR
+#undef U2_KC_WAIT
+#undef U2_KC_LDQ
+    // close the step: the centroid waves leave c(s + 2) in flight, the x waves x(s + 2 .. s + KC_SLOTS - 1) as far as they exist
+    if (!xrole) {
+      if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      wait_x(min(max(nsteps - s - 2, 0), KC_SLOTS - 2));
+    }
+    cbuf = cbuf == 2 ? 0 : cbuf + 1;
+    xslot = xslot == KC_SLOTS - 1 ? 0 : xslot + 1;
+  }
+  __syncthreads();
+  const float margin_unit = margin_rel * sqrtf(__uint_as_float(*cmax2));
+  // arg-min as in kmeans_screen_kernel (branch-free, NaN handling and tie rule there) over this wave's 160 centroids ...
+  float cnr[10];
+#pragma unroll
+  for (int nb = 0; nb < 10; ++nb) {
+    const int j = (ch * 10 + nb) * 16 + fr;
+    cnr[nb] = cn[min(j, K - 1)];
+    cnr[nb] = j < K ? cnr[nb] : INFINITY;
+  }
+  float* const mb = reinterpret_cast<float*>(ks_smem);          // [256 points]{best, second, index} of the upper centroid half
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    float b[4], s2[4];
+    int bn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { b[r] = INFINITY; s2[r] = INFINITY; bn[r] = 0; }
+#pragma unroll
+    for (int nb = 0; nb < 10; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = fmaf(acc[m][nb][r], -2.f, cnr[nb]);
+        const bool lt = v < b[r];
+        s2[r] = fminf(s2[r], lt ? b[r] : v);
+        bn[r] = lt ? nb : bn[r];
+        b[r] = fminf(b[r], v);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int bj = (ch * 10 + bn[r]) * 16 + fr;
+      float bb = b[r], ss = s2[r];
+#define U2_KC_MERGE(CTRL)                                                                                                   \
+      {                                                                                                                      \
+        const float ob = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bb), CTRL, 0xf, 0xf, true));           \
+        const float os = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), CTRL, 0xf, 0xf, true));           \
+        const int oj = __builtin_amdgcn_update_dpp(0, bj, CTRL, 0xf, 0xf, true);                                            \
+        const bool lt = ob < bb || (ob == bb && oj < bj);                                                                    \
+        ss = fminf(fminf(ss, os), lt ? bb : ob);                                                                             \
+        bj = lt ? oj : bj;                                                                                                   \
+        bb = fminf(bb, ob);                                                                                                  \
+      }
+      U2_KC_MERGE(0xB1)    // quad_perm [1, 0, 3, 2]
+      U2_KC_MERGE(0x4E)    // quad_perm [2, 3, 0, 1]
+      U2_KC_MERGE(0x141)   // row_half_mirror
+      U2_KC_MERGE(0x140)   // row_mirror
+#undef U2_KC_MERGE
+      b[r] = bb; s2[r] = ss; bn[r] = bj;
+    }
+    // ... then the two halves of a point: the wave of the upper half leaves its candidate in LDS, the other one merges and writes
+    if (ch == 1 && fr == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* e = mb + (pg * 64 + m * 16 + fg * 4 + r) * 3;
+        e[0] = b[r]; e[1] = s2[r]; e[2] = __int_as_float(bn[r]);
+      }
+    }
+    __syncthreads();
+    if (ch == 0 && fr == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int pl = m * 16 + fg * 4 + r;
+        const int p = p0 + pl;
+        const float* e = mb + (pg * 64 + pl) * 3;
+        const float ob = e[0], os = e[1];
+        const int oj = __float_as_int(e[2]);
+        const bool lt = ob < b[r];                       // equal: the lower half holds the lower index
+        const float ss = fminf(fminf(s2[r], os), lt ? b[r] : ob);
+        const float bb = fminf(b[r], ob);
+        const int bj = lt ? oj : bn[r];
+        if (p < N) {
+          labels[p] = (long long)bj;
+          if (!(ss - bb >= margin_unit * xnorm[p])) list[atomicAdd(nlist, 1)] = p;   // also: NaN anywhere, K == 1
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
 
 // csum[K][D] += x rows by label; counts[K] += 1.  grid = (point chunks, D / DS); LDS holds [K][DS] partial sums.
 template <int DS>
@@ -1005,42 +1156,40 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
     (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)kmeans_screen_kernel<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)kmeans_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const dim3 grid((N + KS_PTS - 1) / KS_PTS), block(512);
   const size_t lds = KS_RING * KS_STAGE;                               // fine pass: both centroid planes, x through registers
   const size_t lds1 = U2_KM_X3 ? (size_t)KS_RING * KS_KMAX * 64 + 3 * KS_PTS * 128     // coarse pass: hi plane (20 KB stages) + three x slots
                                : (size_t)KS_RING * 3 * 8 * 1024 + 2 * KS_PTS * 128;   // round 5: 24 KB stages with filler rows + two x slots
-  const size_t lds_sh = (size_t)KS_RING * KS_KMAX * 64 + 6 * KS_PTS * 64;   // coarse pass over the shadow: 3 x 20 KB + six 16 KB x slots
   const size_t lds3 = 2 * KS_STAGE + 2 * KS_PTS * 128;                // fine pass with the x ring: two centroid stages + two x slots
   static const int xring3 = getenv("U2_KM_XRING3") ? atoi(getenv("U2_KM_XRING3")) : 1;   // measurement knob: 0 = x through registers
   const int* gate = reinterpret_cast<const int*>(state + 1);
   static const int two_level = getenv("U2_KM_ONE_LEVEL") ? 0 : 1;   // measurement knob: the round-3 single (fine) pass
   if (two_level) {
     // coarse pass over everything -> list1; fine pass over list1 -> list2 (both skipped while the coarse pass is switched off)
-    if (shadow) {
-      const float* xn = shadow + km_shadow_words(N, D);
-      hipLaunchKernelGGL((kmeans_screen_kernel<1, false, true>), grid, block, lds_sh, s, shadow, chl, cn, scal, labels, list1,
-                         reinterpret_cast<int*>(scal + 2), N, D, K, 0.02f, (const int*)nullptr, (const int*)nullptr, gate, 0, xn);
-    } else
-    hipLaunchKernelGGL(kmeans_screen_kernel<1>, grid, block, lds1, s, x, chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D,
-                       K, 0.02f, (const int*)nullptr, (const int*)nullptr, gate, 0, (const float*)nullptr);
+    if (shadow)
+      hipLaunchKernelGGL(kmeans_coarse_kernel, grid, block, KC_LDS, s, reinterpret_cast<const unsigned char*>(shadow),
+                         shadow + km_shadow_words(N, D), chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D, K, 0.02f, gate, 0);
+    else
+      hipLaunchKernelGGL(kmeans_screen_kernel<1>, grid, block, lds1, s, x, chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D,
+                         K, 0.02f, (const int*)nullptr, (const int*)nullptr, gate, 0);
     U2_CHECK_LAUNCH();
     if (xring3)
       hipLaunchKernelGGL((kmeans_screen_kernel<3, true>), grid, block, lds3, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1),
-                         N, D, K, 1e-4f, (const int*)list1, reinterpret_cast<const int*>(scal + 2), gate, 0, (const float*)nullptr);
+                         N, D, K, 1e-4f, (const int*)list1, reinterpret_cast<const int*>(scal + 2), gate, 0);
     else
       hipLaunchKernelGGL(kmeans_screen_kernel<3>, grid, block, lds, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N, D,
-                         K, 1e-4f, (const int*)list1, reinterpret_cast<const int*>(scal + 2), gate, 0, (const float*)nullptr);
+                         K, 1e-4f, (const int*)list1, reinterpret_cast<const int*>(scal + 2), gate, 0);
     U2_CHECK_LAUNCH();
   }
   // fine pass over everything -> list2 (the only pass while the coarse one is switched off)
   if (xring3)
     hipLaunchKernelGGL((kmeans_screen_kernel<3, true>), grid, block, lds3, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N,
-                       D, K, 1e-4f, (const int*)nullptr, (const int*)nullptr, two_level ? gate : (const int*)nullptr, 1, (const float*)nullptr);
+                       D, K, 1e-4f, (const int*)nullptr, (const int*)nullptr, two_level ? gate : (const int*)nullptr, 1);
   else
     hipLaunchKernelGGL(kmeans_screen_kernel<3>, grid, block, lds, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N, D, K,
-                       1e-4f, (const int*)nullptr, (const int*)nullptr, two_level ? gate : (const int*)nullptr, 1, (const float*)nullptr);
+                       1e-4f, (const int*)nullptr, (const int*)nullptr, two_level ? gate : (const int*)nullptr, 1);
   U2_CHECK_LAUNCH();
   // the undecided points, exactly; the grid covers the worst case, work-groups beyond the list return immediately
   hipLaunchKernelGGL(kmeans_assign_kernel, dim3((N + KM_PTS - 1) / KM_PTS), dim3(256), 0, s, x, c, cn, labels, N, D, K,
