@@ -661,22 +661,38 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
 
 
 // ---- coarse pass over the shadow (round 6) ----------------------------------------------------------------------------------------
-// hi.hi only, all points, x from the bf16 shadow (km_shadow_kernel) - the first pass of the two-level screening when a shadow is given;
-// same products, margin and list as kmeans_screen_kernel<1>, so the labels and the undecided set are the same.  What differs:
-//  * Wave tile 64 points x 160 centroids (waves (pg, ch) = (w >> 1, w & 1)) instead of 32 x 320: with one MFMA per (point block,
-//    centroid block, step) the 32 x 320 tile reads 20 KB of centroid fragments out of LDS per wave and step for 40 MFMAs - 160 KB per
-//    CU and step, 1280 cycles of the LDS pipe for 1280 cycles of MFMA, plus the LDS-DMA writes: the pass was LDS-bound (2850 cycles per
-//    step measured).  64 x 160: 10 KB of centroid + 4 KB of x fragments per wave, 112 KB per CU; 8 MFMAs per fragment pair instead
-//    of 4 to cover the next pair's read.  The two centroid halves of a point meet in LDS after the loop.
+// hi.hi only, all points, x from the bf16 shadow (km_shadow_kernel) - the first pass of the two-level screening when a shadow is given.
+// Same products and wave tile (32 points x 320 centroids) as kmeans_screen_kernel<1>; what differs:
 //  * The LDS-DMA queues are split by wave: vmcnt retires in order, so a wave that requests both centroids and x cannot wait for "the
 //    centroids of the next step" without also waiting for every x it requested before them - two steps of slack whatever the ring
 //    depth.  Waves 0-3 request the centroid stages (five 1 KB instructions each, ring of three 20 KB stages), waves 4-7 the x slots
 //    of the whole work-group (four 1 KB groups each, ring of six 16 KB slots) and wait for x(s + 1) only: x(s + 2 .. s + 5) stay
 //    in flight, 64 KB of bf16 per CU.  The step-start barrier publishes both to all eight waves.
+//  * The arg-min.  s_memtime stamps (tools/exp/km_trace.sh) put 31 % of a work-group's time into the epilogue of the first version of this
+//    kernel - 3400 instructions per wave for 160 distances per lane, with the matrix pipe idle and nothing in flight.  Now the block
+//    index rides in the low mantissa bits of the distance ((v & ~31) | nb, one v_and_or_b32), so "best and second best" is v_min_f32 +
+//    v_med3_f32 per value with no compares or selects; the cross-lane steps carry (best | 9-bit centroid index, second) only; and the 32
+//    results of a wave are moved into 32 lanes and written by one store.  The bits given up (2^-14 of the distance at most) are added to
+//    the margin, so a point is still either decided correctly or handed to the finer passes; ties need no rule here - a gap of zero is
+//    below any margin.
+#ifdef U2_KM_TRACE
+// measurement build (tools/exp/km_trace.sh): s_memtime of waves 0 (centroid requests) and 4 (x requests) at kernel entry, first barrier,
+// loop exit and kernel exit, per work-group; read back through u2_km_trace_dump
+__device__ unsigned long long km_trace[8192 * 8];
+#define U2_KM_STAMP(I)                                                                                  \
+  if ((w == 0 || w == 4) && lane == 0 && blockIdx.x < 8192) km_trace[blockIdx.x * 8 + (w >> 2) * 4 + (I)] = __builtin_amdgcn_s_memtime()
+#else
+#define U2_KM_STAMP(I)
+#endif
+// v_min_f32 / v_max_f32 as they are: fminf / fmaxf on a value that went through integer instructions get a canonicalising v_max_f32 v, v, v
+// in front (a fifth of the arg-min's instructions); a signalling NaN cannot come out of an fma, and every NaN case goes by the margin
+__device__ __forceinline__ float kc_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float kc_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 constexpr int KC_SLOTS = 6;
 constexpr int KC_SLOT = KS_PTS * 64;           // 16 groups x 1 KB
 constexpr int KC_STAGE = KS_KMAX * 64;         // hi plane: 320 rows x 64 B
-constexpr int KC_LDS = KS_RING * KC_STAGE + KC_SLOTS * KC_SLOT;
+constexpr int KC_RINGS = KS_RING * KC_STAGE + KC_SLOTS * KC_SLOT;
+constexpr int KC_LDS = KC_RINGS + KS_KMAX * 4; // + |c_j|^2
 __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char* __restrict__ xh, const float* __restrict__ xnorm,
                                                             const bf16_t* __restrict__ chl, const float* __restrict__ cn,
                                                             const unsigned* __restrict__ cmax2, long long* __restrict__ labels,
@@ -687,11 +703,18 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
-  const int pg = w >> 1, ch = w & 1;
-  const int p0 = blockIdx.x * KS_PTS + pg * 64;
+  const int p0 = blockIdx.x * KS_PTS + w * 32;
   const int nsteps = D >> 5;
   unsigned char* const xring = ks_smem + KS_RING * KC_STAGE;
+  float* const cnl = reinterpret_cast<float*>(ks_smem + KC_RINGS);
   const bool xrole = w >= 4;
+  U2_KM_STAMP(0);
+  // what the epilogue needs from memory is fetched now: |c_j|^2 into LDS (a huge finite value for j >= K: an infinity would turn into a
+  // NaN when the block index is or-ed into it), and the norm of the point this lane will write (lanes fr < 8: point block fr >> 2, row
+  // fg * 4 + (fr & 3); xnorm is padded to the grid)
+  if (tid < KS_KMAX) cnl[tid] = tid < K ? cn[tid] : 3.0e38f;
+  const int pmine = p0 + ((fr >> 2) & 1) * 16 + fg * 4 + (fr & 3);
+  const float xn = xnorm[pmine];
   // one address set per wave: centroid rows (w * 5 + i) * 16 .. + 15 (64 bytes further per step) or x groups (w - 4) * 4 + i
   // (gridDim.x * 16 KB further per step); i = 4 is unused by the x waves
   const unsigned char* gp[5];
@@ -728,15 +751,16 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
   };
   static_assert(KC_SLOTS - 2 == 4, "wait_x covers 0 .. KC_SLOTS - 2 steps in flight");
   const unsigned lds0 = (unsigned)(size_t)U2_LDS_PTR(ks_smem);
-  const unsigned boff = (unsigned)(fr * 64 + ((fg ^ ks_swz(fr)) << 4) + ch * 10 * 1024);   // B fragment of this wave's block nb: + nb * 1024
-  const unsigned xoff = (unsigned)(size_t)U2_LDS_PTR(xring) + (unsigned)(pg * 4096 + lane * 16);   // A fragment of point block m: + m * 1024
+  const unsigned boff = (unsigned)(fr * 64 + ((fg ^ ks_swz(fr)) << 4));                               // B fragment of block nb: + nb * 1024
+  const unsigned xoff = (unsigned)(size_t)U2_LDS_PTR(xring) + (unsigned)(w * 2048 + lane * 16);      // A fragment of point block m: + m * 1024
 
-  f32x4 acc[4][10];
+  f32x4 acc[2][KS_NB];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int nb = 0; nb < 10; ++nb) acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nb = 0; nb < KS_NB; ++nb) acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // the two plain loads above are the oldest entries of the queue: they have left it when any of the counted waits below is satisfied
   if (!xrole) {                                  // c(0), c(1); complete before step 0: c(0)
     stage_c(0);
     if (nsteps > 1) {
@@ -750,56 +774,61 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
     for (int j = 0; j < npre; ++j) stage_x(j);
     wait_x(npre - 1);
   }
+  U2_KM_STAMP(1);
   int cbuf = 0, xslot = 0;                       // s % 3, s % KC_SLOTS
   for (int s = 0; s < nsteps; ++s) {
     __builtin_amdgcn_s_barrier();   // stage / slot s are complete for every wave, and every wave is done with step s - 1
     asm volatile("" ::: "memory");
-    s16x8 ah[4];
+    s16x8 ah[2];
     const unsigned xs = xoff + (unsigned)(xslot * KC_SLOT);
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
-                 : "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(ah[2]), "=&v"(ah[3]) : "v"(xs) : "memory");
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(ah[0]), "=&v"(ah[1]) : "v"(xs) : "memory");
     // this step's requests go to the stage / slot that every wave read in step s - 1 (the barrier above has seen that)
     if (!xrole) {
       if (s + 2 < nsteps) stage_c(cbuf == 0 ? 2 : cbuf - 1);
     } else {
       if (s + KC_SLOTS - 1 < nsteps) stage_x(xslot == 0 ? KC_SLOTS - 1 : xslot - 1);
     }
-    // centroid fragments two blocks at a time, pair g + 1 requested in front of the MFMAs of pair g (in-order LDS returns, counted waits)
-    s16x8 bq[2][2];
+    // centroid fragments four blocks at a time, group g + 1 requested in front of the eight MFMAs of group g (in-order LDS returns,
+    // counted waits that name the registers they release)
+    s16x8 bq[2][4];
     const unsigned sba = lds0 + (unsigned)(cbuf * KC_STAGE) + boff;
 #define U2_KC_LDQ(SET, NB)                                                                                                    \
-    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"                                             \
-                 : "=&v"(bq[SET][0]), "=&v"(bq[SET][1]) : "v"(sba), "n"((NB) * 1024), "n"(((NB) + 1) * 1024) : "memory")
-#define U2_KC_WAIT(SET, CNT) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bq[SET][0]), "+v"(bq[SET][1]) : "n"(CNT) : "memory")
-#define U2_KC_PAIR(SET, NB)                                                                                                   \
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t"         \
+                 "ds_read_b128 %3, %4 offset:%8"                                                                               \
+                 : "=&v"(bq[SET][0]), "=&v"(bq[SET][1]), "=&v"(bq[SET][2]), "=&v"(bq[SET][3])                                 \
+                 : "v"(sba), "n"((NB) * 1024), "n"(((NB) + 1) * 1024), "n"(((NB) + 2) * 1024), "n"(((NB) + 3) * 1024) : "memory")
+#define U2_KC_WAIT(SET, CNT)                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bq[SET][0]), "+v"(bq[SET][1]), "+v"(bq[SET][2]), "+v"(bq[SET][3]) : "n"(CNT) : "memory")
+#define U2_KC_QUAD(SET, NB)                                                                                                   \
     {                                                                                                                          \
-      const s16x8 b0 = bq[SET][0], b1 = bq[SET][1];                                                                            \
+      const s16x8 b0 = bq[SET][0], b1 = bq[SET][1], b2 = bq[SET][2], b3 = bq[SET][3];                                          \
       acc[0][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b0, acc[0][NB], 0, 0, 0);                                    \
       acc[1][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b0, acc[1][NB], 0, 0, 0);                                    \
-      acc[2][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[2], b0, acc[2][NB], 0, 0, 0);                                    \
-      acc[3][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[3], b0, acc[3][NB], 0, 0, 0);                                    \
       acc[0][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b1, acc[0][NB + 1], 0, 0, 0);                            \
       acc[1][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b1, acc[1][NB + 1], 0, 0, 0);                            \
-      acc[2][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[2], b1, acc[2][NB + 1], 0, 0, 0);                            \
-      acc[3][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[3], b1, acc[3][NB + 1], 0, 0, 0);                            \
+      acc[0][NB + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b2, acc[0][NB + 2], 0, 0, 0);                            \
+      acc[1][NB + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b2, acc[1][NB + 2], 0, 0, 0);                            \
+      acc[0][NB + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b3, acc[0][NB + 3], 0, 0, 0);                            \
+      acc[1][NB + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b3, acc[1][NB + 3], 0, 0, 0);                            \
     }
+    static_assert(KS_NB == 20, "the unrolled group sequence below covers 20 centroid blocks");
     U2_KC_LDQ(0, 0);
-    U2_KC_LDQ(1, 2);
-    // the x fragments were requested first: behind this wait they and pair 0 are there, pair 1 is in flight
-    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(bq[0][0]), "+v"(bq[0][1])::"memory");
-    U2_KC_PAIR(0, 0)
-    U2_KC_LDQ(0, 4);
-    U2_KC_WAIT(1, 2);
-    U2_KC_PAIR(1, 2)
-    U2_KC_LDQ(1, 6);
-    U2_KC_WAIT(0, 2);
-    U2_KC_PAIR(0, 4)
+    U2_KC_LDQ(1, 4);
+    // the x fragments were requested first: behind this wait they and group 0 are there, group 1 is in flight
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[0]), "+v"(ah[1]), "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3])::"memory");
+    U2_KC_QUAD(0, 0)
     U2_KC_LDQ(0, 8);
-    U2_KC_WAIT(1, 2);
-    U2_KC_PAIR(1, 6)
+    U2_KC_WAIT(1, 4);
+    U2_KC_QUAD(1, 4)
+    U2_KC_LDQ(1, 12);
+    U2_KC_WAIT(0, 4);
+    U2_KC_QUAD(0, 8)
+    U2_KC_LDQ(0, 16);
+    U2_KC_WAIT(1, 4);
+    U2_KC_QUAD(1, 12)
     U2_KC_WAIT(0, 0);
-    U2_KC_PAIR(0, 8)
-#undef U2_KC_PAIR
+    U2_KC_QUAD(0, 16)
+#undef U2_KC_QUAD
 #undef U2_KC_WAIT
 #undef U2_KC_LDQ
     // close the step: the centroid waves leave c(s + 2) in flight, the x waves x(s + 2 .. s + KC_SLOTS - 1) as far as they exist
@@ -813,82 +842,56 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
     xslot = xslot == KC_SLOTS - 1 ? 0 : xslot + 1;
   }
   __syncthreads();
-  const float margin_unit = margin_rel * sqrtf(__uint_as_float(*cmax2));
-  // arg-min as in kmeans_screen_kernel (branch-free, NaN handling and tie rule there) over this wave's 160 centroids ...
-  float cnr[10];
+  U2_KM_STAMP(2);
+  const float cmax = sqrtf(__uint_as_float(*cmax2));
+  float cnr[KS_NB];
 #pragma unroll
-  for (int nb = 0; nb < 10; ++nb) {
-    const int j = (ch * 10 + nb) * 16 + fr;
-    cnr[nb] = cn[min(j, K - 1)];
-    cnr[nb] = j < K ? cnr[nb] : INFINITY;
-  }
-  float* const mb = reinterpret_cast<float*>(ks_smem);          // [256 points]{best, second, index} of the upper centroid half
+  for (int nb = 0; nb < KS_NB; ++nb) cnr[nb] = cnl[nb * 16 + fr];
+  float kb = INFINITY, ks = INFINITY;   // (best | centroid index, second best) of the point this lane writes
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
+  for (int m = 0; m < 2; ++m) {
     float b[4], s2[4];
-    int bn[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { b[r] = INFINITY; s2[r] = INFINITY; bn[r] = 0; }
+    for (int r = 0; r < 4; ++r) { b[r] = INFINITY; s2[r] = INFINITY; }
 #pragma unroll
-    for (int nb = 0; nb < 10; ++nb)
+    for (int nb = 0; nb < KS_NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v = fmaf(acc[m][nb][r], -2.f, cnr[nb]);
-        const bool lt = v < b[r];
-        s2[r] = fminf(s2[r], lt ? b[r] : v);
-        bn[r] = lt ? nb : bn[r];
-        b[r] = fminf(b[r], v);
+        float v = fmaf(acc[m][nb][r], -2.f, cnr[nb]);                        // cn - 2 x.c
+        v = __uint_as_float((__float_as_uint(v) & 0xffffffe0u) | (unsigned)nb);
+        s2[r] = __builtin_amdgcn_fmed3f(b[r], s2[r], v);                       // b <= s2: the middle one is the new second best
+        b[r] = kc_min(b[r], v);
       }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      int bj = (ch * 10 + bn[r]) * 16 + fr;
-      float bb = b[r], ss = s2[r];
+      const unsigned ub = __float_as_uint(b[r]);
+      float bb = __uint_as_float((ub & 0xfffffe00u) | ((ub & 31u) << 4) | (unsigned)fr), ss = s2[r];
+      // the 16 lanes of a DPP row hold the 16 centroids of every block: xor 1, xor 2 (quad permutes), the other quad of the half row,
+      // the other half row
 #define U2_KC_MERGE(CTRL)                                                                                                   \
       {                                                                                                                      \
         const float ob = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bb), CTRL, 0xf, 0xf, true));           \
         const float os = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), CTRL, 0xf, 0xf, true));           \
-        const int oj = __builtin_amdgcn_update_dpp(0, bj, CTRL, 0xf, 0xf, true);                                            \
-        const bool lt = ob < bb || (ob == bb && oj < bj);                                                                    \
-        ss = fminf(fminf(ss, os), lt ? bb : ob);                                                                             \
-        bj = lt ? oj : bj;                                                                                                   \
-        bb = fminf(bb, ob);                                                                                                  \
+        ss = kc_min(kc_min(ss, os), kc_max(bb, ob));                                                                         \
+        bb = kc_min(bb, ob);                                                                                                 \
       }
       U2_KC_MERGE(0xB1)    // quad_perm [1, 0, 3, 2]
       U2_KC_MERGE(0x4E)    // quad_perm [2, 3, 0, 1]
       U2_KC_MERGE(0x141)   // row_half_mirror
       U2_KC_MERGE(0x140)   // row_mirror
 #undef U2_KC_MERGE
-      b[r] = bb; s2[r] = ss; bn[r] = bj;
+      const bool mine = fr == m * 4 + r;
+      kb = mine ? bb : kb;
+      ks = mine ? ss : ks;
     }
-    // ... then the two halves of a point: the wave of the upper half leaves its candidate in LDS, the other one merges and writes
-    if (ch == 1 && fr == 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float* e = mb + (pg * 64 + m * 16 + fg * 4 + r) * 3;
-        e[0] = b[r]; e[1] = s2[r]; e[2] = __int_as_float(bn[r]);
-      }
-    }
-    __syncthreads();
-    if (ch == 0 && fr == 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int pl = m * 16 + fg * 4 + r;
-        const int p = p0 + pl;
-        const float* e = mb + (pg * 64 + pl) * 3;
-        const float ob = e[0], os = e[1];
-        const int oj = __float_as_int(e[2]);
-        const bool lt = ob < b[r];                       // equal: the lower half holds the lower index
-        const float ss = fminf(fminf(s2[r], os), lt ? b[r] : ob);
-        const float bb = fminf(b[r], ob);
-        const int bj = lt ? oj : bn[r];
-        if (p < N) {
-          labels[p] = (long long)bj;
-          if (!(ss - bb >= margin_unit * xnorm[p])) list[atomicAdd(nlist, 1)] = p;   // also: NaN anywhere, K == 1
-        }
-      }
-    }
-    __syncthreads();
   }
+  if (fr < 8 && pmine < N) {
+    labels[pmine] = (long long)(__float_as_uint(kb) & 511u);
+    // screening margin + the mantissa bits the indices took: 2^-14 of a distance at most, |distance| <= |c|^2 + 2 |x| |c| (twice that here)
+    const float margin = margin_rel * cmax * xn + 1.2207031e-4f * (cmax * cmax + 2.f * xn * cmax);
+    if (!(ks - kb >= margin)) list[atomicAdd(nlist, 1)] = pmine;   // also: NaN anywhere
+  }
+  U2_KM_STAMP(3);
 }
 
 // csum[K][D] += x rows by label; counts[K] += 1.  grid = (point chunks, D / DS); LDS holds [K][DS] partial sums.
@@ -1101,6 +1104,11 @@ extern "C" long long u2_kmeans_assign_workspace_floats(int N, int D, int K) {
   return (long long)K + 16 + (long long)KS_KMAX * D + 2LL * N + 32;
 }
 
+#ifdef U2_KM_TRACE
+extern "C" int u2_km_trace_dump(unsigned long long* host, int words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(km_trace), (size_t)words * 8);
+}
+#endif
 // words (floats) of the bf16 shadow itself; |x_p| follows it
 static size_t km_shadow_words(int N, int D) { return (size_t)(D >> 5) * (size_t)((N + KS_PTS - 1) / KS_PTS) * 16 * 256; }
 
