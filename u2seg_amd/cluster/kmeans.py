@@ -101,8 +101,8 @@ def last_coarse_undecided(device):
 def update(x, labels, k):
     """c = scatter_add(x by label) / bincount(label) -> (centroids [K, D], counts [K])."""
     n, d = x.shape
-    csum = torch.zeros((k, d), dtype=torch.float32, device=x.device)
-    counts = torch.zeros(k, dtype=torch.float32, device=x.device)
+    buf = torch.zeros(k * d + k, dtype=torch.float32, device=x.device)    # one fill for both
+    csum, counts = buf[: k * d].view(k, d), buf[k * d:]
     _hip.call("u2_kmeans_update", x.contiguous(), labels, csum, counts, n, d, k, _update_workspace(n, d, k, x.device))
     c = torch.empty_like(csum)
     _hip.call("u2_kmeans_finalize", csum, counts, c, d, k)

@@ -688,6 +688,11 @@ __device__ unsigned long long km_trace[8192 * 8];
 // in front (a fifth of the arg-min's instructions); a signalling NaN cannot come out of an fma, and every NaN case goes by the margin
 __device__ __forceinline__ float kc_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float kc_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// timing-only ablations of the loop (results are wrong): 1 no MFMAs, 2 no centroid-fragment reads behind the first group, 4 no LDS-DMA
+// requests in the loop, 8 no barrier
+#ifndef U2_KC_ABL
+#define U2_KC_ABL 0
+#endif
 constexpr int KC_SLOTS = 6;
 constexpr int KC_SLOT = KS_PTS * 64;           // 16 groups x 1 KB
 constexpr int KC_STAGE = KS_KMAX * 64;         // hi plane: 320 rows x 64 B
@@ -777,13 +782,14 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
   U2_KM_STAMP(1);
   int cbuf = 0, xslot = 0;                       // s % 3, s % KC_SLOTS
   for (int s = 0; s < nsteps; ++s) {
-    __builtin_amdgcn_s_barrier();   // stage / slot s are complete for every wave, and every wave is done with step s - 1
+    if (!(U2_KC_ABL & 8)) __builtin_amdgcn_s_barrier();   // stage / slot s are complete for every wave, and every wave is done with step s - 1
     asm volatile("" ::: "memory");
     s16x8 ah[2];
     const unsigned xs = xoff + (unsigned)(xslot * KC_SLOT);
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(ah[0]), "=&v"(ah[1]) : "v"(xs) : "memory");
     // this step's requests go to the stage / slot that every wave read in step s - 1 (the barrier above has seen that)
-    if (!xrole) {
+    if (U2_KC_ABL & 4) {
+    } else if (!xrole) {
       if (s + 2 < nsteps) stage_c(cbuf == 0 ? 2 : cbuf - 1);
     } else {
       if (s + KC_SLOTS - 1 < nsteps) stage_x(xslot == 0 ? KC_SLOTS - 1 : xslot - 1);
@@ -793,6 +799,7 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
     s16x8 bq[2][4];
     const unsigned sba = lds0 + (unsigned)(cbuf * KC_STAGE) + boff;
 #define U2_KC_LDQ(SET, NB)                                                                                                    \
+    if (!(U2_KC_ABL & 2) || (NB) < 8)                                                                                          \
     asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t"         \
                  "ds_read_b128 %3, %4 offset:%8"                                                                               \
                  : "=&v"(bq[SET][0]), "=&v"(bq[SET][1]), "=&v"(bq[SET][2]), "=&v"(bq[SET][3])                                 \
@@ -800,7 +807,7 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
 #define U2_KC_WAIT(SET, CNT)                                                                                                  \
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bq[SET][0]), "+v"(bq[SET][1]), "+v"(bq[SET][2]), "+v"(bq[SET][3]) : "n"(CNT) : "memory")
 #define U2_KC_QUAD(SET, NB)                                                                                                   \
-    {                                                                                                                          \
+    if (!(U2_KC_ABL & 1)) {                                                                                                                       \
       const s16x8 b0 = bq[SET][0], b1 = bq[SET][1], b2 = bq[SET][2], b3 = bq[SET][3];                                          \
       acc[0][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b0, acc[0][NB], 0, 0, 0);                                    \
       acc[1][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b0, acc[1][NB], 0, 0, 0);                                    \
@@ -980,14 +987,27 @@ __global__ __launch_bounds__(256) void km_hist_kernel(const long long* __restric
 
 __global__ __launch_bounds__(256) void km_scan_kernel(const int* __restrict__ counts, int* __restrict__ cursor,
                                                       float* __restrict__ fcounts, int K) {
-  __shared__ int run;
-  if (threadIdx.x == 0) {  // K is a few hundred: a serial scan costs nothing next to the streaming passes
-    int acc = 0;
-    for (int j = 0; j < K; ++j) { cursor[j] = acc; acc += counts[j]; }
-    run = acc;
-  }
+  // exclusive scan: a chunk of consecutive labels per thread, the 256 chunk sums through LDS (the first version - thread 0 walking
+  // all K counts, one dependent global load each - took 17 us at K = 300, a launch that should cost 4)
+  __shared__ int part[256];
+  const int per = (K + 255) / 256, j0 = threadIdx.x * per, j1 = min(K, j0 + per);
+  int sum = 0;
+  for (int j = j0; j < j1; ++j) sum += counts[j];
+  part[threadIdx.x] = sum;
   __syncthreads();
-  for (int j = threadIdx.x; j < K; j += 256) fcounts[j] += (float)counts[j];
+  for (int off = 1; off < 256; off <<= 1) {
+    const int v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int acc = part[threadIdx.x] - sum;
+  for (int j = j0; j < j1; ++j) {
+    const int c = counts[j];
+    cursor[j] = acc;
+    acc += c;
+    fcounts[j] += (float)c;
+  }
 }
 
 // A work-group takes KM_SCAT consecutive points: per-label counts in LDS, ONE global atomic per (work-group, label) to
@@ -1027,9 +1047,12 @@ __global__ __launch_bounds__(256) void km_scatter_kernel(const long long* __rest
 constexpr int KM_SEG = 256;  // label-ordered entries per work-group
 template <int DPT>           // dimensions per thread: D <= 256 * DPT
 __global__ __launch_bounds__(256) void km_segsum_kernel(const float* __restrict__ x, const int* __restrict__ order,
-                                                        const int* __restrict__ lab_sorted, float* __restrict__ csum, int N, int D) {
+                                                        const int* __restrict__ lab_sorted, float* __restrict__ csum, int N, int D,
+                                                        const int* __restrict__ total) {
   const int tid = threadIdx.x;
-  const int e0 = blockIdx.x * KM_SEG, e1 = min(N, e0 + KM_SEG);
+  // *total: the entries of the label-ordered list (the cursor of the last label once km_scatter_kernel has run); points whose label is
+  // outside [0, K) were not scattered and leave unwritten slots behind it
+  const int e0 = blockIdx.x * KM_SEG, e1 = min(min(N, *total), e0 + KM_SEG);
   if (e0 >= e1) return;
   float acc[DPT];
 #pragma unroll
@@ -1049,7 +1072,7 @@ __global__ __launch_bounds__(256) void km_segsum_kernel(const float* __restrict_
     int lab[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      lab[u] = e + u < e1 ? lab_sorted[e + u] : -1;   // -1: beyond the list, or a slot no in-range label was scattered into
+      lab[u] = e + u < e1 ? lab_sorted[e + u] : -1;   // -1: beyond the list (e1 stops at the last scattered entry)
       const bool ok = lab[u] >= 0;
       const float* row = x + (size_t)(ok ? order[e + u] : 0) * D;
 #pragma unroll
@@ -1108,6 +1131,7 @@ extern "C" long long u2_kmeans_assign_workspace_floats(int N, int D, int K) {
 extern "C" int u2_km_trace_dump(unsigned long long* host, int words) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(km_trace), (size_t)words * 8);
 }
+
 #endif
 // words (floats) of the bf16 shadow itself; |x_p| follows it
 static size_t km_shadow_words(int N, int D) { return (size_t)(D >> 5) * (size_t)((N + KS_PTS - 1) / KS_PTS) * 16 * 256; }
@@ -1225,19 +1249,18 @@ extern "C" int u2_kmeans_update(const float* x, const long long* labels, float* 
     int* icounts = lab_sorted + N;
     int* cursor = icounts + K;
     u2_zero_words(icounts, (size_t)K, s);
-    u2_fill_words(lab_sorted, (size_t)N, 0xffffffffu, s);  // labels outside [0, K) leave holes at the end of the list: marked -1
     U2_CHECK_LAUNCH();
-    hipLaunchKernelGGL(km_hist_kernel, dim3(1024), dim3(256), (size_t)K * sizeof(int), s, labels, icounts, N, K);
+    hipLaunchKernelGGL(km_hist_kernel, dim3(256), dim3(256), (size_t)K * sizeof(int), s, labels, icounts, N, K);
     hipLaunchKernelGGL(km_scan_kernel, dim3(1), dim3(256), 0, s, icounts, cursor, counts, K);
     hipLaunchKernelGGL(km_scatter_kernel, dim3((N + KM_SCAT - 1) / KM_SCAT), dim3(256), (size_t)K * sizeof(int), s, labels, cursor, order,
                        lab_sorted, N, K);
     const dim3 grid((N + KM_SEG - 1) / KM_SEG);
     const int dpt = (D + 255) / 256;
-    if (dpt <= 1) hipLaunchKernelGGL(km_segsum_kernel<1>, grid, dim3(256), 0, s, x, order, lab_sorted, csum, N, D);
-    else if (dpt <= 2) hipLaunchKernelGGL(km_segsum_kernel<2>, grid, dim3(256), 0, s, x, order, lab_sorted, csum, N, D);
-    else if (dpt <= 3) hipLaunchKernelGGL(km_segsum_kernel<3>, grid, dim3(256), 0, s, x, order, lab_sorted, csum, N, D);
-    else if (dpt <= 4) hipLaunchKernelGGL(km_segsum_kernel<4>, grid, dim3(256), 0, s, x, order, lab_sorted, csum, N, D);
-    else hipLaunchKernelGGL(km_segsum_kernel<8>, grid, dim3(256), 0, s, x, order, lab_sorted, csum, N, D);
+    if (dpt <= 1) hipLaunchKernelGGL(km_segsum_kernel<1>, grid, dim3(256), 0, s, x, order, lab_sorted, csum, N, D, cursor + K - 1);
+    else if (dpt <= 2) hipLaunchKernelGGL(km_segsum_kernel<2>, grid, dim3(256), 0, s, x, order, lab_sorted, csum, N, D, cursor + K - 1);
+    else if (dpt <= 3) hipLaunchKernelGGL(km_segsum_kernel<3>, grid, dim3(256), 0, s, x, order, lab_sorted, csum, N, D, cursor + K - 1);
+    else if (dpt <= 4) hipLaunchKernelGGL(km_segsum_kernel<4>, grid, dim3(256), 0, s, x, order, lab_sorted, csum, N, D, cursor + K - 1);
+    else hipLaunchKernelGGL(km_segsum_kernel<8>, grid, dim3(256), 0, s, x, order, lab_sorted, csum, N, D, cursor + K - 1);
     U2_CHECK_LAUNCH();
     return 0;
   }
