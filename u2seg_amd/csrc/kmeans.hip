@@ -677,10 +677,10 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
 //    below any margin.
 #ifdef U2_KM_TRACE
 // measurement build (tools/exp/km_trace.sh): s_memtime of waves 0 (centroid requests) and 4 (x requests) at kernel entry, first barrier,
-// loop exit and kernel exit, per work-group; read back through u2_km_trace_dump
-__device__ unsigned long long km_trace[8192 * 8];
+// behind the loop and behind the arg-min of the work-group's first tile, kernel exit; read back through u2_km_trace_dump
+__device__ unsigned long long km_trace[8192 * 16];   // [work-group][role][8]
 #define U2_KM_STAMP(I)                                                                                  \
-  if ((w == 0 || w == 4) && lane == 0 && blockIdx.x < 8192) km_trace[blockIdx.x * 8 + (w >> 2) * 4 + (I)] = __builtin_amdgcn_s_memtime()
+  if ((w == 0 || w == 4) && lane == 0 && blockIdx.x < 8192) km_trace[blockIdx.x * 16 + (w >> 2) * 8 + (I)] = __builtin_amdgcn_s_memtime()
 #else
 #define U2_KM_STAMP(I)
 #endif
@@ -708,41 +708,57 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
-  const int p0 = blockIdx.x * KS_PTS + w * 32;
   const int nsteps = D >> 5;
+  // Persistent: the work-group takes the tiles blockIdx.x, blockIdx.x + gridDim.x, ... (one work-group per CU) and both request streams
+  // run on across the tile boundary - the x of the next tile's first steps is in flight while this tile's last steps and its arg-min
+  // run (as one launch per tile, 7-9 % of a work-group's life was the wait for its first stage).  g counts steps over all tiles of the
+  // work-group: stage g % 3, slot g % KC_SLOTS.
+  const int ntiles = (N + KS_PTS - 1) / KS_PTS;
+  const int nmine = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int T = nmine * nsteps;
+  if (T == 0) return;
   unsigned char* const xring = ks_smem + KS_RING * KC_STAGE;
   float* const cnl = reinterpret_cast<float*>(ks_smem + KC_RINGS);
   const bool xrole = w >= 4;
   U2_KM_STAMP(0);
-  // what the epilogue needs from memory is fetched now: |c_j|^2 into LDS (a huge finite value for j >= K: an infinity would turn into a
-  // NaN when the block index is or-ed into it), and the norm of the point this lane will write (lanes fr < 8: point block fr >> 2, row
-  // fg * 4 + (fr & 3); xnorm is padded to the grid)
+  // |c_j|^2 for the arg-min, in LDS (a huge finite value for j >= K: an infinity would turn into a NaN when the block index is or-ed in)
   if (tid < KS_KMAX) cnl[tid] = tid < K ? cn[tid] : 3.0e38f;
-  const int pmine = p0 + ((fr >> 2) & 1) * 16 + fg * 4 + (fr & 3);
-  const float xn = xnorm[pmine];
-  // one address set per wave: centroid rows (w * 5 + i) * 16 .. + 15 (64 bytes further per step) or x groups (w - 4) * 4 + i
-  // (gridDim.x * 16 KB further per step); i = 4 is unused by the x waves
+  // one address set per wave: centroid rows (w * 5 + i) * 16 .. + 15 (64 bytes further per step, back to the start with every tile) or
+  // x groups (w - 4) * 4 + i of the tile (ntiles * 16 KB further per step); i = 4 is unused by the x waves
+  const size_t xstep = (size_t)ntiles * 16 * 1024;
   const unsigned char* gp[5];
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int row = (w * 5 + i) * 16 + (lane >> 2);
-    gp[i] = xrole ? xh + ((size_t)blockIdx.x * 16 + (size_t)((w - 4) * 4 + (i & 3))) * 1024 + lane * 16
-                  : reinterpret_cast<const unsigned char*>(chl + (size_t)min(row, KS_KMAX - 1) * D + (((lane & 3) ^ ks_swz(lane >> 2)) << 3));
-  }
-  const size_t gstep = xrole ? (size_t)gridDim.x * 16 * 1024 : 64;
-  auto stage_c = [&](int buf) {
+  int rs = 0, rtile = blockIdx.x;                // step and tile of the next request
+  auto point_requests = [&]() {
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      __builtin_amdgcn_global_load_lds(U2_GLB_PTR(gp[i]), U2_LDS_PTR(ks_smem + buf * KC_STAGE + (w * 5 + i) * 1024), 16, 0, 0);
-      gp[i] += gstep;
+      const int row = (w * 5 + i) * 16 + (lane >> 2);
+      gp[i] = xrole ? xh + ((size_t)rtile * 16 + (size_t)((w - 4) * 4 + (i & 3))) * 1024 + lane * 16
+                    : reinterpret_cast<const unsigned char*>(chl + (size_t)min(row, KS_KMAX - 1) * D + (((lane & 3) ^ ks_swz(lane >> 2)) << 3));
     }
+  };
+  point_requests();
+  auto advance_requests = [&]() {
+    if (++rs == nsteps) {
+      rs = 0;
+      rtile += gridDim.x;
+      point_requests();
+    } else {
+      const size_t gstep = xrole ? xstep : 64;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) gp[i] += gstep;
+    }
+  };
+  auto stage_c = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      __builtin_amdgcn_global_load_lds(U2_GLB_PTR(gp[i]), U2_LDS_PTR(ks_smem + buf * KC_STAGE + (w * 5 + i) * 1024), 16, 0, 0);
+    advance_requests();
   };
   auto stage_x = [&](int slot) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds(U2_GLB_PTR(gp[i]), U2_LDS_PTR(xring + slot * KC_SLOT + ((w - 4) * 4 + i) * 1024), 16, 0, 0);
-      gp[i] += gstep;
-    }
+    advance_requests();
   };
   // s_waitcnt vmcnt for a wave-uniform count that is not a compile-time constant: `n` steps of x (four instructions each) may stay in flight
   auto wait_x = [&](int n) {
@@ -759,146 +775,153 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
   const unsigned boff = (unsigned)(fr * 64 + ((fg ^ ks_swz(fr)) << 4));                               // B fragment of block nb: + nb * 1024
   const unsigned xoff = (unsigned)(size_t)U2_LDS_PTR(xring) + (unsigned)(w * 2048 + lane * 16);      // A fragment of point block m: + m * 1024
 
-  f32x4 acc[2][KS_NB];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int nb = 0; nb < KS_NB; ++nb) acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // the two plain loads above are the oldest entries of the queue: they have left it when any of the counted waits below is satisfied
+  // the plain load above is the oldest entry of the queue: it has left it when any of the counted waits below is satisfied
   if (!xrole) {                                  // c(0), c(1); complete before step 0: c(0)
     stage_c(0);
-    if (nsteps > 1) {
+    if (T > 1) {
       stage_c(1);
       asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-  } else {                                       // x(0 .. KC_SLOTS - 2) (step s requests x(s + KC_SLOTS - 1)); complete before step 0: x(0)
-    const int npre = min(KC_SLOTS - 1, nsteps);
+  } else {                                       // x(0 .. KC_SLOTS - 2) (step g requests x(g + KC_SLOTS - 1)); complete before step 0: x(0)
+    const int npre = min(KC_SLOTS - 1, T);
     for (int j = 0; j < npre; ++j) stage_x(j);
     wait_x(npre - 1);
   }
   U2_KM_STAMP(1);
-  int cbuf = 0, xslot = 0;                       // s % 3, s % KC_SLOTS
-  for (int s = 0; s < nsteps; ++s) {
-    if (!(U2_KC_ABL & 8)) __builtin_amdgcn_s_barrier();   // stage / slot s are complete for every wave, and every wave is done with step s - 1
-    asm volatile("" ::: "memory");
-    s16x8 ah[2];
-    const unsigned xs = xoff + (unsigned)(xslot * KC_SLOT);
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(ah[0]), "=&v"(ah[1]) : "v"(xs) : "memory");
-    // this step's requests go to the stage / slot that every wave read in step s - 1 (the barrier above has seen that)
-    if (U2_KC_ABL & 4) {
-    } else if (!xrole) {
-      if (s + 2 < nsteps) stage_c(cbuf == 0 ? 2 : cbuf - 1);
-    } else {
-      if (s + KC_SLOTS - 1 < nsteps) stage_x(xslot == 0 ? KC_SLOTS - 1 : xslot - 1);
-    }
-    // centroid fragments four blocks at a time, group g + 1 requested in front of the eight MFMAs of group g (in-order LDS returns,
-    // counted waits that name the registers they release)
-    s16x8 bq[2][4];
-    const unsigned sba = lds0 + (unsigned)(cbuf * KC_STAGE) + boff;
+  const float cmax = sqrtf(__uint_as_float(*cmax2));
+  int cbuf = 0, xslot = 0, g = 0;                // g % 3, g % KC_SLOTS
+  for (int it = 0; it < nmine; ++it) {
+    f32x4 acc[2][KS_NB];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int nb = 0; nb < KS_NB; ++nb) acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsteps; ++s, ++g) {
+      if (!(U2_KC_ABL & 8)) __builtin_amdgcn_s_barrier();   // stage / slot g are complete for every wave, and every wave is done with step g - 1
+      asm volatile("" ::: "memory");
+      s16x8 ah[2];
+      const unsigned xs = xoff + (unsigned)(xslot * KC_SLOT);
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(ah[0]), "=&v"(ah[1]) : "v"(xs) : "memory");
+      // this step's requests go to the stage / slot that every wave read in step g - 1 (the barrier above has seen that)
+      if (U2_KC_ABL & 4) {
+      } else if (!xrole) {
+        if (g + 2 < T) stage_c(cbuf == 0 ? 2 : cbuf - 1);
+      } else {
+        if (g + KC_SLOTS - 1 < T) stage_x(xslot == 0 ? KC_SLOTS - 1 : xslot - 1);
+      }
+      // centroid fragments four blocks at a time, group g + 1 requested in front of the eight MFMAs of group g (in-order LDS returns,
+      // counted waits that name the registers they release)
+      s16x8 bq[2][4];
+      const unsigned sba = lds0 + (unsigned)(cbuf * KC_STAGE) + boff;
 #define U2_KC_LDQ(SET, NB)                                                                                                    \
-    if (!(U2_KC_ABL & 2) || (NB) < 8)                                                                                          \
-    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t"         \
-                 "ds_read_b128 %3, %4 offset:%8"                                                                               \
-                 : "=&v"(bq[SET][0]), "=&v"(bq[SET][1]), "=&v"(bq[SET][2]), "=&v"(bq[SET][3])                                 \
-                 : "v"(sba), "n"((NB) * 1024), "n"(((NB) + 1) * 1024), "n"(((NB) + 2) * 1024), "n"(((NB) + 3) * 1024) : "memory")
+      if (!(U2_KC_ABL & 2) || (NB) < 8)                                                                                        \
+      asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t"       \
+                   "ds_read_b128 %3, %4 offset:%8"                                                                             \
+                   : "=&v"(bq[SET][0]), "=&v"(bq[SET][1]), "=&v"(bq[SET][2]), "=&v"(bq[SET][3])                               \
+                   : "v"(sba), "n"((NB) * 1024), "n"(((NB) + 1) * 1024), "n"(((NB) + 2) * 1024), "n"(((NB) + 3) * 1024) : "memory")
 #define U2_KC_WAIT(SET, CNT)                                                                                                  \
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bq[SET][0]), "+v"(bq[SET][1]), "+v"(bq[SET][2]), "+v"(bq[SET][3]) : "n"(CNT) : "memory")
+      asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bq[SET][0]), "+v"(bq[SET][1]), "+v"(bq[SET][2]), "+v"(bq[SET][3]) : "n"(CNT) : "memory")
 #define U2_KC_QUAD(SET, NB)                                                                                                   \
-    if (!(U2_KC_ABL & 1)) {                                                                                                                       \
-      const s16x8 b0 = bq[SET][0], b1 = bq[SET][1], b2 = bq[SET][2], b3 = bq[SET][3];                                          \
-      acc[0][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b0, acc[0][NB], 0, 0, 0);                                    \
-      acc[1][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b0, acc[1][NB], 0, 0, 0);                                    \
-      acc[0][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b1, acc[0][NB + 1], 0, 0, 0);                            \
-      acc[1][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b1, acc[1][NB + 1], 0, 0, 0);                            \
-      acc[0][NB + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b2, acc[0][NB + 2], 0, 0, 0);                            \
-      acc[1][NB + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b2, acc[1][NB + 2], 0, 0, 0);                            \
-      acc[0][NB + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b3, acc[0][NB + 3], 0, 0, 0);                            \
-      acc[1][NB + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b3, acc[1][NB + 3], 0, 0, 0);                            \
-    }
-    static_assert(KS_NB == 20, "the unrolled group sequence below covers 20 centroid blocks");
-    U2_KC_LDQ(0, 0);
-    U2_KC_LDQ(1, 4);
-    // the x fragments were requested first: behind this wait they and group 0 are there, group 1 is in flight
-    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[0]), "+v"(ah[1]), "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3])::"memory");
-    U2_KC_QUAD(0, 0)
-    U2_KC_LDQ(0, 8);
-    U2_KC_WAIT(1, 4);
-    U2_KC_QUAD(1, 4)
-    U2_KC_LDQ(1, 12);
-    U2_KC_WAIT(0, 4);
-    U2_KC_QUAD(0, 8)
-    U2_KC_LDQ(0, 16);
-    U2_KC_WAIT(1, 4);
-    U2_KC_QUAD(1, 12)
-    U2_KC_WAIT(0, 0);
-    U2_KC_QUAD(0, 16)
+      if (!(U2_KC_ABL & 1)) {                                                                                                  \
+        const s16x8 b0 = bq[SET][0], b1 = bq[SET][1], b2 = bq[SET][2], b3 = bq[SET][3];                                        \
+        acc[0][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b0, acc[0][NB], 0, 0, 0);                                  \
+        acc[1][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b0, acc[1][NB], 0, 0, 0);                                  \
+        acc[0][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b1, acc[0][NB + 1], 0, 0, 0);                          \
+        acc[1][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b1, acc[1][NB + 1], 0, 0, 0);                          \
+        acc[0][NB + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b2, acc[0][NB + 2], 0, 0, 0);                          \
+        acc[1][NB + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b2, acc[1][NB + 2], 0, 0, 0);                          \
+        acc[0][NB + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b3, acc[0][NB + 3], 0, 0, 0);                          \
+        acc[1][NB + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b3, acc[1][NB + 3], 0, 0, 0);                          \
+      }
+      static_assert(KS_NB == 20, "the unrolled group sequence below covers 20 centroid blocks");
+      U2_KC_LDQ(0, 0);
+      U2_KC_LDQ(1, 4);
+      // the x fragments were requested first: behind this wait they and group 0 are there, group 1 is in flight
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[0]), "+v"(ah[1]), "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3])::"memory");
+      U2_KC_QUAD(0, 0)
+      U2_KC_LDQ(0, 8);
+      U2_KC_WAIT(1, 4);
+      U2_KC_QUAD(1, 4)
+      U2_KC_LDQ(1, 12);
+      U2_KC_WAIT(0, 4);
+      U2_KC_QUAD(0, 8)
+      U2_KC_LDQ(0, 16);
+      U2_KC_WAIT(1, 4);
+      U2_KC_QUAD(1, 12)
+      U2_KC_WAIT(0, 0);
+      U2_KC_QUAD(0, 16)
 #undef U2_KC_QUAD
 #undef U2_KC_WAIT
 #undef U2_KC_LDQ
-    // close the step: the centroid waves leave c(s + 2) in flight, the x waves x(s + 2 .. s + KC_SLOTS - 1) as far as they exist
-    if (!xrole) {
-      if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      wait_x(min(max(nsteps - s - 2, 0), KC_SLOTS - 2));
+      // close the step: the centroid waves leave c(g + 2) in flight, the x waves x(g + 2 .. g + KC_SLOTS - 1) as far as they exist
+      if (!xrole) {
+        if (g + 2 < T) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        wait_x(min(max(T - g - 2, 0), KC_SLOTS - 2));
+      }
+      cbuf = cbuf == 2 ? 0 : cbuf + 1;
+      xslot = xslot == KC_SLOTS - 1 ? 0 : xslot + 1;
     }
-    cbuf = cbuf == 2 ? 0 : cbuf + 1;
-    xslot = xslot == KC_SLOTS - 1 ? 0 : xslot + 1;
-  }
-  __syncthreads();
-  U2_KM_STAMP(2);
-  const float cmax = sqrtf(__uint_as_float(*cmax2));
-  float cnr[KS_NB];
+    if (it == 0) { U2_KM_STAMP(2); }
+    // ---- arg-min of the tile (registers and cnl only: no barrier - the waves meet again at the barrier of the next step) ----
+    // the point this lane writes (lanes fr < 8: point block fr >> 2, row fg * 4 + (fr & 3)); xnorm is padded to whole tiles.  The load
+    // is younger than every request in flight, so the wait in front of its use also waits for those - all but the last step's have
+    // had the arg-min's length to land
+    const int pmine = ((int)blockIdx.x + it * (int)gridDim.x) * KS_PTS + w * 32 + ((fr >> 2) & 1) * 16 + fg * 4 + (fr & 3);
+    const float xn = xnorm[pmine];
+    float cnr[KS_NB];
 #pragma unroll
-  for (int nb = 0; nb < KS_NB; ++nb) cnr[nb] = cnl[nb * 16 + fr];
-  float kb = INFINITY, ks = INFINITY;   // (best | centroid index, second best) of the point this lane writes
+    for (int nb = 0; nb < KS_NB; ++nb) cnr[nb] = cnl[nb * 16 + fr];
+    float kb = INFINITY, ks = INFINITY;   // (best | centroid index, second best) of the point this lane writes
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    float b[4], s2[4];
+    for (int m = 0; m < 2; ++m) {
+      float b[4], s2[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { b[r] = INFINITY; s2[r] = INFINITY; }
+      for (int r = 0; r < 4; ++r) { b[r] = INFINITY; s2[r] = INFINITY; }
 #pragma unroll
-    for (int nb = 0; nb < KS_NB; ++nb)
+      for (int nb = 0; nb < KS_NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = fmaf(acc[m][nb][r], -2.f, cnr[nb]);                        // cn - 2 x.c
+          v = __uint_as_float((__float_as_uint(v) & 0xffffffe0u) | (unsigned)nb);
+          s2[r] = __builtin_amdgcn_fmed3f(b[r], s2[r], v);                       // b <= s2: the middle one is the new second best
+          b[r] = kc_min(b[r], v);
+        }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = fmaf(acc[m][nb][r], -2.f, cnr[nb]);                        // cn - 2 x.c
-        v = __uint_as_float((__float_as_uint(v) & 0xffffffe0u) | (unsigned)nb);
-        s2[r] = __builtin_amdgcn_fmed3f(b[r], s2[r], v);                       // b <= s2: the middle one is the new second best
-        b[r] = kc_min(b[r], v);
-      }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const unsigned ub = __float_as_uint(b[r]);
-      float bb = __uint_as_float((ub & 0xfffffe00u) | ((ub & 31u) << 4) | (unsigned)fr), ss = s2[r];
-      // the 16 lanes of a DPP row hold the 16 centroids of every block: xor 1, xor 2 (quad permutes), the other quad of the half row,
-      // the other half row
+        const unsigned ub = __float_as_uint(b[r]);
+        float bb = __uint_as_float((ub & 0xfffffe00u) | ((ub & 31u) << 4) | (unsigned)fr), ss = s2[r];
+        // the 16 lanes of a DPP row hold the 16 centroids of every block: xor 1, xor 2 (quad permutes), the other quad of the half
+        // row, the other half row
 #define U2_KC_MERGE(CTRL)                                                                                                   \
-      {                                                                                                                      \
-        const float ob = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bb), CTRL, 0xf, 0xf, true));           \
-        const float os = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), CTRL, 0xf, 0xf, true));           \
-        ss = kc_min(kc_min(ss, os), kc_max(bb, ob));                                                                         \
-        bb = kc_min(bb, ob);                                                                                                 \
-      }
-      U2_KC_MERGE(0xB1)    // quad_perm [1, 0, 3, 2]
-      U2_KC_MERGE(0x4E)    // quad_perm [2, 3, 0, 1]
-      U2_KC_MERGE(0x141)   // row_half_mirror
-      U2_KC_MERGE(0x140)   // row_mirror
+        {                                                                                                                    \
+          const float ob = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bb), CTRL, 0xf, 0xf, true));         \
+          const float os = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), CTRL, 0xf, 0xf, true));         \
+          ss = kc_min(kc_min(ss, os), kc_max(bb, ob));                                                                       \
+          bb = kc_min(bb, ob);                                                                                               \
+        }
+        U2_KC_MERGE(0xB1)    // quad_perm [1, 0, 3, 2]
+        U2_KC_MERGE(0x4E)    // quad_perm [2, 3, 0, 1]
+        U2_KC_MERGE(0x141)   // row_half_mirror
+        U2_KC_MERGE(0x140)   // row_mirror
 #undef U2_KC_MERGE
-      const bool mine = fr == m * 4 + r;
-      kb = mine ? bb : kb;
-      ks = mine ? ss : ks;
+        const bool mine = fr == m * 4 + r;
+        kb = mine ? bb : kb;
+        ks = mine ? ss : ks;
+      }
     }
+    if (fr < 8 && pmine < N) {
+      labels[pmine] = (long long)(__float_as_uint(kb) & 511u);
+      // screening margin + the mantissa bits the indices took: 2^-14 of a distance at most, |distance| <= |c|^2 + 2 |x| |c| (twice that here)
+      const float margin = margin_rel * cmax * xn + 1.2207031e-4f * (cmax * cmax + 2.f * xn * cmax);
+      if (!(ks - kb >= margin)) list[atomicAdd(nlist, 1)] = pmine;   // also: NaN anywhere
+    }
+    if (it == 0) { U2_KM_STAMP(3); }
   }
-  if (fr < 8 && pmine < N) {
-    labels[pmine] = (long long)(__float_as_uint(kb) & 511u);
-    // screening margin + the mantissa bits the indices took: 2^-14 of a distance at most, |distance| <= |c|^2 + 2 |x| |c| (twice that here)
-    const float margin = margin_rel * cmax * xn + 1.2207031e-4f * (cmax * cmax + 2.f * xn * cmax);
-    if (!(ks - kb >= margin)) list[atomicAdd(nlist, 1)] = pmine;   // also: NaN anywhere
-  }
-  U2_KM_STAMP(3);
+  U2_KM_STAMP(4);
 }
 
 // csum[K][D] += x rows by label; counts[K] += 1.  grid = (point chunks, D / DS); LDS holds [K][DS] partial sums.
@@ -1133,6 +1156,19 @@ extern "C" int u2_km_trace_dump(unsigned long long* host, int words) {
 }
 
 #endif
+// compute units of the current device (the persistent coarse pass launches one work-group per CU)
+static int km_cu_count() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
 // words (floats) of the bf16 shadow itself; |x_p| follows it
 static size_t km_shadow_words(int N, int D) { return (size_t)(D >> 5) * (size_t)((N + KS_PTS - 1) / KS_PTS) * 16 * 256; }
 
@@ -1201,7 +1237,7 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
   if (two_level) {
     // coarse pass over everything -> list1; fine pass over list1 -> list2 (both skipped while the coarse pass is switched off)
     if (shadow)
-      hipLaunchKernelGGL(kmeans_coarse_kernel, grid, block, KC_LDS, s, reinterpret_cast<const unsigned char*>(shadow),
+      hipLaunchKernelGGL(kmeans_coarse_kernel, dim3(grid.x < (unsigned)km_cu_count() ? grid.x : (unsigned)km_cu_count()), block, KC_LDS, s, reinterpret_cast<const unsigned char*>(shadow),
                          shadow + km_shadow_words(N, D), chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D, K, 0.02f, gate, 0);
     else
       hipLaunchKernelGGL(kmeans_screen_kernel<1>, grid, block, lds1, s, x, chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D,
