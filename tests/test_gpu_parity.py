@@ -751,6 +751,58 @@ def test_kmeans_screened_assign_equals_exact():
     assert n_checked < 1000  # the last (well separated, K = 17) case re-checks almost nothing
 
 
+def test_kmeans_shadow_pass_equals_exact(monkeypatch):
+    """Round 6: the first screening pass over the bf16 shadow of x (u2_kmeans_prepare / u2_kmeans_assign_shadow, kmeans_coarse_kernel:
+    persistent work-groups, index bits in the distances).  Labels must be the exact-fp32 kernel's for every point - more tiles than CUs
+    with a ragged last one, near-duplicate and duplicate centroids, rows of tiny norm (the index bits' share of the margin), a zero row,
+    NaN / Inf rows - and the shadow must follow x: reused for the same tensor, re-made after an in-place write and for another tensor."""
+    from u2seg_amd.cluster import kmeans as KM
+
+    monkeypatch.setattr(KM, "SHADOW_MIN_POINTS", 256)
+    KM.release_shadow()
+    g = torch.Generator().manual_seed(61)
+    n, d, k = 70001, 768, 300
+    centers = torch.randn((k, d), generator=g) * 2
+    xm = centers[torch.randint(0, k, (n,), generator=g)] + 0.5 * torch.randn((n, d), generator=g)
+    xm[100:164] *= 1e-4
+    xm[200] = 0
+    xm[300, 5] = float("nan")
+    xm[301, 7] = float("inf")
+    cm = centers + 0.3 * torch.randn((k, d), generator=g)
+    xu = _clustered_unit_rows(30011, 384, 5, nclusters=12)
+    cu = xu[torch.randperm(30011, generator=g)[:299]].clone()
+    cu[7] = cu[3]
+    cu[100:140] = cu[50:90] + 1e-6
+    cases = [(xm, cm), (xu, cu), (torch.randn((1000, 64), generator=g) * 5, torch.randn((17, 64), generator=g) * 5)]
+    for i, (x, c) in enumerate(cases):
+        xd, cd = x.to(DEV), c.to(DEV)
+        KM._ws_cache.pop("assign:" + str(xd.device), None)   # the first pass starts switched on
+        fast = KM.assign(xd, cd)
+        und = KM.last_coarse_undecided(xd.device)
+        sh = KM._shadow(xd)
+        assert sh is not None and KM._shadow(xd) is sh        # made by assign(), found again
+        exact = KM.assign(xd, cd, exact=True)
+        assert torch.equal(fast, exact), (i, int((fast != exact).sum()), und)
+        if i == 0:
+            assert 0 < und < n // 50, und                     # the pass ran, decided the mixture and handed on the odd rows
+            ref = O.kmeans_assign(x[:600], c)
+            lab = exact[:600].cpu()
+            bad = torch.nonzero((lab != ref) & torch.isfinite(x[:600]).all(1))[:, 0]
+            assert torch.allclose(((x[bad] - c[lab[bad]]) ** 2).sum(1), ((x[bad] - c[ref[bad]]) ** 2).sum(1), rtol=1e-5)  # fp32-level ties only
+            # an in-place write invalidates the shadow: row 0 becomes another cluster's member
+            other = int(exact[1]) if int(exact[1]) != int(exact[0]) else int(exact[2])
+            xd[0] = cd[other]
+            fast2 = KM.assign(xd, cd)
+            assert KM._shadow(xd) is sh                        # same buffer, re-filled (the version moved)
+            assert int(fast2[0]) == other and torch.equal(fast2, KM.assign(xd, cd, exact=True))
+            xc = xd.clone()                                    # another tensor object: its own shadow content
+            xc[1] = cd[int(fast2[0])]
+            fast3 = KM.assign(xc, cd)
+            assert int(fast3[1]) == int(fast2[0]) and torch.equal(fast3, KM.assign(xc, cd, exact=True))
+    KM.release_shadow()
+    KM._ws_cache.pop("assign:" + str(DEV), None)
+
+
 def test_kmeans_two_level_screen_modes():
     """The two-level screen (round 4): on clustered data the first pass (leading bf16 pieces only) decides nearly everything and
     the labels are the exact kernel's; on unstructured data it leaves most points undecided, the labels are still the exact
