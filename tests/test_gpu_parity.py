@@ -773,7 +773,8 @@ def test_kmeans_shadow_pass_equals_exact(monkeypatch):
     cu = xu[torch.randperm(30011, generator=g)[:299]].clone()
     cu[7] = cu[3]
     cu[100:140] = cu[50:90] + 1e-6
-    cases = [(xm, cm), (xu, cu), (torch.randn((1000, 64), generator=g) * 5, torch.randn((17, 64), generator=g) * 5)]
+    cases = [(xm, cm), (xu, cu), (torch.randn((1000, 64), generator=g) * 5, torch.randn((17, 64), generator=g) * 5),
+             (torch.randn((300, 32), generator=g) * 3, torch.randn((5, 32), generator=g) * 3)]   # one step per tile, two tiles
     for i, (x, c) in enumerate(cases):
         xd, cd = x.to(DEV), c.to(DEV)
         KM._ws_cache.pop("assign:" + str(xd.device), None)   # the first pass starts switched on
