@@ -244,6 +244,10 @@ __device__ __forceinline__ uint32_t ks_pack(float lo, float hi) {  // v_cvt_pk_b
   return *reinterpret_cast<const uint32_t*>(&r);
 }
 __device__ __forceinline__ int ks_swz(int row) { return (-(row >> 2)) & 3; }  // 64-byte rows: conflict-free ds_read_b128
+// v_min_f32 / v_max_f32 as they are: fminf / fmaxf on a value that went through integer instructions get a canonicalising v_max_f32 v, v, v
+// in front (a fifth of the arg-min's instructions); a signalling NaN cannot come out of an fma, and every NaN case goes by the margin
+__device__ __forceinline__ float kc_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float kc_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 // ---- the leading-bf16 shadow of x (round 6) ---------------------------------------------------------------------------------
 // x does not change between Lloyd iterations, and the coarse pass only ever uses bf16(x): u2_kmeans_prepare writes that once, in the
@@ -597,39 +601,43 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
     if (fg == 0) norms[w * 32 + m * 16 + fr] = sqrtf(v);
   }
   __syncthreads();
-  const float margin_unit = margin_rel * sqrtf(__uint_as_float(*cmax2));
+  const float cmax = sqrtf(__uint_as_float(*cmax2));
   // Branch-free arg-min (round 4: the first version - km_less per element, one global load of |c_j|^2 per use, ds_bpermute
   // shuffles - compiled to ~700 divergent branches and was 0.32 of the kernel's 1.8 ms, with the matrix pipe idle meanwhile).
+  // Round 6 (from kmeans_coarse_kernel, where the stamps put a third of a work-group's life here): inside a lane the block index rides
+  // in the five low mantissa bits of the distance ((v & ~31) | nb: v_and_or_b32), so best and second best are v_min_f32 + v_med3_f32
+  // per value with no compares or selects; the 2^-18 of a distance those bits cost is added to the margin (twice, generously).  The
+  // cross-lane steps carry the index beside the values - nine index bits would cost 2^-14, which is the fine pass's whole margin - and
+  // the 32 results of a wave are moved into 32 lanes and written by one store.
   // NaN needs no ordering here: a NaN or Inf in x makes |x| and therefore the margin NaN / Inf, one in c makes max|c| NaN, and
-  // `!(gap >= margin)` then sends the point to the exact kernel, which orders NaNs like torch.argmin; v_min / v_cmp_lt simply
-  // skip the NaN operands.  Ties keep the lowest index: ascending blocks with a strict compare inside a lane, (value, index)
-  // order in the cross-lane steps.
+  // `!(gap >= margin)` then sends the point to the exact kernel, which orders NaNs like torch.argmin; v_min skips a NaN operand and
+  // v_med3 answers min3 when it sees one (second best = best: undecided).  Ties need no rule either: a gap of zero is below any margin.
   float cnr[KS_NB];
 #pragma unroll
   for (int nb = 0; nb < KS_NB; ++nb) {
     const int j = nb * 16 + fr;
     cnr[nb] = cn[min(j, K - 1)];
-    cnr[nb] = j < K ? cnr[nb] : INFINITY;
+    cnr[nb] = j < K ? cnr[nb] : 3.0e38f;   // not an infinity: the index bits would turn it into a NaN
   }
+  float kb = INFINITY, ks = INFINITY;   // best / second best / centroid of the point this lane writes (lanes fr < 8: point block
+  int kj = 0;                           // fr >> 2, row fg * 4 + (fr & 3))
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     float b[4], s2[4];
-    int bn[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { b[r] = INFINITY; s2[r] = INFINITY; bn[r] = 0; }
+    for (int r = 0; r < 4; ++r) { b[r] = INFINITY; s2[r] = INFINITY; }
 #pragma unroll
     for (int nb = 0; nb < KS_NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v = fmaf(acc[m][nb][r], -2.f, cnr[nb]);   // cn - 2 x.c (the product by 2 is exact: same value as before)
-        const bool lt = v < b[r];
-        s2[r] = fminf(s2[r], lt ? b[r] : v);
-        bn[r] = lt ? nb : bn[r];
-        b[r] = fminf(b[r], v);
+        float v = fmaf(acc[m][nb][r], -2.f, cnr[nb]);   // cn - 2 x.c
+        v = __uint_as_float((__float_as_uint(v) & 0xffffffe0u) | (unsigned)nb);
+        s2[r] = __builtin_amdgcn_fmed3f(b[r], s2[r], v);  // b <= s2: the middle one is the new second best
+        b[r] = kc_min(b[r], v);
       }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      int bj = bn[r] * 16 + fr;
+      int bj = (int)(__float_as_uint(b[r]) & 31u) * 16 + fr;
       float bb = b[r], ss = s2[r];
       // the 16 lanes of a DPP row hold the 16 centroids of every block: xor 1, xor 2 (quad permutes), then the other quad of
       // the half row, then the other half row (all lanes of a quad / a half row agree by then)
@@ -639,23 +647,30 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
         const float os = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), CTRL, 0xf, 0xf, true));           \
         const int oj = __builtin_amdgcn_update_dpp(0, bj, CTRL, 0xf, 0xf, true);                                            \
         const bool lt = ob < bb || (ob == bb && oj < bj);                                                                    \
-        ss = fminf(fminf(ss, os), lt ? bb : ob);                                                                             \
+        ss = kc_min(kc_min(ss, os), lt ? bb : ob);                                                                           \
         bj = lt ? oj : bj;                                                                                                   \
-        bb = fminf(bb, ob);                                                                                                  \
+        bb = kc_min(bb, ob);                                                                                                 \
       }
       U2_KS_MERGE(0xB1)    // quad_perm [1, 0, 3, 2]
       U2_KS_MERGE(0x4E)    // quad_perm [2, 3, 0, 1]
       U2_KS_MERGE(0x141)   // row_half_mirror
       U2_KS_MERGE(0x140)   // row_mirror
 #undef U2_KS_MERGE
-      const int pl = m * 16 + fg * 4 + r;
-      const int p = p0 + pl;
-      if (fr == 0 && p < N) {
-        const int row = rows ? rows[p] : p;
-        labels[row] = (long long)bj;
-        if (!(ss - bb >= margin_unit * norms[w * 32 + pl])) list[atomicAdd(nlist, 1)] = row;  // also: NaN anywhere, K == 1
-      }
+      const bool mine = fr == m * 4 + r;
+      kb = mine ? bb : kb;
+      ks = mine ? ss : ks;
+      kj = mine ? bj : kj;
     }
+  }
+  const int pl = ((fr >> 2) & 1) * 16 + fg * 4 + (fr & 3);
+  const int p = p0 + pl;
+  if (fr < 8 && p < N) {
+    const int row = rows ? rows[p] : p;
+    labels[row] = (long long)kj;
+    // screening margin + the mantissa bits the block index took: |distance| <= |c|^2 + 2 |x| |c|
+    const float xn = norms[w * 32 + pl];
+    const float margin = margin_rel * cmax * xn + 7.6293945e-6f * (cmax * cmax + 2.f * xn * cmax);
+    if (!(ks - kb >= margin)) list[atomicAdd(nlist, 1)] = row;  // also: NaN anywhere, K == 1
   }
 }
 
@@ -684,10 +699,6 @@ __device__ unsigned long long km_trace[8192 * 16];   // [work-group][role][8]
 #else
 #define U2_KM_STAMP(I)
 #endif
-// v_min_f32 / v_max_f32 as they are: fminf / fmaxf on a value that went through integer instructions get a canonicalising v_max_f32 v, v, v
-// in front (a fifth of the arg-min's instructions); a signalling NaN cannot come out of an fma, and every NaN case goes by the margin
-__device__ __forceinline__ float kc_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float kc_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // timing-only ablations of the loop (results are wrong): 1 no MFMAs, 2 no centroid-fragment reads behind the first group, 4 no LDS-DMA
 // requests in the loop, 8 no barrier
 #ifndef U2_KC_ABL
