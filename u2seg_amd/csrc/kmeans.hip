@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void csplit_kernel(const float* __restrict__ c
                                                      unsigned* __restrict__ cmax2, int D, int K) {
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= KS_KMAX) return;
-  float s = 0.f;
+  float s = 0.f, slo = 0.f;
   // Within every 32-dimension step the dimensions are stored in the order the screening kernel's x loads deliver them: position
   // fg * 8 + e holds dimension fg * 4 + e (e < 4) or 16 + fg * 4 + (e - 4) - a lane of the MFMA A operand then gets its eight
   // values from two 16-byte loads that are 64 bytes apart, and the four lanes of a row read 64 contiguous bytes per instruction.
@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void csplit_kernel(const float* __restrict__ c
     const bf16_t h = f2bf(v);
     chl[(size_t)j * D + d] = h;
     chl[((size_t)KS_KMAX + j) * D + d] = f2bf(v - bf2f(h));
+    slo += (v - bf2f(h)) * (v - bf2f(h));   // |c_j - bf16(c_j)|^2 (the permutation does not change the sum's terms)
     // |c_j|^2 is summed over the UNPERMUTED dimensions, lane by lane exactly as cnorm_kernel does: the re-check must see the
     // same bits as a run of the exact kernel alone, or near-duplicate centroids (exact-fp32 ties) are decided differently
     const float u = j < K ? c[(size_t)j * D + d] : 0.f;
@@ -230,9 +231,11 @@ __global__ __launch_bounds__(256) void csplit_kernel(const float* __restrict__ c
   }
   if (j >= K) return;
   s = wave_sum(s);
+  slo = wave_sum(slo);
   if ((threadIdx.x & 63) == 0) {
     cn[j] = s;
     atomicMax(cmax2, __float_as_uint(s));  // s >= 0: the unsigned order of the bits is the order of the floats
+    atomicMax(cmax2 + 3, __float_as_uint(slo));   // max_j |c_j - bf16(c_j)|^2: the coarse pass's per-point margin
   }
 }
 
@@ -273,17 +276,26 @@ __global__ __launch_bounds__(256) void km_shadow_kernel(const float* __restrict_
   o.x = ks_pack(a.x, a.y); o.y = ks_pack(a.z, a.w); o.z = ks_pack(b.x, b.y); o.w = ks_pack(b.z, b.w);
   xh[t] = o;
 }
+// xn[p] = |x_p|, xn[NP16 + p] = |x_p - bf16(x_p)| (what the coarse pass does not see of the point)
 __global__ __launch_bounds__(256) void km_xnorm_kernel(const float* __restrict__ x, float* __restrict__ xn, int N, int D, int NP16) {
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= NP16) return;
-  float s = 0.f;
+  float s = 0.f, sl = 0.f;
   if (p < N)
     for (int d = (threadIdx.x & 63) * 4; d < D; d += 256) {
       const float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * D + d);
       s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      const uint32_t h0 = ks_pack(v.x, v.y), h1 = ks_pack(v.z, v.w);
+      const float r0 = v.x - __uint_as_float(h0 << 16), r1 = v.y - __uint_as_float(h0 & 0xffff0000u);
+      const float r2 = v.z - __uint_as_float(h1 << 16), r3 = v.w - __uint_as_float(h1 & 0xffff0000u);
+      sl += r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
     }
   s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) xn[p] = sqrtf(s);
+  sl = wave_sum(sl);
+  if ((threadIdx.x & 63) == 0) {
+    xn[p] = sqrtf(s);
+    xn[NP16 + p] = sqrtf(sl);
+  }
 }
 
 // NP = 3: the three products hi.hi + hi.lo + lo.hi (error <= 1.2e-5 |x| |c|, margin_rel 1e-4).  NP = 1 (round 4): hi.hi only - a
@@ -801,7 +813,7 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
     wait_x(npre - 1);
   }
   U2_KM_STAMP(1);
-  const float cmax = sqrtf(__uint_as_float(*cmax2));
+  const float cmax = sqrtf(__uint_as_float(*cmax2)), clomax = sqrtf(__uint_as_float(cmax2[3]));
   int cbuf = 0, xslot = 0, g = 0;                // g % 3, g % KC_SLOTS
   for (int it = 0; it < nmine; ++it) {
     f32x4 acc[2][KS_NB];
@@ -882,7 +894,7 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
     // is younger than every request in flight, so the wait in front of its use also waits for those - all but the last step's have
     // had the arg-min's length to land
     const int pmine = ((int)blockIdx.x + it * (int)gridDim.x) * KS_PTS + w * 32 + ((fr >> 2) & 1) * 16 + fg * 4 + (fr & 3);
-    const float xn = xnorm[pmine];
+    const float xn = xnorm[pmine], xlo = xnorm[ntiles * KS_PTS + pmine];
     float cnr[KS_NB];
 #pragma unroll
     for (int nb = 0; nb < KS_NB; ++nb) cnr[nb] = cnl[nb * 16 + fr];
@@ -926,8 +938,15 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
     }
     if (fr < 8 && pmine < N) {
       labels[pmine] = (long long)(__float_as_uint(kb) & 511u);
-      // screening margin + the mantissa bits the indices took: 2^-14 of a distance at most, |distance| <= |c|^2 + 2 |x| |c| (twice that here)
-      const float margin = margin_rel * cmax * xn + 1.2207031e-4f * (cmax * cmax + 2.f * xn * cmax);
+      // Per-point margin.  What this pass does not see of a product is x.c - x_hi.c_hi = x_lo.c + x_hi.c_lo, at most |x_lo| |c| + |x_hi| |c_lo|
+      // (Cauchy-Schwarz; x_lo = x - bf16(x) and its norm are exact, from u2_kmeans_prepare; |x_hi| <= 1.004 |x|): twice that per
+      // distance, four times between two distances.  With the norms as they are instead of their worst case (2^-9 of |x|, |c| each:
+      // 2^-6 |x| max|c| in all, the 0.02 of kmeans_screen_kernel<1>) the margin is ~0.013 |x| max|c| on fp32 data and zero for
+      // operands that are bf16 values already.  + margin_rel |x| max|c| for everything else (fp32 accumulation here and in the exact
+      // kernel: the fine pass's own margin, three times) + the mantissa bits the indices took (2^-14 of a distance at most,
+      // |distance| <= |c|^2 + 2 |x| |c|; twice that here).
+      const float margin = 4.04f * (xlo * cmax + 1.004f * xn * clomax) + margin_rel * cmax * xn +
+                           1.2207031e-4f * (cmax * cmax + 2.f * xn * cmax);
       if (!(ks - kb >= margin)) list[atomicAdd(nlist, 1)] = pmine;   // also: NaN anywhere
     }
     if (it == 0) { U2_KM_STAMP(3); }
@@ -1146,10 +1165,10 @@ __global__ void km_state_begin_kernel(unsigned* __restrict__ scal, unsigned* __r
   if (threadIdx.x < 4) scal[threadIdx.x] = 0u;
   if (threadIdx.x == 0 && state[0] != KS_MAGIC) { state[0] = KS_MAGIC; state[1] = 0u; state[2] = 0u; state[3] = 0u; }
 }
-__global__ void km_state_end_kernel(const unsigned* __restrict__ scal, unsigned* __restrict__ state, int N) {
+__global__ void km_state_end_kernel(const unsigned* __restrict__ scal, unsigned* __restrict__ state, unsigned limit) {
   if (threadIdx.x != 0) return;
   if (state[1] == 0u) {
-    if (scal[2] > (unsigned)N / 4u) { state[1] = 1u; state[2] = 0u; }
+    if (scal[2] > limit) { state[1] = 1u; state[2] = 0u; }
   } else if (++state[2] >= 64u) {
     state[1] = 0u; state[2] = 0u;
   }
@@ -1185,7 +1204,7 @@ static size_t km_shadow_words(int N, int D) { return (size_t)(D >> 5) * (size_t)
 
 extern "C" long long u2_kmeans_shadow_floats(int N, int D) {
   if (N <= 0 || D % 32 != 0) return 0;
-  return (long long)(km_shadow_words(N, D) + (size_t)((N + KS_PTS - 1) / KS_PTS) * KS_PTS);
+  return (long long)(km_shadow_words(N, D) + 2 * (size_t)((N + KS_PTS - 1) / KS_PTS) * KS_PTS);   // + |x_p|, |x_p - bf16(x_p)|
 }
 
 extern "C" int u2_kmeans_prepare(const float* x, float* shadow, int N, int D, void* stream) {
@@ -1249,7 +1268,7 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
     // coarse pass over everything -> list1; fine pass over list1 -> list2 (both skipped while the coarse pass is switched off)
     if (shadow)
       hipLaunchKernelGGL(kmeans_coarse_kernel, dim3(grid.x < (unsigned)km_cu_count() ? grid.x : (unsigned)km_cu_count()), block, KC_LDS, s, reinterpret_cast<const unsigned char*>(shadow),
-                         shadow + km_shadow_words(N, D), chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D, K, 0.02f, gate, 0);
+                         shadow + km_shadow_words(N, D), chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D, K, 3e-4f, gate, 0);
     else
       hipLaunchKernelGGL(kmeans_screen_kernel<1>, grid, block, lds1, s, x, chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D,
                          K, 0.02f, (const int*)nullptr, (const int*)nullptr, gate, 0);
@@ -1275,7 +1294,11 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
                      (const int*)list2, (const int*)(scal + 1));
   U2_CHECK_LAUNCH();
   if (two_level) {
-    hipLaunchKernelGGL(km_state_end_kernel, dim3(1), dim3(64), 0, s, scal, state, N);
+    // the coarse pass pays while it costs less than the fine pass saves on the points it decides: over the fp32 x it costs half a fine
+    // pass (off above a quarter undecided), over the shadow a third (0.45 vs 1.38 ms at N = 1 M; the fine pass over a list is ~10 %
+    // dearer per point): off above 55 %
+    const unsigned limit = shadow ? (unsigned)((unsigned long long)N * 55u / 100u) : (unsigned)N / 4u;
+    hipLaunchKernelGGL(km_state_end_kernel, dim3(1), dim3(64), 0, s, scal, state, limit);
     U2_CHECK_LAUNCH();
   }
   return 0;
