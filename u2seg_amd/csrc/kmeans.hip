@@ -894,7 +894,14 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
     // is younger than every request in flight, so the wait in front of its use also waits for those - all but the last step's have
     // had the arg-min's length to land
     const int pmine = ((int)blockIdx.x + it * (int)gridDim.x) * KS_PTS + w * 32 + ((fr >> 2) & 1) * 16 + fg * 4 + (fr & 3);
-    const float xn = xnorm[pmine], xlo = xnorm[ntiles * KS_PTS + pmine];
+    // (inline asm: as plain loads the compiler sinks them into the conditional block at the end, right in front of their use - a full
+    // memory round trip per tile with nothing to hide it)
+    float xn, xlo;
+    {
+      const float* np = xnorm + pmine;
+      asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off"
+                   : "=&v"(xn), "=&v"(xlo) : "v"(np), "v"(np + (size_t)ntiles * KS_PTS) : "memory");
+    }
     float cnr[KS_NB];
 #pragma unroll
     for (int nb = 0; nb < KS_NB; ++nb) cnr[nb] = cnl[nb * 16 + fr];
@@ -936,6 +943,7 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
         ks = mine ? ss : ks;
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn), "+v"(xlo)::"memory");
     if (fr < 8 && pmine < N) {
       labels[pmine] = (long long)(__float_as_uint(kb) & 511u);
       // Per-point margin.  What this pass does not see of a product is x.c - x_hi.c_hi = x_lo.c + x_hi.c_lo, at most |x_lo| |c| + |x_hi| |c_lo|
