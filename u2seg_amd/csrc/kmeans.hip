@@ -824,23 +824,9 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
     // the point this lane writes (lanes fr < 8: point block fr >> 2, row fg * 4 + (fr & 3)); xnorm is padded to whole tiles
     const int pmine = ((int)blockIdx.x + it * (int)gridDim.x) * KS_PTS + w * 32 + ((fr >> 2) & 1) * 16 + fg * 4 + (fr & 3);
     float xn, xlo;            // |x_p|, |x_p - bf16(x_p)|
-    bool last_requested = false;
     for (int s = 0; s < nsteps; ++s, ++g) {
       if (!(U2_KC_ABL & 8)) __builtin_amdgcn_s_barrier();   // stage / slot g are complete for every wave, and every wave is done with step g - 1
       asm volatile("" ::: "memory");
-      if (s == nsteps - 1) {
-        // The arg-min's two norms, requested in front of the tile's last ring request: they have the last step and the arg-min to
-        // arrive, and the wait for them leaves that last request in flight.  (Inline asm: as plain loads the compiler sinks them into
-        // the conditional block at the end of the arg-min, right in front of their use - a memory round trip per tile with nothing
-        // to hide it, behind a vmcnt(0) that also drains the ring.  The counted waits of the step are not disturbed: they count
-        // from the youngest request.)
-        const float* np = xnorm + pmine;
-        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off"
-                     : "=&v"(xn), "=&v"(xlo) : "v"(np), "v"(np + (size_t)ntiles * KS_PTS) : "memory");
-#ifndef U2_KM_TRACE   // (the stamps of the measurement build are stores: they would be counted as well)
-        last_requested = !(U2_KC_ABL & 4) && (xrole ? g + KC_SLOTS - 1 < T : g + 2 < T);
-#endif
-      }
       s16x8 ah[2];
       const unsigned xs = xoff + (unsigned)(xslot * KC_SLOT);
       asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(ah[0]), "=&v"(ah[1]) : "v"(xs) : "memory");
@@ -907,6 +893,15 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
     }
     if (it == 0) { U2_KM_STAMP(2); }
     // ---- arg-min of the tile (registers and cnl only: no barrier - the waves meet again at the barrier of the next step) ----
+    {
+      // The two norms, requested now and waited for at the end.  Inline asm: as plain loads the compiler sinks them into the conditional
+      // block at the end, right in front of their use.  They are younger than every ring request, so the wait also waits for those -
+      // which have had a step and the arg-min to arrive.  (Requested in front of the tile's last ring request instead, so that the wait
+      // can leave that one in flight: equal, 1.123-1.134 ms per iteration for all three placements, tools/exp/km_norms_ab.sh.)
+      const float* np = xnorm + pmine;
+      asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off"
+                   : "=&v"(xn), "=&v"(xlo) : "v"(np), "v"(np + (size_t)ntiles * KS_PTS) : "memory");
+    }
     float cnr[KS_NB];
 #pragma unroll
     for (int nb = 0; nb < KS_NB; ++nb) cnr[nb] = cnl[nb * 16 + fr];
@@ -948,10 +943,7 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
         ks = mine ? ss : ks;
       }
     }
-    // the norms have arrived when at most the last step's ring request (four or five instructions) is still in flight
-    if (!last_requested) asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn), "+v"(xlo)::"memory");
-    else if (xrole) asm volatile("s_waitcnt vmcnt(4)" : "+v"(xn), "+v"(xlo)::"memory");
-    else asm volatile("s_waitcnt vmcnt(5)" : "+v"(xn), "+v"(xlo)::"memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn), "+v"(xlo)::"memory");
     if (fr < 8 && pmine < N) {
       labels[pmine] = (long long)(__float_as_uint(kb) & 511u);
       // Per-point margin.  What this pass does not see of a product is x.c - x_hi.c_hi = x_lo.c + x_hi.c_lo, at most |x_lo| |c| + |x_hi| |c_lo|
