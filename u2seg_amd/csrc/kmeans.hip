@@ -1166,8 +1166,9 @@ __global__ void kmeans_finalize_kernel(const float* __restrict__ csum, const flo
 // Workspace words behind the lists: {magic, coarse_off, calls since the coarse pass was switched off, -}.  The coarse (hi.hi)
 // pass costs a third of the fine one and decides everything on clustered data; on unstructured data (randn: the two best of 300
 // distances are closer than its margin for most points) it decides little and would only be overhead.  The flag is sticky per
-// workspace: a coarse pass that leaves more than a quarter of the points undecided switches itself off, every 64th call tries
-// again.  Labels are those of the exact kernel in either mode - the modes differ in time only.
+// workspace: a coarse pass that leaves more than a quarter of the points undecided (over the shadow of x, where it costs a third of
+// a fine pass instead of half: more than 55 %) switches itself off, every 64th call tries again.  Labels are those of the exact
+// kernel in either mode - the modes differ in time only.
 constexpr unsigned KS_MAGIC = 0x4b533431u;
 __global__ void km_state_begin_kernel(unsigned* __restrict__ scal, unsigned* __restrict__ state) {
   if (threadIdx.x < 4) scal[threadIdx.x] = 0u;
