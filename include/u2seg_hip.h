@@ -398,9 +398,10 @@ long long u2_kmeans_assign_workspace_floats(int N, int D, int K);
 int u2_kmeans_assign(const float* x, const float* c, float* workspace, long long* labels, int N, int D, int K, int exact_only,
                      void* stream);
 /* The same with a shadow of x: x does not change between the Lloyd iterations of a run (nn_utils.py:352 builds its x_i once,
- * outside the loop), so u2_kmeans_prepare writes the leading bf16 piece of x and |x_p| once - u2_kmeans_shadow_floats(N, D) floats,
- * 0 when D % 32 != 0 - and the first screening pass of every later E step streams 2 instead of 4 bytes per element.  The values
- * are the ones that pass rounds x to on the fly without a shadow: same products, same labels.  shadow = NULL: u2_kmeans_assign.
+ * outside the loop), so u2_kmeans_prepare writes the leading bf16 piece of x, |x_p| and |x_p - bf16(x_p)| once -
+ * u2_kmeans_shadow_floats(N, D) floats, 0 when D % 32 != 0 - and the first screening pass of every later E step streams 2 instead
+ * of 4 bytes per element, with a margin per point from those two norms instead of their worst case.  The values are the ones that
+ * pass rounds x to on the fly without a shadow: same products, same labels.  shadow = NULL: u2_kmeans_assign.
  * The shadow must be re-made when x changes. */
 long long u2_kmeans_shadow_floats(int N, int D);
 int u2_kmeans_prepare(const float* x, float* shadow, int N, int D, void* stream);
