@@ -591,7 +591,8 @@ def main():
         out.update({"metric": "k-means seconds per Lloyd iteration (u2seg_R50_300 Instance_Clustering: N = 1M x 768 DINO-sized "
                               "embeddings, K = 300)", "value": s_per_iter, "unit": "s/iter", "ms_per_step": s_per_iter * 1e3,
                     "higher_is_better": False, "scaling": "strong", "steps": steps, "warmup": warmup,
-                    "dtype": "f32 (distances screened in split bf16, undecided points in exact fp32)",
+                    "dtype": "f32 (distances screened in split bf16 - the first pass over a bf16 shadow of x made once per run, "
+                             "one_time_shadow_prepare_ms - undecided points in exact fp32)",
                     "config": {"workload": "Lloyd iterations (assign + update) over %d x %d synthetic embeddings (%s), K = %d, rows "
                                            "sharded over the GPUs" % (n_local * world, KMEANS_D, what, KMEANS_K),
                                "parallelism": "rows%d" % world},
@@ -608,9 +609,10 @@ def main():
                 # (algorithmic, not the 3 bf16 piece products the screening kernel executes per product)
                 alg_bytes = 4.0 * n_local * KMEANS_D
                 ach = alg_bytes / s_per_iter / 1e12
-                out["roofline"] = {"kernel": "Lloyd iteration = u2_kmeans_assign (kmeans_screen_kernel: |c|^2 - 2 x.c as hi.hi + hi.lo "
-                                             "+ lo.hi on v_mfma_f32_16x16x32_bf16, + exact-fp32 kmeans_assign_kernel on the undecided "
-                                             "points) + u2_kmeans_update (label-bucketed segmented sums)",
+                out["roofline"] = {"kernel": "Lloyd iteration = u2_kmeans_assign_shadow (kmeans_coarse_kernel: |c|^2 - 2 x.c as hi.hi over "
+                                             "the bf16 shadow of x; kmeans_screen_kernel: hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 "
+                                             "for what it leaves undecided; exact-fp32 kmeans_assign_kernel for what that leaves) + "
+                                             "u2_kmeans_update (label-bucketed segmented sums)",
                                    "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": ach / PEAK_HBM_TBPS,
                                    "traffic": None, "algorithmic_bytes_per_iter": alg_bytes,
                                    "e_step_algorithmic_tflops": a["flops"] / (a["ms"] * 1e-3) / 1e12,
