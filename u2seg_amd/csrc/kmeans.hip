@@ -689,7 +689,10 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
 
 // ---- coarse pass over the shadow (round 6) ----------------------------------------------------------------------------------------
 // hi.hi only, all points, x from the bf16 shadow (km_shadow_kernel) - the first pass of the two-level screening when a shadow is given.
-// Same products and wave tile (32 points x 320 centroids) as kmeans_screen_kernel<1>; what differs:
+// Same products and wave tile (32 points x 320 centroids) as kmeans_screen_kernel<1>; what differs (steps and their measurements:
+// profiles/r06_km_coarse.txt):
+//  * Persistent work-groups (one per CU, tiles blockIdx.x, + gridDim.x, ...): the request streams run on across the tile boundary.
+//  * A margin per point from the exact norms of x - bf16(x) and c - bf16(c) instead of their worst case (at the arg-min below).
 //  * The LDS-DMA queues are split by wave: vmcnt retires in order, so a wave that requests both centroids and x cannot wait for "the
 //    centroids of the next step" without also waiting for every x it requested before them - two steps of slack whatever the ring
 //    depth.  Waves 0-3 request the centroid stages (five 1 KB instructions each, ring of three 20 KB stages), waves 4-7 the x slots
