@@ -804,6 +804,40 @@ def test_kmeans_shadow_pass_equals_exact(monkeypatch):
     KM._ws_cache.pop("assign:" + str(DEV), None)
 
 
+@pytest.mark.parametrize("k", [321, 641, 800, 1280])
+def test_kmeans_more_than_320_centroids(monkeypatch, k):
+    """Round 6: K > 320 (u2seg_R50_800 clusters into 800): the first screening pass runs once per block of 320 centroids over the shadow
+    of x, the blocks' candidates are merged per point and what stays undecided goes to the exact kernel.  Labels == the exact kernel's,
+    with a block of one centroid (321, 641), duplicates across blocks, a ragged last tile and more tiles than CUs."""
+    from u2seg_amd.cluster import kmeans as KM
+
+    monkeypatch.setattr(KM, "SHADOW_MIN_POINTS", 256)
+    KM.release_shadow()
+    g = torch.Generator().manual_seed(70 + k)
+    n, d = 66003, 256
+    centers = torch.randn((k, d), generator=g) * 2
+    x = centers[torch.randint(0, k, (n,), generator=g)] + 0.5 * torch.randn((n, d), generator=g)
+    c = centers + 0.3 * torch.randn((k, d), generator=g)
+    c[k - 1] = c[5]                      # an exact duplicate in another block: the lower index must win
+    c[330 if k > 330 else 10] = c[17] + 1e-6
+    x[77] = float("nan")
+    xd, cd = x.to(DEV), c.to(DEV)
+    fast = KM.assign(xd, cd)
+    und = KM.last_recheck_count(xd.device)
+    exact = KM.assign(xd, cd, exact=True)
+    assert KM.last_recheck_count(xd.device) is None
+    assert torch.equal(fast, exact), (k, int((fast != exact).sum()), und)
+    assert 0 < und < n // 4, und          # screened: the duplicates' members and the NaN row, not everything
+    lab = exact[:400].cpu()
+    ref = O.kmeans_assign(x[:400], c)
+    bad = torch.nonzero((lab != ref) & torch.isfinite(x[:400]).all(1))[:, 0]
+    assert torch.allclose(((x[bad] - c[lab[bad]]) ** 2).sum(1), ((x[bad] - c[ref[bad]]) ** 2).sum(1), rtol=1e-5)
+    cnew, counts = KM.update(xd, fast, k)
+    assert float(counts.sum()) == n and torch.equal(counts.cpu(), torch.bincount(fast.cpu(), minlength=k).float())
+    KM.release_shadow()
+    KM._ws_cache.pop("assign:" + str(DEV), None)
+
+
 def test_kmeans_two_level_screen_modes():
     """The two-level screen (round 4): on clustered data the first pass (leading bf16 pieces only) decides nearly everything and
     the labels are the exact kernel's; on unstructured data it leaves most points undecided, the labels are still the exact

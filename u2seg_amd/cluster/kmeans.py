@@ -27,6 +27,7 @@ def _update_workspace(n, d, k, device):
 
 _shadow_cache = {}
 SHADOW = os.environ.get("U2_KM_SHADOW", "1") != "0"     # measurement switch: 0 = every E step reads the fp32 x
+MAX_SCREENED_K = 1280                                   # four blocks of 320 centroids (kmeans.hip: KM_MAX_BLOCKS)
 SHADOW_MIN_POINTS = 1 << 16                             # below this the E step is a few microseconds either way
 
 
@@ -71,20 +72,27 @@ def assign(x, c, exact=False):
     ws = ent[0] if ent is not None else None
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.float32, device=x.device)
-    _ws_cache[key] = (ws, k)
-    sh = None if exact or k < 2 or k > 320 else _shadow(x)
+    sh = None if exact or k < 2 or k > MAX_SCREENED_K else _shadow(x)
+    # which counters of the workspace the call fills: "two-level" (K <= 320: both screening passes), "blocks" (K > 320 over the shadow:
+    # the first pass per block of 320 centroids, then the exact kernel), None (the exact kernel alone)
+    if exact or k < 2 or d % 32 != 0 or n < 256:
+        mode = None
+    elif k <= 320:
+        mode = "two-level"
+    else:
+        mode = "blocks" if sh is not None else None
+    _ws_cache[key] = (ws, k, mode)
     _hip.call("u2_kmeans_assign_shadow", x, sh, c.contiguous(), ws, labels, n, d, k, int(exact))
     return labels
 
 
 def last_recheck_count(device):
-    """How many points the last assign() on `device` sent to the exact kernel (reads the workspace: one host sync)."""
+    """How many points the last assign() on `device` sent to the exact kernel after screening (reads the workspace: one host sync);
+    None when that call did not screen (exact=True, K > 1280, D % 32 != 0, fewer than 256 points)."""
     ent = _ws_cache.get("assign:" + str(device))
-    if ent is None:
+    if ent is None or ent[2] is None:
         return None
-    ws, k = ent if isinstance(ent, tuple) else (ent, None)
-    if k is None:
-        return None
+    ws, k, _ = ent
     return int(ws.view(torch.int32)[((k + 3) & ~3) + 1])
 
 
@@ -92,10 +100,10 @@ def last_coarse_undecided(device):
     """How many points the first (leading-bf16-piece) screening pass of the last assign() left undecided; 0 when that pass was
     switched off or skipped (reads the workspace: one host sync)."""
     ent = _ws_cache.get("assign:" + str(device))
-    if ent is None or not isinstance(ent, tuple) or ent[1] is None:
+    if ent is None or ent[2] is None:
         return None
-    ws, k = ent
-    return int(ws.view(torch.int32)[((k + 3) & ~3) + 2])
+    ws, k, mode = ent
+    return int(ws.view(torch.int32)[((k + 3) & ~3) + (2 if mode == "two-level" else 1)])   # "blocks": its undecided ARE the re-checked
 
 
 def update(x, labels, k):

@@ -7,6 +7,7 @@
 // the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, an fma chain in k order), so labels agree with the reference
 // except where two centroids are equidistant to within fp32 rounding of the two formulations.
 // Empty clusters give 0/0 = NaN centroids exactly like the reference (noted at usl-imagenet.py:135).
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(256, 1) void kmeans_assign_kernel(const float* __re
 // into the MFMA A-operand registers (each element is needed by exactly one wave) and is split there; the split
 // centroids (L2-resident, 2 x 320 x D bf16) stream through a three-stage LDS ring by LDS-DMA, 40 KB per 32-dimension step.
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int KM_MAX_BLOCKS = 4;             // blocks of 320 centroids the screened E step serves (K <= 1280)
 constexpr int KS_PTS = 256;
 constexpr int KS_NB = 20;                    // 16-centroid blocks: 320 centroids
 constexpr int KS_KMAX = KS_NB * 16;
@@ -728,7 +730,10 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
                                                             const bf16_t* __restrict__ chl, const float* __restrict__ cn,
                                                             const unsigned* __restrict__ cmax2, long long* __restrict__ labels,
                                                             int* __restrict__ list, int* __restrict__ nlist, int N, int D, int K,
-                                                            float margin_rel, const int* __restrict__ gate, int gate_want) {
+                                                            float margin_rel, const int* __restrict__ gate, int gate_want,
+                                                            float2* __restrict__ part) {
+  // part != nullptr (K > 320, one launch per block of 320 centroids - chl, cn, K are the block's): the point's (best | index inside the
+  // block, second best) go to part[p] and km_chunk_merge_kernel decides over all blocks
   extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
   if (gate && (*gate == 1) != (gate_want != 0)) return;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -947,7 +952,9 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn), "+v"(xlo)::"memory");
-    if (fr < 8 && pmine < N) {
+    if (part) {
+      if (fr < 8 && pmine < N) part[pmine] = float2{kb, ks};
+    } else if (fr < 8 && pmine < N) {
       labels[pmine] = (long long)(__float_as_uint(kb) & 511u);
       // Per-point margin.  What this pass does not see of a product is x.c - x_hi.c_hi = x_lo.c + x_hi.c_lo, at most |x_lo| |c| + |x_hi| |c_lo|
       // (Cauchy-Schwarz; x_lo = x - bf16(x) and its norm are exact, from u2_kmeans_prepare; |x_hi| <= 1.004 |x|): twice that per
@@ -963,6 +970,30 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
     if (it == 0) { U2_KM_STAMP(3); }
   }
   U2_KM_STAMP(4);
+}
+
+// K > 320: the per-block candidates of kmeans_coarse_kernel (part[b][N]) -> label and, where the two best of ALL centroids are closer
+// than the coarse margin, an entry of the exact kernel's list.  Second best overall = min(second of the best block, best of the others).
+__global__ __launch_bounds__(256) void km_chunk_merge_kernel(const float2* __restrict__ part, int nblocks, const float* __restrict__ xnorm,
+                                                             int npad, const unsigned* __restrict__ scal, long long* __restrict__ labels,
+                                                             int* __restrict__ list, int* __restrict__ nlist, int N, float margin_rel) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= N) return;
+  float bb = INFINITY, ss = INFINITY;
+  int bj = 0;
+  for (int b = 0; b < nblocks; ++b) {
+    const float2 v = part[(size_t)b * N + p];
+    const bool lt = v.x < bb;                                  // ties: the lower block (a zero gap goes to the exact kernel anyway)
+    ss = fminf(fminf(ss, v.y), lt ? bb : v.x);
+    bj = lt ? b * KS_KMAX + (int)(__float_as_uint(v.x) & 511u) : bj;
+    bb = fminf(bb, v.x);
+  }
+  labels[p] = (long long)bj;
+  const float cmax = sqrtf(__uint_as_float(scal[0])), clomax = sqrtf(__uint_as_float(scal[3]));
+  const float xn = xnorm[p], xlo = xnorm[npad + p];
+  const float margin = 4.04f * (xlo * cmax + 1.004f * xn * clomax) + margin_rel * cmax * xn +   // kmeans_coarse_kernel's margin
+                       1.2207031e-4f * (cmax * cmax + 2.f * xn * cmax);
+  if (!(ss - bb >= margin)) list[atomicAdd(nlist, 1)] = p;
 }
 
 // csum[K][D] += x rows by label; counts[K] += 1.  grid = (point chunks, D / DS); LDS holds [K][DS] partial sums.
@@ -1189,7 +1220,9 @@ __global__ void km_state_end_kernel(const unsigned* __restrict__ scal, unsigned*
 extern "C" long long u2_kmeans_assign_workspace_floats(int N, int D, int K) {
   // |c|^2 [K] | max |c|^2, exact-list length, coarse-list length [4] | split centroids [2][320][D] bf16 | exact re-check list [N]
   // | undecided list of the coarse pass [N] | screening state [4]
-  return (long long)K + 16 + (long long)KS_KMAX * D + 2LL * N + 32;
+  // K > 320 (u2_kmeans_assign_shadow only): the split centroids of every block of 320, and the blocks' candidates [blocks][N]{best, second}
+  const long long blocks = (K + KS_KMAX - 1) / KS_KMAX;
+  return (long long)K + 16 + blocks * KS_KMAX * D + 2LL * N + 32 + (blocks > 1 ? blocks * 2LL * N + 8 : 0);
 }
 
 #ifdef U2_KM_TRACE
@@ -1243,6 +1276,41 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
   hipStream_t s = (hipStream_t)stream;
   float* cn = workspace;
   const bool screen = !exact_only && D % 32 == 0 && K <= KS_KMAX && K >= 2 && N >= KS_PTS;
+  // K > 320 (the 800 clusters of u2seg_R50_800): the coarse pass once per block of 320 centroids over the shadow, the blocks' candidates
+  // merged per point, what stays undecided straight to the exact kernel (13.6 -> 1.9 ms at N = 1 M, K = 800 on clustered data)
+  const int blocks = (K + KS_KMAX - 1) / KS_KMAX;
+  if (!exact_only && shadow && D % 32 == 0 && K > KS_KMAX && blocks <= KM_MAX_BLOCKS && N >= KS_PTS) {
+    unsigned* scal = reinterpret_cast<unsigned*>(workspace + ((K + 3) & ~3));
+    bf16_t* chl = reinterpret_cast<bf16_t*>(workspace + ((K + 3) & ~3) + 4);
+    int* list2 = reinterpret_cast<int*>(workspace + ((K + 3) & ~3) + 4 + (size_t)blocks * KS_KMAX * D);
+    float* pbase = reinterpret_cast<float*>(list2 + 2 * (size_t)N + 32);
+    pbase += (2 - ((reinterpret_cast<size_t>(pbase) >> 2) & 1)) & 1;     // 8-byte aligned
+    float2* part = reinterpret_cast<float2*>(pbase);
+    u2_zero_words(scal, 4, s);
+    for (int b = 0; b < blocks; ++b) {
+      hipLaunchKernelGGL(csplit_kernel, dim3(KS_KMAX / 4), dim3(256), 0, s, c + (size_t)b * KS_KMAX * D, chl + (size_t)b * 2 * KS_KMAX * D,
+                         cn + b * KS_KMAX, scal, D, std::min(KS_KMAX, K - b * KS_KMAX));
+      U2_CHECK_LAUNCH();
+    }
+    static PerDeviceOnce attr_set;
+    if (auto once_guard = attr_set.first())
+      (void)hipFuncSetAttribute((const void*)kmeans_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const unsigned tiles = (unsigned)((N + KS_PTS - 1) / KS_PTS), cus = (unsigned)km_cu_count();
+    const float* xn = shadow + km_shadow_words(N, D);
+    for (int b = 0; b < blocks; ++b) {
+      hipLaunchKernelGGL(kmeans_coarse_kernel, dim3(tiles < cus ? tiles : cus), dim3(512), KC_LDS, s, reinterpret_cast<const unsigned char*>(shadow),
+                         xn, chl + (size_t)b * 2 * KS_KMAX * D, cn + b * KS_KMAX, scal, labels, (int*)nullptr, (int*)nullptr, N, D,
+                         std::min(KS_KMAX, K - b * KS_KMAX), 3e-4f, (const int*)nullptr, 0, part + (size_t)b * N);
+      U2_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(km_chunk_merge_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, blocks, xn, (int)(tiles * KS_PTS), scal, labels, list2,
+                       reinterpret_cast<int*>(scal + 1), N, 3e-4f);
+    U2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(kmeans_assign_kernel, dim3((N + KM_PTS - 1) / KM_PTS), dim3(256), 0, s, x, c, cn, labels, N, D, K, (const int*)list2,
+                       (const int*)(scal + 1));
+    U2_CHECK_LAUNCH();
+    return 0;
+  }
   if (!screen) {
     hipLaunchKernelGGL(cnorm_kernel, dim3((K + 3) / 4), dim3(256), 0, s, c, cn, D, K);
     U2_CHECK_LAUNCH();
@@ -1280,7 +1348,7 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
     // coarse pass over everything -> list1; fine pass over list1 -> list2 (both skipped while the coarse pass is switched off)
     if (shadow)
       hipLaunchKernelGGL(kmeans_coarse_kernel, dim3(grid.x < (unsigned)km_cu_count() ? grid.x : (unsigned)km_cu_count()), block, KC_LDS, s, reinterpret_cast<const unsigned char*>(shadow),
-                         shadow + km_shadow_words(N, D), chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D, K, 3e-4f, gate, 0);
+                         shadow + km_shadow_words(N, D), chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D, K, 3e-4f, gate, 0, (float2*)nullptr);
     else
       hipLaunchKernelGGL(kmeans_screen_kernel<1>, grid, block, lds1, s, x, chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D,
                          K, 0.02f, (const int*)nullptr, (const int*)nullptr, gate, 0);
