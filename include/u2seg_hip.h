@@ -401,7 +401,9 @@ int u2_kmeans_assign(const float* x, const float* c, float* workspace, long long
  * outside the loop), so u2_kmeans_prepare writes the leading bf16 piece of x, |x_p| and |x_p - bf16(x_p)| once -
  * u2_kmeans_shadow_floats(N, D) floats, 0 when D % 32 != 0 - and the first screening pass of every later E step streams 2 instead
  * of 4 bytes per element, with a margin per point from those two norms instead of their worst case.  The values are the ones that
- * pass rounds x to on the fly without a shadow: same products, same labels.  shadow = NULL: u2_kmeans_assign.
+ * pass rounds x to on the fly without a shadow: same products, same labels.  shadow = NULL: u2_kmeans_assign.  With a shadow the
+ * screening also serves 320 < K <= 1280 (one first pass per block of 320 centroids, then the exact kernel for the undecided points;
+ * [... + 1] counts those, [... + 2] is not written); without one such K run the exact kernel alone.
  * The shadow must be re-made when x changes. */
 long long u2_kmeans_shadow_floats(int N, int D);
 int u2_kmeans_prepare(const float* x, float* shadow, int N, int D, void* stream);
