@@ -45,10 +45,20 @@ __device__ __forceinline__ bool km_less(float v, int j, float bv, int bj) {
 __global__ __launch_bounds__(256, 1) void kmeans_assign_kernel(const float* __restrict__ x, const float* __restrict__ c,
                                                                const float* __restrict__ cn, long long* __restrict__ labels,
                                                                int N, int D, int K, const int* __restrict__ rows,
-                                                               const int* __restrict__ nrows) {
+                                                               const int* __restrict__ nrows, const unsigned* __restrict__ scal,
+                                                               unsigned* __restrict__ state, unsigned limit) {
   __shared__ float stage[2 * KM_STAGE];  // [2][xs: KM_PTS x KM_PITCH | cs: 320 x KM_PITCH]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int p0 = blockIdx.x * KM_PTS;
+  // the last launch of a two-level E step also keeps the screening state (see km_state_begin_kernel): a coarse pass that left more than
+  // `limit` points undecided switches itself off, every 64th call tries again
+  if (state && blockIdx.x == 0 && tid == 0) {
+    if (state[1] == 0u) {
+      if (scal[2] > limit) { state[1] = 1u; state[2] = 0u; }
+    } else if (++state[2] >= 64u) {
+      state[1] = 0u; state[2] = 0u;
+    }
+  }
   if (rows) {
     N = min(N, *nrows);
     if (p0 >= N) return;
@@ -306,7 +316,8 @@ __global__ __launch_bounds__(256) void km_xnorm_kernel(const float* __restrict__
 // centroid vs the next differ by ~|c - c'|^2, two orders above the margin) and hands the rest to the NP = 3 pass.
 // rows / nrows: the kernel labels the points rows[0 .. *nrows) (the undecided list of the coarser pass) instead of 0 .. N - 1.
 // gate / gate_want: the launch is skipped (work-groups leave at once) unless (*gate == 1) == gate_want - the host queues the
-// coarse pass, the fine pass over its list and the fine pass over everything, and a flag in the workspace picks two of the three.
+// coarse pass and the fine pass, and a flag in the workspace says whether the coarse one runs; gate_want = 2: the fine pass takes
+// rows / nrows while the flag is 0 and every point while it is 1.
 template <int NP, bool XR3 = false>
 __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restrict__ x, const bf16_t* __restrict__ chl,
                                                             const float* __restrict__ cn, const unsigned* __restrict__ cmax2,
@@ -315,7 +326,13 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
                                                             const int* __restrict__ rows, const int* __restrict__ nrows,
                                                             const int* __restrict__ gate, int gate_want) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
-  if (gate && (*gate == 1) != (gate_want != 0)) return;
+  if (gate) {
+    if (gate_want == 2) {                      // one launch for both cases: coarse pass off -> every point, on -> its list
+      if (*gate == 1) rows = nullptr;
+    } else if ((*gate == 1) != (gate_want != 0)) {
+      return;
+    }
+  }
   if (rows) {
     N = min(N, *nrows);
     if ((int)blockIdx.x * KS_PTS >= N) return;
@@ -1208,14 +1225,6 @@ __global__ void km_state_begin_kernel(unsigned* __restrict__ scal, unsigned* __r
   if (threadIdx.x < 4) scal[threadIdx.x] = 0u;
   if (threadIdx.x == 0 && state[0] != KS_MAGIC) { state[0] = KS_MAGIC; state[1] = 0u; state[2] = 0u; state[3] = 0u; }
 }
-__global__ void km_state_end_kernel(const unsigned* __restrict__ scal, unsigned* __restrict__ state, unsigned limit) {
-  if (threadIdx.x != 0) return;
-  if (state[1] == 0u) {
-    if (scal[2] > limit) { state[1] = 1u; state[2] = 0u; }
-  } else if (++state[2] >= 64u) {
-    state[1] = 0u; state[2] = 0u;
-  }
-}
 
 extern "C" long long u2_kmeans_assign_workspace_floats(int N, int D, int K) {
   // |c|^2 [K] | max |c|^2, exact-list length, coarse-list length [4] | split centroids [2][320][D] bf16 | exact re-check list [N]
@@ -1307,7 +1316,7 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
                        reinterpret_cast<int*>(scal + 1), N, 3e-4f);
     U2_CHECK_LAUNCH();
     hipLaunchKernelGGL(kmeans_assign_kernel, dim3((N + KM_PTS - 1) / KM_PTS), dim3(256), 0, s, x, c, cn, labels, N, D, K, (const int*)list2,
-                       (const int*)(scal + 1));
+                       (const int*)(scal + 1), (const unsigned*)nullptr, (unsigned*)nullptr, 0u);
     U2_CHECK_LAUNCH();
     return 0;
   }
@@ -1315,7 +1324,7 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
     hipLaunchKernelGGL(cnorm_kernel, dim3((K + 3) / 4), dim3(256), 0, s, c, cn, D, K);
     U2_CHECK_LAUNCH();
     hipLaunchKernelGGL(kmeans_assign_kernel, dim3((N + KM_PTS - 1) / KM_PTS), dim3(256), 0, s, x, c, cn, labels, N, D, K,
-                       (const int*)nullptr, (const int*)nullptr);
+                       (const int*)nullptr, (const int*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr, 0u);
     U2_CHECK_LAUNCH();
     return 0;
   }
@@ -1353,34 +1362,27 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
       hipLaunchKernelGGL(kmeans_screen_kernel<1>, grid, block, lds1, s, x, chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D,
                          K, 0.02f, (const int*)nullptr, (const int*)nullptr, gate, 0);
     U2_CHECK_LAUNCH();
+  }
+  // fine pass -> list2: over the coarse pass's list, or over everything while the coarse pass is switched off (or not built in)
+  {
+    const int* rows = two_level ? (const int*)list1 : (const int*)nullptr;
+    const int* nrows = two_level ? reinterpret_cast<const int*>(scal + 2) : (const int*)nullptr;
     if (xring3)
-      hipLaunchKernelGGL((kmeans_screen_kernel<3, true>), grid, block, lds3, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1),
-                         N, D, K, 1e-4f, (const int*)list1, reinterpret_cast<const int*>(scal + 2), gate, 0);
+      hipLaunchKernelGGL((kmeans_screen_kernel<3, true>), grid, block, lds3, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N,
+                         D, K, 1e-4f, rows, nrows, two_level ? gate : (const int*)nullptr, 2);
     else
-      hipLaunchKernelGGL(kmeans_screen_kernel<3>, grid, block, lds, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N, D,
-                         K, 1e-4f, (const int*)list1, reinterpret_cast<const int*>(scal + 2), gate, 0);
+      hipLaunchKernelGGL(kmeans_screen_kernel<3>, grid, block, lds, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N, D, K,
+                         1e-4f, rows, nrows, two_level ? gate : (const int*)nullptr, 2);
     U2_CHECK_LAUNCH();
   }
-  // fine pass over everything -> list2 (the only pass while the coarse one is switched off)
-  if (xring3)
-    hipLaunchKernelGGL((kmeans_screen_kernel<3, true>), grid, block, lds3, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N,
-                       D, K, 1e-4f, (const int*)nullptr, (const int*)nullptr, two_level ? gate : (const int*)nullptr, 1);
-  else
-    hipLaunchKernelGGL(kmeans_screen_kernel<3>, grid, block, lds, s, x, chl, cn, scal, labels, list2, reinterpret_cast<int*>(scal + 1), N, D, K,
-                       1e-4f, (const int*)nullptr, (const int*)nullptr, two_level ? gate : (const int*)nullptr, 1);
-  U2_CHECK_LAUNCH();
-  // the undecided points, exactly; the grid covers the worst case, work-groups beyond the list return immediately
+  // The undecided points, exactly; the grid covers the worst case, work-groups beyond the list return immediately.  Its first thread
+  // also keeps the screening state.  The coarse pass pays while it costs less than the fine pass saves on the points it decides: over
+  // the fp32 x it costs half a fine pass (off above a quarter undecided), over the shadow a third (0.45 vs 1.38 ms at N = 1 M; the
+  // fine pass over a list is ~10 % dearer per point): off above 55 %.
+  const unsigned limit = shadow ? (unsigned)((unsigned long long)N * 55u / 100u) : (unsigned)N / 4u;
   hipLaunchKernelGGL(kmeans_assign_kernel, dim3((N + KM_PTS - 1) / KM_PTS), dim3(256), 0, s, x, c, cn, labels, N, D, K,
-                     (const int*)list2, (const int*)(scal + 1));
+                     (const int*)list2, (const int*)(scal + 1), (const unsigned*)scal, two_level ? state : (unsigned*)nullptr, limit);
   U2_CHECK_LAUNCH();
-  if (two_level) {
-    // the coarse pass pays while it costs less than the fine pass saves on the points it decides: over the fp32 x it costs half a fine
-    // pass (off above a quarter undecided), over the shadow a third (0.45 vs 1.38 ms at N = 1 M; the fine pass over a list is ~10 %
-    // dearer per point): off above 55 %
-    const unsigned limit = shadow ? (unsigned)((unsigned long long)N * 55u / 100u) : (unsigned)N / 4u;
-    hipLaunchKernelGGL(km_state_end_kernel, dim3(1), dim3(64), 0, s, scal, state, limit);
-    U2_CHECK_LAUNCH();
-  }
   return 0;
 }
 
