@@ -608,13 +608,20 @@ def main():
                 # MFMA, so the iteration is priced against HBM; the E step's algorithmic 2*N*K*D flop are reported beside it
                 # (algorithmic, not the 3 bf16 piece products the screening kernel executes per product)
                 alg_bytes = 4.0 * n_local * KMEANS_D
+                # measured HBM bytes of one iteration: the committed PMC passes are of THIS configuration only (N = 1 M on one GPU,
+                # K = 300, clustered data: E step over the bf16 shadow 1.6 GB + M step 3.1 GB)
+                km_traffic, km_note = None, "no PMC profile committed for this configuration"
+                kp = os.path.join(ROOT, "profiles", "r06_km_pmc_traffic.json")
+                if os.path.exists(kp) and world == 1 and n_local == 1000000 and k == KMEANS_K and data_kind == "mixture":
+                    kj = json.load(open(kp))
+                    km_traffic, km_note = kj["kmeans_iteration_hbm_bytes"], "HBM bytes per iteration from profiles/r06_km_pmc_traffic.json (%s)" % kj["note"]
                 ach = alg_bytes / s_per_iter / 1e12
                 out["roofline"] = {"kernel": "Lloyd iteration = u2_kmeans_assign_shadow (kmeans_coarse_kernel: |c|^2 - 2 x.c as hi.hi over "
                                              "the bf16 shadow of x; kmeans_screen_kernel: hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 "
                                              "for what it leaves undecided; exact-fp32 kmeans_assign_kernel for what that leaves) + "
                                              "u2_kmeans_update (label-bucketed segmented sums)",
                                    "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": ach / PEAK_HBM_TBPS,
-                                   "traffic": None, "algorithmic_bytes_per_iter": alg_bytes,
+                                   "traffic": km_traffic, "traffic_note": km_note, "algorithmic_bytes_per_iter": alg_bytes,
                                    "e_step_algorithmic_tflops": a["flops"] / (a["ms"] * 1e-3) / 1e12,
                                    "e_step_frac_of_bf16_mfma_peak": a["flops"] / (a["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                                    "rechecked_points_last_call": rechecks[-1],
