@@ -6,7 +6,7 @@ TAG=${1:-r06}
 OUT=$R/gpurun_out/${TAG}_km_ablate.txt
 cd $R
 : > $OUT
-for A in 0 1 2 4 8 3 5 6 7; do
+for A in ${KC_ABL_LIST:-0 1 2 4 8 3 5 6 7}; do
   ( cd u2seg_amd/csrc && touch kmeans.hip && ./build.sh -DU2_KM_TRACE -DU2_KC_ABL=$A > /dev/null 2>&1 )
   echo "# U2_KC_ABL=$A" >> $OUT
   PYTHONPATH=$R python tools/exp/km_trace.py 2>&1 | grep -v amdgpu.ids | grep -v "raw span" >> $OUT
