@@ -838,6 +838,44 @@ def test_kmeans_more_than_320_centroids(monkeypatch, k):
     KM._ws_cache.pop("assign:" + str(DEV), None)
 
 
+def test_kmeans_random_shapes_equal_exact(monkeypatch):
+    """Random (N, D, K) through every screening path (shadow forced on; K up to 1280, D from one 32-dimension step up): clustered rows,
+    unstructured rows with rows as centroids, bf16-valued rows with norms spread over six decades and a duplicated centroid, rows with a
+    large common mean.  Labels of two consecutive calls (the second may run with the first pass switched off) == the exact kernel's."""
+    from u2seg_amd.cluster import kmeans as KM
+
+    monkeypatch.setattr(KM, "SHADOW_MIN_POINTS", 256)
+    g = torch.Generator().manual_seed(5)
+    for i in range(16):
+        d = [32, 64, 96, 128, 256, 384, 768][int(torch.randint(0, 7, (1,), generator=g))]
+        k = int(torch.randint(2, 1281, (1,), generator=g)) if i % 3 else int(torch.randint(2, 321, (1,), generator=g))
+        n = int(torch.randint(256, 40000, (1,), generator=g))
+        kind = i % 4
+        if kind == 0:
+            cen = torch.randn((k, d), generator=g) * 2
+            x = cen[torch.randint(0, k, (n,), generator=g)] + 0.5 * torch.randn((n, d), generator=g)
+            c = cen + 0.3 * torch.randn((k, d), generator=g)
+        else:
+            x = torch.randn((n, d), generator=g)
+            if kind == 2:
+                x = (x * 3).bfloat16().float()
+                x[: n // 10] *= 1e-3
+                x[n // 10: n // 5] *= 1e3
+            elif kind == 3:
+                x = x + 10.0
+            c = x[torch.randperm(n, generator=g)[:k]].clone() if k <= n else torch.randn((k, d), generator=g) + (10.0 if kind == 3 else 0.0)
+            if kind == 2 and k > 3:
+                c[k - 1] = c[0]
+        xd, cd = x.to(DEV), c.to(DEV)
+        KM._ws_cache.pop("assign:" + str(DEV), None)
+        KM.release_shadow()
+        first, second = KM.assign(xd, cd), KM.assign(xd, cd)
+        exact = KM.assign(xd, cd, exact=True)
+        assert torch.equal(first, exact) and torch.equal(second, exact), (i, kind, n, d, k, int((first != exact).sum()))
+    KM.release_shadow()
+    KM._ws_cache.pop("assign:" + str(DEV), None)
+
+
 def test_kmeans_two_level_screen_modes():
     """The two-level screen (round 4): on clustered data the first pass (leading bf16 pieces only) decides nearly everything and
     the labels are the exact kernel's; on unstructured data it leaves most points undecided, the labels are still the exact
