@@ -220,11 +220,14 @@ constexpr int KS_RING = 3;
 constexpr int KS_DMA = KS_STAGE / 1024 / 8;  // LDS-DMA instructions per wave per step (5)
 
 // chl [2][320][D] bf16 (hi plane, lo plane; rows >= K zero), cn[j] = |c_j|^2 in fp32, *cmax2 = max_j cn[j]
+// mu != nullptr (the first pass over the shadow works on x - mu, c - mu; see km_shadow_kernel): chc [320][D] = bf16(c - mu) in the same
+// dimension order, cnc[j] = |c_j - mu|^2, cs[0] = max_j of it, cs[1] = max_j |(c_j - mu) - bf16(c_j - mu)|^2
 __global__ __launch_bounds__(256) void csplit_kernel(const float* __restrict__ c, bf16_t* __restrict__ chl, float* __restrict__ cn,
-                                                     unsigned* __restrict__ cmax2, int D, int K) {
+                                                     unsigned* __restrict__ cmax2, int D, int K, const float* __restrict__ mu,
+                                                     bf16_t* __restrict__ chc, float* __restrict__ cnc, unsigned* __restrict__ cs) {
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= KS_KMAX) return;
-  float s = 0.f, slo = 0.f;
+  float s = 0.f, slo = 0.f, sc = 0.f, sclo = 0.f;
   // Within every 32-dimension step the dimensions are stored in the order the screening kernel's x loads deliver them: position
   // fg * 8 + e holds dimension fg * 4 + e (e < 4) or 16 + fg * 4 + (e - 4) - a lane of the MFMA A operand then gets its eight
   // values from two 16-byte loads that are 64 bytes apart, and the four lanes of a row read 64 contiguous bytes per instruction.
@@ -236,6 +239,13 @@ __global__ __launch_bounds__(256) void csplit_kernel(const float* __restrict__ c
     chl[(size_t)j * D + d] = h;
     chl[((size_t)KS_KMAX + j) * D + d] = f2bf(v - bf2f(h));
     slo += (v - bf2f(h)) * (v - bf2f(h));   // |c_j - bf16(c_j)|^2 (the permutation does not change the sum's terms)
+    if (mu) {
+      const float vc = j < K ? v - mu[src] : 0.f;
+      const bf16_t hc = f2bf(vc);
+      chc[(size_t)j * D + d] = hc;
+      sc += vc * vc;
+      sclo += (vc - bf2f(hc)) * (vc - bf2f(hc));
+    }
     // |c_j|^2 is summed over the UNPERMUTED dimensions, lane by lane exactly as cnorm_kernel does: the re-check must see the
     // same bits as a run of the exact kernel alone, or near-duplicate centroids (exact-fp32 ties) are decided differently
     const float u = j < K ? c[(size_t)j * D + d] : 0.f;
@@ -247,7 +257,16 @@ __global__ __launch_bounds__(256) void csplit_kernel(const float* __restrict__ c
   if ((threadIdx.x & 63) == 0) {
     cn[j] = s;
     atomicMax(cmax2, __float_as_uint(s));  // s >= 0: the unsigned order of the bits is the order of the floats
-    atomicMax(cmax2 + 3, __float_as_uint(slo));   // max_j |c_j - bf16(c_j)|^2: the coarse pass's per-point margin
+    atomicMax(cmax2 + 3, __float_as_uint(slo));   // max_j |c_j - bf16(c_j)|^2
+  }
+  if (mu) {
+    sc = wave_sum(sc);
+    sclo = wave_sum(sclo);
+    if ((threadIdx.x & 63) == 0) {
+      cnc[j] = sc;
+      atomicMax(cs, __float_as_uint(sc));
+      atomicMax(cs + 1, __float_as_uint(sclo));
+    }
   }
 }
 
@@ -271,7 +290,35 @@ __device__ __forceinline__ float kc_max(float a, float b) { float r; asm("v_max_
 // G = 16 * ceil(N / 256); the 16 bytes of lane (fg, fr) = fg * 16 + fr are point fr's positions fg * 8 .. + 7 of the step in
 // csplit_kernel's dimension order - a group is 1 KB, one LDS-DMA instruction, and lands in LDS as the MFMA A fragment of 16 points
 // (lane L reads byte L * 16: conflict-free by construction).  Points >= N are zero.  Behind it: |x_p| in fp32, [G * 16].
-__global__ __launch_bounds__(256) void km_shadow_kernel(const float* __restrict__ x, uint4* __restrict__ xh, int N, int D, int G) {
+// Column mean of x in a fixed order (deterministic: the shadow of a given x is the same in every run): partial sums of 1024-row slabs,
+// then one thread per column over the slabs.
+constexpr int KM_MU_ROWS = 1024;
+__global__ __launch_bounds__(256) void km_colsum_kernel(const float* __restrict__ x, float* __restrict__ part, int N, int D) {
+  const int r0 = blockIdx.x * KM_MU_ROWS, r1 = min(N, r0 + KM_MU_ROWS);
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+      s0 += x[(size_t)r * D + d]; s1 += x[(size_t)(r + 1) * D + d]; s2 += x[(size_t)(r + 2) * D + d]; s3 += x[(size_t)(r + 3) * D + d];
+    }
+    for (; r < r1; ++r) s0 += x[(size_t)r * D + d];
+    part[(size_t)blockIdx.x * D + d] = (s0 + s1) + (s2 + s3);
+  }
+}
+__global__ __launch_bounds__(256) void km_mu_kernel(const float* __restrict__ part, int nslabs, float* __restrict__ mu, int N, int D) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  float s = 0.f;
+  for (int b = 0; b < nslabs; ++b) s += part[(size_t)b * D + d];
+  s /= (float)N;
+  mu[d] = (s == s && fabsf(s) != INFINITY) ? s : 0.f;    // a NaN / Inf somewhere in the column: no translation of that column
+}
+// The shadow holds bf16(x - mu): argmin_j |x - c_j|^2 does not change when x and every c_j are translated by the same vector, and the
+// first pass's margin is proportional to |x - mu| |c - mu| instead of |x| |c| - on L2-normalised features with a common direction
+// (F.normalize(DINO features): usl-imagenet.py:103; mean cosine between rows 0.3-0.8) that is what lets it decide anything at all.
+// Any mu is valid as long as x and c use the same one; mu = the column mean of x, fixed when the shadow is made.
+__global__ __launch_bounds__(256) void km_shadow_kernel(const float* __restrict__ x, const float* __restrict__ mu, uint4* __restrict__ xh,
+                                                        int N, int D, int G) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int lane = (int)(t & 63), fr = lane & 15, fg = lane >> 4;
   const size_t gi = t >> 6;                     // step * G + group
@@ -281,21 +328,29 @@ __global__ __launch_bounds__(256) void km_shadow_kernel(const float* __restrict_
   float4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
   if (p < N) {
     const float* src = x + (size_t)p * D + step * 32 + fg * 4;
+    const float* ms = mu + step * 32 + fg * 4;
     a = *reinterpret_cast<const float4*>(src);
     b = *reinterpret_cast<const float4*>(src + 16);
+    const float4 ma = *reinterpret_cast<const float4*>(ms), mb = *reinterpret_cast<const float4*>(ms + 16);
+    a.x -= ma.x; a.y -= ma.y; a.z -= ma.z; a.w -= ma.w;
+    b.x -= mb.x; b.y -= mb.y; b.z -= mb.z; b.w -= mb.w;
   }
   uint4 o;
   o.x = ks_pack(a.x, a.y); o.y = ks_pack(a.z, a.w); o.z = ks_pack(b.x, b.y); o.w = ks_pack(b.z, b.w);
   xh[t] = o;
 }
-// xn[p] = |x_p|, xn[NP16 + p] = |x_p - bf16(x_p)| (what the coarse pass does not see of the point)
-__global__ __launch_bounds__(256) void km_xnorm_kernel(const float* __restrict__ x, float* __restrict__ xn, int N, int D, int NP16) {
+// with y = x_p - mu: xn[p] = |y|, xn[NP16 + p] = |y - bf16(y)| (what the coarse pass does not see of the point), xn[2 NP16 + p] = |x_p|
+__global__ __launch_bounds__(256) void km_xnorm_kernel(const float* __restrict__ x, const float* __restrict__ mu, float* __restrict__ xn,
+                                                       int N, int D, int NP16) {
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= NP16) return;
-  float s = 0.f, sl = 0.f;
+  float s = 0.f, sl = 0.f, so = 0.f;
   if (p < N)
     for (int d = (threadIdx.x & 63) * 4; d < D; d += 256) {
-      const float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * D + d);
+      float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * D + d);
+      const float4 m = *reinterpret_cast<const float4*>(mu + d);
+      so += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w;
       s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
       const uint32_t h0 = ks_pack(v.x, v.y), h1 = ks_pack(v.z, v.w);
       const float r0 = v.x - __uint_as_float(h0 << 16), r1 = v.y - __uint_as_float(h0 & 0xffff0000u);
@@ -304,9 +359,11 @@ __global__ __launch_bounds__(256) void km_xnorm_kernel(const float* __restrict__
     }
   s = wave_sum(s);
   sl = wave_sum(sl);
+  so = wave_sum(so);
   if ((threadIdx.x & 63) == 0) {
     xn[p] = sqrtf(s);
     xn[NP16 + p] = sqrtf(sl);
+    xn[2 * (size_t)NP16 + p] = sqrtf(so);
   }
 }
 
@@ -743,9 +800,12 @@ constexpr int KC_SLOT = KS_PTS * 64;           // 16 groups x 1 KB
 constexpr int KC_STAGE = KS_KMAX * 64;         // hi plane: 320 rows x 64 B
 constexpr int KC_RINGS = KS_RING * KC_STAGE + KC_SLOTS * KC_SLOT;
 constexpr int KC_LDS = KC_RINGS + KS_KMAX * 4; // + |c_j|^2
+// chl / cn / cs: the centred centroids of csplit_kernel (chc, cnc, {max |c - mu|^2, max |(c - mu) - bf16(c - mu)|^2}); cmax2: max |c|^2
+// of the centroids as they are (the exact kernel's frame); xnorm: km_xnorm_kernel's three arrays
 __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char* __restrict__ xh, const float* __restrict__ xnorm,
                                                             const bf16_t* __restrict__ chl, const float* __restrict__ cn,
-                                                            const unsigned* __restrict__ cmax2, long long* __restrict__ labels,
+                                                            const unsigned* __restrict__ cs, const unsigned* __restrict__ cmax2,
+                                                            long long* __restrict__ labels,
                                                             int* __restrict__ list, int* __restrict__ nlist, int N, int D, int K,
                                                             float margin_rel, const int* __restrict__ gate, int gate_want,
                                                             float2* __restrict__ part) {
@@ -838,7 +898,7 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
     wait_x(npre - 1);
   }
   U2_KM_STAMP(1);
-  const float cmax = sqrtf(__uint_as_float(*cmax2)), clomax = sqrtf(__uint_as_float(cmax2[3]));
+  const float cmax = sqrtf(__uint_as_float(cs[0])), clomax = sqrtf(__uint_as_float(cs[1])), cmax_o = sqrtf(__uint_as_float(*cmax2));
   int cbuf = 0, xslot = 0, g = 0;                // g % 3, g % KC_SLOTS
   for (int it = 0; it < nmine; ++it) {
     f32x4 acc[2][KS_NB];
@@ -848,7 +908,7 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
       for (int nb = 0; nb < KS_NB; ++nb) acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     // the point this lane writes (lanes fr < 8: point block fr >> 2, row fg * 4 + (fr & 3)); xnorm is padded to whole tiles
     const int pmine = ((int)blockIdx.x + it * (int)gridDim.x) * KS_PTS + w * 32 + ((fr >> 2) & 1) * 16 + fg * 4 + (fr & 3);
-    float xn, xlo;            // |x_p|, |x_p - bf16(x_p)|
+    float xn, xlo, xno;       // |y|, |y - bf16(y)| for y = x_p - mu, and |x_p|
     for (int s = 0; s < nsteps; ++s, ++g) {
       if (!(U2_KC_ABL & 8)) __builtin_amdgcn_s_barrier();   // stage / slot g are complete for every wave, and every wave is done with step g - 1
       asm volatile("" ::: "memory");
@@ -924,8 +984,9 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
       // which have had a step and the arg-min to arrive.  (Requested in front of the tile's last ring request instead, so that the wait
       // can leave that one in flight: equal, 1.123-1.134 ms per iteration for all three placements, tools/exp/km_norms_ab.sh.)
       const float* np = xnorm + pmine;
-      asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off"
-                   : "=&v"(xn), "=&v"(xlo) : "v"(np), "v"(np + (size_t)ntiles * KS_PTS) : "memory");
+      asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %4, off\n\tglobal_load_dword %2, %5, off"
+                   : "=&v"(xn), "=&v"(xlo), "=&v"(xno) : "v"(np), "v"(np + (size_t)ntiles * KS_PTS), "v"(np + 2 * (size_t)ntiles * KS_PTS)
+                   : "memory");
     }
     float cnr[KS_NB];
 #pragma unroll
@@ -968,19 +1029,20 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
         ks = mine ? ss : ks;
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn), "+v"(xlo)::"memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn), "+v"(xlo), "+v"(xno)::"memory");
     if (part) {
       if (fr < 8 && pmine < N) part[pmine] = float2{kb, ks};
     } else if (fr < 8 && pmine < N) {
       labels[pmine] = (long long)(__float_as_uint(kb) & 511u);
-      // Per-point margin.  What this pass does not see of a product is x.c - x_hi.c_hi = x_lo.c + x_hi.c_lo, at most |x_lo| |c| + |x_hi| |c_lo|
-      // (Cauchy-Schwarz; x_lo = x - bf16(x) and its norm are exact, from u2_kmeans_prepare; |x_hi| <= 1.004 |x|): twice that per
-      // distance, four times between two distances.  With the norms as they are instead of their worst case (2^-9 of |x|, |c| each:
-      // 2^-6 |x| max|c| in all, the 0.02 of kmeans_screen_kernel<1>) the margin is ~0.013 |x| max|c| on fp32 data and zero for
-      // operands that are bf16 values already.  + margin_rel |x| max|c| for everything else (fp32 accumulation here and in the exact
-      // kernel: the fine pass's own margin, three times) + the mantissa bits the indices took (2^-14 of a distance at most,
-      // |distance| <= |c|^2 + 2 |x| |c|; twice that here).
-      const float margin = 4.04f * (xlo * cmax + 1.004f * xn * clomax) + margin_rel * cmax * xn +
+      // Per-point margin, in the translated frame (x, c stand for x - mu, c - mu).  What this pass does not see of a product is
+      // x.c - x_hi.c_hi = x_lo.c + x_hi.c_lo, at most |x_lo| |c| + |x_hi| |c_lo| (Cauchy-Schwarz; x_lo = x - bf16(x) and its norm are
+      // exact, from u2_kmeans_prepare; |x_hi| <= 1.004 |x|): twice that per distance, four times between two distances.  With the norms
+      // as they are instead of their worst case (2^-9 of |x|, |c| each: 2^-6 |x| max|c| in all, the 0.02 of kmeans_screen_kernel<1>) the
+      // margin is ~0.013 |x| max|c| on fp32 data and zero for operands that are bf16 values already.  + the mantissa bits the indices
+      // took (2^-14 of a distance at most, |distance| <= |c|^2 + 2 |x| |c|; twice that here).  + margin_rel |x| max|c| of the
+      // UNTRANSLATED operands for everything else: the labels must be the exact kernel's, whose own fp32 rounding is proportional to
+      // the norms it sees (the fine pass's margin, three times), and the roundings of x - mu, c - mu.
+      const float margin = 4.04f * (xlo * cmax + 1.004f * xn * clomax) + margin_rel * cmax_o * xno +
                            1.2207031e-4f * (cmax * cmax + 2.f * xn * cmax);
       if (!(ks - kb >= margin)) list[atomicAdd(nlist, 1)] = pmine;   // also: NaN anywhere
     }
@@ -992,7 +1054,8 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
 // K > 320: the per-block candidates of kmeans_coarse_kernel (part[b][N]) -> label and, where the two best of ALL centroids are closer
 // than the coarse margin, an entry of the exact kernel's list.  Second best overall = min(second of the best block, best of the others).
 __global__ __launch_bounds__(256) void km_chunk_merge_kernel(const float2* __restrict__ part, int nblocks, const float* __restrict__ xnorm,
-                                                             int npad, const unsigned* __restrict__ scal, long long* __restrict__ labels,
+                                                             int npad, const unsigned* __restrict__ cs, const unsigned* __restrict__ scal,
+                                                             long long* __restrict__ labels,
                                                              int* __restrict__ list, int* __restrict__ nlist, int N, float margin_rel) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= N) return;
@@ -1006,9 +1069,9 @@ __global__ __launch_bounds__(256) void km_chunk_merge_kernel(const float2* __res
     bb = fminf(bb, v.x);
   }
   labels[p] = (long long)bj;
-  const float cmax = sqrtf(__uint_as_float(scal[0])), clomax = sqrtf(__uint_as_float(scal[3]));
-  const float xn = xnorm[p], xlo = xnorm[npad + p];
-  const float margin = 4.04f * (xlo * cmax + 1.004f * xn * clomax) + margin_rel * cmax * xn +   // kmeans_coarse_kernel's margin
+  const float cmax = sqrtf(__uint_as_float(cs[0])), clomax = sqrtf(__uint_as_float(cs[1])), cmax_o = sqrtf(__uint_as_float(scal[0]));
+  const float xn = xnorm[p], xlo = xnorm[npad + p], xno = xnorm[2 * (size_t)npad + p];
+  const float margin = 4.04f * (xlo * cmax + 1.004f * xn * clomax) + margin_rel * cmax_o * xno +   // kmeans_coarse_kernel's margin
                        1.2207031e-4f * (cmax * cmax + 2.f * xn * cmax);
   if (!(ss - bb >= margin)) list[atomicAdd(nlist, 1)] = p;
 }
@@ -1221,17 +1284,22 @@ __global__ void kmeans_finalize_kernel(const float* __restrict__ csum, const flo
 // a fine pass instead of half: more than 55 %) switches itself off, every 64th call tries again.  Labels are those of the exact
 // kernel in either mode - the modes differ in time only.
 constexpr unsigned KS_MAGIC = 0x4b533431u;
-__global__ void km_state_begin_kernel(unsigned* __restrict__ scal, unsigned* __restrict__ state) {
-  if (threadIdx.x < 4) scal[threadIdx.x] = 0u;
+__global__ void km_state_begin_kernel(unsigned* __restrict__ scal, unsigned* __restrict__ state, unsigned* __restrict__ cs) {
+  if (threadIdx.x < 4) { scal[threadIdx.x] = 0u; cs[threadIdx.x] = 0u; }
   if (threadIdx.x == 0 && state[0] != KS_MAGIC) { state[0] = KS_MAGIC; state[1] = 0u; state[2] = 0u; state[3] = 0u; }
 }
 
+static long long km_blocks(int K) { return (K + KS_KMAX - 1) / KS_KMAX; }
+static long long km_ws_base_floats(int N, int D, int K) {
+  const long long blocks = km_blocks(K);
+  return (((long long)K + 16 + blocks * KS_KMAX * D + 2LL * N + 32 + (blocks > 1 ? blocks * 2LL * N + 8 : 0)) + 3) & ~3LL;
+}
 extern "C" long long u2_kmeans_assign_workspace_floats(int N, int D, int K) {
   // |c|^2 [K] | max |c|^2, exact-list length, coarse-list length [4] | split centroids [2][320][D] bf16 | exact re-check list [N]
   // | undecided list of the coarse pass [N] | screening state [4]
   // K > 320 (u2_kmeans_assign_shadow only): the split centroids of every block of 320, and the blocks' candidates [blocks][N]{best, second}
-  const long long blocks = (K + KS_KMAX - 1) / KS_KMAX;
-  return (long long)K + 16 + blocks * KS_KMAX * D + 2LL * N + 32 + (blocks > 1 ? blocks * 2LL * N + 8 : 0);
+  // behind all of that, for u2_kmeans_assign_shadow: {max |c - mu|^2, max residual^2} [4] | |c_j - mu|^2 [blocks][320] | bf16(c - mu) [blocks][320][D]
+  return km_ws_base_floats(N, D, K) + 8 + km_blocks(K) * KS_KMAX + km_blocks(K) * (KS_KMAX / 2) * (long long)D;
 }
 
 #ifdef U2_KM_TRACE
@@ -1258,17 +1326,26 @@ static size_t km_shadow_words(int N, int D) { return (size_t)(D >> 5) * (size_t)
 
 extern "C" long long u2_kmeans_shadow_floats(int N, int D) {
   if (N <= 0 || D % 32 != 0) return 0;
-  return (long long)(km_shadow_words(N, D) + 2 * (size_t)((N + KS_PTS - 1) / KS_PTS) * KS_PTS);   // + |x_p|, |x_p - bf16(x_p)|
+  // + |x_p - mu|, |(x_p - mu) - bf16(x_p - mu)|, |x_p| (each padded to whole tiles) + mu [D]
+  return (long long)(km_shadow_words(N, D) + 3 * (size_t)((N + KS_PTS - 1) / KS_PTS) * KS_PTS + (size_t)((D + 63) & ~63));
 }
 
 extern "C" int u2_kmeans_prepare(const float* x, float* shadow, int N, int D, void* stream) {
   if (N <= 0 || D % 32 != 0 || !shadow) return -1;
   hipStream_t s = (hipStream_t)stream;
   const int G = ((N + KS_PTS - 1) / KS_PTS) * 16;
-  const size_t threads = (size_t)(D >> 5) * G * 64;
-  hipLaunchKernelGGL(km_shadow_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, reinterpret_cast<uint4*>(shadow), N, D, G);
+  float* mu = shadow + km_shadow_words(N, D) + 3 * (size_t)G * 16;
+  // the column mean first; its slab sums use the (not yet written) shadow as scratch: slabs x D floats <= N D / 2
+  const int slabs = (N + KM_MU_ROWS - 1) / KM_MU_ROWS;
+  hipLaunchKernelGGL(km_colsum_kernel, dim3(slabs), dim3(256), 0, s, x, shadow, N, D);
   U2_CHECK_LAUNCH();
-  hipLaunchKernelGGL(km_xnorm_kernel, dim3((G * 16 + 3) / 4), dim3(256), 0, s, x, shadow + km_shadow_words(N, D), N, D, G * 16);
+  hipLaunchKernelGGL(km_mu_kernel, dim3((D + 255) / 256), dim3(256), 0, s, (const float*)shadow, slabs, mu, N, D);
+  U2_CHECK_LAUNCH();
+  const size_t threads = (size_t)(D >> 5) * G * 64;
+  hipLaunchKernelGGL(km_shadow_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, (const float*)mu, reinterpret_cast<uint4*>(shadow),
+                     N, D, G);
+  U2_CHECK_LAUNCH();
+  hipLaunchKernelGGL(km_xnorm_kernel, dim3((G * 16 + 3) / 4), dim3(256), 0, s, x, (const float*)mu, shadow + km_shadow_words(N, D), N, D, G * 16);
   U2_CHECK_LAUNCH();
   return 0;
 }
@@ -1288,6 +1365,11 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
   // K > 320 (the 800 clusters of u2seg_R50_800): the coarse pass once per block of 320 centroids over the shadow, the blocks' candidates
   // merged per point, what stays undecided straight to the exact kernel (13.6 -> 1.9 ms at N = 1 M, K = 800 on clustered data)
   const int blocks = (K + KS_KMAX - 1) / KS_KMAX;
+  // centred centroids for the first pass over the shadow (csplit_kernel), behind everything else in the workspace
+  unsigned* cs = reinterpret_cast<unsigned*>(workspace + km_ws_base_floats(N, D, K));
+  float* cnc = reinterpret_cast<float*>(cs + 8);
+  bf16_t* chc = reinterpret_cast<bf16_t*>(cnc + (size_t)blocks * KS_KMAX);
+  const float* mu = shadow ? shadow + km_shadow_words(N, D) + 3 * (size_t)((N + KS_PTS - 1) / KS_PTS) * KS_PTS : nullptr;
   if (!exact_only && shadow && D % 32 == 0 && K > KS_KMAX && blocks <= KM_MAX_BLOCKS && N >= KS_PTS) {
     unsigned* scal = reinterpret_cast<unsigned*>(workspace + ((K + 3) & ~3));
     bf16_t* chl = reinterpret_cast<bf16_t*>(workspace + ((K + 3) & ~3) + 4);
@@ -1296,9 +1378,11 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
     pbase += (2 - ((reinterpret_cast<size_t>(pbase) >> 2) & 1)) & 1;     // 8-byte aligned
     float2* part = reinterpret_cast<float2*>(pbase);
     u2_zero_words(scal, 4, s);
+    u2_zero_words(cs, 4, s);
     for (int b = 0; b < blocks; ++b) {
       hipLaunchKernelGGL(csplit_kernel, dim3(KS_KMAX / 4), dim3(256), 0, s, c + (size_t)b * KS_KMAX * D, chl + (size_t)b * 2 * KS_KMAX * D,
-                         cn + b * KS_KMAX, scal, D, std::min(KS_KMAX, K - b * KS_KMAX));
+                         cn + b * KS_KMAX, scal, D, std::min(KS_KMAX, K - b * KS_KMAX), mu, chc + (size_t)b * KS_KMAX * D, cnc + b * KS_KMAX,
+                         cs);
       U2_CHECK_LAUNCH();
     }
     static PerDeviceOnce attr_set;
@@ -1308,11 +1392,11 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
     const float* xn = shadow + km_shadow_words(N, D);
     for (int b = 0; b < blocks; ++b) {
       hipLaunchKernelGGL(kmeans_coarse_kernel, dim3(tiles < cus ? tiles : cus), dim3(512), KC_LDS, s, reinterpret_cast<const unsigned char*>(shadow),
-                         xn, chl + (size_t)b * 2 * KS_KMAX * D, cn + b * KS_KMAX, scal, labels, (int*)nullptr, (int*)nullptr, N, D,
+                         xn, chc + (size_t)b * KS_KMAX * D, cnc + b * KS_KMAX, cs, scal, labels, (int*)nullptr, (int*)nullptr, N, D,
                          std::min(KS_KMAX, K - b * KS_KMAX), 3e-4f, (const int*)nullptr, 0, part + (size_t)b * N);
       U2_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(km_chunk_merge_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, blocks, xn, (int)(tiles * KS_PTS), scal, labels, list2,
+    hipLaunchKernelGGL(km_chunk_merge_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, blocks, xn, (int)(tiles * KS_PTS), cs, scal, labels, list2,
                        reinterpret_cast<int*>(scal + 1), N, 3e-4f);
     U2_CHECK_LAUNCH();
     hipLaunchKernelGGL(kmeans_assign_kernel, dim3((N + KM_PTS - 1) / KM_PTS), dim3(256), 0, s, x, c, cn, labels, N, D, K, (const int*)list2,
@@ -1334,9 +1418,9 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
   int* list1 = list2 + N;
   unsigned* state = reinterpret_cast<unsigned*>(list1 + N);
   state += (4 - ((reinterpret_cast<size_t>(state) >> 2) & 3)) & 3;   // 16-byte aligned (the slack is in the + 32 of the size)
-  hipLaunchKernelGGL(km_state_begin_kernel, dim3(1), dim3(64), 0, s, scal, state);
+  hipLaunchKernelGGL(km_state_begin_kernel, dim3(1), dim3(64), 0, s, scal, state, cs);
   U2_CHECK_LAUNCH();
-  hipLaunchKernelGGL(csplit_kernel, dim3(KS_KMAX / 4), dim3(256), 0, s, c, chl, cn, scal, D, K);
+  hipLaunchKernelGGL(csplit_kernel, dim3(KS_KMAX / 4), dim3(256), 0, s, c, chl, cn, scal, D, K, mu, chc, cnc, cs);
   U2_CHECK_LAUNCH();
   static PerDeviceOnce attr_set;
   if (auto once_guard = attr_set.first()) {
@@ -1357,7 +1441,8 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
     // coarse pass over everything -> list1; fine pass over list1 -> list2 (both skipped while the coarse pass is switched off)
     if (shadow)
       hipLaunchKernelGGL(kmeans_coarse_kernel, dim3(grid.x < (unsigned)km_cu_count() ? grid.x : (unsigned)km_cu_count()), block, KC_LDS, s, reinterpret_cast<const unsigned char*>(shadow),
-                         shadow + km_shadow_words(N, D), chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D, K, 3e-4f, gate, 0, (float2*)nullptr);
+                         shadow + km_shadow_words(N, D), chc, cnc, cs, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D, K, 3e-4f, gate, 0,
+                         (float2*)nullptr);
     else
       hipLaunchKernelGGL(kmeans_screen_kernel<1>, grid, block, lds1, s, x, chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D,
                          K, 0.02f, (const int*)nullptr, (const int*)nullptr, gate, 0);
