@@ -838,6 +838,31 @@ def test_kmeans_more_than_320_centroids(monkeypatch, k):
     KM._ws_cache.pop("assign:" + str(DEV), None)
 
 
+def test_kmeans_first_pass_is_translation_invariant(monkeypatch):
+    """Round 6: the first screening pass works on x - mean(x), c - mean(x) (argmin_j |x - c_j|^2 does not change under a common translation):
+    clustered rows with a common offset of 25 per dimension - |x| |c| is 600 x the cluster spread, the untranslated margin would leave
+    every point undecided - are decided by it as the same rows without the offset are; labels == the exact kernel's in both cases."""
+    from u2seg_amd.cluster import kmeans as KM
+
+    monkeypatch.setattr(KM, "SHADOW_MIN_POINTS", 256)
+    g = torch.Generator().manual_seed(91)
+    n, d, k = 30000, 256, 64
+    cen = torch.randn((k, d), generator=g) * 2
+    x0 = cen[torch.randint(0, k, (n,), generator=g)] + 0.5 * torch.randn((n, d), generator=g)
+    c0 = cen + 0.3 * torch.randn((k, d), generator=g)
+    left = []
+    for off in (0.0, 25.0):
+        xd, cd = (x0 + off).to(DEV), (c0 + off).to(DEV)
+        KM._ws_cache.pop("assign:" + str(DEV), None)
+        KM.release_shadow()
+        fast = KM.assign(xd, cd)
+        left.append(KM.last_coarse_undecided(xd.device))
+        assert torch.equal(fast, KM.assign(xd, cd, exact=True)), off
+    assert left[0] < n // 100 and left[1] < n // 20, left
+    KM.release_shadow()
+    KM._ws_cache.pop("assign:" + str(DEV), None)
+
+
 def test_kmeans_random_shapes_equal_exact(monkeypatch):
     """Random (N, D, K) through every screening path (shadow forced on; K up to 1280, D from one 32-dimension step up): clustered rows,
     unstructured rows with rows as centroids, bf16-valued rows with norms spread over six decades and a duplicated centroid, rows with a
