@@ -398,7 +398,9 @@ long long u2_kmeans_assign_workspace_floats(int N, int D, int K);
 int u2_kmeans_assign(const float* x, const float* c, float* workspace, long long* labels, int N, int D, int K, int exact_only,
                      void* stream);
 /* The same with a shadow of x: x does not change between the Lloyd iterations of a run (nn_utils.py:352 builds its x_i once,
- * outside the loop), so u2_kmeans_prepare writes the leading bf16 piece of x, |x_p| and |x_p - bf16(x_p)| once -
+ * outside the loop), so u2_kmeans_prepare writes mu = the column mean of x, the leading bf16 piece of x - mu (argmin_j |x - c_j|^2
+ * does not change under a common translation, and the screening margin is proportional to the norms of what is multiplied), its norm,
+ * the norm of its bf16 rounding residue and |x_p| once -
  * u2_kmeans_shadow_floats(N, D) floats, 0 when D % 32 != 0 - and the first screening pass of every later E step streams 2 instead
  * of 4 bytes per element, with a margin per point from those two norms instead of their worst case.  The values are the ones that
  * pass rounds x to on the fly without a shadow: same products, same labels.  shadow = NULL: u2_kmeans_assign.  With a shadow the
