@@ -220,14 +220,31 @@ constexpr int KS_RING = 3;
 constexpr int KS_DMA = KS_STAGE / 1024 / 8;  // LDS-DMA instructions per wave per step (5)
 
 // chl [2][320][D] bf16 (hi plane, lo plane; rows >= K zero), cn[j] = |c_j|^2 in fp32, *cmax2 = max_j cn[j]
-// mu != nullptr (the first pass over the shadow works on x - mu, c - mu; see km_shadow_kernel): chc [320][D] = bf16(c - mu) in the same
-// dimension order, cnc[j] = |c_j - mu|^2, cs[0] = max_j of it, cs[1] = max_j |(c_j - mu) - bf16(c_j - mu)|^2
+typedef __attribute__((ext_vector_type(2))) float ks_hf32x2;
+// fp16 (round to nearest even) for the shadow of the first pass: same two bytes and the same MFMA rate as bf16, eleven significant bits
+// instead of eight - and the pass's margin is made of the exact norms of what the rounding dropped
+typedef _Float16 ks_h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 ks_h16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t ks_pack_h(float lo, float hi) {
+  const ks_hf32x2 v = {lo, hi};
+  const ks_h16x2 r = __builtin_convertvector(v, ks_h16x2);
+  return *reinterpret_cast<const uint32_t*>(&r);
+}
+__device__ __forceinline__ float ks_h_lo(uint32_t w) { const ks_h16x2 r = *reinterpret_cast<const ks_h16x2*>(&w); return (float)r[0]; }
+__device__ __forceinline__ float ks_h_hi(uint32_t w) { const ks_h16x2 r = *reinterpret_cast<const ks_h16x2*>(&w); return (float)r[1]; }
+__device__ __forceinline__ unsigned short ks_f2h(float v) { const _Float16 h = (_Float16)v; return *reinterpret_cast<const unsigned short*>(&h); }
+__device__ __forceinline__ float ks_h2f(unsigned short b) { return (float)*reinterpret_cast<const _Float16*>(&b); }
+// mu != nullptr (the first pass over the shadow works on x - mu, c - mu; see km_shadow_kernel): chc [320][D] = fp16(S (c - mu)) in the same
+// dimension order (S = mu[-...]: the shadow's power-of-two scale, aux[0] behind mu), cnc[j] = |c_j - mu|^2, cs[0] = max_j of it,
+// cs[1] = max_j |(c_j - mu) - chc_j / S|^2
 __global__ __launch_bounds__(256) void csplit_kernel(const float* __restrict__ c, bf16_t* __restrict__ chl, float* __restrict__ cn,
                                                      unsigned* __restrict__ cmax2, int D, int K, const float* __restrict__ mu,
-                                                     bf16_t* __restrict__ chc, float* __restrict__ cnc, unsigned* __restrict__ cs) {
+                                                     bf16_t* __restrict__ chc, float* __restrict__ cnc, unsigned* __restrict__ cs,
+                                                     const float* __restrict__ aux) {
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= KS_KMAX) return;
   float s = 0.f, slo = 0.f, sc = 0.f, sclo = 0.f;
+  const float S = mu ? aux[0] : 1.f, Sinv = mu ? aux[1] : 1.f;
   // Within every 32-dimension step the dimensions are stored in the order the screening kernel's x loads deliver them: position
   // fg * 8 + e holds dimension fg * 4 + e (e < 4) or 16 + fg * 4 + (e - 4) - a lane of the MFMA A operand then gets its eight
   // values from two 16-byte loads that are 64 bytes apart, and the four lanes of a row read 64 contiguous bytes per instruction.
@@ -257,10 +274,11 @@ __global__ __launch_bounds__(256) void csplit_kernel(const float* __restrict__ c
       slo += (v - bf2f(h)) * (v - bf2f(h));   // |c_j - bf16(c_j)|^2 (the permutation does not change the sum's terms)
       if (mu) {
         const float vc = j < K ? v - mm[i] : 0.f;
-        const bf16_t hc = f2bf(vc);
+        const unsigned short hc = ks_f2h(vc * S);
         chc[(size_t)j * D + d] = hc;
         sc += vc * vc;
-        sclo += (vc - bf2f(hc)) * (vc - bf2f(hc));
+        const float rc = vc - ks_h2f(hc) * Sinv;
+        sclo += rc * rc;
       }
       // |c_j|^2 is summed over the UNPERMUTED dimensions, lane by lane exactly as cnorm_kernel does: the re-check must see the
       // same bits as a run of the exact kernel alone, or near-duplicate centroids (exact-fp32 ties) are decided differently
@@ -333,8 +351,10 @@ __global__ __launch_bounds__(256) void km_mu_kernel(const float* __restrict__ pa
 // first pass's margin is proportional to |x - mu| |c - mu| instead of |x| |c| - on L2-normalised features with a common direction
 // (F.normalize(DINO features): usl-imagenet.py:103; mean cosine between rows 0.3-0.8) that is what lets it decide anything at all.
 // Any mu is valid as long as x and c use the same one; mu = the column mean of x, fixed when the shadow is made.
+// Stored as fp16(S (x - mu)), S a power of two that puts the largest |x_p - mu| at 2^13 .. 2^14 (km_scale_kernel): the scaling is exact,
+// nothing overflows, and elements down to 2^-28 of the largest norm keep their eleven bits.
 __global__ __launch_bounds__(256) void km_shadow_kernel(const float* __restrict__ x, const float* __restrict__ mu, uint4* __restrict__ xh,
-                                                        int N, int D, int G) {
+                                                        int N, int D, int G, const float* __restrict__ aux) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int lane = (int)(t & 63), fr = lane & 15, fg = lane >> 4;
   const size_t gi = t >> 6;                     // step * G + group
@@ -348,19 +368,22 @@ __global__ __launch_bounds__(256) void km_shadow_kernel(const float* __restrict_
     a = *reinterpret_cast<const float4*>(src);
     b = *reinterpret_cast<const float4*>(src + 16);
     const float4 ma = *reinterpret_cast<const float4*>(ms), mb = *reinterpret_cast<const float4*>(ms + 16);
-    a.x -= ma.x; a.y -= ma.y; a.z -= ma.z; a.w -= ma.w;
-    b.x -= mb.x; b.y -= mb.y; b.z -= mb.z; b.w -= mb.w;
+    const float S = aux[0];
+    a.x = (a.x - ma.x) * S; a.y = (a.y - ma.y) * S; a.z = (a.z - ma.z) * S; a.w = (a.w - ma.w) * S;
+    b.x = (b.x - mb.x) * S; b.y = (b.y - mb.y) * S; b.z = (b.z - mb.z) * S; b.w = (b.w - mb.w) * S;
   }
   uint4 o;
-  o.x = ks_pack(a.x, a.y); o.y = ks_pack(a.z, a.w); o.z = ks_pack(b.x, b.y); o.w = ks_pack(b.z, b.w);
+  o.x = ks_pack_h(a.x, a.y); o.y = ks_pack_h(a.z, a.w); o.z = ks_pack_h(b.x, b.y); o.w = ks_pack_h(b.z, b.w);
   xh[t] = o;
 }
-// with y = x_p - mu: xn[p] = |y|, xn[NP16 + p] = |y - bf16(y)| (what the coarse pass does not see of the point), xn[2 NP16 + p] = |x_p|
+// with y = x_p - mu.  Phase 0: xn[p] = |y|, xn[2 NP16 + p] = |x_p|, *maxn2 = max_p |y|^2 (for the scale).  Phase 1 (S known):
+// xn[NP16 + p] = |y - fp16(S y) / S| - what the first pass does not see of the point, exactly.
 __global__ __launch_bounds__(256) void km_xnorm_kernel(const float* __restrict__ x, const float* __restrict__ mu, float* __restrict__ xn,
-                                                       int N, int D, int NP16) {
+                                                       int N, int D, int NP16, int phase, float* __restrict__ aux) {
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= NP16) return;
   float s = 0.f, sl = 0.f, so = 0.f;
+  const float S = phase ? aux[0] : 1.f, Sinv = phase ? aux[1] : 1.f;
   if (p < N)
     for (int d = (threadIdx.x & 63) * 4; d < D; d += 256) {
       float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * D + d);
@@ -368,19 +391,39 @@ __global__ __launch_bounds__(256) void km_xnorm_kernel(const float* __restrict__
       so += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
       v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w;
       s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-      const uint32_t h0 = ks_pack(v.x, v.y), h1 = ks_pack(v.z, v.w);
-      const float r0 = v.x - __uint_as_float(h0 << 16), r1 = v.y - __uint_as_float(h0 & 0xffff0000u);
-      const float r2 = v.z - __uint_as_float(h1 << 16), r3 = v.w - __uint_as_float(h1 & 0xffff0000u);
-      sl += r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
+      if (phase) {
+        const uint32_t h0 = ks_pack_h(v.x * S, v.y * S), h1 = ks_pack_h(v.z * S, v.w * S);
+        const float r0 = v.x - ks_h_lo(h0) * Sinv, r1 = v.y - ks_h_hi(h0) * Sinv;
+        const float r2 = v.z - ks_h_lo(h1) * Sinv, r3 = v.w - ks_h_hi(h1) * Sinv;
+        sl += r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
+      }
     }
   s = wave_sum(s);
   sl = wave_sum(sl);
   so = wave_sum(so);
   if ((threadIdx.x & 63) == 0) {
-    xn[p] = sqrtf(s);
-    xn[NP16 + p] = sqrtf(sl);
-    xn[2 * (size_t)NP16 + p] = sqrtf(so);
+    if (phase) {
+      xn[NP16 + p] = sqrtf(sl);
+    } else {
+      xn[p] = sqrtf(s);
+      xn[2 * (size_t)NP16 + p] = sqrtf(so);
+      if (p < N) atomicMax(reinterpret_cast<unsigned*>(aux + 2), __float_as_uint(s));   // s >= 0 (a NaN sorts above everything)
+    }
   }
+}
+// aux[0] = S, aux[1] = 1 / S from aux[2] = max_p |x_p - mu|^2: the largest norm lands in [2^13, 2^14); S = 1 when that maximum is 0 or
+// not finite (such rows are undecided in every screening pass anyway)
+__global__ void km_scale_kernel(float* __restrict__ aux) {
+  if (threadIdx.x != 0) return;
+  const float m = sqrtf(aux[2]);
+  float S = 1.f;
+  if (m > 0.f && m < 3.0e38f) {
+    int e;
+    (void)frexpf(m, &e);                         // m = f 2^e, 0.5 <= f < 1
+    S = ldexpf(1.f, min(max(14 - e, -100), 100));
+  }
+  aux[0] = S;
+  aux[1] = 1.f / S;
 }
 
 // NP = 3: the three products hi.hi + hi.lo + lo.hi (error <= 1.2e-5 |x| |c|, margin_rel 1e-4).  NP = 1 (round 4): hi.hi only - a
@@ -824,7 +867,7 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
                                                             long long* __restrict__ labels,
                                                             int* __restrict__ list, int* __restrict__ nlist, int N, int D, int K,
                                                             float margin_rel, const int* __restrict__ gate, int gate_want,
-                                                            float2* __restrict__ part) {
+                                                            float2* __restrict__ part, const float* __restrict__ aux) {
   // part != nullptr (K > 320, one launch per block of 320 centroids - chl, cn, K are the block's): the point's (best | index inside the
   // block, second best) go to part[p] and km_chunk_merge_kernel decides over all blocks
   extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
@@ -915,6 +958,7 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
   }
   U2_KM_STAMP(1);
   const float cmax = sqrtf(__uint_as_float(cs[0])), clomax = sqrtf(__uint_as_float(cs[1])), cmax_o = sqrtf(__uint_as_float(*cmax2));
+  const float m2s = -2.f * aux[1] * aux[1];      // -2 / S^2
   int cbuf = 0, xslot = 0, g = 0;                // g % 3, g % KC_SLOTS
   for (int it = 0; it < nmine; ++it) {
     f32x4 acc[2][KS_NB];
@@ -953,14 +997,14 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
 #define U2_KC_QUAD(SET, NB)                                                                                                   \
       if (!(U2_KC_ABL & 1)) {                                                                                                  \
         const s16x8 b0 = bq[SET][0], b1 = bq[SET][1], b2 = bq[SET][2], b3 = bq[SET][3];                                        \
-        acc[0][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b0, acc[0][NB], 0, 0, 0);                                  \
-        acc[1][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b0, acc[1][NB], 0, 0, 0);                                  \
-        acc[0][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b1, acc[0][NB + 1], 0, 0, 0);                          \
-        acc[1][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b1, acc[1][NB + 1], 0, 0, 0);                          \
-        acc[0][NB + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b2, acc[0][NB + 2], 0, 0, 0);                          \
-        acc[1][NB + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b2, acc[1][NB + 2], 0, 0, 0);                          \
-        acc[0][NB + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], b3, acc[0][NB + 3], 0, 0, 0);                          \
-        acc[1][NB + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1], b3, acc[1][NB + 3], 0, 0, 0);                          \
+        acc[0][NB] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ks_h16x8, ah[0]), __builtin_bit_cast(ks_h16x8, b0), acc[0][NB], 0, 0, 0);                                  \
+        acc[1][NB] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ks_h16x8, ah[1]), __builtin_bit_cast(ks_h16x8, b0), acc[1][NB], 0, 0, 0);                                  \
+        acc[0][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ks_h16x8, ah[0]), __builtin_bit_cast(ks_h16x8, b1), acc[0][NB + 1], 0, 0, 0);                          \
+        acc[1][NB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ks_h16x8, ah[1]), __builtin_bit_cast(ks_h16x8, b1), acc[1][NB + 1], 0, 0, 0);                          \
+        acc[0][NB + 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ks_h16x8, ah[0]), __builtin_bit_cast(ks_h16x8, b2), acc[0][NB + 2], 0, 0, 0);                          \
+        acc[1][NB + 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ks_h16x8, ah[1]), __builtin_bit_cast(ks_h16x8, b2), acc[1][NB + 2], 0, 0, 0);                          \
+        acc[0][NB + 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ks_h16x8, ah[0]), __builtin_bit_cast(ks_h16x8, b3), acc[0][NB + 3], 0, 0, 0);                          \
+        acc[1][NB + 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ks_h16x8, ah[1]), __builtin_bit_cast(ks_h16x8, b3), acc[1][NB + 3], 0, 0, 0);                          \
       }
       static_assert(KS_NB == 20, "the unrolled group sequence below covers 20 centroid blocks");
       U2_KC_LDQ(0, 0);
@@ -1017,7 +1061,7 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
       for (int nb = 0; nb < KS_NB; ++nb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = fmaf(acc[m][nb][r], -2.f, cnr[nb]);                        // cn - 2 x.c
+          float v = fmaf(acc[m][nb][r], m2s, cnr[nb]);                         // cn - 2 x.c (the products carry the shadow's scale twice)
           v = __uint_as_float((__float_as_uint(v) & 0xffffffe0u) | (unsigned)nb);
           s2[r] = __builtin_amdgcn_fmed3f(b[r], s2[r], v);                       // b <= s2: the middle one is the new second best
           b[r] = kc_min(b[r], v);
@@ -1060,7 +1104,8 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
       // the norms it sees (the fine pass's margin, three times), and the roundings of x - mu, c - mu.
       const float margin = 4.04f * (xlo * cmax + 1.004f * xn * clomax) + margin_rel * cmax_o * xno +
                            1.2207031e-4f * (cmax * cmax + 2.f * xn * cmax);
-      if (!(ks - kb >= margin)) list[atomicAdd(nlist, 1)] = pmine;   // also: NaN anywhere
+      // also: NaN anywhere; and an operand beyond the shadow's range (a centroid far outside the data: its products are infinite)
+      if (!(ks - kb >= margin) || !(fabsf(kb) < 3.0e38f)) list[atomicAdd(nlist, 1)] = pmine;
     }
     if (it == 0) { U2_KM_STAMP(3); }
   }
@@ -1089,7 +1134,7 @@ __global__ __launch_bounds__(256) void km_chunk_merge_kernel(const float2* __res
   const float xn = xnorm[p], xlo = xnorm[npad + p], xno = xnorm[2 * (size_t)npad + p];
   const float margin = 4.04f * (xlo * cmax + 1.004f * xn * clomax) + margin_rel * cmax_o * xno +   // kmeans_coarse_kernel's margin
                        1.2207031e-4f * (cmax * cmax + 2.f * xn * cmax);
-  if (!(ss - bb >= margin)) list[atomicAdd(nlist, 1)] = p;
+  if (!(ss - bb >= margin) || !(fabsf(bb) < 3.0e38f)) list[atomicAdd(nlist, 1)] = p;
 }
 
 // csum[K][D] += x rows by label; counts[K] += 1.  grid = (point chunks, D / DS); LDS holds [K][DS] partial sums.
@@ -1343,7 +1388,8 @@ static size_t km_shadow_words(int N, int D) { return (size_t)(D >> 5) * (size_t)
 extern "C" long long u2_kmeans_shadow_floats(int N, int D) {
   if (N <= 0 || D % 32 != 0) return 0;
   // + |x_p - mu|, |(x_p - mu) - bf16(x_p - mu)|, |x_p| (each padded to whole tiles) + mu [D]
-  return (long long)(km_shadow_words(N, D) + 3 * (size_t)((N + KS_PTS - 1) / KS_PTS) * KS_PTS + (size_t)((D + 63) & ~63));
+  // + aux [64]: the scale S, 1 / S, max |x_p - mu|^2
+  return (long long)(km_shadow_words(N, D) + 3 * (size_t)((N + KS_PTS - 1) / KS_PTS) * KS_PTS + (size_t)((D + 63) & ~63) + 64);
 }
 
 extern "C" int u2_kmeans_prepare(const float* x, float* shadow, int N, int D, void* stream) {
@@ -1357,11 +1403,18 @@ extern "C" int u2_kmeans_prepare(const float* x, float* shadow, int N, int D, vo
   U2_CHECK_LAUNCH();
   hipLaunchKernelGGL(km_mu_kernel, dim3((D + 255) / 256), dim3(256), 0, s, (const float*)shadow, slabs, mu, N, D);
   U2_CHECK_LAUNCH();
+  float* aux = mu + ((D + 63) & ~63);
+  float* xn = shadow + km_shadow_words(N, D);
+  u2_zero_words(reinterpret_cast<unsigned*>(aux), 4, s);
+  hipLaunchKernelGGL(km_xnorm_kernel, dim3((G * 16 + 3) / 4), dim3(256), 0, s, x, (const float*)mu, xn, N, D, G * 16, 0, aux);
+  U2_CHECK_LAUNCH();
+  hipLaunchKernelGGL(km_scale_kernel, dim3(1), dim3(64), 0, s, aux);
+  U2_CHECK_LAUNCH();
   const size_t threads = (size_t)(D >> 5) * G * 64;
   hipLaunchKernelGGL(km_shadow_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, (const float*)mu, reinterpret_cast<uint4*>(shadow),
-                     N, D, G);
+                     N, D, G, (const float*)aux);
   U2_CHECK_LAUNCH();
-  hipLaunchKernelGGL(km_xnorm_kernel, dim3((G * 16 + 3) / 4), dim3(256), 0, s, x, (const float*)mu, shadow + km_shadow_words(N, D), N, D, G * 16);
+  hipLaunchKernelGGL(km_xnorm_kernel, dim3((G * 16 + 3) / 4), dim3(256), 0, s, x, (const float*)mu, xn, N, D, G * 16, 1, aux);
   U2_CHECK_LAUNCH();
   return 0;
 }
@@ -1386,6 +1439,7 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
   float* cnc = reinterpret_cast<float*>(cs + 8);
   bf16_t* chc = reinterpret_cast<bf16_t*>(cnc + (size_t)blocks * KS_KMAX);
   const float* mu = shadow ? shadow + km_shadow_words(N, D) + 3 * (size_t)((N + KS_PTS - 1) / KS_PTS) * KS_PTS : nullptr;
+  const float* aux = mu ? mu + ((D + 63) & ~63) : nullptr;    // {S, 1 / S, ...} of the shadow
   if (!exact_only && shadow && D % 32 == 0 && K > KS_KMAX && blocks <= KM_MAX_BLOCKS && N >= KS_PTS) {
     unsigned* scal = reinterpret_cast<unsigned*>(workspace + ((K + 3) & ~3));
     bf16_t* chl = reinterpret_cast<bf16_t*>(workspace + ((K + 3) & ~3) + 4);
@@ -1398,7 +1452,7 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
     for (int b = 0; b < blocks; ++b) {
       hipLaunchKernelGGL(csplit_kernel, dim3(KS_KMAX / 4), dim3(256), 0, s, c + (size_t)b * KS_KMAX * D, chl + (size_t)b * 2 * KS_KMAX * D,
                          cn + b * KS_KMAX, scal, D, std::min(KS_KMAX, K - b * KS_KMAX), mu, chc + (size_t)b * KS_KMAX * D, cnc + b * KS_KMAX,
-                         cs);
+                         cs, aux);
       U2_CHECK_LAUNCH();
     }
     static PerDeviceOnce attr_set;
@@ -1409,7 +1463,7 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
     for (int b = 0; b < blocks; ++b) {
       hipLaunchKernelGGL(kmeans_coarse_kernel, dim3(tiles < cus ? tiles : cus), dim3(512), KC_LDS, s, reinterpret_cast<const unsigned char*>(shadow),
                          xn, chc + (size_t)b * KS_KMAX * D, cnc + b * KS_KMAX, cs, scal, labels, (int*)nullptr, (int*)nullptr, N, D,
-                         std::min(KS_KMAX, K - b * KS_KMAX), 3e-4f, (const int*)nullptr, 0, part + (size_t)b * N);
+                         std::min(KS_KMAX, K - b * KS_KMAX), 3e-4f, (const int*)nullptr, 0, part + (size_t)b * N, aux);
       U2_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(km_chunk_merge_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, blocks, xn, (int)(tiles * KS_PTS), cs, scal, labels, list2,
@@ -1436,7 +1490,7 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
   state += (4 - ((reinterpret_cast<size_t>(state) >> 2) & 3)) & 3;   // 16-byte aligned (the slack is in the + 32 of the size)
   hipLaunchKernelGGL(km_state_begin_kernel, dim3(1), dim3(64), 0, s, scal, state, cs);
   U2_CHECK_LAUNCH();
-  hipLaunchKernelGGL(csplit_kernel, dim3(KS_KMAX / 4), dim3(256), 0, s, c, chl, cn, scal, D, K, mu, chc, cnc, cs);
+  hipLaunchKernelGGL(csplit_kernel, dim3(KS_KMAX / 4), dim3(256), 0, s, c, chl, cn, scal, D, K, mu, chc, cnc, cs, aux);
   U2_CHECK_LAUNCH();
   static PerDeviceOnce attr_set;
   if (auto once_guard = attr_set.first()) {
@@ -1458,7 +1512,7 @@ extern "C" int u2_kmeans_assign_shadow(const float* x, const float* shadow, cons
     if (shadow)
       hipLaunchKernelGGL(kmeans_coarse_kernel, dim3(grid.x < (unsigned)km_cu_count() ? grid.x : (unsigned)km_cu_count()), block, KC_LDS, s, reinterpret_cast<const unsigned char*>(shadow),
                          shadow + km_shadow_words(N, D), chc, cnc, cs, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D, K, 3e-4f, gate, 0,
-                         (float2*)nullptr);
+                         (float2*)nullptr, aux);
     else
       hipLaunchKernelGGL(kmeans_screen_kernel<1>, grid, block, lds1, s, x, chl, cn, scal, labels, list1, reinterpret_cast<int*>(scal + 2), N, D,
                          K, 0.02f, (const int*)nullptr, (const int*)nullptr, gate, 0);
