@@ -380,10 +380,10 @@ __global__ __launch_bounds__(256) void km_shadow_kernel(const float* __restrict_
 // xn[NP16 + p] = |y - fp16(S y) / S| - what the first pass does not see of the point, exactly.
 __global__ __launch_bounds__(256) void km_xnorm_kernel(const float* __restrict__ x, const float* __restrict__ mu, float* __restrict__ xn,
                                                        int N, int D, int NP16, int phase, float* __restrict__ aux) {
-  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= NP16) return;
-  float s = 0.f, sl = 0.f, so = 0.f;
   const float S = phase ? aux[0] : 1.f, Sinv = phase ? aux[1] : 1.f;
+  float wmax = 0.f;       // largest finite |y|^2 this wave has seen (one atomic per wave: a million of them on one address took 6 ms)
+  for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < NP16; p += gridDim.x * 4) {
+  float s = 0.f, sl = 0.f, so = 0.f;
   if (p < N)
     for (int d = (threadIdx.x & 63) * 4; d < D; d += 256) {
       float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * D + d);
@@ -407,12 +407,14 @@ __global__ __launch_bounds__(256) void km_xnorm_kernel(const float* __restrict__
     } else {
       xn[p] = sqrtf(s);
       xn[2 * (size_t)NP16 + p] = sqrtf(so);
-      if (p < N) atomicMax(reinterpret_cast<unsigned*>(aux + 2), __float_as_uint(s));   // s >= 0 (a NaN sorts above everything)
+      if (p < N && s < 3.0e38f) wmax = fmaxf(wmax, s);   // rows with a NaN / Inf do not set the scale (no pass decides them anyway)
     }
   }
+  }
+  if (!phase && (threadIdx.x & 63) == 0)   // >= 0: the unsigned order of the bits is the order of the floats
+    atomicMax(reinterpret_cast<unsigned*>(aux + 2), __float_as_uint(wmax));
 }
-// aux[0] = S, aux[1] = 1 / S from aux[2] = max_p |x_p - mu|^2: the largest norm lands in [2^13, 2^14); S = 1 when that maximum is 0 or
-// not finite (such rows are undecided in every screening pass anyway)
+// aux[0] = S, aux[1] = 1 / S from aux[2] = the largest finite |x_p - mu|^2: that norm lands in [2^13, 2^14); S = 1 when there is none
 __global__ void km_scale_kernel(float* __restrict__ aux) {
   if (threadIdx.x != 0) return;
   const float m = sqrtf(aux[2]);
@@ -1406,7 +1408,8 @@ extern "C" int u2_kmeans_prepare(const float* x, float* shadow, int N, int D, vo
   float* aux = mu + ((D + 63) & ~63);
   float* xn = shadow + km_shadow_words(N, D);
   u2_zero_words(reinterpret_cast<unsigned*>(aux), 4, s);
-  hipLaunchKernelGGL(km_xnorm_kernel, dim3((G * 16 + 3) / 4), dim3(256), 0, s, x, (const float*)mu, xn, N, D, G * 16, 0, aux);
+  const int xblocks = std::min((G * 16 + 3) / 4, 4096);
+  hipLaunchKernelGGL(km_xnorm_kernel, dim3(xblocks), dim3(256), 0, s, x, (const float*)mu, xn, N, D, G * 16, 0, aux);
   U2_CHECK_LAUNCH();
   hipLaunchKernelGGL(km_scale_kernel, dim3(1), dim3(64), 0, s, aux);
   U2_CHECK_LAUNCH();
@@ -1414,7 +1417,7 @@ extern "C" int u2_kmeans_prepare(const float* x, float* shadow, int N, int D, vo
   hipLaunchKernelGGL(km_shadow_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, (const float*)mu, reinterpret_cast<uint4*>(shadow),
                      N, D, G, (const float*)aux);
   U2_CHECK_LAUNCH();
-  hipLaunchKernelGGL(km_xnorm_kernel, dim3((G * 16 + 3) / 4), dim3(256), 0, s, x, (const float*)mu, xn, N, D, G * 16, 1, aux);
+  hipLaunchKernelGGL(km_xnorm_kernel, dim3(xblocks), dim3(256), 0, s, x, (const float*)mu, xn, N, D, G * 16, 1, aux);
   U2_CHECK_LAUNCH();
   return 0;
 }
