@@ -577,7 +577,7 @@ def main():
             lab = KM.assign(x, state["c"])
             state["c"], _ = KM.update_sharded(x, lab, k) if world > 1 else KM.update(x, lab, k)
 
-        # once per run of kmeans(), not per iteration: the bf16 shadow of x the first screening pass streams (timed on its own here;
+        # once per run of kmeans(), not per iteration: the 16-bit shadow of x the first screening pass streams (timed on its own here;
         # the reference's niter is 100 - nn_utils.py:382 - so it adds a hundredth of this to an iteration)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -591,7 +591,7 @@ def main():
         out.update({"metric": "k-means seconds per Lloyd iteration (u2seg_R50_%d Instance_Clustering: N = 1M x 768 DINO-sized "
                               "embeddings, K = %d)" % (k, k), "value": s_per_iter, "unit": "s/iter", "ms_per_step": s_per_iter * 1e3,
                     "higher_is_better": False, "scaling": "strong", "steps": steps, "warmup": warmup,
-                    "dtype": "f32 (distances screened in split bf16 - the first pass over a bf16 shadow of x made once per run, "
+                    "dtype": "f32 (distances screened in split bf16 - the first pass over a 16-bit shadow of x made once per run, "
                              "one_time_shadow_prepare_ms - undecided points in exact fp32)",
                     "config": {"workload": "Lloyd iterations (assign + update) over %d x %d synthetic embeddings (%s), K = %d, rows "
                                            "sharded over the GPUs" % (n_local * world, KMEANS_D, what, k),
@@ -600,7 +600,7 @@ def main():
                     "one_time_shadow_prepare_ms": prepare_ms})
         if rank == 0:
             ks = timer.summary()
-            if "u2_kmeans_assign_shadow" in ks:      # the product path (cluster/kmeans.py assign): same E step, x's bf16 shadow beside x
+            if "u2_kmeans_assign_shadow" in ks:      # the product path (cluster/kmeans.py assign): same E step, x's 16-bit shadow beside x
                 ks["u2_kmeans_assign"] = ks.pop("u2_kmeans_assign_shadow")
             a = ks.get("u2_kmeans_assign")
             if a:
@@ -609,7 +609,7 @@ def main():
                 # (algorithmic, not the 3 bf16 piece products the screening kernel executes per product)
                 alg_bytes = 4.0 * n_local * KMEANS_D
                 # measured HBM bytes of one iteration: the committed PMC passes are of THIS configuration only (N = 1 M on one GPU,
-                # K = 300, clustered data: E step over the bf16 shadow 1.6 GB + M step 3.1 GB)
+                # K = 300, clustered data: E step over the 16-bit shadow 1.6 GB + M step 3.1 GB)
                 km_traffic, km_note = None, "no PMC profile committed for this configuration"
                 kp = os.path.join(ROOT, "profiles", "r06_km_pmc_traffic.json")
                 if os.path.exists(kp) and world == 1 and n_local == 1000000 and k == KMEANS_K and data_kind == "mixture":
@@ -617,7 +617,7 @@ def main():
                     km_traffic, km_note = kj["kmeans_iteration_hbm_bytes"], "HBM bytes per iteration from profiles/r06_km_pmc_traffic.json (%s)" % kj["note"]
                 ach = alg_bytes / s_per_iter / 1e12
                 out["roofline"] = {"kernel": "Lloyd iteration = u2_kmeans_assign_shadow (kmeans_coarse_kernel: |c|^2 - 2 x.c as hi.hi over "
-                                             "the bf16 shadow of x; kmeans_screen_kernel: hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 "
+                                             "the 16-bit shadow of x; kmeans_screen_kernel: hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 "
                                              "for what it leaves undecided; exact-fp32 kmeans_assign_kernel for what that leaves) + "
                                              "u2_kmeans_update (label-bucketed segmented sums)",
                                    "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": ach / PEAK_HBM_TBPS,
@@ -637,7 +637,7 @@ def main():
         from u2seg_amd.cluster import kmeans as KM
         from u2seg_amd.layers import functional as Fn
 
-        KM.release_shadow()   # the k-means workloads' bf16 shadow of x (half of x)
+        KM.release_shadow()   # the k-means workloads' 16-bit shadow of x (half of x)
         gc.collect()
         torch.cuda.synchronize()
         torch.cuda.empty_cache()

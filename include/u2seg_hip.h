@@ -398,12 +398,13 @@ long long u2_kmeans_assign_workspace_floats(int N, int D, int K);
 int u2_kmeans_assign(const float* x, const float* c, float* workspace, long long* labels, int N, int D, int K, int exact_only,
                      void* stream);
 /* The same with a shadow of x: x does not change between the Lloyd iterations of a run (nn_utils.py:352 builds its x_i once,
- * outside the loop), so u2_kmeans_prepare writes mu = the column mean of x, the leading bf16 piece of x - mu (argmin_j |x - c_j|^2
- * does not change under a common translation, and the screening margin is proportional to the norms of what is multiplied), its norm,
- * the norm of its bf16 rounding residue and |x_p| once -
+ * outside the loop), so u2_kmeans_prepare writes mu = the column mean of x, fp16(S (x - mu)) with a power-of-two scale S (argmin_j
+ * |x - c_j|^2 does not change under a common translation, and the screening margin is proportional to the norms of what is
+ * multiplied; fp16 has the MFMA rate of bf16 and three more bits), the norm of x - mu, the norm of what the rounding dropped and |x_p|
+ * once -
  * u2_kmeans_shadow_floats(N, D) floats, 0 when D % 32 != 0 - and the first screening pass of every later E step streams 2 instead
- * of 4 bytes per element, with a margin per point from those two norms instead of their worst case.  The values are the ones that
- * pass rounds x to on the fly without a shadow: same products, same labels.  shadow = NULL: u2_kmeans_assign.  With a shadow the
+ * of 4 bytes per element, with a margin per point from those norms instead of a worst case.  Labels are the exact kernel's either way;
+ * shadow = NULL: u2_kmeans_assign (first pass on bf16(x), rounded on the fly).  With a shadow the
  * screening also serves 320 < K <= 1280 (one first pass per block of 320 centroids, then the exact kernel for the undecided points;
  * [... + 1] counts those, [... + 2] is not written); without one such K run the exact kernel alone.
  * The shadow must be re-made when x changes. */

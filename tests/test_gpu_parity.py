@@ -752,7 +752,7 @@ def test_kmeans_screened_assign_equals_exact():
 
 
 def test_kmeans_shadow_pass_equals_exact(monkeypatch):
-    """Round 6: the first screening pass over the bf16 shadow of x (u2_kmeans_prepare / u2_kmeans_assign_shadow, kmeans_coarse_kernel:
+    """Round 6: the first screening pass over the 16-bit shadow of x (u2_kmeans_prepare / u2_kmeans_assign_shadow, kmeans_coarse_kernel:
     persistent work-groups, index bits in the distances).  Labels must be the exact-fp32 kernel's for every point - more tiles than CUs
     with a ragged last one, near-duplicate and duplicate centroids, rows of tiny norm (the index bits' share of the margin), a zero row,
     NaN / Inf rows - and the shadow must follow x: reused for the same tensor, re-made after an in-place write and for another tensor."""

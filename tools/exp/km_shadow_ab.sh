@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the k-means coarse pass over the bf16 shadow of x (u2_kmeans_prepare + u2_kmeans_assign_shadow, default) vs reading the fp32 x
+# A/B of the k-means coarse pass over the 16-bit shadow of x (u2_kmeans_prepare + u2_kmeans_assign_shadow, default) vs reading the fp32 x
 # every iteration (U2_KM_SHADOW=0): correctness (the k-means GPU tests incl. config 4 at full size), then `bench.py --workload kmeans`
 # for both data kinds, A / B / A on one box.
 # usage (repo root, through gpurun): tools/exp/km_shadow_ab.sh <tag>

@@ -32,7 +32,7 @@ SHADOW_MIN_POINTS = 1 << 16                             # below this the E step 
 
 
 def _shadow(x):
-    """bf16 shadow of x for the first screening pass (u2_kmeans_prepare), made once per tensor: the entry is keyed by the tensor
+    """16-bit shadow of x for the first screening pass (u2_kmeans_prepare), made once per tensor: the entry is keyed by the tensor
     OBJECT (weak reference - a new tensor at a recycled address cannot match) and its version counter (any in-place write to the
     storage, through any view, invalidates it)."""
     n, d = x.shape

@@ -317,8 +317,9 @@ __device__ __forceinline__ int ks_swz(int row) { return (-(row >> 2)) & 3; }  //
 __device__ __forceinline__ float kc_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float kc_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-// ---- the leading-bf16 shadow of x (round 6) ---------------------------------------------------------------------------------
-// x does not change between Lloyd iterations, and the coarse pass only ever uses bf16(x): u2_kmeans_prepare writes that once, in the
+// ---- the 16-bit shadow of x (round 6) -----------------------------------------------------------------------------------------
+// x does not change between Lloyd iterations, and the coarse pass only ever uses a 16-bit rounding of it (bf16(x) at first, fp16 of the
+// translated and scaled x now - see km_shadow_kernel): u2_kmeans_prepare writes that once, in the
 // order the coarse pass consumes it, and every later E step streams 2 instead of 4 bytes per element (the values are the ones the
 // kernel packed on the fly before - same products, same labels).  Layout: [D / 32 steps][G groups of 16 points][64 lanes][8 bf16],
 // G = 16 * ceil(N / 256); the 16 bytes of lane (fg, fr) = fg * 16 + fr are point fr's positions fg * 8 .. + 7 of the step in
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void km_mu_kernel(const float* __restrict__ pa
   s /= (float)N;
   mu[d] = (s == s && fabsf(s) != INFINITY) ? s : 0.f;    // a NaN / Inf somewhere in the column: no translation of that column
 }
-// The shadow holds bf16(x - mu): argmin_j |x - c_j|^2 does not change when x and every c_j are translated by the same vector, and the
+// The shadow holds a rounding of x - mu: argmin_j |x - c_j|^2 does not change when x and every c_j are translated by the same vector, and the
 // first pass's margin is proportional to |x - mu| |c - mu| instead of |x| |c| - on L2-normalised features with a common direction
 // (F.normalize(DINO features): usl-imagenet.py:103; mean cosine between rows 0.3-0.8) that is what lets it decide anything at all.
 // Any mu is valid as long as x and c use the same one; mu = the column mean of x, fixed when the shadow is made.
@@ -825,11 +826,12 @@ __global__ __launch_bounds__(512) void kmeans_screen_kernel(const float* __restr
 
 
 // ---- coarse pass over the shadow (round 6) ----------------------------------------------------------------------------------------
-// hi.hi only, all points, x from the bf16 shadow (km_shadow_kernel) - the first pass of the two-level screening when a shadow is given.
+// One product per pair, all points, x from the fp16 shadow (km_shadow_kernel) - the first pass of the two-level screening when a shadow is given.
 // Same products and wave tile (32 points x 320 centroids) as kmeans_screen_kernel<1>; what differs (steps and their measurements:
 // profiles/r06_km_coarse.txt):
 //  * Persistent work-groups (one per CU, tiles blockIdx.x, + gridDim.x, ...): the request streams run on across the tile boundary.
-//  * A margin per point from the exact norms of x - bf16(x) and c - bf16(c) instead of their worst case (at the arg-min below).
+//  * fp16 operands (v_mfma_f32_16x16x32_f16: the rate of the bf16 instruction, three more significant bits) and a margin per point from
+//    the exact norms of what their rounding dropped instead of a worst case (at the arg-min below).
 //  * The LDS-DMA queues are split by wave: vmcnt retires in order, so a wave that requests both centroids and x cannot wait for "the
 //    centroids of the next step" without also waiting for every x it requested before them - two steps of slack whatever the ring
 //    depth.  Waves 0-3 request the centroid stages (five 1 KB instructions each, ring of three 20 KB stages), waves 4-7 the x slots
@@ -861,7 +863,7 @@ constexpr int KC_SLOT = KS_PTS * 64;           // 16 groups x 1 KB
 constexpr int KC_STAGE = KS_KMAX * 64;         // hi plane: 320 rows x 64 B
 constexpr int KC_RINGS = KS_RING * KC_STAGE + KC_SLOTS * KC_SLOT;
 constexpr int KC_LDS = KC_RINGS + KS_KMAX * 4; // + |c_j|^2
-// chl / cn / cs: the centred centroids of csplit_kernel (chc, cnc, {max |c - mu|^2, max |(c - mu) - bf16(c - mu)|^2}); cmax2: max |c|^2
+// chl / cn / cs: the centred centroids of csplit_kernel (chc, cnc, {max |c - mu|^2, max |(c - mu) - chc / S|^2}); cmax2: max |c|^2
 // of the centroids as they are (the exact kernel's frame); xnorm: km_xnorm_kernel's three arrays
 __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char* __restrict__ xh, const float* __restrict__ xnorm,
                                                             const bf16_t* __restrict__ chl, const float* __restrict__ cn,
@@ -1097,10 +1099,11 @@ __global__ __launch_bounds__(512) void kmeans_coarse_kernel(const unsigned char*
     } else if (fr < 8 && pmine < N) {
       labels[pmine] = (long long)(__float_as_uint(kb) & 511u);
       // Per-point margin, in the translated frame (x, c stand for x - mu, c - mu).  What this pass does not see of a product is
-      // x.c - x_hi.c_hi = x_lo.c + x_hi.c_lo, at most |x_lo| |c| + |x_hi| |c_lo| (Cauchy-Schwarz; x_lo = x - bf16(x) and its norm are
+      // x.c - x_hi.c_hi = x_lo.c + x_hi.c_lo, at most |x_lo| |c| + |x_hi| |c_lo| (Cauchy-Schwarz; x_lo = x - (its fp16 shadow) / S and its norm are
       // exact, from u2_kmeans_prepare; |x_hi| <= 1.004 |x|): twice that per distance, four times between two distances.  With the norms
-      // as they are instead of their worst case (2^-9 of |x|, |c| each: 2^-6 |x| max|c| in all, the 0.02 of kmeans_screen_kernel<1>) the
-      // margin is ~0.013 |x| max|c| on fp32 data and zero for operands that are bf16 values already.  + the mantissa bits the indices
+      // as they are instead of a worst case (bf16: 2^-9 of |x|, |c| each, 2^-6 |x| max|c| in all - the 0.02 of kmeans_screen_kernel<1>;
+      // measured 0.013 with bf16 operands) the margin is ~0.002 |x| max|c| on fp32 data with the fp16 operands, and zero for operands
+      // that are fp16 values already.  + the mantissa bits the indices
       // took (2^-14 of a distance at most, |distance| <= |c|^2 + 2 |x| |c|; twice that here).  + margin_rel |x| max|c| of the
       // UNTRANSLATED operands for everything else: the labels must be the exact kernel's, whose own fp32 rounding is proportional to
       // the norms it sees (the fine pass's margin, three times), and the roundings of x - mu, c - mu.
@@ -1361,7 +1364,7 @@ extern "C" long long u2_kmeans_assign_workspace_floats(int N, int D, int K) {
   // |c|^2 [K] | max |c|^2, exact-list length, coarse-list length [4] | split centroids [2][320][D] bf16 | exact re-check list [N]
   // | undecided list of the coarse pass [N] | screening state [4]
   // K > 320 (u2_kmeans_assign_shadow only): the split centroids of every block of 320, and the blocks' candidates [blocks][N]{best, second}
-  // behind all of that, for u2_kmeans_assign_shadow: {max |c - mu|^2, max residual^2} [4] | |c_j - mu|^2 [blocks][320] | bf16(c - mu) [blocks][320][D]
+  // behind all of that, for u2_kmeans_assign_shadow: {max |c - mu|^2, max residual^2} [4] | |c_j - mu|^2 [blocks][320] | fp16(S (c - mu)) [blocks][320][D]
   return km_ws_base_floats(N, D, K) + 8 + km_blocks(K) * KS_KMAX + km_blocks(K) * (KS_KMAX / 2) * (long long)D;
 }
 
@@ -1384,12 +1387,12 @@ static int km_cu_count() {
   return cus[dev];
 }
 
-// words (floats) of the bf16 shadow itself; |x_p| follows it
+// words (floats) of the 16-bit shadow itself; the norms, mu and the scale follow it
 static size_t km_shadow_words(int N, int D) { return (size_t)(D >> 5) * (size_t)((N + KS_PTS - 1) / KS_PTS) * 16 * 256; }
 
 extern "C" long long u2_kmeans_shadow_floats(int N, int D) {
   if (N <= 0 || D % 32 != 0) return 0;
-  // + |x_p - mu|, |(x_p - mu) - bf16(x_p - mu)|, |x_p| (each padded to whole tiles) + mu [D]
+  // + |x_p - mu|, |(x_p - mu) - shadow_p / S|, |x_p| (each padded to whole tiles) + mu [D]
   // + aux [64]: the scale S, 1 / S, max |x_p - mu|^2
   return (long long)(km_shadow_words(N, D) + 3 * (size_t)((N + KS_PTS - 1) / KS_PTS) * KS_PTS + (size_t)((D + 63) & ~63) + 64);
 }
