@@ -773,8 +773,12 @@ def test_kmeans_shadow_pass_equals_exact(monkeypatch):
     cu = xu[torch.randperm(30011, generator=g)[:299]].clone()
     cu[7] = cu[3]
     cu[100:140] = cu[50:90] + 1e-6
+    cfar = cm[:40].clone()
+    cfar[5] = 1e6                        # a centroid beyond the fp16 range of the scaled shadow: its candidates are not finite
     cases = [(xm, cm), (xu, cu), (torch.randn((1000, 64), generator=g) * 5, torch.randn((17, 64), generator=g) * 5),
-             (torch.randn((300, 32), generator=g) * 3, torch.randn((5, 32), generator=g) * 3)]   # one step per tile, two tiles
+             (torch.randn((300, 32), generator=g) * 3, torch.randn((5, 32), generator=g) * 3),   # one step per tile, two tiles
+             (xm[:9000, :256] * 1e-12, cm[:, :256] * 1e-12), (xm[:9000, :256] * 1e12, cm[:, :256] * 1e12),   # the power-of-two scale
+             (xm[:9000], cfar)]
     for i, (x, c) in enumerate(cases):
         xd, cd = x.to(DEV), c.to(DEV)
         KM._ws_cache.pop("assign:" + str(xd.device), None)   # the first pass starts switched on
