@@ -444,6 +444,10 @@ int main(int argc, char** argv) {
       if (u2_conv_last_kernel() != 2900) { printf("FAIL %-28s did not take the halo kernel (%d)\n", c.name, u2_conv_last_kernel()); ++f; }
       f += test_wgrad(c, 4096 | (1 << 14));
       f += test_wgrad(c, 4096, true);
+      // partial blocks + reduction pass instead of the atomic epilogue (bit 17), plain and into a strided gradient
+      f += test_wgrad(c, 4096 | (1 << 17));
+      f += test_wgrad(c, 4096 | (1 << 17), true);
+      f += test_wgrad(c, 4096 | (1 << 17) | (1 << 14), true);
     }
     return f;
   };

@@ -535,13 +535,14 @@ def test_fused_1x1_backward_full_shape_auto(F):
     assert rel_err(x.grad.reshape(-1, cin)[idx].float(), ref_dx) < ULP
 
 
-@pytest.mark.parametrize("variant", [4096, 4096 | (1 << 14)])
+@pytest.mark.parametrize("variant", [4096, 4096 | (1 << 14), 4096 | (1 << 17), 4096 | (1 << 17) | (1 << 14), 4096 | (1 << 16)])
 @pytest.mark.parametrize("shape", [(2, 64, 64, 14, 14), (1, 128, 136, 13, 17), (3, 96, 200, 25, 42), (2, 64, 256, 40, 70),
                                    (2, 32, 8, 3, 11), (1, 32, 72, 5, 101)])
 def test_wgrad_halo_kernel(F, variant, shape):
     """conv_wgrad_halo_kernel (3x3 / stride 1 / pad 1, all nine taps per work-group over padded pixel coordinates) forced on
     small maps - every row wrap count (W + 1 < 16, < 32, >= 32), partial channel tiles, one to many steps per work-group -
-    vs fp32; the automatic dispatch only takes it from ~4000 positions per work-group (the full-shape test below)."""
+    vs fp32, with the atomic epilogue (bit 16) and with partial blocks + wgrad_halo_reduce_kernel (bit 17); the automatic
+    dispatch takes it from ~400 positions per work-group (test_wgrad_halo_mid_size_shapes_auto_dispatch)."""
     b, cin, cout, h, w_ = shape
     g = torch.Generator().manual_seed(h * 100 + w_ + variant)
     x = bf(torch.randn((b, cin, h, w_), generator=g))
@@ -555,6 +556,40 @@ def test_wgrad_halo_kernel(F, variant, shape):
         y.backward(nhwc(gy))
         assert last_kernel() == 2900, last_kernel()
     assert rel_err(wd.grad.cpu(), w.grad) < WG_TOL
+
+
+@pytest.mark.parametrize("name,b,h,w,cin,cout", [
+    ("fpn_output4 / res4 conv2 3x3 256->256 @50x84", 16, 50, 84, 256, 256),
+    ("res3 conv2 3x3 128->128 @100x168", 16, 100, 168, 128, 128),
+    ("res5 conv2 3x3 512->512 @25x42", 16, 25, 42, 512, 512),
+    ("mask head 3x3 256->256 @260x14x14", 260, 14, 14, 256, 256),
+    ("fpn_output5 3x3 256->256 @25x42", 16, 25, 42, 256, 256),
+    ("res2 conv2 3x3 64->64 @200x336", 16, 200, 336, 64, 64),
+])
+def test_wgrad_halo_mid_size_shapes_auto_dispatch(F, name, b, h, w, cin, cout):
+    """Round 6: the mid-size 3x3 weight gradients of the benchmark step through the automatic dispatch - the nine-tap halo
+    kernel with the partial-block epilogue (wgrad_halo.hip: 256 work-groups x 288 KB of plain stores + one reduction pass
+    instead of as many atomics) - on a sampled 16 x 16 channel block of all nine taps vs fp32, twice into the same gradient
+    (the pass adds into dw, it does not overwrite it)."""
+    g = torch.Generator().manual_seed(len(name))
+    x = torch.randn((b, h, w, cin), generator=g).bfloat16().to(DEV)
+    wt = torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5
+    wd = wt.to(DEV).requires_grad_(True)
+    gy = torch.randn((b, h, w, cout), generator=g).bfloat16().to(DEV)
+    with forced():
+        for _ in range(2):
+            y, _ = F._Conv2dFn.apply(x, wd, None, 1, 1, False, False)
+            y.backward(gy)
+            assert last_kernel() == 2900, (name, last_kernel())
+    n0, c0 = cout - 16, cin // 2
+    xs = x[..., c0:c0 + 16].float().permute(0, 3, 1, 2)
+    gs = gy[..., n0:n0 + 16].float().permute(0, 3, 1, 2)
+    # dW[n][c][kh][kw] = sum_m gy[m][n] * x[m + (kh - 1, kw - 1)][c]
+    xp = TF.pad(xs, (1, 1, 1, 1))
+    ref = torch.stack([torch.stack([torch.einsum("bnhw,bchw->nc", gs, xp[:, :, kh:kh + h, kw:kw + w]) for kw in range(3)], -1)
+                       for kh in range(3)], -2)
+    got = wd.grad[n0:n0 + 16, c0:c0 + 16].float()
+    assert rel_err(got.cpu(), 2 * ref.cpu()) < WG_TOL, name
 
 
 def _sampled_conv_ref(x, w, bias, pos, pad):

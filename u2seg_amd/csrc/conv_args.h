@@ -69,7 +69,7 @@ int launch_conv_stream(ConvArgs& a, int N, int C, int variant, hipStream_t s);
 // return convention as launch_conv_tile.  g_last_conv_kernel code: 2900.
 int launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* dw, long long dw_sn, int dw_st, int dw_sc, int n_valid,
                       int c_valid, const bf16_t* zero, int B, int H, int W, int C, int x_ld, int N, int dy_ld, int rounds,
-                      int force, hipStream_t s);
+                      int force, int part_mode, hipStream_t s);
 
 // wgrad_stream.hip: 1x1 / stride 1 weight gradient over large maps - a persistent work-group per pixel range accumulates a whole
 // block of dW in registers, operands streamed once through an LDS ring of whole pixel rows; same return convention as

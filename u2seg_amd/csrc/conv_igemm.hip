@@ -1549,7 +1549,8 @@ extern "C" int u2_conv_wgrad_into(const void* x, const void* dy, float* dw, int 
   const bool halo_ok = KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Hin == Hout && Win == Wout;
   if (halo_ok && !(variant & 8192) && (variant & 0x7ff) == 0) {
     const int rc = launch_wgrad_halo(a.x, a.dy, dw, dw_stride_n, dw_stride_tap, dw_stride_c, n_valid, c_valid, a.zero, B, Hin, Win,
-                                     C, x_ld, N, dy_ld, ((variant >> 14) & 3) + 1, (variant & 4096) ? 1 : 0, (hipStream_t)stream);
+                                     C, x_ld, N, dy_ld, ((variant >> 14) & 3) + 1, (variant & 4096) ? 1 : 0,
+                                     (variant & 65536) ? 1 : ((variant & 131072) ? 2 : 0), (hipStream_t)stream);
     if (rc == 1) { g_last_conv_kernel = 2900; return 0; }
     if (rc < 0) return rc;
   }

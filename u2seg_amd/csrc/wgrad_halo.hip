@@ -34,7 +34,14 @@ struct WgradHaloArgs {
   int B, H, W, C, x_ld, N, dy_ld;
   int Mp;  // B * H * (W + 1) padded positions
   int tiles_c, tiles, pix_per_wg;
+  // Partial blocks instead of atomics (round 6): when `part` is set a work-group stores its 9 x 64 x 128 fp32 block, [tap][c][n]
+  // with n fastest, at part + (split * tiles + tile) * PART_BLOCK and wgrad_halo_reduce_kernel sums the splits into dw.  All 256
+  // work-groups of a launch reach their 288 KB epilogue at the same moment; as atomics that is 75 MB at the ~1 TB/s fp32
+  // atomics retire at (tests/native/atomics_bench) - as long as the whole reduction of a 50 x 84 map - as plain 16-byte stores
+  // plus one pass that reads them back it is 2 x 75 MB at 4-5 TB/s.
+  float* part;
 };
+constexpr int PART_BLOCK = 9 * 64 * 128;
 
 constexpr int HS = 32;                  // padded positions per step
 constexpr int YB = HS * 256;            // dY image [32 px][128 n], 8 KB
@@ -301,6 +308,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgradHaloArg
 
   // D[i = n][c]: a lane holds column c = fr, rows n = fg * 4 + r of each 16 x 16 block
   if (!wave_active) return;
+  if (a.part) {  // 16 B per lane: rows fg * 4 .. + 3 of column c are consecutive in the [tap][c][n] block
+    float* pt = a.part + ((size_t)split * a.tiles + tile) * PART_BLOCK + (wc * 16 + fr) * 128 + wr * 64 + fg * 4;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(pt + t * (64 * 128) + i * 16) = acc[t][i];
+    return;
+  }
   const int c = c0 + wc * 16 + fr;
   if (c >= a.c_valid) return;
 #pragma unroll
@@ -316,6 +331,50 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgradHaloArg
     }
 }
 
+// Sums the partial blocks of a launch over its pixel splits and adds the result into dw.  A work-group takes 8 columns c of one
+// (tile, tap) pair: 32 lanes x 16 B per column and split (coalesced), eight splits in flight per thread; the sums go through
+// LDS so that the dw accesses run along c (the contiguous direction of both gradient layouts).  blockIdx.z = a group of
+// `per_group` consecutive splits (launches with two tiles and 128 splits); several groups meet in dw through atomics.
+__global__ __launch_bounds__(256) void wgrad_halo_reduce_kernel(const float* __restrict__ part, int splits, int per_group,
+                                                                const WgradHaloArgs a) {
+  __shared__ float sm[8][128 + 1];
+  const int tlin = blockIdx.x, slab = blockIdx.y;   // tlin = tile * 9 + tap
+  const int tile = tlin / 9, tap = tlin - tile * 9;
+  const int tile_n = tile / a.tiles_c, tile_c = tile - tile_n * a.tiles_c;
+  const int tid = threadIdx.x;
+  const int nq = tid & 31, ci = tid >> 5;
+  {
+    const float* src = part + (size_t)tlin * (64 * 128) + (slab * 8 + ci) * 128 + nq * 4;
+    const size_t sstride = (size_t)a.tiles * PART_BLOCK;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    int sp = blockIdx.z * per_group;
+    const int sp_end = min(splits, sp + per_group);
+    for (; sp + 7 < sp_end; sp += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)(sp + k) * sstride));
+      s0 += (v[0] + v[2]) + (v[4] + v[6]);
+      s1 += (v[1] + v[3]) + (v[5] + v[7]);
+    }
+    for (; sp < sp_end; ++sp) s0 += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)sp * sstride));
+    s0 += s1;
+    float* row = sm[ci] + nq * 4;
+    row[0] = s0[0]; row[1] = s0[1]; row[2] = s0[2]; row[3] = s0[3];
+  }
+  __syncthreads();
+  const int c_rel = tid & 7;
+  const int c = tile_c * 64 + slab * 8 + c_rel;
+  if (c >= a.c_valid) return;
+  float* dst = a.dw + (size_t)tap * a.dw_st + (size_t)c * a.dw_sc;
+  for (int nl = tid >> 3; nl < 128; nl += 32) {
+    const int n = tile_n * 128 + nl;
+    if (n < a.n_valid) {
+      if (gridDim.z == 1) dst[n * a.dw_sn] += sm[c_rel][nl];
+      else atomicAdd(dst + n * a.dw_sn, sm[c_rel][nl]);
+    }
+  }
+}
+
 }  // namespace
 
 namespace u2conv {
@@ -323,7 +382,7 @@ namespace u2conv {
 // returns 1 when the launch was taken, 0 when the shape is not served, -1000 - hipError_t on a launch failure
 int launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* dw, long long dw_sn, int dw_st, int dw_sc, int n_valid,
                       int c_valid, const bf16_t* zero, int B, int H, int W, int C, int x_ld, int N, int dy_ld, int rounds,
-                      int force, hipStream_t s) {
+                      int force, int part_mode, hipStream_t s) {
   if (H < 2 || W < 11 || (C & 7) || (N & 7)) return 0;
   const long long Mp = (long long)B * H * (W + 1);
   if (Mp >= (1LL << 30)) return 0;
@@ -346,17 +405,43 @@ int launch_wgrad_halo(const bf16_t* x, const bf16_t* dy, float* dw, long long dw
   // Measured against the per-tap kernel (tests/native/selftest bench2w, profiles/r02_wgrad_halo.txt): +35..50 % on the
   // stride-4 maps, +17 % on 100x168 x 256 ch, +65 % on the 64-channel res2 layers; below ~4000 positions per work-group the
   // 288 KB atomic epilogue that all work-groups reach at the same moment outweighs the faster reduction (-6..-20 %).
-  if (!force && Mp / nsplit < 4000) return 0;
+  // Round 6: the partial-block epilogue (part_mode 0 = automatic, 1 = atomics only, 2 = partial blocks wherever there is
+  // something to reduce) costs ~2 x 15 us per launch where the atomics cost ~75, so the kernel now also takes the mid-size maps
+  // from the per-tap kernel (tests/native/selftest bench2w, profiles/r06_wgrad_halo_part.txt; per-tap -> atomics -> partials):
+  // 50 x 84 x 256 0.132 -> 0.142 -> 0.112 ms, 100 x 168 x 128 0.130 -> 0.153 -> 0.112, 25 x 42 x 512 0.135 -> 0.137 -> 0.114,
+  // the 14 x 14 mask-head maps 0.142 -> 0.145 -> 0.114, 25 x 42 x 256 0.060 -> 0.086 -> 0.054; and where it ran with atomics:
+  // 200 x 336 x 64 0.170 -> 0.145, 100 x 168 x 256 0.355 -> 0.335; equal on the 200 x 336 maps with >= 128 channels (33 000
+  // positions per work-group), which keep the atomics.
+  const long long per_wg = Mp / nsplit;
+  const bool use_part = part_mode == 2 ? nsplit >= 2 : (part_mode == 0 && per_wg < 16000 && nsplit >= 2);
+  if (!force && per_wg < (use_part ? 384 : 4000)) return 0;
   int ppw = (int)((Mp + nsplit - 1) / nsplit);
   ppw = (ppw + HS - 1) / HS * HS;
   a.pix_per_wg = ppw;
+  nsplit = (int)((Mp + ppw - 1) / ppw);   // the ranges that are not empty (a multiple of 8 is only needed for the XCD grouping)
+  const int nsplit_grid = (nsplit + 7) & ~7;
+  a.part = nullptr;
+  if (use_part) {
+    a.part = (float*)scratch_get(2, s, (size_t)nsplit * a.tiles * PART_BLOCK * sizeof(float), (size_t)96 << 20, false);
+    if (!a.part && !force && per_wg < 4000) return 0;   // no scratch: the per-tap kernel takes the small maps
+  }
   static PerDeviceOnce attr_set;
   if (auto once_guard = attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL(conv_wgrad_halo_kernel, dim3((unsigned)(nsplit * a.tiles)), dim3(512), RING * STAGE, s, a);
+  hipLaunchKernelGGL(conv_wgrad_halo_kernel, dim3((unsigned)(nsplit_grid * a.tiles)), dim3(512), RING * STAGE, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return -1000 - (int)e;
+  if (a.part) {
+    int groups = (512 + a.tiles * 72 - 1) / (a.tiles * 72);   // >= ~512 work-groups in the reduction pass
+    if (groups > nsplit / 4) groups = nsplit / 4 > 1 ? nsplit / 4 : 1;
+    const int per_group = (nsplit + groups - 1) / groups;
+    groups = (nsplit + per_group - 1) / per_group;
+    hipLaunchKernelGGL(wgrad_halo_reduce_kernel, dim3((unsigned)(a.tiles * 9), 8, (unsigned)groups), dim3(256), 0, s, a.part, nsplit,
+                       per_group, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return -1000 - (int)e;
+  }
   return 1;
 }
 
