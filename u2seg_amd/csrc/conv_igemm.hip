@@ -962,7 +962,15 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_kernel(const WgradArgs a) {
 // ------------------------------------------------------------------------------------------------
 constexpr int WG256_IMG = WP * 128 * 2;          // 8 KB: one [32 px][128 ch] image
 constexpr int WG256_STAGE = 4 * WG256_IMG;       // dy lo / dy hi / x lo / x hi
-constexpr int WG256_STAGES = 3;
+#ifndef U2_WG256_PIPE
+// 1: fragment reads half a step ahead of their MFMAs in a four-stage ring (round 6).  Built on the reading that the drained
+// wait behind a step's 24 transposing reads is what holds the kernel at ~2 100 cycles per 1 024-cycle step - and measured EQUAL
+// (tests/native/selftest bench2w, same box: fc1 0.340 -> 0.351 ms, res4 1x1 0.070 -> 0.071, 8192^3 890 TFLOP/s either way;
+// profiles/r06_wgrad_halo_part.txt), so the read latency is not what the step waits for; fc1's 600 TFLOP/s is this kernel's
+// 890 x the 196 tiles on 256 CUs.  Default 0: the round-2 loop (all reads, one wait, 32 MFMAs) in a three-stage ring.
+#define U2_WG256_PIPE 0
+#endif
+constexpr int WG256_STAGES = U2_WG256_PIPE ? 4 : 3;
 
 __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1087,6 +1095,85 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
     __builtin_amdgcn_s_setprio(0);
   };
 
+#if U2_WG256_PIPE
+  // Round 6: fragment reads one half step ahead of their MFMAs in a four-stage ring.  A step is two batches of 16 MFMAs per
+  // wave (dY fragments x the first / the second 64 channels of x); the second batch's x fragments are requested in front of
+  // the first batch, the NEXT step's dY and first-batch fragments in front of the second one - behind the step's barrier,
+  // which sits between the batches -, so every transposing read has 16 MFMAs (256 cycles of the matrix pipe) to come back and
+  // the pipe has work queued while the waves meet at the barrier.  All waits are counted (LDS returns in order; no scalar loads
+  // inside the loop - checked in the generated code).  Results identical to the default loop, time too (see U2_WG256_PIPE).
+  union Frag { unsigned long long u[2]; s16x8 v; };
+  Frag yA[4], yB[4], xl[4], xh[4];
+#define U2_W_RD(F, BASE, OFF, Q)                                                                                        \
+  do {                                                                                                                  \
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(F.u[0]) : "v"((BASE) + (unsigned)((OFF)[0] ^ ((Q) << 5))) : "memory"); \
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(F.u[1]) : "v"((BASE) + (unsigned)((OFF)[1] ^ ((Q) << 5))) : "memory"); \
+  } while (0)
+#define U2_W_TIE(F) "+v"(F[0].u[0]), "+v"(F[0].u[1]), "+v"(F[1].u[0]), "+v"(F[1].u[1]), "+v"(F[2].u[0]), "+v"(F[2].u[1]), "+v"(F[3].u[0]), "+v"(F[3].u[1])
+#define U2_W_STEP(YC, YN)                                                                                      \
+  do {                                                                                                         \
+    const unsigned sb = lds0 + (unsigned)(buf * WG256_STAGE);                                                  \
+    const unsigned sn = lds0 + (unsigned)(((buf + 1) & 3) * WG256_STAGE);                                      \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) U2_W_RD(xh[q], sb, xoff0[1], q);                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                            \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(YC[i].v, xl[j].v, acc[i][j], 0, 0, 0);             \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    if (st + 1 < nsteps) {                                                                                     \
+      /* stage st + 1 landed (stage st + 2 may be in flight); every wave has left stage st - 1 */              \
+      if (st + 2 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                    \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
+      __builtin_amdgcn_s_barrier();                                                                            \
+      asm volatile("" ::: "memory");                                                                           \
+      if (st + 3 < nsteps) issue((buf + 3) & 3);                                                               \
+    }                                                                                                          \
+    /* The next step's dY fragments, the wait for xh (lgkmcnt counts to 15: not all 16 requests in front of it), then the  \
+       next step's first x fragments.  The last step requests them too (stale ring contents, never multiplied): no        \
+       register written by a read in flight meets a compiler-made copy at a control-flow join, and the counts stay exact */ \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) U2_W_RD(YN[q], sn, yoff0, q);                                \
+    asm volatile("s_waitcnt lgkmcnt(8)" : U2_W_TIE(xh)::"memory");                                             \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) U2_W_RD(xl[q], sn, xoff0[0], q);                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                            \
+        acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(YC[i].v, xh[j].v, acc[i][4 + j], 0, 0, 0);     \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" : U2_W_TIE(YN), U2_W_TIE(xl)::"memory");                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  } while (0)
+  static_assert(WG256_STAGES == 4, "the ring indices of the pipelined loop are written for four stages");
+  (void)compute;
+  issue(0);
+  if (nsteps > 1) issue(1);
+  if (nsteps > 2) issue(2);
+  if (nsteps > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nsteps == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    U2_W_RD(yA[q], lds0, yoff0, q);
+    U2_W_RD(xl[q], lds0, xoff0[0], q);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : U2_W_TIE(yA), U2_W_TIE(xl)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    int buf = 0, st = 0;
+    for (;;) {
+      U2_W_STEP(yA, yB);
+      ++st; buf = (buf + 1) & 3;
+      if (st >= nsteps) break;
+      U2_W_STEP(yB, yA);
+      ++st; buf = (buf + 1) & 3;
+      if (st >= nsteps) break;
+    }
+  }
+#undef U2_W_STEP
+#undef U2_W_TIE
+#undef U2_W_RD
+#else
   // three-stage ring: steps st+1 and st+2 are in flight while step st is multiplied (4 LDS-DMA loads per thread per step)
   issue(0);
   if (nsteps > 1) issue(1);
@@ -1098,6 +1185,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
     if (st + 2 < nsteps) issue((st + 2) % WG256_STAGES);
     compute(st % WG256_STAGES);
   }
+
+#endif
 
   // D[i = n][j = c]: lane holds column c = fr, rows n = fg*4 + r
   if (a.part) {
