@@ -175,6 +175,21 @@ int u2_wgrad_permute_add(const float* scratch, float* grad, int N, int Cin, int 
  * meta_arch/semantic_seg.py:206-211 (bilinear x2), meta_arch/rcnn.py:223-234 (normalise + pad) feeding the stem. */
 int u2_maxpool3x3s2_fwd(const void* x, void* y, void* idx, int B, int H, int W, int C, void* stream);
 int u2_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, int B, int H, int W, int C, void* stream);
+/* Round 6: the stem's tail - norm -> relu_ -> max_pool2d (backbone/resnet.py:355-359, layers/batch_norm.py:169-197) - without the
+ * 550 MB activation between the normalisation and the pool.  Forward: y / idx of u2_maxpool3x3s2_fwd applied to
+ * u2_affine_act(x, scale, shift, relu = 1), bit for bit (the nine taps are normalised, rounded to bf16 and compared as the two
+ * launches do).  Backward: u2_norm_bwd_reduce / u2_norm_bwd_apply (mask recomputed from x * mask_scale + mask_shift > 0) on the
+ * gradient u2_maxpool3x3s2_bwd would have stored, which is rebuilt per input pixel from dy / idx instead:
+ * sums[0][c] += sum dz, sums[1][c] += sum dz * (x - mean) * invstd (fp32 [2][C], zeroed by the caller); dx = k1 dz + k2 x + k3 with
+ * the coefficients of u2_bn_finalize_bwd.  x: [B][H][W][C] bf16 conv output, y / idx / dy: [B][Ho][Wo][C]; C / 8 must divide 256. */
+int u2_affine_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, void* idx, int B, int H, int W,
+                               int C, void* stream);
+int u2_affine_relu_maxpool_bwd_reduce(const void* dy, const void* idx, const void* x, const float* mean, const float* invstd,
+                                      const float* mask_scale, const float* mask_shift, float* sums, int B, int H, int W, int C,
+                                      void* stream);
+int u2_affine_relu_maxpool_bwd_apply(const void* dy, const void* idx, const void* x, const float* k1, const float* k2,
+                                     const float* k3, const float* mask_scale, const float* mask_shift, void* dx, int B, int H, int W,
+                                     int C, void* stream);
 int u2_fpn_upsample_add_fwd(const void* lateral, const void* top, void* out, int B, int H, int W, int C, void* stream);
 int u2_fpn_upsample_add_bwd(const void* dout, void* dtop, int B, int H, int W, int C, void* stream);
 int u2_bilinear_up2_fwd(const void* x, const void* addend /*nullable, out = up2(x) + addend*/, void* out, int B, int H,

@@ -143,6 +143,56 @@ def test_batch_norm_residual_relu(F):
     assert rel_err(gd.grad.cpu(), gamma.grad) < 1e-4 and rel_err(bd.grad.cpu(), beta.grad) < 1e-4
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 23, 31), (1, 64, 40, 66), (3, 32, 7, 9), (2, 128, 12, 10)])
+def test_stem_tail_norm_relu_maxpool_one_pass(F, shape):
+    """Round 6: norm -> relu_ -> max_pool2d(3, 2, 1) of the stem (backbone/resnet.py:355-359) as one pass each way
+    (`batch_norm_relu_max_pool`): pooled values bit-identical to `max_pool_3x3_s2(batch_norm_act(..., relu=True))`, the input
+    gradient identical to that path's up to the summation order of the two column sums, and both against the reference formula
+    (train-mode batch_norm under autocast rounding: the norm output is a bf16 tensor).  Odd and even map sizes (windows cut by
+    the border on every side), negative gammas (the affine map is decreasing there: the pool cannot be commuted with it)."""
+    b, c, h, w = shape
+    g = torch.Generator().manual_seed(h * 10 + w)
+    x = bf(torch.randn((b, c, h, w), generator=g) * 2 + 0.3)
+    gamma = (1 + 0.2 * torch.randn(c, generator=g))
+    gamma[::5] *= -1
+    gamma = gamma.requires_grad_(True)
+    beta = (0.1 * torch.randn(c, generator=g)).requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    xr = x.clone().requires_grad_(True)
+    yr = TF.max_pool2d(bf(TF.relu(bf(TF.batch_norm(xr, rm, rv, gamma, beta, True, 0.1, 1e-5)))), 3, 2, 1)
+    gy = bf(torch.randn(yr.shape, generator=g))
+    yr.backward(gy)
+
+    def run(fused):
+        xd = nhwc(x).requires_grad_(True)
+        gd, bd = gamma.detach().to(DEV).requires_grad_(True), beta.detach().to(DEV).requires_grad_(True)
+        rmd, rvd = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        xf = nchw(xd)
+        stats = torch.stack([xf.sum((0, 2, 3)), (xf * xf).sum((0, 2, 3))]).to(DEV)
+        if fused:
+            y = F.batch_norm_relu_max_pool(xd, stats, gd, bd, rmd, rvd, 0.1, 1e-5)
+        else:
+            y = F.max_pool_3x3_s2(F.batch_norm_act(xd, stats, gd, bd, rmd, rvd, None, True, 0.1, 1e-5))
+        y.backward(nhwc(gy))
+        return y.detach(), xd.grad, gd.grad, bd.grad, rmd, rvd
+
+    yf, dxf, dgf, dbf, rmf, rvf = run(True)
+    yu, dxu, dgu, dbu, rmu, rvu = run(False)
+    assert torch.equal(yf, yu)                                  # pooled activations: bit for bit
+    assert torch.equal(rmf, rmu) and torch.equal(rvf, rvu)       # running statistics
+    assert rel_err(dxf.float(), dxu.float()) < 4e-3              # one bf16 step: the column sums are summed in another order
+    assert rel_err(dgf, dgu) < 1e-5 and rel_err(dbf, dbu) < 1e-5
+    assert rel_err(nchw(yf), yr.detach()) < 4e-3
+    assert rel_err(nchw(dxf), xr.grad) < 5e-3
+    assert rel_err(dgf.cpu(), gamma.grad) < 1e-4 and rel_err(dbf.cpu(), beta.grad) < 1e-4
+    # inference form: the same pooled map from scale / shift
+    with torch.no_grad():
+        xd = nhwc(x)
+        sc = (1 + 0.1 * torch.randn(c, generator=g)).to(DEV)
+        sh = (0.1 * torch.randn(c, generator=g)).to(DEV)
+        assert torch.equal(F.affine_relu_max_pool(xd, sc, sh), F.max_pool_3x3_s2(F.affine_act(xd, sc, sh, None, True)))
+
+
 def test_group_norm_relu(F):
     g = torch.Generator().manual_seed(6)
     x = bf(torch.randn((2, 128, 9, 14), generator=g) * 1.5)

@@ -102,6 +102,212 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16_t* __restri
   }
 }
 
+// ---- Round 6: the stem's tail as one pass each way (backbone/resnet.py:355-359: conv1 -> norm -> relu_ -> max_pool2d) ----
+// The ReLU output of the stem's normalisation (550 MB at batch 16 x 800 x 1344) has one reader, the max pool, and its gradient
+// one writer, the pool's backward pass.  Forward: the pool evaluates relu(bf16(x * scale + shift)) on the nine taps itself
+// (affine_act_fast_kernel's expression and rounding, then maxpool_fwd_kernel's comparison on the ROUNDED values: pooled values and
+// winner slots are bit-identical to the two launches) - 1.1 GB less.  Backward: the column reduction and the apply pass of the
+// normalisation rebuild the pool's gradient of an input pixel from the <= 4 windows that contain it (maxpool_bwd_kernel's sum,
+// rounded to bf16 as the stored map was) instead of reading it: the 550 MB map is neither written nor read twice.
+__device__ __forceinline__ void mp_load_coef(const float* __restrict__ a, int c, float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = a[c + e];
+}
+// two floats -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32: one instruction where f2bf is seven; these passes
+// are VALU-bound - the first form of the forward pass spent 1 200 instructions per 16-byte item and ran at 1.8 TB/s)
+typedef __attribute__((ext_vector_type(2))) __bf16 mp_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float mp_f32x2;
+__device__ __forceinline__ uint32_t mp_pack(float lo, float hi) {
+  const mp_f32x2 v = {lo, hi};
+  const mp_bf16x2 r = __builtin_convertvector(v, mp_bf16x2);
+  return *reinterpret_cast<const uint32_t*>(&r);
+}
+
+// Forward.  The activation of a tap is >= 0 (ReLU), so its bf16 pattern orders like an unsigned integer: the running maximum and
+// its slot are ONE v_max_u32 on key = pattern << 4 | (8 - slot) - among equal values the lowest slot wins, max_pool2d's rule and
+// maxpool_fwd_kernel's.  (A -0 the ReLU may leave compares as +0 and is stored as +0; NaN patterns sort above infinity.)
+__global__ __launch_bounds__(256) void affine_relu_maxpool_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift, bf16_t* __restrict__ y,
+                                                                      uint8_t* __restrict__ idx, int B, int H, int W, int C, int Ho,
+                                                                      int Wo) {
+  const int cpr = C >> 3;   // host: cpr divides 256, so a thread keeps its channel chunk for its whole life
+  const int cc = threadIdx.x % cpr;
+  float sc[8], sh[8];
+  mp_load_coef(scale, cc * 8, sc);
+  mp_load_coef(shift, cc * 8, sh);
+  for (int row_ = blockIdx.y; row_ < B * Ho; row_ += gridDim.y)
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < Wo * cpr; t += gridDim.x * 256) {
+    const int b = row_ / Ho, oy = row_ - b * Ho;
+    const int ox = t / cpr;
+    uint4 q[9];
+    bool ok[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+        ok[ky * 3 + kx] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        if (ok[ky * 3 + kx])
+          q[ky * 3 + kx] = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * C + cc * 8);
+      }
+    uint32_t key[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) key[e] = 0u;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      if (!ok[k]) continue;
+      const uint32_t* v = reinterpret_cast<const uint32_t*>(&q[k]);
+      const uint32_t code = (uint32_t)(8 - k);
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const float f0 = fmaxf(__uint_as_float(v[e2] << 16) * sc[2 * e2] + sh[2 * e2], 0.f);
+        const float f1 = fmaxf(__uint_as_float(v[e2] & 0xffff0000u) * sc[2 * e2 + 1] + sh[2 * e2 + 1], 0.f);
+        const uint32_t pk = mp_pack(f0, f1) & 0x7fff7fffu;   // the activation as affine_act stores it
+        key[2 * e2] = max(key[2 * e2], ((pk << 4) & 0xffff0u) | code);
+        key[2 * e2 + 1] = max(key[2 * e2 + 1], ((pk >> 12) & 0xffff0u) | code);
+      }
+    }
+    uint32_t o[4], bi[2] = {0u, 0u};
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) o[e2] = (key[2 * e2] >> 4) | ((key[2 * e2 + 1] >> 4) << 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bi[e >> 2] |= (8u - (key[e] & 15u)) << (8 * (e & 3));
+    const size_t off = (((size_t)b * Ho + oy) * Wo + ox) * C + cc * 8;
+    *reinterpret_cast<uint4*>(y + off) = *reinterpret_cast<const uint4*>(o);
+    *reinterpret_cast<uint2*>(idx + off) = *reinterpret_cast<const uint2*>(bi);
+  }
+}
+
+// Backward.  A thread takes a 2 x 2 block of input pixels {2a, 2a + 1} x {2c, 2c + 1} and one 8-channel chunk: the block lies in the
+// four windows (a .. a + 1) x (c .. c + 1), loaded once, and its pixels sit at FIXED slots of them - (2a, 2c): window (a, c) slot 4;
+// (2a, 2c + 1): (a, c) 5, (a, c + 1) 3; (2a + 1, 2c): (a, c) 7, (a + 1, c) 1; (2a + 1, 2c + 1): (a, c) 8, (a, c + 1) 6, (a + 1, c) 2,
+// (a + 1, c + 1) 0 - nine compare-and-add steps for four pixels, no divergence (the per-pixel form walked up to four windows per
+// pixel with the lanes of a wave on both parities).  A pixel's gradient is the fp32 sum over its windows in maxpool_bwd_kernel's
+// order, rounded to bf16 as the stored map was.
+// APPLY = false: sums[0][c] += sum dz, sums[1][c] += sum dz * (x - mean) * invstd  (colreduce_kernel<1, 2, false>'s quantities);
+// APPLY = true:  dx = k1 dz + k2 x + k3  (norm_bwd_apply_fast_kernel<2>'s expression);  dz = pool gradient where x * msc + msh > 0
+template <bool APPLY>
+__global__ __launch_bounds__(256) void affine_relu_maxpool_bwd_kernel(const bf16_t* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                                      const bf16_t* __restrict__ x, const float* __restrict__ p1,
+                                                                      const float* __restrict__ p2, const float* __restrict__ p3,
+                                                                      const float* __restrict__ msc, const float* __restrict__ msh,
+                                                                      float* __restrict__ sums, bf16_t* __restrict__ dx, int B, int H,
+                                                                      int W, int C, int Ho, int Wo) {
+  __shared__ float part[2][2048];
+  const int cpr = C >> 3;
+  const int cc = threadIdx.x % cpr;
+  const int Hb = (H + 1) >> 1, Wb = (W + 1) >> 1;
+  float a1[8], a2[8], a3[8], ms[8], mh[8], s0[8], s1[8];
+  mp_load_coef(p1, cc * 8, a1);   // APPLY: k1, k2, k3;  reduce: mean, invstd
+  mp_load_coef(p2, cc * 8, a2);
+  if (APPLY) mp_load_coef(p3, cc * 8, a3);
+  mp_load_coef(msc, cc * 8, ms);
+  mp_load_coef(msh, cc * 8, mh);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+  for (int rp = blockIdx.y; rp < B * Hb; rp += gridDim.y)
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < Wb * cpr; t += gridDim.x * 256) {
+    const int b = rp / Hb, a = rp - b * Hb;
+    const int c = t / cpr;
+    // the four windows: 0 = (a, c), 1 = (a, c + 1), 2 = (a + 1, c), 3 = (a + 1, c + 1)
+    uint2 iq[4];
+    uint4 dq[4], xq[4];
+    bool wv[4], pv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int oy = a + (k >> 1), ox = c + (k & 1);
+      wv[k] = oy < Ho && ox < Wo;
+      iq[k] = uint2{0xffffffffu, 0xffffffffu};   // slot 255: matches nothing
+      dq[k] = uint4{0u, 0u, 0u, 0u};
+      if (wv[k]) {
+        const size_t off = (((size_t)b * Ho + oy) * Wo + ox) * C + cc * 8;
+        iq[k] = *reinterpret_cast<const uint2*>(idx + off);
+        dq[k] = *reinterpret_cast<const uint4*>(dy + off);
+      }
+      const int iy = 2 * a + (k >> 1), ix = 2 * c + (k & 1);
+      pv[k] = iy < H && ix < W;
+      if (pv[k]) {
+        const mp_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const mp_u32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + cc * 8));
+        xq[k] = uint4{v.x, v.y, v.z, v.w};
+      }
+    }
+    float dv[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t* d = reinterpret_cast<const uint32_t*>(&dq[k]);
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        dv[k][2 * e2] = __uint_as_float(d[e2] << 16);
+        dv[k][2 * e2 + 1] = __uint_as_float(d[e2] & 0xffff0000u);
+      }
+    }
+    // (window, slot) pairs of pixel p, in maxpool_bwd_kernel's order
+    constexpr int NPAIR[4] = {1, 2, 2, 4};
+    constexpr int PW[4][4] = {{0, 0, 0, 0}, {0, 1, 0, 0}, {0, 2, 0, 0}, {0, 1, 2, 3}};
+    constexpr int PS[4][4] = {{4, 0, 0, 0}, {5, 3, 0, 0}, {7, 1, 0, 0}, {8, 6, 2, 0}};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (!pv[p]) continue;
+      float g[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j >= NPAIR[p]) continue;
+        const int k = PW[p][j];
+        const uint32_t pat = (uint32_t)PS[p][j] * 0x01010101u;
+        const uint32_t m0 = iq[k].x ^ pat, m1 = iq[k].y ^ pat;   // a zero byte = this pixel is the window's winner
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t byte = ((e < 4 ? m0 : m1) >> (8 * (e & 3))) & 0xffu;
+          g[e] += byte == 0u ? dv[k][e] : 0.f;
+        }
+      }
+      const uint32_t* xv = reinterpret_cast<const uint32_t*>(&xq[p]);
+      uint32_t o[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const uint32_t gp = mp_pack(g[2 * e2], g[2 * e2 + 1]);   // the gradient map as maxpool_bwd_kernel stores it
+        float dz[2] = {__uint_as_float(gp << 16), __uint_as_float(gp & 0xffff0000u)};
+        const float xf[2] = {__uint_as_float(xv[e2] << 16), __uint_as_float(xv[e2] & 0xffff0000u)};
+        float r[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = 2 * e2 + h;
+          if (!(xf[h] * ms[e] + mh[e] > 0.f)) dz[h] = 0.f;
+          if (APPLY) {
+            r[h] = a1[e] * dz[h] + a2[e] * xf[h] + a3[e];
+          } else {
+            s0[e] += dz[h];
+            s1[e] += dz[h] * (xf[h] - a1[e]) * a2[e];
+          }
+        }
+        if (APPLY) o[e2] = mp_pack(r[0], r[1]);
+      }
+      if (APPLY) {
+        const int iy = 2 * a + (p >> 1), ix = 2 * c + (p & 1);
+        __builtin_nontemporal_store(mp_u32x4{o[0], o[1], o[2], o[3]},
+                                    reinterpret_cast<mp_u32x4*>(dx + (((size_t)b * H + iy) * W + ix) * C + cc * 8));
+      }
+    }
+  }
+  if (!APPLY) {
+    const int rl = threadIdx.x / cpr, rows_par = 256 / cpr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      part[0][rl * cpr * 8 + cc * 8 + e] = s0[e];
+      part[1][rl * cpr * 8 + cc * 8 + e] = s1[e];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < cpr * 8; j += 256) {
+      float t0 = 0.f, t1 = 0.f;
+      for (int q = 0; q < rows_par; ++q) { t0 += part[0][q * cpr * 8 + j]; t1 += part[1][q * cpr * 8 + j]; }
+      atomicAdd(sums + j, t0);
+      atomicAdd(sums + C + j, t1);
+    }
+  }
+}
+
 // ---- FPN top-down: out = lateral + nearest_x2(top) ----
 __global__ __launch_bounds__(256) void upadd_fwd_kernel(const bf16_t* __restrict__ lat, const bf16_t* __restrict__ top,
                                                         bf16_t* __restrict__ out, int B, int H, int W, int C) {
@@ -319,6 +525,56 @@ extern "C" int u2_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, in
   else
     hipLaunchKernelGGL(maxpool_bwd_kernel<false>, dim3((W * (C >> 3) + 255) / 256, rows_grid(B * H)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)dy, (const uint8_t*)idx, (bf16_t*)dx, B, H, W, C, Ho, Wo);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+static bool stem_tail_ok(int C) { const int cpr = C >> 3; return (C & 7) == 0 && cpr >= 1 && cpr <= 256 && 256 % cpr == 0; }
+
+extern "C" int u2_affine_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, void* idx, int B, int H,
+                                          int W, int C, void* stream) {
+  if (!stem_tail_ok(C)) return -1;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  if (!((size_t)B * Ho * Wo)) return 0;
+  hipLaunchKernelGGL(affine_relu_maxpool_fwd_kernel, dim3((Wo * (C >> 3) + 255) / 256, rows_grid(B * Ho)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)x, scale, shift, (bf16_t*)y, (uint8_t*)idx, B, H, W, C, Ho, Wo);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+// rows of the grid: the reduction keeps its sums per thread and flushes once per work-group (2 C atomics), so its work-groups walk
+// many rows; the apply pass takes the same shape
+static dim3 stem_tail_bwd_grid(int B, int H, int W, int C) {
+  const int Hb = (H + 1) / 2, Wb = (W + 1) / 2;   // a thread takes a 2 x 2 block of input pixels
+  const int gx = (Wb * (C >> 3) + 255) / 256;
+  int gy = 4096 / gx;
+  if (gy < 1) gy = 1;
+  if (gy > B * Hb) gy = B * Hb;
+  return dim3(gx, gy);
+}
+
+extern "C" int u2_affine_relu_maxpool_bwd_reduce(const void* dy, const void* idx, const void* x, const float* mean,
+                                                 const float* invstd, const float* mask_scale, const float* mask_shift, float* sums,
+                                                 int B, int H, int W, int C, void* stream) {
+  if (!stem_tail_ok(C)) return -1;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  if (!((size_t)B * H * W)) return 0;
+  hipLaunchKernelGGL(affine_relu_maxpool_bwd_kernel<false>, stem_tail_bwd_grid(B, H, W, C), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, (const uint8_t*)idx, (const bf16_t*)x, mean, invstd, (const float*)nullptr, mask_scale,
+                     mask_shift, sums, (bf16_t*)nullptr, B, H, W, C, Ho, Wo);
+  U2_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int u2_affine_relu_maxpool_bwd_apply(const void* dy, const void* idx, const void* x, const float* k1, const float* k2,
+                                                const float* k3, const float* mask_scale, const float* mask_shift, void* dx, int B,
+                                                int H, int W, int C, void* stream) {
+  if (!stem_tail_ok(C)) return -1;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  if (!((size_t)B * H * W)) return 0;
+  hipLaunchKernelGGL(affine_relu_maxpool_bwd_kernel<true>, stem_tail_bwd_grid(B, H, W, C), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, (const uint8_t*)idx, (const bf16_t*)x, k1, k2, k3, mask_scale, mask_shift, (float*)nullptr,
+                     (bf16_t*)dx, B, H, W, C, Ho, Wo);
   U2_CHECK_LAUNCH();
   return 0;
 }

@@ -804,6 +804,87 @@ def max_pool_3x3_s2(x):
     return _MaxPoolFn.apply(x)
 
 
+STEM_TAIL_FUSE = os.environ.get("U2_STEM_TAIL_FUSE", "1") != "0"
+
+
+class _BatchNormReluMaxPoolFn(Function):
+    """The stem's tail, norm -> relu_ -> max_pool2d(3, 2, 1) (backbone/resnet.py:355-359), without the activation between the
+    normalisation and the pool (round 6): the pool normalises its nine taps itself, and the normalisation's backward passes
+    rebuild the pool's gradient per input pixel from (dy, idx).  Pooled values and winner slots are those of
+    `max_pool_3x3_s2(batch_norm_act(y, ..., relu=True))`, bit for bit; the statistics steps (all-reduce of [sum | sumsq | count]
+    forward, of [sum dz | sum dz xhat] backward) are `_BatchNormActFn`'s."""
+
+    @staticmethod
+    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, momentum, eps, grad_dst, sync):
+        _check_act(y)
+        b, h, w, c = y.shape
+        m = b * h * w
+        world = _world() if sync else 1
+        count, count_dev = float(m), None
+        if world > 1:
+            packed = getattr(stats, "_u2_packed", None)
+            if packed is None or packed.numel() != 2 * c + 1:
+                packed = torch.cat([stats.reshape(-1).float(), stats.new_zeros(1, dtype=torch.float32)])
+            packed[2 * c :].fill_(float(m))
+            dist.all_reduce(packed)
+            stats, count_dev = packed[: 2 * c].view(2, c), packed[2 * c :]
+        coef = torch.empty((4, c), dtype=torch.float32, device=y.device)
+        mean, invstd, scale, shift = coef[0], coef[1], coef[2], coef[3]
+        _hip.call("u2_bn_finalize_fwd", stats, count, count_dev, gamma, beta, running_mean, running_var, momentum, eps, mean,
+                  invstd, scale, shift, c)
+        ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        out = torch.empty((b, ho, wo, c), dtype=BF16, device=y.device)
+        idx = torch.empty((b, ho, wo, c), dtype=torch.uint8, device=y.device)
+        _hip.call("u2_affine_relu_maxpool_fwd", y, scale, shift, out, idx, b, h, w, c)
+        ctx.save_for_backward(y, idx, gamma, mean, invstd, scale, shift)
+        ctx.cfg = (count, world)
+        ctx.count_dev = count_dev
+        ctx.grad_dst = grad_dst
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, idx, gamma, mean, invstd, msc, msh = ctx.saved_tensors
+        count, world = ctx.cfg
+        b, h, w, c = y.shape
+        dy = dy.contiguous()
+        sums = zeros_f32((2, c), y.device)
+        _hip.call("u2_affine_relu_maxpool_bwd_reduce", dy, idx, y, mean, invstd, msc, msh, sums, b, h, w, c)
+        local = sums
+        if world > 1:
+            local = sums.clone()
+            dist.all_reduce(sums)
+        coef = torch.empty((5, c), dtype=torch.float32, device=y.device)
+        direct = ctx.grad_dst is not None
+        dgamma, dbeta = ctx.grad_dst if direct else (coef[0], coef[1])
+        _hip.call("u2_bn_finalize_bwd", sums, count, ctx.count_dev, gamma, mean, invstd, local, dgamma, dbeta, coef[2], coef[3],
+                  coef[4], c, int(direct))
+        dx = torch.empty_like(y)
+        _hip.call("u2_affine_relu_maxpool_bwd_apply", dy, idx, y, coef[2], coef[3], coef[4], msc, msh, dx, b, h, w, c)
+        return dx, None, (None if direct else dgamma), (None if direct else dbeta), None, None, None, None, None, None
+
+
+def stem_tail_ok(c):
+    """Channel counts the one-pass stem tail serves (a thread keeps one 8-channel chunk: C / 8 must divide 256)."""
+    return STEM_TAIL_FUSE and c % 8 == 0 and 1 <= c // 8 <= 256 and 256 % (c // 8) == 0
+
+
+def batch_norm_relu_max_pool(y, stats, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, sync=True):
+    gd, bd = grad_slot(gamma), grad_slot(beta)
+    grad_dst = (gd, bd) if gd is not None and bd is not None else None
+    return _BatchNormReluMaxPoolFn.apply(y, stats, gamma, beta, running_mean, running_var, momentum, eps, grad_dst, sync)
+
+
+def affine_relu_max_pool(y, scale, shift):
+    """Inference: max_pool_3x3_s2(affine_act(y, scale, shift, relu=True)) in one pass; no autograd."""
+    b, h, w, c = y.shape
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    out = torch.empty((b, ho, wo, c), dtype=BF16, device=y.device)
+    idx = torch.empty((b, ho, wo, c), dtype=torch.uint8, device=y.device)
+    _hip.call("u2_affine_relu_maxpool_fwd", y, scale.contiguous(), shift.contiguous(), out, idx, b, h, w, c)
+    return out
+
+
 class _UpsampleAddFn(Function):
     @staticmethod
     def forward(ctx, lateral, top):

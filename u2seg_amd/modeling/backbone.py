@@ -47,12 +47,18 @@ class BasicStem(nn.Module):
     def forward(self, images, pixel_mean, pixel_std, padded_hw):
         conv, norm = self.conv1, self.conv1.norm
         y, stats = F.stem_conv(conv.weight, images, pixel_mean, pixel_std, padded_hw[0], padded_hw[1])
+        fuse = F.stem_tail_ok(y.shape[-1])   # norm -> relu -> pool as one pass each way (round 6)
         if self.training and hasattr(norm, "momentum"):
             norm.count_batch()
+            if fuse:
+                return F.batch_norm_relu_max_pool(y, stats, norm.weight, norm.bias, norm.running_mean, norm.running_var,
+                                                  norm.momentum, norm.eps, sync=norm.sync)
             x = F.batch_norm_act(y, stats, norm.weight, norm.bias, norm.running_mean, norm.running_var, None, True,
                                  norm.momentum, norm.eps, sync=norm.sync)
         else:
             scale, shift = norm.eval_scale_shift()
+            if fuse and not (torch.is_grad_enabled() and y.requires_grad):
+                return F.affine_relu_max_pool(y, scale.float(), shift.float())
             x = F.affine_act(y, scale.float(), shift.float(), None, True)
         return F.max_pool_3x3_s2(x)
 
