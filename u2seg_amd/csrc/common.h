@@ -45,13 +45,23 @@ struct PerDeviceOnce {
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, NaN preserving (same rule as torch's float->bfloat16)
+// round-to-nearest-even (the rule of torch's float -> bfloat16).  Round 6: the hardware conversion (v_cvt_pk_bf16_f32, one
+// instruction; adjacent conversions pair up) instead of the seven-instruction integer form - the element-wise passes spend
+// 20-26 VALU instructions per element, two thirds of them in two roundings, and at 16 bytes per lane that is as long as their
+// memory time.  Same result for every finite input and infinity; a NaN stays a NaN (quiet, payload not preserved).
+#ifndef U2_SOFT_F2BF
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  const __bf16 h = (__bf16)f;
+  return *reinterpret_cast<const bf16_t*>(&h);
+}
+#else
 __device__ __forceinline__ bf16_t f2bf(float f) {
   uint32_t u = __float_as_uint(f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+#endif
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
