@@ -248,6 +248,31 @@ def test_pool_and_resample(F):
     assert rel_err(nchw(ad.grad), ar.grad) < 5e-3 and torch.equal(nchw(addd.grad), gy)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 7, 9), (1, 128, 25, 42), (3, 64, 1, 5), (2, 128, 12, 1)])
+@pytest.mark.parametrize("with_addend", [False, True])
+def test_bilinear_up2_blocked_equals_per_pixel(F, shape, with_addend):
+    """Round 6: nn.Upsample(scale 2, bilinear) of the semantic head (meta_arch/semantic_seg.py:206-211) by 2 x 2 output blocks
+    (four taps per four outputs) equals the per-pixel kernel bit for bit - odd sizes, one-row / one-column maps (both taps
+    clamped onto the same source row), with and without the running sum - and the reference formula to one bf16 step."""
+    import os
+    b, c, h, w = shape
+    g = torch.Generator().manual_seed(h * 50 + w)
+    a = bf(torch.randn((b, c, h, w), generator=g))
+    add = bf(torch.randn((b, c, 2 * h, 2 * w), generator=g)) if with_addend else None
+    ad, addd = nhwc(a), (nhwc(add) if with_addend else None)
+    with torch.no_grad():
+        y_block = F.bilinear_up2(ad, addd)
+        os.environ["U2_BILINEAR_PER_PIXEL"] = "1"
+        try:
+            y_pixel = F.bilinear_up2(ad, addd)
+        finally:
+            del os.environ["U2_BILINEAR_PER_PIXEL"]
+    assert torch.equal(y_block, y_pixel)
+    yr = TF.interpolate(a, scale_factor=2.0, mode="bilinear", align_corners=False)
+    yr = bf(bf(yr) + add) if with_addend else bf(yr)
+    assert rel_err(nchw(y_block), yr) < 5e-3
+
+
 def test_sem_seg_loss(F):
     """bilinear x4 + CE(mean, ignore 255): loss 1e-4 relative; logit gradient 1e-2 of its range (bf16 output)."""
     g = torch.Generator().manual_seed(9)

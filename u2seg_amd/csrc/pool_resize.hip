@@ -400,6 +400,73 @@ __global__ __launch_bounds__(256) void bilinear2_fwd_kernel(const bf16_t* __rest
   }
 }
 
+// Round 6: the same pass by blocks of 2 x 2 output pixels.  Output rows 2k + 1 and 2k + 2 (k = -1 .. H - 1) read the SAME two source
+// rows (k, k + 1, clamped: bil2_src of either row returns them) with weights 0.25 / 0.75, and so do the columns: a thread loads
+// four taps for up to four outputs (the per-pixel kernel: four taps per output, 16-byte loads at 17 TB/s out of L1 / L2 for a pass
+// that moves 1 GB), and the horizontal step hx * v00 + lx * v01 is shared by the two rows.  Every output is formed by the per-pixel
+// kernel's expression with bil2_src's own weights: bit-identical (tests: the semantic-head chain against the oracle, and
+// test_bilinear_up2_blocked_equals_per_pixel against the kernel above, which stays as the reference form).
+__global__ __launch_bounds__(256) void bilinear2_fwd_block_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ addend,
+                                                                  bf16_t* __restrict__ out, int B, int H, int W, int C) {
+  const int cpr = C >> 3;
+  const int Ho = H * 2, Wo = W * 2;
+  for (int row_ = blockIdx.y; row_ < B * (H + 1); row_ += gridDim.y)
+  for (int t_ = blockIdx.x * 256 + threadIdx.x; t_ < (W + 1) * cpr; t_ += gridDim.x * 256) {
+    const int b = row_ / (H + 1), k = row_ - b * (H + 1) - 1;
+    const int jj = t_ / cpr, cc = t_ - jj * cpr;
+    const int j = jj - 1;
+    // output rows / columns of the block; the first valid one names the taps (the other one, where it exists, has the same)
+    const int oya = 2 * k + 1, oyb = 2 * k + 2, oxa = 2 * j + 1, oxb = 2 * j + 2;
+    const bool va = oya >= 0, vb = oyb < Ho, ua = oxa >= 0, ub = oxb < Wo;
+    int y0, y1, x0, x1, t0, t1;
+    float lya = 0.f, lyb = 0.f, lxa = 0.f, lxb = 0.f;
+    if (va) bil2_src(oya, H, y0, y1, lya);
+    if (vb) { if (va) bil2_src(oyb, H, t0, t1, lyb); else bil2_src(oyb, H, y0, y1, lyb); }
+    if (ua) bil2_src(oxa, W, x0, x1, lxa);
+    if (ub) { if (ua) bil2_src(oxb, W, t0, t1, lxb); else bil2_src(oxb, W, x0, x1, lxb); }
+    const bf16_t* base = x + (size_t)b * H * W * C + cc * 8;
+    const uint4 q00 = *reinterpret_cast<const uint4*>(base + ((size_t)y0 * W + x0) * C);
+    const uint4 q01 = *reinterpret_cast<const uint4*>(base + ((size_t)y0 * W + x1) * C);
+    const uint4 q10 = *reinterpret_cast<const uint4*>(base + ((size_t)y1 * W + x0) * C);
+    const uint4 q11 = *reinterpret_cast<const uint4*>(base + ((size_t)y1 * W + x1) * C);
+    uint4 aq[4];
+    size_t at[4];
+    bool ok[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int oy = (p >> 1) ? oyb : oya, ox = (p & 1) ? oxb : oxa;
+      ok[p] = ((p >> 1) ? vb : va) && ((p & 1) ? ub : ua);
+      at[p] = ((((size_t)b * Ho + oy) * Wo + ox) * cpr + cc) * 8;
+      if (ok[p] && addend) aq[p] = *reinterpret_cast<const uint4*>(addend + at[p]);
+    }
+    const bf16_t* v00 = reinterpret_cast<const bf16_t*>(&q00);
+    const bf16_t* v01 = reinterpret_cast<const bf16_t*>(&q01);
+    const bf16_t* v10 = reinterpret_cast<const bf16_t*>(&q10);
+    const bf16_t* v11 = reinterpret_cast<const bf16_t*>(&q11);
+    bf16_t o[4][8];
+#pragma unroll
+    for (int cx = 0; cx < 2; ++cx) {
+      const float lx = cx ? lxb : lxa, hx = 1.f - lx;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float top = hx * bf2f(v00[e]) + lx * bf2f(v01[e]);
+        const float bot = hx * bf2f(v10[e]) + lx * bf2f(v11[e]);
+#pragma unroll
+        for (int ry = 0; ry < 2; ++ry) {
+          const float ly = ry ? lyb : lya, hy = 1.f - ly;
+          float f = hy * top + ly * bot;
+          const int p = ry * 2 + cx;
+          if (addend) f = bf2f(f2bf(f)) + bf2f(reinterpret_cast<const bf16_t*>(&aq[p])[e]);
+          o[p][e] = f2bf(f);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      if (ok[p]) *reinterpret_cast<uint4*>(out + at[p]) = *reinterpret_cast<const uint4*>(o[p]);
+  }
+}
+
 // gather form of the transpose: input pixel (y,x) collects from output rows {2y-1..2y+2} that reference it
 __global__ __launch_bounds__(256) void bilinear2_bwd_kernel(const bf16_t* __restrict__ dout, bf16_t* __restrict__ dx, int B,
                                                             int H, int W, int C) {
@@ -604,8 +671,14 @@ extern "C" int u2_bilinear_up2_fwd(const void* x, const void* addend, void* out,
   if (C & 7) return -1;
   const size_t total = (size_t)B * H * 2 * W * 2 * (C >> 3);
   if (!total) return 0;
-  hipLaunchKernelGGL(bilinear2_fwd_kernel, dim3((W * 2 * (C >> 3) + 255) / 256, rows_grid(B * H * 2)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                     (const bf16_t*)addend, (bf16_t*)out, B, H, W, C);
+  // U2_BILINEAR_PER_PIXEL=1: the round-1 kernel, one output pixel per thread (A/B runs and the blocked kernel's test; read per call)
+  const char* pp = getenv("U2_BILINEAR_PER_PIXEL");
+  if (pp && atoi(pp) == 1)
+    hipLaunchKernelGGL(bilinear2_fwd_kernel, dim3((W * 2 * (C >> 3) + 255) / 256, rows_grid(B * H * 2)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (const bf16_t*)addend, (bf16_t*)out, B, H, W, C);
+  else
+    hipLaunchKernelGGL(bilinear2_fwd_block_kernel, dim3(((W + 1) * (C >> 3) + 255) / 256, rows_grid((long long)B * (H + 1))), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)addend, (bf16_t*)out, B, H, W, C);
   U2_CHECK_LAUNCH();
   return 0;
 }
