@@ -4,10 +4,16 @@ Cases: no ROIs at all (the kernel's fixed cost + the epilogue), ROIs of 32 / 64 
 with and without the two addend maps."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import ctypes
 import torch
 from u2seg_amd.layers import functional as F
 
 dev = "cuda:0"
+from u2seg_amd import _hip
+try:
+    TRACE = ctypes.CDLL(_hip.lib_path()).u2_debug_gs_trace
+except AttributeError:
+    TRACE = None
 B, H, W, C = 16, 200, 336, 256
 shapes = [(B, H, W, C), (B, H // 2, W // 2, C), (B, H // 4, W // 4, C), (B, H // 8, W // 8, C)]
 scales = [0.25, 0.125, 0.0625, 0.03125]
@@ -50,3 +56,12 @@ for name, n_box, n_mask, size in (("no ROIs", 0, 0, 32), ("128 per image and set
     else:
         sets = [make_set(n_box, size, 7) for _ in range(3)] + [make_set(n_mask, size, 14)]
     print("%-34s gather %.3f ms   + 2 addends %.3f ms" % (name, timeit(sets, ()), timeit(sets, adds)))
+    if TRACE is not None:   # -DGS_TRACE build: shader-clock ticks of thread 0 per phase, averaged over the work-groups of one launch
+        buf = (ctypes.c_ulonglong * 8)()
+        TRACE(buf, 1)
+        F._roi_gather(shapes, scales, sets, dev, level=0, addends=())
+        torch.cuda.synchronize()
+        TRACE(buf, 1)
+        wg = max(buf[7], 1)
+        print("    per work-group (ticks of 10 ns): scan %.0f  tables %.0f  staging %.0f  accumulation %.0f  loop rest %.0f  epilogue issue %.0f;  %.2f batches"
+              % tuple([buf[k] / wg for k in range(6)] + [buf[6] / wg]))

@@ -12,6 +12,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <vector>
 #include "common.h"
 #include "u2seg_hip.h"
 
@@ -387,6 +389,15 @@ typedef float gs_f2 __attribute__((ext_vector_type(2)));
 #ifndef GS_OCC
 #define GS_OCC 4
 #endif
+#ifdef GS_TRACE
+// debug build (-DGS_TRACE, tools/exp/roi_gather_trace.sh): shader-clock ticks of thread 0 per phase, summed over the work-groups
+// (one slot per work-group, plain adds: stamps through same-address atomics slowed the kernel six-fold)
+constexpr int GS_TRACE_WGS = 20000;
+__device__ unsigned long long g_gs_trace[GS_TRACE_WGS][8];
+#define GS_T(k) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); g_gs_trace[gs_wg][k] += now_ - t_last; t_last = now_; } } while (0)
+#else
+#define GS_T(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(256, GS_OCC) void roi_align_bwd_gather_kernel(const RoiSetsDev sets, bf16_t* __restrict__ gfeat, int level,
                                                                    int nlevels, int H, int W, int C, float scale,
                                                                    const bf16_t* __restrict__ add0, const bf16_t* __restrict__ add1) {
@@ -397,6 +408,11 @@ __global__ __launch_bounds__(256, GS_OCC) void roi_align_bwd_gather_kernel(const
   __shared__ float tabY[GS_KB][TS][GS_MAXP];                                  // [roi][tile row][bin row]
   __shared__ __attribute__((aligned(16))) float tabX[GS_KB][GS_MAXP][TS];     // [roi][bin column][tile column]
   __shared__ int rmask[GS_KB], cmask[GS_KB];                                  // bins with a weight on some tile row / column
+  // round 6: per tile row / per 4-pixel quad of columns, the bins that carry weight on it (double-buffered by batch parity: the
+  // buffer of the next batch is cleared while this one is multiplied).  The accumulation walks the set bits instead of testing
+  // every bin row and column of the ROI's rectangle for a zero weight - an LDS round trip per test, ~30 per (item, ROI), which a
+  // phase trace (tools/exp/roi_gather_trace.sh) put at half of a work-group's life on the stride-4 level.
+  __shared__ unsigned rowbits[2][GS_KB][GS_TS], colbits[2][GS_KB][2];
   __shared__ __attribute__((aligned(16))) unsigned char stage[GS_STAGE_BYTES];
   const int b = blockIdx.z;
   const int ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
@@ -412,6 +428,14 @@ __global__ __launch_bounds__(256, GS_OCC) void roi_align_bwd_gather_kernel(const
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[q][j][e] = gs_f2{0.f, 0.f};
   if (tid < GS_KB) { rmask[tid] = 0; cmask[tid] = 0; }
+  if (tid < 2 * GS_KB * TS) (&rowbits[0][0][0])[tid] = 0u;
+  if (tid < 2 * GS_KB * 2) (&colbits[0][0][0])[tid] = 0u;
+  int par = 0;   // batch parity (uniform)
+#ifdef GS_TRACE
+  const int gs_wg = (int)(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % GS_TRACE_WGS;
+  unsigned long long t_last = __builtin_readcyclecounter();
+  if (tid == 0) g_gs_trace[gs_wg][7] += 1ull;
+#endif
 
   for (int si = 0; si < sets.n; ++si) {
     const RoiSetDev st = sets.s[si];
@@ -443,8 +467,12 @@ __global__ __launch_bounds__(256, GS_OCC) void roi_align_bwd_gather_kernel(const
       }
       __syncthreads();
       const int n = nlist;
+      GS_T(0);   // scan
       for (int k0 = 0; k0 < n; k0 += GS_KB) {
         const int nb = min(GS_KB, n - k0);
+#ifdef GS_TRACE
+        if (tid == 0) g_gs_trace[gs_wg][6] += 1ull;
+#endif
         // 1-D weight sums of this batch of ROIs for the tile's 8 pixel rows and 8 pixel columns
         for (int t = tid; t < nb * 2 * TS * P; t += 256) {
           const int bin = t % P;
@@ -457,15 +485,18 @@ __global__ __launch_bounds__(256, GS_OCC) void roi_align_bwd_gather_kernel(const
             const float inv_g = g.bh / (float)g.gh;
             for (int iy = 0; iy < g.gh; ++iy) sum += axis_weight(g.sh + bin * g.bh + (iy + 0.5f) * inv_g, H, ty0 + rc);
             tabY[kk][rc][bin] = sum;
-            if (sum != 0.f) atomicOr(&rmask[kk], 1 << bin);
+            if (sum != 0.f) { atomicOr(&rmask[kk], 1 << bin); atomicOr(&rowbits[par][kk][rc], 1u << bin); }
           } else {
             const float inv_g = g.bw / (float)g.gw;
             for (int ix = 0; ix < g.gw; ++ix) sum += axis_weight(g.sw + bin * g.bw + (ix + 0.5f) * inv_g, W, tx0 + rc);
             tabX[kk][bin][rc] = sum;
-            if (sum != 0.f) atomicOr(&cmask[kk], 1 << bin);
+            if (sum != 0.f) { atomicOr(&cmask[kk], 1 << bin); atomicOr(&colbits[par][kk][rc >> 2], 1u << bin); }
           }
         }
         __syncthreads();
+        if (tid < GS_KB * TS) (&rowbits[par ^ 1][0][0])[tid] = 0u;
+        if (tid < GS_KB * 2) (&colbits[par ^ 1][0][0])[tid] = 0u;
+        GS_T(1);   // tables
         // the bin rectangle of every ROI of the batch that carries weight on the tile, and its place in the stage
         int ph_lo[GS_KB], ph_n[GS_KB], pw_lo[GS_KB], pw_n[GS_KB], sbase[GS_KB];
         int used = 0;
@@ -495,6 +526,7 @@ __global__ __launch_bounds__(256, GS_OCC) void roi_align_bwd_gather_kernel(const
           }
         }
         __syncthreads();
+        GS_T(2);   // staging
         if (tid < GS_KB) { rmask[tid] = 0; cmask[tid] = 0; }  // for the next batch (every thread holds its copy by now)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -507,42 +539,64 @@ __global__ __launch_bounds__(256, GS_OCC) void roi_align_bwd_gather_kernel(const
 #pragma unroll
           for (int kk = 0; kk < GS_KB; ++kk) {
             if (kk >= nb || ph_n[kk] == 0) continue;
+            unsigned rb = rowbits[par][kk][row];
+            const unsigned cb = colbits[par][kk][quad];
+            if (rb == 0u || cb == 0u) continue;   // no weight on this row / these four columns (also: outside the ROI's footprint)
             const RoiGeom& g = list[k0 + kk];
-            if (py < g.py0 || py > g.py1 || px + 3 < g.px0 || px > g.px1) continue;
             const float ic = g.inv_cnt;
             const bool staged = sbase[kk] >= 0;
             const bf16_t* rbase = st.dout + (size_t)g.r * P * P * C + ch * 8;
             const unsigned char* sb = stage + ((size_t)sbase[kk] * cpr + ch) * 16;
-            for (int i = 0; i < ph_n[kk]; ++i) {
-              const int ph = ph_lo[kk] + i;
-              const float ay = tabY[kk][row][ph];
-              if (ay == 0.f) continue;
-              const float ayc = ay * ic;
-              for (int jx = 0; jx < pw_n[kk]; ++jx) {
-                const int pw = pw_lo[kk] + jx;
-                const float4 ax = *reinterpret_cast<const float4*>(&tabX[kk][pw][quad * 4]);
-                if (ax.x == 0.f && ax.y == 0.f && ax.z == 0.f && ax.w == 0.f) continue;
-                uint4 dq;
-                if (staged) dq = *reinterpret_cast<const uint4*>(sb + (size_t)(i * pw_n[kk] + jx) * cpr * 16);
-                else dq = *reinterpret_cast<const uint4*>(rbase + (size_t)(ph * P + pw) * C);
-                const uint32_t dw[4] = {dq.x, dq.y, dq.z, dq.w};
-                const float w0 = ayc * ax.x, w1 = ayc * ax.y, w2 = ayc * ax.z, w3 = ayc * ax.w;
+            while (rb) {
+              const int ph = __ffs(rb) - 1;
+              rb &= rb - 1u;
+              const float ayc = tabY[kk][row][ph] * ic;
+              const int i = ph - ph_lo[kk];
+              unsigned m = cb;
+              while (m) {   // two bin columns per turn: their four LDS reads are independent and go out together
+                const int pw0 = __ffs(m) - 1;
+                m &= m - 1u;
+                const bool two = m != 0u;
+                const int pw1 = two ? __ffs(m) - 1 : pw0;
+                m &= m - 1u;
+                const float4 ax0 = *reinterpret_cast<const float4*>(&tabX[kk][pw0][quad * 4]);
+                float4 ax1 = *reinterpret_cast<const float4*>(&tabX[kk][pw1][quad * 4]);
+                uint4 dq0, dq1;
+                if (staged) {
+                  dq0 = *reinterpret_cast<const uint4*>(sb + (size_t)(i * pw_n[kk] + pw0 - pw_lo[kk]) * cpr * 16);
+                  dq1 = *reinterpret_cast<const uint4*>(sb + (size_t)(i * pw_n[kk] + pw1 - pw_lo[kk]) * cpr * 16);
+                } else {
+                  dq0 = *reinterpret_cast<const uint4*>(rbase + (size_t)(ph * P + pw0) * C);
+                  dq1 = *reinterpret_cast<const uint4*>(rbase + (size_t)(ph * P + pw1) * C);
+                }
+                if (!two) ax1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const uint32_t dw0[4] = {dq0.x, dq0.y, dq0.z, dq0.w}, dw1[4] = {dq1.x, dq1.y, dq1.z, dq1.w};
+                const float u0 = ayc * ax0.x, u1 = ayc * ax0.y, u2 = ayc * ax0.z, u3 = ayc * ax0.w;
+                const float v0 = ayc * ax1.x, v1 = ayc * ax1.y, v2 = ayc * ax1.z, v3 = ayc * ax1.w;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                  const gs_f2 d = gs_f2{__uint_as_float(dw[e] << 16), __uint_as_float(dw[e] & 0xffff0000u)};
-                  acc[q][0][e] = __builtin_elementwise_fma(gs_f2{w0, w0}, d, acc[q][0][e]);
-                  acc[q][1][e] = __builtin_elementwise_fma(gs_f2{w1, w1}, d, acc[q][1][e]);
-                  acc[q][2][e] = __builtin_elementwise_fma(gs_f2{w2, w2}, d, acc[q][2][e]);
-                  acc[q][3][e] = __builtin_elementwise_fma(gs_f2{w3, w3}, d, acc[q][3][e]);
+                  const gs_f2 d0 = gs_f2{__uint_as_float(dw0[e] << 16), __uint_as_float(dw0[e] & 0xffff0000u)};
+                  const gs_f2 d1 = gs_f2{__uint_as_float(dw1[e] << 16), __uint_as_float(dw1[e] & 0xffff0000u)};
+                  acc[q][0][e] = __builtin_elementwise_fma(gs_f2{u0, u0}, d0, acc[q][0][e]);
+                  acc[q][1][e] = __builtin_elementwise_fma(gs_f2{u1, u1}, d0, acc[q][1][e]);
+                  acc[q][2][e] = __builtin_elementwise_fma(gs_f2{u2, u2}, d0, acc[q][2][e]);
+                  acc[q][3][e] = __builtin_elementwise_fma(gs_f2{u3, u3}, d0, acc[q][3][e]);
+                  acc[q][0][e] = __builtin_elementwise_fma(gs_f2{v0, v0}, d1, acc[q][0][e]);
+                  acc[q][1][e] = __builtin_elementwise_fma(gs_f2{v1, v1}, d1, acc[q][1][e]);
+                  acc[q][2][e] = __builtin_elementwise_fma(gs_f2{v2, v2}, d1, acc[q][2][e]);
+                  acc[q][3][e] = __builtin_elementwise_fma(gs_f2{v3, v3}, d1, acc[q][3][e]);
                 }
               }
             }
           }
         }
         __syncthreads();
+        par ^= 1;
+        GS_T(3);   // accumulation
       }
     }
   }
+  GS_T(4);     // what is left of the loops
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int item = q * 256 + tid;
@@ -576,6 +630,7 @@ __global__ __launch_bounds__(256, GS_OCC) void roi_align_bwd_gather_kernel(const
       *reinterpret_cast<uint4*>(gfeat + at) = *reinterpret_cast<const uint4*>(o);
     }
   }
+  GS_T(5);     // epilogue (issue only: the stores retire behind the work-group)
 }
 
 // single-channel fp32 ROIAlign used for ground-truth mask crops (BitMasks.crop_and_resize,
@@ -1153,6 +1208,21 @@ extern "C" int u2_roi_group(const float* rois, const int* level, int* order, int
   U2_CHECK_LAUNCH();
   return 0;
 }
+
+#ifdef GS_TRACE
+extern "C" int u2_debug_gs_trace(unsigned long long* out8, int reset) {   // sums over the work-group slots
+  static std::vector<unsigned long long> h((size_t)GS_TRACE_WGS * 8);
+  if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_gs_trace), h.size() * 8) != hipSuccess) return -1;
+  for (int k = 0; k < 8; ++k) out8[k] = 0;
+  for (int w = 0; w < GS_TRACE_WGS; ++w)
+    for (int k = 0; k < 8; ++k) out8[k] += h[(size_t)w * 8 + k];
+  if (reset) {
+    std::fill(h.begin(), h.end(), 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_gs_trace), h.data(), h.size() * 8) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 extern "C" int u2_roi_align_bwd_gather_sum(void* const* gfeats, const int* Hs, const int* Ws, const float* scales, int nlevels,
                                            int level_mask, int nsets, const void* const* rois, const void* const* order,
