@@ -970,7 +970,14 @@ constexpr int WG256_STAGE = 4 * WG256_IMG;       // dy lo / dy hi / x lo / x hi
 // 890 x the 196 tiles on 256 CUs.  Default 0: the round-2 loop (all reads, one wait, 32 MFMAs) in a three-stage ring.
 #define U2_WG256_PIPE 0
 #endif
-constexpr int WG256_STAGES = U2_WG256_PIPE ? 4 : 3;
+#ifndef U2_WG256_STAGES
+// LDS ring depth of the default loop (3 ... 5: 96 ... 160 KB, stages - 1 of them in flight behind the step).  Round 6, with the counters
+// of fc1's launch in hand (38 % of the wave cycles in s_waitcnt, no LDS bank conflicts, hardly any wait for LDS issue): 3 / 4 / 5
+// stages measure the same on fc1 (0.351-0.359 ms), the stride-16 1x1 layers (0.069-0.074) and 8192^3 (0.90-0.91 PFLOP/s) -
+// tools/exp/wg256_stages_ab.sh - so it is not bytes in flight either.
+#define U2_WG256_STAGES 3
+#endif
+constexpr int WG256_STAGES = U2_WG256_PIPE ? 4 : U2_WG256_STAGES;
 
 __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1174,15 +1181,21 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
 #undef U2_W_TIE
 #undef U2_W_RD
 #else
-  // three-stage ring: steps st+1 and st+2 are in flight while step st is multiplied (4 LDS-DMA loads per thread per step)
-  issue(0);
-  if (nsteps > 1) issue(1);
+  // ring of WG256_STAGES stages: steps st+1 .. st+STAGES-1 are in flight while step st is multiplied (4 LDS-DMA loads per thread
+  // per step); at the barrier of step st everything but the stages behind it has landed
+  static_assert(WG256_STAGES >= 3 && WG256_STAGES <= 5, "ring depth");
+#pragma unroll
+  for (int s0 = 0; s0 < WG256_STAGES - 1; ++s0)
+    if (s0 < nsteps) issue(s0);
   for (int st = 0; st < nsteps; ++st) {
-    if (st + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    const int behind = min(WG256_STAGES - 2, nsteps - 1 - st);   // stages issued behind step st that may still be in flight
+    if (behind >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (behind == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (st + 2 < nsteps) issue((st + 2) % WG256_STAGES);
+    if (st + WG256_STAGES - 1 < nsteps) issue((st + WG256_STAGES - 1) % WG256_STAGES);
     compute(st % WG256_STAGES);
   }
 
