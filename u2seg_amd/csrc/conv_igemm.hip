@@ -1001,6 +1001,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
   const int nsteps = (mend - mbeg + WP - 1) / WP;
   const int hw = a.Hout * a.Wout;
   const bool direct = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad_h == 0 && a.pad_w == 0);
+  // a "fully connected" conv (one output position per image, no padding: fc1's 7 x 7): pixel m reads input row (m, kh, kw) - no
+  // coordinates to carry (the general path below re-derives them with two integer divisions per step when Wout < 32)
+  const bool fc = !direct && a.Hout == 1 && a.Wout == 1 && a.pad_h == 0 && a.pad_w == 0;
+  const size_t fc_pitch = (size_t)a.Hin * a.Win * a.x_ld, fc_off = ((size_t)kh * a.Win + kw) * a.x_ld;
 
   // staging: wave w moves pixels 4w .. 4w+3 of the step (16 chunks each) of all four images
   const int pix = w * 4 + (lane >> 4);
@@ -1019,6 +1023,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
     if (mok) {
       if (direct) {
         xrow = a.x + (size_t)cm * a.x_ld;
+      } else if (fc) {
+        xrow = a.x + (size_t)cm * fc_pitch + fc_off;
       } else {
         const int sy = coy * a.stride - a.pad_h + kh;
         const int sx = cox * a.stride - a.pad_w + kw;
@@ -1034,7 +1040,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
       glds16(xsrc, base + (2 + im) * WG256_IMG + w * 1024);
     }
     cm += WP;
-    if (!direct) {
+    if (!direct && !fc) {
       if (a.Wout >= WP) {
         cox += WP;
         while (cox >= a.Wout) { cox -= a.Wout; if (++coy == a.Hout) { coy = 0; ++cimg; } }
