@@ -157,6 +157,9 @@ constexpr int FS_MAXP = 14, FS_MAXR = 16;
 #ifndef FS_PAIR
 #define FS_PAIR 1
 #endif
+#ifndef FS_QUAD
+#define FS_QUAD 1
+#endif
 
 // One work item = (bin row ph, 8-channel chunk) sweeping ALL bin columns of the row (round 5).  Neighbouring bins overlap by one or
 // two pixel columns (bin pw ends at floor(last sample) + 1, bin pw + 1 starts at floor(its first sample) >= floor(that last sample)),
@@ -325,6 +328,45 @@ __global__ __launch_bounds__(256, FS_OCC) void roi_align_fwd_sep_kernel(const Ro
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     const int ny = cnt[0][ph], nx = cnt[1][pw], y0 = lo[0][ph], x0 = lo[1][pw];
+#if FS_QUAD
+    // round 6: two pixel rows x two pixel columns of the bin in flight per thread (four independent 16-byte loads per round trip
+    // instead of two: the pass is bound by the latency of its dependent loads times the threads resident).  A missing second row /
+    // column re-reads the first one with weight 0; the sum's terms are the same, their order within a 2 x 2 block is not.
+    for (int ky = 0; ky < ny; ky += 2) {
+      const bool r1 = ky + 1 < ny;
+      const float a0 = wtab[0][ph][ky], a1 = r1 ? wtab[0][ph][ky + 1] : 0.f;
+      if (a0 == 0.f && a1 == 0.f) continue;
+      const bf16_t* row0 = f + (plane + (size_t)(y0 + ky) * W + x0) * C + cc * 8;
+      const bf16_t* row1 = r1 ? row0 + (size_t)W * C : row0;
+      for (int kx = 0; kx < nx; kx += 2) {
+        const bool c1 = kx + 1 < nx;
+        const float b0 = wtab[1][pw][kx], b1 = c1 ? wtab[1][pw][kx + 1] : 0.f;
+        const size_t o0 = (size_t)kx * C, o1 = c1 ? o0 + C : o0;
+        bf16_t v00[8], v01[8], v10[8], v11[8];
+        *reinterpret_cast<uint4*>(v00) = *reinterpret_cast<const uint4*>(row0 + o0);
+        *reinterpret_cast<uint4*>(v01) = *reinterpret_cast<const uint4*>(row0 + o1);
+        *reinterpret_cast<uint4*>(v10) = *reinterpret_cast<const uint4*>(row1 + o0);
+        *reinterpret_cast<uint4*>(v11) = *reinterpret_cast<const uint4*>(row1 + o1);
+        const float w00 = a0 * b0, w01 = a0 * b1, w10 = a1 * b0, w11 = a1 * b1;
+        if (w00 != 0.f) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += w00 * bf2f(v00[e]);
+        }
+        if (w01 != 0.f) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += w01 * bf2f(v01[e]);
+        }
+        if (w10 != 0.f) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += w10 * bf2f(v10[e]);
+        }
+        if (w11 != 0.f) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += w11 * bf2f(v11[e]);
+        }
+      }
+    }
+#else
     for (int ky = 0; ky < ny; ++ky) {
       const float a = wtab[0][ph][ky];
       if (a == 0.f) continue;
@@ -358,6 +400,7 @@ __global__ __launch_bounds__(256, FS_OCC) void roi_align_fwd_sep_kernel(const Ro
         for (int e = 0; e < 8; ++e) acc[e] += wgt * bf2f(v[e]);
       }
     }
+#endif
     bf16_t o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e] * inv_cnt);
