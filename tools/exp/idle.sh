@@ -5,6 +5,6 @@ TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_idle -o bench -- \
   python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra > $R/gpurun_out/${TAG}_idle.log 2>&1
-cd $R/tools && python step_idle.py $R/gpurun_out/${TAG}_idle 40 > $R/gpurun_out/${TAG}_step_idle.txt
+cd $R/tools && python step_idle.py $R/gpurun_out/${TAG}_idle 12 ${2:-0} ${3:-0} > $R/gpurun_out/${TAG}_step_idle.txt
 rm -rf $R/gpurun_out/${TAG}_idle
-cat $R/gpurun_out/${TAG}_step_idle.txt
+head -20 $R/gpurun_out/${TAG}_step_idle.txt

@@ -2,7 +2,7 @@
 """Where the chip is idle inside ONE overlapped training step, out of a rocprofv3 --kernel-trace CSV: the union of the kernels'
 [start, end] intervals between two consecutive optimizer launches against the step's span, and the longest gaps with the kernels on
 either side of them (a gap = no kernel of ANY stream running: a host synchronisation, a launch-bound stretch, a dependency chain).
-usage: tools/step_idle.py <dir with *_kernel_trace.csv> [top]"""
+usage: tools/step_idle.py <dir with *_kernel_trace.csv> [top] [from_ms to_ms]   (a window: every dispatch in it, with its queue)"""
 import csv
 import glob
 import sys
@@ -49,6 +49,15 @@ def main():
     print("longest gaps (us, at ms of the step, kernel before -> kernel after):")
     for g in sorted(gaps, reverse=True)[:top]:
         print("  %7.1f  @%6.2f  %s  ->  %s" % (g[0], g[1], g[2][:60], g[3][:60]))
+    if len(sys.argv) > 4:
+        lo, hi = float(sys.argv[3]), float(sys.argv[4])
+        queues = {}
+        print("dispatches starting in [%.2f, %.2f) ms: start ms, duration us, queue, kernel" % (lo, hi))
+        for r in seg:
+            st = (int(r["Start_Timestamp"]) - t0) / 1e6
+            if lo <= st < hi:
+                q = queues.setdefault(r.get("Queue_Id", "?"), len(queues))
+                print("  %7.3f %8.1f  q%d  %s" % (st, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, q, short(r["Kernel_Name"])[:70]))
 
 
 if __name__ == "__main__":

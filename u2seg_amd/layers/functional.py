@@ -203,6 +203,37 @@ def join_aux_stream(device, index=0):
         torch.cuda.current_stream(s.device).wait_stream(s)
 
 
+# ---- an independent branch issued in pieces where the main chain is host-bound (round 6) ----
+# The proposal bookkeeping of the ROI heads (match / relabel / sample between the cascade stages: ~40 tiny launches and one host
+# synchronisation each) leaves the chip idle for 0.6-1.3 ms at a time while the host catches up (tools/step_idle.py: 3.7 ms of a 58 ms
+# step).  A branch that only shares the FPN maps with it - the semantic head - is therefore not launched as a whole beside the RPN
+# but handed over as a list of pieces; the bookkeeping code calls issue_deferred_piece() right before it becomes host-bound, and the
+# piece's kernels (on the branch's own stream) run while the host synchronises and launches the small stuff.
+_deferred_pieces = []
+
+
+def defer_pieces(pieces):
+    """Queue closures (each launches one piece of an independent branch on that branch's stream)."""
+    _deferred_pieces.extend(pieces)
+
+
+def issue_deferred_piece(n=1):
+    """Launch the next n queued pieces (no-op when nothing is queued)."""
+    while n > 0 and _deferred_pieces:
+        _deferred_pieces.pop(0)()
+        n -= 1
+
+
+def flush_deferred():
+    """Launch whatever is still queued (the owner of the branch calls this before it joins the branch's stream)."""
+    issue_deferred_piece(len(_deferred_pieces))
+
+
+def clear_deferred():
+    """Drop queued pieces (a forward pass that raised midway must not leave its pieces to the next one)."""
+    del _deferred_pieces[:]
+
+
 def join_all_streams():
     """The current stream waits for the side stream and every further compute stream: used where gradients are consumed
     (optimizer step, gradient all-reduce - also the one of the arena's tail that starts inside the backward pass, when

@@ -1,5 +1,7 @@
 """Meta-architectures: GeneralizedRCNN and PanopticFPN with detectron2's forward contract
 (detectron2/modeling/meta_arch/rcnn.py:25-234, meta_arch/panoptic_fpn.py:21-181, meta_arch/build.py:7-25)."""
+import os
+
 import torch
 from torch import nn
 
@@ -180,18 +182,47 @@ class PanopticFPN(GeneralizedRCNN):
         # kernels fill the chip while the proposal / sampling bookkeeping of the other branch occupies a few CUs at a time
         # (autograd replays every node on the stream of its forward pass, so the backward passes overlap the same way).
         aux = F.aux_stream(self.device) if sem_f[self.sem_seg_head.in_features[0]].is_cuda else None
-        if aux is not None:
+        gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+        F.clear_deferred()
+        if aux is not None and os.environ.get("U2_SEM_PIECES", "1") != "0":
+            # Round 6: the head is handed over in pieces (level stacks, then predictor + loss) that the ROI heads launch - on `aux` -
+            # where their own chain is about to be host-bound: in front of the sampler's host synchronisation, between the cascade
+            # stages, in front of the losses (layers/functional.py:defer_pieces).  Launched as a whole in front of the RPN (rounds
+            # 2-5) it ran beside the RPN's convolutions and was finished when the idle stretches began (tools/step_idle.py).
+            sem_seg_losses = {}
             main = torch.cuda.current_stream(self.device)
-            aux.wait_stream(main)
-            with torch.cuda.stream(aux):
-                _, sem_seg_losses = self.sem_seg_head(sem_f, gt_sem_seg)
+            first = [True]
+
+            def on_aux(piece):
+                def run():
+                    if first[0]:
+                        aux.wait_stream(main)   # the FPN maps and the targets exist (nothing later on `main` is an input)
+                        first[0] = False
+                    # (the call sites sit inside the samplers' torch.no_grad() regions: the piece is part of the differentiated graph)
+                    with torch.cuda.stream(aux), torch.enable_grad():
+                        piece()
+                return run
+
+            pieces = [on_aux(pc) for pc in self.sem_seg_head.training_pieces(sem_f, gt_sem_seg, sem_seg_losses)]
+            # two pieces per call site at first (stride 4 and 8: the two long ones), then one: five pieces over four call sites
+            F.defer_pieces([lambda a=pieces[0], b=pieces[1]: (a(), b())] + pieces[2:] if len(pieces) > 4 else pieces)
             for t in list(sem_f.values()) + [gt_sem_seg]:
                 t.record_stream(aux)
+            proposals, proposal_losses = self.proposal_generator(image_sizes, rpn_f, gt_instances)
+            _, detector_losses = self.roi_heads(None, roi_f, proposals, gt_instances)
+            F.flush_deferred()
         else:
-            _, sem_seg_losses = self.sem_seg_head(sem_f, gt_sem_seg)
-        gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
-        proposals, proposal_losses = self.proposal_generator(image_sizes, rpn_f, gt_instances)
-        _, detector_losses = self.roi_heads(None, roi_f, proposals, gt_instances)
+            if aux is not None:
+                main = torch.cuda.current_stream(self.device)
+                aux.wait_stream(main)
+                with torch.cuda.stream(aux):
+                    _, sem_seg_losses = self.sem_seg_head(sem_f, gt_sem_seg)
+                for t in list(sem_f.values()) + [gt_sem_seg]:
+                    t.record_stream(aux)
+            else:
+                _, sem_seg_losses = self.sem_seg_head(sem_f, gt_sem_seg)
+            proposals, proposal_losses = self.proposal_generator(image_sizes, rpn_f, gt_instances)
+            _, detector_losses = self.roi_heads(None, roi_f, proposals, gt_instances)
         F.join_aux_stream(self.device)  # semantic head and RPN losses
         losses = sem_seg_losses
         losses.update(proposal_losses)

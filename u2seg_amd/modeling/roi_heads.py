@@ -449,6 +449,7 @@ class ROIHeads(nn.Module):
         s = sampled.shape[1]
         flags = [cvalid.sum(dim=1)] + ([lp.finite.reshape(1).to(torch.int64)] if lp.finite is not None else [])
         vals = torch.cat(flags).tolist()  # the one host synchronisation of the sampler
+        F.issue_deferred_piece()  # the chip is idle from here until the first stage's kernels are launched (functional.defer_pieces)
         if lp.finite is not None:
             check_finite(bool(vals[-1]), self.training)
             lp.finite = None
@@ -658,6 +659,7 @@ class CascadeROIHeads(StandardROIHeads):
             head_outputs.append((self.box_predictor[k], predictions, proposals))
         if self.training:
             losses = {}
+            F.issue_deferred_piece()
             for stage, (predictor, predictions, props) in enumerate(head_outputs):
                 stage_losses = predictor.losses(predictions, props)
                 losses.update({k + "_stage{}".format(stage): v for k, v in stage_losses.items()})
@@ -711,6 +713,7 @@ class CascadeROIHeads(StandardROIHeads):
         if not bool(nonempty.all()):  # cascade_rcnn.py:291-294: ragged result, take the per-image path
             props = self._create_proposals_from_boxes(list(boxes), image_sizes)
             return self._match_and_label_boxes(props, stage, targets)
+        F.issue_deferred_piece()  # behind the host synchronisation: match / relabel below are ~20 tiny launches
         pt = PaddedTargets.of(targets, dev)
         thr = self.cascade_ious[stage]
         match, labels, _ = F.iou_match(boxes.contiguous(), pt.boxes, pt.counts, thr, thr, False)

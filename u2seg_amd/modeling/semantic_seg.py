@@ -84,6 +84,30 @@ class SemSegFPNHead(nn.Module):
                 x = x + y
         return self.predictor(x)
 
+    def training_pieces(self, features, targets_u8, out):
+        """The training forward pass as closures that launch it piece by piece, in the order of `layers` (level stacks from the
+        common stride upwards, each adding the running sum; predictor + loss last): `out` receives {"loss_sem_seg"} with the last
+        piece.  Same kernels in the same order as forward(): where the pieces are launched is the caller's business
+        (layers.functional.defer_pieces)."""
+        state = {"x": None}
+
+        def level(f, head):
+            def run():
+                x, y = state["x"], features[f]
+                ops = list(head)
+                for i, op in enumerate(ops):
+                    last = i == len(ops) - 1
+                    y = op(y, x if last else None) if isinstance(op, _Upsample2) else op(y)
+                state["x"] = y if x is None or isinstance(ops[-1], _Upsample2) else x + y
+            return run
+
+        def tail():
+            loss = F.sem_seg_loss(self.predictor(state["x"]), targets_u8, self.num_classes, self.ignore_value)
+            out["loss_sem_seg"] = loss * self.loss_weight
+            state["x"] = None
+
+        return [level(f, head) for f, head in zip(self.in_features, self.scale_heads)] + [tail]
+
     def forward(self, features, targets_u8=None):
         """targets_u8: [B, H, W] uint8 (ignore_value where unlabeled).  Training -> (None, {"loss_sem_seg"});
         inference -> ([B, num_classes, H, W] fp32 logits, {})."""
