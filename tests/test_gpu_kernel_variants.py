@@ -61,7 +61,11 @@ def forced(conv=None, wgrad=None):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = str(v)
-        yield
+        # the kernel tests see the library's own dispatch: the product path's rule of where the stream-K form may run
+        # (layers/functional.py:streamk_region - only the bottom-up backbone asks for it) is tested in test_streamk_region_rule
+        from u2seg_amd.layers import functional as _fn
+        with _fn.streamk_region():
+            yield
     finally:
         for k, v in old.items():
             if v is None:
@@ -705,3 +709,41 @@ def test_conv_accumulating_epilogue(F, shape):
         assert code is None or last_kernel() == code, last_kernel()
     assert got.data_ptr() == out.data_ptr()
     assert rel_err(got.permute(0, 3, 1, 2)[:, :cout].float().cpu(), ref) < ULP
+
+
+def test_streamk_region_rule(F):
+    """Where the product path lets a convolution take the stream-K form (layers/functional.py:streamk_region): inside the region
+    (the bottom-up backbone) the library's fill rule decides - fpn_output4's shape takes configuration 501, forward and data
+    gradient -, outside it the call carries variant bit 28 and runs whole tiles (101) while the branch streams are on, and the
+    rule is off when they are off (set_stream_overlap(False)) or U2_STREAMK_EVERYWHERE=1; results agree either way."""
+    g = torch.Generator().manual_seed(5)
+    b, h, w, c = 16, 50, 84, 256
+    x = torch.randn((b, h, w, c), generator=g).bfloat16().to(DEV)
+    wt = (torch.randn((c, c, 3, 3), generator=g) / (c * 9) ** 0.5).to(DEV)
+    old = {k: os.environ.pop(k, None) for k in ("U2_CONV_VARIANT", "U2_STREAMK_EVERYWHERE", "U2_AUX_STREAM")}
+    try:
+        with F.streamk_region():
+            xin = x.clone().requires_grad_(True)
+            y_in, _ = F._Conv2dFn.apply(xin, wt, None, 1, 1, False, False)
+            assert last_kernel() == 501, last_kernel()
+        y_out, _ = F._Conv2dFn.apply(x, wt, None, 1, 1, False, False)
+        assert last_kernel() == 101, last_kernel()
+        # the backward pass of a layer created inside the region keeps the permission outside of it
+        y_in.backward(torch.ones_like(y_in))
+        F.join_all_streams()
+        assert xin.grad is not None
+        F.set_stream_overlap(False)
+        try:
+            F._Conv2dFn.apply(x, wt, None, 1, 1, False, False)
+            assert last_kernel() == 501, last_kernel()
+        finally:
+            F.set_stream_overlap(True)
+        os.environ["U2_STREAMK_EVERYWHERE"] = "1"
+        F._Conv2dFn.apply(x, wt, None, 1, 1, False, False)
+        assert last_kernel() == 501, last_kernel()
+        assert float((y_in.float() - y_out.float()).abs().max()) <= 2 ** -7 * float(y_out.float().abs().max())
+    finally:
+        os.environ.pop("U2_STREAMK_EVERYWHERE", None)
+        for k, v in old.items():
+            if v is not None:
+                os.environ[k] = v

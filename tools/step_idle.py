@@ -46,6 +46,10 @@ def main():
                 h[2] += g[0]
                 break
     print("gaps by length (us): " + ", ".join("<%g: %d (%.2f ms)" % (h[0], h[1], h[2] / 1e3) for h in hist))
+    bins = {}
+    for g in gaps:
+        bins[int(g[1])] = bins.get(int(g[1]), 0.0) + g[0]
+    print("idle us per ms of the step: " + " ".join("%d:%d" % (b, bins.get(b, 0)) for b in range(int(span) + 1)))
     print("longest gaps (us, at ms of the step, kernel before -> kernel after):")
     for g in sorted(gaps, reverse=True)[:top]:
         print("  %7.1f  @%6.2f  %s  ->  %s" % (g[0], g[1], g[2][:60], g[3][:60]))

@@ -203,6 +203,38 @@ def join_aux_stream(device, index=0):
         torch.cuda.current_stream(s.device).wait_stream(s)
 
 
+# ---- where the stream-K form of the tile kernel may be used (round 6) ----
+# Found with tools/exp/hang_hunt.sh: the driver's bench command hung in 4 of 23 runs (the chip never finished; the host sat in the
+# step's first synchronisation), in 0 of 24 with the stream-K form forbidden, in 0 of 40 with the branch streams (semantic head, mask
+# head) switched off, and still in 3 of 30 with the stream-K launches of different streams ordered behind each other by events.  So
+# ONE stream-K launch - whose owners spin for peers that the dispatcher has yet to place on a CU, conv_tile.hip - can stall for good
+# while kernels of a branch stream compete for the CUs; the mechanism is not understood (the weight-gradient side stream beside
+# stream-K launches: 0 of 20).  Until it is, the product path asks for the stream-K form only where no branch stream has work in
+# flight: inside the bottom-up backbone (forward: nothing else has been launched yet; backward: the heads' streams have been
+# joined by the FPN's gradient fan-in), and anywhere when the branch streams are off (set_stream_overlap(False)).  Elsewhere the
+# calls carry variant bit 28 (whole tiles).  U2_STREAMK_EVERYWHERE=1 restores the old behaviour.
+_NO_STREAMK = 1 << 28
+_SK_REGION = [0]
+
+
+class streamk_region:
+    """with streamk_region(): the convolutions created inside (and their backward passes) may take the stream-K form."""
+
+    def __enter__(self):
+        _SK_REGION[0] += 1
+
+    def __exit__(self, *exc):
+        _SK_REGION[0] -= 1
+        return False
+
+
+def _conv_variant():
+    if _SK_REGION[0] > 0 or not _AUX_ENABLED or os.environ.get("U2_AUX_STREAM", "1") == "0" \
+            or os.environ.get("U2_STREAMK_EVERYWHERE", "0") == "1" or "U2_CONV_VARIANT" in os.environ:
+        return 0   # (U2_CONV_VARIANT: tests and A/B runs steer the library's dispatch themselves; it only applies to variant 0)
+    return _NO_STREAMK
+
+
 # ---- an independent branch issued in pieces where the main chain is host-bound (round 6) ----
 # The proposal bookkeeping of the ROI heads (match / relabel / sample between the cascade stages: ~40 tiny launches and one host
 # synchronisation each) leaves the chip idle for 0.6-1.3 ms at a time while the host catches up (tools/step_idle.py: 3.7 ms of a 58 ms
@@ -341,8 +373,9 @@ class _Conv2dFn(Function):
         bias_f = None
         if bias is not None:
             bias_f = _conv_bias(bias, round_bias)
+        ctx.variant = _conv_variant()
         _hip.call("u2_conv_igemm", x, wk, out, bias_f, None if _DET_STATS else stats, b, h, w_, cp, cp, ho, wo, n, npad, kh, kw,
-                  pad, pad, stride, 1, int(relu), 0, 0)
+                  pad, pad, stride, 1, int(relu), 0, ctx.variant)
         if want_stats and _DET_STATS:
             stats = _fixed_order_stats(out, n)
         ctx.save_for_backward(x, weight, out if relu else None)
@@ -421,11 +454,11 @@ class _Conv2dFn(Function):
                 # is the plain GEMM dx[b, (kh,kw,c)] = dz[b, :] . W[:, (kh,kw,c)]
                 wt = weight_fc_dgrad_layout(weight, cp, npad, ctx.param)
                 _hip.call("u2_conv_igemm", dz, wt, dx, None, None, 1, b, 1, npad, npad, b, 1, kh * kw * cp, kh * kw * cp,
-                          1, 1, 0, 0, 1, 1, 0, 0, 0)
+                          1, 1, 0, 0, 1, 1, 0, 0, ctx.variant)
             else:
                 wd = weight_dgrad_layout(weight, cp, npad, ctx.param)
                 _hip.call("u2_conv_igemm", dz, wd, dx, None, None, b, ho, wo, npad, npad, h, w_, cp, cp, kh, kw,
-                          kh - 1 - pad, kw - 1 - pad, 1, stride, 0, 0, 0)
+                          kh - 1 - pad, kw - 1 - pad, 1, stride, 0, 0, ctx.variant)
         if ctx.needs_input_grad[1] and not fused:
             dst = ctx.wgrad_dst
             arena = ctx.arena
@@ -533,7 +566,7 @@ def conv2d_add_(x, weight, bias, out, stride=1, pad=0, relu=False, param=None):
     wk = weight_fwd_layout(weight, cp, param)
     bias_f = bias.detach().float().contiguous() if bias is not None else None
     _hip.call("u2_conv_igemm", x, wk, out, bias_f, None, b, h, w_, cp, cp, ho, wo, n, npad, kh, kw, pad, pad, stride, 1, int(relu),
-              1, 0)
+              1, _conv_variant())
     return out
 
 

@@ -258,7 +258,9 @@ class FPN(Backbone):
 
     def forward(self, images, pixel_mean, pixel_std, padded_hw):
         """fpn.py:126-167: lateral 1x1, nearest x2 of the coarser level + add, output 3x3."""
-        return self.forward_features(self.bottom_up(images, pixel_mean, pixel_std, padded_hw))
+        with F.streamk_region():   # no branch stream has work in flight while these layers run, forward or backward (layers/functional.py)
+            bottom_up_features = self.bottom_up(images, pixel_mean, pixel_std, padded_hw)
+        return self.forward_features(bottom_up_features)
 
     def forward_features(self, bottom_up_features):
         maps, carry = {}, None

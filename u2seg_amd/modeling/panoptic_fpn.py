@@ -174,6 +174,7 @@ class PanopticFPN(GeneralizedRCNN):
             return self.inference(batched_inputs)
         features, image_sizes, padded_hw = self._backbone_features(batched_inputs)
         self._watch_feature_grads(features)
+        gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         assert "sem_seg" in batched_inputs[0]
         gt_sem_seg = self._sem_seg_targets(batched_inputs, padded_hw)
         sem_f, rpn_f, roi_f = self._fan_out_features(
@@ -182,7 +183,6 @@ class PanopticFPN(GeneralizedRCNN):
         # kernels fill the chip while the proposal / sampling bookkeeping of the other branch occupies a few CUs at a time
         # (autograd replays every node on the stream of its forward pass, so the backward passes overlap the same way).
         aux = F.aux_stream(self.device) if sem_f[self.sem_seg_head.in_features[0]].is_cuda else None
-        gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         F.clear_deferred()
         if aux is not None and os.environ.get("U2_SEM_PIECES", "1") != "0":
             # Round 6: the head is handed over in pieces (level stacks, then predictor + loss) that the ROI heads launch - on `aux` -
