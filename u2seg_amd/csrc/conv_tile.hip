@@ -967,6 +967,13 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv_tile_kernel(const Conv
 // but at most eight work-groups of the launch run to completion and free their CUs; the hardware dispatches work-groups of a
 // grid in index order, so the missing peer is the next one to get a CU.  The scheme relies on that in-order dispatch (as
 // every persistent-kernel hand-over does); it does NOT rely on co-residency of the whole grid.
+//
+// Round 6: MEASURED OTHERWISE.  With the semantic / mask head's kernels on their own streams beside it, the driver's bench command hung
+// in 4 of 23 runs (tools/exp/hang_hunt.sh: the chip never finishes a step), in 0 of 24 with this form forbidden (variant bit 28), in 0
+// of 40 with those streams off, and still in 3 of 30 with the stream-K launches of different streams ordered behind each other by
+// events - one launch of this form beside kernels of another stream is enough.  What the argument above misses is not understood.
+// The product path (layers/functional.py:streamk_region) asks for this form only where no branch stream has work in flight and
+// passes bit 28 elsewhere; callers with several streams must do the same.
 constexpr int SK_MAX_GROUPS = 512;
 constexpr size_t SK_WS_LIMIT = (size_t)64 << 20;
 bool sk_scratch(hipStream_t s, ConvArgs& a, size_t need_bytes) {

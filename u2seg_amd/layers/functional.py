@@ -228,10 +228,21 @@ class streamk_region:
         return False
 
 
+def _several_ranks():
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def _conv_variant():
-    if _SK_REGION[0] > 0 or not _AUX_ENABLED or os.environ.get("U2_AUX_STREAM", "1") == "0" \
-            or os.environ.get("U2_STREAMK_EVERYWHERE", "0") == "1" or "U2_CONV_VARIANT" in os.environ:
+    if os.environ.get("U2_STREAMK_EVERYWHERE", "0") == "1" or "U2_CONV_VARIANT" in os.environ:
         return 0   # (U2_CONV_VARIANT: tests and A/B runs steer the library's dispatch themselves; it only applies to variant 0)
+    if _several_ranks():
+        # the gradient exchange of the arena's tail (RCCL kernels on their own stream, solver/build.py:begin_all_reduce_tail) runs
+        # beside the backbone's backward pass: another stream competing for the CUs - never measured, so not risked
+        return _NO_STREAMK
+    if _SK_REGION[0] > 0 or not _AUX_ENABLED or os.environ.get("U2_AUX_STREAM", "1") == "0":
+        return 0
     return _NO_STREAMK
 
 
