@@ -440,6 +440,14 @@ def main():
         sampled = max(1, steps // 16)
 
         marks = []
+        # the collector's generation-2 passes walk the whole module tree (tens of ms of host time in the middle of a step that is host-bound in
+        # places): collect once here, keep what is alive out of later passes; U2_BENCH_GC=0 leaves the collector alone
+        import gc
+
+        manage_gc = os.environ.get("U2_BENCH_GC", "1") != "0"
+        if manage_gc:
+            gc.collect()
+            gc.freeze()
         cg0, cpu0 = _cgroup_cpu_stat(), time.process_time()
         t0 = time.time()
         for i in range(steps):
@@ -471,6 +479,8 @@ def main():
                                       "cgroup_cpu_max": cg1.get("cpu_max")}
         timer.enabled = False
         Fn.set_stream_overlap(True)
+        if manage_gc:
+            gc.unfreeze()
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
