@@ -79,7 +79,14 @@ def _conv(a):
     return a
 
 
+# the raw handle of torch's current stream without building a torch.cuda.Stream object per launch: under cProfile the object form is
+# 40 % of a binding call (tools/exp/host_profile.py), and the ROI heads' forward phase is host-bound
+_raw_stream = None if os.environ.get("U2_HIP_STREAM_OBJECT", "0") == "1" else getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
